@@ -1,0 +1,74 @@
+"""ctypes binding of libdsmil_hip.so (include/dsmil_hip.h).  Thin: it passes ``data_ptr()``s,
+sizes and the current HIP stream, and turns negative status codes into RuntimeError.
+
+There is deliberately NO fallback: if the shared object is missing or lacks a symbol the import
+of the HIP path fails loudly (``NativeLibraryError``)."""
+import ctypes
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libdsmil_hip.so")
+
+c_f32p = ctypes.c_void_p
+c_i64p = ctypes.c_void_p
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class AggParams(ctypes.Structure):
+    """struct dsmil_agg_params (include/dsmil_hip.h)."""
+    _fields_ = [("fc_w", ctypes.c_void_p), ("fc_b", ctypes.c_void_p),
+                ("q0_w", ctypes.c_void_p), ("q0_b", ctypes.c_void_p),
+                ("q2_w", ctypes.c_void_p), ("q2_b", ctypes.c_void_p),
+                ("fcc_w", ctypes.c_void_p), ("fcc_b", ctypes.c_void_p),
+                ("K", ctypes.c_int32), ("Kv", ctypes.c_int32),
+                ("C", ctypes.c_int32), ("nonlinear", ctypes.c_int32)]
+
+
+# symbol -> (restype, argtypes); must list every function include/dsmil_hip.h declares
+SIGNATURES = {
+    "dsmil_abi_version": (ctypes.c_int, []),
+    "dsmil_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "dsmil_agg_tile_rows": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64]),
+    "dsmil_agg_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
+                                                    ctypes.c_int32, ctypes.c_int32]),
+    "dsmil_fc_forward": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                        c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
+    "dsmil_agg_forward": (ctypes.c_int, [c_f32p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.POINTER(AggParams), c_f32p, c_f32p,
+                                         c_f32p, c_f32p, c_f32p, c_i64p, ctypes.c_void_p,
+                                         ctypes.c_size_t, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library (loads on first use)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                f"(or dsmil-wsi_amd/build.py); the HIP path has no fallback")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().dsmil_strerror(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")

@@ -1,0 +1,801 @@
+// DSMIL dual-stream aggregator, forward — hand-written HIP for gfx950 (MI355X, CDNA4).
+//
+// What it computes (reference: dsmil.py FCLayer :6-12, BClassifier.forward :46-62,
+// MILNet.forward :70-74), for a batch of independent variable-length bags:
+//   c    = x W_i^T + b_i                          instance logits            [N,C]
+//   idx  = argmax_n c[n,:]                         critical instances         [C]
+//   Q    = tanh(relu(x W1^T + b1) W2^T + b2)      queries                    [N,128]
+//   qmax = Q-MLP(x[idx])                                                      [C,128]
+//   A    = softmax_n(Q qmax^T / sqrt(128))        attention over instances   [N,C]
+//   B    = A^T V,  pred = Conv1d(C,C,K)(B)         bag embedding / bag logits
+//
+// Launch sequence on one stream (no host sync, hipGraph-capturable):
+//   k_logits_argmax   HBM stream over x: c, per-tile (max,idx) partials        (VALU)
+//   k_qmax            per (bag,class): finish argmax, run the query MLP on the critical row
+//   k_query_attend    the dominant kernel: per 32-row wave tile the query MLP runs TRANSPOSED
+//                     on exact-f32 MFMA (v_mfma_f32_32x32x2_f32): H^T = W1 X^T keeps instances
+//                     on the MFMA column axis so the ReLU'd H^T accumulator registers are fed
+//                     straight back as the B operand of Q^T = W2 H^T (no LDS round trip);
+//                     scores, tile-local softmax statistics and the weighted value sum are
+//                     fused behind it.  Q is never written to memory.
+//   k_finish          combine tile partials: A = exp(s-m)/l, B, pred
+//
+// MFMA fragment maps used (cdna_hip_programming.md §3): 32x32x2 f32: A lane l = A[i=l&31][k=l>>5],
+// B lane l = B[k=l>>5][j=l&31], D lane l reg r = D[(r&3)+8*(r>>2)+4*(l>>5)][l&31].
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "dsmil_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int QD = DSMIL_Q_DIM;  // 128
+constexpr int BK = 32;           // k-chunk staged per pipeline step
+constexpr int LDK = BK + 4;      // LDS row stride in floats (144 B): conflict-free ds_read_b128
+constexpr int W_TILE = QD * LDK; // floats per staged weight chunk
+constexpr int R0 = 128;          // rows per workgroup of k_logits_argmax
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// 4 consecutive floats at p[k..k+3], zero beyond klim.  VEC=4 needs 16-B aligned rows.
+template <int VEC>
+__device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int k, int klim) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (VEC == 4) {
+        if (k < klim) v = *reinterpret_cast<const f32x4*>(p + k);
+    } else {
+        if (k + 0 < klim) v[0] = p[k + 0];
+        if (k + 1 < klim) v[1] = p[k + 1];
+        if (k + 2 < klim) v[2] = p[k + 2];
+        if (k + 3 < klim) v[3] = p[k + 3];
+    }
+    return v;
+}
+
+// better (value, index): larger value wins, lowest index wins on exact ties
+__device__ __forceinline__ bool better(float v, long long i, float bv, long long bi) {
+    return (v > bv) || (v == bv && i < bi);
+}
+
+// --------------------------------------------------------------------------------------------
+// k_logits_argmax: c = x W_i^T + b_i (dsmil.py:11) and per-tile arg-max partials (dsmil.py:52).
+// One wave owns 32 rows, 4 rows in flight; lanes stride the feature axis with 16-B loads.
+// If classes_in != nullptr the logits are taken from it (BClassifier.forward(feats, c)).
+// --------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_logits_argmax(
+    const float* __restrict__ feats, const int64_t* __restrict__ offsets,
+    const float* __restrict__ fc_w, const float* __restrict__ fc_b,
+    const float* __restrict__ classes_in, float* __restrict__ classes_out,
+    float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C) {
+    const int bag = blockIdx.y;
+    const long long off0 = offsets[bag];
+    const long long Nb = offsets[bag + 1] - off0;
+    const long long row0 = (long long)blockIdx.x * R0;
+    if (row0 >= Nb) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long slot = off0 / R0 + bag + blockIdx.x;
+    __shared__ float s_v[4];
+    __shared__ long long s_i[4];
+
+    for (int c0 = 0; c0 < C; c0 += 2) {
+        const int c1 = (c0 + 1 < C) ? c0 + 1 : c0;
+        float bv0 = -INFINITY, bv1 = -INFINITY;
+        long long bi0 = 0x7fffffffffffffffLL, bi1 = 0x7fffffffffffffffLL;
+        for (int rg = 0; rg < 8; ++rg) {
+            const long long rbase = row0 + wave * 32 + rg * 4;
+            if (rbase >= Nb) break;  // wave-uniform
+            float v[4][2];
+            if (classes_in == nullptr) {
+                float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+                const float* xr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    long long r = rbase + j;
+                    if (r >= Nb) r = Nb - 1;
+                    xr[j] = feats + (off0 + r) * (long long)K;
+                }
+                for (int k0 = 0; k0 < K; k0 += 256) {
+                    const int k = k0 + lane * 4;
+                    const f32x4 w0 = load4<VEC>(fc_w + (long long)c0 * K, k, K);
+                    const f32x4 w1 = load4<VEC>(fc_w + (long long)c1 * K, k, K);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 x = load4<VEC>(xr[j], k, K);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[j][0] = fmaf(x[e], w0[e], acc[j][0]);
+                            acc[j][1] = fmaf(x[e], w1[e], acc[j][1]);
+                        }
+                    }
+                }
+                const float b0 = fc_b[c0], b1 = fc_b[c1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j][0] = wave_sum(acc[j][0]) + b0;
+                    v[j][1] = wave_sum(acc[j][1]) + b1;
+                }
+                if (lane < 4 && rbase + lane < Nb) {
+                    float o0 = v[0][0], o1 = v[0][1];
+                    if (lane == 1) { o0 = v[1][0]; o1 = v[1][1]; }
+                    if (lane == 2) { o0 = v[2][0]; o1 = v[2][1]; }
+                    if (lane == 3) { o0 = v[3][0]; o1 = v[3][1]; }
+                    float* o = classes_out + (off0 + rbase + lane) * (long long)C;
+                    o[c0] = o0;
+                    if (c1 != c0) o[c1] = o1;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    long long r = rbase + j;
+                    if (r >= Nb) r = Nb - 1;
+                    const float* ci = classes_in + (off0 + r) * (long long)C;
+                    v[j][0] = ci[c0];
+                    v[j][1] = ci[c1];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long r = rbase + j;
+                if (r < Nb) {
+                    if (better(v[j][0], r, bv0, bi0)) { bv0 = v[j][0]; bi0 = r; }
+                    if (better(v[j][1], r, bv1, bi1)) { bv1 = v[j][1]; bi1 = r; }
+                }
+            }
+        }
+        // combine the 4 waves (values are wave-uniform)
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = cc ? c1 : c0;
+            if (cc && c1 == c0) break;
+            __syncthreads();
+            if (lane == 0) { s_v[wave] = cc ? bv1 : bv0; s_i[wave] = cc ? bi1 : bi0; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float bv = s_v[0];
+                long long bi = s_i[0];
+                for (int w = 1; w < 4; ++w)
+                    if (better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
+                part_val[slot * C + c] = bv;
+                part_idx[slot * C + c] = bi;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_qmax: one workgroup per (bag, class).  Finishes the arg-max over the bag's tile partials
+// (dsmil.py:52), then q_max = q(feats[idx]) (dsmil.py:53-54) on the VALU.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_qmax(
+    const float* __restrict__ feats, const int64_t* __restrict__ offsets,
+    const float* __restrict__ part_val, const long long* __restrict__ part_idx,
+    const float* __restrict__ q0_w, const float* __restrict__ q0_b,
+    const float* __restrict__ q2_w, const float* __restrict__ q2_b,
+    float* __restrict__ qmax, int64_t* __restrict__ idx_out, int K, int C, int nonlinear) {
+    const int bag = blockIdx.x, c = blockIdx.y;
+    const long long off0 = offsets[bag];
+    const long long Nb = offsets[bag + 1] - off0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float s_v[256];
+    __shared__ long long s_i[256];
+    __shared__ float s_h[QD];
+    const long long slot0 = off0 / R0 + bag;
+    const long long ntile = (Nb + R0 - 1) / R0;
+    float bv = -INFINITY;
+    long long bi = 0x7fffffffffffffffLL;
+    for (long long t = threadIdx.x; t < ntile; t += 256) {
+        const float v = part_val[(slot0 + t) * C + c];
+        const long long i = part_idx[(slot0 + t) * C + c];
+        if (better(v, i, bv, bi)) { bv = v; bi = i; }
+    }
+    s_v[threadIdx.x] = bv;
+    s_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            if (better(s_v[threadIdx.x + s], s_i[threadIdx.x + s], s_v[threadIdx.x], s_i[threadIdx.x])) {
+                s_v[threadIdx.x] = s_v[threadIdx.x + s];
+                s_i[threadIdx.x] = s_i[threadIdx.x + s];
+            }
+        }
+        __syncthreads();
+    }
+    long long best = s_i[0];
+    if (best < 0 || best >= Nb) best = 0;  // all-NaN / empty guard: stay in bounds
+    if (threadIdx.x == 0) idx_out[(long long)bag * C + c] = best;
+    const float* x = feats + (off0 + best) * (long long)K;
+    // layer 1: wave w computes hidden units 32w..32w+31, lanes stride k
+    for (int jj = 0; jj < 32; ++jj) {
+        const int j = wave * 32 + jj;
+        const float* wr = q0_w + (long long)j * K;
+        float a = 0.f;
+        for (int k = lane; k < K; k += 64) a = fmaf(x[k], wr[k], a);
+        a = wave_sum(a) + q0_b[j];
+        if (nonlinear) a = fmaxf(a, 0.f);
+        if (lane == 0) s_h[j] = a;
+    }
+    __syncthreads();
+    float* out = qmax + ((long long)bag * C + c) * QD;
+    if (!nonlinear) {
+        if (threadIdx.x < QD) out[threadIdx.x] = s_h[threadIdx.x];
+        return;
+    }
+    for (int jj = 0; jj < 32; ++jj) {
+        const int j = wave * 32 + jj;
+        const float* wr = q2_w + (long long)j * QD;
+        float a = fmaf(s_h[lane], wr[lane], s_h[lane + 64] * wr[lane + 64]);
+        a = wave_sum(a) + q2_b[j];
+        if (lane == 0) out[j] = tanhf(a);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_query_attend — the dominant kernel.  NW waves per workgroup, 32 instance rows per wave.
+// --------------------------------------------------------------------------------------------
+struct AttendArgs {
+    const float* feats;
+    const float* vals;
+    const int64_t* offsets;
+    const float* q0_w;
+    const float* q0_b;
+    const float* q2_w;
+    const float* q2_b;
+    const float* qmax;  // [n_bags, C, 128]
+    float* scores;      // [total_rows, C]  (the A buffer; normalised in place by k_finish)
+    float* part_ml;     // [slots, C, 2]
+    float* part_B;      // [slots, C, Kv]
+    int K, Kv, C, nonlinear;
+};
+
+template <int NW, int VEC>
+__global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(AttendArgs a) {
+    constexpr int T = NW * 64;
+    constexpr int BM = NW * 32;
+    constexpr int X_TILE = BM * LDK;
+    constexpr int WPT = (QD * (BK / 4)) / T;  // float4 per thread per weight chunk
+    constexpr int XPT = (BM * (BK / 4)) / T;  // == 4
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sW = smem;               // [2][W_TILE]
+    float* sX = smem + 2 * W_TILE;  // [2][X_TILE]
+
+    const int bag = blockIdx.y;
+    const long long off0 = a.offsets[bag];
+    const long long Nb = a.offsets[bag + 1] - off0;
+    const long long row0 = (long long)blockIdx.x * BM;
+    if (row0 >= Nb) return;
+    const long long slot = off0 / BM + bag + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int K = a.K;
+    const int nk1 = (K + BK - 1) / BK;
+    const int nk = nk1 + (a.nonlinear ? QD / BK : 0);
+
+    f32x4 wreg[WPT], xreg[XPT];
+    auto stage_load = [&](int ci) {
+        const float* wb;
+        int ld, k0, klim;
+        if (ci < nk1) { wb = a.q0_w; ld = K; k0 = ci * BK; klim = K; }
+        else { wb = a.q2_w; ld = QD; k0 = (ci - nk1) * BK; klim = QD; }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int f = tid + T * i, r = f >> 3, c4 = f & 7;
+            wreg[i] = load4<VEC>(wb + (long long)r * ld, k0 + c4 * 4, klim);
+        }
+        if (ci < nk1) {
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int f = tid + T * i, r = f >> 3, c4 = f & 7;
+                long long gr = row0 + r;
+                if (gr >= Nb) gr = Nb - 1;  // clamp: rows past the bag end are masked later
+                xreg[i] = load4<VEC>(a.feats + (off0 + gr) * (long long)K, k0 + c4 * 4, klim);
+            }
+        }
+    };
+    auto stage_write = [&](int ci) {
+        float* w = sW + (ci & 1) * W_TILE;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int f = tid + T * i, r = f >> 3, c4 = f & 7;
+            *reinterpret_cast<f32x4*>(w + r * LDK + c4 * 4) = wreg[i];
+        }
+        if (ci < nk1) {
+            float* x = sX + (ci & 1) * X_TILE;
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int f = tid + T * i, r = f >> 3, c4 = f & 7;
+                *reinterpret_cast<f32x4*>(x + r * LDK + c4 * 4) = xreg[i];
+            }
+        }
+    };
+
+    f32x16 H[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H[t][r] = 0.f;
+
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    const int frag_off = l31 * LDK + 4 * hi;  // this lane's row / k-half inside a chunk
+    // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] * X[n][k]
+    for (int ci = 0; ci < nk1; ++ci) {
+        if (ci + 1 < nk) stage_load(ci + 1);
+        const float* w = sW + (ci & 1) * W_TILE + frag_off;
+        const float* x = sX + (ci & 1) * X_TILE + wave * 32 * LDK + frag_off;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const f32x4 xb = *reinterpret_cast<const f32x4*>(x + kg * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(w + t * 32 * LDK + kg * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    H[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xb[j], H[t], 0, 0, 0);
+            }
+        }
+        if (ci + 1 < nk) stage_write(ci + 1);
+        __syncthreads();
+    }
+    // ---- bias (+ReLU): H^T row j = 32t + 8g + 4hi + e  for reg r = 4g + e
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.q0_b + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = H[t][4 * g + e] + b[e];
+                H[t][4 * g + e] = a.nonlinear ? fmaxf(v, 0.f) : v;
+            }
+        }
+    f32x16 Q[4];
+    if (a.nonlinear) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Q[t][r] = 0.f;
+        // ---- GEMM 2 (transposed): Q^T[j2][n] += W2[j2][k] * H^T[k][n]; chunk t feeds k=32t..32t+31
+        // straight from the accumulator registers of H[t]: reg 4g+e holds k = 8g + 4hi + e.
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ci = nk1 + t;
+            if (t < 3) stage_load(ci + 1);
+            const float* w = sW + (ci & 1) * W_TILE + frag_off;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) {
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(w + t2 * 32 * LDK + g * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        Q[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[e], H[t][4 * g + e], Q[t2], 0, 0, 0);
+                }
+            }
+            if (t < 3) stage_write(ci + 1);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = tanhf(Q[t][4 * g + e] + b[e]);
+            }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Q[t] = H[t];
+    }
+    // From here on the staging LDS is free (every wave is past the last barrier above).
+    // ---- scores, tile softmax statistics, weighted value sum — two classes per sweep
+    const long long wrow0 = row0 + wave * 32;           // first row of this wave
+    const long long myrow = wrow0 + l31;                // this lane's instance row (bag-local)
+    const bool valid = myrow < Nb;
+    const float scale = 0.08838834764831845f;           // 1/sqrt(128), dsmil.py:56
+    const int Kv = a.Kv;
+    const float* vbase = a.vals + off0 * (long long)Kv;
+    float* sRed = smem;                                  // [NW][4]: m0,l0,m1,l1 per wave
+    float* sB = smem + 64;                               // [NW][2][512]
+    for (int c0 = 0; c0 < a.C; c0 += 2) {
+        const int c1 = (c0 + 1 < a.C) ? c0 + 1 : c0;
+        const float* qm0 = a.qmax + ((long long)bag * a.C + c0) * QD;
+        const float* qm1 = a.qmax + ((long long)bag * a.C + c1) * QD;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(qm0 + 32 * t + 8 * g + 4 * hi);
+                const f32x4 u1 = *reinterpret_cast<const f32x4*>(qm1 + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s0 = fmaf(Q[t][4 * g + e], u0[e], s0);
+                    s1 = fmaf(Q[t][4 * g + e], u1[e], s1);
+                }
+            }
+        s0 = (s0 + __shfl_xor(s0, 32, 64)) * scale;
+        s1 = (s1 + __shfl_xor(s1, 32, 64)) * scale;
+        if (valid && hi == 0) {
+            float* o = a.scores + (off0 + myrow) * (long long)a.C;
+            o[c0] = s0;
+            if (c1 != c0) o[c1] = s1;
+        }
+        const float mw0 = wave_max(valid ? s0 : -INFINITY);
+        const float mw1 = wave_max(valid ? s1 : -INFINITY);
+        const float p0 = valid ? expf(s0 - mw0) : 0.f;
+        const float p1 = valid ? expf(s1 - mw1) : 0.f;
+        const float lw0 = wave_sum(hi == 0 ? p0 : 0.f);
+        const float lw1 = wave_sum(hi == 0 ? p1 : 0.f);
+        // block-level max / sum
+        float f0 = 1.f, f1 = 1.f;
+        if constexpr (NW > 1) {
+            __syncthreads();
+            if (lane == 0) {
+                sRed[wave * 4 + 0] = mw0; sRed[wave * 4 + 1] = lw0;
+                sRed[wave * 4 + 2] = mw1; sRed[wave * 4 + 3] = lw1;
+            }
+            __syncthreads();
+            float mb0 = -INFINITY, mb1 = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { mb0 = fmaxf(mb0, sRed[w * 4 + 0]); mb1 = fmaxf(mb1, sRed[w * 4 + 2]); }
+            f0 = expf(mw0 - mb0);  // 0 for a wave with no valid row (mw = -inf, mb finite)
+            f1 = expf(mw1 - mb1);
+            if (tid == 0) {
+                float lb0 = 0.f, lb1 = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    lb0 += sRed[w * 4 + 1] * expf(sRed[w * 4 + 0] - mb0);
+                    lb1 += sRed[w * 4 + 3] * expf(sRed[w * 4 + 2] - mb1);
+                }
+                float* ml = a.part_ml + (slot * a.C + c0) * 2;
+                ml[0] = mb0; ml[1] = lb0;
+                if (c1 != c0) { ml[2] = mb1; ml[3] = lb1; }
+            }
+        } else {
+            if (tid == 0) {
+                float* ml = a.part_ml + (slot * a.C + c0) * 2;
+                ml[0] = mw0; ml[1] = lw0;
+                if (c1 != c0) { ml[2] = mw1; ml[3] = lw1; }
+            }
+        }
+        const float pp0 = p0 * f0, pp1 = p1 * f1;  // weights relative to the BLOCK max
+        // ---- weighted value sum: Bpart[c][k] = sum_n p[n][c] * V[n][k], 512 k per sweep
+        for (int k0 = 0; k0 < Kv; k0 += 512) {
+            f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+            const int ka = k0 + lane * 4, kb = ka + 256;
+#pragma unroll 4
+            for (int n = 0; n < 32; ++n) {
+                long long r = wrow0 + n;
+                if (r >= Nb) r = Nb - 1;  // weight is 0 there
+                const float w0 = __shfl(pp0, n, 64), w1 = __shfl(pp1, n, 64);
+                const float* vr = vbase + r * (long long)Kv;
+                const f32x4 va = load4<VEC>(vr, ka, Kv);
+                const f32x4 vb = load4<VEC>(vr, kb, Kv);
+                acc00 += w0 * va; acc01 += w0 * vb;
+                acc10 += w1 * va; acc11 += w1 * vb;
+            }
+            float* pb0 = a.part_B + (slot * a.C + c0) * (long long)Kv;
+            float* pb1 = a.part_B + (slot * a.C + c1) * (long long)Kv;
+            if constexpr (NW > 1) {
+                __syncthreads();
+                float* my = sB + wave * 1024;
+                *reinterpret_cast<f32x4*>(my + lane * 4) = acc00;
+                *reinterpret_cast<f32x4*>(my + 256 + lane * 4) = acc01;
+                *reinterpret_cast<f32x4*>(my + 512 + lane * 4) = acc10;
+                *reinterpret_cast<f32x4*>(my + 768 + lane * 4) = acc11;
+                __syncthreads();
+                for (int e = tid; e < 1024; e += T) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) s += sB[w * 1024 + e];
+                    const int cc = e >> 9, k = k0 + (e & 511);
+                    if (k < Kv && (cc == 0 || c1 != c0)) (cc ? pb1 : pb0)[k] = s;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (ka + e < Kv) { pb0[ka + e] = acc00[e]; if (c1 != c0) pb1[ka + e] = acc10[e]; }
+                    if (kb + e < Kv) { pb0[kb + e] = acc01[e]; if (c1 != c0) pb1[kb + e] = acc11[e]; }
+                }
+            }
+        }
+        if constexpr (NW > 1) __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// k_finish: per bag, combine tile partials (online-softmax merge), normalise A in place,
+// produce B (dsmil.py:57-59) and pred = Conv1d(C,C,Kv)(B) (dsmil.py:60-61).
+// grid = (chunks, n_bags); chunk j normalises rows [j*FR, (j+1)*FR) and owns a slice of k.
+// --------------------------------------------------------------------------------------------
+constexpr int FR = 2048;
+__global__ __launch_bounds__(256) void k_finish(
+    const int64_t* __restrict__ offsets, const float* __restrict__ part_ml,
+    const float* __restrict__ part_B, const float* __restrict__ fcc_w,
+    const float* __restrict__ fcc_b, float* __restrict__ A, float* __restrict__ B,
+    float* __restrict__ pred_part, int Kv, int C, int BM, int nchunk_max) {
+    const int bag = blockIdx.y;
+    const long long off0 = offsets[bag];
+    const long long Nb = offsets[bag + 1] - off0;
+    const long long nchunk = (Nb + FR - 1) / FR;
+    if ((long long)blockIdx.x >= nchunk) return;
+    const long long slot0 = off0 / BM + bag;
+    const long long ntile = (Nb + BM - 1) / BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float s_red[8];
+    __shared__ float s_m, s_il;
+    // k-slice owned by this chunk
+    const int ks = (int)((Kv + nchunk - 1) / nchunk);
+    const int kbeg = (int)blockIdx.x * ks;
+    const int kend = (kbeg + ks < Kv) ? kbeg + ks : Kv;
+    for (int c = 0; c < C; ++c) {
+        // global max
+        float m = -INFINITY;
+        for (long long t = tid; t < ntile; t += 256) m = fmaxf(m, part_ml[((slot0 + t) * C + c) * 2]);
+        m = wave_max(m);
+        __syncthreads();
+        if (lane == 0) s_red[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        float l = 0.f;
+        for (long long t = tid; t < ntile; t += 256) {
+            const float* ml = part_ml + ((slot0 + t) * C + c) * 2;
+            l += ml[1] * expf(ml[0] - m);
+        }
+        l = wave_sum(l);
+        __syncthreads();
+        if (lane == 0) s_red[4 + wave] = l;
+        __syncthreads();
+        l = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+        const float il = 1.f / l;
+        // A = exp(s - m) / l for this chunk's rows
+        const long long rbeg = (long long)blockIdx.x * FR;
+        const long long rend = (rbeg + FR < Nb) ? rbeg + FR : Nb;
+        for (long long r = rbeg + tid; r < rend; r += 256) {
+            float* p = A + (off0 + r) * (long long)C + c;
+            *p = expf(*p - m) * il;
+        }
+        // B[c][k] for this chunk's k-slice; 4 waves split the tiles, lanes walk k
+        for (int kb = kbeg; kb < kend; kb += 64) {
+            const int k = kb + lane;
+            float acc = 0.f;
+            if (k < kend)
+                for (long long t = wave; t < ntile; t += 4) {
+                    const float w = expf(part_ml[((slot0 + t) * C + c) * 2] - m);
+                    acc = fmaf(part_B[((slot0 + t) * C + c) * (long long)Kv + k], w, acc);
+                }
+            __shared__ float s_acc[4][64];
+            __syncthreads();
+            s_acc[wave][lane] = acc;
+            __syncthreads();
+            if (wave == 0 && k < kend) {
+                const float b = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * il;
+                B[((long long)bag * C + c) * Kv + k] = b;
+                s_acc[0][lane] = b;
+            }
+            __syncthreads();
+            // partial Conv1d dot products for this k-run: pred_part[bag][chunk][o][c]
+            if (tid < C) {
+                const int o = tid;
+                float d = 0.f;
+                const int kn = (kend - kb < 64) ? kend - kb : 64;
+                for (int e = 0; e < kn; ++e)
+                    d = fmaf(fcc_w[((long long)o * C + c) * Kv + kb + e], s_acc[0][e], d);
+                float* pp = pred_part + (((long long)bag * nchunk_max + blockIdx.x) * C + o) * C + c;
+                *pp = (kb == kbeg ? 0.f : *pp) + d;
+            }
+        }
+        if (kbeg >= kend && tid < C)
+            pred_part[(((long long)bag * nchunk_max + blockIdx.x) * C + tid) * C + c] = 0.f;
+        __syncthreads();
+    }
+    (void)s_m; (void)s_il;
+}
+
+// pred[bag][o] = fcc_b[o] + sum_{chunk,c} pred_part  (fixed order => deterministic)
+__global__ void k_pred(const int64_t* __restrict__ offsets, const float* __restrict__ pred_part,
+                       const float* __restrict__ fcc_b, float* __restrict__ pred, int C,
+                       int nchunk_max, int n_bags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bags * C) return;
+    const int bag = i / C, o = i % C;
+    const long long Nb = offsets[bag + 1] - offsets[bag];
+    const long long nchunk = (Nb + FR - 1) / FR;
+    float s = fcc_b[o];
+    for (long long j = 0; j < nchunk; ++j)
+        for (int c = 0; c < C; ++c) s += pred_part[(((long long)bag * nchunk_max + j) * C + o) * C + c];
+    pred[i] = s;
+}
+
+// FCLayer alone
+template <int VEC>
+__global__ __launch_bounds__(256) void k_fc(const float* __restrict__ feats,
+                                            const float* __restrict__ fc_w,
+                                            const float* __restrict__ fc_b,
+                                            float* __restrict__ classes, long long N, int K, int C) {
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * 4;
+    for (long long r = wid; r < N; r += nw) {
+        const float* x = feats + r * K;
+        for (int c = 0; c < C; ++c) {
+            float acc = 0.f;
+            for (int k0 = 0; k0 < K; k0 += 256) {
+                const int k = k0 + lane * 4;
+                const f32x4 xv = load4<VEC>(x, k, K);
+                const f32x4 wv = load4<VEC>(fc_w + (long long)c * K, k, K);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = fmaf(xv[e], wv[e], acc);
+            }
+            acc = wave_sum(acc) + fc_b[c];
+            if (lane == 0) classes[r * C + c] = acc;
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+struct WsLayout {
+    size_t part_val, part_idx, qmax, part_ml, part_B, pred_part, total;
+    long long slots0, slots, nchunk_max;
+};
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int pick_nw(int n_bags, long long total_rows) {
+    // 128-row workgroups (4 waves) once they alone give >= 2 workgroups per CU; otherwise
+    // 32-row single-wave workgroups so that a lone bag still spreads over the chip.
+    const long long tiles128 = total_rows / 128 + n_bags;
+    return tiles128 >= 512 ? 4 : 1;
+}
+
+WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int Kv, int C, int BM) {
+    WsLayout w;
+    w.slots0 = total_rows / R0 + n_bags + 1;
+    w.slots = total_rows / BM + n_bags + 1;
+    w.nchunk_max = (max_rows + FR - 1) / FR;
+    if (w.nchunk_max < 1) w.nchunk_max = 1;
+    size_t o = 0;
+    w.part_val = o; o = al(o + (size_t)w.slots0 * C * sizeof(float));
+    w.part_idx = o; o = al(o + (size_t)w.slots0 * C * sizeof(long long));
+    w.qmax = o; o = al(o + (size_t)n_bags * C * QD * sizeof(float));
+    w.part_ml = o; o = al(o + (size_t)w.slots * C * 2 * sizeof(float));
+    w.part_B = o; o = al(o + (size_t)w.slots * C * Kv * sizeof(float));
+    w.pred_part = o; o = al(o + (size_t)n_bags * w.nchunk_max * C * C * sizeof(float));
+    w.total = o;
+    return w;
+}
+
+template <int NW, int VEC>
+int launch_attend(const AttendArgs& a, long long max_rows, int n_bags, hipStream_t st) {
+    constexpr int BM = NW * 32;
+    const size_t lds = (size_t)(2 * W_TILE + 2 * BM * LDK) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_query_attend<NW, VEC>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((max_rows + BM - 1) / BM), (unsigned)n_bags);
+    hipLaunchKernelGGL((k_query_attend<NW, VEC>), grid, dim3(NW * 64), lds, st, a);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsmil_abi_version(void) { return DSMIL_ABI_VERSION; }
+
+const char* dsmil_strerror(int code) {
+    switch (code) {
+        case DSMIL_OK: return "ok";
+        case DSMIL_E_INVALID: return "invalid argument";
+        case DSMIL_E_UNSUPPORTED: return "unsupported shape or dtype";
+        case DSMIL_E_WORKSPACE: return "workspace too small";
+        case DSMIL_E_LAUNCH: return "kernel launch failed";
+        case DSMIL_E_ALIGN: return "pointer not aligned";
+        default: return "unknown error";
+    }
+}
+
+int dsmil_agg_tile_rows(int32_t n_bags, int64_t total_rows) { return pick_nw(n_bags, total_rows) * 32; }
+
+size_t dsmil_agg_workspace_bytes(int32_t n_bags, int64_t total_rows, int32_t K, int32_t Kv,
+                                 int32_t C) {
+    (void)K;
+    if (n_bags <= 0 || total_rows <= 0 || Kv <= 0 || C <= 0) return 0;
+    // max_rows <= total_rows bounds the chunk count; tile rows as the launcher will pick them
+    return ws_layout(n_bags, total_rows, total_rows, Kv, C, pick_nw(n_bags, total_rows) * 32).total;
+}
+
+int dsmil_fc_forward(const float* feats, int64_t total_rows, int32_t K, int32_t C,
+                     const float* fc_w, const float* fc_b, float* classes, void* stream) {
+    if (!feats || !fc_w || !fc_b || !classes || total_rows <= 0 || K <= 0 || C <= 0) return DSMIL_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    long long blocks = (total_rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    const bool v4 = (K % 4 == 0) && (((uintptr_t)feats | (uintptr_t)fc_w) % 16 == 0);
+    if (v4) hipLaunchKernelGGL(k_fc<4>, dim3((unsigned)blocks), dim3(256), 0, st, feats, fc_w, fc_b, classes, (long long)total_rows, K, C);
+    else hipLaunchKernelGGL(k_fc<1>, dim3((unsigned)blocks), dim3(256), 0, st, feats, fc_w, fc_b, classes, (long long)total_rows, K, C);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
+int dsmil_agg_forward(const float* feats, const float* vals, const int64_t* offsets,
+                      int32_t n_bags, int64_t total_rows, int64_t max_rows,
+                      const dsmil_agg_params* p, const float* classes_in, float* classes_out,
+                      float* A, float* B, float* pred, int64_t* idx, void* ws, size_t ws_bytes,
+                      void* stream) {
+    if (!feats || !offsets || !p || !A || !B || !pred || !idx || !ws) return DSMIL_E_INVALID;
+    if (n_bags <= 0 || total_rows <= 0 || max_rows <= 0 || max_rows > total_rows) return DSMIL_E_INVALID;
+    if (p->K <= 0 || p->Kv <= 0 || p->C <= 0) return DSMIL_E_INVALID;
+    if (!p->q0_w || !p->q0_b || !p->fcc_w || !p->fcc_b) return DSMIL_E_INVALID;
+    if (p->nonlinear && (!p->q2_w || !p->q2_b)) return DSMIL_E_INVALID;
+    if (!classes_in && (!p->fc_w || !p->fc_b || !classes_out)) return DSMIL_E_INVALID;
+    if (n_bags > 65535) return DSMIL_E_UNSUPPORTED;
+    if (!vals) vals = feats;
+    if (vals == feats && p->Kv != p->K) return DSMIL_E_INVALID;
+    if (((uintptr_t)ws % 256) || ((uintptr_t)p->q0_b % 16) || (p->nonlinear && ((uintptr_t)p->q2_b % 16)))
+        return DSMIL_E_ALIGN;
+    const int K = p->K, Kv = p->Kv, C = p->C;
+    const int NW = pick_nw(n_bags, total_rows);
+    const int BM = NW * 32;
+    const WsLayout L = ws_layout(n_bags, total_rows, max_rows, Kv, C, BM);
+    if (ws_bytes < L.total) return DSMIL_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* w8 = (char*)ws;
+    float* part_val = (float*)(w8 + L.part_val);
+    long long* part_idx = (long long*)(w8 + L.part_idx);
+    float* qmax = (float*)(w8 + L.qmax);
+    float* part_ml = (float*)(w8 + L.part_ml);
+    float* part_B = (float*)(w8 + L.part_B);
+    float* pred_part = (float*)(w8 + L.pred_part);
+
+    const bool v4 = (K % 4 == 0) && (Kv % 4 == 0) &&
+                    (((uintptr_t)feats | (uintptr_t)vals | (uintptr_t)p->q0_w | (uintptr_t)p->fc_w |
+                      (uintptr_t)(p->nonlinear ? p->q2_w : p->q0_w)) % 16 == 0);
+    // 1. instance logits + arg-max partials
+    {
+        dim3 grid((unsigned)((max_rows + R0 - 1) / R0), (unsigned)n_bags);
+        if (v4) hipLaunchKernelGGL(k_logits_argmax<4>, grid, dim3(256), 0, st, feats, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
+        else hipLaunchKernelGGL(k_logits_argmax<1>, grid, dim3(256), 0, st, feats, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    }
+    // 2. critical instance + its query
+    hipLaunchKernelGGL(k_qmax, dim3((unsigned)n_bags, (unsigned)C), dim3(256), 0, st, feats, offsets,
+                       part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear);
+    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    // 3. query MLP on MFMA + scores + tile softmax + weighted value sum
+    AttendArgs a{feats, vals, offsets, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, A, part_ml, part_B,
+                 K, Kv, C, p->nonlinear};
+    int rc;
+    if (NW == 4) rc = v4 ? launch_attend<4, 4>(a, max_rows, n_bags, st) : launch_attend<4, 1>(a, max_rows, n_bags, st);
+    else rc = v4 ? launch_attend<1, 4>(a, max_rows, n_bags, st) : launch_attend<1, 1>(a, max_rows, n_bags, st);
+    if (rc != DSMIL_OK) return rc;
+    // 4. combine
+    {
+        dim3 grid((unsigned)L.nchunk_max, (unsigned)n_bags);
+        hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, p->fcc_b,
+                           A, B, pred_part, Kv, C, BM, (int)L.nchunk_max);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+        const int n = n_bags * C;
+        hipLaunchKernelGGL(k_pred, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, offsets, pred_part,
+                           p->fcc_b, pred, C, (int)L.nchunk_max, n_bags);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    }
+    return DSMIL_OK;
+}
+
+}  // extern "C"

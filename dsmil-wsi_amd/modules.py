@@ -1,0 +1,262 @@
+"""Drop-in mirror of the reference model API (dsmil.py:6-74): FCLayer, IClassifier, BClassifier,
+MILNet — same constructor signatures, forward tuples, attribute names and state_dict keys.
+
+Parameters live in ordinary nn.Linear / nn.Conv1d sub-modules so that ``.apply(init)``
+(train_tcga.py:229-239), ``state_dict()/load_state_dict()`` (train_tcga.py:186, testing_c16.py:122),
+``copy.deepcopy`` and ``.cuda()/.cpu()`` behave exactly as with the reference.  When the input
+is a CUDA(HIP) tensor the forward runs in libdsmil_hip.so (hand-written gfx950 kernels); a CPU
+tensor takes the plain torch-CPU route (BASELINE config 0: MUSK1 plumbing via train_mil.py).
+There is no silent GPU fallback: a missing native library raises.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+Q_DIM = 128
+
+
+class FCLayer(nn.Module):
+    """dsmil.py:6-12."""
+
+    def __init__(self, in_size, out_size=1):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(in_size, out_size))
+
+    def forward(self, feats):
+        lin = self.fc[0]
+        if feats.is_cuda:
+            x = _FCFunction.apply(feats, lin.weight, lin.bias)
+        else:
+            x = lin(feats)
+        return feats, x
+
+
+class IClassifier(nn.Module):
+    """dsmil.py:14-25: (feats.view(B,-1), Linear(feats)) around an arbitrary feature extractor."""
+
+    def __init__(self, feature_extractor, feature_size, output_class):
+        super().__init__()
+        self.feature_extractor = feature_extractor
+        self.fc = nn.Linear(feature_size, output_class)
+
+    def forward(self, x):
+        fe = self.feature_extractor
+        fused = getattr(fe, "forward_with_head", None)
+        if fused is not None and x.is_cuda:
+            # our HIP ResNet produces features and the instance logits in one launch sequence
+            return fused(x, self.fc.weight, self.fc.bias)
+        feats = fe(x)
+        feats = feats.view(feats.shape[0], -1)
+        if feats.is_cuda:
+            c = _FCFunction.apply(feats, self.fc.weight, self.fc.bias)
+        else:
+            c = self.fc(feats)
+        return feats, c
+
+
+class BClassifier(nn.Module):
+    """dsmil.py:27-62."""
+
+    def __init__(self, input_size, output_class, dropout_v=0.0, nonlinear=True, passing_v=False):
+        super().__init__()
+        if nonlinear:
+            self.q = nn.Sequential(nn.Linear(input_size, Q_DIM), nn.ReLU(), nn.Linear(Q_DIM, Q_DIM), nn.Tanh())
+        else:
+            self.q = nn.Linear(input_size, Q_DIM)
+        if passing_v:
+            self.v = nn.Sequential(nn.Dropout(dropout_v), nn.Linear(input_size, input_size), nn.ReLU())
+        else:
+            self.v = nn.Identity()
+        self.fcc = nn.Conv1d(output_class, output_class, kernel_size=input_size)
+
+    # -- helpers --------------------------------------------------------------------------
+    @property
+    def nonlinear(self):
+        return isinstance(self.q, nn.Sequential)
+
+    @property
+    def passing_v(self):
+        return not isinstance(self.v, nn.Identity)
+
+    def _weights(self):
+        if self.nonlinear:
+            q0, q2 = self.q[0], self.q[2]
+            d = {"q0_w": q0.weight, "q0_b": q0.bias, "q2_w": q2.weight, "q2_b": q2.bias}
+        else:
+            d = {"q0_w": self.q.weight, "q0_b": self.q.bias, "q2_w": None, "q2_b": None}
+        d["fcc_w"] = self.fcc.weight
+        d["fcc_b"] = self.fcc.bias
+        return d
+
+    def _forward_cpu(self, feats, c):
+        V = self.v(feats)
+        Q = self.q(feats).view(feats.shape[0], -1)
+        m_indices = torch.argmax(c, dim=0)  # lowest index on ties
+        q_max = self.q(feats.index_select(0, m_indices))
+        A = F.softmax(Q.mm(q_max.t()) / (Q.shape[1] ** 0.5), dim=0)
+        B = A.t().mm(V).unsqueeze(0)
+        C = self.fcc(B).view(1, -1)
+        return C, A, B
+
+    def forward(self, feats, c):
+        if not feats.is_cuda:
+            return self._forward_cpu(feats, c)
+        vals = self.v(feats) if self.passing_v else None  # passing_v: unused by every script
+        w = self._weights()
+        pred, A, B = _AggFunction.apply(feats, c, vals, None, None, w["q0_w"], w["q0_b"], w["q2_w"],
+                                        w["q2_b"], w["fcc_w"], w["fcc_b"], self.nonlinear)[1:4]
+        return pred, A, B
+
+
+class MILNet(nn.Module):
+    """dsmil.py:64-74."""
+
+    def __init__(self, i_classifier, b_classifier):
+        super().__init__()
+        self.i_classifier = i_classifier
+        self.b_classifier = b_classifier
+
+    def forward(self, x):
+        ic, bc = self.i_classifier, self.b_classifier
+        if (x.is_cuda and isinstance(ic, FCLayer) and isinstance(bc, BClassifier)
+                and not bc.passing_v and x.dim() == 2):
+            # one fused native call: instance logits + aggregator (dsmil.py:70-74)
+            w = bc._weights()
+            lin = ic.fc[0]
+            classes, pred, A, B = _AggFunction.apply(x, None, None, lin.weight, lin.bias, w["q0_w"],
+                                                     w["q0_b"], w["q2_w"], w["q2_b"], w["fcc_w"],
+                                                     w["fcc_b"], bc.nonlinear)[0:4]
+            return classes, pred, A, B
+        feats, classes = ic(x)
+        prediction_bag, A, B = bc(feats, classes)
+        return classes, prediction_bag, A, B
+
+    @torch.no_grad()
+    def forward_bags(self, bags):
+        """Batched inference over many independent bags in ONE native call sequence ("varlen").
+
+        ``bags`` is a list of [N_i, K] CUDA tensors, or a tuple (feats [sum N_i, K], lengths).
+        Returns a list of (classes, pred, A, B) tuples shaped like ``forward``'s.  New capability
+        (the reference loops one bag per iteration, train_tcga.py:92-99)."""
+        ic, bc = self.i_classifier, self.b_classifier
+        if not (isinstance(ic, FCLayer) and isinstance(bc, BClassifier) and not bc.passing_v):
+            return [self.forward(b) for b in bags]
+        if isinstance(bags, tuple):
+            feats, lengths = bags
+        else:
+            lengths = [int(b.shape[0]) for b in bags]
+            feats = torch.cat(list(bags), dim=0)
+        w = bc._weights()
+        lin = ic.fc[0]
+        w["fc_w"], w["fc_b"] = lin.weight, lin.bias
+        classes, pred, A, B, _ = ops.agg_forward(feats, lengths, {k: (v.detach() if v is not None else None)
+                                                                  for k, v in w.items()},
+                                                 nonlinear=bc.nonlinear)
+        out, o = [], 0
+        for i, n in enumerate(lengths):
+            out.append((classes[o:o + n], pred[i:i + 1], A[o:o + n], B[i:i + 1]))
+            o += n
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd glue
+# ---------------------------------------------------------------------------------------------
+class _FCFunction(torch.autograd.Function):
+    """c = x W^T + b in the native library; backward is three small dense products."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return ops.fc_forward(x.detach(), w.detach(), b.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = g.mm(w) if ctx.needs_input_grad[0] else None
+        gw = g.t().mm(x) if ctx.needs_input_grad[1] else None
+        gb = g.sum(0) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+class _AggFunction(torch.autograd.Function):
+    """Forward = dsmil_agg_forward (HIP).  Backward = analytic gradient of dsmil.py:46-62 (the
+    arg-max indices are constants, as in the reference's autograd graph); it re-derives Q from
+    the saved inputs.  Round 1 composes the backward from dense torch products on the GPU — the
+    native backward is SURVEY.md §8(f) row N1."""
+
+    @staticmethod
+    def forward(ctx, feats, c_in, vals, fc_w, fc_b, q0_w, q0_b, q2_w, q2_b, fcc_w, fcc_b, nonlinear):
+        det = lambda t: t.detach() if t is not None else None
+        w = {"fc_w": det(fc_w), "fc_b": det(fc_b), "q0_w": det(q0_w), "q0_b": det(q0_b),
+             "q2_w": det(q2_w), "q2_b": det(q2_b), "fcc_w": det(fcc_w), "fcc_b": det(fcc_b)}
+        N = feats.shape[0]
+        classes, pred, A, B, idx = ops.agg_forward(feats.detach(), [N], w, classes_in=det(c_in),
+                                                   vals=det(vals), nonlinear=nonlinear)
+        ctx.nonlinear = nonlinear
+        ctx.has_cin = c_in is not None
+        ctx.has_vals = vals is not None
+        ctx.save_for_backward(feats, vals, fc_w, q0_w, q0_b, q2_w, q2_b, fcc_w, A, B, idx)
+        ctx.mark_non_differentiable(idx)
+        return classes, pred, A, B, idx
+
+    @staticmethod
+    def backward(ctx, g_cls, g_pred, g_A, g_B, _g_idx):
+        feats, vals, fc_w, q0_w, q0_b, q2_w, q2_b, fcc_w, A, B, idx = ctx.saved_tensors
+        x = feats
+        V = vals if ctx.has_vals else feats
+        idx = idx[0]
+        scale = Q_DIM ** -0.5
+        C = fcc_w.shape[0]
+        zeros = torch.zeros
+        g_pred = g_pred if g_pred is not None else zeros((1, C), device=x.device)
+        # ---- bag head
+        g_fcc_b = g_pred[0]
+        g_fcc_w = g_pred[0][:, None, None] * B[0][None]
+        gB = torch.einsum("o,ock->ck", g_pred[0], fcc_w)
+        if g_B is not None:
+            gB = gB + g_B[0]
+        gA = V.mm(gB.t())
+        if g_A is not None:
+            gA = gA + g_A
+        gs = A * (gA - (A * gA).sum(0, keepdim=True)) * scale
+        # ---- recompute the query stream
+        pre1 = F.linear(x, q0_w, q0_b)
+        if ctx.nonlinear:
+            h1 = pre1.clamp_min(0)
+            Q = torch.tanh(F.linear(h1, q2_w, q2_b))
+        else:
+            Q = pre1
+        qmax = Q[idx]
+        gQ = gs.mm(qmax)
+        gQ.index_add_(0, idx, gs.t().mm(Q))
+        if ctx.nonlinear:
+            gz2 = gQ * (1 - Q * Q)
+            g_q2_w = gz2.t().mm(h1)
+            g_q2_b = gz2.sum(0)
+            gh1 = gz2.mm(q2_w) * (pre1 > 0)
+        else:
+            g_q2_w = g_q2_b = None
+            gh1 = gQ
+        g_q0_w = gh1.t().mm(x)
+        g_q0_b = gh1.sum(0)
+        # ---- instance stream (FCLayer fused in) and inputs
+        g_fc_w = g_fc_b = g_cin = None
+        if ctx.has_cin:
+            g_cin = None  # c only feeds the (non-differentiable) indices: dsmil.py:52
+        elif g_cls is not None:
+            g_fc_w = g_cls.t().mm(x)
+            g_fc_b = g_cls.sum(0)
+        g_x = g_vals = None
+        if ctx.needs_input_grad[0]:
+            g_x = gh1.mm(q0_w)
+            if not ctx.has_cin and g_cls is not None:
+                g_x = g_x + g_cls.mm(fc_w)
+            if not ctx.has_vals:
+                g_x = g_x + A.mm(gB)
+        if ctx.has_vals and ctx.needs_input_grad[2]:
+            g_vals = A.mm(gB)
+        return (g_x, g_cin, g_vals, g_fc_w, g_fc_b, g_q0_w, g_q0_b, g_q2_w, g_q2_b,
+                g_fcc_w, g_fcc_b, None)

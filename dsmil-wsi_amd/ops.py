@@ -1,0 +1,125 @@
+"""Host-side operators over the C-ABI (include/dsmil_hip.h) for CUDA(HIP) tensors.
+
+PyTorch is plumbing here: it owns device memory and the stream; all arithmetic of the forward
+hot path happens in libdsmil_hip.so.  Functions raise if handed CPU tensors — the CPU route of
+the nn.Modules (config 0, MUSK1 plumbing) never comes through this file.
+"""
+import collections
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native
+
+Q_DIM = 128
+
+_ws_cache = {}
+_off_cache = collections.OrderedDict()
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _workspace(device, nbytes):
+    buf = _ws_cache.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _ws_cache[device] = buf
+    return buf
+
+
+def offsets_tensor(lengths, device):
+    """Device int64 [n_bags+1] prefix offsets for a tuple of bag lengths (cached: a repeated bag
+    shape costs no H2D copy, keeping MILNet.forward free of host syncs)."""
+    key = (str(device), tuple(int(n) for n in lengths))
+    t = _off_cache.get(key)
+    if t is None:
+        off = np.zeros(len(key[1]) + 1, np.int64)
+        np.cumsum(np.asarray(key[1], np.int64), out=off[1:])
+        t = torch.from_numpy(off).to(device)
+        _off_cache[key] = t
+        if len(_off_cache) > 256:
+            _off_cache.popitem(last=False)
+    else:
+        _off_cache.move_to_end(key)
+    return t
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA(HIP) tensor for the native path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def fc_forward(feats, fc_w, fc_b):
+    """FCLayer / IClassifier.fc on the GPU: dsmil.py:11,24."""
+    feats = _f32c(feats, "feats"); fc_w = _f32c(fc_w, "fc_w"); fc_b = _f32c(fc_b, "fc_b")
+    N, K = feats.shape
+    C = fc_w.shape[0]
+    out = torch.empty((N, C), dtype=torch.float32, device=feats.device)
+    if N == 0:
+        return out
+    with torch.cuda.device(feats.device):
+        rc = _native.lib().dsmil_fc_forward(_ptr(feats), N, K, C, _ptr(fc_w), _ptr(fc_b), _ptr(out),
+                                            _stream(feats.device))
+    _native.check(rc, "dsmil_fc_forward")
+    return out
+
+
+def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, offsets=None):
+    """dsmil_agg_forward over a batch of bags stored back to back.
+
+    feats [total,K] fp32 CUDA; lengths: python ints (bag sizes); w: dict of CUDA fp32 tensors with
+    keys fc_w fc_b q0_w q0_b q2_w q2_b fcc_w fcc_b (fc_* may be None when classes_in is given).
+    Returns (classes [total,C], pred [n_bags,C], A [total,C], B [n_bags,C,Kv], idx int64 [n_bags,C]).
+    """
+    feats = _f32c(feats, "feats")
+    dev = feats.device
+    total, K = feats.shape
+    lengths = [int(n) for n in lengths]
+    if sum(lengths) != total:
+        raise ValueError(f"bag lengths sum to {sum(lengths)} but feats has {total} rows")
+    if any(n <= 0 for n in lengths):
+        raise ValueError("every bag needs at least one instance (the reference's sort/index_select "
+                         "at dsmil.py:52-53 fails on an empty bag too)")
+    n_bags = len(lengths)
+    vals = feats if vals is None else _f32c(vals, "vals")
+    Kv = vals.shape[1]
+    fcc_w = _f32c(w["fcc_w"], "fcc_w")
+    C = fcc_w.shape[0]
+    if fcc_w.shape[2] != Kv:
+        raise ValueError(f"fcc kernel_size {fcc_w.shape[2]} != value width {Kv}")
+    classes_in = _f32c(classes_in, "classes_in")
+    if classes_in is not None and tuple(classes_in.shape) != (total, C):
+        raise ValueError(f"c must be [{total},{C}], got {tuple(classes_in.shape)}")
+    keep = [_f32c(w.get(k), k) for k in ("fc_w", "fc_b", "q0_w", "q0_b", "q2_w", "q2_b", "fcc_w", "fcc_b")]
+    p = _native.AggParams(*[(t.data_ptr() if t is not None else 0) for t in keep],
+                          K, Kv, C, 1 if nonlinear else 0)
+    off = offsets if offsets is not None else offsets_tensor(lengths, dev)
+    classes = classes_in if classes_in is not None else torch.empty((total, C), dtype=torch.float32, device=dev)
+    A = torch.empty((total, C), dtype=torch.float32, device=dev)
+    B = torch.empty((n_bags, C, Kv), dtype=torch.float32, device=dev)
+    pred = torch.empty((n_bags, C), dtype=torch.float32, device=dev)
+    idx = torch.empty((n_bags, C), dtype=torch.int64, device=dev)
+    L = _native.lib()
+    nbytes = L.dsmil_agg_workspace_bytes(n_bags, total, K, Kv, C)
+    ws = _workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        rc = L.dsmil_agg_forward(_ptr(feats), _ptr(vals), _ptr(off), n_bags, total, max(lengths),
+                                 ctypes.byref(p), _ptr(classes_in),
+                                 _ptr(classes if classes_in is None else None),
+                                 _ptr(A), _ptr(B), _ptr(pred), _ptr(idx), _ptr(ws), ws.numel(),
+                                 _stream(dev))
+    _native.check(rc, "dsmil_agg_forward")
+    del keep
+    return classes, pred, A, B, idx

@@ -1,0 +1,101 @@
+/*
+ * dsmil_hip.h — C-ABI of libdsmil_hip.so: the MI355X (gfx950) implementation of the two DSMIL
+ * hot paths.  Plain pointers and sizes only; every pointer named "device" is HBM memory owned
+ * by the caller; nothing is allocated, freed or synchronised inside the library; all work is
+ * enqueued on the HIP stream handed in (hipStream_t passed as void*), in order, and is
+ * hipGraph-capturable.  Every function returns 0 on success or a negative DSMIL_E_* code;
+ * dsmil_strerror() names it.  No C++ exceptions cross this boundary.
+ *
+ * The reference (binli123/dsmil-wsi) has no FFI of its own: its boundary is the nn.Module API of
+ * dsmil.py.  Each entry point below therefore cites the reference forward it replaces, and
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ */
+#ifndef DSMIL_HIP_H
+#define DSMIL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSMIL_ABI_VERSION 1
+#define DSMIL_Q_DIM 128 /* query width hard-coded at dsmil.py:31,33 */
+
+enum {
+    DSMIL_OK = 0,
+    DSMIL_E_INVALID = -1,     /* null pointer / non-positive size / bad flag           */
+    DSMIL_E_UNSUPPORTED = -2, /* shape or dtype outside what the kernels implement      */
+    DSMIL_E_WORKSPACE = -3,   /* workspace smaller than dsmil_*_workspace_bytes() says  */
+    DSMIL_E_LAUNCH = -4,      /* hipGetLastError() != hipSuccess after a launch         */
+    DSMIL_E_ALIGN = -5        /* a pointer is not aligned as the kernels require        */
+};
+
+enum { DSMIL_F32 = 0, DSMIL_BF16 = 1 };
+
+/* Parameters of FCLayer + BClassifier, row-major fp32 device pointers, named after the
+ * reference state_dict keys (dsmil.py:9,31,33,44):
+ *   fc_w  [C,K]  fc_b [C]      i_classifier.fc.0.{weight,bias}      (may be NULL when the
+ *                               caller supplies instance logits, see classes_in)
+ *   q0_w  [128,K] q0_b [128]   b_classifier.q.0.*  (b_classifier.q.* when nonlinear == 0)
+ *   q2_w  [128,128] q2_b [128] b_classifier.q.2.*  (ignored when nonlinear == 0)
+ *   fcc_w [C,C,Kv] fcc_b [C]   b_classifier.fcc.*  (Conv1d(C,C,kernel_size=Kv))
+ */
+typedef struct dsmil_agg_params {
+    const float* fc_w;
+    const float* fc_b;
+    const float* q0_w;
+    const float* q0_b;
+    const float* q2_w;
+    const float* q2_b;
+    const float* fcc_w;
+    const float* fcc_b;
+    int32_t K;         /* feature width of feats (512; 166 MUSK1; 1024 tree)           */
+    int32_t Kv;        /* width of the value rows (== K unless passing_v)               */
+    int32_t C;         /* number of classes                                             */
+    int32_t nonlinear; /* dsmil.py:30-33: 1 = Linear-ReLU-Linear-Tanh query, 0 = Linear  */
+} dsmil_agg_params;
+
+/* Replaces MILNet.forward / FCLayer.forward + BClassifier.forward (dsmil.py:10-12,46-62,70-74)
+ * for a BATCH of n_bags independent bags stored back to back ("varlen"):
+ *   feats    device [total_rows, K] fp32 row-major; bag b owns rows offsets[b]..offsets[b+1]-1
+ *   vals     device [total_rows, Kv] fp32 — V of dsmil.py:48; pass feats (or NULL) when
+ *            v = Identity (passing_v=False, the only form any reference script uses)
+ *   offsets  device int64 [n_bags+1], offsets[0] == 0, non-decreasing, every bag >= 1 row
+ *   max_rows the largest bag length (host value; sizes the launch grid)
+ *   classes_in  device [total_rows, C] or NULL.  NULL: instance logits are computed here
+ *            (FCLayer) and written to classes_out.  Non-NULL: BClassifier.forward(feats, c)
+ *            with caller-supplied c (attention_map.py:85); classes_out may then be NULL.
+ * Outputs (device, fp32 unless noted):
+ *   classes_out [total_rows, C]   instance logits           (dsmil.py:11)
+ *   A           [total_rows, C]   attention, softmax over each bag's instances (dsmil.py:56)
+ *   B           [n_bags, C, Kv]   bag embeddings            (dsmil.py:57-59)
+ *   pred        [n_bags, C]       bag logits                (dsmil.py:60-61)
+ *   idx         int64 [n_bags, C] critical-instance index, bag-local (dsmil.py:52, row 0 of
+ *                                 the descending sort; lowest index wins on exact ties)
+ *   ws / ws_bytes  scratch of at least dsmil_agg_workspace_bytes(...) bytes, 256-B aligned
+ */
+int dsmil_agg_forward(const float* feats, const float* vals, const int64_t* offsets,
+                      int32_t n_bags, int64_t total_rows, int64_t max_rows,
+                      const dsmil_agg_params* p, const float* classes_in, float* classes_out,
+                      float* A, float* B, float* pred, int64_t* idx, void* ws, size_t ws_bytes,
+                      void* stream);
+
+size_t dsmil_agg_workspace_bytes(int32_t n_bags, int64_t total_rows, int32_t K, int32_t Kv,
+                                 int32_t C);
+
+/* FCLayer.forward alone (dsmil.py:10-12): classes[total_rows, C] = feats @ fc_w^T + fc_b. */
+int dsmil_fc_forward(const float* feats, int64_t total_rows, int32_t K, int32_t C,
+                     const float* fc_w, const float* fc_b, float* classes, void* stream);
+
+const char* dsmil_strerror(int code);
+int dsmil_abi_version(void);
+/* Name + per-launch average of the dominant kernel is measured by the caller with HIP events;
+ * this only reports the tile geometry the launcher would pick (rows per workgroup). */
+int dsmil_agg_tile_rows(int32_t n_bags, int64_t total_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSMIL_HIP_H */
