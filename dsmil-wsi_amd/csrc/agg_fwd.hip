@@ -73,9 +73,9 @@ __device__ __forceinline__ bool better(float v, long long i, float bv, long long
 // --------------------------------------------------------------------------------------------
 // k_logits_argmax: c = x W_i^T + b_i (dsmil.py:11) and per-tile arg-max partials (dsmil.py:52).
 // One wave owns 32 rows, 4 rows in flight; lanes stride the feature axis with 16-B loads.
-// If classes_in != nullptr the logits are taken from it (BClassifier.forward(feats, c)).
+// GIVEN = true: the logits are taken from classes_in (BClassifier.forward(feats, c)).
 // --------------------------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, bool GIVEN>
 __global__ __launch_bounds__(256) void k_logits_argmax(
     const float* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ fc_w, const float* __restrict__ fc_b,
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void k_logits_argmax(
     if (row0 >= Nb) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long slot = off0 / R0 + bag + blockIdx.x;
-    __shared__ float s_v[4];
-    __shared__ long long s_i[4];
+    __shared__ float s_v[8];
+    __shared__ long long s_i[8];
 
     for (int c0 = 0; c0 < C; c0 += 2) {
         const int c1 = (c0 + 1 < C) ? c0 + 1 : c0;
@@ -98,87 +98,85 @@ __global__ __launch_bounds__(256) void k_logits_argmax(
         for (int rg = 0; rg < 8; ++rg) {
             const long long rbase = row0 + wave * 32 + rg * 4;
             if (rbase >= Nb) break;  // wave-uniform
-            float v[4][2];
-            if (classes_in == nullptr) {
-                float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-                const float* xr[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    long long r = rbase + j;
-                    if (r >= Nb) r = Nb - 1;
-                    xr[j] = feats + (off0 + r) * (long long)K;
-                }
+            float va0, va1, vb0, vb1, vc0, vc1, vd0, vd1;  // rows a..d, classes c0/c1
+            const long long ra = rbase, rb = (rbase + 1 < Nb) ? rbase + 1 : Nb - 1,
+                            rc = (rbase + 2 < Nb) ? rbase + 2 : Nb - 1, rd = (rbase + 3 < Nb) ? rbase + 3 : Nb - 1;
+            if constexpr (!GIVEN) {
+                const float* xa = feats + (off0 + ra) * (long long)K;
+                const float* xb = feats + (off0 + rb) * (long long)K;
+                const float* xc = feats + (off0 + rc) * (long long)K;
+                const float* xd = feats + (off0 + rd) * (long long)K;
+                const float* w0p = fc_w + (long long)c0 * K;
+                const float* w1p = fc_w + (long long)c1 * K;
+                va0 = va1 = vb0 = vb1 = vc0 = vc1 = vd0 = vd1 = 0.f;
                 for (int k0 = 0; k0 < K; k0 += 256) {
                     const int k = k0 + lane * 4;
-                    const f32x4 w0 = load4<VEC>(fc_w + (long long)c0 * K, k, K);
-                    const f32x4 w1 = load4<VEC>(fc_w + (long long)c1 * K, k, K);
+                    const f32x4 w0 = load4<VEC>(w0p, k, K);
+                    const f32x4 w1 = load4<VEC>(w1p, k, K);
+                    const f32x4 a = load4<VEC>(xa, k, K);
+                    const f32x4 b = load4<VEC>(xb, k, K);
+                    const f32x4 c = load4<VEC>(xc, k, K);
+                    const f32x4 d = load4<VEC>(xd, k, K);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4 x = load4<VEC>(xr[j], k, K);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            acc[j][0] = fmaf(x[e], w0[e], acc[j][0]);
-                            acc[j][1] = fmaf(x[e], w1[e], acc[j][1]);
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        va0 = fmaf(a[e], w0[e], va0); va1 = fmaf(a[e], w1[e], va1);
+                        vb0 = fmaf(b[e], w0[e], vb0); vb1 = fmaf(b[e], w1[e], vb1);
+                        vc0 = fmaf(c[e], w0[e], vc0); vc1 = fmaf(c[e], w1[e], vc1);
+                        vd0 = fmaf(d[e], w0[e], vd0); vd1 = fmaf(d[e], w1[e], vd1);
                     }
                 }
                 const float b0 = fc_b[c0], b1 = fc_b[c1];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j][0] = wave_sum(acc[j][0]) + b0;
-                    v[j][1] = wave_sum(acc[j][1]) + b1;
-                }
+                va0 = wave_sum(va0) + b0; va1 = wave_sum(va1) + b1;
+                vb0 = wave_sum(vb0) + b0; vb1 = wave_sum(vb1) + b1;
+                vc0 = wave_sum(vc0) + b0; vc1 = wave_sum(vc1) + b1;
+                vd0 = wave_sum(vd0) + b0; vd1 = wave_sum(vd1) + b1;
                 if (lane < 4 && rbase + lane < Nb) {
-                    float o0 = v[0][0], o1 = v[0][1];
-                    if (lane == 1) { o0 = v[1][0]; o1 = v[1][1]; }
-                    if (lane == 2) { o0 = v[2][0]; o1 = v[2][1]; }
-                    if (lane == 3) { o0 = v[3][0]; o1 = v[3][1]; }
+                    const float o0 = lane == 0 ? va0 : lane == 1 ? vb0 : lane == 2 ? vc0 : vd0;
+                    const float o1 = lane == 0 ? va1 : lane == 1 ? vb1 : lane == 2 ? vc1 : vd1;
                     float* o = classes_out + (off0 + rbase + lane) * (long long)C;
                     o[c0] = o0;
                     if (c1 != c0) o[c1] = o1;
                 }
             } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    long long r = rbase + j;
-                    if (r >= Nb) r = Nb - 1;
-                    const float* ci = classes_in + (off0 + r) * (long long)C;
-                    v[j][0] = ci[c0];
-                    v[j][1] = ci[c1];
-                }
+                const float* ci = classes_in + off0 * (long long)C;
+                va0 = ci[ra * C + c0]; va1 = ci[ra * C + c1];
+                vb0 = ci[rb * C + c0]; vb1 = ci[rb * C + c1];
+                vc0 = ci[rc * C + c0]; vc1 = ci[rc * C + c1];
+                vd0 = ci[rd * C + c0]; vd1 = ci[rd * C + c1];
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const long long r = rbase + j;
-                if (r < Nb) {
-                    if (better(v[j][0], r, bv0, bi0)) { bv0 = v[j][0]; bi0 = r; }
-                    if (better(v[j][1], r, bv1, bi1)) { bv1 = v[j][1]; bi1 = r; }
-                }
-            }
+            // rows past the end were clamped to Nb-1: a duplicate can never beat itself (same index)
+            if (better(va0, ra, bv0, bi0)) { bv0 = va0; bi0 = ra; }
+            if (better(vb0, rb, bv0, bi0)) { bv0 = vb0; bi0 = rb; }
+            if (better(vc0, rc, bv0, bi0)) { bv0 = vc0; bi0 = rc; }
+            if (better(vd0, rd, bv0, bi0)) { bv0 = vd0; bi0 = rd; }
+            if (better(va1, ra, bv1, bi1)) { bv1 = va1; bi1 = ra; }
+            if (better(vb1, rb, bv1, bi1)) { bv1 = vb1; bi1 = rb; }
+            if (better(vc1, rc, bv1, bi1)) { bv1 = vc1; bi1 = rc; }
+            if (better(vd1, rd, bv1, bi1)) { bv1 = vd1; bi1 = rd; }
         }
         // combine the 4 waves (values are wave-uniform)
-        for (int cc = 0; cc < 2; ++cc) {
-            const int c = cc ? c1 : c0;
-            if (cc && c1 == c0) break;
-            __syncthreads();
-            if (lane == 0) { s_v[wave] = cc ? bv1 : bv0; s_i[wave] = cc ? bi1 : bi0; }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                float bv = s_v[0];
-                long long bi = s_i[0];
-                for (int w = 1; w < 4; ++w)
-                    if (better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
-                part_val[slot * C + c] = bv;
-                part_idx[slot * C + c] = bi;
-            }
+        __syncthreads();
+        if (lane == 0) { s_v[wave] = bv0; s_i[wave] = bi0; s_v[4 + wave] = bv1; s_i[4 + wave] = bi1; }
+        __syncthreads();
+        if (threadIdx.x < 2 && (threadIdx.x == 0 || c1 != c0)) {
+            const int h = threadIdx.x * 4;
+            float bv = s_v[h];
+            long long bi = s_i[h];
+            for (int w = 1; w < 4; ++w)
+                if (better(s_v[h + w], s_i[h + w], bv, bi)) { bv = s_v[h + w]; bi = s_i[h + w]; }
+            const int c = threadIdx.x ? c1 : c0;
+            part_val[slot * C + c] = bv;
+            part_idx[slot * C + c] = bi;
         }
     }
 }
 
 // --------------------------------------------------------------------------------------------
 // k_qmax: one workgroup per (bag, class).  Finishes the arg-max over the bag's tile partials
-// (dsmil.py:52), then q_max = q(feats[idx]) (dsmil.py:53-54) on the VALU.
+// (dsmil.py:52), then q_max = q(feats[idx]) (dsmil.py:53-54) on the VALU, 8 hidden units in
+// flight per wave so the dependent shuffle chains overlap.
 // --------------------------------------------------------------------------------------------
+template <int VEC>
 __global__ __launch_bounds__(256) void k_qmax(
     const float* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ part_val, const long long* __restrict__ part_idx,
@@ -189,8 +187,8 @@ __global__ __launch_bounds__(256) void k_qmax(
     const long long off0 = offsets[bag];
     const long long Nb = offsets[bag + 1] - off0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ float s_v[256];
-    __shared__ long long s_i[256];
+    __shared__ float s_v[4];
+    __shared__ long long s_i[4];
     __shared__ float s_h[QD];
     const long long slot0 = off0 / R0 + bag;
     const long long ntile = (Nb + R0 - 1) / R0;
@@ -201,31 +199,42 @@ __global__ __launch_bounds__(256) void k_qmax(
         const long long i = part_idx[(slot0 + t) * C + c];
         if (better(v, i, bv, bi)) { bv = v; bi = i; }
     }
-    s_v[threadIdx.x] = bv;
-    s_i[threadIdx.x] = bi;
-    __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            if (better(s_v[threadIdx.x + s], s_i[threadIdx.x + s], s_v[threadIdx.x], s_i[threadIdx.x])) {
-                s_v[threadIdx.x] = s_v[threadIdx.x + s];
-                s_i[threadIdx.x] = s_i[threadIdx.x + s];
-            }
-        }
-        __syncthreads();
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const long long oi = __shfl_xor(bi, o, 64);
+        if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
     }
-    long long best = s_i[0];
-    if (best < 0 || best >= Nb) best = 0;  // all-NaN / empty guard: stay in bounds
+    if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+    __syncthreads();
+    bv = s_v[0]; bi = s_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
+    long long best = bi;
+    if (best < 0 || best >= Nb) best = 0;  // all-NaN guard: stay in bounds
     if (threadIdx.x == 0) idx_out[(long long)bag * C + c] = best;
     const float* x = feats + (off0 + best) * (long long)K;
-    // layer 1: wave w computes hidden units 32w..32w+31, lanes stride k
-    for (int jj = 0; jj < 32; ++jj) {
-        const int j = wave * 32 + jj;
-        const float* wr = q0_w + (long long)j * K;
-        float a = 0.f;
-        for (int k = lane; k < K; k += 64) a = fmaf(x[k], wr[k], a);
-        a = wave_sum(a) + q0_b[j];
-        if (nonlinear) a = fmaxf(a, 0.f);
-        if (lane == 0) s_h[j] = a;
+    // layer 1: wave w computes hidden units 32w..32w+31, 8 at a time; lanes stride k by 4
+    for (int jb = 0; jb < 32; jb += 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* wr = q0_w + (long long)(wave * 32 + jb) * K;
+        for (int k0 = 0; k0 < K; k0 += 256) {
+            const int k = k0 + lane * 4;
+            const f32x4 xv = load4<VEC>(x, k, K);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f32x4 wv = load4<VEC>(wr + (long long)u * K, k, K);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[u] = fmaf(xv[e], wv[e], acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float a = wave_sum(acc[u]) + q0_b[wave * 32 + jb + u];
+            if (nonlinear) a = fmaxf(a, 0.f);
+            if (lane == 0) s_h[wave * 32 + jb + u] = a;
+        }
     }
     __syncthreads();
     float* out = qmax + ((long long)bag * C + c) * QD;
@@ -233,12 +242,19 @@ __global__ __launch_bounds__(256) void k_qmax(
         if (threadIdx.x < QD) out[threadIdx.x] = s_h[threadIdx.x];
         return;
     }
-    for (int jj = 0; jj < 32; ++jj) {
-        const int j = wave * 32 + jj;
-        const float* wr = q2_w + (long long)j * QD;
-        float a = fmaf(s_h[lane], wr[lane], s_h[lane + 64] * wr[lane + 64]);
-        a = wave_sum(a) + q2_b[j];
-        if (lane == 0) out[j] = tanhf(a);
+    const float h0 = s_h[lane], h1 = s_h[lane + 64];
+    for (int jb = 0; jb < 32; jb += 8) {
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* wr = q2_w + (long long)(wave * 32 + jb + u) * QD;
+            acc[u] = fmaf(h0, wr[lane], h1 * wr[lane + 64]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float a = wave_sum(acc[u]) + q2_b[wave * 32 + jb + u];
+            if (lane == 0) out[wave * 32 + jb + u] = tanhf(a);
+        }
     }
 }
 
@@ -678,6 +694,17 @@ WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int Kv,
     return w;
 }
 
+// Optional timing of the dominant kernel with HIP events on the launch stream (bench.py's
+// roofline leg).  Off by default; never used inside graph capture.
+constexpr int PROF_RING = 512;
+struct ProfState {
+    bool on = false;
+    int n = 0;
+    hipEvent_t ev0[PROF_RING], ev1[PROF_RING];
+    bool created = false;
+};
+ProfState g_prof;
+
 template <int NW, int VEC>
 int launch_attend(const AttendArgs& a, long long max_rows, int n_bags, hipStream_t st) {
     constexpr int BM = NW * 32;
@@ -689,7 +716,10 @@ int launch_attend(const AttendArgs& a, long long max_rows, int n_bags, hipStream
         attr_done = true;
     }
     dim3 grid((unsigned)((max_rows + BM - 1) / BM), (unsigned)n_bags);
+    const bool prof = g_prof.on && g_prof.n < PROF_RING;
+    if (prof) (void)hipEventRecord(g_prof.ev0[g_prof.n], st);
     hipLaunchKernelGGL((k_query_attend<NW, VEC>), grid, dim3(NW * 64), lds, st, a);
+    if (prof) (void)hipEventRecord(g_prof.ev1[g_prof.n++], st);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
@@ -709,6 +739,34 @@ const char* dsmil_strerror(int code) {
         case DSMIL_E_ALIGN: return "pointer not aligned";
         default: return "unknown error";
     }
+}
+
+int dsmil_profile_enable(int on) {
+    if (on && !g_prof.created) {
+        for (int i = 0; i < PROF_RING; ++i) {
+            if (hipEventCreate(&g_prof.ev0[i]) != hipSuccess) return DSMIL_E_LAUNCH;
+            if (hipEventCreate(&g_prof.ev1[i]) != hipSuccess) return DSMIL_E_LAUNCH;
+        }
+        g_prof.created = true;
+    }
+    g_prof.on = on != 0;
+    g_prof.n = 0;
+    return DSMIL_OK;
+}
+
+int dsmil_profile_collect(double* total_ms, int64_t* launches) {
+    if (!total_ms || !launches) return DSMIL_E_INVALID;
+    double t = 0.0;
+    for (int i = 0; i < g_prof.n; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof.ev1[i]) != hipSuccess) return DSMIL_E_LAUNCH;
+        if (hipEventElapsedTime(&ms, g_prof.ev0[i], g_prof.ev1[i]) != hipSuccess) return DSMIL_E_LAUNCH;
+        t += ms;
+    }
+    *total_ms = t;
+    *launches = g_prof.n;
+    g_prof.n = 0;
+    return DSMIL_OK;
 }
 
 int dsmil_agg_tile_rows(int32_t n_bags, int64_t total_rows) { return pick_nw(n_bags, total_rows) * 32; }
@@ -769,13 +827,16 @@ int dsmil_agg_forward(const float* feats, const float* vals, const int64_t* offs
     // 1. instance logits + arg-max partials
     {
         dim3 grid((unsigned)((max_rows + R0 - 1) / R0), (unsigned)n_bags);
-        if (v4) hipLaunchKernelGGL(k_logits_argmax<4>, grid, dim3(256), 0, st, feats, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
-        else hipLaunchKernelGGL(k_logits_argmax<1>, grid, dim3(256), 0, st, feats, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
+        if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true>), grid, dim3(256), 0, st, feats, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
+        else if (v4) hipLaunchKernelGGL((k_logits_argmax<4, false>), grid, dim3(256), 0, st, feats, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
+        else hipLaunchKernelGGL((k_logits_argmax<1, false>), grid, dim3(256), 0, st, feats, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
     // 2. critical instance + its query
-    hipLaunchKernelGGL(k_qmax, dim3((unsigned)n_bags, (unsigned)C), dim3(256), 0, st, feats, offsets,
-                       part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear);
+    if (v4) hipLaunchKernelGGL(k_qmax<4>, dim3((unsigned)n_bags, (unsigned)C), dim3(256), 0, st, feats, offsets,
+                               part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear);
+    else hipLaunchKernelGGL(k_qmax<1>, dim3((unsigned)n_bags, (unsigned)C), dim3(256), 0, st, feats, offsets,
+                            part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     // 3. query MLP on MFMA + scores + tile softmax + weighted value sum
     AttendArgs a{feats, vals, offsets, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, A, part_ml, part_B,

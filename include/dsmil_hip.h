@@ -91,9 +91,15 @@ int dsmil_fc_forward(const float* feats, int64_t total_rows, int32_t K, int32_t 
 
 const char* dsmil_strerror(int code);
 int dsmil_abi_version(void);
-/* Name + per-launch average of the dominant kernel is measured by the caller with HIP events;
- * this only reports the tile geometry the launcher would pick (rows per workgroup). */
+/* Rows per workgroup the launcher picks for the dominant kernel (k_query_attend). */
 int dsmil_agg_tile_rows(int32_t n_bags, int64_t total_rows);
+
+/* Measurement hooks (bench.py's roofline leg; no reference counterpart).  While enabled, every
+ * launch of the dominant kernel is bracketed by hipEventRecord on its own launch stream (up to
+ * 512 launches); dsmil_profile_collect() synchronises on them, returns the summed kernel time
+ * and the launch count, and resets the ring.  Not for use under graph capture. */
+int dsmil_profile_enable(int on);
+int dsmil_profile_collect(double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }
