@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the DSMIL aggregator hot path on MI355X (BASELINE.json configs[1]).
+"""bench.py — throughput of the two DSMIL hot paths on MI355X: the aggregator (BASELINE.json
+configs[1], the headline `value`) and the ResNet-18-IN patch embedder (`embedder` sub-object).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -11,6 +12,11 @@ head) over one batch of --bags synthetic 10 000 x 512 fp32 bags that are already
 HBM.  The batch (default 64 distinct bags = 1.31 GB) is larger than the 256 MiB Infinity Cache,
 so every step streams its features from HBM.  Bags are independent units: with N ranks each rank
 owns its own --bags bags (weak scaling), there is no data-path collective.
+
+The embedder leg (same run, reported under "embedder") times IClassifier over --patches synthetic
+224x224 patches per rank per step (ResNet-18 + InstanceNorm on f32 MFMA, then Linear(512,C));
+with N ranks each rank embeds its own shard of the slide and ONE RCCL all-gather of the
+[--patches, 512] feature rows follows inside the timed step.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_query_attend), timed
 live with HIP events on its launch stream inside the library; `cpu_baseline` is the numpy oracle
@@ -74,6 +80,97 @@ def cpu_baseline(weights, N, K, C, budget_s):
             "sample": f"{n} forwards of a {N}x{K} fp32 bag (C={C}) by oracle/agg_oracle.py (numpy/BLAS) in {el:.1f}s"}
 
 
+FLOPS_PER_PATCH = 3627122688          # 2 x 1 813 561 344 MAC, 20 convs
+STEM_FLOPS_PER_PATCH = 2 * 12544 * 64 * 147
+
+
+def embedder_cpu_baseline(budget_s):
+    """oracle/resnet_oracle.py (torch CPU ops, fp32) on the host cores, bounded."""
+    import resnet_oracle as ro
+    from inputs import make_patches
+    w = ro.make_weights(seed=11)
+    x = torch.from_numpy(make_patches(7, 8))
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        ro.resnet18_in_features(x[:2], w)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            ro.resnet18_in_features(x, w)
+            n += x.shape[0]
+            el = time.perf_counter() - t0
+            if el >= budget_s:
+                break
+    return {"value": round(n / el, 2), "unit": "patches/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} patches (batches of 8, 224x224) through oracle/resnet_oracle.py (torch CPU fp32) in {el:.1f}s"}
+
+
+def embedder_leg(args, dev, rank, world, dist, L):
+    import torch.nn as nn
+    import dsmil
+    import resnet_oracle as ro
+    from dsmil_wsi_amd.resnet import resnet18
+    from conftest import load_weights
+    res = resnet18(pretrained=False, norm_layer=nn.InstanceNorm2d)
+    for p in res.parameters():
+        p.requires_grad = False
+    res.fc = nn.Identity()
+    res.load_state_dict(ro.make_weights(seed=11), strict=True)
+    wt = load_weights("tcga")
+    ic = dsmil.IClassifier(res, 512, output_class=2)
+    with torch.no_grad():
+        ic.fc.weight.copy_(torch.from_numpy(wt["fc_w"]))
+        ic.fc.bias.copy_(torch.from_numpy(wt["fc_b"]))
+    ic = ic.to(dev).eval()
+    Bp = args.patches
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    x = torch.rand((Bp, 3, 224, 224), generator=g, device=dev, dtype=torch.float32)
+    gathered = torch.empty((world * Bp, 512), device=dev) if world > 1 else None
+
+    def step():
+        with torch.no_grad():
+            feats, c = ic(x)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, feats)
+        return feats
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        feats = step()
+    fence()
+    L.dsmil_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        feats = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tot_ms, launches = ctypes.c_double(0), ctypes.c_int64(0)
+    L.dsmil_profile_collect(1, ctypes.byref(tot_ms), ctypes.byref(launches))
+    L.dsmil_profile_enable(0)
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(feats).all()
+    value = world * Bp * args.steps / dt
+    conv_flops = (FLOPS_PER_PATCH - STEM_FLOPS_PER_PATCH) * Bp * args.steps
+    ach = conv_flops / (tot_ms.value * 1e-3) / 1e12 if tot_ms.value > 0 else None
+    return {"metric": "patches/sec embedded (ResNet-18-IN, 224x224, bs=%d)" % Bp, "value": round(value, 1),
+            "unit": "patches/s", "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "f32",
+            "config": {"workload": f"IClassifier(ResNet-18 InstanceNorm, fc=Identity)+Linear(512,2), {Bp} synthetic "
+                                   f"224x224 patches per GPU per step, kaiming(seed 11) weights",
+                       "collective": "all_gather_into_tensor([%d,512] f32) per step" % Bp if world > 1 else "none"},
+            "roofline": {"kernel": "k_conv (19 implicit-GEMM convs per forward)", "bound": "mfma",
+                         "achieved": round(ach, 2) if ach else None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4) if ach else None, "traffic": None,
+                         "kernel_ms_total": round(tot_ms.value, 3), "launches": int(launches.value),
+                         "alg_flops_total": conv_flops,
+                         "whole_path_frac_of_roofline": round(value / world / (PEAK_F32_MFMA_TFLOPS * 1e12 / FLOPS_PER_PATCH), 4)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,7 +181,9 @@ def main():
     ap.add_argument("--feats", type=int, default=512)
     ap.add_argument("--weights", default="c16", choices=["c16", "tcga"],
                     help="c16: Camelyon16 aggregator (C=1, BASELINE configs[1]); tcga: C=2")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--patches", type=int, default=256, help="patches per rank per embedder step")
+    ap.add_argument("--workload", default="both", choices=["both", "aggregator", "embedder"])
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -138,7 +237,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     tot_ms, launches = ctypes.c_double(0), ctypes.c_int64(0)
-    L.dsmil_profile_collect(ctypes.byref(tot_ms), ctypes.byref(launches))
+    L.dsmil_profile_collect(0, ctypes.byref(tot_ms), ctypes.byref(launches))
     L.dsmil_profile_enable(0)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -148,6 +247,12 @@ def main():
     A = out[2]
     s = A.view(nb, N, C).sum(1)
     assert torch.isfinite(out[1]).all() and torch.allclose(s, torch.ones_like(s), atol=1e-4)
+
+    emb = None
+    if args.workload in ("both", "embedder"):
+        del feats, out, A, s
+        torch.cuda.empty_cache()
+        emb = embedder_leg(args, dev, rank, world, dist, L)
 
     if rank == 0:
         bags_total = world * nb * args.steps
@@ -180,8 +285,12 @@ def main():
                              value / world / (1.0 / max(flops_per_bag(N, K, C) / (PEAK_F32_MFMA_TFLOPS * 1e12),
                                                              bytes_per_bag(N, K, C) / (PEAK_HBM_GBS * 1e9))), 4)},
         }
+        if emb is not None:
+            line["embedder"] = emb
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wnp, N, K, C, args.cpu_seconds)
+            if emb is not None:
+                emb["cpu_baseline"] = embedder_cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -35,7 +35,13 @@ SIGNATURES = {
     "dsmil_agg_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
                                                     ctypes.c_int32, ctypes.c_int32]),
     "dsmil_profile_enable": (ctypes.c_int, [ctypes.c_int]),
-    "dsmil_profile_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    "dsmil_profile_collect": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    "dsmil_resnet18_packed_bytes": (ctypes.c_size_t, []),
+    "dsmil_resnet18_pack": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), c_f32p, ctypes.c_void_p]),
+    "dsmil_resnet18_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "dsmil_resnet18in_forward": (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p,
+                                                c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dsmil_fc_forward": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                         c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
     "dsmil_agg_forward": (ctypes.c_int, [c_f32p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int64,

@@ -27,6 +27,7 @@
 #include <stdint.h>
 #include <math.h>
 #include "dsmil_hip.h"
+#include "prof.h"
 
 namespace {
 
@@ -694,17 +695,6 @@ WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int Kv,
     return w;
 }
 
-// Optional timing of the dominant kernel with HIP events on the launch stream (bench.py's
-// roofline leg).  Off by default; never used inside graph capture.
-constexpr int PROF_RING = 512;
-struct ProfState {
-    bool on = false;
-    int n = 0;
-    hipEvent_t ev0[PROF_RING], ev1[PROF_RING];
-    bool created = false;
-};
-ProfState g_prof;
-
 template <int NW, int VEC>
 int launch_attend(const AttendArgs& a, long long max_rows, int n_bags, hipStream_t st) {
     constexpr int BM = NW * 32;
@@ -716,10 +706,9 @@ int launch_attend(const AttendArgs& a, long long max_rows, int n_bags, hipStream
         attr_done = true;
     }
     dim3 grid((unsigned)((max_rows + BM - 1) / BM), (unsigned)n_bags);
-    const bool prof = g_prof.on && g_prof.n < PROF_RING;
-    if (prof) (void)hipEventRecord(g_prof.ev0[g_prof.n], st);
+    const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
     hipLaunchKernelGGL((k_query_attend<NW, VEC>), grid, dim3(NW * 64), lds, st, a);
-    if (prof) (void)hipEventRecord(g_prof.ev1[g_prof.n++], st);
+    dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
@@ -739,34 +728,6 @@ const char* dsmil_strerror(int code) {
         case DSMIL_E_ALIGN: return "pointer not aligned";
         default: return "unknown error";
     }
-}
-
-int dsmil_profile_enable(int on) {
-    if (on && !g_prof.created) {
-        for (int i = 0; i < PROF_RING; ++i) {
-            if (hipEventCreate(&g_prof.ev0[i]) != hipSuccess) return DSMIL_E_LAUNCH;
-            if (hipEventCreate(&g_prof.ev1[i]) != hipSuccess) return DSMIL_E_LAUNCH;
-        }
-        g_prof.created = true;
-    }
-    g_prof.on = on != 0;
-    g_prof.n = 0;
-    return DSMIL_OK;
-}
-
-int dsmil_profile_collect(double* total_ms, int64_t* launches) {
-    if (!total_ms || !launches) return DSMIL_E_INVALID;
-    double t = 0.0;
-    for (int i = 0; i < g_prof.n; ++i) {
-        float ms = 0.f;
-        if (hipEventSynchronize(g_prof.ev1[i]) != hipSuccess) return DSMIL_E_LAUNCH;
-        if (hipEventElapsedTime(&ms, g_prof.ev0[i], g_prof.ev1[i]) != hipSuccess) return DSMIL_E_LAUNCH;
-        t += ms;
-    }
-    *total_ms = t;
-    *launches = g_prof.n;
-    g_prof.n = 0;
-    return DSMIL_OK;
 }
 
 int dsmil_agg_tile_rows(int32_t n_bags, int64_t total_rows) { return pick_nw(n_bags, total_rows) * 32; }

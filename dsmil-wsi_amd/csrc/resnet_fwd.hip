@@ -1,0 +1,689 @@
+// ResNet-18 (InstanceNorm2d, fc = Identity) patch embedder, forward — hand-written HIP for gfx950.
+//
+// Replaces the torchvision backbone behind dsmil.IClassifier (reference call sites:
+// compute_feats.py:146-170,211; dsmil.py:21-25).  fp32 end to end on exact-f32 MFMA
+// (v_mfma_f32_32x32x2_f32), activations NHWC in HBM.
+//
+// InstanceNorm cannot be folded into the conv weights (per-image, per-channel statistics over
+// H x W, eps = 1e-5, biased variance, no affine).  Each convolution therefore writes its RAW output
+// plus per-32-pixel-tile (mean, M2) partials from its epilogue registers; a tiny finalize kernel
+// merges them (Chan) into mean/rstd per (image, channel); and the CONSUMER applies
+// (x - mean) * rstd (+ReLU) while it stages its input tile into LDS.  Residual add + ReLU is the
+// one remaining elementwise pass per BasicBlock.
+//
+//   k_stem            7x7 s2 conv on the NCHW input (Cin = 3, K = 147): input window + weights in LDS
+//   k_norm_relu_maxpool  IN + ReLU + 3x3 s2 max-pool of the stem output (max commutes with the
+//                     increasing map x -> relu((x-mean)*rstd), so the window max is taken on raw values)
+//   k_conv<NT,NORM>   implicit-GEMM 3x3 / 1x1 conv, M = flattened (image, y, x) output pixels,
+//                     128 pixels x NT*32 channels per workgroup, K looped as (cin-chunk, tap)
+//   k_in_finalize_*   partials -> mean, rstd
+//   k_norm_add_relu   out = relu(IN(y2) + identity | IN(y_downsample)); the last one also
+//                     average-pools (adaptive_avg_pool2d(1)) into the 512-d feature row
+//
+// MFMA maps as in agg_fwd.hip; here A = pixels (rows), B = output channels (cols), so that for one
+// accumulator register the 32 lanes of a half-wave hold 32 consecutive channels of one pixel:
+// the NHWC store is 128-B coalesced.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "dsmil_hip.h"
+#include "prof.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;
+constexpr float IN_EPS = 1e-5f;
+
+__device__ __forceinline__ int drow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ---------------------------------------------------------------------------------------------
+// statistics epilogue shared by the conv kernels: one wave holds a 32(pixel) x 32(channel)
+// accumulator tile; rows [lo, hi_) of it belong to one image.  Returns (mean, M2) of those rows
+// for this lane's channel (valid in every lane).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_stats(const f32x16& acc, int hi, int lo, int hi_, float& mean, float& m2) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = drow(r, hi);
+        s += (row >= lo && row < hi_) ? acc[r] : 0.f;
+    }
+    s += __shfl_xor(s, 32, 64);
+    const float cnt = (float)(hi_ - lo);
+    mean = s / cnt;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = drow(r, hi);
+        const float d = acc[r] - mean;
+        q += (row >= lo && row < hi_) ? d * d : 0.f;
+    }
+    q += __shfl_xor(q, 32, 64);
+    m2 = q;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv: implicit GEMM.  x NHWC [B,H,W,Cin] (Cin % 32 == 0), w packed [taps][Cout][Cin],
+// y raw NHWC [B,Ho,Wo,Cout].  NORM: x is a RAW conv output; apply relu((x-mean)*rstd) on load.
+// ---------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* in_mean;  // [B,Cin]
+    const float* in_rstd;
+    float* y;
+    float* part;           // [tiles32][nslots][Cout][2]
+    int B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, nslots;
+    long long Mtot;
+};
+
+template <int NT, bool NORM>
+__global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
+    constexpr int TN = NT * 32;
+    constexpr int WPT = (TN * 8) / 256;  // float4 per thread per weight chunk
+    constexpr int X_TILE = 128 * LDK, W_TILE = TN * LDK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sX = smem;                // [2][X_TILE]
+    float* sW = smem + 2 * X_TILE;   // [2][W_TILE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * 128;
+    const int n0 = blockIdx.y * TN;
+    const int HW = a.Ho * a.Wo;
+    const int taps = a.ks * a.ks;
+    const int nsteps = taps * (a.Cin / BK);
+    const int c4 = tid & 7;
+
+    // per-thread pixel metadata for the 4 rows it stages
+    int iy0[4], ix0[4], nb[4], nimg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long p = m0 + (tid >> 3) + 32 * i;
+        if (p < a.Mtot) {
+            const int n = (int)(p / HW), rem = (int)(p - (long long)n * HW);
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            iy0[i] = oy * a.stride - a.pad;
+            ix0[i] = ox * a.stride - a.pad;
+            nb[i] = n * a.H * a.W;
+            nimg[i] = n;
+        } else {
+            iy0[i] = -100000; ix0[i] = -100000; nb[i] = 0; nimg[i] = 0;
+        }
+    }
+    f32x4 xreg[4], wreg[WPT];
+    f32x4 mu[4], rs[4];
+    auto stage_load = [&](int st) {
+        const int cc = st / taps, tap = st - cc * taps;
+        const int kh = tap / a.ks, kw = tap - kh * a.ks;
+        const int c0 = cc * BK + c4 * 4;
+        if constexpr (NORM) {
+            if (tap == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    mu[i] = *reinterpret_cast<const f32x4*>(a.in_mean + (long long)nimg[i] * a.Cin + c0);
+                    rs[i] = *reinterpret_cast<const f32x4*>(a.in_rstd + (long long)nimg[i] * a.Cin + c0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = iy0[i] + kh, ix = ix0[i] + kw;
+            const bool ok = (iy >= 0) && (iy < a.H) && (ix >= 0) && (ix < a.W);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                v = *reinterpret_cast<const f32x4*>(a.x + (long long)(nb[i] + iy * a.W + ix) * a.Cin + c0);
+                if constexpr (NORM) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf((v[e] - mu[i][e]) * rs[i][e], 0.f);
+                }
+            }
+            xreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int r = (tid >> 3) + 32 * i;
+            wreg[i] = *reinterpret_cast<const f32x4*>(a.w + ((long long)tap * a.Cout + n0 + r) * a.Cin + c0);
+        }
+    };
+    auto stage_write = [&](int st) {
+        float* x = sX + (st & 1) * X_TILE;
+        float* w = sW + (st & 1) * W_TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4*>(x + ((tid >> 3) + 32 * i) * LDK + c4 * 4) = xreg[i];
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            *reinterpret_cast<f32x4*>(w + ((tid >> 3) + 32 * i) * LDK + c4 * 4) = wreg[i];
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    const int frag = l31 * LDK + 4 * hi;
+    for (int st = 0; st < nsteps; ++st) {
+        if (st + 1 < nsteps) stage_load(st + 1);
+        const float* x = sX + (st & 1) * X_TILE + wave * 32 * LDK + frag;
+        const float* w = sW + (st & 1) * W_TILE + frag;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const f32x4 xa = *reinterpret_cast<const f32x4*>(x + kg * 8);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 wb = *reinterpret_cast<const f32x4*>(w + t * 32 * LDK + kg * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j], wb[j], acc[t], 0, 0, 0);
+            }
+        }
+        if (st + 1 < nsteps) stage_write(st + 1);
+        __syncthreads();
+    }
+    // ---- epilogue: raw store (128-B coalesced per half-wave) + statistics partials
+    const long long tbase = m0 + wave * 32;  // first flattened pixel of this wave's tile
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co = n0 + t * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long p = tbase + drow(r, hi);
+            if (p < a.Mtot) a.y[p * a.Cout + co] = acc[t][r];
+        }
+    }
+    if (tbase < a.Mtot) {
+        const long long tile32 = tbase >> 5;
+        const int nfirst = (int)(tbase / HW);
+        for (int s = 0; s < a.nslots; ++s) {
+            const long long ibeg = (long long)(nfirst + s) * HW, iend = ibeg + HW;
+            long long lo = ibeg - tbase, hi_ = ((iend < a.Mtot) ? iend : a.Mtot) - tbase;
+            if (lo < 0) lo = 0;
+            if (hi_ > 32) hi_ = 32;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float mean = 0.f, m2 = 0.f;
+                if (hi_ > lo) tile_stats(acc[t], hi, (int)lo, (int)hi_, mean, m2);
+                if (hi == 0) {
+                    float* o = a.part + ((tile32 * a.nslots + s) * a.Cout + n0 + t * 32 + l31) * 2;
+                    o[0] = mean;
+                    o[1] = m2;
+                }
+            }
+        }
+    }
+}
+
+// partials of flattened 32-pixel tiles -> mean / rstd per (image, channel)
+__global__ void k_in_finalize_flat(const float* __restrict__ part, float* __restrict__ mean,
+                                   float* __restrict__ rstd, int B, int HW, int C, int nslots,
+                                   long long Mtot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int n = i / C, c = i - n * C;
+    const long long ibeg = (long long)n * HW, iend = ibeg + HW;
+    const long long t0 = ibeg >> 5, t1 = (iend - 1) >> 5;
+    float cnt = 0.f, mu = 0.f, m2 = 0.f;
+    for (long long t = t0; t <= t1; ++t) {
+        const long long tb = t << 5;
+        const int s = n - (int)(tb / HW);
+        long long lo = ibeg - tb, hi = ((iend < Mtot) ? iend : Mtot) - tb;
+        if (lo < 0) lo = 0;
+        if (hi > 32) hi = 32;
+        if (hi <= lo || s < 0 || s >= nslots) continue;
+        const float* o = part + ((t * nslots + s) * C + c) * 2;
+        const float cb = (float)(hi - lo), mb = o[0], qb = o[1];
+        const float tot = cnt + cb, d = mb - mu;
+        mu += d * (cb / tot);
+        m2 += qb + d * d * (cnt * cb / tot);
+        cnt = tot;
+    }
+    mean[i] = mu;
+    rstd[i] = 1.0f / sqrtf(m2 / cnt + IN_EPS);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_stem: conv 7x7 stride 2 pad 3, Cin = 3 -> 64, input NCHW fp32 (what VF.to_tensor yields,
+// compute_feats.py:35-39), weight [64][3][7][7] read as [64][147] (k = c*49 + kh*7 + kw).
+// Workgroup = 8 x 16 output pixels (4 waves x 32 px) x 64 channels.
+// ---------------------------------------------------------------------------------------------
+constexpr int ST_ROWS = 21, ST_LW = 40, ST_PLANE = ST_ROWS * ST_LW;  // input window per channel
+constexpr int ST_K = 147, ST_KP = 152, ST_LDW = 156;
+
+__host__ __device__ constexpr int stem_off(int k) {
+    return k >= ST_K ? 0 : (k / 49) * ST_PLANE + ((k % 49) / 7) * ST_LW + (k % 7);
+}
+
+template <int KG>
+__device__ __forceinline__ void stem_kgroup(const float* __restrict__ sIn, const float* __restrict__ sW,
+                                            int pixbase, int frag, int hi, f32x16 (&acc)[2]) {
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(sW + frag + KG * 8);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(sW + 32 * ST_LDW + frag + KG * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int off = hi ? stem_off(KG * 8 + 4 + j) : stem_off(KG * 8 + j);
+        const float av = sIn[pixbase + off];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w0[j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w1[j], acc[1], 0, 0, 0);
+    }
+}
+
+template <int KG>
+struct StemLoop {
+    static __device__ __forceinline__ void run(const float* sIn, const float* sW, int pixbase, int frag, int hi,
+                                               f32x16 (&acc)[2]) {
+        StemLoop<KG - 1>::run(sIn, sW, pixbase, frag, hi, acc);
+        stem_kgroup<KG>(sIn, sW, pixbase, frag, hi, acc);
+    }
+};
+template <>
+struct StemLoop<-1> {
+    static __device__ __forceinline__ void run(const float*, const float*, int, int, int, f32x16 (&)[2]) {}
+};
+
+__global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const float* __restrict__ w,
+                                              float* __restrict__ y, float* __restrict__ part, int B,
+                                              int H, int W, int Ho, int Wo, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float sIn[3 * ST_PLANE];
+    __shared__ __attribute__((aligned(16))) float sW[64 * ST_LDW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int tile = blockIdx.x, n = blockIdx.y;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int oy0 = ty * 8, ox0 = tx * 16;
+    const int iy00 = oy0 * 2 - 3, ix00 = ox0 * 2 - 3;
+    // stage the input window (zero padded) and the weights (K padded to 152 with zeros)
+    for (int e = tid; e < 3 * ST_PLANE; e += 256) {
+        const int c = e / ST_PLANE, r = (e - c * ST_PLANE) / ST_LW, col = e - c * ST_PLANE - r * ST_LW;
+        const int iy = iy00 + r, ix = ix00 + col;
+        float v = 0.f;
+        if (col < 37 && iy >= 0 && iy < H && ix >= 0 && ix < W)
+            v = x[(((long long)n * 3 + c) * H + iy) * W + ix];
+        sIn[e] = v;
+    }
+    for (int e = tid; e < 64 * ST_KP; e += 256) {
+        const int co = e / ST_KP, k = e - co * ST_KP;
+        sW[co * ST_LDW + k] = (k < ST_K) ? w[co * ST_K + k] : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;
+    const int pixbase = (2 * py) * ST_LW + 2 * px;
+    const int frag = l31 * ST_LDW + 4 * hi;
+    StemLoop<ST_KP / 8 - 1>::run(sIn, sW, pixbase, frag, hi, acc);
+    // store raw NHWC + statistics partial (cnt, mean, M2) per (image, tile, wave, channel)
+    int cnt = 0;
+    float s0 = 0.f, s1 = 0.f;
+    bool okr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = drow(r, hi);
+        const int oy = oy0 + 2 * wave + (q >> 4), ox = ox0 + (q & 15);
+        okr[r] = (oy < Ho) && (ox < Wo);
+        if (okr[r]) {
+            float* o = y + (((long long)n * Ho + oy) * Wo + ox) * 64;
+            o[l31] = acc[0][r];
+            o[32 + l31] = acc[1][r];
+            s0 += acc[0][r];
+            s1 += acc[1][r];
+            ++cnt;
+        }
+    }
+    cnt += __shfl_xor(cnt, 32, 64);
+    s0 += __shfl_xor(s0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    const float fc = (float)cnt;
+    const float m0 = cnt ? s0 / fc : 0.f, m1 = cnt ? s1 / fc : 0.f;
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (okr[r]) {
+            const float d0 = acc[0][r] - m0, d1 = acc[1][r] - m1;
+            q0 += d0 * d0;
+            q1 += d1 * d1;
+        }
+    q0 += __shfl_xor(q0, 32, 64);
+    q1 += __shfl_xor(q1, 32, 64);
+    if (hi == 0) {
+        float* o = part + ((((long long)n * tiles_x * tiles_y + tile) * 4 + wave) * 64) * 3;
+        o[l31 * 3 + 0] = fc; o[l31 * 3 + 1] = m0; o[l31 * 3 + 2] = q0;
+        o[(32 + l31) * 3 + 0] = fc; o[(32 + l31) * 3 + 1] = m1; o[(32 + l31) * 3 + 2] = q1;
+    }
+}
+
+__global__ void k_in_finalize_stem(const float* __restrict__ part, float* __restrict__ mean,
+                                   float* __restrict__ rstd, int B, int nparts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 64) return;
+    const int n = i >> 6, c = i & 63;
+    float cnt = 0.f, mu = 0.f, m2 = 0.f;
+    for (int t = 0; t < nparts; ++t) {
+        const float* o = part + (((long long)n * nparts + t) * 64 + c) * 3;
+        const float cb = o[0];
+        if (cb <= 0.f) continue;
+        const float tot = cnt + cb, d = o[1] - mu;
+        mu += d * (cb / tot);
+        m2 += o[2] + d * d * (cnt * cb / tot);
+        cnt = tot;
+    }
+    mean[i] = mu;
+    rstd[i] = 1.0f / sqrtf(m2 / cnt + IN_EPS);
+}
+
+// IN + ReLU + MaxPool2d(3, stride 2, pad 1) of the raw stem output, NHWC, C = 64
+__global__ __launch_bounds__(256) void k_norm_relu_maxpool(const float* __restrict__ y,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           float* __restrict__ out, int B, int Hi, int Wi,
+                                                           int Ho, int Wo, int C) {
+    const int c4n = C / 4;
+    const long long total = (long long)B * Ho * Wo * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        long long p = i / c4n;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if (iy < 0 || iy >= Hi) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if (ix < 0 || ix >= Wi) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(y + (((long long)n * Hi + iy) * Wi + ix) * C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+        }
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (long long)n * C + c4 * 4);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + (long long)n * C + c4 * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf((m[e] - mu[e]) * rs[e], 0.f);
+        *reinterpret_cast<f32x4*>(out + (((long long)n * Ho + oy) * Wo + ox) * C + c4 * 4) = o;
+    }
+}
+
+// out = relu(IN(y2) + (DOWN ? IN(yd) : idn))   NHWC
+template <bool DOWN>
+__global__ __launch_bounds__(256) void k_norm_add_relu(const float* __restrict__ y2, const float* __restrict__ m2,
+                                                       const float* __restrict__ r2, const float* __restrict__ idn,
+                                                       const float* __restrict__ md, const float* __restrict__ rd,
+                                                       float* __restrict__ out, long long npix, int HW, int C) {
+    const int c4n = C / 4;
+    const long long total = npix * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const long long p = i / c4n;
+        const int n = (int)(p / HW);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y2 + p * C + c4 * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(m2 + (long long)n * C + c4 * 4);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(r2 + (long long)n * C + c4 * 4);
+        f32x4 id = *reinterpret_cast<const f32x4*>(idn + p * C + c4 * 4);
+        if constexpr (DOWN) {
+            const f32x4 mud = *reinterpret_cast<const f32x4*>(md + (long long)n * C + c4 * 4);
+            const f32x4 rsd = *reinterpret_cast<const f32x4*>(rd + (long long)n * C + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) id[e] = (id[e] - mud[e]) * rsd[e];
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf((v[e] - mu[e]) * rs[e] + id[e], 0.f);
+        *reinterpret_cast<f32x4*>(out + p * C + c4 * 4) = o;
+    }
+}
+
+// last block: feats[n][c] = mean_p relu(IN(y2) + idn)   (adaptive_avg_pool2d(1) + flatten)
+__global__ void k_norm_add_relu_pool(const float* __restrict__ y2, const float* __restrict__ m2,
+                                     const float* __restrict__ r2, const float* __restrict__ idn,
+                                     float* __restrict__ feats, int B, int HW, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int n = i / C, c = i - n * C;
+    const float mu = m2[i], rs = r2[i];
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) {
+        const long long o = ((long long)n * HW + p) * C + c;
+        s += fmaxf((y2[o] - mu) * rs + idn[o], 0.f);
+    }
+    feats[i] = s / (float)HW;
+}
+
+// OIHW -> [tap][O][I]
+__global__ void k_pack_conv(const float* __restrict__ w, float* __restrict__ out, int O, int I, int taps) {
+    const long long total = (long long)O * I * taps;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % I);
+        const long long r = i / I;
+        const int o = (int)(r % O), t = (int)(r / O);
+        out[i] = w[((long long)o * I + ci) * taps + t];
+    }
+}
+
+// ---- host ----------------------------------------------------------------------------------
+struct ConvSpec { int cout, cin, ks, stride, pad; };
+// torchvision state_dict order of the 20 bias-free convolutions
+const ConvSpec kSpecs[20] = {
+    {64, 3, 7, 2, 3},
+    {64, 64, 3, 1, 1}, {64, 64, 3, 1, 1}, {64, 64, 3, 1, 1}, {64, 64, 3, 1, 1},
+    {128, 64, 3, 2, 1}, {128, 128, 3, 1, 1}, {128, 64, 1, 2, 0}, {128, 128, 3, 1, 1}, {128, 128, 3, 1, 1},
+    {256, 128, 3, 2, 1}, {256, 256, 3, 1, 1}, {256, 128, 1, 2, 0}, {256, 256, 3, 1, 1}, {256, 256, 3, 1, 1},
+    {512, 256, 3, 2, 1}, {512, 512, 3, 1, 1}, {512, 256, 1, 2, 0}, {512, 512, 3, 1, 1}, {512, 512, 3, 1, 1},
+};
+
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline long long wsize(int i) { return (long long)kSpecs[i].cout * kSpecs[i].cin * kSpecs[i].ks * kSpecs[i].ks; }
+inline size_t pack_offset(int i) {  // floats; conv 0 (stem) is used unpacked
+    size_t o = 0;
+    for (int j = 1; j < i; ++j) o += (size_t)wsize(j);
+    return o;
+}
+inline int outdim(int x, int ks, int s, int p) { return (x + 2 * p - ks) / s + 1; }
+
+struct Dims { int H1, W1, Hp, Wp, h[5], w[5]; };
+Dims dims_for(int H, int W) {
+    Dims d;
+    d.H1 = outdim(H, 7, 2, 3); d.W1 = outdim(W, 7, 2, 3);
+    d.Hp = outdim(d.H1, 3, 2, 1); d.Wp = outdim(d.W1, 3, 2, 1);
+    d.h[1] = d.Hp; d.w[1] = d.Wp;
+    for (int l = 2; l <= 4; ++l) { d.h[l] = outdim(d.h[l - 1], 3, 2, 1); d.w[l] = outdim(d.w[l - 1], 3, 2, 1); }
+    return d;
+}
+
+struct RWs {
+    size_t y0, buf[5], stat[4][2], part, total;  // stat[k] = {mean, rstd}
+    long long act_elems, part_elems;
+};
+RWs rws_layout(int B, int H, int W) {
+    const Dims d = dims_for(H, W);
+    RWs r;
+    size_t o = 0;
+    const long long y0e = (long long)B * d.H1 * d.W1 * 64;
+    r.act_elems = (long long)B * d.Hp * d.Wp * 64;  // largest post-pool activation
+    r.y0 = o; o = al256(o + (size_t)y0e * 4);
+    for (int i = 0; i < 5; ++i) { r.buf[i] = o; o = al256(o + (size_t)r.act_elems * 4); }
+    for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 2; ++j) { r.stat[k][j] = o; o = al256(o + (size_t)B * 512 * 4); }
+    // partials: stem (n, tiles*4, 64, 3) or flat (tiles32, nslots, C, 2); take the max over layers
+    const long long stem_parts = (long long)B * ((d.H1 + 7) / 8) * ((d.W1 + 15) / 16) * 4 * 64 * 3;
+    long long mx = stem_parts;
+    for (int l = 1; l <= 4; ++l) {
+        const int HW = d.h[l] * d.w[l];
+        const int C = 64 << (l - 1);
+        const long long M = (long long)B * HW;
+        const int nslots = 31 / HW + 2;
+        const long long e = ((M + 31) / 32) * nslots * C * 2;
+        if (e > mx) mx = e;
+    }
+    r.part_elems = mx;
+    r.part = o; o = al256(o + (size_t)mx * 4);
+    r.total = o;
+    return r;
+}
+
+int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_mean, const float* in_rstd,
+             float* y, float* part, float* mean, float* rstd, int B, int H, int W, const ConvSpec& s) {
+    ConvArgs a;
+    a.x = x; a.w = wpk; a.in_mean = in_mean; a.in_rstd = in_rstd; a.y = y; a.part = part;
+    a.B = B; a.H = H; a.W = W; a.Cin = s.cin;
+    a.Ho = outdim(H, s.ks, s.stride, s.pad); a.Wo = outdim(W, s.ks, s.stride, s.pad);
+    a.Cout = s.cout; a.ks = s.ks; a.stride = s.stride; a.pad = s.pad;
+    const int HW = a.Ho * a.Wo;
+    a.nslots = 31 / HW + 2;
+    a.Mtot = (long long)B * HW;
+    const unsigned gx = (unsigned)((a.Mtot + 127) / 128);
+    const bool norm = in_mean != nullptr;
+    const int slot = dsmil_prof::begin(dsmil_prof::CH_CONV, st);
+    if (s.cout == 64) {
+        const size_t lds = (size_t)(2 * 128 * LDK + 2 * 64 * LDK) * 4;
+        dim3 grid(gx, 1);
+        if (norm) hipLaunchKernelGGL((k_conv<2, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((k_conv<2, false>), grid, dim3(256), lds, st, a);
+    } else {
+        const size_t lds = (size_t)(2 * 128 * LDK + 2 * 128 * LDK) * 4;
+        dim3 grid(gx, (unsigned)(s.cout / 128));
+        if (norm) hipLaunchKernelGGL((k_conv<4, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((k_conv<4, false>), grid, dim3(256), lds, st, a);
+    }
+    dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
+    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    const int n = B * s.cout;
+    hipLaunchKernelGGL(k_in_finalize_flat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, mean, rstd,
+                       B, HW, s.cout, a.nslots, a.Mtot);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
+bool g_attr_done = false;
+void set_conv_attrs() {
+    if (g_attr_done) return;
+    const int l4 = (2 * 128 * LDK + 2 * 128 * LDK) * 4, l2 = (2 * 128 * LDK + 2 * 64 * LDK) * 4;
+    (void)hipFuncSetAttribute((const void*)k_conv<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
+    (void)hipFuncSetAttribute((const void*)k_conv<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
+    (void)hipFuncSetAttribute((const void*)k_conv<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
+    (void)hipFuncSetAttribute((const void*)k_conv<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
+    g_attr_done = true;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dsmil_resnet18_packed_bytes(void) { return pack_offset(20) * sizeof(float); }
+
+int dsmil_resnet18_pack(const float* const* conv_w, float* packed, void* stream) {
+    if (!conv_w || !packed) return DSMIL_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 1; i < 20; ++i) {
+        if (!conv_w[i]) return DSMIL_E_INVALID;
+        const ConvSpec& s = kSpecs[i];
+        const long long total = wsize(i);
+        long long blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
+                           packed + pack_offset(i), s.cout, s.cin, s.ks * s.ks);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    }
+    return DSMIL_OK;
+}
+
+size_t dsmil_resnet18_workspace_bytes(int32_t B, int32_t H, int32_t W) {
+    if (B <= 0 || H < 32 || W < 32) return 0;
+    return rws_layout(B, H, W).total;
+}
+
+int dsmil_resnet18in_forward(const float* x_nchw, int32_t B, int32_t H, int32_t W, const float* conv1_w,
+                             const float* packed, const float* fc_w, const float* fc_b, int32_t C,
+                             float* feats, float* classes, void* ws, size_t ws_bytes, void* stream) {
+    if (!x_nchw || !conv1_w || !packed || !feats || !ws) return DSMIL_E_INVALID;
+    if (B <= 0 || H < 32 || W < 32) return DSMIL_E_INVALID;
+    if (classes && (!fc_w || !fc_b || C <= 0)) return DSMIL_E_INVALID;
+    if (((uintptr_t)ws % 256) || ((uintptr_t)packed % 16)) return DSMIL_E_ALIGN;
+    const RWs L = rws_layout(B, H, W);
+    if (ws_bytes < L.total) return DSMIL_E_WORKSPACE;
+    const Dims d = dims_for(H, W);
+    if (d.h[4] < 1 || d.w[4] < 1) return DSMIL_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    set_conv_attrs();
+    char* w8 = (char*)ws;
+    float* y0 = (float*)(w8 + L.y0);
+    float* buf[5];
+    for (int i = 0; i < 5; ++i) buf[i] = (float*)(w8 + L.buf[i]);
+    float* mean[4];
+    float* rstd[4];
+    for (int k = 0; k < 4; ++k) { mean[k] = (float*)(w8 + L.stat[k][0]); rstd[k] = (float*)(w8 + L.stat[k][1]); }
+    float* part = (float*)(w8 + L.part);
+
+    // ---- stem: conv1 -> IN -> ReLU -> maxpool
+    {
+        const int tx = (d.W1 + 15) / 16, ty = (d.H1 + 7) / 8;
+        hipLaunchKernelGGL(k_stem, dim3((unsigned)(tx * ty), (unsigned)B), dim3(256), 0, st, x_nchw, conv1_w, y0,
+                           part, B, H, W, d.H1, d.W1, tx, ty);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+        hipLaunchKernelGGL(k_in_finalize_stem, dim3((unsigned)((B * 64 + 255) / 256)), dim3(256), 0, st, part,
+                           mean[0], rstd[0], B, tx * ty * 4);
+        const long long total = (long long)B * d.Hp * d.Wp * 16;
+        long long blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(k_norm_relu_maxpool, dim3((unsigned)blocks), dim3(256), 0, st, y0, mean[0], rstd[0],
+                           buf[0], B, d.H1, d.W1, d.Hp, d.Wp, 64);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    }
+    // ---- layers 1..4, two BasicBlocks each.  cur = block input (materialised, normalised)
+    float* cur = buf[0];
+    float* y1 = buf[1];
+    float* y2 = buf[2];
+    float* yd = buf[3];
+    float* nxt = buf[4];
+    int ci = 1;  // index into kSpecs / packed weights
+    int Hc = d.Hp, Wc = d.Wp;
+    for (int l = 1; l <= 4; ++l) {
+        for (int b = 0; b < 2; ++b) {
+            const bool down = (l > 1 && b == 0);
+            const ConvSpec& sa = kSpecs[ci];
+            const ConvSpec& sb = kSpecs[ci + 1];
+            const int Ho = outdim(Hc, sa.ks, sa.stride, sa.pad), Wo = outdim(Wc, sa.ks, sa.stride, sa.pad);
+            int rc = run_conv(st, cur, packed + pack_offset(ci), nullptr, nullptr, y1, part, mean[1], rstd[1], B, Hc, Wc, sa);
+            if (rc) return rc;
+            rc = run_conv(st, y1, packed + pack_offset(ci + 1), mean[1], rstd[1], y2, part, mean[2], rstd[2], B, Ho, Wo, sb);
+            if (rc) return rc;
+            if (down) {
+                rc = run_conv(st, cur, packed + pack_offset(ci + 2), nullptr, nullptr, yd, part, mean[3], rstd[3], B, Hc, Wc, kSpecs[ci + 2]);
+                if (rc) return rc;
+            }
+            const long long npix = (long long)B * Ho * Wo;
+            const int Cc = sa.cout;
+            if (l == 4 && b == 1) {
+                hipLaunchKernelGGL(k_norm_add_relu_pool, dim3((unsigned)((B * Cc + 255) / 256)), dim3(256), 0, st, y2,
+                                   mean[2], rstd[2], cur, feats, B, Ho * Wo, Cc);
+            } else {
+                long long blocks = (npix * (Cc / 4) + 255) / 256;
+                if (blocks > 8192) blocks = 8192;
+                if (down) hipLaunchKernelGGL(k_norm_add_relu<true>, dim3((unsigned)blocks), dim3(256), 0, st, y2, mean[2], rstd[2], yd, mean[3], rstd[3], nxt, npix, Ho * Wo, Cc);
+                else hipLaunchKernelGGL(k_norm_add_relu<false>, dim3((unsigned)blocks), dim3(256), 0, st, y2, mean[2], rstd[2], cur, nullptr, nullptr, nxt, npix, Ho * Wo, Cc);
+            }
+            if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+            float* t = cur; cur = nxt; nxt = t;
+            ci += down ? 3 : 2;
+            Hc = Ho; Wc = Wo;
+        }
+    }
+    if (classes) return dsmil_fc_forward(feats, B, 512, C, fc_w, fc_b, classes, stream);
+    return DSMIL_OK;
+}
+
+}  // extern "C"

@@ -43,10 +43,14 @@ class IClassifier(nn.Module):
 
     def forward(self, x):
         fe = self.feature_extractor
-        fused = getattr(fe, "forward_with_head", None)
-        if fused is not None and x.is_cuda:
-            # our HIP ResNet produces features and the instance logits in one launch sequence
-            return fused(x, self.fc.weight, self.fc.bias)
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not (
+                torch.is_grad_enabled() and any(p.requires_grad for p in fe.parameters())):
+            # ResNet-18 + InstanceNorm with fc = Identity (ours or torchvision's, compute_feats.py:157,170):
+            # features and instance logits come from one native launch sequence
+            from .resnet import resnet18_in_convs
+            convs = resnet18_in_convs(fe)
+            if convs is not None and isinstance(getattr(fe, "fc", None), nn.Identity):
+                return ops.resnet18in_forward(x, convs, self.fc.weight, self.fc.bias)
         feats = fe(x)
         feats = feats.view(feats.shape[0], -1)
         if feats.is_cuda:

@@ -123,3 +123,66 @@ def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, o
     _native.check(rc, "dsmil_agg_forward")
     del keep
     return classes, pred, A, B, idx
+
+
+# ---------------------------------------------------------------------------------------------
+# patch embedder (ResNet-18 + InstanceNorm) — compute_feats.py:146-170,211 / dsmil.py:21-25
+# ---------------------------------------------------------------------------------------------
+_pack_cache = {}
+
+
+def _packed_resnet_weights(convs):
+    """Device buffer with the 19 non-stem conv weights re-laid-out as [tap][Cout][Cin]
+    (dsmil_resnet18_pack).  Cached per weight set; rebuilt when any tensor was modified in place
+    (``_version``), re-assigned or moved (``data_ptr``)."""
+    key = tuple((w.data_ptr(), w._version) for w in convs)
+    dev = convs[0].device
+    ent = _pack_cache.get(str(dev))
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    L = _native.lib()
+    buf = torch.empty(L.dsmil_resnet18_packed_bytes() // 4, dtype=torch.float32, device=dev)
+    keep = [_f32c(w.detach(), "conv weight") for w in convs]
+    arr = (ctypes.c_void_p * 20)(*[t.data_ptr() for t in keep])
+    with torch.cuda.device(dev):
+        rc = L.dsmil_resnet18_pack(arr, _ptr(buf), _stream(dev))
+    _native.check(rc, "dsmil_resnet18_pack")
+    _pack_cache[str(dev)] = (key, buf)
+    return buf
+
+
+RESNET18_SHAPES = [(64, 3, 7, 7)] + [(64, 64, 3, 3)] * 4 + \
+    [(128, 64, 3, 3), (128, 128, 3, 3), (128, 64, 1, 1), (128, 128, 3, 3), (128, 128, 3, 3)] + \
+    [(256, 128, 3, 3), (256, 256, 3, 3), (256, 128, 1, 1), (256, 256, 3, 3), (256, 256, 3, 3)] + \
+    [(512, 256, 3, 3), (512, 512, 3, 3), (512, 256, 1, 1), (512, 512, 3, 3), (512, 512, 3, 3)]
+
+
+def resnet18in_forward(x, convs, fc_w=None, fc_b=None):
+    """x [B,3,H,W] fp32 CUDA in [0,1]; convs: the 20 conv weights in torchvision state_dict order.
+    Returns (feats [B,512], classes [B,C] or None)."""
+    x = _f32c(x, "x")
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError(f"expected [B,3,H,W] patches, got {tuple(x.shape)}")
+    if len(convs) != 20 or any(tuple(w.shape) != s for w, s in zip(convs, RESNET18_SHAPES)):
+        raise ValueError("conv weights do not have the ResNet-18 shapes / order")
+    B, _, H, W = x.shape
+    dev = x.device
+    feats = torch.empty((B, 512), dtype=torch.float32, device=dev)
+    if B == 0:
+        return feats, (torch.empty((0, fc_w.shape[0]), device=dev) if fc_w is not None else None)
+    fc_w = _f32c(fc_w.detach(), "fc_w") if fc_w is not None else None
+    fc_b = _f32c(fc_b.detach(), "fc_b") if fc_b is not None else None
+    C = fc_w.shape[0] if fc_w is not None else 0
+    classes = torch.empty((B, C), dtype=torch.float32, device=dev) if fc_w is not None else None
+    packed = _packed_resnet_weights(convs)
+    conv1 = _f32c(convs[0].detach(), "conv1.weight")
+    L = _native.lib()
+    nbytes = L.dsmil_resnet18_workspace_bytes(B, H, W)
+    if nbytes == 0:
+        raise ValueError(f"unsupported patch size {H}x{W}")
+    ws = _workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        rc = L.dsmil_resnet18in_forward(_ptr(x), B, H, W, _ptr(conv1), _ptr(packed), _ptr(fc_w), _ptr(fc_b),
+                                        C, _ptr(feats), _ptr(classes), _ptr(ws), ws.numel(), _stream(dev))
+    _native.check(rc, "dsmil_resnet18in_forward")
+    return feats, classes

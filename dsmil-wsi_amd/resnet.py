@@ -1,0 +1,144 @@
+"""ResNet-18/34 constructors with torchvision's attribute names and state_dict order.
+
+The reference builds its embedder with ``torchvision.models.resnet18(norm_layer=nn.InstanceNorm2d)``
+and replaces ``fc`` by ``nn.Identity()`` (compute_feats.py:146-170); its checkpoint loaders zip
+tensors onto the model BY POSITION (compute_feats.py:226-231), so the registration order
+conv1, bn1, layer1..4 (block: conv1, bn1, conv2, bn2, downsample.0, downsample.1), fc is part
+of the contract.  torchvision is not installed in this image, so the entry points import this
+module instead; with InstanceNorm and a CUDA(HIP) input the forward runs in libdsmil_hip.so
+(dsmil_resnet18in_forward), otherwise (CPU tensors, BatchNorm, ResNet-34, autograd) it runs the
+plain torch ops of the same graph.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        idn = x if self.downsample is None else self.downsample(x)
+        return self.relu(out + idn)
+
+
+class ResNet(nn.Module):
+    def __init__(self, layers, num_classes=1000, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self._norm_layer = norm_layer
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = norm_layer(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, layers[0], 1)
+        self.layer2 = self._make_layer(128, layers[1], 2)
+        self.layer3 = self._make_layer(256, layers[2], 2)
+        self.layer4 = self._make_layer(512, layers[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride, bias=False),
+                                 self._norm_layer(planes))
+        seq = [BasicBlock(self.inplanes, planes, stride, down, self._norm_layer)]
+        self.inplanes = planes
+        seq += [BasicBlock(planes, planes, norm_layer=self._norm_layer) for _ in range(1, blocks)]
+        return nn.Sequential(*seq)
+
+    # ---- torch-op graph (CPU tensors, BatchNorm, training) --------------------------------
+    def _features_torch(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return torch.flatten(self.avgpool(x), 1)
+
+    # ---- native path ----------------------------------------------------------------------
+    def _native_ok(self, x):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3):
+            return False
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False  # embedder training (SimCLR) is outside the hot path
+        return resnet18_in_convs(self) is not None
+
+    def forward_with_head(self, x, fc_w, fc_b):
+        """(feats, Linear(feats)) in one native call sequence — what IClassifier.forward needs."""
+        if self._native_ok(x) and isinstance(self.fc, nn.Identity):
+            return ops.resnet18in_forward(x, resnet18_in_convs(self), fc_w, fc_b)
+        feats = self.forward(x)
+        feats = feats.view(feats.shape[0], -1)
+        return feats, torch.nn.functional.linear(feats, fc_w, fc_b)
+
+    def forward(self, x):
+        if self._native_ok(x):
+            feats, _ = ops.resnet18in_forward(x, resnet18_in_convs(self))
+        else:
+            feats = self._features_torch(x)
+        return self.fc(feats)
+
+
+def _is_plain_instance_norm(m):
+    return isinstance(m, nn.InstanceNorm2d) and not m.affine and not m.track_running_stats and abs(m.eps - 1e-5) < 1e-12
+
+
+def resnet18_in_convs(model):
+    """If ``model`` is structurally a ResNet-18 with plain InstanceNorm2d everywhere (ours or
+    torchvision's), return its 20 conv weights in state_dict order; else None."""
+    try:
+        convs = [model.conv1.weight]
+        norms = [model.bn1]
+        for li in (1, 2, 3, 4):
+            layer = getattr(model, f"layer{li}")
+            if len(layer) != 2:
+                return None
+            for blk in layer:
+                if not hasattr(blk, "conv2") or hasattr(blk, "conv3"):
+                    return None
+                convs += [blk.conv1.weight, blk.conv2.weight]
+                norms += [blk.bn1, blk.bn2]
+                if blk.downsample is not None:
+                    convs.append(blk.downsample[0].weight)
+                    norms.append(blk.downsample[1])
+    except AttributeError:
+        return None
+    if len(convs) != 20 or not all(_is_plain_instance_norm(n) for n in norms):
+        return None
+    if any(tuple(w.shape) != s for w, s in zip(convs, ops.RESNET18_SHAPES)):
+        return None
+    return convs
+
+
+def resnet18(pretrained=False, weights=None, norm_layer=None, **kwargs):
+    """torchvision.models.resnet18 signature subset used by the reference
+    (compute_feats.py:157 ``pretrained=``, testing_c16.py:113 ``weights=None``)."""
+    if pretrained or weights is not None:
+        raise ValueError("pretrained ImageNet weights need torchvision and a download; not available offline")
+    return ResNet([2, 2, 2, 2], norm_layer=norm_layer, **kwargs)
+
+
+def resnet34(pretrained=False, weights=None, norm_layer=None, **kwargs):
+    if pretrained or weights is not None:
+        raise ValueError("pretrained ImageNet weights need torchvision and a download; not available offline")
+    return ResNet([3, 4, 6, 3], norm_layer=norm_layer, **kwargs)

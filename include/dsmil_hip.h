@@ -89,17 +89,39 @@ size_t dsmil_agg_workspace_bytes(int32_t n_bags, int64_t total_rows, int32_t K, 
 int dsmil_fc_forward(const float* feats, int64_t total_rows, int32_t K, int32_t C,
                      const float* fc_w, const float* fc_b, float* classes, void* stream);
 
+/* ---- patch embedder: ResNet-18 with InstanceNorm2d, fc = Identity --------------------------
+ * Replaces the torchvision backbone that compute_feats.py:157,170 builds and dsmil.IClassifier
+ * wraps (dsmil.py:21-25): feats[B,512] = flatten(avgpool(resnet18_IN(x))), and, when `classes`
+ * is non-NULL, classes[B,C] = feats @ fc_w^T + fc_b (IClassifier.fc, dsmil.py:24).
+ *   x_nchw   device [B,3,H,W] fp32 in [0,1] (what VF.to_tensor yields, compute_feats.py:35-39)
+ *   conv1_w  device [64,3,7,7] fp32 — feature_extractor.conv1.weight, used as is
+ *   packed   device buffer of dsmil_resnet18_packed_bytes() bytes filled by dsmil_resnet18_pack()
+ *            from the other 19 conv weights
+ *   ws       scratch of dsmil_resnet18_workspace_bytes(B,H,W) bytes, 256-B aligned
+ * conv_w[20]: device pointers to the 20 bias-free conv weights [Cout,Cin,k,k] fp32 in torchvision
+ * state_dict order (conv1; layerL.0.conv1, layerL.0.conv2, [layerL.0.downsample.0], layerL.1.conv1,
+ * layerL.1.conv2 for L = 1..4) — the order compute_feats.py:226-231 relies on.  conv_w[0] is not
+ * read by the packer. */
+size_t dsmil_resnet18_packed_bytes(void);
+int dsmil_resnet18_pack(const float* const* conv_w, float* packed, void* stream);
+size_t dsmil_resnet18_workspace_bytes(int32_t B, int32_t H, int32_t W);
+int dsmil_resnet18in_forward(const float* x_nchw, int32_t B, int32_t H, int32_t W,
+                             const float* conv1_w, const float* packed, const float* fc_w,
+                             const float* fc_b, int32_t C, float* feats, float* classes, void* ws,
+                             size_t ws_bytes, void* stream);
+
 const char* dsmil_strerror(int code);
 int dsmil_abi_version(void);
 /* Rows per workgroup the launcher picks for the dominant kernel (k_query_attend). */
 int dsmil_agg_tile_rows(int32_t n_bags, int64_t total_rows);
 
 /* Measurement hooks (bench.py's roofline leg; no reference counterpart).  While enabled, every
- * launch of the dominant kernel is bracketed by hipEventRecord on its own launch stream (up to
- * 512 launches); dsmil_profile_collect() synchronises on them, returns the summed kernel time
- * and the launch count, and resets the ring.  Not for use under graph capture. */
+ * launch of a dominant kernel is bracketed by hipEventRecord on its own launch stream (up to 4096
+ * launches per channel: 0 = k_query_attend of the aggregator, 1 = k_conv of the embedder);
+ * dsmil_profile_collect() synchronises on them, returns the summed kernel time and the launch
+ * count of one channel, and resets it.  Not for use under graph capture. */
 int dsmil_profile_enable(int on);
-int dsmil_profile_collect(double* total_ms, int64_t* launches);
+int dsmil_profile_collect(int channel, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

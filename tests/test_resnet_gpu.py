@@ -1,0 +1,88 @@
+"""Parity of the HIP patch embedder (ResNet-18 + InstanceNorm, through the C-ABI) with the CPU
+oracle restatement (oracle/resnet_oracle.py; PARITY UNPINNED by the reference, see its header).
+Tolerance: 1e-4 abs on the 512-d features (= the quantum of the reference's '%.4f' CSV,
+compute_feats.py:82) and on the instance logits."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import dsmil
+import resnet_oracle as ro
+from dsmil_wsi_amd.resnet import resnet18
+from inputs import make_patches
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(seed, C=2):
+    res = resnet18(pretrained=False, norm_layer=nn.InstanceNorm2d)
+    for p in res.parameters():
+        p.requires_grad = False                                # compute_feats.py:168-169
+    res.fc = nn.Identity()
+    w = ro.make_weights(seed=seed)
+    res.load_state_dict(w, strict=True)
+    ic = dsmil.IClassifier(res, 512, output_class=C)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        ic.fc.weight.copy_(torch.randn(ic.fc.weight.shape, generator=g) * 0.1)
+        ic.fc.bias.copy_(torch.randn(ic.fc.bias.shape, generator=g) * 0.1)
+    return ic.eval(), w
+
+
+def _ref(x, w, ic, dtype=torch.float64):
+    w64 = {k: v.to(dtype) for k, v in w.items()}
+    f, c = ro.iclassifier_forward(x.cpu().to(dtype), w64, ic.fc.weight.detach().cpu().to(dtype),
+                                  ic.fc.bias.detach().cpu().to(dtype))
+    return f.numpy(), c.numpy()
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 224, 224), (3, 224, 224), (5, 224, 224), (2, 256, 256), (4, 96, 96), (2, 160, 224)])
+def test_embedder_vs_oracle(B, H, W):
+    ic, w = _build(seed=11)
+    x = torch.from_numpy(make_patches(7 + B, B, H, W))
+    ref_f, ref_c = _ref(x, w, ic)
+    icg = ic.cuda()
+    with torch.no_grad():
+        feats, c = icg(x.cuda())
+    assert feats.shape == (B, 512) and c.shape == (B, 2)
+    np.testing.assert_allclose(feats.cpu().numpy(), ref_f, atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(c.cpu().numpy(), ref_c, atol=1e-4, rtol=1e-4)
+
+
+def test_images_are_independent_of_batch_composition():
+    """InstanceNorm uses per-image statistics: sharding a slide's patches over ranks must not
+    change any row.  Tiles of 128 flattened pixels straddle images in layers 2-4."""
+    ic, w = _build(seed=12)
+    x = torch.from_numpy(make_patches(99, 6, 224, 224)).cuda()
+    icg = ic.cuda()
+    with torch.no_grad():
+        full, _ = icg(x)
+        a, _ = icg(x[:2])
+        b, _ = icg(x[2:])
+    np.testing.assert_allclose(torch.cat([a, b]).cpu().numpy(), full.cpu().numpy(), atol=2e-6, rtol=1e-5)
+
+
+def test_constant_image_does_not_produce_nan():
+    """A flat (background) tile has zero variance in conv1's border-free region; eps keeps IN finite."""
+    ic, w = _build(seed=13)
+    x = torch.full((2, 3, 224, 224), 0.8)
+    ref_f, _ = _ref(x, w, ic)
+    with torch.no_grad():
+        feats, _ = ic.cuda()(x.cuda())
+    assert torch.isfinite(feats).all()
+    np.testing.assert_allclose(feats.cpu().numpy(), ref_f, atol=2e-3, rtol=2e-3)
+
+
+def test_weight_update_invalidates_packed_cache():
+    ic, w = _build(seed=14)
+    icg = ic.cuda()
+    x = torch.from_numpy(make_patches(5, 2, 224, 224)).cuda()
+    with torch.no_grad():
+        f1, _ = icg(x)
+        w2 = ro.make_weights(seed=15)
+        icg.feature_extractor.load_state_dict({k: v.cuda() for k, v in w2.items()}, strict=True)
+        f2, _ = icg(x)
+    ref2, _ = _ref(x.cpu(), w2, ic)
+    assert not np.allclose(f1.cpu().numpy(), f2.cpu().numpy(), atol=1e-3)
+    np.testing.assert_allclose(f2.cpu().numpy(), ref2, atol=1e-4, rtol=1e-4)

@@ -1,0 +1,65 @@
+"""Host-side checks of the embedder boundary (CPU): our ResNet constructor has torchvision's
+state_dict names/order (the positional-zip loader of compute_feats.py:226-231 depends on it), and
+its torch-op graph equals the oracle restatement."""
+import collections
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import dsmil
+import resnet_oracle as ro
+from dsmil_wsi_amd.resnet import resnet18, resnet18_in_convs
+from inputs import make_patches
+
+
+def test_state_dict_is_the_20_conv_tensors_in_torchvision_order():
+    net = resnet18(pretrained=False, norm_layer=nn.InstanceNorm2d)
+    net.fc = nn.Identity()                                     # compute_feats.py:170
+    keys = list(net.state_dict().keys())
+    assert keys == [n + ".weight" for n, *_ in ro.CONV_TABLE]
+    for (name, cout, cin, k, _s, _p), (kk, v) in zip(ro.CONV_TABLE, net.state_dict().items()):
+        assert tuple(v.shape) == (cout, cin, k, k), kk
+    assert sum(v.numel() for v in net.state_dict().values()) == 11166912
+
+
+def test_positional_zip_load_like_compute_feats():
+    """compute_feats.py:219-233: pop 4 projection-head tensors of the SimCLR checkpoint, zip the
+    rest BY POSITION onto IClassifier's keys, load with strict=False."""
+    res = resnet18(norm_layer=nn.InstanceNorm2d)
+    res.fc = nn.Identity()
+    ic = dsmil.IClassifier(res, 512, output_class=2)
+    w = ro.make_weights(seed=3)
+    simclr = collections.OrderedDict(("features." + str(i), v) for i, v in enumerate(w.values()))
+    for n in ("l1.weight", "l1.bias", "l2.weight", "l2.bias"):           # resnet_simclr.py:19-20
+        simclr[n] = torch.zeros(1)
+    for _ in range(4):
+        simclr.popitem()
+    new_sd = collections.OrderedDict()
+    for (k, v), (k0, _v0) in zip(simclr.items(), ic.state_dict().items()):
+        new_sd[k0] = v
+    missing = ic.load_state_dict(new_sd, strict=False)
+    assert set(missing.missing_keys) == {"fc.weight", "fc.bias"}
+    for (name, *_), got in zip(ro.CONV_TABLE, resnet18_in_convs(res)):
+        assert torch.equal(got, w[name + ".weight"])
+
+
+def test_module_graph_equals_oracle_on_cpu():
+    res = resnet18(norm_layer=nn.InstanceNorm2d)
+    res.fc = nn.Identity()
+    w = ro.make_weights(seed=5)
+    res.load_state_dict(w, strict=True)
+    ic = dsmil.IClassifier(res, 512, output_class=2).eval()
+    x = torch.from_numpy(make_patches(1, 2, 64, 64))
+    with torch.no_grad():
+        feats, c = ic(x)
+        ref_f, ref_c = ro.iclassifier_forward(x, w, ic.fc.weight, ic.fc.bias)
+    np.testing.assert_allclose(feats.numpy(), ref_f.numpy(), atol=1e-5)
+    np.testing.assert_allclose(c.numpy(), ref_c.numpy(), atol=1e-5)
+    assert feats.shape == (2, 512) and c.shape == (2, 2)
+
+
+def test_structural_detection_rejects_other_norms():
+    assert resnet18_in_convs(resnet18(norm_layer=nn.BatchNorm2d)) is None
+    assert resnet18_in_convs(resnet18(norm_layer=nn.InstanceNorm2d)) is not None
+    assert resnet18_in_convs(nn.Linear(3, 3)) is None
