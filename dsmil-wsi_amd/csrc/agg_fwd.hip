@@ -66,6 +66,19 @@ __device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int k, int k
     return v;
 }
 
+// Staging variant: never branches for VEC=4 — the address is clamped into the row (klim % 4 == 0,
+// klim >= 4) and the caller zeroes out-of-range k later (at LDS-write time), so a run of these
+// loads issues back to back and stays in flight under the MFMAs.
+template <int VEC>
+__device__ __forceinline__ f32x4 load4_clamped(const float* __restrict__ p, int k, int klim) {
+    if constexpr (VEC == 4) {
+        const int kc = k < klim ? k : klim - 4;
+        return *reinterpret_cast<const f32x4*>(p + kc);
+    } else {
+        return load4<1>(p, k, klim);
+    }
+}
+
 // better (value, index): larger value wins, lowest index wins on exact ties
 __device__ __forceinline__ bool better(float v, long long i, float bv, long long bi) {
     return (v > bv) || (v == bv && i < bi);
@@ -301,38 +314,50 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
     const int nk = nk1 + (a.nonlinear ? QD / BK : 0);
 
     f32x4 wreg[WPT], xreg[XPT];
+    bool kok = true;  // this thread's k-slice of the staged chunk lies inside the weight row
+    // stage_load only ISSUES global loads (clamped addresses, no branches) so they stay in flight
+    // under the MFMAs of the current chunk; stage_write zeroes the weight k-tail (K % 32 != 0)
+    // and moves the registers to LDS.  Feature values beyond K are multiplied by those zeros.
     auto stage_load = [&](int ci) {
         const float* wb;
         int ld, k0, klim;
         if (ci < nk1) { wb = a.q0_w; ld = K; k0 = ci * BK; klim = K; }
         else { wb = a.q2_w; ld = QD; k0 = (ci - nk1) * BK; klim = QD; }
+        const int k = k0 + (tid & 7) * 4;
+        kok = k < klim;
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            const int f = tid + T * i, r = f >> 3, c4 = f & 7;
-            wreg[i] = load4<VEC>(wb + (long long)r * ld, k0 + c4 * 4, klim);
+            const int r = (tid + T * i) >> 3;
+            wreg[i] = load4_clamped<VEC>(wb + (long long)r * ld, k, klim);
         }
         if (ci < nk1) {
 #pragma unroll
             for (int i = 0; i < XPT; ++i) {
-                const int f = tid + T * i, r = f >> 3, c4 = f & 7;
+                const int r = (tid + T * i) >> 3;
                 long long gr = row0 + r;
                 if (gr >= Nb) gr = Nb - 1;  // clamp: rows past the bag end are masked later
-                xreg[i] = load4<VEC>(a.feats + (off0 + gr) * (long long)K, k0 + c4 * 4, klim);
+                xreg[i] = load4_clamped<VEC>(a.feats + (off0 + gr) * (long long)K, k, klim);
             }
         }
     };
     auto stage_write = [&](int ci) {
         float* w = sW + (ci & 1) * W_TILE;
+        const int c4 = tid & 7;
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            const int f = tid + T * i, r = f >> 3, c4 = f & 7;
-            *reinterpret_cast<f32x4*>(w + r * LDK + c4 * 4) = wreg[i];
+            const int r = (tid + T * i) >> 3;
+            f32x4 v = wreg[i];
+            if constexpr (VEC == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = kok ? v[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(w + r * LDK + c4 * 4) = v;
         }
         if (ci < nk1) {
             float* x = sX + (ci & 1) * X_TILE;
 #pragma unroll
             for (int i = 0; i < XPT; ++i) {
-                const int f = tid + T * i, r = f >> 3, c4 = f & 7;
+                const int r = (tid + T * i) >> 3;
                 *reinterpret_cast<f32x4*>(x + r * LDK + c4 * 4) = xreg[i];
             }
         }

@@ -117,6 +117,10 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     }
     f32x4 xreg[4], wreg[WPT];
     f32x4 mu[4], rs[4];
+    unsigned okmask = 0;  // bit i: tap of row i is inside the image (else zero padding)
+    // stage_load only ISSUES the global loads (branch-free, clamped addresses) so that they fly
+    // under this step's MFMAs; normalisation, padding select and the LDS write happen in
+    // stage_write, after the MFMAs, where the data is first needed.
     auto stage_load = [&](int st) {
         const int cc = st / taps, tap = st - cc * taps;
         const int kh = tap / a.ks, kw = tap - kh * a.ks;
@@ -130,19 +134,14 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
                 }
             }
         }
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int iy = iy0[i] + kh, ix = ix0[i] + kw;
             const bool ok = (iy >= 0) && (iy < a.H) && (ix >= 0) && (ix < a.W);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                v = *reinterpret_cast<const f32x4*>(a.x + (long long)(nb[i] + iy * a.W + ix) * a.Cin + c0);
-                if constexpr (NORM) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf((v[e] - mu[i][e]) * rs[i][e], 0.f);
-                }
-            }
-            xreg[i] = v;
+            okmask |= ok ? (1u << i) : 0u;
+            const int iyc = min(max(iy, 0), a.H - 1), ixc = min(max(ix, 0), a.W - 1);
+            xreg[i] = *reinterpret_cast<const f32x4*>(a.x + (long long)(nb[i] + iyc * a.W + ixc) * a.Cin + c0);
         }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
@@ -154,8 +153,16 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         float* x = sX + (st & 1) * X_TILE;
         float* w = sW + (st & 1) * W_TILE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<f32x4*>(x + ((tid >> 3) + 32 * i) * LDK + c4 * 4) = xreg[i];
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = xreg[i];
+            const bool ok = (okmask >> i) & 1u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (NORM) v[e] = fmaxf((v[e] - mu[i][e]) * rs[i][e], 0.f);
+                v[e] = ok ? v[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(x + ((tid >> 3) + 32 * i) * LDK + c4 * 4) = v;
+        }
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
             *reinterpret_cast<f32x4*>(w + ((tid >> 3) + 32 * i) * LDK + c4 * 4) = wreg[i];
