@@ -1,0 +1,97 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU plumbing: contiguous patch sharding + ONE
+all-gather of feature rows reproduces the unsharded bag bit for bit; bag round-robin covers every
+bag exactly once."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "oracle")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import torch.nn as nn
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dsmil
+    import resnet_oracle as ro
+    from dsmil_wsi_amd import dist as dd
+    from dsmil_wsi_amd.resnet import resnet18
+    from inputs import make_patches
+    from util import build_net
+    torch.set_num_threads(2)
+    res = resnet18(norm_layer=nn.InstanceNorm2d)
+    res.fc = nn.Identity()
+    res.load_state_dict(ro.make_weights(seed=21), strict=True)
+    ic = dsmil.IClassifier(res, 512, output_class=2).eval()
+    torch.manual_seed(0)
+    with torch.no_grad():
+        ic.fc.weight.normal_(0, 0.1)
+        ic.fc.bias.zero_()
+    x = torch.from_numpy(make_patches(31, n_total, 64, 64))       # the slide's ordered patches
+
+    def embed(lo, hi):
+        with torch.no_grad():
+            return ic(x[lo:hi])[0]
+    feats = dd.embed_rows_sharded(embed, n_total)
+    with torch.no_grad():
+        full = ic(x)[0]
+    same = bool(torch.equal(feats, full))
+    # aggregate the gathered bag on every rank; all ranks must agree
+    net = build_net("tcga")
+    with torch.no_grad():
+        pred = net.b_classifier(feats, net.i_classifier(feats)[1])[0]
+    gathered = [torch.empty_like(pred) for _ in range(world)]
+    dist.all_gather(gathered, pred)
+    agree = all(torch.equal(g, pred) for g in gathered)
+    bags = dd.shard_bags(7, rank, world)
+    q.put((rank, same, agree, tuple(feats.shape), bags, dd.shard_range(n_total, rank, world)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [5, 8])
+def test_sharded_embed_all_gather_equals_unsharded(n_total):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    for rank, same, agree, shape, bags, rng in res:
+        assert same, "gathered feature rows differ from the unsharded embedding"
+        assert agree, "ranks disagree on the aggregated bag"
+        assert shape == (n_total, 512)
+    assert sorted(res[0][4] + res[1][4]) == list(range(7))
+    assert res[0][5][1] == res[1][5][0] and res[0][5][0] == 0 and res[1][5][1] == n_total
+
+
+def test_shard_range_partitions_exactly():
+    import dsmil  # noqa: F401  (registers the dsmil_wsi_amd package)
+    from dsmil_wsi_amd.dist import shard_range
+    for n in (0, 1, 7, 10000, 100003):
+        for w in (1, 2, 3, 8):
+            ranges = [shard_range(n, r, w) for r in range(w)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
