@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's compute_feats.py (same flags, folder conventions and CSV
+outputs: compute_feats.py:128-262), with the embedder running in libdsmil_hip.so.
+
+WSI/<dataset>/{single|pyramid}/<class>/<slide>/*.jpeg  ->  datasets/<dataset>/<class>/<slide>.csv
+plus the per-class index CSVs and the shuffled dataset CSV (compute_feats.py:249-260).
+Launch under torchrun to shard each slide's patches over the GPUs of a node.
+"""
+import argparse
+import copy
+import glob
+import os
+
+import pandas as pd
+import torch
+import torch.nn as nn
+from sklearn.utils import shuffle
+
+import dsmil as mil
+from dsmil_wsi_amd import dist as ddist
+from dsmil_wsi_amd import pipeline
+
+try:  # torchvision is optional: the in-tree constructor has its names and state_dict order
+    import torchvision.models as models
+except Exception:  # pragma: no cover
+    from dsmil_wsi_amd import resnet as models
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Compute TCGA features from SimCLR embedder")
+    p.add_argument("--num_classes", default=2, type=int, help="Number of output classes [2]")
+    p.add_argument("--batch_size", default=128, type=int, help="Batch size of dataloader [128]")
+    p.add_argument("--num_workers", default=4, type=int, help="Number of threads for datalodaer")
+    p.add_argument("--gpu_index", type=int, nargs="+", default=(0,), help="GPU ID(s) [0]")
+    p.add_argument("--backbone", default="resnet18", type=str, help="Embedder backbone [resnet18]")
+    p.add_argument("--norm_layer", default="instance", type=str, help="Normalization layer [instance]")
+    p.add_argument("--magnification", default="single", type=str,
+                   help="single | tree | high | low")
+    p.add_argument("--weights", default=None, type=str, help="Folder of the pretrained weights, simclr/runs/*")
+    p.add_argument("--weights_high", default=None, type=str)
+    p.add_argument("--weights_low", default=None, type=str)
+    p.add_argument("--tree_fusion", default="cat", type=str, help="[cat|fusion]")
+    p.add_argument("--dataset", default="TCGA-lung-single", type=str, help="Dataset folder name")
+    return p
+
+
+def build_backbone(args):
+    norm = nn.InstanceNorm2d if args.norm_layer == "instance" else nn.BatchNorm2d
+    pretrain = args.norm_layer == "batch" and args.weights == "ImageNet"
+    ctor = {"resnet18": (getattr(models, "resnet18", None), 512), "resnet34": (getattr(models, "resnet34", None), 512),
+            "resnet50": (getattr(models, "resnet50", None), 2048), "resnet101": (getattr(models, "resnet101", None), 2048)}
+    fn, num_feats = ctor[args.backbone]
+    if fn is None:
+        raise ValueError(f"backbone {args.backbone} needs torchvision")
+    resnet = fn(pretrained=pretrain, norm_layer=norm)
+    for prm in resnet.parameters():
+        prm.requires_grad = False
+    resnet.fc = nn.Identity()
+    return resnet, num_feats
+
+
+def load_embedder(i_classifier, run, out_name, args, device):
+    if run is not None:
+        path = os.path.join("simclr", "runs", run, "checkpoints", "model.pth")
+    else:
+        path = glob.glob("simclr/runs/*/checkpoints/*.pth")[-1]
+    new_sd = pipeline.load_simclr_weights(i_classifier, torch.load(path, map_location=device))
+    if ddist.world_rank()[1] == 0:
+        os.makedirs(os.path.join("embedder", args.dataset), exist_ok=True)
+        torch.save(new_sd, os.path.join("embedder", args.dataset, out_name))
+    print("Use pretrained features.")
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    world = ddist.init_from_env()
+    if world == 1:
+        os.environ["CUDA_VISIBLE_DEVICES"] = ",".join(str(x) for x in tuple(args.gpu_index))
+    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    resnet, num_feats = build_backbone(args)
+    imagenet = "ImageNet" in (args.weights, args.weights_high, args.weights_low)
+    if imagenet and args.norm_layer != "batch":
+        raise ValueError("Please use batch normalization for ImageNet feature")
+    if args.magnification == "tree" and args.weights_high is not None and args.weights_low is not None:
+        ic_h = mil.IClassifier(resnet, num_feats, output_class=args.num_classes).to(device)
+        ic_l = mil.IClassifier(copy.deepcopy(resnet), num_feats, output_class=args.num_classes).to(device)
+        if imagenet:
+            print("Use ImageNet features.")
+        else:
+            load_embedder(ic_h, args.weights_high, "embedder-high.pth", args, device)
+            load_embedder(ic_l, args.weights_low, "embedder-low.pth", args, device)
+    else:
+        i_classifier = mil.IClassifier(resnet, num_feats, output_class=args.num_classes).to(device)
+        if imagenet:
+            print("Use ImageNet features.")
+        else:
+            load_embedder(i_classifier, args.weights, "embedder.pth", args, device)
+    sub = "pyramid" if args.magnification in ("tree", "low", "high") else "single"
+    bags_list = sorted(glob.glob(os.path.join("WSI", args.dataset, sub, "*", "*")))
+    feats_path = os.path.join("datasets", args.dataset)
+    os.makedirs(feats_path, exist_ok=True)
+    if args.magnification == "tree":
+        pipeline.compute_tree_feats(args, bags_list, ic_l, ic_h, feats_path)
+    else:
+        pipeline.compute_feats(args, bags_list, i_classifier, feats_path, args.magnification)
+    if ddist.world_rank()[1] == 0:  # compute_feats.py:249-260
+        all_df = []
+        for i, item in enumerate(sorted(glob.glob(os.path.join("datasets", args.dataset, "*" + os.path.sep)))):
+            bag_df = pd.DataFrame(glob.glob(os.path.join(item, "*.csv")))
+            bag_df["label"] = i
+            bag_df.to_csv(os.path.join("datasets", args.dataset, item.split(os.path.sep)[2] + ".csv"), index=False)
+            all_df.append(bag_df)
+        bags_path = shuffle(pd.concat(all_df, axis=0, ignore_index=True))
+        bags_path.to_csv(os.path.join("datasets", args.dataset, args.dataset + ".csv"), index=False)
+
+
+if __name__ == "__main__":
+    main()

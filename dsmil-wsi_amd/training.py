@@ -1,0 +1,408 @@
+"""Aggregator training / evaluation drivers with the semantics of the reference's train_tcga.py
+(one bag per optimiser step, loss = 0.5*BCE(bag logits) + 0.5*BCE(max instance logits),
+Adam(betas=(0.5,0.9)) + cosine annealing, ROC-optimal thresholds, three evaluation schemes) and
+train_mil.py (classical MIL benchmarks, 10-fold CV).  The per-bag forward/backward goes through
+dsmil.MILNet, i.e. the HIP aggregator when the bag lives on the GPU.
+
+Differences that do not change results: bags are cached in HBM after their first load instead of
+being re-read from disk every iteration (train_tcga.py:62; 288 GB of HBM holds whole feature
+sets), and ``dropout_patches`` with rate 0 skips the full-bag row permutation
+(train_tcga.py:65,78-83: the aggregator is permutation-invariant).
+"""
+import copy
+import datetime
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+# ---- data plumbing (train_tcga.py:19-51) ---------------------------------------------------
+def get_bag_feats(csv_file_df, args):
+    import pandas as pd
+    from sklearn.utils import shuffle
+    if args.dataset == "TCGA-lung-default":
+        feats_csv_path = "datasets/tcga-dataset/tcga_lung_data_feats/" + csv_file_df.iloc[0].split("/")[1] + ".csv"
+    else:
+        feats_csv_path = csv_file_df.iloc[0]
+    feats = shuffle(pd.read_csv(feats_csv_path)).reset_index(drop=True).to_numpy()
+    label = np.zeros(args.num_classes)
+    if args.num_classes == 1:
+        label[0] = csv_file_df.iloc[1]
+    elif int(csv_file_df.iloc[1]) <= (len(label) - 1):
+        label[int(csv_file_df.iloc[1])] = 1
+    return label, feats, feats_csv_path
+
+
+def generate_pt_files(args, df, temp_train_dir="temp_train"):
+    """CSV -> one [N, feats_size + C] tensor per bag (features || repeated label)."""
+    import shutil
+    if os.path.exists(temp_train_dir):
+        shutil.rmtree(temp_train_dir, ignore_errors=True)
+    os.makedirs(temp_train_dir, exist_ok=True)
+    print("Creating intermediate training files.")
+    for i in range(len(df)):
+        label, feats, path = get_bag_feats(df.iloc[i], args)
+        bag_feats = torch.tensor(np.array(feats), dtype=torch.float32)
+        bag_label = torch.tensor(np.array([label]), dtype=torch.float32).repeat(bag_feats.size(0), 1)
+        torch.save(torch.cat((bag_feats, bag_label), dim=1),
+                   os.path.join(temp_train_dir, os.path.splitext(path)[0].split(os.sep)[-1] + ".pt"))
+
+
+class BagCache:
+    """path -> stacked [N, feats+C] tensor resident on the training device."""
+
+    def __init__(self, device):
+        self.device = device
+        self.store = {}
+
+    def get(self, item):
+        if torch.is_tensor(item):
+            return item.to(self.device)
+        t = self.store.get(item)
+        if t is None:
+            t = torch.load(item, map_location=self.device)
+            self.store[item] = t
+        return t
+
+
+def dropout_patches(feats, p):
+    """train_tcga.py:78-83 — keep int(N*p) randomly chosen rows (p = 1 - dropout rate)."""
+    n = feats.size(0)
+    keep = int(n * p)
+    if keep >= n:
+        return feats
+    idx = torch.randperm(n, device=feats.device)[:keep]
+    return feats.index_select(0, idx)
+
+
+def bag_loss(milnet, criterion, bag_feats, bag_label):
+    """train_tcga.py:67-71."""
+    ins_prediction, bag_prediction, _, _ = milnet(bag_feats)
+    max_prediction, _ = torch.max(ins_prediction, 0)
+    loss = 0.5 * criterion(bag_prediction.view(1, -1), bag_label.view(1, -1)) + \
+        0.5 * criterion(max_prediction.view(1, -1), bag_label.view(1, -1))
+    return loss, bag_prediction, max_prediction
+
+
+def train(args, train_df, milnet, criterion, optimizer, cache=None, log=True):
+    """train_tcga.py:55-76: one optimiser step per bag, bags in random order."""
+    from sklearn.utils import shuffle
+    milnet.train()
+    device = next(milnet.parameters()).device
+    cache = cache or BagCache(device)
+    total_loss = 0.0
+    dirs = shuffle(list(train_df))
+    for i, item in enumerate(dirs):
+        optimizer.zero_grad()
+        stacked = cache.get(item)
+        bag_label = stacked[0, args.feats_size:].unsqueeze(0).float()
+        bag_feats = dropout_patches(stacked[:, :args.feats_size], 1 - args.dropout_patch).reshape(-1, args.feats_size)
+        loss, _, _ = bag_loss(milnet, criterion, bag_feats, bag_label)
+        loss.backward()
+        optimizer.step()
+        total_loss += loss.item()
+        if log:
+            sys.stdout.write("\r Training bag [%d/%d] bag loss: %.4f" % (i, len(dirs), loss.item()))
+    return total_loss / max(1, len(dirs))
+
+
+def optimal_thresh(fpr, tpr, thresholds, p=0):
+    loss = (fpr - tpr) - p * tpr / (fpr + tpr + 1)
+    idx = np.argmin(loss, axis=0)
+    return fpr[idx], tpr[idx], thresholds[idx]
+
+
+def multi_label_roc(labels, predictions, num_classes, pos_label=1, log=True):
+    from sklearn.metrics import roc_auc_score, roc_curve
+    aucs, thresholds, thresholds_optimal = [], [], []
+    if predictions.ndim == 1:
+        predictions = predictions[:, None]
+    if labels.ndim == 1:
+        labels = labels[:, None]
+    for c in range(num_classes):
+        fpr, tpr, threshold = roc_curve(labels[:, c], predictions[:, c], pos_label=1)
+        _, _, th = optimal_thresh(fpr, tpr, threshold)
+        try:
+            c_auc = roc_auc_score(labels[:, c], predictions[:, c])
+        except ValueError as e:
+            if "Only one class present" not in str(e):
+                raise
+            c_auc = 1
+        if log:
+            print("ROC AUC score:", c_auc)
+        aucs.append(c_auc)
+        thresholds.append(threshold)
+        thresholds_optimal.append(th)
+    return aucs, thresholds, thresholds_optimal
+
+
+@torch.no_grad()
+def test(args, test_df, milnet, criterion, thresholds=None, return_predictions=False, cache=None, log=True):
+    """train_tcga.py:85-132."""
+    milnet.eval()
+    device = next(milnet.parameters()).device
+    cache = cache or BagCache(device)
+    total_loss, labels, preds = 0.0, [], []
+    for i, item in enumerate(test_df):
+        stacked = cache.get(item)
+        bag_label = stacked[0, args.feats_size:].unsqueeze(0).float()
+        bag_feats = dropout_patches(stacked[:, :args.feats_size], 1 - args.dropout_patch).reshape(-1, args.feats_size)
+        loss, bag_prediction, max_prediction = bag_loss(milnet, criterion, bag_feats, bag_label)
+        total_loss += loss.item()
+        if log:
+            sys.stdout.write("\r Testing bag [%d/%d] bag loss: %.4f" % (i, len(test_df), loss.item()))
+        labels.append(bag_label.squeeze().cpu().numpy().astype(int))
+        if args.average:
+            preds.append((torch.sigmoid(max_prediction) + torch.sigmoid(bag_prediction)).squeeze().cpu().numpy())
+        else:
+            preds.append(torch.sigmoid(bag_prediction).squeeze().cpu().numpy())
+    test_labels = np.array(labels)
+    test_predictions = np.array(preds)
+    auc_value, _, thresholds_optimal = multi_label_roc(test_labels, test_predictions, args.num_classes, log=log)
+    if thresholds:
+        thresholds_optimal = thresholds
+    if args.num_classes == 1:
+        test_predictions = (test_predictions >= thresholds_optimal[0]).astype(test_predictions.dtype)
+        test_labels = np.squeeze(test_labels)
+    else:
+        for c in range(args.num_classes):
+            test_predictions[:, c] = (test_predictions[:, c] >= thresholds_optimal[c]).astype(test_predictions.dtype)
+    bag_score = sum(np.array_equal(test_labels[i], test_predictions[i]) for i in range(len(test_df)))
+    avg_score = bag_score / max(1, len(test_df))
+    if return_predictions:
+        return total_loss / len(test_df), avg_score, auc_value, thresholds_optimal, test_predictions, test_labels
+    return total_loss / max(1, len(test_df)), avg_score, auc_value, thresholds_optimal
+
+
+# ---- model / optimiser construction (train_tcga.py:229-243) -------------------------------
+def apply_sparse_init(m):
+    if isinstance(m, (nn.Linear, nn.Conv2d, nn.Conv1d)):
+        nn.init.orthogonal_(m.weight)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+
+def init_model(args, mil, device):
+    i_classifier = mil.FCLayer(in_size=args.feats_size, out_size=args.num_classes)
+    b_classifier = mil.BClassifier(input_size=args.feats_size, output_class=args.num_classes,
+                                   dropout_v=args.dropout_node, nonlinear=args.non_linearity)
+    milnet = mil.MILNet(i_classifier, b_classifier).to(device)
+    milnet.apply(apply_sparse_init)
+    criterion = nn.BCEWithLogitsLoss()
+    optimizer = torch.optim.Adam(milnet.parameters(), lr=args.lr, betas=(0.5, 0.9), weight_decay=args.weight_decay)
+    scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, args.num_epochs, 0.000005)
+    return milnet, criterion, optimizer, scheduler
+
+
+def save_model(args, fold, run, save_path, model, thresholds_optimal):
+    save_name = os.path.join(save_path, f"fold_{fold}_{run + 1}.pth")
+    torch.save(model.state_dict(), save_name)
+    print("Best model saved at: " + save_name)
+    print("Best thresholds ===>>> " + "|".join("class-{}>>{}".format(*k) for k in enumerate(thresholds_optimal)))
+    with open(os.path.join(save_path, f"fold_{fold}_{run + 1}.json"), "w") as f:
+        json.dump([float(x) for x in thresholds_optimal], f)
+
+
+def fit(args, mil, device, train_path, val_path, tag, run, save_path, cache, keep_best=False):
+    """The epoch loop shared by the three schemes (train_tcga.py:272-287 and its two copies)."""
+    milnet, criterion, optimizer, scheduler = init_model(args, mil, device)
+    best_score, best_ac, best_auc, counter, best = 0, 0, 0, 0, None
+    for epoch in range(1, args.num_epochs + 1):
+        counter += 1
+        train_loss = train(args, train_path, milnet, criterion, optimizer, cache)
+        test_loss, avg_score, aucs, th = test(args, val_path, milnet, criterion, cache=cache)
+        print("\r Epoch [%d/%d] train loss: %.4f test loss: %.4f, average score: %.4f, AUC: " %
+              (epoch, args.num_epochs, train_loss, test_loss, avg_score) +
+              "|".join("class-{}>>{}".format(*k) for k in enumerate(aucs)))
+        scheduler.step()
+        current = (sum(aucs) + avg_score) / 2
+        if current > best_score:
+            counter, best_score, best_ac, best_auc = 0, current, avg_score, aucs
+            save_model(args, tag, run, save_path, milnet, th)
+            if keep_best:
+                best = (copy.deepcopy(milnet), th)
+        if counter > args.stop_epochs:
+            break
+    return best_ac, best_auc, best, criterion
+
+
+def run_eval_scheme(args, mil, device, bags_path=None):
+    """train_tcga.py:252-429."""
+    from sklearn.model_selection import KFold
+    from sklearn.utils import shuffle
+    bags_path = bags_path if bags_path is not None else glob.glob("temp_train/*.pt")
+    save_path = os.path.join("weights", datetime.date.today().strftime("%Y%m%d"))
+    os.makedirs(save_path, exist_ok=True)
+    run = len(glob.glob(os.path.join(save_path, "*.pth")))
+    cache = BagCache(device)
+    fold_results = []
+    if args.eval_scheme == "5-fold-cv":
+        kf = KFold(n_splits=5, shuffle=True, random_state=42)
+        for fold, (tr, te) in enumerate(kf.split(bags_path)):
+            print(f"Starting CV fold {fold}.")
+            ac, auc, _, _ = fit(args, mil, device, [bags_path[i] for i in tr], [bags_path[i] for i in te],
+                                fold, run, save_path, cache)
+            fold_results.append((ac, auc))
+    elif args.eval_scheme == "5-time-train+valid+test":
+        for it in range(5):
+            print(f"Starting iteration {it + 1}.")
+            bags_path = shuffle(bags_path)
+            n = len(bags_path)
+            train_end = int(n * (1 - args.split - 0.1))
+            val_end = train_end + int(n * 0.1)
+            ac, auc, best, criterion = fit(args, mil, device, bags_path[:train_end], bags_path[train_end:val_end],
+                                           it, run, save_path, cache, keep_best=True)
+            if best is not None:  # the reference calls test() with its arguments swapped here (:341)
+                test(args, bags_path[val_end:], best[0], criterion, cache=cache)
+            fold_results.append((ac, auc))
+    elif args.eval_scheme == "5-fold-cv-standalone-test":
+        from scipy.stats import mode
+        from sklearn.metrics import accuracy_score, balanced_accuracy_score, hamming_loss
+        bags_path = shuffle(bags_path)
+        n_res = int(args.split * len(bags_path))
+        reserved, bags_path = bags_path[:n_res], bags_path[n_res:]
+        kf = KFold(n_splits=5, shuffle=True, random_state=42)
+        fold_models = []
+        for fold, (tr, te) in enumerate(kf.split(bags_path)):
+            print(f"Starting CV fold {fold}.")
+            ac, auc, best, criterion = fit(args, mil, device, [bags_path[i] for i in tr],
+                                           [bags_path[i] for i in te], fold, run, save_path, cache, keep_best=True)
+            fold_results.append((ac, auc))
+            fold_models.append(best)
+        fold_predictions = []
+        for model, th in fold_models:
+            _, _, _, _, pred, test_labels = test(args, reserved, model.to(device), criterion, thresholds=th,
+                                                 return_predictions=True, cache=cache)
+            fold_predictions.append(pred)
+        combined = np.squeeze(np.asarray(mode(np.stack(fold_predictions, axis=0), axis=0, keepdims=True).mode[0]))
+        if args.num_classes > 1:
+            print("Hamming Loss:", hamming_loss(test_labels, combined))
+            print("Subset Accuracy (Exact Match Ratio):", accuracy_score(test_labels, combined))
+        else:
+            print("Accuracy:", accuracy_score(test_labels, combined))
+            print("Balanced Accuracy:", balanced_accuracy_score(test_labels, combined))
+        os.makedirs("test", exist_ok=True)
+        with open("test/test_list.json", "w") as f:
+            json.dump(list(reserved), f)
+        for i, (model, th) in enumerate(fold_models):
+            torch.save(model.state_dict(), f"test/mil_weights_fold_{i}.pth")
+            with open(f"test/mil_threshold_fold_{i}.json", "w") as f:
+                json.dump([float(x) for x in th], f)
+    else:
+        raise ValueError(f"unknown --eval_scheme {args.eval_scheme}")
+    if fold_results:
+        print(f"Final results: Mean Accuracy: {np.mean([r[0] for r in fold_results])}")
+        for i, m in enumerate(np.mean(np.array([r[1] for r in fold_results]), axis=0)):
+            print(f"Class {i}: Mean AUC = {m:.4f}")
+    return fold_results
+
+
+# ---- classical MIL benchmarks (train_mil.py) -------------------------------------------------
+def parse_mil_file(path):
+    """train_mil.py:17-35 — lines 'inst:bag:label idx:val idx:val ...' (svmlight-like).
+    Returns (features [n_inst, n_feat] float, bag_id [n_inst], label [n_inst])."""
+    rows, bag_ids, labels = [], [], []
+    n_feat = 0
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if not line or line.startswith("#"):
+                continue
+            head, *pairs = line.split()
+            _inst, bag, lab = head.split(":")
+            kv = [(int(p.split(":")[0]), float(p.split(":")[1])) for p in pairs]
+            n_feat = max(n_feat, max((k for k, _ in kv), default=0) + 1)
+            rows.append(kv)
+            bag_ids.append(int(bag))
+            labels.append(1.0 if float(lab) > 0 else 0.0)
+    X = np.zeros((len(rows), n_feat), np.float32)
+    for i, kv in enumerate(rows):
+        for k, v in kv:
+            X[i, k] = v
+    return X, np.asarray(bag_ids), np.asarray(labels, np.float32)
+
+
+def group_bags(X, bag_ids, labels):
+    """train_mil.py:143-149 — one [n_i, F] array + one bag label per bag id."""
+    bags, ys = [], []
+    for b in np.unique(bag_ids):
+        m = bag_ids == b
+        bags.append(X[m])
+        ys.append(float(labels[m].max()))
+    return bags, np.asarray(ys, np.float32)
+
+
+def mil_epoch_train(bags, ys, idx, milnet, criterion, optimizer, device):
+    """train_mil.py:42-59 (instances of a bag are shuffled, :46)."""
+    milnet.train()
+    total = 0.0
+    for i in idx:
+        optimizer.zero_grad()
+        x = torch.from_numpy(bags[i][np.random.permutation(len(bags[i]))]).to(device)
+        y = torch.tensor([[ys[i]]], device=device)
+        classes, bag_prediction, _, _ = milnet(x)
+        max_prediction, _ = torch.max(classes, 0)
+        loss = 0.5 * criterion(bag_prediction.view(1, -1), y.view(1, -1)) + \
+            0.5 * criterion(max_prediction.view(1, -1), y.view(1, -1))
+        loss.backward()
+        optimizer.step()
+        total += loss.item()
+    return total / max(1, len(idx))
+
+
+@torch.no_grad()
+def mil_epoch_test(bags, ys, idx, milnet, criterion, device):
+    """train_mil.py:61-80."""
+    milnet.eval()
+    total, preds = 0.0, []
+    for i in idx:
+        x = torch.from_numpy(bags[i]).to(device)
+        y = torch.tensor([[ys[i]]], device=device)
+        classes, bag_prediction, _, _ = milnet(x)
+        max_prediction, _ = torch.max(classes, 0)
+        loss = 0.5 * criterion(bag_prediction.view(1, -1), y.view(1, -1)) + \
+            0.5 * criterion(max_prediction.view(1, -1), y.view(1, -1))
+        total += loss.item()
+        preds.append(float(torch.sigmoid(bag_prediction).squeeze()))  # train_mil.py:77
+    return total / max(1, len(idx)), np.asarray(preds)
+
+
+def five_scores(bag_labels, bag_predictions):
+    """train_mil.py:87-97."""
+    from sklearn.metrics import precision_recall_fscore_support, roc_auc_score, roc_curve
+    fpr, tpr, threshold = roc_curve(bag_labels, bag_predictions, pos_label=1)
+    _, _, th = optimal_thresh(fpr, tpr, threshold)
+    auc_value = roc_auc_score(bag_labels, bag_predictions)
+    hard = (np.asarray(bag_predictions) >= th).astype(int)
+    precision, recall, fscore, _ = precision_recall_fscore_support(bag_labels, hard, average="binary", zero_division=0)
+    accuracy = 1 - np.count_nonzero(np.asarray(bag_labels).astype(int) - hard) / len(bag_labels)
+    return accuracy, auc_value, precision, recall, fscore
+
+
+def write_synthetic_mil_file(path, n_bags=92, n_inst=476, n_feat=166, n_pos=47, seed=0):
+    """A stand-in for musk1norm.svm (a download, download.py:33-37) in the same text format:
+    92 bags / 476 instances / 166 features / 47 positive bags.  Positive
+    bags carry one 'witness' instance shifted along a fixed direction so the task is learnable."""
+    rng = np.random.default_rng(seed)
+    sizes = np.full(n_bags, n_inst // n_bags)
+    sizes[: n_inst - sizes.sum()] += 1
+    pos = np.zeros(n_bags, bool)
+    pos[rng.permutation(n_bags)[:n_pos]] = True
+    direction = rng.standard_normal(n_feat).astype(np.float32)
+    direction /= np.linalg.norm(direction)
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    inst = 0
+    with open(path, "w") as f:
+        for b in range(n_bags):
+            X = rng.standard_normal((sizes[b], n_feat)).astype(np.float32)
+            if pos[b]:
+                X[0] += 6.0 * direction
+            for r in X:
+                f.write(f"{inst}:{b}:{1 if pos[b] else -1} " + " ".join(f"{k}:{v:.6f}" for k, v in enumerate(r)) + "\n")
+                inst += 1
+    return path
