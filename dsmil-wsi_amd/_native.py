@@ -34,6 +34,12 @@ SIGNATURES = {
     "dsmil_agg_tile_rows": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64]),
     "dsmil_agg_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
                                                     ctypes.c_int32, ctypes.c_int32]),
+    "dsmil_agg_packed_bf16_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
+    "dsmil_agg_pack_bf16": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "dsmil_agg_forward_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i64p, ctypes.c_int32,
+                                              ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(AggParams),
+                                              ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64p,
+                                              ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dsmil_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "dsmil_profile_collect": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "dsmil_resnet18_packed_bytes": (ctypes.c_size_t, []),

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 #include "dsmil_hip.h"
 #include "prof.h"
 
@@ -51,11 +52,34 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// 4 consecutive floats at p[k..k+3], zero beyond klim.  VEC=4 needs 16-B aligned rows.
-template <int VEC>
-__device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int k, int klim) {
+typedef unsigned short bf16_t;  // raw bfloat16 bits (storage type of the bf16 path)
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even, like torch .bfloat16()
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+// 4 consecutive elements at p[k..k+3] as floats, zero beyond klim.  VEC=4 needs rows aligned to
+// 4 elements (16 B for fp32, 8 B for bf16).
+template <int VEC, typename T = float>
+__device__ __forceinline__ f32x4 load4(const T* __restrict__ p, int k, int klim) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (VEC == 4) {
+    if constexpr (sizeof(T) == 2) {
+        if constexpr (VEC == 4) {
+            if (k < klim) {
+                const uint2 t = *reinterpret_cast<const uint2*>(p + k);
+                v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+                v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k + e < klim) v[e] = bf2f(p[k + e]);
+        }
+    } else if constexpr (VEC == 4) {
         if (k < klim) v = *reinterpret_cast<const f32x4*>(p + k);
     } else {
         if (k + 0 < klim) v[0] = p[k + 0];
@@ -89,9 +113,9 @@ __device__ __forceinline__ bool better(float v, long long i, float bv, long long
 // One wave owns 32 rows, 4 rows in flight; lanes stride the feature axis with 16-B loads.
 // GIVEN = true: the logits are taken from classes_in (BClassifier.forward(feats, c)).
 // --------------------------------------------------------------------------------------------
-template <int VEC, bool GIVEN>
+template <int VEC, bool GIVEN, typename T = float>
 __global__ __launch_bounds__(256) void k_logits_argmax(
-    const float* __restrict__ feats, const int64_t* __restrict__ offsets,
+    const T* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ fc_w, const float* __restrict__ fc_b,
     const float* __restrict__ classes_in, float* __restrict__ classes_out,
     float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C) {
@@ -116,10 +140,10 @@ __global__ __launch_bounds__(256) void k_logits_argmax(
             const long long ra = rbase, rb = (rbase + 1 < Nb) ? rbase + 1 : Nb - 1,
                             rc = (rbase + 2 < Nb) ? rbase + 2 : Nb - 1, rd = (rbase + 3 < Nb) ? rbase + 3 : Nb - 1;
             if constexpr (!GIVEN) {
-                const float* xa = feats + (off0 + ra) * (long long)K;
-                const float* xb = feats + (off0 + rb) * (long long)K;
-                const float* xc = feats + (off0 + rc) * (long long)K;
-                const float* xd = feats + (off0 + rd) * (long long)K;
+                const T* xa = feats + (off0 + ra) * (long long)K;
+                const T* xb = feats + (off0 + rb) * (long long)K;
+                const T* xc = feats + (off0 + rc) * (long long)K;
+                const T* xd = feats + (off0 + rd) * (long long)K;
                 const float* w0p = fc_w + (long long)c0 * K;
                 const float* w1p = fc_w + (long long)c1 * K;
                 va0 = va1 = vb0 = vb1 = vc0 = vc1 = vd0 = vd1 = 0.f;
@@ -127,10 +151,10 @@ __global__ __launch_bounds__(256) void k_logits_argmax(
                     const int k = k0 + lane * 4;
                     const f32x4 w0 = load4<VEC>(w0p, k, K);
                     const f32x4 w1 = load4<VEC>(w1p, k, K);
-                    const f32x4 a = load4<VEC>(xa, k, K);
-                    const f32x4 b = load4<VEC>(xb, k, K);
-                    const f32x4 c = load4<VEC>(xc, k, K);
-                    const f32x4 d = load4<VEC>(xd, k, K);
+                    const f32x4 a = load4<VEC, T>(xa, k, K);
+                    const f32x4 b = load4<VEC, T>(xb, k, K);
+                    const f32x4 c = load4<VEC, T>(xc, k, K);
+                    const f32x4 d = load4<VEC, T>(xd, k, K);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         va0 = fmaf(a[e], w0[e], va0); va1 = fmaf(a[e], w1[e], va1);
@@ -190,9 +214,9 @@ __global__ __launch_bounds__(256) void k_logits_argmax(
 // (dsmil.py:52), then q_max = q(feats[idx]) (dsmil.py:53-54) on the VALU, 8 hidden units in
 // flight per wave so the dependent shuffle chains overlap.
 // --------------------------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, typename T = float>
 __global__ __launch_bounds__(256) void k_qmax(
-    const float* __restrict__ feats, const int64_t* __restrict__ offsets,
+    const T* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ part_val, const long long* __restrict__ part_idx,
     const float* __restrict__ q0_w, const float* __restrict__ q0_b,
     const float* __restrict__ q2_w, const float* __restrict__ q2_b,
@@ -228,14 +252,14 @@ __global__ __launch_bounds__(256) void k_qmax(
     long long best = bi;
     if (best < 0 || best >= Nb) best = 0;  // all-NaN guard: stay in bounds
     if (threadIdx.x == 0) idx_out[(long long)bag * C + c] = best;
-    const float* x = feats + (off0 + best) * (long long)K;
+    const T* x = feats + (off0 + best) * (long long)K;
     // layer 1: wave w computes hidden units 32w..32w+31, 8 at a time; lanes stride k by 4
     for (int jb = 0; jb < 32; jb += 8) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float* wr = q0_w + (long long)(wave * 32 + jb) * K;
         for (int k0 = 0; k0 < K; k0 += 256) {
             const int k = k0 + lane * 4;
-            const f32x4 xv = load4<VEC>(x, k, K);
+            const f32x4 xv = load4<VEC, T>(x, k, K);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const f32x4 wv = load4<VEC>(wr + (long long)u * K, k, K);
@@ -276,8 +300,9 @@ __global__ __launch_bounds__(256) void k_qmax(
 // k_query_attend — the dominant kernel.  NW waves per workgroup, 32 instance rows per wave.
 // --------------------------------------------------------------------------------------------
 struct AttendArgs {
-    const float* feats;
-    const float* vals;
+    const void* feats;  // fp32 or bf16 [total_rows, K]
+    const void* vals;   // fp32 or bf16 [total_rows, Kv]
+    const bf16_t* wpk;  // bf16 path: packed W1 [128][K64] then W2 permuted [128][128]
     const int64_t* offsets;
     const float* q0_w;
     const float* q0_b;
@@ -288,160 +313,20 @@ struct AttendArgs {
     float* part_ml;     // [slots, C, 2]
     float* part_B;      // [slots, C, Kv]
     int K, Kv, C, nonlinear;
+    int expt;  // DSMIL_EXPT debugging knob (0 in production): ablation switches for profiling
 };
 
-template <int NW, int VEC>
-__global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(AttendArgs a) {
-    constexpr int T = NW * 64;
-    constexpr int BM = NW * 32;
-    constexpr int X_TILE = BM * LDK;
-    constexpr int WPT = (QD * (BK / 4)) / T;  // float4 per thread per weight chunk
-    constexpr int XPT = (BM * (BK / 4)) / T;  // == 4
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sW = smem;               // [2][W_TILE]
-    float* sX = smem + 2 * W_TILE;  // [2][X_TILE]
-
-    const int bag = blockIdx.y;
-    const long long off0 = a.offsets[bag];
-    const long long Nb = a.offsets[bag + 1] - off0;
-    const long long row0 = (long long)blockIdx.x * BM;
-    if (row0 >= Nb) return;
-    const long long slot = off0 / BM + bag + blockIdx.x;
+// --------------------------------------------------------------------------------------------
+// attend_tail: everything behind the query MLP, shared by the fp32 and bf16 kernels.  Q holds
+// Q^T in the MFMA D layout: lane (l31, hi), tile t, reg 4g+e  <->  Q[row l31][32t + 8g + 4hi + e].
+// Scores (dsmil.py:55-56), tile softmax statistics, weighted value sum (dsmil.py:57).
+// --------------------------------------------------------------------------------------------
+template <int NW, int VEC, typename T>
+__device__ __forceinline__ void attend_tail(const AttendArgs& a, const f32x16 (&Q)[4], float* smem, int bag,
+                                            long long off0, long long Nb, long long row0, long long slot) {
+    constexpr int T_ = NW * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int K = a.K;
-    const int nk1 = (K + BK - 1) / BK;
-    const int nk = nk1 + (a.nonlinear ? QD / BK : 0);
-
-    f32x4 wreg[WPT], xreg[XPT];
-    bool kok = true;  // this thread's k-slice of the staged chunk lies inside the weight row
-    // stage_load only ISSUES global loads (clamped addresses, no branches) so they stay in flight
-    // under the MFMAs of the current chunk; stage_write zeroes the weight k-tail (K % 32 != 0)
-    // and moves the registers to LDS.  Feature values beyond K are multiplied by those zeros.
-    auto stage_load = [&](int ci) {
-        const float* wb;
-        int ld, k0, klim;
-        if (ci < nk1) { wb = a.q0_w; ld = K; k0 = ci * BK; klim = K; }
-        else { wb = a.q2_w; ld = QD; k0 = (ci - nk1) * BK; klim = QD; }
-        const int k = k0 + (tid & 7) * 4;
-        kok = k < klim;
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int r = (tid + T * i) >> 3;
-            wreg[i] = load4_clamped<VEC>(wb + (long long)r * ld, k, klim);
-        }
-        if (ci < nk1) {
-#pragma unroll
-            for (int i = 0; i < XPT; ++i) {
-                const int r = (tid + T * i) >> 3;
-                long long gr = row0 + r;
-                if (gr >= Nb) gr = Nb - 1;  // clamp: rows past the bag end are masked later
-                xreg[i] = load4_clamped<VEC>(a.feats + (off0 + gr) * (long long)K, k, klim);
-            }
-        }
-    };
-    auto stage_write = [&](int ci) {
-        float* w = sW + (ci & 1) * W_TILE;
-        const int c4 = tid & 7;
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int r = (tid + T * i) >> 3;
-            f32x4 v = wreg[i];
-            if constexpr (VEC == 4) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = kok ? v[e] : 0.f;
-            }
-            *reinterpret_cast<f32x4*>(w + r * LDK + c4 * 4) = v;
-        }
-        if (ci < nk1) {
-            float* x = sX + (ci & 1) * X_TILE;
-#pragma unroll
-            for (int i = 0; i < XPT; ++i) {
-                const int r = (tid + T * i) >> 3;
-                *reinterpret_cast<f32x4*>(x + r * LDK + c4 * 4) = xreg[i];
-            }
-        }
-    };
-
-    f32x16 H[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) H[t][r] = 0.f;
-
-    stage_load(0);
-    stage_write(0);
-    __syncthreads();
-    const int frag_off = l31 * LDK + 4 * hi;  // this lane's row / k-half inside a chunk
-    // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] * X[n][k]
-    for (int ci = 0; ci < nk1; ++ci) {
-        if (ci + 1 < nk) stage_load(ci + 1);
-        const float* w = sW + (ci & 1) * W_TILE + frag_off;
-        const float* x = sX + (ci & 1) * X_TILE + wave * 32 * LDK + frag_off;
-#pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-            const f32x4 xb = *reinterpret_cast<const f32x4*>(x + kg * 8);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f32x4 wa = *reinterpret_cast<const f32x4*>(w + t * 32 * LDK + kg * 8);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    H[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xb[j], H[t], 0, 0, 0);
-            }
-        }
-        if (ci + 1 < nk) stage_write(ci + 1);
-        __syncthreads();
-    }
-    // ---- bias (+ReLU): H^T row j = 32t + 8g + 4hi + e  for reg r = 4g + e
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(a.q0_b + 32 * t + 8 * g + 4 * hi);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = H[t][4 * g + e] + b[e];
-                H[t][4 * g + e] = a.nonlinear ? fmaxf(v, 0.f) : v;
-            }
-        }
-    f32x16 Q[4];
-    if (a.nonlinear) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Q[t][r] = 0.f;
-        // ---- GEMM 2 (transposed): Q^T[j2][n] += W2[j2][k] * H^T[k][n]; chunk t feeds k=32t..32t+31
-        // straight from the accumulator registers of H[t]: reg 4g+e holds k = 8g + 4hi + e.
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int ci = nk1 + t;
-            if (t < 3) stage_load(ci + 1);
-            const float* w = sW + (ci & 1) * W_TILE + frag_off;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int t2 = 0; t2 < 4; ++t2) {
-                    const f32x4 wa = *reinterpret_cast<const f32x4*>(w + t2 * 32 * LDK + g * 8);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        Q[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[e], H[t][4 * g + e], Q[t2], 0, 0, 0);
-                }
-            }
-            if (t < 3) stage_write(ci + 1);
-            __syncthreads();
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * t + 8 * g + 4 * hi);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = tanhf(Q[t][4 * g + e] + b[e]);
-            }
-    } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) Q[t] = H[t];
-    }
     // From here on the staging LDS is free (every wave is past the last barrier above).
     // ---- scores, tile softmax statistics, weighted value sum — two classes per sweep
     const long long wrow0 = row0 + wave * 32;           // first row of this wave
@@ -449,7 +334,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
     const bool valid = myrow < Nb;
     const float scale = 0.08838834764831845f;           // 1/sqrt(128), dsmil.py:56
     const int Kv = a.Kv;
-    const float* vbase = a.vals + off0 * (long long)Kv;
+    const T* vbase = reinterpret_cast<const T*>(a.vals) + off0 * (long long)Kv;
     float* sRed = smem;                                  // [NW][4]: m0,l0,m1,l1 per wave
     float* sB = smem + 64;                               // [NW][2][512]
     for (int c0 = 0; c0 < a.C; c0 += 2) {
@@ -516,7 +401,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
         }
         const float pp0 = p0 * f0, pp1 = p1 * f1;  // weights relative to the BLOCK max
         // ---- weighted value sum: Bpart[c][k] = sum_n p[n][c] * V[n][k], 512 k per sweep
-        for (int k0 = 0; k0 < Kv; k0 += 512) {
+        for (int k0 = 0; k0 < ((a.expt & 1) ? 0 : Kv); k0 += 512) {
             f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
             const int ka = k0 + lane * 4, kb = ka + 256;
 #pragma unroll 4
@@ -524,9 +409,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
                 long long r = wrow0 + n;
                 if (r >= Nb) r = Nb - 1;  // weight is 0 there
                 const float w0 = __shfl(pp0, n, 64), w1 = __shfl(pp1, n, 64);
-                const float* vr = vbase + r * (long long)Kv;
-                const f32x4 va = load4<VEC>(vr, ka, Kv);
-                const f32x4 vb = load4<VEC>(vr, kb, Kv);
+                const T* vr = vbase + r * (long long)Kv;
+                const f32x4 va = load4<VEC, T>(vr, ka, Kv);
+                const f32x4 vb = load4<VEC, T>(vr, kb, Kv);
                 acc00 += w0 * va; acc01 += w0 * vb;
                 acc10 += w1 * va; acc11 += w1 * vb;
             }
@@ -540,7 +425,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
                 *reinterpret_cast<f32x4*>(my + 512 + lane * 4) = acc10;
                 *reinterpret_cast<f32x4*>(my + 768 + lane * 4) = acc11;
                 __syncthreads();
-                for (int e = tid; e < 1024; e += T) {
+                for (int e = tid; e < 1024; e += T_) {
                     float s = 0.f;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) s += sB[w * 1024 + e];
@@ -556,6 +441,347 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
             }
         }
         if constexpr (NW > 1) __syncthreads();
+    }
+}
+
+template <int NW, int VEC>
+__global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(AttendArgs a) {
+    constexpr int T = NW * 64;
+    constexpr int BM = NW * 32;
+    constexpr int X_TILE = BM * LDK;
+    constexpr int WPT = (QD * (BK / 4)) / T;  // float4 per thread per weight chunk
+    constexpr int XPT = (BM * (BK / 4)) / T;  // == 4
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sW = smem;               // [2][W_TILE]
+    float* sX = smem + 2 * W_TILE;  // [2][X_TILE]
+
+    const int bag = blockIdx.y;
+    const long long off0 = a.offsets[bag];
+    const long long Nb = a.offsets[bag + 1] - off0;
+    const long long row0 = (long long)blockIdx.x * BM;
+    if (row0 >= Nb) return;
+    const long long slot = off0 / BM + bag + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int K = a.K;
+    const int nk1 = (K + BK - 1) / BK;
+    const int nk = nk1 + (a.nonlinear ? QD / BK : 0);
+
+    f32x4 wreg[WPT], xreg[XPT];
+    bool kok = true;  // this thread's k-slice of the staged chunk lies inside the weight row
+    // stage_load only ISSUES global loads (clamped addresses, no branches) so they stay in flight
+    // under the MFMAs of the current chunk; stage_write zeroes the weight k-tail (K % 32 != 0)
+    // and moves the registers to LDS.  Feature values beyond K are multiplied by those zeros.
+    auto stage_load = [&](int ci) {
+        const float* wb;
+        int ld, k0, klim;
+        if (ci < nk1) { wb = a.q0_w; ld = K; k0 = ci * BK; klim = K; }
+        else { wb = a.q2_w; ld = QD; k0 = (ci - nk1) * BK; klim = QD; }
+        const int k = k0 + (tid & 7) * 4;
+        kok = k < klim;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int r = (tid + T * i) >> 3;
+            wreg[i] = load4_clamped<VEC>(wb + (long long)r * ld, k, klim);
+        }
+        if (ci < nk1) {
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int r = (tid + T * i) >> 3;
+                long long gr = row0 + r;
+                if (gr >= Nb) gr = Nb - 1;  // clamp: rows past the bag end are masked later
+                xreg[i] = load4_clamped<VEC>(reinterpret_cast<const float*>(a.feats) + (off0 + gr) * (long long)K, k, klim);
+            }
+        }
+    };
+    auto stage_write = [&](int ci) {
+        float* w = sW + (ci & 1) * W_TILE;
+        const int c4 = tid & 7;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int r = (tid + T * i) >> 3;
+            f32x4 v = wreg[i];
+            if constexpr (VEC == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = kok ? v[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(w + r * LDK + c4 * 4) = v;
+        }
+        if (ci < nk1) {
+            float* x = sX + (ci & 1) * X_TILE;
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int r = (tid + T * i) >> 3;
+                *reinterpret_cast<f32x4*>(x + r * LDK + c4 * 4) = xreg[i];
+            }
+        }
+    };
+
+    f32x16 H[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H[t][r] = 0.f;
+
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    const int frag_off = l31 * LDK + 4 * hi;  // this lane's row / k-half inside a chunk
+    // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] * X[n][k]
+    for (int ci = 0; ci < nk1; ++ci) {
+        if (ci + 1 < nk && !(a.expt & 8)) stage_load(ci + 1);
+        const float* w = sW + (ci & 1) * W_TILE + frag_off;
+        const float* x = sX + (ci & 1) * X_TILE + wave * 32 * LDK + frag_off;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const f32x4 xb = *reinterpret_cast<const f32x4*>(x + kg * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(w + t * 32 * LDK + kg * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    H[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xb[j], H[t], 0, 0, 0);
+            }
+        }
+        if (!(a.expt & 16)) {
+            if (ci + 1 < nk) stage_write(ci + 1);
+            __syncthreads();
+        }
+    }
+    // ---- bias (+ReLU): H^T row j = 32t + 8g + 4hi + e  for reg r = 4g + e
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.q0_b + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = H[t][4 * g + e] + b[e];
+                H[t][4 * g + e] = a.nonlinear ? fmaxf(v, 0.f) : v;
+            }
+        }
+    f32x16 Q[4];
+    if (a.nonlinear) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Q[t][r] = 0.f;
+        // ---- GEMM 2 (transposed): Q^T[j2][n] += W2[j2][k] * H^T[k][n]; chunk t feeds k=32t..32t+31
+        // straight from the accumulator registers of H[t]: reg 4g+e holds k = 8g + 4hi + e.
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ci = nk1 + t;
+            if (t < 3) stage_load(ci + 1);
+            const float* w = sW + (ci & 1) * W_TILE + frag_off;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) {
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(w + t2 * 32 * LDK + g * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        Q[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[e], H[t][4 * g + e], Q[t2], 0, 0, 0);
+                }
+            }
+            if (t < 3) stage_write(ci + 1);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = (a.expt & 2) ? (Q[t][4 * g + e] + b[e]) * 0.5f : tanhf(Q[t][4 * g + e] + b[e]);
+            }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Q[t] = H[t];
+    }
+    if (a.expt & 4) {  // ablation: stop after the MLP (keep the accumulators live)
+        float keep = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) keep += Q[t][r];
+        if (keep == 12345.678f) a.scores[0] = keep;
+        return;
+    }
+    attend_tail<NW, VEC, float>(a, Q, smem, bag, off0, Nb, row0, slot);
+}
+
+// --------------------------------------------------------------------------------------------
+// k_query_attend_bf16 — BASELINE config 2: bf16 storage (features + query weights), f32
+// accumulate / softmax.  v_mfma_f32_32x32x16_bf16, same transposed chain as the fp32 kernel:
+// the ReLU'd H^T accumulators are rounded to bf16 and fed back as the B operand; W2 is packed
+// with its k axis permuted so that MFMA step (t, s) contracts exactly the hidden units that
+// accumulator registers 8s..8s+7 of tile t hold:  W2p[j][32t+16s+8hi+e] = W2[j][32t+16s+(e&3)+8(e>>2)+4hi].
+// 64 bf16 (128 B) per staged row, so LDS geometry and fragment addressing equal the fp32 kernel's.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend_bf16(AttendArgs a) {
+    constexpr int T = NW * 64;
+    constexpr int BM = NW * 32;
+    constexpr int X_TILE = BM * LDK;
+    constexpr int WPT = (QD * 8) / T;
+    constexpr int XPT = (BM * 8) / T;
+    constexpr int BKH = 64;  // bf16 elements per staged chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sW = smem;
+    float* sX = smem + 2 * W_TILE;
+    const int bag = blockIdx.y;
+    const long long off0 = a.offsets[bag];
+    const long long Nb = a.offsets[bag + 1] - off0;
+    const long long row0 = (long long)blockIdx.x * BM;
+    if (row0 >= Nb) return;
+    const long long slot = off0 / BM + bag + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int K = a.K;
+    const int K64 = (K + BKH - 1) / BKH * BKH;
+    const int nk1 = K64 / BKH;
+    const int nk = nk1 + (a.nonlinear ? QD / BKH : 0);
+    const bf16_t* feats = reinterpret_cast<const bf16_t*>(a.feats);
+    const bf16_t* w1p = a.wpk;
+    const bf16_t* w2p = a.wpk + (long long)QD * K64;
+
+    f32x4 wreg[WPT], xreg[XPT];
+    auto stage_load = [&](int ci) {
+        const bf16_t* wb;
+        int ld, k0;
+        if (ci < nk1) { wb = w1p; ld = K64; k0 = ci * BKH; }
+        else { wb = w2p; ld = QD; k0 = (ci - nk1) * BKH; }
+        const int k = k0 + (tid & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int r = (tid + T * i) >> 3;
+            wreg[i] = *reinterpret_cast<const f32x4*>(wb + (long long)r * ld + k);
+        }
+        if (ci < nk1) {
+            const int kc = (k + 8 <= K) ? k : K - 8;  // beyond K the packed weights are zero
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int r = (tid + T * i) >> 3;
+                long long gr = row0 + r;
+                if (gr >= Nb) gr = Nb - 1;
+                xreg[i] = *reinterpret_cast<const f32x4*>(feats + (off0 + gr) * (long long)K + kc);
+            }
+        }
+    };
+    auto stage_write = [&](int ci) {
+        float* w = sW + (ci & 1) * W_TILE;
+        const int c4 = tid & 7;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            *reinterpret_cast<f32x4*>(w + ((tid + T * i) >> 3) * LDK + c4 * 4) = wreg[i];
+        if (ci < nk1) {
+            float* x = sX + (ci & 1) * X_TILE;
+#pragma unroll
+            for (int i = 0; i < XPT; ++i)
+                *reinterpret_cast<f32x4*>(x + ((tid + T * i) >> 3) * LDK + c4 * 4) = xreg[i];
+        }
+    };
+
+    f32x16 H[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H[t][r] = 0.f;
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    const int frag = l31 * LDK + 4 * hi;
+    for (int ci = 0; ci < nk1; ++ci) {
+        if (ci + 1 < nk) stage_load(ci + 1);
+        const float* w = sW + (ci & 1) * W_TILE + frag;
+        const float* x = sX + (ci & 1) * X_TILE + wave * 32 * LDK + frag;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 xb = *reinterpret_cast<const bf16x8*>(x + ks * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 wa = *reinterpret_cast<const bf16x8*>(w + t * 32 * LDK + ks * 8);
+                H[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, H[t], 0, 0, 0);
+            }
+        }
+        if (ci + 1 < nk) stage_write(ci + 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.q0_b + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = H[t][4 * g + e] + b[e];
+                H[t][4 * g + e] = a.nonlinear ? fmaxf(v, 0.f) : v;
+            }
+        }
+    f32x16 Q[4];
+    if (a.nonlinear) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Q[t][r] = 0.f;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int ci = nk1 + c2;
+            if (c2 < 1) stage_load(ci + 1);
+            const float* w = sW + (ci & 1) * W_TILE + frag;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * c2 + tt;
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx) {
+                    union { unsigned u[4]; bf16x8 v; } hb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        hb.u[e] = pack_bf16x2(H[t][8 * sidx + 2 * e], H[t][8 * sidx + 2 * e + 1]);
+#pragma unroll
+                    for (int t2 = 0; t2 < 4; ++t2) {
+                        const bf16x8 wa = *reinterpret_cast<const bf16x8*>(w + t2 * 32 * LDK + tt * 16 + sidx * 8);
+                        Q[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, hb.v, Q[t2], 0, 0, 0);
+                    }
+                }
+            }
+            if (c2 < 1) stage_write(ci + 1);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = tanhf(Q[t][4 * g + e] + b[e]);
+            }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Q[t] = H[t];
+    }
+    attend_tail<NW, 4, bf16_t>(a, Q, smem, bag, off0, Nb, row0, slot);
+}
+
+// W1 [128,K] fp32 -> bf16 [128,K64] zero padded; W2 [128,128] fp32 -> bf16 with the k permutation
+// described above.  RNE rounding (== torch .bfloat16()).
+__global__ void k_pack_agg_bf16(const float* __restrict__ q0_w, const float* __restrict__ q2_w,
+                                bf16_t* __restrict__ out, int K, int K64) {
+    const int n1 = QD * K64;
+    const int total = n1 + (q2_w ? QD * QD : 0);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i < n1) {
+            const int j = i / K64, k = i - j * K64;
+            out[i] = k < K ? f2bf(q0_w[(long long)j * K + k]) : (bf16_t)0;
+        } else {
+            const int q = i - n1, j = q / QD, kk = q - j * QD;
+            const int base = kk & ~15, r = kk & 15, hi = r >> 3, e = r & 7;
+            out[i] = f2bf(q2_w[j * QD + base + (e & 3) + 8 * (e >> 2) + 4 * hi]);
+        }
     }
 }
 
@@ -737,6 +963,23 @@ int launch_attend(const AttendArgs& a, long long max_rows, int n_bags, hipStream
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
+template <int NW>
+int launch_attend_bf16(const AttendArgs& a, long long max_rows, int n_bags, hipStream_t st) {
+    constexpr int BM = NW * 32;
+    const size_t lds = (size_t)(2 * W_TILE + 2 * BM * LDK) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_query_attend_bf16<NW>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((max_rows + BM - 1) / BM), (unsigned)n_bags);
+    const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
+    hipLaunchKernelGGL((k_query_attend_bf16<NW>), grid, dim3(NW * 64), lds, st, a);
+    dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
 }  // namespace
 
 extern "C" {
@@ -777,23 +1020,27 @@ int dsmil_fc_forward(const float* feats, int64_t total_rows, int32_t K, int32_t 
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
-int dsmil_agg_forward(const float* feats, const float* vals, const int64_t* offsets,
-                      int32_t n_bags, int64_t total_rows, int64_t max_rows,
-                      const dsmil_agg_params* p, const float* classes_in, float* classes_out,
-                      float* A, float* B, float* pred, int64_t* idx, void* ws, size_t ws_bytes,
-                      void* stream) {
+static int agg_forward_impl(const void* feats, const void* vals, const int64_t* offsets,
+                            int32_t n_bags, int64_t total_rows, int64_t max_rows, const dsmil_agg_params* p,
+                            const void* packed_bf16, bool bf16, const float* classes_in, float* classes_out,
+                            float* A, float* B, float* pred, int64_t* idx, void* ws, size_t ws_bytes,
+                            void* stream) {
     if (!feats || !offsets || !p || !A || !B || !pred || !idx || !ws) return DSMIL_E_INVALID;
     if (n_bags <= 0 || total_rows <= 0 || max_rows <= 0 || max_rows > total_rows) return DSMIL_E_INVALID;
     if (p->K <= 0 || p->Kv <= 0 || p->C <= 0) return DSMIL_E_INVALID;
     if (!p->q0_w || !p->q0_b || !p->fcc_w || !p->fcc_b) return DSMIL_E_INVALID;
     if (p->nonlinear && (!p->q2_w || !p->q2_b)) return DSMIL_E_INVALID;
     if (!classes_in && (!p->fc_w || !p->fc_b || !classes_out)) return DSMIL_E_INVALID;
+    if (bf16 && !packed_bf16) return DSMIL_E_INVALID;
     if (n_bags > 65535) return DSMIL_E_UNSUPPORTED;
     if (!vals) vals = feats;
     if (vals == feats && p->Kv != p->K) return DSMIL_E_INVALID;
     if (((uintptr_t)ws % 256) || ((uintptr_t)p->q0_b % 16) || (p->nonlinear && ((uintptr_t)p->q2_b % 16)))
         return DSMIL_E_ALIGN;
     const int K = p->K, Kv = p->Kv, C = p->C;
+    if (bf16 && ((K % 8) || (Kv % 4) || ((uintptr_t)feats % 16) || ((uintptr_t)vals % 8) ||
+                 ((uintptr_t)packed_bf16 % 16)))
+        return DSMIL_E_UNSUPPORTED;
     const int NW = pick_nw(n_bags, total_rows);
     const int BM = NW * 32;
     const WsLayout L = ws_layout(n_bags, total_rows, max_rows, Kv, C, BM);
@@ -806,29 +1053,39 @@ int dsmil_agg_forward(const float* feats, const float* vals, const int64_t* offs
     float* part_ml = (float*)(w8 + L.part_ml);
     float* part_B = (float*)(w8 + L.part_B);
     float* pred_part = (float*)(w8 + L.pred_part);
+    const float* f32 = (const float*)feats;
+    const bf16_t* b16 = (const bf16_t*)feats;
 
-    const bool v4 = (K % 4 == 0) && (Kv % 4 == 0) &&
-                    (((uintptr_t)feats | (uintptr_t)vals | (uintptr_t)p->q0_w | (uintptr_t)p->fc_w |
-                      (uintptr_t)(p->nonlinear ? p->q2_w : p->q0_w)) % 16 == 0);
+    const bool v4 = bf16 || ((K % 4 == 0) && (Kv % 4 == 0) &&
+                             (((uintptr_t)feats | (uintptr_t)vals | (uintptr_t)p->q0_w | (uintptr_t)p->fc_w |
+                               (uintptr_t)(p->nonlinear ? p->q2_w : p->q0_w)) % 16 == 0));
+    const bool w4 = (K % 4 == 0) && (((uintptr_t)p->q0_w | (uintptr_t)p->fc_w) % 16 == 0);
     // 1. instance logits + arg-max partials
     {
         dim3 grid((unsigned)((max_rows + R0 - 1) / R0), (unsigned)n_bags);
-        if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true>), grid, dim3(256), 0, st, feats, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
-        else if (v4) hipLaunchKernelGGL((k_logits_argmax<4, false>), grid, dim3(256), 0, st, feats, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
-        else hipLaunchKernelGGL((k_logits_argmax<1, false>), grid, dim3(256), 0, st, feats, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
+        if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
+        else if (bf16 && w4) hipLaunchKernelGGL((k_logits_argmax<4, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
+        else if (bf16) hipLaunchKernelGGL((k_logits_argmax<1, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
+        else if (v4) hipLaunchKernelGGL((k_logits_argmax<4, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
+        else hipLaunchKernelGGL((k_logits_argmax<1, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
     // 2. critical instance + its query
-    if (v4) hipLaunchKernelGGL(k_qmax<4>, dim3((unsigned)n_bags, (unsigned)C), dim3(256), 0, st, feats, offsets,
-                               part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear);
-    else hipLaunchKernelGGL(k_qmax<1>, dim3((unsigned)n_bags, (unsigned)C), dim3(256), 0, st, feats, offsets,
-                            part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear);
-    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    {
+        dim3 grid((unsigned)n_bags, (unsigned)C);
+        if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), grid, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear);
+        else if (bf16) hipLaunchKernelGGL((k_qmax<1, bf16_t>), grid, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear);
+        else if (v4) hipLaunchKernelGGL((k_qmax<4, float>), grid, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear);
+        else hipLaunchKernelGGL((k_qmax<1, float>), grid, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    }
     // 3. query MLP on MFMA + scores + tile softmax + weighted value sum
-    AttendArgs a{feats, vals, offsets, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, A, part_ml, part_B,
-                 K, Kv, C, p->nonlinear};
+    AttendArgs a{feats, vals, (const bf16_t*)packed_bf16, offsets, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, A,
+                 part_ml, part_B, K, Kv, C, p->nonlinear, 0};
+    if (const char* e = getenv("DSMIL_EXPT")) a.expt = atoi(e);
     int rc;
-    if (NW == 4) rc = v4 ? launch_attend<4, 4>(a, max_rows, n_bags, st) : launch_attend<4, 1>(a, max_rows, n_bags, st);
+    if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, n_bags, st) : launch_attend_bf16<1>(a, max_rows, n_bags, st);
+    else if (NW == 4) rc = v4 ? launch_attend<4, 4>(a, max_rows, n_bags, st) : launch_attend<4, 1>(a, max_rows, n_bags, st);
     else rc = v4 ? launch_attend<1, 4>(a, max_rows, n_bags, st) : launch_attend<1, 1>(a, max_rows, n_bags, st);
     if (rc != DSMIL_OK) return rc;
     // 4. combine
@@ -843,6 +1100,38 @@ int dsmil_agg_forward(const float* feats, const float* vals, const int64_t* offs
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
     return DSMIL_OK;
+}
+
+int dsmil_agg_forward(const float* feats, const float* vals, const int64_t* offsets,
+                      int32_t n_bags, int64_t total_rows, int64_t max_rows,
+                      const dsmil_agg_params* p, const float* classes_in, float* classes_out,
+                      float* A, float* B, float* pred, int64_t* idx, void* ws, size_t ws_bytes,
+                      void* stream) {
+    return agg_forward_impl(feats, vals, offsets, n_bags, total_rows, max_rows, p, nullptr, false, classes_in,
+                            classes_out, A, B, pred, idx, ws, ws_bytes, stream);
+}
+
+size_t dsmil_agg_packed_bf16_bytes(int32_t K) {
+    if (K <= 0) return 0;
+    const size_t K64 = ((size_t)K + 63) / 64 * 64;
+    return (QD * K64 + QD * QD) * sizeof(bf16_t);
+}
+
+int dsmil_agg_pack_bf16(const float* q0_w, const float* q2_w, int32_t K, void* packed, void* stream) {
+    if (!q0_w || !packed || K <= 0) return DSMIL_E_INVALID;
+    const int K64 = (K + 63) / 64 * 64;
+    hipLaunchKernelGGL(k_pack_agg_bf16, dim3(256), dim3(256), 0, (hipStream_t)stream, q0_w, q2_w,
+                       (bf16_t*)packed, K, K64);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
+int dsmil_agg_forward_bf16(const void* feats_bf16, const void* vals_bf16, const int64_t* offsets,
+                           int32_t n_bags, int64_t total_rows, int64_t max_rows,
+                           const dsmil_agg_params* p, const void* packed, const float* classes_in,
+                           float* classes_out, float* A, float* B, float* pred, int64_t* idx, void* ws,
+                           size_t ws_bytes, void* stream) {
+    return agg_forward_impl(feats_bf16, vals_bf16, offsets, n_bags, total_rows, max_rows, p, packed, true,
+                            classes_in, classes_out, A, B, pred, idx, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

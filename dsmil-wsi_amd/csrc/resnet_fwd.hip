@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 #include "dsmil_hip.h"
 #include "prof.h"
 
@@ -82,27 +83,35 @@ struct ConvArgs {
     long long Mtot;
 };
 
-template <int NT, bool NORM>
+// MW = m-tiles (of 32 pixels) per workgroup (4 -> 128 px, 2 -> 64 px); the 4 waves form an
+// MW x (4/MW) grid, each wave owning 32 pixels x NT*32 channels.  <4,4>: 128x128, <4,2>: 128x64,
+// <2,1>: 64x64 (finer work units for the late layers, whose 128x128 tiling yields only 392
+// workgroups for 256 CUs).
+template <int MW, int NT, bool NORM, int NBUF = 2>
 __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
-    constexpr int TN = NT * 32;
-    constexpr int WPT = (TN * 8) / 256;  // float4 per thread per weight chunk
-    constexpr int X_TILE = 128 * LDK, W_TILE = TN * LDK;
+    constexpr int NWN = 4 / MW;
+    constexpr int BM = MW * 32;
+    constexpr int TN = NWN * NT * 32;
+    constexpr int XPT = BM / 32;  // float4 per thread per activation chunk
+    constexpr int WPT = TN / 32;  // float4 per thread per weight chunk
+    constexpr int X_TILE = BM * LDK, W_TILE = TN * LDK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sX = smem;                // [2][X_TILE]
-    float* sW = smem + 2 * X_TILE;   // [2][W_TILE]
+    float* sX = smem;                   // [NBUF][X_TILE]
+    float* sW = smem + NBUF * X_TILE;   // [NBUF][W_TILE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % MW, wn = wave / MW;
     const int l31 = lane & 31, hi = lane >> 5;
-    const long long m0 = (long long)blockIdx.x * 128;
+    const long long m0 = (long long)blockIdx.x * BM;
     const int n0 = blockIdx.y * TN;
     const int HW = a.Ho * a.Wo;
     const int taps = a.ks * a.ks;
     const int nsteps = taps * (a.Cin / BK);
     const int c4 = tid & 7;
 
-    // per-thread pixel metadata for the 4 rows it stages
-    int iy0[4], ix0[4], nb[4], nimg[4];
+    // per-thread pixel metadata for the rows it stages
+    int iy0[XPT], ix0[XPT], nb[XPT], nimg[XPT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < XPT; ++i) {
         const long long p = m0 + (tid >> 3) + 32 * i;
         if (p < a.Mtot) {
             const int n = (int)(p / HW), rem = (int)(p - (long long)n * HW);
@@ -115,8 +124,8 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
             iy0[i] = -100000; ix0[i] = -100000; nb[i] = 0; nimg[i] = 0;
         }
     }
-    f32x4 xreg[4], wreg[WPT];
-    f32x4 mu[4], rs[4];
+    f32x4 xreg[XPT], wreg[WPT];
+    f32x4 mu[XPT], rs[XPT];
     unsigned okmask = 0;  // bit i: tap of row i is inside the image (else zero padding)
     // stage_load only ISSUES the global loads (branch-free, clamped addresses) so that they fly
     // under this step's MFMAs; normalisation, padding select and the LDS write happen in
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         if constexpr (NORM) {
             if (tap == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < XPT; ++i) {
                     mu[i] = *reinterpret_cast<const f32x4*>(a.in_mean + (long long)nimg[i] * a.Cin + c0);
                     rs[i] = *reinterpret_cast<const f32x4*>(a.in_rstd + (long long)nimg[i] * a.Cin + c0);
                 }
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         }
         okmask = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < XPT; ++i) {
             const int iy = iy0[i] + kh, ix = ix0[i] + kw;
             const bool ok = (iy >= 0) && (iy < a.H) && (ix >= 0) && (ix < a.W);
             okmask |= ok ? (1u << i) : 0u;
@@ -150,10 +159,10 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         }
     };
     auto stage_write = [&](int st) {
-        float* x = sX + (st & 1) * X_TILE;
-        float* w = sW + (st & 1) * W_TILE;
+        float* x = sX + (st & (NBUF - 1)) * X_TILE;
+        float* w = sW + (st & (NBUF - 1)) * W_TILE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < XPT; ++i) {
             f32x4 v = xreg[i];
             const bool ok = (okmask >> i) & 1u;
 #pragma unroll
@@ -180,8 +189,8 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     const int frag = l31 * LDK + 4 * hi;
     for (int st = 0; st < nsteps; ++st) {
         if (st + 1 < nsteps) stage_load(st + 1);
-        const float* x = sX + (st & 1) * X_TILE + wave * 32 * LDK + frag;
-        const float* w = sW + (st & 1) * W_TILE + frag;
+        const float* x = sX + (st & (NBUF - 1)) * X_TILE + wm * 32 * LDK + frag;
+        const float* w = sW + (st & (NBUF - 1)) * W_TILE + wn * NT * 32 * LDK + frag;
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
             const f32x4 xa = *reinterpret_cast<const f32x4*>(x + kg * 8);
@@ -193,14 +202,16 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j], wb[j], acc[t], 0, 0, 0);
             }
         }
+        if constexpr (NBUF == 1) __syncthreads();  // single LDS buffer: everyone done reading first
         if (st + 1 < nsteps) stage_write(st + 1);
         __syncthreads();
     }
     // ---- epilogue: raw store (128-B coalesced per half-wave) + statistics partials
-    const long long tbase = m0 + wave * 32;  // first flattened pixel of this wave's tile
+    const long long tbase = m0 + wm * 32;  // first flattened pixel of this wave's tile
+    const int cbase = n0 + wn * NT * 32;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int co = n0 + t * 32 + l31;
+        const int co = cbase + t * 32 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long long p = tbase + drow(r, hi);
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
                 float mean = 0.f, m2 = 0.f;
                 if (hi_ > lo) tile_stats(acc[t], hi, (int)lo, (int)hi_, mean, m2);
                 if (hi == 0) {
-                    float* o = a.part + ((tile32 * a.nslots + s) * a.Cout + n0 + t * 32 + l31) * 2;
+                    float* o = a.part + ((tile32 * a.nslots + s) * a.Cout + cbase + t * 32 + l31) * 2;
                     o[0] = mean;
                     o[1] = m2;
                 }
@@ -229,32 +240,54 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     }
 }
 
-// partials of flattened 32-pixel tiles -> mean / rstd per (image, channel)
-__global__ void k_in_finalize_flat(const float* __restrict__ part, float* __restrict__ mean,
-                                   float* __restrict__ rstd, int B, int HW, int C, int nslots,
-                                   long long Mtot) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C) return;
-    const int n = i / C, c = i - n * C;
+// partials of flattened 32-pixel tiles -> mean / rstd per (image, channel).  One workgroup per
+// image; thread (c mod 64, g) sums the tiles t = g mod 4 of its channel: first the weighted means,
+// then M2 about the image mean (M2 = sum M2_t + cnt_t (mean_t - mean)^2) — two flat reductions,
+// no serial Chan chain.
+__global__ __launch_bounds__(256) void k_in_finalize_flat(const float* __restrict__ part, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, int B, int HW, int C,
+                                                         int nslots, long long Mtot) {
+    const int n = blockIdx.x;
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long long ibeg = (long long)n * HW, iend = ibeg + HW;
     const long long t0 = ibeg >> 5, t1 = (iend - 1) >> 5;
-    float cnt = 0.f, mu = 0.f, m2 = 0.f;
-    for (long long t = t0; t <= t1; ++t) {
-        const long long tb = t << 5;
-        const int s = n - (int)(tb / HW);
-        long long lo = ibeg - tb, hi = ((iend < Mtot) ? iend : Mtot) - tb;
-        if (lo < 0) lo = 0;
-        if (hi > 32) hi = 32;
-        if (hi <= lo || s < 0 || s >= nslots) continue;
-        const float* o = part + ((t * nslots + s) * C + c) * 2;
-        const float cb = (float)(hi - lo), mb = o[0], qb = o[1];
-        const float tot = cnt + cb, d = mb - mu;
-        mu += d * (cb / tot);
-        m2 += qb + d * d * (cnt * cb / tot);
-        cnt = tot;
+    __shared__ float red[4][64];
+    for (int c = cl; c < C; c += 64) {
+        float s = 0.f;
+        for (long long t = t0 + g; t <= t1; t += 4) {
+            const long long tb = t << 5;
+            const int sl = n - (int)(tb / HW);
+            long long lo = ibeg - tb, hi = ((iend < Mtot) ? iend : Mtot) - tb;
+            if (lo < 0) lo = 0;
+            if (hi > 32) hi = 32;
+            if (hi <= lo || sl < 0 || sl >= nslots) continue;
+            s += (float)(hi - lo) * part[((t * nslots + sl) * C + c) * 2];
+        }
+        __syncthreads();
+        red[g][cl] = s;
+        __syncthreads();
+        const float mu = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)HW;
+        float q = 0.f;
+        for (long long t = t0 + g; t <= t1; t += 4) {
+            const long long tb = t << 5;
+            const int sl = n - (int)(tb / HW);
+            long long lo = ibeg - tb, hi = ((iend < Mtot) ? iend : Mtot) - tb;
+            if (lo < 0) lo = 0;
+            if (hi > 32) hi = 32;
+            if (hi <= lo || sl < 0 || sl >= nslots) continue;
+            const float* o = part + ((t * nslots + sl) * C + c) * 2;
+            const float d = o[0] - mu;
+            q += o[1] + (float)(hi - lo) * d * d;
+        }
+        __syncthreads();
+        red[g][cl] = q;
+        __syncthreads();
+        if (g == 0) {
+            const float m2 = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+            mean[(long long)n * C + c] = mu;
+            rstd[(long long)n * C + c] = 1.0f / sqrtf(m2 / (float)HW + IN_EPS);
+        }
     }
-    mean[i] = mu;
-    rstd[i] = 1.0f / sqrtf(m2 / cnt + IN_EPS);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -367,23 +400,36 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
     }
 }
 
-__global__ void k_in_finalize_stem(const float* __restrict__ part, float* __restrict__ mean,
-                                   float* __restrict__ rstd, int B, int nparts) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * 64) return;
-    const int n = i >> 6, c = i & 63;
-    float cnt = 0.f, mu = 0.f, m2 = 0.f;
-    for (int t = 0; t < nparts; ++t) {
+// stem partials (cnt, mean, M2) -> mean / rstd; one workgroup per image, 64 channels x 4 tile groups
+__global__ __launch_bounds__(256) void k_in_finalize_stem(const float* __restrict__ part, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, int B, int nparts) {
+    const int n = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    __shared__ float red[2][4][64];
+    float s = 0.f, cnt = 0.f;
+    for (int t = g; t < nparts; t += 4) {
         const float* o = part + (((long long)n * nparts + t) * 64 + c) * 3;
-        const float cb = o[0];
-        if (cb <= 0.f) continue;
-        const float tot = cnt + cb, d = o[1] - mu;
-        mu += d * (cb / tot);
-        m2 += o[2] + d * d * (cnt * cb / tot);
-        cnt = tot;
+        s += o[0] * o[1];
+        cnt += o[0];
     }
-    mean[i] = mu;
-    rstd[i] = 1.0f / sqrtf(m2 / cnt + IN_EPS);
+    red[0][g][c] = s;
+    red[1][g][c] = cnt;
+    __syncthreads();
+    const float tot = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    const float mu = ((red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c])) / tot;
+    float q = 0.f;
+    for (int t = g; t < nparts; t += 4) {
+        const float* o = part + (((long long)n * nparts + t) * 64 + c) * 3;
+        const float d = o[1] - mu;
+        q += o[2] + o[0] * d * d;
+    }
+    __syncthreads();
+    red[0][g][c] = q;
+    __syncthreads();
+    if (g == 0) {
+        const float m2 = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        mean[n * 64 + c] = mu;
+        rstd[n * 64 + c] = 1.0f / sqrtf(m2 / tot + IN_EPS);
+    }
 }
 
 // IN + ReLU + MaxPool2d(3, stride 2, pad 1) of the raw stem output, NHWC, C = 64
@@ -553,24 +599,41 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
     const int HW = a.Ho * a.Wo;
     a.nslots = 31 / HW + 2;
     a.Mtot = (long long)B * HW;
-    const unsigned gx = (unsigned)((a.Mtot + 127) / 128);
     const bool norm = in_mean != nullptr;
     const int slot = dsmil_prof::begin(dsmil_prof::CH_CONV, st);
-    if (s.cout == 64) {
+    // tile choice: 128x64 for Cout = 64; 128x128 while that yields >= 4 workgroups per CU;
+    // 64x64 (finer units, less tail quantisation) for the small late-layer maps
+    const long long blocks128 = ((a.Mtot + 127) / 128) * (s.cout / 128 > 0 ? s.cout / 128 : 1);
+    static const int expt = getenv("DSMIL_CONV_EXPT") ? atoi(getenv("DSMIL_CONV_EXPT")) : 0;
+    if (s.cout == 64 && (expt & 1)) {
+        const size_t lds = (size_t)(128 * LDK + 64 * LDK) * 4;
+        dim3 grid((unsigned)((a.Mtot + 127) / 128), 1);
+        if (norm) hipLaunchKernelGGL((k_conv<4, 2, true, 1>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((k_conv<4, 2, false, 1>), grid, dim3(256), lds, st, a);
+    } else if (s.cout == 64) {
         const size_t lds = (size_t)(2 * 128 * LDK + 2 * 64 * LDK) * 4;
-        dim3 grid(gx, 1);
-        if (norm) hipLaunchKernelGGL((k_conv<2, true>), grid, dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((k_conv<2, false>), grid, dim3(256), lds, st, a);
-    } else {
+        dim3 grid((unsigned)((a.Mtot + 127) / 128), 1);
+        if (norm) hipLaunchKernelGGL((k_conv<4, 2, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((k_conv<4, 2, false>), grid, dim3(256), lds, st, a);
+    } else if (blocks128 >= 1024 && (expt & 2)) {
+        const size_t lds = (size_t)(128 * LDK + 128 * LDK) * 4;
+        dim3 grid((unsigned)((a.Mtot + 127) / 128), (unsigned)(s.cout / 128));
+        if (norm) hipLaunchKernelGGL((k_conv<4, 4, true, 1>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((k_conv<4, 4, false, 1>), grid, dim3(256), lds, st, a);
+    } else if (blocks128 >= ((expt & 4) ? 256 : 1024)) {
         const size_t lds = (size_t)(2 * 128 * LDK + 2 * 128 * LDK) * 4;
-        dim3 grid(gx, (unsigned)(s.cout / 128));
-        if (norm) hipLaunchKernelGGL((k_conv<4, true>), grid, dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((k_conv<4, false>), grid, dim3(256), lds, st, a);
+        dim3 grid((unsigned)((a.Mtot + 127) / 128), (unsigned)(s.cout / 128));
+        if (norm) hipLaunchKernelGGL((k_conv<4, 4, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((k_conv<4, 4, false>), grid, dim3(256), lds, st, a);
+    } else {
+        const size_t lds = (size_t)(2 * 64 * LDK + 2 * 64 * LDK) * 4;
+        dim3 grid((unsigned)((a.Mtot + 63) / 64), (unsigned)(s.cout / 64));
+        if (norm) hipLaunchKernelGGL((k_conv<2, 1, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((k_conv<2, 1, false>), grid, dim3(256), lds, st, a);
     }
     dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
-    const int n = B * s.cout;
-    hipLaunchKernelGGL(k_in_finalize_flat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, mean, rstd,
+    hipLaunchKernelGGL(k_in_finalize_flat, dim3((unsigned)B), dim3(256), 0, st, part, mean, rstd,
                        B, HW, s.cout, a.nslots, a.Mtot);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
@@ -579,10 +642,10 @@ bool g_attr_done = false;
 void set_conv_attrs() {
     if (g_attr_done) return;
     const int l4 = (2 * 128 * LDK + 2 * 128 * LDK) * 4, l2 = (2 * 128 * LDK + 2 * 64 * LDK) * 4;
-    (void)hipFuncSetAttribute((const void*)k_conv<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
-    (void)hipFuncSetAttribute((const void*)k_conv<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
-    (void)hipFuncSetAttribute((const void*)k_conv<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
-    (void)hipFuncSetAttribute((const void*)k_conv<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
+    (void)hipFuncSetAttribute((const void*)k_conv<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
+    (void)hipFuncSetAttribute((const void*)k_conv<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
+    (void)hipFuncSetAttribute((const void*)k_conv<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
+    (void)hipFuncSetAttribute((const void*)k_conv<4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
     g_attr_done = true;
 }
 
@@ -641,7 +704,7 @@ int dsmil_resnet18in_forward(const float* x_nchw, int32_t B, int32_t H, int32_t 
         hipLaunchKernelGGL(k_stem, dim3((unsigned)(tx * ty), (unsigned)B), dim3(256), 0, st, x_nchw, conv1_w, y0,
                            part, B, H, W, d.H1, d.W1, tx, ty);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
-        hipLaunchKernelGGL(k_in_finalize_stem, dim3((unsigned)((B * 64 + 255) / 256)), dim3(256), 0, st, part,
+        hipLaunchKernelGGL(k_in_finalize_stem, dim3((unsigned)B), dim3(256), 0, st, part,
                            mean[0], rstd[0], B, tx * ty * 4);
         const long long total = (long long)B * d.Hp * d.Wp * 16;
         long long blocks = (total + 255) / 256;

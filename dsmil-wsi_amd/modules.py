@@ -174,6 +174,8 @@ class _FCFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
+        if x.dtype != torch.float32:  # non-fp32 rows (bf16 storage): f32 accumulate, result in x.dtype
+            return ops.fc_forward(x.detach().float(), w.detach().float(), b.detach().float()).to(x.dtype)
         return ops.fc_forward(x.detach(), w.detach(), b.detach())
 
     @staticmethod
@@ -199,6 +201,13 @@ class _AggFunction(torch.autograd.Function):
         N = feats.shape[0]
         classes, pred, A, B, idx = ops.agg_forward(feats.detach(), [N], w, classes_in=det(c_in),
                                                    vals=det(vals), nonlinear=nonlinear)
+        if feats.dtype == torch.bfloat16:
+            # bf16-storage path (BASELINE config 2) is inference only; results keep the input dtype
+            ctx.bf16 = True
+            out = tuple(t.to(torch.bfloat16) for t in (classes, pred, A, B))
+            ctx.mark_non_differentiable(*out, idx)
+            return (*out, idx)
+        ctx.bf16 = False
         ctx.nonlinear = nonlinear
         ctx.has_cin = c_in is not None
         ctx.has_vals = vals is not None
@@ -208,6 +217,8 @@ class _AggFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_cls, g_pred, g_A, g_B, _g_idx):
+        if ctx.bf16:
+            raise NotImplementedError("the bf16-storage aggregator path is inference only")
         feats, vals, fc_w, q0_w, q0_b, q2_w, q2_b, fcc_w, A, B, idx = ctx.saved_tensors
         x = feats
         V = vals if ctx.has_vals else feats

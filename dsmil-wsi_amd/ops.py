@@ -76,14 +76,47 @@ def fc_forward(feats, fc_w, fc_b):
     return out
 
 
-def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, offsets=None):
-    """dsmil_agg_forward over a batch of bags stored back to back.
+_bf16_cache = {}
 
-    feats [total,K] fp32 CUDA; lengths: python ints (bag sizes); w: dict of CUDA fp32 tensors with
+
+def _bf16_params(w, nonlinear, dev):
+    """bf16 path: every weight/bias rounded to bf16 (what module.bfloat16() would hold), kept as
+    fp32 tensors for the f32-accumulating stages + the packed bf16 MFMA operands.  Cached per
+    parameter set (data_ptr, _version)."""
+    names = ("fc_w", "fc_b", "q0_w", "q0_b", "q2_w", "q2_b", "fcc_w", "fcc_b")
+    key = tuple((w[k].data_ptr(), w[k]._version) if w.get(k) is not None else None for k in names)
+    ent = _bf16_cache.get(str(dev))
+    if ent is not None and ent[0] == key:
+        return ent[1], ent[2]
+    r = {k: (w[k].detach().to(torch.bfloat16).to(torch.float32).contiguous() if w.get(k) is not None else None)
+         for k in names}
+    L = _native.lib()
+    K = r["q0_w"].shape[1]
+    packed = torch.empty(L.dsmil_agg_packed_bf16_bytes(K), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.dsmil_agg_pack_bf16(_ptr(r["q0_w"]), _ptr(r["q2_w"] if nonlinear else None), K, _ptr(packed),
+                                   _stream(dev))
+    _native.check(rc, "dsmil_agg_pack_bf16")
+    _bf16_cache[str(dev)] = (key, r, packed)
+    return r, packed
+
+
+def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, offsets=None):
+    """dsmil_agg_forward / dsmil_agg_forward_bf16 over a batch of bags stored back to back.
+
+    feats [total,K] fp32 or bf16 CUDA; lengths: python ints (bag sizes); w: dict of CUDA tensors with
     keys fc_w fc_b q0_w q0_b q2_w q2_b fcc_w fcc_b (fc_* may be None when classes_in is given).
+    A bf16 `feats` selects the bf16-storage path (BASELINE config 2): weights are rounded to bf16,
+    accumulation stays f32, outputs are fp32.
     Returns (classes [total,C], pred [n_bags,C], A [total,C], B [n_bags,C,Kv], idx int64 [n_bags,C]).
     """
-    feats = _f32c(feats, "feats")
+    bf16 = feats.dtype == torch.bfloat16
+    if not feats.is_cuda:
+        raise RuntimeError("feats must be a CUDA(HIP) tensor for the native path")
+    if bf16:
+        feats = feats if feats.is_contiguous() else feats.contiguous()
+    else:
+        feats = _f32c(feats, "feats")
     dev = feats.device
     total, K = feats.shape
     lengths = [int(n) for n in lengths]
@@ -93,15 +126,24 @@ def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, o
         raise ValueError("every bag needs at least one instance (the reference's sort/index_select "
                          "at dsmil.py:52-53 fails on an empty bag too)")
     n_bags = len(lengths)
-    vals = feats if vals is None else _f32c(vals, "vals")
+    if vals is None:
+        vals = feats
+    elif bf16:
+        vals = vals.to(torch.bfloat16).contiguous()
+    else:
+        vals = _f32c(vals, "vals")
     Kv = vals.shape[1]
+    packed = None
+    if bf16:
+        w, packed = _bf16_params(w, nonlinear, dev)
     fcc_w = _f32c(w["fcc_w"], "fcc_w")
     C = fcc_w.shape[0]
     if fcc_w.shape[2] != Kv:
         raise ValueError(f"fcc kernel_size {fcc_w.shape[2]} != value width {Kv}")
-    classes_in = _f32c(classes_in, "classes_in")
-    if classes_in is not None and tuple(classes_in.shape) != (total, C):
-        raise ValueError(f"c must be [{total},{C}], got {tuple(classes_in.shape)}")
+    if classes_in is not None:
+        classes_in = _f32c(classes_in.float(), "classes_in")
+        if tuple(classes_in.shape) != (total, C):
+            raise ValueError(f"c must be [{total},{C}], got {tuple(classes_in.shape)}")
     keep = [_f32c(w.get(k), k) for k in ("fc_w", "fc_b", "q0_w", "q0_b", "q2_w", "q2_b", "fcc_w", "fcc_b")]
     p = _native.AggParams(*[(t.data_ptr() if t is not None else 0) for t in keep],
                           K, Kv, C, 1 if nonlinear else 0)
@@ -115,12 +157,19 @@ def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, o
     nbytes = L.dsmil_agg_workspace_bytes(n_bags, total, K, Kv, C)
     ws = _workspace(dev, nbytes)
     with torch.cuda.device(dev):
-        rc = L.dsmil_agg_forward(_ptr(feats), _ptr(vals), _ptr(off), n_bags, total, max(lengths),
-                                 ctypes.byref(p), _ptr(classes_in),
-                                 _ptr(classes if classes_in is None else None),
-                                 _ptr(A), _ptr(B), _ptr(pred), _ptr(idx), _ptr(ws), ws.numel(),
-                                 _stream(dev))
-    _native.check(rc, "dsmil_agg_forward")
+        if bf16:
+            rc = L.dsmil_agg_forward_bf16(_ptr(feats), _ptr(vals), _ptr(off), n_bags, total, max(lengths),
+                                          ctypes.byref(p), _ptr(packed), _ptr(classes_in),
+                                          _ptr(classes if classes_in is None else None),
+                                          _ptr(A), _ptr(B), _ptr(pred), _ptr(idx), _ptr(ws), ws.numel(),
+                                          _stream(dev))
+        else:
+            rc = L.dsmil_agg_forward(_ptr(feats), _ptr(vals), _ptr(off), n_bags, total, max(lengths),
+                                     ctypes.byref(p), _ptr(classes_in),
+                                     _ptr(classes if classes_in is None else None),
+                                     _ptr(A), _ptr(B), _ptr(pred), _ptr(idx), _ptr(ws), ws.numel(),
+                                     _stream(dev))
+    _native.check(rc, "dsmil_agg_forward_bf16" if bf16 else "dsmil_agg_forward")
     del keep
     return classes, pred, A, B, idx
 

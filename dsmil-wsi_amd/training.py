@@ -211,7 +211,7 @@ def save_model(args, fold, run, save_path, model, thresholds_optimal):
 def fit(args, mil, device, train_path, val_path, tag, run, save_path, cache, keep_best=False):
     """The epoch loop shared by the three schemes (train_tcga.py:272-287 and its two copies)."""
     milnet, criterion, optimizer, scheduler = init_model(args, mil, device)
-    best_score, best_ac, best_auc, counter, best = 0, 0, 0, 0, None
+    best_score, best_ac, best_auc, counter, best = 0, 0, [0.0] * args.num_classes, 0, None
     for epoch in range(1, args.num_epochs + 1):
         counter += 1
         train_loss = train(args, train_path, milnet, criterion, optimizer, cache)

@@ -85,6 +85,21 @@ int dsmil_agg_forward(const float* feats, const float* vals, const int64_t* offs
 size_t dsmil_agg_workspace_bytes(int32_t n_bags, int64_t total_rows, int32_t K, int32_t Kv,
                                  int32_t C);
 
+/* bf16-storage variant (BASELINE.json configs[2]: "2-class DSMIL aggregator bf16"; the reference
+ * itself is fp32 only).  feats/vals are bfloat16 [total_rows,K] / [total_rows,Kv]; the query MLP
+ * runs on bf16 MFMA with f32 accumulation from `packed` (dsmil_agg_pack_bf16: q0_w/q2_w rounded
+ * to bf16, RNE); instance logits, scores, softmax, value sum and the bag head accumulate in f32
+ * from the fp32 pointers in *p (the caller passes bf16-rounded values there if it wants the
+ * "everything rounded to bf16" semantics of module.bfloat16()).  Outputs are fp32.
+ * Requires K % 8 == 0 and Kv % 4 == 0 (else DSMIL_E_UNSUPPORTED). */
+size_t dsmil_agg_packed_bf16_bytes(int32_t K);
+int dsmil_agg_pack_bf16(const float* q0_w, const float* q2_w, int32_t K, void* packed, void* stream);
+int dsmil_agg_forward_bf16(const void* feats_bf16, const void* vals_bf16, const int64_t* offsets,
+                           int32_t n_bags, int64_t total_rows, int64_t max_rows,
+                           const dsmil_agg_params* p, const void* packed, const float* classes_in,
+                           float* classes_out, float* A, float* B, float* pred, int64_t* idx, void* ws,
+                           size_t ws_bytes, void* stream);
+
 /* FCLayer.forward alone (dsmil.py:10-12): classes[total_rows, C] = feats @ fc_w^T + fc_b. */
 int dsmil_fc_forward(const float* feats, int64_t total_rows, int32_t K, int32_t C,
                      const float* fc_w, const float* fc_b, float* classes, void* stream);
