@@ -80,6 +80,15 @@ def cpu_baseline(weights, N, K, C, budget_s):
             "sample": f"{n} forwards of a {N}x{K} fp32 bag (C={C}) by oracle/agg_oracle.py (numpy/BLAS) in {el:.1f}s"}
 
 
+def _pmc(name, key):
+    """HBM bytes from the committed PMC summary (profiles/): (2*FETCH_SIZE + WRITE_SIZE), or None."""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(path)).get(key)
+    except Exception:
+        return None
+
+
 FLOPS_PER_PATCH = 3627122688          # 2 x 1 813 561 344 MAC, 20 convs (SURVEY.md §8d)
 STEM_FLOPS_PER_PATCH = 2 * 12544 * 64 * 147
 
@@ -165,7 +174,8 @@ def embedder_leg(args, dev, rank, world, dist, L):
                        "collective": "all_gather_into_tensor([%d,512] f32) per step" % Bp if world > 1 else "none"},
             "roofline": {"kernel": "k_conv (19 implicit-GEMM convs per forward)", "bound": "mfma",
                          "achieved": round(ach, 2) if ach else None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4) if ach else None, "traffic": None,
+                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4) if ach else None,
+                         "traffic": _pmc("pmc_k_conv.json", "hbm_bytes_per_forward"),
                          "kernel_ms_total": round(tot_ms.value, 3), "launches": int(launches.value),
                          "alg_flops_total": conv_flops,
                          "whole_path_frac_of_roofline": round(value / world / (PEAK_F32_MFMA_TFLOPS * 1e12 / FLOPS_PER_PATCH), 4)}}
@@ -263,13 +273,7 @@ def main():
         kern_ms = tot_ms.value / max(1, launches.value)
         fl = attend_flops_per_bag(N, K, C) * nb
         achieved = fl / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_k_query_attend.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = _pmc("pmc_k_query_attend.json", "hbm_bytes_per_launch") if (nb, N, K) == (64, 10000, 512) else None
         line = {
             "metric": "bags/sec aggregated (10kx512)", "value": round(value, 1), "unit": "bags/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
