@@ -404,7 +404,7 @@ __device__ __forceinline__ void attend_tail(const AttendArgs& a, const f32x16 (&
         for (int k0 = 0; k0 < ((a.expt & 1) ? 0 : Kv); k0 += 512) {
             f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
             const int ka = k0 + lane * 4, kb = ka + 256;
-#pragma unroll 4
+#pragma unroll 8
             for (int n = 0; n < 32; ++n) {
                 long long r = wrow0 + n;
                 if (r >= Nb) r = Nb - 1;  // weight is 0 there
@@ -446,11 +446,13 @@ __device__ __forceinline__ void attend_tail(const AttendArgs& a, const f32x16 (&
 
 template <int NW, int VEC>
 __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(AttendArgs a) {
+    static_assert(NW == 1 || NW == 4 || NW == 8, "tile geometries: 32, 128 or 256 rows");
     constexpr int T = NW * 64;
     constexpr int BM = NW * 32;
     constexpr int X_TILE = BM * LDK;
-    constexpr int WPT = (QD * (BK / 4)) / T;  // float4 per thread per weight chunk
+    constexpr int WPT = (QD * (BK / 4)) / T;  // float4 per thread per weight chunk (4 or 16)
     constexpr int XPT = (BM * (BK / 4)) / T;  // == 4
+    constexpr int WPS = WPT >= 4 ? WPT / 4 : 1;  // weight float4 per pipeline slot (slots past WPT idle)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sW = smem;               // [2][W_TILE]
     float* sX = smem + 2 * W_TILE;  // [2][X_TILE]
@@ -466,55 +468,70 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
     const int K = a.K;
     const int nk1 = (K + BK - 1) / BK;
     const int nk = nk1 + (a.nonlinear ? QD / BK : 0);
+    const float* feats = reinterpret_cast<const float*>(a.feats);
+    const int c4 = tid & 7;
 
+    // Staging pipeline, distance 2, ONE register set (write-then-reissue):
+    //   iteration ci:  MFMAs on LDS buffer ci&1  ||  registers (chunk ci+1, loaded during
+    //   iteration ci-1) -> LDS buffer (ci+1)&1  ||  global loads of chunk ci+2 -> same registers.
+    // Each of the 4 k-groups of a chunk carries one slot (1/4 of the chunk's registers), placed
+    // behind that k-group's MFMAs so address arithmetic, ds_write and load issue hide under the
+    // 64-cycle MFMAs instead of forming a bubble at the chunk boundary.  One barrier per chunk.
     f32x4 wreg[WPT], xreg[XPT];
-    bool kok = true;  // this thread's k-slice of the staged chunk lies inside the weight row
-    // stage_load only ISSUES global loads (clamped addresses, no branches) so they stay in flight
-    // under the MFMAs of the current chunk; stage_write zeroes the weight k-tail (K % 32 != 0)
-    // and moves the registers to LDS.  Feature values beyond K are multiplied by those zeros.
-    auto stage_load = [&](int ci) {
-        const float* wb;
-        int ld, k0, klim;
+    bool kok = true;                 // weight k-slice of the chunk held in registers is in range
+    const float* xrow[XPT];
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        long long gr = row0 + ((tid + T * i) >> 3);
+        if (gr >= Nb) gr = Nb - 1;   // clamp: rows past the bag end are masked later
+        xrow[i] = feats + (off0 + gr) * (long long)K;
+    }
+    auto chunk_src = [&](int ci, const float*& wb, int& ld, int& k, int& klim) {
+        int k0;
         if (ci < nk1) { wb = a.q0_w; ld = K; k0 = ci * BK; klim = K; }
         else { wb = a.q2_w; ld = QD; k0 = (ci - nk1) * BK; klim = QD; }
-        const int k = k0 + (tid & 7) * 4;
-        kok = k < klim;
+        k = k0 + c4 * 4;
+    };
+    // issue the loads of pipeline slot q of chunk ci.  Branch-free on purpose (a branch around a
+    // load makes hipcc fall back to vmcnt(0) waits): past the last chunk the last one is simply
+    // re-loaded, and `with_x` is a literal at every call site.
+    auto load_slot = [&](int ci, int q, const bool with_x) {
+        const int cw = ci < nk ? ci : nk - 1;
+        const float* wb; int ld, k, klim;
+        chunk_src(cw, wb, ld, k, klim);
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int r = (tid + T * i) >> 3;
-            wreg[i] = load4_clamped<VEC>(wb + (long long)r * ld, k, klim);
+        for (int j = 0; j < WPS; ++j) {
+            const int i = q * WPS + j;
+            if (i < WPT) wreg[i] = load4_clamped<VEC>(wb + (long long)((tid + T * i) >> 3) * ld, k, klim);
         }
-        if (ci < nk1) {
-#pragma unroll
-            for (int i = 0; i < XPT; ++i) {
-                const int r = (tid + T * i) >> 3;
-                long long gr = row0 + r;
-                if (gr >= Nb) gr = Nb - 1;  // clamp: rows past the bag end are masked later
-                xreg[i] = load4_clamped<VEC>(reinterpret_cast<const float*>(a.feats) + (off0 + gr) * (long long)K, k, klim);
-            }
+        if (with_x) {
+            const int cx = ci < nk1 ? ci : nk1 - 1;
+            xreg[q] = load4_clamped<VEC>(xrow[q], cx * BK + c4 * 4, K);
         }
     };
-    auto stage_write = [&](int ci) {
+    // move pipeline slot q of the chunk held in registers (chunk ci) to its LDS buffer; past the
+    // last chunk this writes into a buffer nobody reads any more
+    auto write_slot = [&](int ci, int q, bool ok, const bool with_x) {
         float* w = sW + (ci & 1) * W_TILE;
-        const int c4 = tid & 7;
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int r = (tid + T * i) >> 3;
-            f32x4 v = wreg[i];
-            if constexpr (VEC == 4) {
+        for (int j = 0; j < WPS; ++j) {
+            const int i = q * WPS + j;
+            if (i < WPT) {
+                f32x4 v = wreg[i];
+                if constexpr (VEC == 4) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = kok ? v[e] : 0.f;
-            }
-            *reinterpret_cast<f32x4*>(w + r * LDK + c4 * 4) = v;
-        }
-        if (ci < nk1) {
-            float* x = sX + (ci & 1) * X_TILE;
-#pragma unroll
-            for (int i = 0; i < XPT; ++i) {
-                const int r = (tid + T * i) >> 3;
-                *reinterpret_cast<f32x4*>(x + r * LDK + c4 * 4) = xreg[i];
+                    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;   // zero the weight k-tail
+                }
+                *reinterpret_cast<f32x4*>(w + ((tid + T * i) >> 3) * LDK + c4 * 4) = v;
             }
         }
+        if (with_x)
+            *reinterpret_cast<f32x4*>(sX + (ci & 1) * X_TILE + ((tid + T * q) >> 3) * LDK + c4 * 4) = xreg[q];
+    };
+    auto k_in_range = [&](int ci) {
+        const float* wb; int ld, k, klim;
+        chunk_src(ci < nk ? ci : nk - 1, wb, ld, k, klim);
+        return k < klim;
     };
 
     f32x16 H[4];
@@ -523,15 +540,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
 #pragma unroll
         for (int r = 0; r < 16; ++r) H[t][r] = 0.f;
 
-    stage_load(0);
-    stage_write(0);
+    // prologue: chunk 0 -> LDS, chunk 1 -> registers
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_slot(0, q, true);
+    kok = k_in_range(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) write_slot(0, q, kok, true);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_slot(1, q, true);
+    kok = k_in_range(1);
     __syncthreads();
     const int frag_off = l31 * LDK + 4 * hi;  // this lane's row / k-half inside a chunk
     // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] * X[n][k]
     for (int ci = 0; ci < nk1; ++ci) {
-        if (ci + 1 < nk && !(a.expt & 8)) stage_load(ci + 1);
         const float* w = sW + (ci & 1) * W_TILE + frag_off;
         const float* x = sX + (ci & 1) * X_TILE + wave * 32 * LDK + frag_off;
+        const bool kok_next = k_in_range(ci + 2);
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
             const f32x4 xb = *reinterpret_cast<const f32x4*>(x + kg * 8);
@@ -539,14 +563,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
             for (int t = 0; t < 4; ++t) {
                 const f32x4 wa = *reinterpret_cast<const f32x4*>(w + t * 32 * LDK + kg * 8);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    H[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xb[j], H[t], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) H[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xb[j], H[t], 0, 0, 0);
             }
+            write_slot(ci + 1, kg, kok, true);
+            load_slot(ci + 2, kg, true);
+            __builtin_amdgcn_sched_barrier(0);  // keep each slot inside its own k-group
         }
-        if (!(a.expt & 16)) {
-            if (ci + 1 < nk) stage_write(ci + 1);
-            __syncthreads();
-        }
+        kok = kok_next;
+        __syncthreads();
     }
     // ---- bias (+ReLU): H^T row j = 32t + 8g + 4hi + e  for reg r = 4g + e
 #pragma unroll
@@ -571,8 +595,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int ci = nk1 + t;
-            if (t < 3) stage_load(ci + 1);
             const float* w = sW + (ci & 1) * W_TILE + frag_off;
+            const bool kok_next = k_in_range(ci + 2);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -582,8 +606,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
                     for (int e = 0; e < 4; ++e)
                         Q[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[e], H[t][4 * g + e], Q[t2], 0, 0, 0);
                 }
+                write_slot(ci + 1, g, kok, false);
+                load_slot(ci + 2, g, false);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (t < 3) stage_write(ci + 1);
+            kok = kok_next;
             __syncthreads();
         }
 #pragma unroll
@@ -592,13 +619,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * t + 8 * g + 4 * hi);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = (a.expt & 2) ? (Q[t][4 * g + e] + b[e]) * 0.5f : tanhf(Q[t][4 * g + e] + b[e]);
+                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = tanhf(Q[t][4 * g + e] + b[e]);
             }
     } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t) Q[t] = H[t];
     }
-    if (a.expt & 4) {  // ablation: stop after the MLP (keep the accumulators live)
+    if (a.expt & 4) {  // ablation knob (DSMIL_EXPT): stop after the MLP, keep the accumulators live
         float keep = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -923,6 +950,8 @@ struct WsLayout {
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 int pick_nw(int n_bags, long long total_rows) {
+    static const int force = getenv("DSMIL_NW") ? atoi(getenv("DSMIL_NW")) : 0;  // experiments only
+    if (force == 8 || force == 4 || force == 1) return force;
     // 128-row workgroups (4 waves) once they alone give >= 2 workgroups per CU; otherwise
     // 32-row single-wave workgroups so that a lone bag still spreads over the chip.
     const long long tiles128 = total_rows / 128 + n_bags;
@@ -1085,6 +1114,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     if (const char* e = getenv("DSMIL_EXPT")) a.expt = atoi(e);
     int rc;
     if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, n_bags, st) : launch_attend_bf16<1>(a, max_rows, n_bags, st);
+    else if (NW == 8) rc = launch_attend<8, 4>(a, max_rows, n_bags, st);
     else if (NW == 4) rc = v4 ? launch_attend<4, 4>(a, max_rows, n_bags, st) : launch_attend<4, 1>(a, max_rows, n_bags, st);
     else rc = v4 ? launch_attend<1, 4>(a, max_rows, n_bags, st) : launch_attend<1, 1>(a, max_rows, n_bags, st);
     if (rc != DSMIL_OK) return rc;
