@@ -52,8 +52,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Every feature / weight / workspace pointer handed to this library is device GLOBAL memory.  Inside
+// out-of-line (noinline) device functions hipcc cannot infer that and would emit FLAT loads, whose
+// lgkmcnt accounting serialises them with the LDS reads; the hot loads therefore say so explicitly.
+#define DSMIL_GLOBAL __attribute__((address_space(1)))
+
 typedef unsigned short bf16_t;  // raw bfloat16 bits (storage type of the bf16 path)
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even, like torch .bfloat16()
     unsigned u = __float_as_uint(f);
@@ -70,7 +76,7 @@ __device__ __forceinline__ f32x4 load4(const T* __restrict__ p, int k, int klim)
     if constexpr (sizeof(T) == 2) {
         if constexpr (VEC == 4) {
             if (k < klim) {
-                const uint2 t = *reinterpret_cast<const uint2*>(p + k);
+                const u32x2 t = *(const DSMIL_GLOBAL u32x2*)(p + k);
                 v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
                 v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
             }
@@ -80,7 +86,7 @@ __device__ __forceinline__ f32x4 load4(const T* __restrict__ p, int k, int klim)
                 if (k + e < klim) v[e] = bf2f(p[k + e]);
         }
     } else if constexpr (VEC == 4) {
-        if (k < klim) v = *reinterpret_cast<const f32x4*>(p + k);
+        if (k < klim) v = *(const DSMIL_GLOBAL f32x4*)(p + k);
     } else {
         if (k + 0 < klim) v[0] = p[k + 0];
         if (k + 1 < klim) v[1] = p[k + 1];
@@ -97,7 +103,7 @@ template <int VEC>
 __device__ __forceinline__ f32x4 load4_clamped(const float* __restrict__ p, int k, int klim) {
     if constexpr (VEC == 4) {
         const int kc = k < klim ? k : klim - 4;
-        return *reinterpret_cast<const f32x4*>(p + kc);
+        return *(const DSMIL_GLOBAL f32x4*)(p + kc);
     } else {
         return load4<1>(p, k, klim);
     }
@@ -113,21 +119,20 @@ __device__ __forceinline__ bool better(float v, long long i, float bv, long long
 // One wave owns 32 rows, 4 rows in flight; lanes stride the feature axis with 16-B loads.
 // GIVEN = true: the logits are taken from classes_in (BClassifier.forward(feats, c)).
 // --------------------------------------------------------------------------------------------
+// Work of ONE 128-row tile of one bag by a 256-thread workgroup; s_v / s_i: 8-entry LDS scratch.
 template <int VEC, bool GIVEN, typename T = float>
-__global__ __launch_bounds__(256) void k_logits_argmax(
+__device__ __forceinline__ void logits_tile(
     const T* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ fc_w, const float* __restrict__ fc_b,
     const float* __restrict__ classes_in, float* __restrict__ classes_out,
-    float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C) {
-    const int bag = blockIdx.y;
+    float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C,
+    int bag, int tile, float* s_v, long long* s_i) {
     const long long off0 = offsets[bag];
     const long long Nb = offsets[bag + 1] - off0;
-    const long long row0 = (long long)blockIdx.x * R0;
+    const long long row0 = (long long)tile * R0;
     if (row0 >= Nb) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long slot = off0 / R0 + bag + blockIdx.x;
-    __shared__ float s_v[8];
-    __shared__ long long s_i[8];
+    const long long slot = off0 / R0 + bag + tile;
 
     for (int c0 = 0; c0 < C; c0 += 2) {
         const int c1 = (c0 + 1 < C) ? c0 + 1 : c0;
@@ -209,25 +214,36 @@ __global__ __launch_bounds__(256) void k_logits_argmax(
     }
 }
 
+template <int VEC, bool GIVEN, typename T = float>
+__global__ __launch_bounds__(256) void k_logits_argmax(
+    const T* __restrict__ feats, const int64_t* __restrict__ offsets,
+    const float* __restrict__ fc_w, const float* __restrict__ fc_b,
+    const float* __restrict__ classes_in, float* __restrict__ classes_out,
+    float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C, int bag0) {
+    __shared__ float s_v[8];
+    __shared__ long long s_i[8];
+    logits_tile<VEC, GIVEN, T>(feats, offsets, fc_w, fc_b, classes_in, classes_out, part_val, part_idx, K, C,
+                               bag0 + (int)blockIdx.y, (int)blockIdx.x, s_v, s_i);
+}
+
 // --------------------------------------------------------------------------------------------
 // k_qmax: one workgroup per (bag, class).  Finishes the arg-max over the bag's tile partials
 // (dsmil.py:52), then q_max = q(feats[idx]) (dsmil.py:53-54) on the VALU, 8 hidden units in
 // flight per wave so the dependent shuffle chains overlap.
 // --------------------------------------------------------------------------------------------
+// One (bag, class) by a 256-thread workgroup; s_v[4], s_i[4], s_h[128]: LDS scratch.  Ends with
+// every thread past its last LDS read (callers may reuse the scratch after a __syncthreads()).
 template <int VEC, typename T = float>
-__global__ __launch_bounds__(256) void k_qmax(
+__device__ __forceinline__ void qmax_block(
     const T* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ part_val, const long long* __restrict__ part_idx,
     const float* __restrict__ q0_w, const float* __restrict__ q0_b,
     const float* __restrict__ q2_w, const float* __restrict__ q2_b,
-    float* __restrict__ qmax, int64_t* __restrict__ idx_out, int K, int C, int nonlinear) {
-    const int bag = blockIdx.x, c = blockIdx.y;
+    float* __restrict__ qmax, int64_t* __restrict__ idx_out, int K, int C, int nonlinear,
+    int bag, int c, float* s_v, long long* s_i, float* s_h) {
     const long long off0 = offsets[bag];
     const long long Nb = offsets[bag + 1] - off0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ float s_v[4];
-    __shared__ long long s_i[4];
-    __shared__ float s_h[QD];
     const long long slot0 = off0 / R0 + bag;
     const long long ntile = (Nb + R0 - 1) / R0;
     float bv = -INFINITY;
@@ -314,7 +330,22 @@ struct AttendArgs {
     float* part_B;      // [slots, C, Kv]
     int K, Kv, C, nonlinear;
     int expt;  // DSMIL_EXPT debugging knob (0 in production): ablation switches for profiling
+    int bag0;  // first bag of this launch (chunked pipelining over bags)
 };
+
+template <int VEC, typename T = float>
+__global__ __launch_bounds__(256) void k_qmax(
+    const T* __restrict__ feats, const int64_t* __restrict__ offsets,
+    const float* __restrict__ part_val, const long long* __restrict__ part_idx,
+    const float* __restrict__ q0_w, const float* __restrict__ q0_b,
+    const float* __restrict__ q2_w, const float* __restrict__ q2_b,
+    float* __restrict__ qmax, int64_t* __restrict__ idx_out, int K, int C, int nonlinear, int bag0) {
+    __shared__ float s_v[4];
+    __shared__ long long s_i[4];
+    __shared__ float s_h[QD];
+    qmax_block<VEC, T>(feats, offsets, part_val, part_idx, q0_w, q0_b, q2_w, q2_b, qmax, idx_out, K, C, nonlinear,
+                       bag0 + (int)blockIdx.x, (int)blockIdx.y, s_v, s_i, s_h);
+}
 
 // --------------------------------------------------------------------------------------------
 // attend_tail: everything behind the query MLP, shared by the fp32 and bf16 kernels.  Q holds
@@ -445,7 +476,7 @@ __device__ __forceinline__ void attend_tail(const AttendArgs& a, const f32x16 (&
 }
 
 template <int NW, int VEC>
-__global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(AttendArgs a) {
+__device__ __forceinline__ void attend_tile(const AttendArgs& a, int bag, int tile, float* smem) {
     static_assert(NW == 1 || NW == 4 || NW == 8, "tile geometries: 32, 128 or 256 rows");
     constexpr int T = NW * 64;
     constexpr int BM = NW * 32;
@@ -453,16 +484,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
     constexpr int WPT = (QD * (BK / 4)) / T;  // float4 per thread per weight chunk (4 or 16)
     constexpr int XPT = (BM * (BK / 4)) / T;  // == 4
     constexpr int WPS = WPT >= 4 ? WPT / 4 : 1;  // weight float4 per pipeline slot (slots past WPT idle)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sW = smem;               // [2][W_TILE]
     float* sX = smem + 2 * W_TILE;  // [2][X_TILE]
 
-    const int bag = blockIdx.y;
     const long long off0 = a.offsets[bag];
     const long long Nb = a.offsets[bag + 1] - off0;
-    const long long row0 = (long long)blockIdx.x * BM;
+    const long long row0 = (long long)tile * BM;
     if (row0 >= Nb) return;
-    const long long slot = off0 / BM + bag + blockIdx.x;
+    const long long slot = off0 / BM + bag + tile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int K = a.K;
@@ -637,6 +666,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
     attend_tail<NW, VEC, float>(a, Q, smem, bag, off0, Nb, row0, slot);
 }
 
+template <int NW, int VEC>
+__global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(AttendArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    attend_tile<NW, VEC>(a, a.bag0 + (int)blockIdx.y, (int)blockIdx.x, smem);
+}
+
 // --------------------------------------------------------------------------------------------
 // k_query_attend_bf16 — BASELINE config 2: bf16 storage (features + query weights), f32
 // accumulate / softmax.  v_mfma_f32_32x32x16_bf16, same transposed chain as the fp32 kernel:
@@ -660,7 +695,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend_bf1
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sW = smem;
     float* sX = smem + 2 * W_TILE;
-    const int bag = blockIdx.y;
+    const int bag = a.bag0 + blockIdx.y;
     const long long off0 = a.offsets[bag];
     const long long Nb = a.offsets[bag + 1] - off0;
     const long long row0 = (long long)blockIdx.x * BM;
@@ -1089,35 +1124,38 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
                              (((uintptr_t)feats | (uintptr_t)vals | (uintptr_t)p->q0_w | (uintptr_t)p->fc_w |
                                (uintptr_t)(p->nonlinear ? p->q2_w : p->q0_w)) % 16 == 0));
     const bool w4 = (K % 4 == 0) && (((uintptr_t)p->q0_w | (uintptr_t)p->fc_w) % 16 == 0);
-    // 1. instance logits + arg-max partials
-    {
-        dim3 grid((unsigned)((max_rows + R0 - 1) / R0), (unsigned)n_bags);
-        if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
-        else if (bf16 && w4) hipLaunchKernelGGL((k_logits_argmax<4, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
-        else if (bf16) hipLaunchKernelGGL((k_logits_argmax<1, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
-        else if (v4) hipLaunchKernelGGL((k_logits_argmax<4, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
-        else hipLaunchKernelGGL((k_logits_argmax<1, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C);
-        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
-    }
-    // 2. critical instance + its query
-    {
-        dim3 grid((unsigned)n_bags, (unsigned)C);
-        if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), grid, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear);
-        else if (bf16) hipLaunchKernelGGL((k_qmax<1, bf16_t>), grid, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear);
-        else if (v4) hipLaunchKernelGGL((k_qmax<4, float>), grid, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear);
-        else hipLaunchKernelGGL((k_qmax<1, float>), grid, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear);
-        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
-    }
-    // 3. query MLP on MFMA + scores + tile softmax + weighted value sum
     AttendArgs a{feats, vals, (const bf16_t*)packed_bf16, offsets, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, A,
-                 part_ml, part_B, K, Kv, C, p->nonlinear, 0};
+                 part_ml, part_B, K, Kv, C, p->nonlinear, 0, 0};
     if (const char* e = getenv("DSMIL_EXPT")) a.expt = atoi(e);
-    int rc;
-    if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, n_bags, st) : launch_attend_bf16<1>(a, max_rows, n_bags, st);
-    else if (NW == 8) rc = launch_attend<8, 4>(a, max_rows, n_bags, st);
-    else if (NW == 4) rc = v4 ? launch_attend<4, 4>(a, max_rows, n_bags, st) : launch_attend<4, 1>(a, max_rows, n_bags, st);
-    else rc = v4 ? launch_attend<1, 4>(a, max_rows, n_bags, st) : launch_attend<1, 1>(a, max_rows, n_bags, st);
-    if (rc != DSMIL_OK) return rc;
+    {
+        // Tried and rejected here (round 1, numbers in DESIGN.md §3): (a) chunking the batch and running
+        // chunk c+1's HBM-bound logits on a helper stream under chunk c's MFMA-bound attend, and (b) one
+        // persistent launch pulling logits/attend work items from a device queue with in-launch
+        // release/acquire hand-offs.  Both were slower than these plain back-to-back launches.
+        const int b0 = 0, nb = n_bags;
+        // 1. instance logits + arg-max partials
+        dim3 grid((unsigned)((max_rows + R0 - 1) / R0), (unsigned)nb);
+        if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
+        else if (bf16 && w4) hipLaunchKernelGGL((k_logits_argmax<4, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
+        else if (bf16) hipLaunchKernelGGL((k_logits_argmax<1, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
+        else if (v4) hipLaunchKernelGGL((k_logits_argmax<4, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
+        else hipLaunchKernelGGL((k_logits_argmax<1, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+        // 2. critical instance + its query
+        dim3 gq((unsigned)nb, (unsigned)C);
+        if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), gq, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0);
+        else if (bf16) hipLaunchKernelGGL((k_qmax<1, bf16_t>), gq, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0);
+        else if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0);
+        else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+        // 3. query MLP on MFMA + scores + tile softmax + weighted value sum
+        int rc;
+        if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, nb, st) : launch_attend_bf16<1>(a, max_rows, nb, st);
+        else if (NW == 8) rc = launch_attend<8, 4>(a, max_rows, nb, st);
+        else if (NW == 4) rc = v4 ? launch_attend<4, 4>(a, max_rows, nb, st) : launch_attend<4, 1>(a, max_rows, nb, st);
+        else rc = v4 ? launch_attend<1, 4>(a, max_rows, nb, st) : launch_attend<1, 1>(a, max_rows, nb, st);
+        if (rc != DSMIL_OK) return rc;
+    }
     // 4. combine
     {
         dim3 grid((unsigned)L.nchunk_max, (unsigned)n_bags);
