@@ -291,6 +291,288 @@ __global__ __launch_bounds__(256) void k_in_finalize_flat(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_conv_wino: 3x3 stride-1 pad-1 convolution by Winograd F(2x2, 3x3), fused end to end
+// (13 of the 20 convolutions, ~80 % of the direct-form FLOPs; 2.25x fewer MFMA FLOPs).
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A,   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],
+//   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1]
+// Work unit: 64 flattened output tiles (2x2 pixels each; flattening over (image, ty, tx) lets the
+// 7x7 and 14x14 maps fill units across images) x 64 output channels; 4 waves = 2 tile groups x 2
+// channel groups, each wave owning 32 tiles x 32 channels x all 16 transform positions = 16
+// accumulator tiles (256 VGPRs, one wave per SIMD).  Per 8-channel chunk the staging threads load
+// each tile's 4x4 input patch (IN + ReLU of the producer applied on the fly), transform it
+// (B^T d B, separable; the two thread halves produce columns {0,1} / {2,3}) and write V[16][64][8]
+// to LDS next to the pre-transformed weights U[16][64][8]; the MFMA loop is then 16 independent
+// K=8 products.  The inverse transform A^T m A runs on the accumulators in registers; raw NHWC
+// store and (cnt, mean, M2) statistics partials per 32-tile wave tile follow as in k_conv.
+// ---------------------------------------------------------------------------------------------
+constexpr int WK = 8;            // channels per chunk
+constexpr int WLD = WK + 4;      // LDS row stride (48 B): conflict-free ds_read_b128
+constexpr int WTILE = 16 * 64 * WLD;
+
+struct WinoArgs {
+    const float* x;        // NHWC [B,H,W,C]
+    const float* u;        // [16][C/8][Cout][8]
+    const float* in_mean;  // [B,C] or null
+    const float* in_rstd;
+    float* y;              // raw NHWC [B,H,W,Cout]
+    float* part;           // [tiles32][nslots][Cout][3]
+    int B, H, W, C, Cout, TY, TX, nslots;
+    long long Ttot;        // B*TY*TX
+};
+
+template <bool NORM>
+__global__ __launch_bounds__(256, 1) void k_conv_wino(WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sV = smem;
+    float* sU = smem + WTILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long long t0 = (long long)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 64;
+    const int HWt = a.TY * a.TX;
+    const int nchunks = a.C / WK;
+    // ---- staging role of this thread: channel group g (4 ch), tile ts, column half h
+    const int g = tid & 1, ts = (tid >> 1) & 63, h = tid >> 7;
+    const long long Tst = t0 + ts;
+    const bool tvalid = Tst < a.Ttot;
+    int sn = 0, iy0 = 0, ix0 = 0;
+    if (tvalid) {
+        sn = (int)(Tst / HWt);
+        const int rem = (int)(Tst - (long long)sn * HWt);
+        const int ty = rem / a.TX, tx = rem - ty * a.TX;
+        iy0 = 2 * ty - 1;
+        ix0 = 2 * tx - 1 + h;  // this half loads input columns h .. h+2 of the 4x4 patch
+    }
+    unsigned okmask = 0;       // bit (i*3+jj): patch pixel inside the image
+    long long poff[12];        // element offsets of the 12 patch pixels (clamped)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            const int iy = iy0 + i, ix = ix0 + jj;
+            const bool ok = tvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            okmask |= ok ? (1u << (i * 3 + jj)) : 0u;
+            const int iyc = min(max(iy, 0), a.H - 1), ixc = min(max(ix, 0), a.W - 1);
+            poff[i * 3 + jj] = ((long long)(sn * a.H + iyc) * a.W + ixc) * a.C + g * 4;
+        }
+    f32x4 d[12], ureg[8], mu, rs;
+    auto load_chunk = [&](int cc) {
+        const int c0 = cc * WK;
+        if constexpr (NORM) {
+            mu = *reinterpret_cast<const f32x4*>(a.in_mean + (long long)sn * a.C + c0 + g * 4);
+            rs = *reinterpret_cast<const f32x4*>(a.in_rstd + (long long)sn * a.C + c0 + g * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 12; ++q) d[q] = *reinterpret_cast<const f32x4*>(a.x + poff[q] + c0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int f = tid + 256 * q, pos = f >> 7, within = f & 127;
+            ureg[q] = *reinterpret_cast<const f32x4*>(a.u + (((long long)pos * nchunks + cc) * a.Cout + n0) * WK + within * 4);
+        }
+    };
+    auto write_chunk = [&]() {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const bool ok = (okmask >> q) & 1u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = d[q][e];
+                if constexpr (NORM) v = fmaxf((v - mu[e]) * rs[e], 0.f);
+                d[q][e] = ok ? v : 0.f;
+            }
+        }
+        // rows: t[xi][jj] = (B^T d)[xi][col jj]
+        f32x4 t[4][3];
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            t[0][jj] = d[0 * 3 + jj] - d[2 * 3 + jj];
+            t[1][jj] = d[1 * 3 + jj] + d[2 * 3 + jj];
+            t[2][jj] = d[2 * 3 + jj] - d[1 * 3 + jj];
+            t[3][jj] = d[1 * 3 + jj] - d[3 * 3 + jj];
+        }
+        // columns: half 0 holds patch columns 0,1,2 -> nu = 0,1; half 1 holds 1,2,3 -> nu = 2,3
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            f32x4 va, vb;
+            if (h == 0) { va = t[xi][0] - t[xi][2]; vb = t[xi][1] + t[xi][2]; }
+            else { va = t[xi][1] - t[xi][0]; vb = t[xi][0] - t[xi][2]; }
+            const int nu = 2 * h;
+            *reinterpret_cast<f32x4*>(sV + ((xi * 4 + nu) * 64 + ts) * WLD + g * 4) = va;
+            *reinterpret_cast<f32x4*>(sV + ((xi * 4 + nu + 1) * 64 + ts) * WLD + g * 4) = vb;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int f = tid + 256 * q, pos = f >> 7, within = f & 127;
+            *reinterpret_cast<f32x4*>(sU + (pos * 64 + (within >> 1)) * WLD + (within & 1) * 4) = ureg[q];
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    load_chunk(0);
+    write_chunk();
+    __syncthreads();
+    const float* vfrag = sV + (wm * 32 + l31) * WLD + 4 * hi;
+    const float* ufrag = sU + (wn * 32 + l31) * WLD + 4 * hi;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        if (cc + 1 < nchunks) load_chunk(cc + 1);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(vfrag + p * 64 * WLD);
+            const f32x4 ub = *reinterpret_cast<const f32x4*>(ufrag + p * 64 * WLD);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], ub[j], acc[p], 0, 0, 0);
+        }
+        __syncthreads();
+        if (cc + 1 < nchunks) {
+            write_chunk();
+            __syncthreads();
+        }
+    }
+    // ---- inverse transform in registers, raw store, statistics partials
+    const long long tbase = t0 + wm * 32;
+    const int co = n0 + wn * 32 + l31;
+    float y00[16], y01[16], y10[16], y11[16];
+    unsigned vmask[16];  // 4 validity bits per accumulator row (tile)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#define M_(xi, nu) acc[(xi) * 4 + (nu)][r]
+        const float r0a = M_(0, 0) + M_(0, 1) + M_(0, 2), r0b = M_(0, 1) - M_(0, 2) - M_(0, 3);
+        const float r1a = M_(1, 0) + M_(1, 1) + M_(1, 2), r1b = M_(1, 1) - M_(1, 2) - M_(1, 3);
+        const float r2a = M_(2, 0) + M_(2, 1) + M_(2, 2), r2b = M_(2, 1) - M_(2, 2) - M_(2, 3);
+        const float r3a = M_(3, 0) + M_(3, 1) + M_(3, 2), r3b = M_(3, 1) - M_(3, 2) - M_(3, 3);
+#undef M_
+        y00[r] = r0a + r1a + r2a; y01[r] = r0b + r1b + r2b;
+        y10[r] = r1a - r2a - r3a; y11[r] = r1b - r2b - r3b;
+        const long long T = tbase + drow(r, hi);
+        unsigned vm = 0;
+        if (T < a.Ttot) {
+            const int n = (int)(T / HWt), rem = (int)(T - (long long)n * HWt);
+            const int ty = rem / a.TX, tx = rem - ty * a.TX;
+            const int oy = 2 * ty, ox = 2 * tx;
+            float* o = a.y + ((long long)(n * a.H + oy) * a.W + ox) * a.Cout + co;
+            const bool by = oy + 1 < a.H, bx = ox + 1 < a.W;
+            o[0] = y00[r]; vm = 1u;
+            if (bx) { o[a.Cout] = y01[r]; vm |= 2u; }
+            if (by) { o[(long long)a.W * a.Cout] = y10[r]; vm |= 4u; }
+            if (by && bx) { o[(long long)(a.W + 1) * a.Cout] = y11[r]; vm |= 8u; }
+        }
+        vmask[r] = vm;
+    }
+    if (tbase < a.Ttot) {
+        const long long tile32 = tbase >> 5;
+        const int nfirst = (int)(tbase / HWt);
+        for (int s = 0; s < a.nslots; ++s) {
+            const long long ibeg = (long long)(nfirst + s) * HWt, iend = ibeg + HWt;
+            long long lo = ibeg - tbase, hi_ = ((iend < a.Ttot) ? iend : a.Ttot) - tbase;
+            if (lo < 0) lo = 0;
+            if (hi_ > 32) hi_ = 32;
+            float sum = 0.f, cnt = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = drow(r, hi);
+                const unsigned vm = (row >= lo && row < hi_) ? vmask[r] : 0u;
+                sum += ((vm & 1u) ? y00[r] : 0.f) + ((vm & 2u) ? y01[r] : 0.f) + ((vm & 4u) ? y10[r] : 0.f) + ((vm & 8u) ? y11[r] : 0.f);
+                cnt += (float)__popc(vm);
+            }
+            sum += __shfl_xor(sum, 32, 64);
+            cnt += __shfl_xor(cnt, 32, 64);
+            const float mean = cnt > 0.f ? sum / cnt : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = drow(r, hi);
+                const unsigned vm = (row >= lo && row < hi_) ? vmask[r] : 0u;
+                const float d0 = y00[r] - mean, d1 = y01[r] - mean, d2 = y10[r] - mean, d3 = y11[r] - mean;
+                q += ((vm & 1u) ? d0 * d0 : 0.f) + ((vm & 2u) ? d1 * d1 : 0.f) + ((vm & 4u) ? d2 * d2 : 0.f) + ((vm & 8u) ? d3 * d3 : 0.f);
+            }
+            q += __shfl_xor(q, 32, 64);
+            if (hi == 0) {
+                float* o = a.part + ((tile32 * a.nslots + s) * a.Cout + co) * 3;
+                o[0] = cnt; o[1] = mean; o[2] = q;
+            }
+        }
+    }
+}
+
+// (cnt, mean, M2) partials of flattened 32-tile groups -> mean / rstd per (image, channel)
+__global__ __launch_bounds__(256) void k_in_finalize_cnt(const float* __restrict__ part, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, int HWt, int C, int nslots,
+                                                        long long Ttot) {
+    const int n = blockIdx.x;
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long long ibeg = (long long)n * HWt, iend = ibeg + HWt;
+    const long long t0 = ibeg >> 5, t1 = (iend - 1) >> 5;
+    __shared__ float red[2][4][64];
+    for (int c = cl; c < C; c += 64) {
+        float s = 0.f, cnt = 0.f;
+        for (long long t = t0 + g; t <= t1; t += 4) {
+            const int sl = n - (int)((t << 5) / HWt);
+            if (sl < 0 || sl >= nslots) continue;
+            const float* o = part + ((t * nslots + sl) * C + c) * 3;
+            s += o[0] * o[1];
+            cnt += o[0];
+        }
+        __syncthreads();
+        red[0][g][cl] = s;
+        red[1][g][cl] = cnt;
+        __syncthreads();
+        const float tot = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+        const float mu = ((red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl])) / tot;
+        float q = 0.f;
+        for (long long t = t0 + g; t <= t1; t += 4) {
+            const int sl = n - (int)((t << 5) / HWt);
+            if (sl < 0 || sl >= nslots) continue;
+            const float* o = part + ((t * nslots + sl) * C + c) * 3;
+            const float dlt = o[1] - mu;
+            q += o[2] + o[0] * dlt * dlt;
+        }
+        __syncthreads();
+        red[0][g][cl] = q;
+        __syncthreads();
+        if (g == 0) {
+            const float m2 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+            mean[(long long)n * C + c] = mu;
+            rstd[(long long)n * C + c] = 1.0f / sqrtf(m2 / tot + IN_EPS);
+        }
+    }
+    (void)Ttot;
+}
+
+// OIHW 3x3 weights -> Winograd domain U = G g G^T, laid out [16][I/8][O][8]
+__global__ void k_pack_wino(const float* __restrict__ w, float* __restrict__ out, int O, int I) {
+    const long long total = (long long)O * I;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % I), o = (int)(i / I);
+        const float* gw = w + i * 9;
+        float gg[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) gg[r][c] = gw[r * 3 + c];
+        float tmp[4][3];  // G g
+        for (int c = 0; c < 3; ++c) {
+            tmp[0][c] = gg[0][c];
+            tmp[1][c] = 0.5f * (gg[0][c] + gg[1][c] + gg[2][c]);
+            tmp[2][c] = 0.5f * (gg[0][c] - gg[1][c] + gg[2][c]);
+            tmp[3][c] = gg[2][c];
+        }
+        for (int xi = 0; xi < 4; ++xi) {
+            float u4[4];
+            u4[0] = tmp[xi][0];
+            u4[1] = 0.5f * (tmp[xi][0] + tmp[xi][1] + tmp[xi][2]);
+            u4[2] = 0.5f * (tmp[xi][0] - tmp[xi][1] + tmp[xi][2]);
+            u4[3] = tmp[xi][2];
+            for (int nu = 0; nu < 4; ++nu)
+                out[(((long long)(xi * 4 + nu) * (I / 8) + ci / 8) * O + o) * 8 + (ci & 7)] = u4[nu];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_stem: conv 7x7 stride 2 pad 3, Cin = 3 -> 64, input NCHW fp32 (what VF.to_tensor yields,
 // compute_feats.py:35-39), weight [64][3][7][7] read as [64][147] (k = c*49 + kh*7 + kw).
 // Workgroup = 8 x 16 output pixels (4 waves x 32 px) x 64 channels.
@@ -540,7 +822,15 @@ const ConvSpec kSpecs[20] = {
 };
 
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
-inline long long wsize(int i) { return (long long)kSpecs[i].cout * kSpecs[i].cin * kSpecs[i].ks * kSpecs[i].ks; }
+inline bool use_wino(const ConvSpec& s) {  // 3x3 stride-1 convs run as Winograd F(2x2,3x3)
+    static const int off = getenv("DSMIL_NO_WINO") ? atoi(getenv("DSMIL_NO_WINO")) : 0;
+    return !off && s.ks == 3 && s.stride == 1 && s.pad == 1 && s.cin % WK == 0 && s.cout % 64 == 0;
+}
+// floats of conv i in the packed buffer: 16 transform positions for Winograd convs, ks*ks taps otherwise
+inline long long wsize(int i) {
+    const ConvSpec& s = kSpecs[i];
+    return (long long)s.cout * s.cin * (use_wino(s) ? 16 : s.ks * s.ks);
+}
 inline size_t pack_offset(int i) {  // floats; conv 0 (stem) is used unpacked
     size_t o = 0;
     for (int j = 1; j < i; ++j) o += (size_t)wsize(j);
@@ -582,6 +872,10 @@ RWs rws_layout(int B, int H, int W) {
         const int nslots = 31 / HW + 2;
         const long long e = ((M + 31) / 32) * nslots * C * 2;
         if (e > mx) mx = e;
+        const int HWt = ((d.h[l] + 1) / 2) * ((d.w[l] + 1) / 2);
+        const long long Tt = (long long)B * HWt;
+        const long long ew = ((Tt + 31) / 32) * (31 / HWt + 2) * C * 3;  // Winograd (cnt, mean, M2) partials
+        if (ew > mx) mx = ew;
     }
     r.part_elems = mx;
     r.part = o; o = al256(o + (size_t)mx * 4);
@@ -591,6 +885,25 @@ RWs rws_layout(int B, int H, int W) {
 
 int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_mean, const float* in_rstd,
              float* y, float* part, float* mean, float* rstd, int B, int H, int W, const ConvSpec& s) {
+    if (use_wino(s)) {
+        WinoArgs wa;
+        wa.x = x; wa.u = wpk; wa.in_mean = in_mean; wa.in_rstd = in_rstd; wa.y = y; wa.part = part;
+        wa.B = B; wa.H = H; wa.W = W; wa.C = s.cin; wa.Cout = s.cout;
+        wa.TY = (H + 1) / 2; wa.TX = (W + 1) / 2;
+        const int HWt = wa.TY * wa.TX;
+        wa.nslots = 31 / HWt + 2;
+        wa.Ttot = (long long)B * HWt;
+        const size_t lds = (size_t)2 * WTILE * sizeof(float);
+        dim3 grid((unsigned)((wa.Ttot + 63) / 64), (unsigned)(s.cout / 64));
+        const int slot = dsmil_prof::begin(dsmil_prof::CH_CONV, st);
+        if (in_mean) hipLaunchKernelGGL((k_conv_wino<true>), grid, dim3(256), lds, st, wa);
+        else hipLaunchKernelGGL((k_conv_wino<false>), grid, dim3(256), lds, st, wa);
+        dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+        hipLaunchKernelGGL(k_in_finalize_cnt, dim3((unsigned)B), dim3(256), 0, st, part, mean, rstd, HWt, s.cout,
+                           wa.nslots, wa.Ttot);
+        return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+    }
     ConvArgs a;
     a.x = x; a.w = wpk; a.in_mean = in_mean; a.in_rstd = in_rstd; a.y = y; a.part = part;
     a.B = B; a.H = H; a.W = W; a.Cin = s.cin;
@@ -646,6 +959,8 @@ void set_conv_attrs() {
     (void)hipFuncSetAttribute((const void*)k_conv<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
     (void)hipFuncSetAttribute((const void*)k_conv<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
     (void)hipFuncSetAttribute((const void*)k_conv<4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
+    (void)hipFuncSetAttribute((const void*)k_conv_wino<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WTILE * 4);
+    (void)hipFuncSetAttribute((const void*)k_conv_wino<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WTILE * 4);
     g_attr_done = true;
 }
 
@@ -661,11 +976,18 @@ int dsmil_resnet18_pack(const float* const* conv_w, float* packed, void* stream)
     for (int i = 1; i < 20; ++i) {
         if (!conv_w[i]) return DSMIL_E_INVALID;
         const ConvSpec& s = kSpecs[i];
-        const long long total = wsize(i);
-        long long blocks = (total + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
-                           packed + pack_offset(i), s.cout, s.cin, s.ks * s.ks);
+        if (use_wino(s)) {
+            long long blocks = ((long long)s.cout * s.cin + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(k_pack_wino, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
+                               packed + pack_offset(i), s.cout, s.cin);
+        } else {
+            const long long total = wsize(i);
+            long long blocks = (total + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
+                               packed + pack_offset(i), s.cout, s.cin, s.ks * s.ks);
+        }
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
     return DSMIL_OK;
