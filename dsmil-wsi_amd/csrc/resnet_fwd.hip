@@ -295,19 +295,31 @@ __global__ __launch_bounds__(256) void k_in_finalize_flat(const float* __restric
 // (13 of the 20 convolutions, ~80 % of the direct-form FLOPs; 2.25x fewer MFMA FLOPs).
 //   Y = A^T [ (G g G^T) .* (B^T d B) ] A,   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],
 //   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1]
-// Work unit: 64 flattened output tiles (2x2 pixels each; flattening over (image, ty, tx) lets the
-// 7x7 and 14x14 maps fill units across images) x 64 output channels; 4 waves = 2 tile groups x 2
-// channel groups, each wave owning 32 tiles x 32 channels x all 16 transform positions = 16
-// accumulator tiles (256 VGPRs, one wave per SIMD).  Per 8-channel chunk the staging threads load
-// each tile's 4x4 input patch (IN + ReLU of the producer applied on the fly), transform it
-// (B^T d B, separable; the two thread halves produce columns {0,1} / {2,3}) and write V[16][64][8]
-// to LDS next to the pre-transformed weights U[16][64][8]; the MFMA loop is then 16 independent
-// K=8 products.  The inverse transform A^T m A runs on the accumulators in registers; raw NHWC
-// store and (cnt, mean, M2) statistics partials per 32-tile wave tile follow as in k_conv.
+// Work unit: up to 32 output tiles (2x2 pixels each) arranged as IB images x TYB x TXB tiles (the
+// host picks the shape that fills the 32 MFMA rows best per layer) x 64 output channels.
+// 4 waves = 2 channel groups (wn) x 2 position halves (wp: transform rows xi in {2wp, 2wp+1});
+// a wave owns 32 tiles x 32 channels x 8 positions = 8 accumulator tiles (128 VGPRs), so TWO
+// independent workgroups share a CU (2 waves per SIMD) and hide each other's prologue, epilogue
+// and barrier stalls — single-wave-per-SIMD versions with all 16 positions per wave were 3x off.
+// Data flow per 8-channel chunk, one barrier interval:
+//   * the unit's input region ((2TYB+2) x (2TXB+2) pixels per image) is loaded ONCE from global
+//     into a raw LDS buffer (no per-tile re-fetch of overlapping 4x4 patches);
+//   * each thread transforms one (tile, 4-channel group, column half h, row half v): 9 ds_reads of
+//     raw pixels, IN + ReLU of the producer and zero padding applied on the fly, B^T d B for
+//     4 of the 16 positions, 4 ds_writes into V[16][32][8] of the NEXT chunk (double buffered);
+//   * the pre-transformed weights U[16][C/8][Cout][8] are read by each lane straight from L2 in
+//     MFMA B-operand order (fully coalesced, no LDS), re-issued position by position;
+//   * 8 positions x 4 MFMAs (K = 8) on the CURRENT chunk.
+// The inverse transform is linear: each position half reduces its 8 accumulator tiles to four
+// partial outputs, the wp = 1 wave hands them to its wp = 0 partner through LDS, which stores the
+// raw NHWC pixels and the (cnt, mean, M2) statistics partials per (image, unit).
 // ---------------------------------------------------------------------------------------------
 constexpr int WK = 8;            // channels per chunk
 constexpr int WLD = WK + 4;      // LDS row stride (48 B): conflict-free ds_read_b128
-constexpr int WTILE = 16 * 64 * WLD;
+constexpr int WTT = 32;          // tile slots per unit
+constexpr int WTILE = 16 * WTT * WLD;
+constexpr int WRAW_MAX = 256;    // raw-region pixels per unit the host may choose (x WLD floats)
+constexpr int WRPT = (WRAW_MAX * 2 + 255) / 256;  // raw float4 loads per thread per chunk
 
 struct WinoArgs {
     const float* x;        // NHWC [B,H,W,C]
@@ -315,205 +327,254 @@ struct WinoArgs {
     const float* in_mean;  // [B,C] or null
     const float* in_rstd;
     float* y;              // raw NHWC [B,H,W,Cout]
-    float* part;           // [tiles32][nslots][Cout][3]
-    int B, H, W, C, Cout, TY, TX, nslots;
-    long long Ttot;        // B*TY*TX
+    float* part;           // [B][PB][Cout][3]   (cnt, mean, M2)
+    int B, H, W, C, Cout, TY, TX;
+    int IB, TYB, TXB;      // unit shape: images x tile rows x tile cols (IB*TYB*TXB <= 32)
+    int nby, nbx, PB;      // units per image along y / x, PB = nby*nbx
+    int expt;              // DSMIL_WINO_EXPT ablation knob (0 in production)
 };
 
 template <bool NORM>
-__global__ __launch_bounds__(256, 1) void k_conv_wino(WinoArgs a) {
+__global__ __launch_bounds__(256, 2) void k_conv_wino(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sV = smem;
-    float* sU = smem + WTILE;
+    float* sV = smem;                       // [2][WTILE]
+    float* sR = smem + 2 * WTILE;           // [2][WRAW_MAX * WLD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wn = wave & 1, wp = wave >> 1;
     const int l31 = lane & 31, hi = lane >> 5;
-    const long long t0 = (long long)blockIdx.x * 64;
     const int n0 = blockIdx.y * 64;
-    const int HWt = a.TY * a.TX;
     const int nchunks = a.C / WK;
-    // ---- staging role of this thread: channel group g (4 ch), tile ts, column half h
-    const int g = tid & 1, ts = (tid >> 1) & 63, h = tid >> 7;
-    const long long Tst = t0 + ts;
-    const bool tvalid = Tst < a.Ttot;
-    int sn = 0, iy0 = 0, ix0 = 0;
-    if (tvalid) {
-        sn = (int)(Tst / HWt);
-        const int rem = (int)(Tst - (long long)sn * HWt);
-        const int ty = rem / a.TX, tx = rem - ty * a.TX;
-        iy0 = 2 * ty - 1;
-        ix0 = 2 * tx - 1 + h;  // this half loads input columns h .. h+2 of the 4x4 patch
+    // ---- which unit
+    int bid = blockIdx.x;
+    const int bx = bid % a.nbx; bid /= a.nbx;
+    const int by = bid % a.nby; bid /= a.nby;
+    const int img0 = bid * a.IB;
+    const int ty0 = by * a.TYB, tx0 = bx * a.TXB;
+    const int pb = by * a.nbx + bx;
+    const int RH = 2 * a.TYB + 2, RW = 2 * a.TXB + 2, RP = RH * RW;   // raw region per image
+    const int tpi = a.TYB * a.TXB;                                   // tile slots per image
+    const int iy_org = 2 * ty0 - 1, ix_org = 2 * tx0 - 1;            // image coords of raw (0,0)
+
+    // ---- raw staging role: element e = tid + 256 q -> (pixel e>>1, channel group e&1).  The producer's
+    // IN + ReLU and the zero padding are applied HERE, once per staged pixel, so the transform below
+    // is pure adds (a first version normalised and masked per tile: ~2x the VALU work, and the
+    // instruction stream, not the MFMA pipe, was the limit).
+    int roff[WRPT];   // global element offset of the pixel (x C); -1 = zero padding, -2 = unused slot
+    int rlds[WRPT];   // LDS float offset inside a raw buffer
+    int rsto[WRPT];   // element offset of the pixel's image in in_mean / in_rstd
+#pragma unroll
+    for (int q = 0; q < WRPT; ++q) {
+        const int e = tid + 256 * q, px = e >> 1, gg = e & 1;
+        roff[q] = -2; rlds[q] = 0; rsto[q] = gg * 4;
+        if (px < a.IB * RP) {
+            const int il = px / RP, rem = px - il * RP, ry = rem / RW, rx = rem - ry * RW;
+            const int n = img0 + il, iy = iy_org + ry, ix = ix_org + rx;
+            roff[q] = -1;
+            if (n < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                roff[q] = ((n * a.H + iy) * a.W + ix) * a.C + gg * 4;
+                rsto[q] = n * a.C + gg * 4;
+            }
+            rlds[q] = px * WLD + gg * 4;
+        }
     }
-    unsigned okmask = 0;       // bit (i*3+jj): patch pixel inside the image
-    long long poff[12];        // element offsets of the 12 patch pixels (clamped)
+    // ---- transform role: channel group g, tile slot ts, column half h (nu in {2h,2h+1}),
+    //      row half v (xi in {2v,2v+1}): patch rows v..v+2, columns h..h+2
+    const int g = tid & 1, ts = (tid >> 1) & 31, h = (tid >> 6) & 1, v = tid >> 7;
+    const int sil = ts / tpi, srem = ts - sil * tpi, styl = srem / a.TXB, stxl = srem - styl * a.TXB;
+    // LDS float offset of this role's first patch pixel (row 2*styl+v, col 2*stxl+h) in a raw buffer;
+    // slots past the unit's tiles read pixel 0 (their accumulator rows are never stored)
+    const int praw = (ts < a.IB * tpi) ? ((sil * RH + 2 * styl + v) * RW + 2 * stxl + h) * WLD + g * 4 : g * 4;
+
+    f32x4 rreg[WRPT], rmu[WRPT], rrs[WRPT];
+    auto raw_load = [&](int cc) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj) {
-            const int iy = iy0 + i, ix = ix0 + jj;
-            const bool ok = tvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            okmask |= ok ? (1u << (i * 3 + jj)) : 0u;
-            const int iyc = min(max(iy, 0), a.H - 1), ixc = min(max(ix, 0), a.W - 1);
-            poff[i * 3 + jj] = ((long long)(sn * a.H + iyc) * a.W + ixc) * a.C + g * 4;
-        }
-    f32x4 d[12], ureg[8], mu, rs;
-    auto load_chunk = [&](int cc) {
-        const int c0 = cc * WK;
-        if constexpr (NORM) {
-            mu = *reinterpret_cast<const f32x4*>(a.in_mean + (long long)sn * a.C + c0 + g * 4);
-            rs = *reinterpret_cast<const f32x4*>(a.in_rstd + (long long)sn * a.C + c0 + g * 4);
-        }
-#pragma unroll
-        for (int q = 0; q < 12; ++q) d[q] = *reinterpret_cast<const f32x4*>(a.x + poff[q] + c0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int f = tid + 256 * q, pos = f >> 7, within = f & 127;
-            ureg[q] = *reinterpret_cast<const f32x4*>(a.u + (((long long)pos * nchunks + cc) * a.Cout + n0) * WK + within * 4);
-        }
-    };
-    auto write_chunk = [&]() {
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            const bool ok = (okmask >> q) & 1u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = d[q][e];
-                if constexpr (NORM) v = fmaxf((v - mu[e]) * rs[e], 0.f);
-                d[q][e] = ok ? v : 0.f;
+        for (int q = 0; q < WRPT; ++q) {
+            const int off = roff[q] < 0 ? 0 : roff[q];
+            rreg[q] = *reinterpret_cast<const f32x4*>(a.x + (long long)off + cc * WK);
+            if constexpr (NORM) {
+                rmu[q] = *reinterpret_cast<const f32x4*>(a.in_mean + rsto[q] + cc * WK);
+                rrs[q] = *reinterpret_cast<const f32x4*>(a.in_rstd + rsto[q] + cc * WK);
             }
         }
-        // rows: t[xi][jj] = (B^T d)[xi][col jj]
-        f32x4 t[4][3];
+    };
+    auto raw_write = [&](int cc) {
+        float* r = sR + (cc & 1) * (WRAW_MAX * WLD);
 #pragma unroll
-        for (int jj = 0; jj < 3; ++jj) {
-            t[0][jj] = d[0 * 3 + jj] - d[2 * 3 + jj];
-            t[1][jj] = d[1 * 3 + jj] + d[2 * 3 + jj];
-            t[2][jj] = d[2 * 3 + jj] - d[1 * 3 + jj];
-            t[3][jj] = d[1 * 3 + jj] - d[3 * 3 + jj];
-        }
-        // columns: half 0 holds patch columns 0,1,2 -> nu = 0,1; half 1 holds 1,2,3 -> nu = 2,3
+        for (int q = 0; q < WRPT; ++q) {
+            if (roff[q] == -2) continue;
+            f32x4 x = rreg[q];
+            const bool ok = roff[q] >= 0;
 #pragma unroll
-        for (int xi = 0; xi < 4; ++xi) {
-            f32x4 va, vb;
-            if (h == 0) { va = t[xi][0] - t[xi][2]; vb = t[xi][1] + t[xi][2]; }
-            else { va = t[xi][1] - t[xi][0]; vb = t[xi][0] - t[xi][2]; }
-            const int nu = 2 * h;
-            *reinterpret_cast<f32x4*>(sV + ((xi * 4 + nu) * 64 + ts) * WLD + g * 4) = va;
-            *reinterpret_cast<f32x4*>(sV + ((xi * 4 + nu + 1) * 64 + ts) * WLD + g * 4) = vb;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int f = tid + 256 * q, pos = f >> 7, within = f & 127;
-            *reinterpret_cast<f32x4*>(sU + (pos * 64 + (within >> 1)) * WLD + (within & 1) * 4) = ureg[q];
+            for (int e = 0; e < 4; ++e) {
+                float xv = x[e];
+                if constexpr (NORM) xv = fmaxf((xv - rmu[q][e]) * rrs[q][e], 0.f);
+                x[e] = ok ? xv : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(r + rlds[q]) = x;
         }
     };
-
-    f32x16 acc[16];
+    // transform this role's share of chunk cc: raw[cc&1] -> V[cc&1][positions (2v+{0,1})*4 + 2h+{0,1}]
+    auto transform = [&](int cc) {
+        const float* r = sR + (cc & 1) * (WRAW_MAX * WLD) + praw;
+        float* vv = sV + (cc & 1) * WTILE;
+        f32x4 d[9];
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) d[i * 3 + jj] = *reinterpret_cast<const f32x4*>(r + (i * RW + jj) * WLD);
+        // rows (B^T d): v = 0 -> xi 0,1 from patch rows 0,1,2; v = 1 -> xi 2,3 from patch rows 1,2,3
+        f32x4 t[2][3];
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            if (v == 0) { t[0][jj] = d[jj] - d[6 + jj]; t[1][jj] = d[3 + jj] + d[6 + jj]; }
+            else { t[0][jj] = d[3 + jj] - d[jj]; t[1][jj] = d[jj] - d[6 + jj]; }
+        }
+        // columns (.. B): h = 0 -> nu 0,1 from patch columns 0,1,2; h = 1 -> nu 2,3 from columns 1,2,3
+#pragma unroll
+        for (int x2 = 0; x2 < 2; ++x2) {
+            f32x4 va, vb;
+            if (h == 0) { va = t[x2][0] - t[x2][2]; vb = t[x2][1] + t[x2][2]; }
+            else { va = t[x2][1] - t[x2][0]; vb = t[x2][0] - t[x2][2]; }
+            const int pos = (2 * v + x2) * 4 + 2 * h;
+            *reinterpret_cast<f32x4*>(vv + (pos * WTT + ts) * WLD + g * 4) = va;
+            *reinterpret_cast<f32x4*>(vv + ((pos + 1) * WTT + ts) * WLD + g * 4) = vb;
+        }
+    };
+    // B operand (weights) of position p (of this wave's half) for this lane — straight from
+    // global/L2; one running pointer per position, advanced by a chunk (Cout*8 floats) per step
+    const float* up[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+        up[p] = a.u + ((long long)(8 * wp + p) * nchunks * a.Cout + n0 + wn * 32 + l31) * WK + 4 * hi;
+    const int ustep = a.Cout * WK;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-    load_chunk(0);
-    write_chunk();
+    f32x4 ub[8];
+    // ---- prologue: raw(0) -> LDS, V(0), raw(1) -> LDS, weights of chunk 0
+    raw_load(0);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) { ub[p] = *reinterpret_cast<const f32x4*>(up[p]); up[p] += ustep; }
+    raw_write(0);
     __syncthreads();
-    const float* vfrag = sV + (wm * 32 + l31) * WLD + 4 * hi;
-    const float* ufrag = sU + (wn * 32 + l31) * WLD + 4 * hi;
+    transform(0);
+    if (nchunks > 1) { raw_load(1); raw_write(1); }
+    __syncthreads();
+    const int vfo = ((8 * wp) * WTT + l31) * WLD + 4 * hi;
     for (int cc = 0; cc < nchunks; ++cc) {
-        if (cc + 1 < nchunks) load_chunk(cc + 1);
+        const bool more = cc + 1 < nchunks, more2 = cc + 2 < nchunks;   // block-uniform
+        if (more2 && !(a.expt & 2)) raw_load(cc + 2);
+        if (more && !(a.expt & 1)) transform(cc + 1);   // raw[(cc+1)&1] -> V[(cc+1)&1]; the co-resident workgroup's MFMAs cover it
+        const float* vb = sV + (cc & 1) * WTILE + vfo;
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const f32x4 va = *reinterpret_cast<const f32x4*>(vfrag + p * 64 * WLD);
-            const f32x4 ub = *reinterpret_cast<const f32x4*>(ufrag + p * 64 * WLD);
+        for (int p = 0; p < 8; ++p) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(vb + p * WTT * WLD);
+            const f32x4 w = ub[p];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], ub[j], acc[p], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], w[j], acc[p], 0, 0, 0);
+            if (more && !(a.expt & 4)) { ub[p] = *reinterpret_cast<const f32x4*>(up[p]); up[p] += ustep; }
         }
+        if (more2 && !(a.expt & 2)) raw_write(cc + 2);   // raw[cc&1] was consumed by the transform of chunk cc
         __syncthreads();
-        if (cc + 1 < nchunks) {
-            write_chunk();
-            __syncthreads();
-        }
     }
-    // ---- inverse transform in registers, raw store, statistics partials
-    const long long tbase = t0 + wm * 32;
-    const int co = n0 + wn * 32 + l31;
+    if (a.expt & 8) {  // ablation: no epilogue
+        float keep = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) keep += acc[p][r];
+        if (keep == 123.456f) a.y[0] = keep;
+        return;
+    }
+    // ---- inverse transform: partial outputs of this wave's two xi rows
+    //   ra[xi] = m[xi][0]+m[xi][1]+m[xi][2], rb[xi] = m[xi][1]-m[xi][2]-m[xi][3]
+    //   Y[0][.] = r.[0]+r.[1]+r.[2],  Y[1][.] = r.[1]-r.[2]-r.[3]
     float y00[16], y01[16], y10[16], y11[16];
-    unsigned vmask[16];  // 4 validity bits per accumulator row (tile)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-#define M_(xi, nu) acc[(xi) * 4 + (nu)][r]
-        const float r0a = M_(0, 0) + M_(0, 1) + M_(0, 2), r0b = M_(0, 1) - M_(0, 2) - M_(0, 3);
-        const float r1a = M_(1, 0) + M_(1, 1) + M_(1, 2), r1b = M_(1, 1) - M_(1, 2) - M_(1, 3);
-        const float r2a = M_(2, 0) + M_(2, 1) + M_(2, 2), r2b = M_(2, 1) - M_(2, 2) - M_(2, 3);
-        const float r3a = M_(3, 0) + M_(3, 1) + M_(3, 2), r3b = M_(3, 1) - M_(3, 2) - M_(3, 3);
-#undef M_
-        y00[r] = r0a + r1a + r2a; y01[r] = r0b + r1b + r2b;
-        y10[r] = r1a - r2a - r3a; y11[r] = r1b - r2b - r3b;
-        const long long T = tbase + drow(r, hi);
+        const float raA = acc[0][r] + acc[1][r] + acc[2][r], rbA = acc[1][r] - acc[2][r] - acc[3][r];  // xi = 2wp
+        const float raB = acc[4][r] + acc[5][r] + acc[6][r], rbB = acc[5][r] - acc[6][r] - acc[7][r];  // xi = 2wp+1
+        if (wp == 0) { y00[r] = raA + raB; y01[r] = rbA + rbB; y10[r] = raB; y11[r] = rbB; }
+        else { y00[r] = raA; y01[r] = rbA; y10[r] = -raA - raB; y11[r] = -rbA - rbB; }
+    }
+    // hand the wp = 1 partials to the wp = 0 partner (same wn) through LDS (the V buffers are free now)
+    float* xch = smem + (wn * 64 + lane) * 65;  // [2 partner pairs][64 lanes][64 (+1 pad)]
+    if (wp == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            xch[r] = y00[r]; xch[16 + r] = y01[r]; xch[32 + r] = y10[r]; xch[48 + r] = y11[r];
+        }
+    }
+    __syncthreads();
+    if (wp == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        y00[r] += xch[r]; y01[r] += xch[16 + r]; y10[r] += xch[32 + r]; y11[r] += xch[48 + r];
+    }
+    // ---- raw store + statistics partials (wp = 0 waves)
+    const int co = n0 + wn * 32 + l31;
+    unsigned vmask[16];  // 4 validity bits per accumulator row (tile slot)
+    int rimg[16];        // local image of the row's tile slot (or -1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int slot = drow(r, hi);
+        const int il = slot / tpi, rem = slot - il * tpi, tyl = rem / a.TXB, txl = rem - tyl * a.TXB;
+        const int n = img0 + il, ty = ty0 + tyl, tx = tx0 + txl;
         unsigned vm = 0;
-        if (T < a.Ttot) {
-            const int n = (int)(T / HWt), rem = (int)(T - (long long)n * HWt);
-            const int ty = rem / a.TX, tx = rem - ty * a.TX;
+        rimg[r] = -1;
+        if (slot < a.IB * tpi && n < a.B && ty < a.TY && tx < a.TX) {
             const int oy = 2 * ty, ox = 2 * tx;
             float* o = a.y + ((long long)(n * a.H + oy) * a.W + ox) * a.Cout + co;
-            const bool by = oy + 1 < a.H, bx = ox + 1 < a.W;
+            const bool byv = oy + 1 < a.H, bxv = ox + 1 < a.W;
             o[0] = y00[r]; vm = 1u;
-            if (bx) { o[a.Cout] = y01[r]; vm |= 2u; }
-            if (by) { o[(long long)a.W * a.Cout] = y10[r]; vm |= 4u; }
-            if (by && bx) { o[(long long)(a.W + 1) * a.Cout] = y11[r]; vm |= 8u; }
+            if (bxv) { o[a.Cout] = y01[r]; vm |= 2u; }
+            if (byv) { o[(long long)a.W * a.Cout] = y10[r]; vm |= 4u; }
+            if (byv && bxv) { o[(long long)(a.W + 1) * a.Cout] = y11[r]; vm |= 8u; }
+            rimg[r] = il;
         }
         vmask[r] = vm;
     }
-    if (tbase < a.Ttot) {
-        const long long tile32 = tbase >> 5;
-        const int nfirst = (int)(tbase / HWt);
-        for (int s = 0; s < a.nslots; ++s) {
-            const long long ibeg = (long long)(nfirst + s) * HWt, iend = ibeg + HWt;
-            long long lo = ibeg - tbase, hi_ = ((iend < a.Ttot) ? iend : a.Ttot) - tbase;
-            if (lo < 0) lo = 0;
-            if (hi_ > 32) hi_ = 32;
-            float sum = 0.f, cnt = 0.f;
+    for (int il = 0; il < a.IB; ++il) {
+        const int n = img0 + il;
+        if (n >= a.B) break;
+        float sum = 0.f, cnt = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = drow(r, hi);
-                const unsigned vm = (row >= lo && row < hi_) ? vmask[r] : 0u;
-                sum += ((vm & 1u) ? y00[r] : 0.f) + ((vm & 2u) ? y01[r] : 0.f) + ((vm & 4u) ? y10[r] : 0.f) + ((vm & 8u) ? y11[r] : 0.f);
-                cnt += (float)__popc(vm);
-            }
-            sum += __shfl_xor(sum, 32, 64);
-            cnt += __shfl_xor(cnt, 32, 64);
-            const float mean = cnt > 0.f ? sum / cnt : 0.f;
-            float q = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const unsigned vm = (rimg[r] == il) ? vmask[r] : 0u;
+            sum += ((vm & 1u) ? y00[r] : 0.f) + ((vm & 2u) ? y01[r] : 0.f) + ((vm & 4u) ? y10[r] : 0.f) + ((vm & 8u) ? y11[r] : 0.f);
+            cnt += (float)__popc(vm);
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        cnt += __shfl_xor(cnt, 32, 64);
+        const float mean = cnt > 0.f ? sum / cnt : 0.f;
+        float q = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = drow(r, hi);
-                const unsigned vm = (row >= lo && row < hi_) ? vmask[r] : 0u;
-                const float d0 = y00[r] - mean, d1 = y01[r] - mean, d2 = y10[r] - mean, d3 = y11[r] - mean;
-                q += ((vm & 1u) ? d0 * d0 : 0.f) + ((vm & 2u) ? d1 * d1 : 0.f) + ((vm & 4u) ? d2 * d2 : 0.f) + ((vm & 8u) ? d3 * d3 : 0.f);
-            }
-            q += __shfl_xor(q, 32, 64);
-            if (hi == 0) {
-                float* o = a.part + ((tile32 * a.nslots + s) * a.Cout + co) * 3;
-                o[0] = cnt; o[1] = mean; o[2] = q;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const unsigned vm = (rimg[r] == il) ? vmask[r] : 0u;
+            const float d0 = y00[r] - mean, d1 = y01[r] - mean, d2 = y10[r] - mean, d3 = y11[r] - mean;
+            q += ((vm & 1u) ? d0 * d0 : 0.f) + ((vm & 2u) ? d1 * d1 : 0.f) + ((vm & 4u) ? d2 * d2 : 0.f) + ((vm & 8u) ? d3 * d3 : 0.f);
+        }
+        q += __shfl_xor(q, 32, 64);
+        if (hi == 0) {
+            float* o = a.part + (((long long)n * a.PB + pb) * a.Cout + co) * 3;
+            o[0] = cnt; o[1] = mean; o[2] = q;
         }
     }
 }
 
-// (cnt, mean, M2) partials of flattened 32-tile groups -> mean / rstd per (image, channel)
+// (cnt, mean, M2) partials [B][nparts][C][3] -> mean / rstd per (image, channel)
 __global__ __launch_bounds__(256) void k_in_finalize_cnt(const float* __restrict__ part, float* __restrict__ mean,
-                                                        float* __restrict__ rstd, int HWt, int C, int nslots,
-                                                        long long Ttot) {
+                                                        float* __restrict__ rstd, int nparts, int C) {
     const int n = blockIdx.x;
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const long long ibeg = (long long)n * HWt, iend = ibeg + HWt;
-    const long long t0 = ibeg >> 5, t1 = (iend - 1) >> 5;
     __shared__ float red[2][4][64];
     for (int c = cl; c < C; c += 64) {
         float s = 0.f, cnt = 0.f;
-        for (long long t = t0 + g; t <= t1; t += 4) {
-            const int sl = n - (int)((t << 5) / HWt);
-            if (sl < 0 || sl >= nslots) continue;
-            const float* o = part + ((t * nslots + sl) * C + c) * 3;
+        for (int t = g; t < nparts; t += 4) {
+            const float* o = part + (((long long)n * nparts + t) * C + c) * 3;
             s += o[0] * o[1];
             cnt += o[0];
         }
@@ -524,10 +585,8 @@ __global__ __launch_bounds__(256) void k_in_finalize_cnt(const float* __restrict
         const float tot = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
         const float mu = ((red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl])) / tot;
         float q = 0.f;
-        for (long long t = t0 + g; t <= t1; t += 4) {
-            const int sl = n - (int)((t << 5) / HWt);
-            if (sl < 0 || sl >= nslots) continue;
-            const float* o = part + ((t * nslots + sl) * C + c) * 3;
+        for (int t = g; t < nparts; t += 4) {
+            const float* o = part + (((long long)n * nparts + t) * C + c) * 3;
             const float dlt = o[1] - mu;
             q += o[2] + o[0] * dlt * dlt;
         }
@@ -540,7 +599,6 @@ __global__ __launch_bounds__(256) void k_in_finalize_cnt(const float* __restrict
             rstd[(long long)n * C + c] = 1.0f / sqrtf(m2 / tot + IN_EPS);
         }
     }
-    (void)Ttot;
 }
 
 // OIHW 3x3 weights -> Winograd domain U = G g G^T, laid out [16][I/8][O][8]
@@ -848,6 +906,26 @@ Dims dims_for(int H, int W) {
     return d;
 }
 
+// Winograd unit shape: IB images x TYB x TXB tiles with IB*TYB*TXB <= 32 and a raw input region of
+// at most WRAW_MAX pixels, maximising the fraction of the 32 MFMA rows that carry real tiles.
+void wino_shape(int B, int TY, int TX, int& IB, int& TYB, int& TXB) {
+    double best = -1.0;
+    IB = 1; TYB = 1; TXB = TX < WTT ? TX : WTT;
+    for (int txb = 1; txb <= TX && txb <= WTT; ++txb) {
+        if (txb != TX && txb != (TX + 1) / 2 && txb != (TX + 2) / 3 && txb != (TX + 3) / 4 && txb != 32 && txb != 16) continue;
+        for (int tyb = 1; tyb <= TY && tyb * txb <= WTT; ++tyb)
+            for (int ib = 1; ib <= 16 && ib * tyb * txb <= WTT && ib <= B; ++ib) {
+                if (ib > 1 && (tyb != TY && txb != TX) ) continue;  // several images per unit only for whole rows
+                if ((long long)ib * (2 * tyb + 2) * (2 * txb + 2) > WRAW_MAX) continue;
+                const double units = (double)((B + ib - 1) / ib) * ((TY + tyb - 1) / tyb) * ((TX + txb - 1) / txb);
+                const double util = (double)B * TY * TX / (units * (double)WTT);
+                // prefer higher utilisation, then fewer raw pixels per tile (less halo)
+                const double score = util - 1e-4 * (double)(2 * tyb + 2) * (2 * txb + 2) / (tyb * txb);
+                if (score > best) { best = score; IB = ib; TYB = tyb; TXB = txb; }
+            }
+    }
+}
+
 struct RWs {
     size_t y0, buf[5], stat[4][2], part, total;  // stat[k] = {mean, rstd}
     long long act_elems, part_elems;
@@ -874,7 +952,12 @@ RWs rws_layout(int B, int H, int W) {
         if (e > mx) mx = e;
         const int HWt = ((d.h[l] + 1) / 2) * ((d.w[l] + 1) / 2);
         const long long Tt = (long long)B * HWt;
-        const long long ew = ((Tt + 31) / 32) * (31 / HWt + 2) * C * 3;  // Winograd (cnt, mean, M2) partials
+        (void)Tt;
+        int ib, tyb, txb;
+        const int TYl = (d.h[l] + 1) / 2, TXl = (d.w[l] + 1) / 2;
+        wino_shape(B, TYl, TXl, ib, tyb, txb);
+        const long long PBl = (long long)((TYl + tyb - 1) / tyb) * ((TXl + txb - 1) / txb);
+        const long long ew = (long long)B * PBl * C * 3;  // Winograd (cnt, mean, M2) partials
         if (ew > mx) mx = ew;
     }
     r.part_elems = mx;
@@ -890,18 +973,18 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
         wa.x = x; wa.u = wpk; wa.in_mean = in_mean; wa.in_rstd = in_rstd; wa.y = y; wa.part = part;
         wa.B = B; wa.H = H; wa.W = W; wa.C = s.cin; wa.Cout = s.cout;
         wa.TY = (H + 1) / 2; wa.TX = (W + 1) / 2;
-        const int HWt = wa.TY * wa.TX;
-        wa.nslots = 31 / HWt + 2;
-        wa.Ttot = (long long)B * HWt;
-        const size_t lds = (size_t)2 * WTILE * sizeof(float);
-        dim3 grid((unsigned)((wa.Ttot + 63) / 64), (unsigned)(s.cout / 64));
+        wino_shape(B, wa.TY, wa.TX, wa.IB, wa.TYB, wa.TXB);
+        static const int wexpt = getenv("DSMIL_WINO_EXPT") ? atoi(getenv("DSMIL_WINO_EXPT")) : 0;
+        wa.expt = wexpt;
+        wa.nby = (wa.TY + wa.TYB - 1) / wa.TYB; wa.nbx = (wa.TX + wa.TXB - 1) / wa.TXB; wa.PB = wa.nby * wa.nbx;
+        const size_t lds = (size_t)(2 * WTILE + 2 * WRAW_MAX * WLD) * sizeof(float);
+        dim3 grid((unsigned)(((B + wa.IB - 1) / wa.IB) * wa.PB), (unsigned)(s.cout / 64));
         const int slot = dsmil_prof::begin(dsmil_prof::CH_CONV, st);
         if (in_mean) hipLaunchKernelGGL((k_conv_wino<true>), grid, dim3(256), lds, st, wa);
         else hipLaunchKernelGGL((k_conv_wino<false>), grid, dim3(256), lds, st, wa);
         dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
-        hipLaunchKernelGGL(k_in_finalize_cnt, dim3((unsigned)B), dim3(256), 0, st, part, mean, rstd, HWt, s.cout,
-                           wa.nslots, wa.Ttot);
+        hipLaunchKernelGGL(k_in_finalize_cnt, dim3((unsigned)B), dim3(256), 0, st, part, mean, rstd, wa.PB, s.cout);
         return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
     }
     ConvArgs a;
@@ -959,8 +1042,8 @@ void set_conv_attrs() {
     (void)hipFuncSetAttribute((const void*)k_conv<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
     (void)hipFuncSetAttribute((const void*)k_conv<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
     (void)hipFuncSetAttribute((const void*)k_conv<4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
-    (void)hipFuncSetAttribute((const void*)k_conv_wino<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WTILE * 4);
-    (void)hipFuncSetAttribute((const void*)k_conv_wino<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WTILE * 4);
+    (void)hipFuncSetAttribute((const void*)k_conv_wino<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * WTILE + 2 * WRAW_MAX * WLD) * 4);
+    (void)hipFuncSetAttribute((const void*)k_conv_wino<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * WTILE + 2 * WRAW_MAX * WLD) * 4);
     g_attr_done = true;
 }
 
