@@ -327,7 +327,7 @@ struct WinoArgs {
     const float* in_mean;  // [B,C] or null
     const float* in_rstd;
     float* y;              // raw NHWC [B,H,W,Cout]
-    float* part;           // [B][PB][Cout][3]   (cnt, mean, M2)
+    float* part;           // [B][PB][2][Cout][3]   (cnt, mean, M2) per output-row half
     int B, H, W, C, Cout, TY, TX;
     int IB, TYB, TXB;      // unit shape: images x tile rows x tile cols (IB*TYB*TXB <= 32)
     int nby, nbx, PB;      // units per image along y / x, PB = nby*nbx
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
     f32x4 ub[8];
-    // ---- prologue: raw(0) -> LDS, V(0), raw(1) -> LDS, weights of chunk 0
+    // ---- prologue: raw(0) -> LDS, V(0), raw(1) -> LDS, raw(2) -> registers, weights of chunk 0
     raw_load(0);
 #pragma unroll
     for (int p = 0; p < 8; ++p) { ub[p] = *reinterpret_cast<const f32x4*>(up[p]); up[p] += ustep; }
@@ -462,12 +462,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoArgs a) {
     __syncthreads();
     transform(0);
     if (nchunks > 1) { raw_load(1); raw_write(1); }
+    if (nchunks > 2) raw_load(2);
     __syncthreads();
     const int vfo = ((8 * wp) * WTT + l31) * WLD + 4 * hi;
+    // iteration cc: transform(cc+1) [raw(cc+1) was written an iteration ago], MFMAs(cc) with the weight
+    // loads of chunk cc+1 re-issued behind each position, then raw(cc+2) registers -> LDS (loaded a
+    // whole iteration ago) and the global loads of raw(cc+3) into the same registers.
     for (int cc = 0; cc < nchunks; ++cc) {
-        const bool more = cc + 1 < nchunks, more2 = cc + 2 < nchunks;   // block-uniform
-        if (more2 && !(a.expt & 2)) raw_load(cc + 2);
-        if (more && !(a.expt & 1)) transform(cc + 1);   // raw[(cc+1)&1] -> V[(cc+1)&1]; the co-resident workgroup's MFMAs cover it
+        const bool more = cc + 1 < nchunks, more2 = cc + 2 < nchunks, more3 = cc + 3 < nchunks;   // block-uniform
+        if (more && !(a.expt & 1)) transform(cc + 1);
         const float* vb = sV + (cc & 1) * WTILE + vfo;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -477,7 +480,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoArgs a) {
             for (int j = 0; j < 4; ++j) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], w[j], acc[p], 0, 0, 0);
             if (more && !(a.expt & 4)) { ub[p] = *reinterpret_cast<const f32x4*>(up[p]); up[p] += ustep; }
         }
-        if (more2 && !(a.expt & 2)) raw_write(cc + 2);   // raw[cc&1] was consumed by the transform of chunk cc
+        if (!(a.expt & 2)) {
+            if (more2) raw_write(cc + 2);   // raw[cc&1] was consumed by transform(cc) an iteration ago
+            if (more3) raw_load(cc + 3);
+        }
         __syncthreads();
     }
     if (a.expt & 8) {  // ablation: no epilogue
@@ -500,23 +506,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoArgs a) {
         if (wp == 0) { y00[r] = raA + raB; y01[r] = rbA + rbB; y10[r] = raB; y11[r] = rbB; }
         else { y00[r] = raA; y01[r] = rbA; y10[r] = -raA - raB; y11[r] = -rbA - rbB; }
     }
-    // hand the wp = 1 partials to the wp = 0 partner (same wn) through LDS (the V buffers are free now)
-    float* xch = smem + (wn * 64 + lane) * 65;  // [2 partner pairs][64 lanes][64 (+1 pad)]
-    if (wp == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            xch[r] = y00[r]; xch[16 + r] = y01[r]; xch[32 + r] = y10[r]; xch[48 + r] = y11[r];
-        }
-    }
-    __syncthreads();
-    if (wp == 1) return;
+    // exchange through LDS (the V buffers are free now): the wp = 0 wave finishes output row 0
+    // (y00, y01), the wp = 1 wave output row 1 (y10, y11); each sends the other row's partials
+    float* xch = smem + ((wn * 2 + wp) * 64 + lane) * 33;        // [2 wn][2 wp][64 lanes][32 (+1 pad)]
+    float* xpr = smem + ((wn * 2 + (wp ^ 1)) * 64 + lane) * 33;  // the partner's slot
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        y00[r] += xch[r]; y01[r] += xch[16 + r]; y10[r] += xch[32 + r]; y11[r] += xch[48 + r];
+        xch[r] = wp == 0 ? y10[r] : y00[r];
+        xch[16 + r] = wp == 0 ? y11[r] : y01[r];
     }
-    // ---- raw store + statistics partials (wp = 0 waves)
+    __syncthreads();
+    float ya[16], yb[16];  // this wave's output row: pixels (oy+wp, ox) and (oy+wp, ox+1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        ya[r] = (wp == 0 ? y00[r] : y10[r]) + xpr[r];
+        yb[r] = (wp == 0 ? y01[r] : y11[r]) + xpr[16 + r];
+    }
+    // ---- raw store + statistics partials
     const int co = n0 + wn * 32 + l31;
-    unsigned vmask[16];  // 4 validity bits per accumulator row (tile slot)
+    unsigned vmask[16];  // 2 validity bits per accumulator row (tile slot)
     int rimg[16];        // local image of the row's tile slot (or -1)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -525,14 +533,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoArgs a) {
         const int n = img0 + il, ty = ty0 + tyl, tx = tx0 + txl;
         unsigned vm = 0;
         rimg[r] = -1;
-        if (slot < a.IB * tpi && n < a.B && ty < a.TY && tx < a.TX) {
-            const int oy = 2 * ty, ox = 2 * tx;
+        const int oy = 2 * ty + wp, ox = 2 * tx;
+        if (slot < a.IB * tpi && n < a.B && ty < a.TY && tx < a.TX && oy < a.H) {
             float* o = a.y + ((long long)(n * a.H + oy) * a.W + ox) * a.Cout + co;
-            const bool byv = oy + 1 < a.H, bxv = ox + 1 < a.W;
-            o[0] = y00[r]; vm = 1u;
-            if (bxv) { o[a.Cout] = y01[r]; vm |= 2u; }
-            if (byv) { o[(long long)a.W * a.Cout] = y10[r]; vm |= 4u; }
-            if (byv && bxv) { o[(long long)(a.W + 1) * a.Cout] = y11[r]; vm |= 8u; }
+            o[0] = ya[r]; vm = 1u;
+            if (ox + 1 < a.W) { o[a.Cout] = yb[r]; vm |= 2u; }
             rimg[r] = il;
         }
         vmask[r] = vm;
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const unsigned vm = (rimg[r] == il) ? vmask[r] : 0u;
-            sum += ((vm & 1u) ? y00[r] : 0.f) + ((vm & 2u) ? y01[r] : 0.f) + ((vm & 4u) ? y10[r] : 0.f) + ((vm & 8u) ? y11[r] : 0.f);
+            sum += ((vm & 1u) ? ya[r] : 0.f) + ((vm & 2u) ? yb[r] : 0.f);
             cnt += (float)__popc(vm);
         }
         sum += __shfl_xor(sum, 32, 64);
@@ -554,12 +559,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const unsigned vm = (rimg[r] == il) ? vmask[r] : 0u;
-            const float d0 = y00[r] - mean, d1 = y01[r] - mean, d2 = y10[r] - mean, d3 = y11[r] - mean;
-            q += ((vm & 1u) ? d0 * d0 : 0.f) + ((vm & 2u) ? d1 * d1 : 0.f) + ((vm & 4u) ? d2 * d2 : 0.f) + ((vm & 8u) ? d3 * d3 : 0.f);
+            const float d0 = ya[r] - mean, d1 = yb[r] - mean;
+            q += ((vm & 1u) ? d0 * d0 : 0.f) + ((vm & 2u) ? d1 * d1 : 0.f);
         }
         q += __shfl_xor(q, 32, 64);
         if (hi == 0) {
-            float* o = a.part + (((long long)n * a.PB + pb) * a.Cout + co) * 3;
+            float* o = a.part + ((((long long)n * a.PB + pb) * 2 + wp) * a.Cout + co) * 3;
             o[0] = cnt; o[1] = mean; o[2] = q;
         }
     }
@@ -957,7 +962,7 @@ RWs rws_layout(int B, int H, int W) {
         const int TYl = (d.h[l] + 1) / 2, TXl = (d.w[l] + 1) / 2;
         wino_shape(B, TYl, TXl, ib, tyb, txb);
         const long long PBl = (long long)((TYl + tyb - 1) / tyb) * ((TXl + txb - 1) / txb);
-        const long long ew = (long long)B * PBl * C * 3;  // Winograd (cnt, mean, M2) partials
+        const long long ew = (long long)B * PBl * 2 * C * 3;  // Winograd (cnt, mean, M2) partials
         if (ew > mx) mx = ew;
     }
     r.part_elems = mx;
@@ -984,7 +989,7 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
         else hipLaunchKernelGGL((k_conv_wino<false>), grid, dim3(256), lds, st, wa);
         dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
-        hipLaunchKernelGGL(k_in_finalize_cnt, dim3((unsigned)B), dim3(256), 0, st, part, mean, rstd, wa.PB, s.cout);
+        hipLaunchKernelGGL(k_in_finalize_cnt, dim3((unsigned)B), dim3(256), 0, st, part, mean, rstd, wa.PB * 2, s.cout);
         return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
     }
     ConvArgs a;
