@@ -674,74 +674,108 @@ struct StemLoop<-1> {
     static __device__ __forceinline__ void run(const float*, const float*, int, int, int, f32x16 (&)[2]) {}
 };
 
+// One workgroup walks a whole ROW of 8x16-pixel tiles of one image: the 64x147 weights are staged
+// in LDS once per row (not once per tile), and the next tile's input window is prefetched into
+// registers under the current tile's MFMAs and written to the other LDS window buffer.
+constexpr int ST_WPT = (3 * ST_PLANE + 255) / 256;  // window floats per thread
+
 __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const float* __restrict__ w,
                                               float* __restrict__ y, float* __restrict__ part, int B,
                                               int H, int W, int Ho, int Wo, int tiles_x, int tiles_y) {
-    __shared__ __attribute__((aligned(16))) float sIn[3 * ST_PLANE];
+    __shared__ __attribute__((aligned(16))) float sIn[2][3 * ST_PLANE];
     __shared__ __attribute__((aligned(16))) float sW[64 * ST_LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int tile = blockIdx.x, n = blockIdx.y;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int oy0 = ty * 8, ox0 = tx * 16;
-    const int iy00 = oy0 * 2 - 3, ix00 = ox0 * 2 - 3;
-    // stage the input window (zero padded) and the weights (K padded to 152 with zeros)
-    for (int e = tid; e < 3 * ST_PLANE; e += 256) {
-        const int c = e / ST_PLANE, r = (e - c * ST_PLANE) / ST_LW, col = e - c * ST_PLANE - r * ST_LW;
-        const int iy = iy00 + r, ix = ix00 + col;
-        float v = 0.f;
-        if (col < 37 && iy >= 0 && iy < H && ix >= 0 && ix < W)
-            v = x[(((long long)n * 3 + c) * H + iy) * W + ix];
-        sIn[e] = v;
+    const int ty = blockIdx.x, n = blockIdx.y;
+    const int oy0 = ty * 8;
+    const int iy00 = oy0 * 2 - 3;
+    // per-thread window elements: row base offset in x (or -1) and column inside the window
+    int wrow[ST_WPT], wcol[ST_WPT];
+#pragma unroll
+    for (int q = 0; q < ST_WPT; ++q) {
+        const int e = tid + 256 * q;
+        wrow[q] = -1; wcol[q] = 0;
+        if (e < 3 * ST_PLANE) {
+            const int c = e / ST_PLANE, r = (e - c * ST_PLANE) / ST_LW, col = e - c * ST_PLANE - r * ST_LW;
+            const int iy = iy00 + r;
+            wcol[q] = col;
+            if (col < 37 && iy >= 0 && iy < H) wrow[q] = ((n * 3 + c) * H + iy) * W;
+        }
     }
+    float wreg[ST_WPT];
+    auto win_load = [&](int tx) {
+        const int ix00 = tx * 32 - 3;
+#pragma unroll
+        for (int q = 0; q < ST_WPT; ++q) {
+            const int ix = ix00 + wcol[q];
+            const bool ok = wrow[q] >= 0 && ix >= 0 && ix < W;
+            const float v = x[ok ? (long long)wrow[q] + ix : 0];
+            wreg[q] = ok ? v : 0.f;
+        }
+    };
+    auto win_write = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < ST_WPT; ++q) {
+            const int e = tid + 256 * q;
+            if (e < 3 * ST_PLANE) sIn[buf][e] = wreg[q];
+        }
+    };
+    win_load(0);
     for (int e = tid; e < 64 * ST_KP; e += 256) {
         const int co = e / ST_KP, k = e - co * ST_KP;
         sW[co * ST_LDW + k] = (k < ST_K) ? w[co * ST_K + k] : 0.f;
     }
+    win_write(0);
     __syncthreads();
-    f32x16 acc[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
     const int py = 2 * wave + (l31 >> 4), px = l31 & 15;
     const int pixbase = (2 * py) * ST_LW + 2 * px;
     const int frag = l31 * ST_LDW + 4 * hi;
-    StemLoop<ST_KP / 8 - 1>::run(sIn, sW, pixbase, frag, hi, acc);
-    // store raw NHWC + statistics partial (cnt, mean, M2) per (image, tile, wave, channel)
-    int cnt = 0;
-    float s0 = 0.f, s1 = 0.f;
-    bool okr[16];
+    for (int tx = 0; tx < tiles_x; ++tx) {
+        const int ox0 = tx * 16;
+        if (tx + 1 < tiles_x) win_load(tx + 1);
+        f32x16 acc[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int q = drow(r, hi);
-        const int oy = oy0 + 2 * wave + (q >> 4), ox = ox0 + (q & 15);
-        okr[r] = (oy < Ho) && (ox < Wo);
-        if (okr[r]) {
-            float* o = y + (((long long)n * Ho + oy) * Wo + ox) * 64;
-            o[l31] = acc[0][r];
-            o[32 + l31] = acc[1][r];
-            s0 += acc[0][r];
-            s1 += acc[1][r];
-            ++cnt;
-        }
-    }
-    cnt += __shfl_xor(cnt, 32, 64);
-    s0 += __shfl_xor(s0, 32, 64);
-    s1 += __shfl_xor(s1, 32, 64);
-    const float fc = (float)cnt;
-    const float m0 = cnt ? s0 / fc : 0.f, m1 = cnt ? s1 / fc : 0.f;
-    float q0 = 0.f, q1 = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        StemLoop<ST_KP / 8 - 1>::run(sIn[tx & 1], sW, pixbase, frag, hi, acc);
+        if (tx + 1 < tiles_x) win_write((tx + 1) & 1);
+        // store raw NHWC + statistics partial (cnt, mean, M2) per (image, tile, wave, channel)
+        int cnt = 0;
+        float s0 = 0.f, s1 = 0.f;
+        bool okr[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        if (okr[r]) {
-            const float d0 = acc[0][r] - m0, d1 = acc[1][r] - m1;
-            q0 += d0 * d0;
-            q1 += d1 * d1;
+        for (int r = 0; r < 16; ++r) {
+            const int q = drow(r, hi);
+            const int oy = oy0 + 2 * wave + (q >> 4), ox = ox0 + (q & 15);
+            okr[r] = (oy < Ho) && (ox < Wo);
+            if (okr[r]) {
+                float* o = y + (((long long)n * Ho + oy) * Wo + ox) * 64;
+                o[l31] = acc[0][r];
+                o[32 + l31] = acc[1][r];
+                s0 += acc[0][r];
+                s1 += acc[1][r];
+                ++cnt;
+            }
         }
-    q0 += __shfl_xor(q0, 32, 64);
-    q1 += __shfl_xor(q1, 32, 64);
-    if (hi == 0) {
-        float* o = part + ((((long long)n * tiles_x * tiles_y + tile) * 4 + wave) * 64) * 3;
-        o[l31 * 3 + 0] = fc; o[l31 * 3 + 1] = m0; o[l31 * 3 + 2] = q0;
-        o[(32 + l31) * 3 + 0] = fc; o[(32 + l31) * 3 + 1] = m1; o[(32 + l31) * 3 + 2] = q1;
+        cnt += __shfl_xor(cnt, 32, 64);
+        s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        const float fc = (float)cnt;
+        const float m0 = cnt ? s0 / fc : 0.f, m1 = cnt ? s1 / fc : 0.f;
+        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (okr[r]) {
+                const float d0 = acc[0][r] - m0, d1 = acc[1][r] - m1;
+                q0 += d0 * d0;
+                q1 += d1 * d1;
+            }
+        q0 += __shfl_xor(q0, 32, 64);
+        q1 += __shfl_xor(q1, 32, 64);
+        if (hi == 0) {
+            float* o = part + ((((long long)n * tiles_x * tiles_y + ty * tiles_x + tx) * 4 + wave) * 64) * 3;
+            o[l31 * 3 + 0] = fc; o[l31 * 3 + 1] = m0; o[l31 * 3 + 2] = q0;
+            o[(32 + l31) * 3 + 0] = fc; o[(32 + l31) * 3 + 1] = m1; o[(32 + l31) * 3 + 2] = q1;
+        }
+        __syncthreads();
     }
 }
 
@@ -1111,7 +1145,7 @@ int dsmil_resnet18in_forward(const float* x_nchw, int32_t B, int32_t H, int32_t 
     // ---- stem: conv1 -> IN -> ReLU -> maxpool
     {
         const int tx = (d.W1 + 15) / 16, ty = (d.H1 + 7) / 8;
-        hipLaunchKernelGGL(k_stem, dim3((unsigned)(tx * ty), (unsigned)B), dim3(256), 0, st, x_nchw, conv1_w, y0,
+        hipLaunchKernelGGL(k_stem, dim3((unsigned)ty, (unsigned)B), dim3(256), 0, st, x_nchw, conv1_w, y0,
                            part, B, H, W, d.H1, d.W1, tx, ty);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         hipLaunchKernelGGL(k_in_finalize_stem, dim3((unsigned)B), dim3(256), 0, st, part,
