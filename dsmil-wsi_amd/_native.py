@@ -27,6 +27,12 @@ class AggParams(ctypes.Structure):
                 ("C", ctypes.c_int32), ("nonlinear", ctypes.c_int32)]
 
 
+class AggGrads(ctypes.Structure):
+    """struct dsmil_agg_grads (include/dsmil_hip.h)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in
+                ("fc_w", "fc_b", "q0_w", "q0_b", "q2_w", "q2_b", "fcc_w", "fcc_b")]
+
+
 # symbol -> (restype, argtypes); must list every function include/dsmil_hip.h declares
 SIGNATURES = {
     "dsmil_abi_version": (ctypes.c_int, []),
@@ -50,6 +56,12 @@ SIGNATURES = {
                                                 c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dsmil_fc_forward": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                         c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
+    "dsmil_agg_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                                             ctypes.c_int32]),
+    "dsmil_agg_backward": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int64, ctypes.POINTER(AggParams), c_f32p,
+                                          c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                          ctypes.POINTER(AggGrads), c_f32p, ctypes.c_void_p, ctypes.c_size_t,
+                                          ctypes.c_void_p]),
     "dsmil_agg_forward": (ctypes.c_int, [c_f32p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int64,
                                          ctypes.c_int64, ctypes.POINTER(AggParams), c_f32p, c_f32p,
                                          c_f32p, c_f32p, c_f32p, c_i64p, ctypes.c_void_p,

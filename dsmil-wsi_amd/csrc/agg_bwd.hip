@@ -1,0 +1,531 @@
+// DSMIL dual-stream aggregator, backward — hand-written HIP for gfx950 (MI355X, CDNA4).
+//
+// Gradient of dsmil.py:46-62 (+ the fused FCLayer, dsmil.py:6-12) for ONE bag, as autograd would
+// produce it for train_tcga.py:67-72 (the arg-max indices are constants; nonlinear or linear query;
+// v = Identity or caller-supplied value rows).  Notation: x [N,K], c = x Wf^T + bf, H = relu(x W1^T+b1),
+// Q = tanh(H W2^T + b2), q_c = Q[idx_c], s = Q q^T / sqrt(128), A = softmax_n(s), B = A^T V,
+// pred = fcc(B).
+//   gB  = g_B + sum_o g_pred[o] fcc_w[o]            g_fcc_w = g_pred (x) B,  g_fcc_b = g_pred
+//   gA  = g_A + V gB^T                              D_c = <gB_c, B_c> (+ sum_n A g_A)   [= sum_n A gA]
+//   gs  = A (gA - D) / sqrt(128)
+//   gQ  = gs q  (+ at row idx_c:  sum_n gs[n,c] Q[n])        gz2 = gQ (1 - Q^2)
+//   g_W2 = gz2^T H, g_b2 = colsum gz2, gH = (gz2 W2) [H > 0], g_W1 = gH^T x, g_b1 = colsum gH
+//   g_Wf = g_c^T x, g_bf = colsum g_c
+// Launch sequence (one stream, no host sync):
+//   k_bwd_prep      gB, D, g_fcc_*, W2^T                       (1 workgroup)
+//   dsmil_fc_forward  gA = V gB^T                              (HBM stream, reuses the forward kernel)
+//   k_bwd_qrow      q_c = q(x[idx_c])                          (1 workgroup per class)
+//   k_bwd_rows      recompute H, Q per 32-row wave tile on f32 MFMA (mlp_tile of the forward),
+//                   gs, gz2 -> workspace (row-major gz2, H, Q, gs)
+//   k_tn_small      g_q = gs^T Q        then k_bwd_critical adds it into gz2 at the critical rows
+//   k_bwd_gh        gH = (gz2 W2) [H>0]  — the forward GEMM-1 pipeline with X := gz2, W := W2^T
+//   k_tn_gemm       g_W2 = gz2^T H, g_W1 = gH^T x  (contraction over instances on f32 MFMA,
+//                   split over row ranges, deterministic two-stage reduction) + column sums
+//   k_tn_small      g_Wf = g_c^T x, g_bf
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "agg_common.h"
+
+namespace {
+
+// instance rows per workgroup of the contraction-over-N kernels: >= 128, multiple of 32, and at most
+// 256 row ranges per bag (bounds the partial buffers; ~1000 workgroups on the 4-slab weight GEMM)
+inline int tn_rows(long long N) {
+    long long r = (N + 255) / 256;
+    r = (r + 31) / 32 * 32;
+    return (int)(r < 128 ? 128 : r);
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- k_bwd_prep ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bwd_prep(
+    const float* __restrict__ fcc_w, const float* __restrict__ Bm, const float* __restrict__ g_pred,
+    const float* __restrict__ g_B, const float* __restrict__ A, const float* __restrict__ g_A,
+    const float* __restrict__ q2_w, float* __restrict__ gB, float* __restrict__ Dv,
+    float* __restrict__ g_fcc_w, float* __restrict__ g_fcc_b, float* __restrict__ W2T,
+    float* __restrict__ zero128, long long N, int Kv, int C, int nonlinear) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    for (int c = 0; c < C; ++c) {
+        float dpart = 0.f;
+        for (int k = tid; k < Kv; k += 256) {
+            float g = g_B ? g_B[c * Kv + k] : 0.f;
+            for (int o = 0; o < C; ++o) g = fmaf(g_pred[o], fcc_w[((long long)o * C + c) * Kv + k], g);
+            gB[c * Kv + k] = g;
+            dpart = fmaf(g, Bm[c * Kv + k], dpart);
+        }
+        if (g_A)
+            for (long long n = tid; n < N; n += 256) dpart = fmaf(A[n * C + c], g_A[n * C + c], dpart);
+        const float d = block_sum_256(dpart, red);
+        if (tid == 0) Dv[c] = d;
+    }
+    for (long long i = tid; i < (long long)C * C * Kv; i += 256) {
+        const int o = (int)(i / ((long long)C * Kv));
+        const long long ck = i - (long long)o * C * Kv;
+        g_fcc_w[i] = g_pred[o] * Bm[ck];
+    }
+    if (tid < C) g_fcc_b[tid] = g_pred[tid];
+    if (tid < QD) zero128[tid] = 0.f;
+    if (nonlinear)
+        for (int i = tid; i < QD * QD; i += 256) W2T[i] = q2_w[(i & (QD - 1)) * QD + (i >> 7)];  // W2T[j][j2] = W2[j2][j]
+}
+
+// ---- k_bwd_qrow: q_c = q(x[idx_c]) (dsmil.py:53-54), one workgroup per class ------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_bwd_qrow(
+    const float* __restrict__ feats, const int64_t* __restrict__ idx, const float* __restrict__ q0_w,
+    const float* __restrict__ q0_b, const float* __restrict__ q2_w, const float* __restrict__ q2_b,
+    float* __restrict__ qmax, int K, int nonlinear) {
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float s_h[QD];
+    const float* x = feats + idx[c] * (long long)K;
+    for (int jb = 0; jb < 32; jb += 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* wr = q0_w + (long long)(wave * 32 + jb) * K;
+        for (int k0 = 0; k0 < K; k0 += 256) {
+            const int k = k0 + lane * 4;
+            const f32x4 xv = load4<VEC, float>(x, k, K);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f32x4 wv = load4<VEC, float>(wr + (long long)u * K, k, K);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[u] = fmaf(xv[e], wv[e], acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float a = wave_sum(acc[u]) + q0_b[wave * 32 + jb + u];
+            if (nonlinear) a = fmaxf(a, 0.f);
+            if (lane == 0) s_h[wave * 32 + jb + u] = a;
+        }
+    }
+    __syncthreads();
+    float* out = qmax + (long long)c * QD;
+    if (!nonlinear) {
+        if (threadIdx.x < QD) out[threadIdx.x] = s_h[threadIdx.x];
+        return;
+    }
+    const float h0 = s_h[lane], h1 = s_h[lane + 64];
+    for (int jj = 0; jj < 32; ++jj) {
+        const float* wr = q2_w + (long long)(wave * 32 + jj) * QD;
+        const float a = wave_sum(fmaf(h0, wr[lane], h1 * wr[lane + 64])) + q2_b[wave * 32 + jj];
+        if (lane == 0) out[wave * 32 + jj] = tanhf(a);
+    }
+}
+
+// ---- k_bwd_rows ----------------------------------------------------------------------------
+struct BwdRowsArgs {
+    AttendArgs at;        // feats, offsets (2 entries: 0, N), q-weights, qmax; bag 0
+    const float* A;       // [N,C]
+    const float* gA;      // [N,C]  = V gB^T
+    const float* g_A;     // [N,C] or null
+    const float* Dv;      // [C]
+    float* gs;            // [N,C]
+    float* gz2;           // [N,128]
+    float* Hbuf;          // [N,128]
+    float* Qbuf;          // [N,128]
+};
+
+template <int NW, int VEC>
+__global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_bwd_rows(BwdRowsArgs b) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AttendArgs& a = b.at;
+    f32x16 H[4], Q[4];
+    if (!mlp_tile<NW, VEC>(a, 0, (int)blockIdx.x, smem, H, Q)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const long long Nb = a.offsets[1] - a.offsets[0];
+    const long long row = (long long)blockIdx.x * (NW * 32) + wave * 32 + l31;
+    const bool valid = row < Nb;
+    const long long rc = valid ? row : Nb - 1;
+    const int C = a.C;
+    const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+    f32x16 G[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) G[t][r] = 0.f;
+    for (int c = 0; c < C; ++c) {
+        float ga = b.gA[rc * C + c];
+        if (b.g_A) ga += b.g_A[rc * C + c];
+        const float gsc = valid ? b.A[rc * C + c] * (ga - b.Dv[c]) * scale : 0.f;
+        if (valid && hi == 0) b.gs[row * C + c] = gsc;
+        const float* qm = a.qmax + (long long)c * QD;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(qm + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) G[t][4 * g + e] = fmaf(gsc, u[e], G[t][4 * g + e]);
+            }
+    }
+    if (!valid) return;
+    // gz2 = gQ (1 - Q^2) for the tanh query; rows go to the workspace row-major (4 units per store)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 gz, hv, qv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float q = Q[t][4 * g + e];
+                gz[e] = a.nonlinear ? G[t][4 * g + e] * (1.f - q * q) : G[t][4 * g + e];
+                hv[e] = H[t][4 * g + e];
+                qv[e] = q;
+            }
+            const long long o = row * QD + 32 * t + 8 * g + 4 * hi;
+            *reinterpret_cast<f32x4*>(b.gz2 + o) = gz;
+            *reinterpret_cast<f32x4*>(b.Hbuf + o) = hv;
+            *reinterpret_cast<f32x4*>(b.Qbuf + o) = qv;
+        }
+}
+
+// gz2[idx_c] += g_q[c] (1 - Q[idx_c]^2): q_c IS row idx_c of Q, so its gradient joins that row
+__global__ void k_bwd_critical(const int64_t* __restrict__ idx, const float* __restrict__ gq,
+                               const float* __restrict__ Qbuf, float* __restrict__ gz2, int C, int nonlinear) {
+    const int j = threadIdx.x;  // 128 threads
+    for (int c = 0; c < C; ++c) {
+        const long long o = idx[c] * QD + j;
+        const float q = Qbuf[o];
+        gz2[o] += gq[c * QD + j] * (nonlinear ? (1.f - q * q) : 1.f);
+    }
+}
+
+// ---- k_bwd_gh: gH = (gz2 W2) [H > 0] — forward GEMM-1 pipeline with X := gz2, W := W2^T ------------
+struct GhArgs {
+    AttendArgs at;  // feats = gz2 (K = 128), q0_w = W2T, q0_b = zeros, nonlinear = 0
+    const float* Hbuf;
+    float* gH;
+};
+template <int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_bwd_gh(GhArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x16 H[4], Q[4];
+    if (!mlp_tile<NW, 4>(g.at, 0, (int)blockIdx.x, smem, H, Q)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+    const long long Nb = g.at.offsets[1] - g.at.offsets[0];
+    const long long row = (long long)blockIdx.x * (NW * 32) + wave * 32 + l31;
+    if (row >= Nb) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            const long long o = row * QD + 32 * t + 8 * gg + 4 * hi;
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(g.Hbuf + o);
+            f32x4 out;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[e] = hv[e] > 0.f ? H[t][4 * gg + e] : 0.f;
+            *reinterpret_cast<f32x4*>(g.gH + o) = out;
+        }
+}
+
+// ---- k_tn_gemm: part[s][128][Kc] = Am[rows of split s][128]^T  Bm[rows][Kc]  on f32 MFMA -------------
+// grid = (ceil(Kc/128), splits).  Per 32-row step both operands sit row-major in LDS; MFMA step k
+// contracts instance rows 2k, 2k+1: A lane (m = l31, hi) reads Am[2k+hi][32 mt + l31], B lane reads
+// Bm[2k+hi][32 w + l31] — consecutive lanes, consecutive words: conflict-free ds_read_b32.
+// Wave w owns output columns 32w..32w+31 of the slab, all 4 row tiles (units).  Slab 0 also sums
+// the columns of Am (bias gradient).
+template <int VEC>
+__global__ __launch_bounds__(256, 2) void k_tn_gemm(const float* __restrict__ Am, const float* __restrict__ Bm,
+                                                    float* __restrict__ part, float* __restrict__ part_b,
+                                                    long long N, int Kc, int TNR) {
+    __shared__ __attribute__((aligned(16))) float sA[32 * QD];
+    __shared__ __attribute__((aligned(16))) float sB[32 * QD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int slab = blockIdx.x, split = blockIdx.y;
+    const int k0 = slab * QD;
+    const long long rbeg = (long long)split * TNR, rend = (rbeg + TNR < N) ? rbeg + TNR : N;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float colsum = 0.f;
+    for (long long r0 = rbeg; r0 < rend; r0 += 32) {
+        // stage 32 rows x 128 of both operands (zero beyond the bag / beyond Kc)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i, r = f >> 5, c4 = f & 31;
+            const long long row = r0 + r;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (row < rend) {
+                va = *reinterpret_cast<const f32x4*>(Am + row * QD + c4 * 4);
+                vb = load4<VEC, float>(Bm + row * (long long)Kc, k0 + c4 * 4, Kc);
+            }
+            *reinterpret_cast<f32x4*>(sA + r * QD + c4 * 4) = va;
+            *reinterpret_cast<f32x4*>(sB + r * QD + c4 * 4) = vb;
+        }
+        __syncthreads();
+        if (slab == 0 && tid < QD) {
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) colsum += sA[r * QD + tid];
+        }
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const float bv = sB[(2 * ks + hi) * QD + wave * 32 + l31];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float av = sA[(2 * ks + hi) * QD + t * 32 + l31];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // D[row = unit m][col = slab column]: lane holds column 32w + l31, units drow(r,hi) + 32t
+    const int col = k0 + wave * 32 + l31;
+    if (col < Kc) {
+        float* o = part + (long long)split * QD * Kc;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                o[(long long)m * Kc + col] = acc[t][r];
+            }
+    }
+    if (slab == 0 && tid < QD) part_b[split * QD + tid] = colsum;
+}
+
+// out[i] = sum_s part[s][i]  (fixed order: deterministic)
+__global__ void k_reduce_parts(const float* __restrict__ part, float* __restrict__ out, int S, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += part[(long long)k * n + i];
+        out[i] = s;
+    }
+}
+
+// ---- k_tn_small: part[s][M][Kc] = a[rows][M]^T b[rows][Kc] for a handful of columns M (classes);
+//      also part_a[s][M] = column sums of a.  One wave walks rows, lanes walk the feature axis. -----
+template <int VEC>
+__global__ __launch_bounds__(256) void k_tn_small(const float* __restrict__ a, const float* __restrict__ bm,
+                                                  float* __restrict__ part, float* __restrict__ part_a,
+                                                  long long N, int M, int Kc, int TNR) {
+    __shared__ __attribute__((aligned(16))) float sacc[4][256 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int split = blockIdx.x;
+    const long long rbeg = (long long)split * TNR, rend = (rbeg + TNR < N) ? rbeg + TNR : N;
+    for (int m = 0; m < M; ++m) {
+        float asum = 0.f;
+        for (int kk = 0; kk < Kc; kk += 256) {
+            const int k = kk + lane * 4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (long long r = rbeg + wave; r < rend; r += 4) {
+                const float av = a[r * M + m];
+                const f32x4 bv = load4<VEC, float>(bm + r * (long long)Kc, k, Kc);
+                acc += av * bv;
+                if (kk == 0 && lane == 0) asum += av;
+            }
+            __syncthreads();
+            *reinterpret_cast<f32x4*>(&sacc[wave][lane * 4]) = acc;
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kq = k + e;
+                    if (kq < Kc)
+                        part[((long long)split * M + m) * Kc + kq] =
+                            (sacc[0][lane * 4 + e] + sacc[1][lane * 4 + e]) + (sacc[2][lane * 4 + e] + sacc[3][lane * 4 + e]);
+                }
+            }
+        }
+        if (part_a) {
+            __syncthreads();
+            if (lane == 0) sacc[wave][0] = asum;
+            __syncthreads();
+            if (threadIdx.x == 0) part_a[split * M + m] = (sacc[0][0] + sacc[1][0]) + (sacc[2][0] + sacc[3][0]);
+        }
+    }
+}
+
+// g_vals[n][k] = sum_c A[n][c] gB[c][k]   (B = A^T V  =>  dV = A dB)
+template <int VEC>
+__global__ void k_bwd_gvals(const float* __restrict__ A, const float* __restrict__ gB, float* __restrict__ gv,
+                            long long N, int Kv, int C) {
+    const int k4n = (Kv + 3) / 4;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * k4n) return;
+    const long long n = i / k4n;
+    const int k = (int)(i - n * k4n) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) acc += A[n * C + c] * load4<VEC, float>(gB + (long long)c * Kv, k, Kv);
+    if constexpr (VEC == 4) {
+        *reinterpret_cast<f32x4*>(gv + n * Kv + k) = acc;
+    } else {
+        for (int e = 0; e < 4; ++e)
+            if (k + e < Kv) gv[n * Kv + k + e] = acc[e];
+    }
+}
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+struct BwdWs {
+    size_t gB, Dv, zero, W2T, qmax, gq, gA, gs, gz2, Hb, Qb, gH, part, part_b, off, total;
+    int splits, rows;
+};
+BwdWs bwd_layout(long long N, int K, int Kv, int C) {
+    BwdWs w;
+    w.rows = tn_rows(N);
+    w.splits = (int)((N + w.rows - 1) / w.rows);
+    const int Kmax = K > QD ? K : QD;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t p = o; o = al(o + bytes); return p; };
+    w.gB = take((size_t)C * Kv * 4);
+    w.Dv = take((size_t)C * 4);
+    w.zero = take(QD * 4);
+    w.W2T = take((size_t)QD * QD * 4);
+    w.qmax = take((size_t)C * QD * 4);
+    w.gq = take((size_t)C * QD * 4);
+    w.gA = take((size_t)N * C * 4);
+    w.gs = take((size_t)N * C * 4);
+    w.gz2 = take((size_t)N * QD * 4);
+    w.Hb = take((size_t)N * QD * 4);
+    w.Qb = take((size_t)N * QD * 4);
+    w.gH = take((size_t)N * QD * 4);
+    w.part = take((size_t)w.splits * QD * Kmax * 4);
+    w.part_b = take((size_t)w.splits * QD * 4);
+    w.off = take(2 * sizeof(int64_t));
+    w.total = o;
+    return w;
+}
+
+__global__ void k_set_offsets(int64_t* off, long long N) { off[0] = 0; off[1] = N; }
+
+template <typename KernelT, typename ArgT>
+int launch_tile_kernel(KernelT kern, const ArgT& arg, int nw, long long N, hipStream_t st) {
+    const int BM = nw * 32;
+    const size_t lds = (size_t)(2 * W_TILE + 2 * BM * LDK) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((N + BM - 1) / BM)), dim3(nw * 64), lds, st, arg);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
+int tn_gemm(const float* Am, const float* Bm, long long N, int Kc, float* part, float* part_b, float* out,
+            float* out_b, int splits, bool v4, hipStream_t st) {
+    dim3 grid((unsigned)((Kc + QD - 1) / QD), (unsigned)splits);
+    if (v4) hipLaunchKernelGGL(k_tn_gemm<4>, grid, dim3(256), 0, st, Am, Bm, part, part_b, N, Kc, tn_rows(N));
+    else hipLaunchKernelGGL(k_tn_gemm<1>, grid, dim3(256), 0, st, Am, Bm, part, part_b, N, Kc, tn_rows(N));
+    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    const long long n = (long long)QD * Kc;
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, out, splits, n);
+    if (out_b) hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(128), 0, st, part_b, out_b, splits, (long long)QD);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
+int tn_small(const float* a, const float* bm, long long N, int M, int Kc, float* part, float* part_a, float* out,
+             float* out_a, int splits, bool v4, hipStream_t st) {
+    if (v4) hipLaunchKernelGGL(k_tn_small<4>, dim3((unsigned)splits), dim3(256), 0, st, a, bm, part, part_a, N, M, Kc, tn_rows(N));
+    else hipLaunchKernelGGL(k_tn_small<1>, dim3((unsigned)splits), dim3(256), 0, st, a, bm, part, part_a, N, M, Kc, tn_rows(N));
+    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    const long long n = (long long)M * Kc;
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, out, splits, n);
+    if (out_a) hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(64), 0, st, part_a, out_a, splits, (long long)M);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dsmil_agg_backward_workspace_bytes(int64_t N, int32_t K, int32_t Kv, int32_t C) {
+    if (N <= 0 || K <= 0 || Kv <= 0 || C <= 0) return 0;
+    return bwd_layout(N, K, Kv, C).total;
+}
+
+int dsmil_agg_backward(const float* feats, const float* vals, int64_t N, const dsmil_agg_params* p,
+                       const float* A, const float* Bm, const int64_t* idx, const float* g_classes,
+                       const float* g_pred, const float* g_A, const float* g_B, const dsmil_agg_grads* g,
+                       float* g_vals, void* ws, size_t ws_bytes, void* stream) {
+    if (!feats || !p || !A || !Bm || !idx || !g_pred || !g || !ws) return DSMIL_E_INVALID;
+    if (N <= 0 || p->K <= 0 || p->Kv <= 0 || p->C <= 0) return DSMIL_E_INVALID;
+    if (!p->q0_w || !p->q0_b || !p->fcc_w || (p->nonlinear && (!p->q2_w || !p->q2_b))) return DSMIL_E_INVALID;
+    if (!g->q0_w || !g->q0_b || !g->fcc_w || !g->fcc_b || (p->nonlinear && (!g->q2_w || !g->q2_b))) return DSMIL_E_INVALID;
+    if (g_classes && (!g->fc_w || !g->fc_b)) return DSMIL_E_INVALID;
+    if (!vals) vals = feats;
+    if (vals == feats && p->Kv != p->K) return DSMIL_E_INVALID;
+    if ((uintptr_t)ws % 256) return DSMIL_E_ALIGN;
+    const int K = p->K, Kv = p->Kv, C = p->C;
+    const BwdWs L = bwd_layout(N, K, Kv, C);
+    if (ws_bytes < L.total) return DSMIL_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* w8 = (char*)ws;
+    float* gB = (float*)(w8 + L.gB); float* Dv = (float*)(w8 + L.Dv); float* zero = (float*)(w8 + L.zero);
+    float* W2T = (float*)(w8 + L.W2T); float* qmax = (float*)(w8 + L.qmax); float* gq = (float*)(w8 + L.gq);
+    float* gA = (float*)(w8 + L.gA); float* gs = (float*)(w8 + L.gs); float* gz2 = (float*)(w8 + L.gz2);
+    float* Hb = (float*)(w8 + L.Hb); float* Qb = (float*)(w8 + L.Qb); float* gH = (float*)(w8 + L.gH);
+    float* part = (float*)(w8 + L.part); float* part_b = (float*)(w8 + L.part_b);
+    int64_t* off = (int64_t*)(w8 + L.off);
+    const bool v4 = (K % 4 == 0) && (((uintptr_t)feats | (uintptr_t)p->q0_w | (uintptr_t)p->q0_b |
+                                      (uintptr_t)(p->nonlinear ? p->q2_w : p->q0_w)) % 16 == 0);
+    const bool v4v = (Kv % 4 == 0) && ((uintptr_t)vals % 16 == 0);
+    int rc;
+    // 1. head: gB, D, g_fcc_*, W2^T
+    hipLaunchKernelGGL(k_set_offsets, dim3(1), dim3(1), 0, st, off, (long long)N);
+    hipLaunchKernelGGL(k_bwd_prep, dim3(1), dim3(256), 0, st, p->fcc_w, Bm, g_pred, g_B, A, g_A, p->q2_w, gB, Dv,
+                       g->fcc_w, g->fcc_b, W2T, zero, (long long)N, Kv, C, p->nonlinear);
+    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    // 2. gA = V gB^T  (the forward's FCLayer kernel with W := gB, b := 0)
+    rc = dsmil_fc_forward(vals, N, Kv, C, gB, zero, gA, stream);
+    if (rc) return rc;
+    // 3. critical queries
+    if (v4) hipLaunchKernelGGL(k_bwd_qrow<4>, dim3((unsigned)C), dim3(256), 0, st, feats, idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, K, p->nonlinear);
+    else hipLaunchKernelGGL(k_bwd_qrow<1>, dim3((unsigned)C), dim3(256), 0, st, feats, idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, K, p->nonlinear);
+    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    // 4. per-row part on MFMA
+    const int nw = (N / 128 >= 512) ? 4 : 1;
+    BwdRowsArgs br{};
+    br.at = AttendArgs{feats, feats, nullptr, off, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, nullptr, nullptr, nullptr,
+                       K, K, C, p->nonlinear, 0, 0};
+    br.A = A; br.gA = gA; br.g_A = g_A; br.Dv = Dv; br.gs = gs; br.gz2 = gz2; br.Hbuf = Hb; br.Qbuf = Qb;
+    if (nw == 4) rc = v4 ? launch_tile_kernel(k_bwd_rows<4, 4>, br, 4, N, st) : launch_tile_kernel(k_bwd_rows<4, 1>, br, 4, N, st);
+    else rc = v4 ? launch_tile_kernel(k_bwd_rows<1, 4>, br, 1, N, st) : launch_tile_kernel(k_bwd_rows<1, 1>, br, 1, N, st);
+    if (rc) return rc;
+    // 5. gradient of the critical queries joins their rows
+    rc = tn_small(gs, Qb, N, C, QD, part, nullptr, gq, nullptr, L.splits, true, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_bwd_critical, dim3(1), dim3(QD), 0, st, idx, gq, Qb, gz2, C, p->nonlinear);
+    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    if (p->nonlinear) {
+        // 6. gH = (gz2 W2) [H > 0]
+        GhArgs gh{};
+        gh.at = AttendArgs{gz2, gz2, nullptr, off, W2T, zero, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           QD, QD, C, 0, 0, 0};
+        gh.Hbuf = Hb; gh.gH = gH;
+        rc = (nw == 4) ? launch_tile_kernel(k_bwd_gh<4>, gh, 4, N, st) : launch_tile_kernel(k_bwd_gh<1>, gh, 1, N, st);
+        if (rc) return rc;
+        // 7. weight gradients: contractions over instances
+        rc = tn_gemm(gz2, Hb, N, QD, part, part_b, g->q2_w, g->q2_b, L.splits, true, st);
+        if (rc) return rc;
+        rc = tn_gemm(gH, feats, N, K, part, part_b, g->q0_w, g->q0_b, L.splits, v4, st);
+        if (rc) return rc;
+    } else {
+        rc = tn_gemm(gz2, feats, N, K, part, part_b, g->q0_w, g->q0_b, L.splits, v4, st);
+        if (rc) return rc;
+    }
+    // 8. instance stream (FCLayer)
+    if (g_classes) {
+        rc = tn_small(g_classes, feats, N, C, K, part, part_b, g->fc_w, g->fc_b, L.splits, v4, st);
+        if (rc) return rc;
+    }
+    // 9. gradient of the value rows (only when v is a trainable layer of the caller)
+    if (g_vals) {
+        const long long n4 = (long long)N * ((Kv + 3) / 4);
+        if (v4v && (uintptr_t)g_vals % 16 == 0)
+            hipLaunchKernelGGL(k_bwd_gvals<4>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, A, gB, g_vals, (long long)N, Kv, C);
+        else
+            hipLaunchKernelGGL(k_bwd_gvals<1>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, A, gB, g_vals, (long long)N, Kv, C);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    }
+    return DSMIL_OK;
+}
+
+}  // extern "C"

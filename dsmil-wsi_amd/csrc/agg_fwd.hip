@@ -30,89 +30,9 @@
 #include "dsmil_hip.h"
 #include "prof.h"
 
+#include "agg_common.h"
+
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int QD = DSMIL_Q_DIM;  // 128
-constexpr int BK = 32;           // k-chunk staged per pipeline step
-constexpr int LDK = BK + 4;      // LDS row stride in floats (144 B): conflict-free ds_read_b128
-constexpr int W_TILE = QD * LDK; // floats per staged weight chunk
-constexpr int R0 = 128;          // rows per workgroup of k_logits_argmax
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-// Every feature / weight / workspace pointer handed to this library is device GLOBAL memory.  Inside
-// out-of-line (noinline) device functions hipcc cannot infer that and would emit FLAT loads, whose
-// lgkmcnt accounting serialises them with the LDS reads; the hot loads therefore say so explicitly.
-#define DSMIL_GLOBAL __attribute__((address_space(1)))
-
-typedef unsigned short bf16_t;  // raw bfloat16 bits (storage type of the bf16 path)
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even, like torch .bfloat16()
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
-
-// 4 consecutive elements at p[k..k+3] as floats, zero beyond klim.  VEC=4 needs rows aligned to
-// 4 elements (16 B for fp32, 8 B for bf16).
-template <int VEC, typename T = float>
-__device__ __forceinline__ f32x4 load4(const T* __restrict__ p, int k, int klim) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (sizeof(T) == 2) {
-        if constexpr (VEC == 4) {
-            if (k < klim) {
-                const u32x2 t = *(const DSMIL_GLOBAL u32x2*)(p + k);
-                v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-                v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (k + e < klim) v[e] = bf2f(p[k + e]);
-        }
-    } else if constexpr (VEC == 4) {
-        if (k < klim) v = *(const DSMIL_GLOBAL f32x4*)(p + k);
-    } else {
-        if (k + 0 < klim) v[0] = p[k + 0];
-        if (k + 1 < klim) v[1] = p[k + 1];
-        if (k + 2 < klim) v[2] = p[k + 2];
-        if (k + 3 < klim) v[3] = p[k + 3];
-    }
-    return v;
-}
-
-// Staging variant: never branches for VEC=4 — the address is clamped into the row (klim % 4 == 0,
-// klim >= 4) and the caller zeroes out-of-range k later (at LDS-write time), so a run of these
-// loads issues back to back and stays in flight under the MFMAs.
-template <int VEC>
-__device__ __forceinline__ f32x4 load4_clamped(const float* __restrict__ p, int k, int klim) {
-    if constexpr (VEC == 4) {
-        const int kc = k < klim ? k : klim - 4;
-        return *(const DSMIL_GLOBAL f32x4*)(p + kc);
-    } else {
-        return load4<1>(p, k, klim);
-    }
-}
-
-// better (value, index): larger value wins, lowest index wins on exact ties
-__device__ __forceinline__ bool better(float v, long long i, float bv, long long bi) {
-    return (v > bv) || (v == bv && i < bi);
-}
 
 // --------------------------------------------------------------------------------------------
 // k_logits_argmax: c = x W_i^T + b_i (dsmil.py:11) and per-tile arg-max partials (dsmil.py:52).
@@ -312,27 +232,6 @@ __device__ __forceinline__ void qmax_block(
     }
 }
 
-// --------------------------------------------------------------------------------------------
-// k_query_attend — the dominant kernel.  NW waves per workgroup, 32 instance rows per wave.
-// --------------------------------------------------------------------------------------------
-struct AttendArgs {
-    const void* feats;  // fp32 or bf16 [total_rows, K]
-    const void* vals;   // fp32 or bf16 [total_rows, Kv]
-    const bf16_t* wpk;  // bf16 path: packed W1 [128][K64] then W2 permuted [128][128]
-    const int64_t* offsets;
-    const float* q0_w;
-    const float* q0_b;
-    const float* q2_w;
-    const float* q2_b;
-    const float* qmax;  // [n_bags, C, 128]
-    float* scores;      // [total_rows, C]  (the A buffer; normalised in place by k_finish)
-    float* part_ml;     // [slots, C, 2]
-    float* part_B;      // [slots, C, Kv]
-    int K, Kv, C, nonlinear;
-    int expt;  // DSMIL_EXPT debugging knob (0 in production): ablation switches for profiling
-    int bag0;  // first bag of this launch (chunked pipelining over bags)
-};
-
 template <int VEC, typename T = float>
 __global__ __launch_bounds__(256) void k_qmax(
     const T* __restrict__ feats, const int64_t* __restrict__ offsets,
@@ -347,313 +246,15 @@ __global__ __launch_bounds__(256) void k_qmax(
                        bag0 + (int)blockIdx.x, (int)blockIdx.y, s_v, s_i, s_h);
 }
 
-// --------------------------------------------------------------------------------------------
-// attend_tail: everything behind the query MLP, shared by the fp32 and bf16 kernels.  Q holds
-// Q^T in the MFMA D layout: lane (l31, hi), tile t, reg 4g+e  <->  Q[row l31][32t + 8g + 4hi + e].
-// Scores (dsmil.py:55-56), tile softmax statistics, weighted value sum (dsmil.py:57).
-// --------------------------------------------------------------------------------------------
-template <int NW, int VEC, typename T>
-__device__ __forceinline__ void attend_tail(const AttendArgs& a, const f32x16 (&Q)[4], float* smem, int bag,
-                                            long long off0, long long Nb, long long row0, long long slot) {
-    constexpr int T_ = NW * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    // From here on the staging LDS is free (every wave is past the last barrier above).
-    // ---- scores, tile softmax statistics, weighted value sum — two classes per sweep
-    const long long wrow0 = row0 + wave * 32;           // first row of this wave
-    const long long myrow = wrow0 + l31;                // this lane's instance row (bag-local)
-    const bool valid = myrow < Nb;
-    const float scale = 0.08838834764831845f;           // 1/sqrt(128), dsmil.py:56
-    const int Kv = a.Kv;
-    const T* vbase = reinterpret_cast<const T*>(a.vals) + off0 * (long long)Kv;
-    float* sRed = smem;                                  // [NW][4]: m0,l0,m1,l1 per wave
-    float* sB = smem + 64;                               // [NW][2][512]
-    for (int c0 = 0; c0 < a.C; c0 += 2) {
-        const int c1 = (c0 + 1 < a.C) ? c0 + 1 : c0;
-        const float* qm0 = a.qmax + ((long long)bag * a.C + c0) * QD;
-        const float* qm1 = a.qmax + ((long long)bag * a.C + c1) * QD;
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 u0 = *reinterpret_cast<const f32x4*>(qm0 + 32 * t + 8 * g + 4 * hi);
-                const f32x4 u1 = *reinterpret_cast<const f32x4*>(qm1 + 32 * t + 8 * g + 4 * hi);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s0 = fmaf(Q[t][4 * g + e], u0[e], s0);
-                    s1 = fmaf(Q[t][4 * g + e], u1[e], s1);
-                }
-            }
-        s0 = (s0 + __shfl_xor(s0, 32, 64)) * scale;
-        s1 = (s1 + __shfl_xor(s1, 32, 64)) * scale;
-        if (valid && hi == 0) {
-            float* o = a.scores + (off0 + myrow) * (long long)a.C;
-            o[c0] = s0;
-            if (c1 != c0) o[c1] = s1;
-        }
-        const float mw0 = wave_max(valid ? s0 : -INFINITY);
-        const float mw1 = wave_max(valid ? s1 : -INFINITY);
-        const float p0 = valid ? expf(s0 - mw0) : 0.f;
-        const float p1 = valid ? expf(s1 - mw1) : 0.f;
-        const float lw0 = wave_sum(hi == 0 ? p0 : 0.f);
-        const float lw1 = wave_sum(hi == 0 ? p1 : 0.f);
-        // block-level max / sum
-        float f0 = 1.f, f1 = 1.f;
-        if constexpr (NW > 1) {
-            __syncthreads();
-            if (lane == 0) {
-                sRed[wave * 4 + 0] = mw0; sRed[wave * 4 + 1] = lw0;
-                sRed[wave * 4 + 2] = mw1; sRed[wave * 4 + 3] = lw1;
-            }
-            __syncthreads();
-            float mb0 = -INFINITY, mb1 = -INFINITY;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) { mb0 = fmaxf(mb0, sRed[w * 4 + 0]); mb1 = fmaxf(mb1, sRed[w * 4 + 2]); }
-            f0 = expf(mw0 - mb0);  // 0 for a wave with no valid row (mw = -inf, mb finite)
-            f1 = expf(mw1 - mb1);
-            if (tid == 0) {
-                float lb0 = 0.f, lb1 = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    lb0 += sRed[w * 4 + 1] * expf(sRed[w * 4 + 0] - mb0);
-                    lb1 += sRed[w * 4 + 3] * expf(sRed[w * 4 + 2] - mb1);
-                }
-                float* ml = a.part_ml + (slot * a.C + c0) * 2;
-                ml[0] = mb0; ml[1] = lb0;
-                if (c1 != c0) { ml[2] = mb1; ml[3] = lb1; }
-            }
-        } else {
-            if (tid == 0) {
-                float* ml = a.part_ml + (slot * a.C + c0) * 2;
-                ml[0] = mw0; ml[1] = lw0;
-                if (c1 != c0) { ml[2] = mw1; ml[3] = lw1; }
-            }
-        }
-        const float pp0 = p0 * f0, pp1 = p1 * f1;  // weights relative to the BLOCK max
-        // ---- weighted value sum: Bpart[c][k] = sum_n p[n][c] * V[n][k], 512 k per sweep
-        for (int k0 = 0; k0 < ((a.expt & 1) ? 0 : Kv); k0 += 512) {
-            f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
-            const int ka = k0 + lane * 4, kb = ka + 256;
-#pragma unroll 8
-            for (int n = 0; n < 32; ++n) {
-                long long r = wrow0 + n;
-                if (r >= Nb) r = Nb - 1;  // weight is 0 there
-                const float w0 = __shfl(pp0, n, 64), w1 = __shfl(pp1, n, 64);
-                const T* vr = vbase + r * (long long)Kv;
-                const f32x4 va = load4<VEC, T>(vr, ka, Kv);
-                const f32x4 vb = load4<VEC, T>(vr, kb, Kv);
-                acc00 += w0 * va; acc01 += w0 * vb;
-                acc10 += w1 * va; acc11 += w1 * vb;
-            }
-            float* pb0 = a.part_B + (slot * a.C + c0) * (long long)Kv;
-            float* pb1 = a.part_B + (slot * a.C + c1) * (long long)Kv;
-            if constexpr (NW > 1) {
-                __syncthreads();
-                float* my = sB + wave * 1024;
-                *reinterpret_cast<f32x4*>(my + lane * 4) = acc00;
-                *reinterpret_cast<f32x4*>(my + 256 + lane * 4) = acc01;
-                *reinterpret_cast<f32x4*>(my + 512 + lane * 4) = acc10;
-                *reinterpret_cast<f32x4*>(my + 768 + lane * 4) = acc11;
-                __syncthreads();
-                for (int e = tid; e < 1024; e += T_) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) s += sB[w * 1024 + e];
-                    const int cc = e >> 9, k = k0 + (e & 511);
-                    if (k < Kv && (cc == 0 || c1 != c0)) (cc ? pb1 : pb0)[k] = s;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (ka + e < Kv) { pb0[ka + e] = acc00[e]; if (c1 != c0) pb1[ka + e] = acc10[e]; }
-                    if (kb + e < Kv) { pb0[kb + e] = acc01[e]; if (c1 != c0) pb1[kb + e] = acc11[e]; }
-                }
-            }
-        }
-        if constexpr (NW > 1) __syncthreads();
-    }
-}
-
 template <int NW, int VEC>
 __device__ __forceinline__ void attend_tile(const AttendArgs& a, int bag, int tile, float* smem) {
-    static_assert(NW == 1 || NW == 4 || NW == 8, "tile geometries: 32, 128 or 256 rows");
-    constexpr int T = NW * 64;
     constexpr int BM = NW * 32;
-    constexpr int X_TILE = BM * LDK;
-    constexpr int WPT = (QD * (BK / 4)) / T;  // float4 per thread per weight chunk (4 or 16)
-    constexpr int XPT = (BM * (BK / 4)) / T;  // == 4
-    constexpr int WPS = WPT >= 4 ? WPT / 4 : 1;  // weight float4 per pipeline slot (slots past WPT idle)
-    float* sW = smem;               // [2][W_TILE]
-    float* sX = smem + 2 * W_TILE;  // [2][X_TILE]
-
+    f32x16 H[4], Q[4];
+    if (!mlp_tile<NW, VEC>(a, bag, tile, smem, H, Q)) return;
     const long long off0 = a.offsets[bag];
     const long long Nb = a.offsets[bag + 1] - off0;
     const long long row0 = (long long)tile * BM;
-    if (row0 >= Nb) return;
     const long long slot = off0 / BM + bag + tile;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int K = a.K;
-    const int nk1 = (K + BK - 1) / BK;
-    const int nk = nk1 + (a.nonlinear ? QD / BK : 0);
-    const float* feats = reinterpret_cast<const float*>(a.feats);
-    const int c4 = tid & 7;
-
-    // Staging pipeline, distance 2, ONE register set (write-then-reissue):
-    //   iteration ci:  MFMAs on LDS buffer ci&1  ||  registers (chunk ci+1, loaded during
-    //   iteration ci-1) -> LDS buffer (ci+1)&1  ||  global loads of chunk ci+2 -> same registers.
-    // Each of the 4 k-groups of a chunk carries one slot (1/4 of the chunk's registers), placed
-    // behind that k-group's MFMAs so address arithmetic, ds_write and load issue hide under the
-    // 64-cycle MFMAs instead of forming a bubble at the chunk boundary.  One barrier per chunk.
-    f32x4 wreg[WPT], xreg[XPT];
-    bool kok = true;                 // weight k-slice of the chunk held in registers is in range
-    const float* xrow[XPT];
-#pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-        long long gr = row0 + ((tid + T * i) >> 3);
-        if (gr >= Nb) gr = Nb - 1;   // clamp: rows past the bag end are masked later
-        xrow[i] = feats + (off0 + gr) * (long long)K;
-    }
-    auto chunk_src = [&](int ci, const float*& wb, int& ld, int& k, int& klim) {
-        int k0;
-        if (ci < nk1) { wb = a.q0_w; ld = K; k0 = ci * BK; klim = K; }
-        else { wb = a.q2_w; ld = QD; k0 = (ci - nk1) * BK; klim = QD; }
-        k = k0 + c4 * 4;
-    };
-    // issue the loads of pipeline slot q of chunk ci.  Branch-free on purpose (a branch around a
-    // load makes hipcc fall back to vmcnt(0) waits): past the last chunk the last one is simply
-    // re-loaded, and `with_x` is a literal at every call site.
-    auto load_slot = [&](int ci, int q, const bool with_x) {
-        const int cw = ci < nk ? ci : nk - 1;
-        const float* wb; int ld, k, klim;
-        chunk_src(cw, wb, ld, k, klim);
-#pragma unroll
-        for (int j = 0; j < WPS; ++j) {
-            const int i = q * WPS + j;
-            if (i < WPT) wreg[i] = load4_clamped<VEC>(wb + (long long)((tid + T * i) >> 3) * ld, k, klim);
-        }
-        if (with_x) {
-            const int cx = ci < nk1 ? ci : nk1 - 1;
-            xreg[q] = load4_clamped<VEC>(xrow[q], cx * BK + c4 * 4, K);
-        }
-    };
-    // move pipeline slot q of the chunk held in registers (chunk ci) to its LDS buffer; past the
-    // last chunk this writes into a buffer nobody reads any more
-    auto write_slot = [&](int ci, int q, bool ok, const bool with_x) {
-        float* w = sW + (ci & 1) * W_TILE;
-#pragma unroll
-        for (int j = 0; j < WPS; ++j) {
-            const int i = q * WPS + j;
-            if (i < WPT) {
-                f32x4 v = wreg[i];
-                if constexpr (VEC == 4) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;   // zero the weight k-tail
-                }
-                *reinterpret_cast<f32x4*>(w + ((tid + T * i) >> 3) * LDK + c4 * 4) = v;
-            }
-        }
-        if (with_x)
-            *reinterpret_cast<f32x4*>(sX + (ci & 1) * X_TILE + ((tid + T * q) >> 3) * LDK + c4 * 4) = xreg[q];
-    };
-    auto k_in_range = [&](int ci) {
-        const float* wb; int ld, k, klim;
-        chunk_src(ci < nk ? ci : nk - 1, wb, ld, k, klim);
-        return k < klim;
-    };
-
-    f32x16 H[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) H[t][r] = 0.f;
-
-    // prologue: chunk 0 -> LDS, chunk 1 -> registers
-#pragma unroll
-    for (int q = 0; q < 4; ++q) load_slot(0, q, true);
-    kok = k_in_range(0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) write_slot(0, q, kok, true);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) load_slot(1, q, true);
-    kok = k_in_range(1);
-    __syncthreads();
-    const int frag_off = l31 * LDK + 4 * hi;  // this lane's row / k-half inside a chunk
-    // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] * X[n][k]
-    for (int ci = 0; ci < nk1; ++ci) {
-        const float* w = sW + (ci & 1) * W_TILE + frag_off;
-        const float* x = sX + (ci & 1) * X_TILE + wave * 32 * LDK + frag_off;
-        const bool kok_next = k_in_range(ci + 2);
-#pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-            const f32x4 xb = *reinterpret_cast<const f32x4*>(x + kg * 8);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f32x4 wa = *reinterpret_cast<const f32x4*>(w + t * 32 * LDK + kg * 8);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) H[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xb[j], H[t], 0, 0, 0);
-            }
-            write_slot(ci + 1, kg, kok, true);
-            load_slot(ci + 2, kg, true);
-            __builtin_amdgcn_sched_barrier(0);  // keep each slot inside its own k-group
-        }
-        kok = kok_next;
-        __syncthreads();
-    }
-    // ---- bias (+ReLU): H^T row j = 32t + 8g + 4hi + e  for reg r = 4g + e
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(a.q0_b + 32 * t + 8 * g + 4 * hi);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = H[t][4 * g + e] + b[e];
-                H[t][4 * g + e] = a.nonlinear ? fmaxf(v, 0.f) : v;
-            }
-        }
-    f32x16 Q[4];
-    if (a.nonlinear) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Q[t][r] = 0.f;
-        // ---- GEMM 2 (transposed): Q^T[j2][n] += W2[j2][k] * H^T[k][n]; chunk t feeds k=32t..32t+31
-        // straight from the accumulator registers of H[t]: reg 4g+e holds k = 8g + 4hi + e.
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int ci = nk1 + t;
-            const float* w = sW + (ci & 1) * W_TILE + frag_off;
-            const bool kok_next = k_in_range(ci + 2);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int t2 = 0; t2 < 4; ++t2) {
-                    const f32x4 wa = *reinterpret_cast<const f32x4*>(w + t2 * 32 * LDK + g * 8);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        Q[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[e], H[t][4 * g + e], Q[t2], 0, 0, 0);
-                }
-                write_slot(ci + 1, g, kok, false);
-                load_slot(ci + 2, g, false);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            kok = kok_next;
-            __syncthreads();
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * t + 8 * g + 4 * hi);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = tanhf(Q[t][4 * g + e] + b[e]);
-            }
-    } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) Q[t] = H[t];
-    }
     if (a.expt & 4) {  // ablation knob (DSMIL_EXPT): stop after the MLP, keep the accumulators live
         float keep = 0.f;
 #pragma unroll

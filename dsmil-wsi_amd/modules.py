@@ -190,8 +190,7 @@ class _FCFunction(torch.autograd.Function):
 class _AggFunction(torch.autograd.Function):
     """Forward = dsmil_agg_forward (HIP).  Backward = analytic gradient of dsmil.py:46-62 (the
     arg-max indices are constants, as in the reference's autograd graph); it re-derives Q from
-    the saved inputs.  Round 1 composes the backward from dense torch products on the GPU — the
-    native backward is SURVEY.md §8(f) row N1."""
+    the saved inputs (dsmil_agg_backward, csrc/agg_bwd.hip — SURVEY.md §8(f) row N1)."""
 
     @staticmethod
     def forward(ctx, feats, c_in, vals, fc_w, fc_b, q0_w, q0_b, q2_w, q2_b, fcc_w, fcc_b, nonlinear):
@@ -219,6 +218,30 @@ class _AggFunction(torch.autograd.Function):
     def backward(ctx, g_cls, g_pred, g_A, g_B, _g_idx):
         if ctx.bf16:
             raise NotImplementedError("the bf16-storage aggregator path is inference only")
+        if not ctx.needs_input_grad[0]:
+            return _AggFunction._backward_native(ctx, g_cls, g_pred, g_A, g_B)
+        return _AggFunction._backward_dense(ctx, g_cls, g_pred, g_A, g_B)
+
+    @staticmethod
+    def _backward_native(ctx, g_cls, g_pred, g_A, g_B):
+        """dsmil_agg_backward (HIP): every parameter gradient, and g_vals for a trainable v."""
+        feats, vals, fc_w, q0_w, q0_b, q2_w, q2_b, fcc_w, A, B, idx = ctx.saved_tensors
+        C = fcc_w.shape[0]
+        if g_pred is None:
+            g_pred = torch.zeros((1, C), device=feats.device)
+        w = {"fc_w": fc_w, "fc_b": None, "q0_w": q0_w, "q0_b": q0_b, "q2_w": q2_w, "q2_b": q2_b,
+             "fcc_w": fcc_w, "fcc_b": None}
+        want_v = ctx.has_vals and ctx.needs_input_grad[2]
+        g = ops.agg_backward(feats, w, A, B, idx, g_pred, g_classes=None if ctx.has_cin else g_cls,
+                             g_A=g_A, g_B=g_B[0] if g_B is not None else None,
+                             vals=vals if ctx.has_vals else None, nonlinear=ctx.nonlinear, want_g_vals=want_v)
+        return (None, None, g.get("vals"), g.get("fc_w"), g.get("fc_b"), g["q0_w"], g["q0_b"],
+                g.get("q2_w"), g.get("q2_b"), g["fcc_w"], g["fcc_b"], None)
+
+    @staticmethod
+    def _backward_dense(ctx, g_cls, g_pred, g_A, g_B):
+        """Only when the gradient of the INPUT rows is requested (no reference script does: bags are
+        data, train_tcga.py:60-66): the same analytic gradient composed from dense GPU products."""
         feats, vals, fc_w, q0_w, q0_b, q2_w, q2_b, fcc_w, A, B, idx = ctx.saved_tensors
         x = feats
         V = vals if ctx.has_vals else feats

@@ -174,6 +174,50 @@ def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, o
     return classes, pred, A, B, idx
 
 
+def agg_backward(feats, w, A, B, idx, g_pred, g_classes=None, g_A=None, g_B=None, vals=None, nonlinear=True,
+                 want_g_vals=False):
+    """dsmil_agg_backward: parameter gradients of FCLayer + BClassifier for ONE bag (what autograd
+    derives for train_tcga.py:67-72).  feats [N,K] fp32 CUDA, w as in agg_forward, A [N,C], B [1,C,Kv],
+    idx [1,C] = the forward's outputs; g_* = upstream gradients (None = zero).  Returns a dict with the
+    gradient of every key of ``w`` (fc_* only when g_classes is given, q2_* only when nonlinear) and
+    ``vals`` (when want_g_vals)."""
+    feats = _f32c(feats, "feats")
+    dev = feats.device
+    N, K = feats.shape
+    vals = feats if vals is None else _f32c(vals, "vals")
+    Kv = vals.shape[1]
+    fcc_w = _f32c(w["fcc_w"], "fcc_w")
+    C = fcc_w.shape[0]
+    keep = [_f32c(w.get(k), k) for k in ("fc_w", "fc_b", "q0_w", "q0_b", "q2_w", "q2_b", "fcc_w", "fcc_b")]
+    p = _native.AggParams(*[(t.data_ptr() if t is not None else 0) for t in keep],
+                          K, Kv, C, 1 if nonlinear else 0)
+    A = _f32c(A, "A"); B = _f32c(B, "B")
+    idx = idx.contiguous()
+    g_pred = _f32c(g_pred.reshape(-1), "g_pred")
+    g_classes = _f32c(g_classes, "g_classes"); g_A = _f32c(g_A, "g_A"); g_B = _f32c(g_B, "g_B")
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    out = {"q0_w": new(Q_DIM, K), "q0_b": new(Q_DIM), "fcc_w": new(C, C, Kv), "fcc_b": new(C)}
+    if nonlinear:
+        out["q2_w"], out["q2_b"] = new(Q_DIM, Q_DIM), new(Q_DIM)
+    if g_classes is not None:
+        out["fc_w"], out["fc_b"] = new(C, K), new(C)
+    g = _native.AggGrads(*[(out[k].data_ptr() if k in out else 0)
+                           for k in ("fc_w", "fc_b", "q0_w", "q0_b", "q2_w", "q2_b", "fcc_w", "fcc_b")])
+    g_vals = new(N, Kv) if want_g_vals else None
+    L = _native.lib()
+    nbytes = L.dsmil_agg_backward_workspace_bytes(N, K, Kv, C)
+    ws = _workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        rc = L.dsmil_agg_backward(_ptr(feats), _ptr(vals), N, ctypes.byref(p), _ptr(A), _ptr(B), _ptr(idx),
+                                  _ptr(g_classes), _ptr(g_pred), _ptr(g_A), _ptr(g_B), ctypes.byref(g),
+                                  _ptr(g_vals), _ptr(ws), ws.numel(), _stream(dev))
+    _native.check(rc, "dsmil_agg_backward")
+    del keep
+    if want_g_vals:
+        out["vals"] = g_vals
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # patch embedder (ResNet-18 + InstanceNorm) — compute_feats.py:146-170,211 / dsmil.py:21-25
 # ---------------------------------------------------------------------------------------------

@@ -104,6 +104,35 @@ int dsmil_agg_forward_bf16(const void* feats_bf16, const void* vals_bf16, const 
 int dsmil_fc_forward(const float* feats, int64_t total_rows, int32_t K, int32_t C,
                      const float* fc_w, const float* fc_b, float* classes, void* stream);
 
+/* ---- aggregator backward (training step) -----------------------------------------------------
+ * Replaces what autograd derives for `loss.backward()` in train_tcga.py:67-72 / train_mil.py for
+ * ONE bag through MILNet.forward (dsmil.py:70-74): gradients of every parameter of FCLayer
+ * (dsmil.py:6-12) and BClassifier (dsmil.py:27-62) given the upstream gradients of the forward's
+ * outputs.  Device pointers, fp32, each gradient has its parameter's shape and is OVERWRITTEN
+ * (the caller accumulates into .grad if it needs to).  g_classes / g_A / g_B may be NULL (treated
+ * as zero; with g_classes NULL the fc_* gradients are not written).  The arg-max indices are
+ * constants of the graph, as in torch.sort + index_select (dsmil.py:51-53).  `A`, `B`, `idx` are
+ * the forward's outputs for this bag.  With passing_v (BClassifier.v = Dropout+Linear+ReLU,
+ * dsmil.py:39-44) the caller hands the value rows in `vals` and asks for their gradient in
+ * `g_vals` [N, Kv] (= A gB^T, NULL to skip), which it pushes through its own v layer. */
+typedef struct dsmil_agg_grads {
+    float* fc_w;   /* [C, K]      */
+    float* fc_b;   /* [C]         */
+    float* q0_w;   /* [128, K]    */
+    float* q0_b;   /* [128]       */
+    float* q2_w;   /* [128, 128]  (unused when !nonlinear) */
+    float* q2_b;   /* [128]       */
+    float* fcc_w;  /* [C, C, Kv]  */
+    float* fcc_b;  /* [C]         */
+} dsmil_agg_grads;
+
+size_t dsmil_agg_backward_workspace_bytes(int64_t N, int32_t K, int32_t Kv, int32_t C);
+int dsmil_agg_backward(const float* feats, const float* vals, int64_t N, const dsmil_agg_params* p,
+                       const float* A, const float* B, const int64_t* idx, const float* g_classes,
+                       const float* g_pred, const float* g_A, const float* g_B,
+                       const dsmil_agg_grads* g, float* g_vals, void* ws, size_t ws_bytes,
+                       void* stream);
+
 /* ---- patch embedder: ResNet-18 with InstanceNorm2d, fc = Identity --------------------------
  * Replaces the torchvision backbone that compute_feats.py:157,170 builds and dsmil.IClassifier
  * wraps (dsmil.py:21-25): feats[B,512] = flatten(avgpool(resnet18_IN(x))), and, when `classes`
