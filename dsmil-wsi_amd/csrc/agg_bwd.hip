@@ -306,44 +306,52 @@ __global__ void k_reduce_parts(const float* __restrict__ part, float* __restrict
 }
 
 // ---- k_tn_small: part[s][M][Kc] = a[rows][M]^T b[rows][Kc] for a handful of columns M (classes);
-//      also part_a[s][M] = column sums of a.  One wave walks rows, lanes walk the feature axis. -----
+//      also part_a[s][M] = column sums of a.  grid = (row ranges, 256-wide k-segments); the 4 waves
+//      stride the rows (b row read once for up to 4 classes), then merge through LDS. -------------
 template <int VEC>
 __global__ __launch_bounds__(256) void k_tn_small(const float* __restrict__ a, const float* __restrict__ bm,
                                                   float* __restrict__ part, float* __restrict__ part_a,
                                                   long long N, int M, int Kc, int TNR) {
-    __shared__ __attribute__((aligned(16))) float sacc[4][256 * 4];
+    __shared__ __attribute__((aligned(16))) float sacc[4][4][256];
+    __shared__ float ssum[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int split = blockIdx.x;
+    const int k = blockIdx.y * 256 + lane * 4;
     const long long rbeg = (long long)split * TNR, rend = (rbeg + TNR < N) ? rbeg + TNR : N;
-    for (int m = 0; m < M; ++m) {
-        float asum = 0.f;
-        for (int kk = 0; kk < Kc; kk += 256) {
-            const int k = kk + lane * 4;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (long long r = rbeg + wave; r < rend; r += 4) {
-                const float av = a[r * M + m];
-                const f32x4 bv = load4<VEC, float>(bm + r * (long long)Kc, k, Kc);
-                acc += av * bv;
-                if (kk == 0 && lane == 0) asum += av;
-            }
-            __syncthreads();
-            *reinterpret_cast<f32x4*>(&sacc[wave][lane * 4]) = acc;
-            __syncthreads();
-            if (wave == 0) {
+    for (int m0 = 0; m0 < M; m0 += 4) {
+        f32x4 acc[4];
+        float asum[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int kq = k + e;
-                    if (kq < Kc)
-                        part[((long long)split * M + m) * Kc + kq] =
-                            (sacc[0][lane * 4 + e] + sacc[1][lane * 4 + e]) + (sacc[2][lane * 4 + e] + sacc[3][lane * 4 + e]);
-                }
+        for (int j = 0; j < 4; ++j) { acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; asum[j] = 0.f; }
+#pragma unroll 4
+        for (long long r = rbeg + wave; r < rend; r += 4) {
+            const f32x4 bv = load4<VEC, float>(bm + r * (long long)Kc, k, Kc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float av = (m0 + j < M) ? a[r * M + m0 + j] : 0.f;
+                acc[j] += av * bv;
+                asum[j] += av;
             }
         }
-        if (part_a) {
-            __syncthreads();
-            if (lane == 0) sacc[wave][0] = asum;
-            __syncthreads();
-            if (threadIdx.x == 0) part_a[split * M + m] = (sacc[0][0] + sacc[1][0]) + (sacc[2][0] + sacc[3][0]);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&sacc[wave][j][lane * 4]) = acc[j];
+        if (lane == 0)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ssum[wave][j] = asum[j];
+        __syncthreads();
+        const int m = m0 + wave;  // wave j merges class m0 + j
+        if (m < M) {
+            const f32x4 v = (*reinterpret_cast<const f32x4*>(&sacc[0][wave][lane * 4]) +
+                             *reinterpret_cast<const f32x4*>(&sacc[1][wave][lane * 4])) +
+                            (*reinterpret_cast<const f32x4*>(&sacc[2][wave][lane * 4]) +
+                             *reinterpret_cast<const f32x4*>(&sacc[3][wave][lane * 4]));
+            float* o = part + ((long long)split * M + m) * Kc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k + e < Kc) o[k + e] = v[e];
+            if (part_a && blockIdx.y == 0 && lane == 0)
+                part_a[split * M + m] = (ssum[0][wave] + ssum[1][wave]) + (ssum[2][wave] + ssum[3][wave]);
         }
     }
 }
@@ -423,8 +431,9 @@ int tn_gemm(const float* Am, const float* Bm, long long N, int Kc, float* part, 
 
 int tn_small(const float* a, const float* bm, long long N, int M, int Kc, float* part, float* part_a, float* out,
              float* out_a, int splits, bool v4, hipStream_t st) {
-    if (v4) hipLaunchKernelGGL(k_tn_small<4>, dim3((unsigned)splits), dim3(256), 0, st, a, bm, part, part_a, N, M, Kc, tn_rows(N));
-    else hipLaunchKernelGGL(k_tn_small<1>, dim3((unsigned)splits), dim3(256), 0, st, a, bm, part, part_a, N, M, Kc, tn_rows(N));
+    const dim3 grid((unsigned)splits, (unsigned)((Kc + 255) / 256));
+    if (v4) hipLaunchKernelGGL(k_tn_small<4>, grid, dim3(256), 0, st, a, bm, part, part_a, N, M, Kc, tn_rows(N));
+    else hipLaunchKernelGGL(k_tn_small<1>, grid, dim3(256), 0, st, a, bm, part, part_a, N, M, Kc, tn_rows(N));
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     const long long n = (long long)M * Kc;
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, out, splits, n);

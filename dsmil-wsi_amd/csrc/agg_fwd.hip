@@ -451,30 +451,38 @@ __global__ void k_pack_agg_bf16(const float* __restrict__ q0_w, const float* __r
 // --------------------------------------------------------------------------------------------
 // k_finish: per bag, combine tile partials (online-softmax merge), normalise A in place,
 // produce B (dsmil.py:57-59) and pred = Conv1d(C,C,Kv)(B) (dsmil.py:60-61).
-// grid = (chunks, n_bags); chunk j normalises rows [j*FR, (j+1)*FR) and owns a slice of k.
+// grid = (nblk, n_bags), nblk = max(ceil(max_rows/FR), ceil(Kv/64)): block j normalises an even
+// share of the bag's rows and owns the 64-wide k-run j of B (none when j >= ceil(Kv/64)).  The tile
+// walk of a k-run is spread over 16 thread groups x float4 so that a lone 10k-row bag (313 tiles)
+// is ~5 dependent load rounds instead of ~80.
 // --------------------------------------------------------------------------------------------
 constexpr int FR = 2048;
+inline long long finish_blocks(long long max_rows, int Kv) {
+    const long long a = (max_rows + FR - 1) / FR, b = (Kv + 63) / 64;
+    return a > b ? (a > 1 ? a : 1) : b;
+}
+
+template <int VEC>
 __global__ __launch_bounds__(256) void k_finish(
     const int64_t* __restrict__ offsets, const float* __restrict__ part_ml,
     const float* __restrict__ part_B, const float* __restrict__ fcc_w,
-    const float* __restrict__ fcc_b, float* __restrict__ A, float* __restrict__ B,
-    float* __restrict__ pred_part, int Kv, int C, int BM, int nchunk_max) {
-    const int bag = blockIdx.y;
+    float* __restrict__ A, float* __restrict__ B, float* __restrict__ pred_part, int Kv, int C, int BM) {
+    const int bag = blockIdx.y, nblk = gridDim.x;
     const long long off0 = offsets[bag];
     const long long Nb = offsets[bag + 1] - off0;
-    const long long nchunk = (Nb + FR - 1) / FR;
-    if ((long long)blockIdx.x >= nchunk) return;
     const long long slot0 = off0 / BM + bag;
     const long long ntile = (Nb + BM - 1) / BM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float s_red[8];
-    __shared__ float s_m, s_il;
-    // k-slice owned by this chunk
-    const int ks = (int)((Kv + nchunk - 1) / nchunk);
-    const int kbeg = (int)blockIdx.x * ks;
-    const int kend = (kbeg + ks < Kv) ? kbeg + ks : Kv;
+    __shared__ __attribute__((aligned(16))) float s_acc[16][64];
+    const int kb = (int)blockIdx.x * 64;           // this block's k-run
+    const bool has_k = kb < Kv;
+    const long long rpb = (Nb + nblk - 1) / nblk;  // this block's share of the rows
+    const long long rbeg = (long long)blockIdx.x * rpb;
+    const long long rend = (rbeg + rpb < Nb) ? rbeg + rpb : Nb;
+    const int kq = tid & 15, tg = tid >> 4;
     for (int c = 0; c < C; ++c) {
-        // global max
+        // global max / sum of the bag
         float m = -INFINITY;
         for (long long t = tid; t < ntile; t += 256) m = fmaxf(m, part_ml[((slot0 + t) * C + c) * 2]);
         m = wave_max(m);
@@ -488,67 +496,57 @@ __global__ __launch_bounds__(256) void k_finish(
             l += ml[1] * expf(ml[0] - m);
         }
         l = wave_sum(l);
-        __syncthreads();
         if (lane == 0) s_red[4 + wave] = l;
         __syncthreads();
         l = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
         const float il = 1.f / l;
-        // A = exp(s - m) / l for this chunk's rows
-        const long long rbeg = (long long)blockIdx.x * FR;
-        const long long rend = (rbeg + FR < Nb) ? rbeg + FR : Nb;
+        // A = exp(s - m) / l for this block's rows
         for (long long r = rbeg + tid; r < rend; r += 256) {
             float* p = A + (off0 + r) * (long long)C + c;
             *p = expf(*p - m) * il;
         }
-        // B[c][k] for this chunk's k-slice; 4 waves split the tiles, lanes walk k
-        for (int kb = kbeg; kb < kend; kb += 64) {
+        float* pp = pred_part + (((long long)bag * nblk + blockIdx.x) * C) * C + c;  // [o] stride C
+        if (!has_k) {
+            if (tid < C) pp[tid * C] = 0.f;
+            continue;
+        }
+        // B[c][kb..kb+63]: 16 thread groups walk the tiles, 16 lanes x float4 cover the k-run
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* pb = part_B + (slot0 * C + c) * (long long)Kv;
+        const float* pm = part_ml + (slot0 * C + c) * 2;
+#pragma unroll 4
+        for (long long t = tg; t < ntile; t += 16) {
+            const float w = expf(pm[t * C * 2] - m);
+            acc += w * load4<VEC>(pb + t * C * (long long)Kv, kb + kq * 4, Kv);
+        }
+        *reinterpret_cast<f32x4*>(&s_acc[tg][kq * 4]) = acc;
+        __syncthreads();
+        if (wave == 0) {
+            float b = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) b += s_acc[g][lane];
+            b *= il;
             const int k = kb + lane;
-            float acc = 0.f;
-            if (k < kend)
-                for (long long t = wave; t < ntile; t += 4) {
-                    const float w = expf(part_ml[((slot0 + t) * C + c) * 2] - m);
-                    acc = fmaf(part_B[((slot0 + t) * C + c) * (long long)Kv + k], w, acc);
-                }
-            __shared__ float s_acc[4][64];
-            __syncthreads();
-            s_acc[wave][lane] = acc;
-            __syncthreads();
-            if (wave == 0 && k < kend) {
-                const float b = ((s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane])) * il;
-                B[((long long)bag * C + c) * Kv + k] = b;
-                s_acc[0][lane] = b;
-            }
-            __syncthreads();
-            // partial Conv1d dot products for this k-run: pred_part[bag][chunk][o][c]
-            if (tid < C) {
-                const int o = tid;
-                float d = 0.f;
-                const int kn = (kend - kb < 64) ? kend - kb : 64;
-                for (int e = 0; e < kn; ++e)
-                    d = fmaf(fcc_w[((long long)o * C + c) * Kv + kb + e], s_acc[0][e], d);
-                float* pp = pred_part + (((long long)bag * nchunk_max + blockIdx.x) * C + o) * C + c;
-                *pp = (kb == kbeg ? 0.f : *pp) + d;
+            if (k < Kv) B[((long long)bag * C + c) * Kv + k] = b;
+            // partial Conv1d dot products of this k-run: pred_part[bag][block][o][c]
+            for (int o = 0; o < C; ++o) {
+                const float d = wave_sum(k < Kv ? fcc_w[((long long)o * C + c) * Kv + k] * b : 0.f);
+                if (lane == 0) pp[o * C] = d;
             }
         }
-        if (kbeg >= kend && tid < C)
-            pred_part[(((long long)bag * nchunk_max + blockIdx.x) * C + tid) * C + c] = 0.f;
         __syncthreads();
     }
-    (void)s_m; (void)s_il;
 }
 
-// pred[bag][o] = fcc_b[o] + sum_{chunk,c} pred_part  (fixed order => deterministic)
-__global__ void k_pred(const int64_t* __restrict__ offsets, const float* __restrict__ pred_part,
-                       const float* __restrict__ fcc_b, float* __restrict__ pred, int C,
-                       int nchunk_max, int n_bags) {
+// pred[bag][o] = fcc_b[o] + sum_{block,c} pred_part  (fixed order => deterministic)
+__global__ void k_pred(const float* __restrict__ pred_part, const float* __restrict__ fcc_b,
+                       float* __restrict__ pred, int C, int nblk, int n_bags) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_bags * C) return;
     const int bag = i / C, o = i % C;
-    const long long Nb = offsets[bag + 1] - offsets[bag];
-    const long long nchunk = (Nb + FR - 1) / FR;
     float s = fcc_b[o];
-    for (long long j = 0; j < nchunk; ++j)
-        for (int c = 0; c < C; ++c) s += pred_part[(((long long)bag * nchunk_max + j) * C + o) * C + c];
+    for (int j = 0; j < nblk; ++j)
+        for (int c = 0; c < C; ++c) s += pred_part[(((long long)bag * nblk + j) * C + o) * C + c];
     pred[i] = s;
 }
 
@@ -598,8 +596,7 @@ WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int Kv,
     WsLayout w;
     w.slots0 = total_rows / R0 + n_bags + 1;
     w.slots = total_rows / BM + n_bags + 1;
-    w.nchunk_max = (max_rows + FR - 1) / FR;
-    if (w.nchunk_max < 1) w.nchunk_max = 1;
+    w.nchunk_max = finish_blocks(max_rows, Kv);
     size_t o = 0;
     w.part_val = o; o = al(o + (size_t)w.slots0 * C * sizeof(float));
     w.part_idx = o; o = al(o + (size_t)w.slots0 * C * sizeof(long long));
@@ -760,11 +757,13 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     // 4. combine
     {
         dim3 grid((unsigned)L.nchunk_max, (unsigned)n_bags);
-        hipLaunchKernelGGL(k_finish, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, p->fcc_b,
-                           A, B, pred_part, Kv, C, BM, (int)L.nchunk_max);
+        if (Kv % 4 == 0)
+            hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM);
+        else
+            hipLaunchKernelGGL(k_finish<1>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         const int n = n_bags * C;
-        hipLaunchKernelGGL(k_pred, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, offsets, pred_part,
+        hipLaunchKernelGGL(k_pred, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pred_part,
                            p->fcc_b, pred, C, (int)L.nchunk_max, n_bags);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
