@@ -38,6 +38,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md:42: ~2.5 PF dense bf16 MFMA (no sparsity)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-f32 MFMA (no xf32 on gfx950)
 PEAK_HBM_GBS = 8000.0
 Q = 128
@@ -274,6 +275,7 @@ def main():
         fl = attend_flops_per_bag(N, K, C) * nb
         achieved = fl / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
         traffic = _pmc("pmc_k_query_attend.json", "hbm_bytes_per_launch") if (nb, N, K) == (64, 10000, 512) else None
+        form = int(L.dsmil_agg_mlp_form())
         line = {
             "metric": "bags/sec aggregated (10kx512)", "value": round(value, 1), "unit": "bags/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -283,9 +285,16 @@ def main():
                                    f"{nb} bags x {N} x {K} fp32 per GPU per step, HBM-resident",
                        "bags_per_step_per_gpu": nb, "rows": N, "feats": K, "classes": C,
                        "tile_rows": int(L.dsmil_agg_tile_rows(nb, nb * N)), "parallelism": f"bag-sharded x{world}"},
-            "roofline": {"kernel": "k_query_attend", "bound": "mfma", "achieved": round(achieved, 2) if achieved else None,
+            "roofline": {"kernel": "k_query_attend" + ("_split" if form else ""), "bound": "mfma",
+                         "achieved": round(achieved, 2) if achieved else None,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4) if achieved else None,
+                         "mfma_form": {0: "v_mfma_f32_32x32x2_f32", 9: "bf16 MFMA, exact 3-plane cut, 9 plane products",
+                                       6: "bf16 MFMA, exact 3-plane cut, 6 plane products"}[form],
+                         # the pipe the kernel actually runs on: bf16 dense peak / plane products per MAC
+                         "peak_executed_form": round(PEAK_BF16_MFMA_TFLOPS / form, 1) if form else PEAK_F32_MFMA_TFLOPS,
+                         "frac_executed_form": (round(achieved / (PEAK_BF16_MFMA_TFLOPS / form if form else PEAK_F32_MFMA_TFLOPS), 4)
+                                                if achieved else None),
                          "traffic": traffic, "kernel_ms": round(kern_ms, 4), "launches": int(launches.value),
                          "alg_flops_per_launch": fl,
                          "whole_path_frac_of_roofline": round(

@@ -37,6 +37,7 @@ class AggGrads(ctypes.Structure):
 SIGNATURES = {
     "dsmil_abi_version": (ctypes.c_int, []),
     "dsmil_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "dsmil_agg_mlp_form": (ctypes.c_int, []),
     "dsmil_agg_tile_rows": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64]),
     "dsmil_agg_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
                                                     ctypes.c_int32, ctypes.c_int32]),

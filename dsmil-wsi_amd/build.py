@@ -14,7 +14,8 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB = os.path.join(PKG_DIR, "libdsmil_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("DSMIL_CFLAGS", "").split()
+# DSMIL_CFLAGS: extra compile flags for instrumented builds (e.g. -DDSMIL_TRACE, tools_stamp.py)
 
 
 def sources():

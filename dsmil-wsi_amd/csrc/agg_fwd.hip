@@ -26,11 +26,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "dsmil_hip.h"
 #include "prof.h"
 
 #include "agg_common.h"
+#include "agg_split.h"
 
 namespace {
 
@@ -271,6 +274,32 @@ template <int NW, int VEC>
 __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(AttendArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     attend_tile<NW, VEC>(a, a.bag0 + (int)blockIdx.y, (int)blockIdx.x, smem);
+}
+
+// fp32 in / fp32 out with the query MLP on bf16 MFMA over exact three-plane cuts (agg_split.h)
+template <int NW, int VEC, int NP>
+__global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend_split(AttendArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BM = NW * 32;
+    const int bag = a.bag0 + (int)blockIdx.y, tile = (int)blockIdx.x;
+    f32x16 Q[4];
+    if constexpr (VEC == 4) {
+        if (!mlp_tile_split_dma<NW, NP>(a, bag, tile, smem, Q)) return;
+    } else {
+        if (!mlp_tile_split<NW, VEC, NP>(a, bag, tile, smem, Q)) return;
+    }
+    const long long off0 = a.offsets[bag];
+    const long long Nb = a.offsets[bag + 1] - off0;
+    if (a.expt & 4) {  // ablation knob (DSMIL_EXPT): stop after the MLP, keep the accumulators live
+        float keep = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) keep += Q[t][r];
+        if (keep == 12345.678f) a.scores[0] = keep;
+        return;
+    }
+    attend_tail<NW, VEC, float>(a, Q, smem, bag, off0, Nb, (long long)tile * BM, off0 / BM + bag + tile);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -578,7 +607,7 @@ __global__ __launch_bounds__(256) void k_fc(const float* __restrict__ feats,
 
 // ---- host side ------------------------------------------------------------------------------
 struct WsLayout {
-    size_t part_val, part_idx, qmax, part_ml, part_B, pred_part, total;
+    size_t part_val, part_idx, qmax, part_ml, part_B, pred_part, wsplit, total;
     long long slots0, slots, nchunk_max;
 };
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -592,7 +621,7 @@ int pick_nw(int n_bags, long long total_rows) {
     return tiles128 >= 512 ? 4 : 1;
 }
 
-WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int Kv, int C, int BM) {
+WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int K, int Kv, int C, int BM) {
     WsLayout w;
     w.slots0 = total_rows / R0 + n_bags + 1;
     w.slots = total_rows / BM + n_bags + 1;
@@ -604,6 +633,7 @@ WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int Kv,
     w.part_ml = o; o = al(o + (size_t)w.slots * C * 2 * sizeof(float));
     w.part_B = o; o = al(o + (size_t)w.slots * C * Kv * sizeof(float));
     w.pred_part = o; o = al(o + (size_t)n_bags * w.nchunk_max * C * C * sizeof(float));
+    w.wsplit = o; o = al(o + (size_t)(2 * ((K + 31) / 32) + 8) * S3_CHUNK_F4 * 16);  // cut query weights
     w.total = o;
     return w;
 }
@@ -623,6 +653,42 @@ int launch_attend(const AttendArgs& a, long long max_rows, int n_bags, hipStream
     hipLaunchKernelGGL((k_query_attend<NW, VEC>), grid, dim3(NW * 64), lds, st, a);
     dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
+template <int NW, int VEC, int NP>
+int launch_attend_split(const AttendArgs& a, long long max_rows, int n_bags, hipStream_t st) {
+    constexpr int BM = NW * 32;
+    size_t lds = VEC == 4 ? (size_t)(3 * S3_CHUNK_F4 * 4 + 2 * BM * 32) * sizeof(float)
+                          : (size_t)(2 * S3_CHUNK_F4 * 4 + 2 * BM * LDK) * sizeof(float);
+    if (const char* e = getenv("DSMIL_LDS_PAD")) lds += (size_t)atoi(e);  // experiments: force 1 block/CU
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (getenv("DSMIL_EXPT")) {
+            int nb = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_query_attend_split<NW, VEC, NP>, NW * 64, lds);
+            fprintf(stderr, "[dsmil] k_query_attend_split<%d,%d,%d>: lds %zu B, %d blocks/CU\n", NW, VEC, NP, lds, nb);
+        }
+        (void)hipFuncSetAttribute((const void*)k_query_attend_split<NW, VEC, NP>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((max_rows + BM - 1) / BM), (unsigned)n_bags);
+    const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
+    hipLaunchKernelGGL((k_query_attend_split<NW, VEC, NP>), grid, dim3(NW * 64), lds, st, a);
+    dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
+// DSMIL_MLP = f32 | s9 | s6: which MFMA form the fp32 query MLP uses (see agg_split.h)
+int mlp_mode() {
+    static const int mode = [] {
+        const char* e = getenv("DSMIL_MLP");
+        if (!e) return 9;
+        if (!strcmp(e, "f32")) return 0;
+        if (!strcmp(e, "s6")) return 6;
+        return 9;
+    }();
+    return mode;
 }
 
 template <int NW>
@@ -648,6 +714,8 @@ extern "C" {
 
 int dsmil_abi_version(void) { return DSMIL_ABI_VERSION; }
 
+int dsmil_agg_mlp_form(void) { return mlp_mode(); }
+
 const char* dsmil_strerror(int code) {
     switch (code) {
         case DSMIL_OK: return "ok";
@@ -667,7 +735,7 @@ size_t dsmil_agg_workspace_bytes(int32_t n_bags, int64_t total_rows, int32_t K, 
     (void)K;
     if (n_bags <= 0 || total_rows <= 0 || Kv <= 0 || C <= 0) return 0;
     // max_rows <= total_rows bounds the chunk count; tile rows as the launcher will pick them
-    return ws_layout(n_bags, total_rows, total_rows, Kv, C, pick_nw(n_bags, total_rows) * 32).total;
+    return ws_layout(n_bags, total_rows, total_rows, K, Kv, C, pick_nw(n_bags, total_rows) * 32).total;
 }
 
 int dsmil_fc_forward(const float* feats, int64_t total_rows, int32_t K, int32_t C,
@@ -705,7 +773,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         return DSMIL_E_UNSUPPORTED;
     const int NW = pick_nw(n_bags, total_rows);
     const int BM = NW * 32;
-    const WsLayout L = ws_layout(n_bags, total_rows, max_rows, Kv, C, BM);
+    const WsLayout L = ws_layout(n_bags, total_rows, max_rows, K, Kv, C, BM);
     if (ws_bytes < L.total) return DSMIL_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* w8 = (char*)ws;
@@ -748,14 +816,26 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         // 3. query MLP on MFMA + scores + tile softmax + weighted value sum
         int rc;
+        const int mode = (NW == 8) ? 0 : mlp_mode();
+        if (!bf16 && mode) {
+            const int nks = 2 * ((K + 31) / 32);
+            bf16_t* wsplit = (bf16_t*)(w8 + L.wsplit);
+            hipLaunchKernelGGL(k_pack_agg_split, dim3(64), dim3(256), 0, st, p->q0_w, p->nonlinear ? p->q2_w : nullptr, wsplit, K, nks);
+            if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+            a.wpk = wsplit;
+        }
         if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, nb, st) : launch_attend_bf16<1>(a, max_rows, nb, st);
+        else if (mode == 9 && NW == 4) rc = v4 ? launch_attend_split<4, 4, 9>(a, max_rows, nb, st) : launch_attend_split<4, 1, 9>(a, max_rows, nb, st);
+        else if (mode == 9) rc = v4 ? launch_attend_split<1, 4, 9>(a, max_rows, nb, st) : launch_attend_split<1, 1, 9>(a, max_rows, nb, st);
+        else if (mode == 6 && NW == 4) rc = v4 ? launch_attend_split<4, 4, 6>(a, max_rows, nb, st) : launch_attend_split<4, 1, 6>(a, max_rows, nb, st);
+        else if (mode == 6) rc = v4 ? launch_attend_split<1, 4, 6>(a, max_rows, nb, st) : launch_attend_split<1, 1, 6>(a, max_rows, nb, st);
         else if (NW == 8) rc = launch_attend<8, 4>(a, max_rows, nb, st);
         else if (NW == 4) rc = v4 ? launch_attend<4, 4>(a, max_rows, nb, st) : launch_attend<4, 1>(a, max_rows, nb, st);
         else rc = v4 ? launch_attend<1, 4>(a, max_rows, nb, st) : launch_attend<1, 1>(a, max_rows, nb, st);
         if (rc != DSMIL_OK) return rc;
     }
-    // 4. combine
-    {
+    // 4. combine (skipped under the stamp-trace knob, which leaves its stamps in A)
+    if (!(a.expt & 64)) {
         dim3 grid((unsigned)L.nchunk_max, (unsigned)n_bags);
         if (Kv % 4 == 0)
             hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM);

@@ -100,6 +100,14 @@ int dsmil_agg_forward_bf16(const void* feats_bf16, const void* vals_bf16, const 
                            float* classes_out, float* A, float* B, float* pred, int64_t* idx, void* ws,
                            size_t ws_bytes, void* stream);
 
+/* Which MFMA form dsmil_agg_forward uses for the fp32 query MLP (dsmil.py:31-33,49):
+ *   9 (default) — bf16 MFMA over exact three-plane cuts of both fp32 operands, all 9 plane products
+ *                 (every fp32 product formed exactly, fp32 accumulate; csrc/agg_split.h)
+ *   6           — the same with the three smallest plane products left out (env DSMIL_MLP=s6)
+ *   0           — v_mfma_f32_32x32x2_f32 (env DSMIL_MLP=f32)
+ * The choice is read once per process from the environment variable DSMIL_MLP. */
+int dsmil_agg_mlp_form(void);
+
 /* FCLayer.forward alone (dsmil.py:10-12): classes[total_rows, C] = feats @ fc_w^T + fc_b. */
 int dsmil_fc_forward(const float* feats, int64_t total_rows, int32_t K, int32_t C,
                      const float* fc_w, const float* fc_b, float* classes, void* stream);
