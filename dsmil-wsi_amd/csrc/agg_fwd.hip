@@ -150,6 +150,120 @@ __global__ __launch_bounds__(256) void k_logits_argmax(
 }
 
 // --------------------------------------------------------------------------------------------
+// k_logits_stream: the same work as k_logits_argmax for fp32 rows with K % 4 == 0 and computed
+// logits, shaped for the HBM stream (this pass reads every feature byte once: 1.3 GB per 64 bags).
+// 8 lanes share a row and walk it in 128-B segments, so one load instruction covers 8 rows x one
+// full 128-B line each; 8 segments (1 KiB per lane-row) are in flight before the first FMA; the
+// loads are unconditional (tail segments re-read a clamped address against zero-padded weights in
+// LDS) and non-temporal (the stream is 5x the Infinity Cache and k_query_attend reads it again
+// only after it has all gone by).  The lane reduction is 3 xor-shuffles per 8 rows.
+// Same tile geometry and partial layout as k_logits_argmax (R0 rows per workgroup).
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 load4_stream(const float* p) {
+    return __builtin_nontemporal_load((const DSMIL_GLOBAL f32x4*)p);
+}
+
+template <int CP>  // classes per pass: 1 or 2
+__global__ __launch_bounds__(256) void k_logits_stream(
+    const float* __restrict__ feats, const int64_t* __restrict__ offsets,
+    const float* __restrict__ fc_w, const float* __restrict__ fc_b, float* __restrict__ classes_out,
+    float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C, int bag0) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];  // [CP][Kpad]: weights, zero past K, plus one zero segment
+    __shared__ float s_v[8];
+    __shared__ long long s_i[8];
+    const int bag = bag0 + (int)blockIdx.y, tile = (int)blockIdx.x;
+    const long long off0 = offsets[bag];
+    const long long Nb = offsets[bag + 1] - off0;
+    const long long row0 = (long long)tile * R0;
+    if (row0 >= Nb) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 7, rr = lane >> 3;
+    const long long slot = off0 / R0 + bag + tile;
+    const int nseg = (K + 31) / 32, Kpad = (nseg + 1) * 32;
+
+    for (int c0 = 0; c0 < C; c0 += CP) {
+        const int c1 = (CP == 2 && c0 + 1 < C) ? c0 + 1 : c0;
+        __syncthreads();
+        for (int i = tid; i < CP * Kpad; i += 256) {
+            const int cc = i / Kpad, k = i - cc * Kpad;
+            s_w[i] = k < K ? fc_w[(long long)(cc ? c1 : c0) * K + k] : 0.f;
+        }
+        __syncthreads();
+        const float b0 = fc_b[c0], b1 = fc_b[c1];
+        float bv0 = -INFINITY, bv1 = -INFINITY;
+        long long bi0 = 0x7fffffffffffffffLL, bi1 = 0x7fffffffffffffffLL;
+        for (int g = 0; g < 4; ++g) {
+            const long long rbase = row0 + wave * 32 + g * 8;
+            if (rbase >= Nb) break;  // wave-uniform
+            const long long r = (rbase + rr < Nb) ? rbase + rr : Nb - 1;
+            const float* x = feats + (off0 + r) * (long long)K;
+            float a0 = 0.f, a1 = 0.f;
+            for (int s0 = 0; s0 < nseg; s0 += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int k = (s0 + u) * 32 + j * 4;
+                    k = k < K ? k : K - 4;  // clamped re-read; its weight is zero
+                    v[u] = load4_stream(x + k);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ks = (s0 + u < nseg ? s0 + u : nseg) * 32 + j * 4;  // segment nseg is all zero
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_w + ks);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a0 = fmaf(v[u][e], w0[e], a0);
+                    if constexpr (CP == 2) {
+                        const f32x4 w1 = *reinterpret_cast<const f32x4*>(s_w + Kpad + ks);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a1 = fmaf(v[u][e], w1[e], a1);
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) {
+                a0 += __shfl_xor(a0, m, 64);
+                if constexpr (CP == 2) a1 += __shfl_xor(a1, m, 64);
+            }
+            a0 += b0;
+            a1 += b1;
+            if (j == 0 && rbase + rr < Nb) {
+                float* o = classes_out + (off0 + r) * (long long)C;
+                o[c0] = a0;
+                if (CP == 2 && c1 != c0) o[c1] = a1;
+            }
+            // rows past the end were clamped to Nb-1: a duplicate can never beat itself (same index)
+            if (better(a0, r, bv0, bi0)) { bv0 = a0; bi0 = r; }
+            if (CP == 2 && better(a1, r, bv1, bi1)) { bv1 = a1; bi1 = r; }
+        }
+        // best over the wave's 8 row lanes (lanes of one row agree), then over the 4 waves
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) {
+            const float ov0 = __shfl_xor(bv0, m, 64);
+            const long long oi0 = __shfl_xor(bi0, m, 64);
+            if (better(ov0, oi0, bv0, bi0)) { bv0 = ov0; bi0 = oi0; }
+            if constexpr (CP == 2) {
+                const float ov1 = __shfl_xor(bv1, m, 64);
+                const long long oi1 = __shfl_xor(bi1, m, 64);
+                if (better(ov1, oi1, bv1, bi1)) { bv1 = ov1; bi1 = oi1; }
+            }
+        }
+        __syncthreads();
+        if (lane == 0) { s_v[wave] = bv0; s_i[wave] = bi0; s_v[4 + wave] = bv1; s_i[4 + wave] = bi1; }
+        __syncthreads();
+        if (tid < 2 && (tid == 0 || c1 != c0)) {
+            const int h = tid * 4;
+            float bv = s_v[h];
+            long long bi = s_i[h];
+            for (int w = 1; w < 4; ++w)
+                if (better(s_v[h + w], s_i[h + w], bv, bi)) { bv = s_v[h + w]; bi = s_i[h + w]; }
+            const int c = tid ? c1 : c0;
+            part_val[slot * C + c] = bv;
+            part_idx[slot * C + c] = bi;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // k_qmax: one workgroup per (bag, class).  Finishes the arg-max over the bag's tile partials
 // (dsmil.py:52), then q_max = q(feats[idx]) (dsmil.py:53-54) on the VALU, 8 hidden units in
 // flight per wave so the dependent shuffle chains overlap.
@@ -804,6 +918,11 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
         else if (bf16 && w4) hipLaunchKernelGGL((k_logits_argmax<4, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
         else if (bf16) hipLaunchKernelGGL((k_logits_argmax<1, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
+        else if (v4 && !getenv("DSMIL_LOGITS_OLD")) {
+            const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 31) / 32 + 1) * 32) * sizeof(float);
+            if (C >= 2) hipLaunchKernelGGL(k_logits_stream<2>, grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
+            else hipLaunchKernelGGL(k_logits_stream<1>, grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
+        }
         else if (v4) hipLaunchKernelGGL((k_logits_argmax<4, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
         else hipLaunchKernelGGL((k_logits_argmax<1, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
