@@ -679,9 +679,14 @@ struct StemLoop<-1> {
 // registers under the current tile's MFMAs and written to the other LDS window buffer.
 constexpr int ST_WPT = (3 * ST_PLANE + 255) / 256;  // window floats per thread
 
-__global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const float* __restrict__ w,
+// U8 = true: the input is uint8 NHWC [B,H,W,3] (a decoded image as PIL/numpy hold it) and the
+// to_tensor scaling x/255 (compute_feats.py:35-39 -> VF.to_tensor: IEEE division) is applied here.
+template <bool U8>
+__global__ __launch_bounds__(256) void k_stem(const void* __restrict__ xin, const float* __restrict__ w,
                                               float* __restrict__ y, float* __restrict__ part, int B,
                                               int H, int W, int Ho, int Wo, int tiles_x, int tiles_y) {
+    const float* x = reinterpret_cast<const float*>(xin);
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(xin);
     __shared__ __attribute__((aligned(16))) float sIn[2][3 * ST_PLANE];
     __shared__ __attribute__((aligned(16))) float sW[64 * ST_LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
             const int c = e / ST_PLANE, r = (e - c * ST_PLANE) / ST_LW, col = e - c * ST_PLANE - r * ST_LW;
             const int iy = iy00 + r;
             wcol[q] = col;
-            if (col < 37 && iy >= 0 && iy < H) wrow[q] = ((n * 3 + c) * H + iy) * W;
+            if (col < 37 && iy >= 0 && iy < H) wrow[q] = U8 ? ((n * H + iy) * W) * 3 + c : ((n * 3 + c) * H + iy) * W;
         }
     }
     float wreg[ST_WPT];
@@ -708,7 +713,9 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
         for (int q = 0; q < ST_WPT; ++q) {
             const int ix = ix00 + wcol[q];
             const bool ok = wrow[q] >= 0 && ix >= 0 && ix < W;
-            const float v = x[ok ? (long long)wrow[q] + ix : 0];
+            float v;
+            if constexpr (U8) v = __fdiv_rn((float)xb[ok ? (long long)wrow[q] + 3 * ix : 0], 255.f);
+            else v = x[ok ? (long long)wrow[q] + ix : 0];
             wreg[q] = ok ? v : 0.f;
         }
     };
@@ -1120,9 +1127,9 @@ size_t dsmil_resnet18_workspace_bytes(int32_t B, int32_t H, int32_t W) {
     return rws_layout(B, H, W).total;
 }
 
-int dsmil_resnet18in_forward(const float* x_nchw, int32_t B, int32_t H, int32_t W, const float* conv1_w,
-                             const float* packed, const float* fc_w, const float* fc_b, int32_t C,
-                             float* feats, float* classes, void* ws, size_t ws_bytes, void* stream) {
+static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32_t H, int32_t W, const float* conv1_w,
+                                   const float* packed, const float* fc_w, const float* fc_b, int32_t C,
+                                   float* feats, float* classes, void* ws, size_t ws_bytes, void* stream) {
     if (!x_nchw || !conv1_w || !packed || !feats || !ws) return DSMIL_E_INVALID;
     if (B <= 0 || H < 32 || W < 32) return DSMIL_E_INVALID;
     if (classes && (!fc_w || !fc_b || C <= 0)) return DSMIL_E_INVALID;
@@ -1145,8 +1152,10 @@ int dsmil_resnet18in_forward(const float* x_nchw, int32_t B, int32_t H, int32_t 
     // ---- stem: conv1 -> IN -> ReLU -> maxpool
     {
         const int tx = (d.W1 + 15) / 16, ty = (d.H1 + 7) / 8;
-        hipLaunchKernelGGL(k_stem, dim3((unsigned)ty, (unsigned)B), dim3(256), 0, st, x_nchw, conv1_w, y0,
-                           part, B, H, W, d.H1, d.W1, tx, ty);
+        if (u8) hipLaunchKernelGGL(k_stem<true>, dim3((unsigned)ty, (unsigned)B), dim3(256), 0, st, x_nchw, conv1_w, y0,
+                                   part, B, H, W, d.H1, d.W1, tx, ty);
+        else hipLaunchKernelGGL(k_stem<false>, dim3((unsigned)ty, (unsigned)B), dim3(256), 0, st, x_nchw, conv1_w, y0,
+                                part, B, H, W, d.H1, d.W1, tx, ty);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         hipLaunchKernelGGL(k_in_finalize_stem, dim3((unsigned)B), dim3(256), 0, st, part,
                            mean[0], rstd[0], B, tx * ty * 4);
@@ -1198,6 +1207,20 @@ int dsmil_resnet18in_forward(const float* x_nchw, int32_t B, int32_t H, int32_t 
     }
     if (classes) return dsmil_fc_forward(feats, B, 512, C, fc_w, fc_b, classes, stream);
     return DSMIL_OK;
+}
+
+int dsmil_resnet18in_forward(const float* x_nchw, int32_t B, int32_t H, int32_t W, const float* conv1_w,
+                             const float* packed, const float* fc_w, const float* fc_b, int32_t C,
+                             float* feats, float* classes, void* ws, size_t ws_bytes, void* stream) {
+    return resnet18in_forward_impl(x_nchw, false, B, H, W, conv1_w, packed, fc_w, fc_b, C, feats, classes, ws,
+                                   ws_bytes, stream);
+}
+
+int dsmil_resnet18in_forward_u8(const uint8_t* x_nhwc, int32_t B, int32_t H, int32_t W, const float* conv1_w,
+                                const float* packed, const float* fc_w, const float* fc_b, int32_t C,
+                                float* feats, float* classes, void* ws, size_t ws_bytes, void* stream) {
+    return resnet18in_forward_impl(x_nhwc, true, B, H, W, conv1_w, packed, fc_w, fc_b, C, feats, classes, ws,
+                                   ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -33,6 +33,15 @@ class FCLayer(nn.Module):
         return feats, x
 
 
+def resnet_convs_of(fe):
+    """The 20 conv weights when ``fe`` is a ResNet-18 + InstanceNorm trunk with fc = Identity, else None."""
+    from .resnet import resnet18_in_convs
+    convs = resnet18_in_convs(fe)
+    if convs is not None and isinstance(getattr(fe, "fc", None), nn.Identity):
+        return convs
+    return None
+
+
 class IClassifier(nn.Module):
     """dsmil.py:14-25: (feats.view(B,-1), Linear(feats)) around an arbitrary feature extractor."""
 
@@ -43,13 +52,20 @@ class IClassifier(nn.Module):
 
     def forward(self, x):
         fe = self.feature_extractor
-        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not (
+        if x.dtype == torch.uint8:
+            # decoded images, uint8 NHWC [B,H,W,3] (new ingest path): on the GPU the
+            # ToTensor step is fused into the native stem; elsewhere it is applied here, exactly as
+            # VF.to_tensor does (compute_feats.py:35-39)
+            if x.dim() != 4 or x.shape[3] != 3:
+                raise ValueError(f"uint8 patches must be NHWC [B,H,W,3], got {tuple(x.shape)}")
+            if not x.is_cuda or resnet_convs_of(fe) is None:
+                x = x.permute(0, 3, 1, 2).to(torch.float32).div(255)
+        if x.is_cuda and x.dtype in (torch.float32, torch.uint8) and x.dim() == 4 and not (
                 torch.is_grad_enabled() and any(p.requires_grad for p in fe.parameters())):
             # ResNet-18 + InstanceNorm with fc = Identity (ours or torchvision's, compute_feats.py:157,170):
             # features and instance logits come from one native launch sequence
-            from .resnet import resnet18_in_convs
-            convs = resnet18_in_convs(fe)
-            if convs is not None and isinstance(getattr(fe, "fc", None), nn.Identity):
+            convs = resnet_convs_of(fe)
+            if convs is not None:
                 return ops.resnet18in_forward(x, convs, self.fc.weight, self.fc.bias)
         feats = fe(x)
         feats = feats.view(feats.shape[0], -1)

@@ -251,14 +251,25 @@ RESNET18_SHAPES = [(64, 3, 7, 7)] + [(64, 64, 3, 3)] * 4 + \
 
 
 def resnet18in_forward(x, convs, fc_w=None, fc_b=None):
-    """x [B,3,H,W] fp32 CUDA in [0,1]; convs: the 20 conv weights in torchvision state_dict order.
+    """x: [B,3,H,W] fp32 CUDA in [0,1] (what VF.to_tensor yields), OR decoded images as uint8
+    [B,H,W,3] CUDA (the /255 + HWC->CHW of to_tensor is then fused into the stem, bit-identically);
+    convs: the 20 conv weights in torchvision state_dict order.
     Returns (feats [B,512], classes [B,C] or None)."""
-    x = _f32c(x, "x")
-    if x.dim() != 4 or x.shape[1] != 3:
-        raise ValueError(f"expected [B,3,H,W] patches, got {tuple(x.shape)}")
+    u8 = x.dtype == torch.uint8
+    if u8:
+        if not x.is_cuda:
+            raise RuntimeError("x must be a CUDA(HIP) tensor for the native path")
+        if x.dim() != 4 or x.shape[3] != 3:
+            raise ValueError(f"uint8 patches must be NHWC [B,H,W,3], got {tuple(x.shape)}")
+        x = x if x.is_contiguous() else x.contiguous()
+        B, H, W, _ = x.shape
+    else:
+        x = _f32c(x, "x")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"expected [B,3,H,W] patches, got {tuple(x.shape)}")
+        B, _, H, W = x.shape
     if len(convs) != 20 or any(tuple(w.shape) != s for w, s in zip(convs, RESNET18_SHAPES)):
         raise ValueError("conv weights do not have the ResNet-18 shapes / order")
-    B, _, H, W = x.shape
     dev = x.device
     feats = torch.empty((B, 512), dtype=torch.float32, device=dev)
     if B == 0:
@@ -274,8 +285,9 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None):
     if nbytes == 0:
         raise ValueError(f"unsupported patch size {H}x{W}")
     ws = _workspace(dev, nbytes)
+    fn = L.dsmil_resnet18in_forward_u8 if u8 else L.dsmil_resnet18in_forward
     with torch.cuda.device(dev):
-        rc = L.dsmil_resnet18in_forward(_ptr(x), B, H, W, _ptr(conv1), _ptr(packed), _ptr(fc_w), _ptr(fc_b),
-                                        C, _ptr(feats), _ptr(classes), _ptr(ws), ws.numel(), _stream(dev))
-    _native.check(rc, "dsmil_resnet18in_forward")
+        rc = fn(_ptr(x), B, H, W, _ptr(conv1), _ptr(packed), _ptr(fc_w), _ptr(fc_b),
+                C, _ptr(feats), _ptr(classes), _ptr(ws), ws.numel(), _stream(dev))
+    _native.check(rc, "dsmil_resnet18in_forward_u8" if u8 else "dsmil_resnet18in_forward")
     return feats, classes

@@ -42,9 +42,14 @@ def patch_position(path):
 
 
 class PatchFiles(Dataset):
-    def __init__(self, files, with_position=False):
+    """uint8=False: what the reference's BagDataset + ToTensor yield (float32 CHW, compute_feats.py:21-39).
+    uint8=True: the decoded RGB image as uint8 HWC — ToTensor then runs fused in the native stem
+    (dsmil_resnet18in_forward_u8), bit-identically, and the H2D copy is 4x smaller."""
+
+    def __init__(self, files, with_position=False, uint8=False):
         self.files = list(files)
         self.with_position = with_position
+        self.uint8 = uint8
 
     def __len__(self):
         return len(self.files)
@@ -52,14 +57,17 @@ class PatchFiles(Dataset):
     def __getitem__(self, i):
         from PIL import Image
         with Image.open(self.files[i]) as im:
-            sample = {"input": to_tensor(im.convert("RGB") if im.mode not in ("RGB", "L") else im)}
+            if self.uint8:
+                sample = {"input": torch.from_numpy(np.array(im.convert("RGB"), dtype=np.uint8, copy=True))}
+            else:
+                sample = {"input": to_tensor(im.convert("RGB") if im.mode not in ("RGB", "L") else im)}
         if self.with_position:
             sample["position"] = patch_position(self.files[i])
         return sample
 
 
-def patch_loader(files, batch_size, num_workers, with_position=False):
-    return DataLoader(PatchFiles(files, with_position), batch_size=batch_size, shuffle=False,
+def patch_loader(files, batch_size, num_workers, with_position=False, uint8=False):
+    return DataLoader(PatchFiles(files, with_position, uint8), batch_size=batch_size, shuffle=False,
                       num_workers=num_workers, drop_last=False)
 
 
@@ -86,9 +94,14 @@ def embed_files(i_classifier, files, batch_size=128, num_workers=4, device=None,
     n_total = len(files)
     lo, hi = ddist.shard_range(n_total, rank, world)
     feats_l, cls_l, pos_l = [], [], []
+    # decoded uint8 images go to the GPU as they are when the native ResNet-18-IN stem will take them
+    from .modules import resnet_convs_of
+    u8 = torch.device(device).type == "cuda" and resnet_convs_of(i_classifier.feature_extractor) is not None
     if hi > lo:
-        for batch in patch_loader(files[lo:hi], batch_size, num_workers, want_position):
-            patches = batch["input"].float().to(device, non_blocking=True)
+        for batch in patch_loader(files[lo:hi], batch_size, num_workers, want_position, uint8=u8):
+            patches = batch["input"].to(device, non_blocking=True)
+            if not u8:
+                patches = patches.float()
             feats, classes = i_classifier(patches)
             feats_l.append(feats)
             cls_l.append(classes)

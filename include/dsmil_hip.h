@@ -162,6 +162,16 @@ int dsmil_resnet18in_forward(const float* x_nchw, int32_t B, int32_t H, int32_t 
                              const float* fc_b, int32_t C, float* feats, float* classes, void* ws,
                              size_t ws_bytes, void* stream);
 
+/* The same forward fed with DECODED images: x_nhwc is uint8 [B,H,W,3] (row-major, RGB interleaved, as
+ * PIL / numpy hold a patch).  The ToTensor step of the reference's loader (compute_feats.py:35-39:
+ * VF.to_tensor = HWC uint8 -> CHW float32 / 255, IEEE division) is fused into the stem's input
+ * staging, so results are bit-identical to dsmil_resnet18in_forward on the converted tensor while
+ * the host->device copy and the first HBM read shrink 4x. */
+int dsmil_resnet18in_forward_u8(const uint8_t* x_nhwc, int32_t B, int32_t H, int32_t W,
+                                const float* conv1_w, const float* packed, const float* fc_w,
+                                const float* fc_b, int32_t C, float* feats, float* classes, void* ws,
+                                size_t ws_bytes, void* stream);
+
 const char* dsmil_strerror(int code);
 int dsmil_abi_version(void);
 /* Rows per workgroup the launcher picks for the dominant kernel (k_query_attend). */

@@ -86,3 +86,21 @@ def test_weight_update_invalidates_packed_cache():
     ref2, _ = _ref(x.cpu(), w2, ic)
     assert not np.allclose(f1.cpu().numpy(), f2.cpu().numpy(), atol=1e-3)
     np.testing.assert_allclose(f2.cpu().numpy(), ref2, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 224, 224), (2, 96, 160)])
+def test_uint8_nhwc_ingest_is_bit_identical_to_fp32_entry(B, H, W):
+    """dsmil_resnet18in_forward_u8 (decoded uint8 NHWC images, ToTensor fused into the stem) against
+    dsmil_resnet18in_forward on VF.to_tensor's output: same bits, and both within tolerance of the oracle."""
+    ic, w = _build(seed=13)
+    g = torch.Generator().manual_seed(21 + B)
+    img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    x = img.permute(0, 3, 1, 2).to(torch.float32).div(255).contiguous()
+    ref_f, ref_c = _ref(x, w, ic)
+    icg = ic.cuda()
+    with torch.no_grad():
+        f8, c8 = icg(img.cuda())
+        f, c = icg(x.cuda())
+    assert torch.equal(f8, f) and torch.equal(c8, c)
+    np.testing.assert_allclose(f8.cpu().numpy(), ref_f, atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(c8.cpu().numpy(), ref_c, atol=1e-4, rtol=1e-4)

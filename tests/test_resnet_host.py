@@ -4,6 +4,7 @@ its torch-op graph equals the oracle restatement."""
 import collections
 
 import numpy as np
+import pytest
 import torch
 import torch.nn as nn
 
@@ -57,6 +58,24 @@ def test_module_graph_equals_oracle_on_cpu():
     np.testing.assert_allclose(feats.numpy(), ref_f.numpy(), atol=1e-5)
     np.testing.assert_allclose(c.numpy(), ref_c.numpy(), atol=1e-5)
     assert feats.shape == (2, 512) and c.shape == (2, 2)
+
+
+def test_uint8_nhwc_ingest_equals_to_tensor_on_cpu():
+    """Decoded images (uint8 NHWC) give exactly what VF.to_tensor + the fp32 path give
+    (compute_feats.py:35-39): HWC->CHW, float32, IEEE division by 255."""
+    res = resnet18(norm_layer=nn.InstanceNorm2d)
+    res.fc = nn.Identity()
+    res.load_state_dict(ro.make_weights(seed=6), strict=True)
+    ic = dsmil.IClassifier(res, 512, output_class=2).eval()
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (2, 64, 64, 3), generator=g, dtype=torch.uint8)
+    x = img.permute(0, 3, 1, 2).to(torch.float32).div(255)
+    with torch.no_grad():
+        f8, c8 = ic(img)
+        f, c = ic(x)
+    assert torch.equal(f8, f) and torch.equal(c8, c)
+    with pytest.raises(ValueError):
+        ic(img.permute(0, 3, 1, 2).contiguous())
 
 
 def test_structural_detection_rejects_other_norms():
