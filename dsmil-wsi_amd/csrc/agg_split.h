@@ -14,6 +14,7 @@
 // 128-B lines per row and 32-k chunk) and are cut in registers by the lane that feeds them to the
 // MFMA as the B operand — each element is cut exactly once.
 #pragma once
+#include <type_traits>
 #include "agg_common.h"
 
 namespace {
@@ -316,21 +317,101 @@ __device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag,
     S3_WAIT_VM(WPW);
     __builtin_amdgcn_s_barrier();
     STAMP();
-    // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] X[n][k], 16 k per step
-    for (int s = 0; s < nks; ++s) {
-        // feature chunk c+1 goes out on the even step 2c and is waited for at the end of step 2c+1
-        const bool do_w = s + 2 < nst, do_x = !(s & 1) && (s >> 1) + 1 < nk1;
-        const int issued = (do_w ? WPW : 0) + (do_x ? 4 : 0);
-        if (do_w) issue_w(s + 2);
-        if (do_x) issue_x((s >> 1) + 1);
-        const f32x4* w = sW + (s % 3) * S3_CHUNK_F4 + lane;
+    // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] X[n][k], 16 k per step.
+    // The B operand of step s+1 is read from LDS and cut into planes in the MIDDLE of step s, between
+    // its MFMA groups, so the ~45 VALU ops of the cut issue in MFMA shadows instead of ahead of the
+    // step's first MFMA.  A feature chunk is wave-private (each wave stages and reads its own rows),
+    // so the odd step only has to wait for its OWN DMA pieces of chunk c+1 — no barrier involved.
+    auto read_cut = [&](int s, S3Frag (&xb)[3]) {
         const float* x = sX + ((s >> 1) & 1) * X_TILE + (wave * 32 + l31) * 32;
         const int j0 = ((s & 1) * 4 + hi * 2) ^ fr;
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + j0 * 4);
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(x + (j0 ^ 1) * 4);
         const float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        S3Frag xb[3];
         split3(xv, xb);
+    };
+    S3Frag xb[3];
+    read_cut(0, xb);
+    // one 16-k step; PARITY / NEXT_X / CUT_NEXT are literals at every call site so that the whole
+    // step is ONE basic block (the compiler then interleaves the cut with the MFMAs) and every
+    // wait count is an immediate
+    auto step = [&](int s, auto parity, auto next_x, auto cut_next) {
+        constexpr bool ODD = decltype(parity)::value, NEXT_X = decltype(next_x)::value, CUT = decltype(cut_next)::value;
+        issue_w(s + 2);
+        if constexpr (NEXT_X) issue_x((s >> 1) + 1);
+        const f32x4* w = sW + (s % 3) * S3_CHUNK_F4 + lane;
+        // hand-placed issue order (sched_barrier after every MFMA slot): the compiler otherwise
+        // clumps the ~45 VALU ops of the cut, and the MFMA pipe idles behind the clump
+        const float* xnp = sX + (((s + 1) >> 1) & 1) * X_TILE + (wave * 32 + l31) * 32;
+        const int jn = (((s + 1) & 1) * 4 + hi * 2) ^ fr;
+        f32x4 xr0, xr1;
+        unsigned xu[8], r1u[8], r2u[8];
+        S3Frag xn[3];
+        S3Frag wa[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wa[0][p].f = w[p * 64];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int q = P0; q < 9; ++q) {
+                H[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[t & 1][S3_PA(q)].v, xb[S3_PB(q)].v, H[t], 0, 0, 0);
+                const int k = t * NP + (q - P0);  // filler slot behind this MFMA
+                if (q == P0 && t < 3) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) wa[(t + 1) & 1][p].f = w[((t + 1) * 3 + p) * 64];
+                }
+                if constexpr (CUT) {
+                    if (k == 1) {
+                        if constexpr (ODD) s3_wait_vm_dyn(WPW);  // own pieces of chunk c+1 (issued a step ago) landed
+                        xr0 = *reinterpret_cast<const f32x4*>(xnp + jn * 4);
+                        xr1 = *reinterpret_cast<const f32x4*>(xnp + (jn ^ 1) * 4);
+                    }
+                    if (k >= 6 && k < 14) {  // cut element e: exact residuals
+                        const int e = k - 6;
+                        const float xv = e < 4 ? xr0[e & 3] : xr1[e & 3];
+                        xu[e] = __float_as_uint(xv);
+                        const float r1 = xv - __uint_as_float(xu[e] & 0xFFFF0000u);
+                        r1u[e] = __float_as_uint(r1);
+                        r2u[e] = __float_as_uint(r1 - __uint_as_float(r1u[e] & 0xFFFF0000u));
+                        asm volatile("" : "+v"(r1u[e]), "+v"(r2u[e]));  // pin the piece into this slot
+                    }
+                    if (k >= 14 && k < 18) {  // pack word i of the three planes
+                        const int i = k - 14;
+                        xn[0].u[i] = __builtin_amdgcn_perm(xu[2 * i + 1], xu[2 * i], 0x07060302u);
+                        xn[1].u[i] = __builtin_amdgcn_perm(r1u[2 * i + 1], r1u[2 * i], 0x07060302u);
+                        xn[2].u[i] = __builtin_amdgcn_perm(r2u[2 * i + 1], r2u[2 * i], 0x07060302u);
+                        asm volatile("" : "+v"(xn[0].u[i]), "+v"(xn[1].u[i]), "+v"(xn[2].u[i]));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (CUT) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) xb[p] = xn[p];
+        }
+        s3_wait_vm_dyn(WPW + (NEXT_X ? 4 : 0));  // everything issued BEFORE this step has landed
+        __builtin_amdgcn_s_barrier();
+        STAMP();
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (a.nonlinear) {  // a weight chunk is due two steps ahead throughout GEMM 1
+        for (int c = 0; c + 1 < nk1; ++c) {
+            step(2 * c, F_{}, T_{}, T_{});
+            step(2 * c + 1, T_{}, F_{}, T_{});
+        }
+        step(nks - 2, F_{}, F_{}, T_{});
+        step(nks - 1, T_{}, F_{}, F_{});
+    } else
+    for (int s = 0; s < nks; ++s) {
+        // feature chunk c+1 goes out on the even step 2c; its first use is the mid-step read of step 2c+1
+        const bool do_w = s + 2 < nst, do_x = !(s & 1) && (s >> 1) + 1 < nk1;
+        const int issued = (do_w ? WPW : 0) + (do_x ? 4 : 0);
+        if (do_w) issue_w(s + 2);
+        if (do_x) issue_x((s >> 1) + 1);
+        const f32x4* w = sW + (s % 3) * S3_CHUNK_F4 + lane;
+        S3Frag xn[3];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             S3Frag wa[3];
@@ -339,7 +420,13 @@ __device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag,
 #pragma unroll
             for (int q = P0; q < 9; ++q)
                 H[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[S3_PA(q)].v, xb[S3_PB(q)].v, H[t], 0, 0, 0);
+            if (t == 0 && s + 1 < nks) {
+                if (s & 1) s3_wait_vm_dyn(do_w ? WPW : 0);  // own pieces of chunk c+1 (issued a step ago) landed
+                read_cut(s + 1, xn);
+            }
         }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) xb[p] = xn[p];
         s3_wait_vm_dyn(issued);  // everything issued BEFORE this step has landed
         __builtin_amdgcn_s_barrier();
         STAMP();
