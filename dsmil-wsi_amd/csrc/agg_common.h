@@ -73,6 +73,20 @@ __device__ __forceinline__ f32x4 load4(const T* __restrict__ p, int k, int klim)
     return v;
 }
 
+// 4 consecutive elements at p[k..k+3], 16-B (fp32) / 8-B (bf16) aligned, no range check
+template <typename T>
+__device__ __forceinline__ f32x4 load4_nocheck(const T* __restrict__ p, int k) {
+    if constexpr (sizeof(T) == 2) {
+        const u32x2 t = *(const DSMIL_GLOBAL u32x2*)(p + k);
+        f32x4 v;
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+        return v;
+    } else {
+        return *(const DSMIL_GLOBAL f32x4*)(p + k);
+    }
+}
+
 // Staging variant: never branches for VEC=4 — the address is clamped into the row (klim % 4 == 0,
 // klim >= 4) and the caller zeroes out-of-range k later (at LDS-write time), so a run of these
 // loads issues back to back and stays in flight under the MFMAs.
@@ -200,14 +214,23 @@ __device__ __forceinline__ void attend_tail(const AttendArgs& a, const f32x16 (&
         for (int k0 = 0; k0 < ((a.expt & 1) ? 0 : Kv); k0 += 512) {
             f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
             const int ka = k0 + lane * 4, kb = ka + 256;
+            // VEC = 4: unconditional loads from a clamped column (a lane past Kv accumulates junk it
+            // never stores) — a load behind a per-lane branch is issued alone and waited for at once
+            const int kac = ka < Kv ? ka : Kv - 4, kbc = kb < Kv ? kb : Kv - 4;
 #pragma unroll 8
             for (int n = 0; n < 32; ++n) {
                 long long r = wrow0 + n;
                 if (r >= Nb) r = Nb - 1;  // weight is 0 there
                 const float w0 = __shfl(pp0, n, 64), w1 = __shfl(pp1, n, 64);
                 const T* vr = vbase + r * (long long)Kv;
-                const f32x4 va = load4<VEC, T>(vr, ka, Kv);
-                const f32x4 vb = load4<VEC, T>(vr, kb, Kv);
+                f32x4 va, vb;
+                if constexpr (VEC == 4) {
+                    va = load4_nocheck<T>(vr, kac);
+                    vb = load4_nocheck<T>(vr, kbc);
+                } else {
+                    va = load4<VEC, T>(vr, ka, Kv);
+                    vb = load4<VEC, T>(vr, kb, Kv);
+                }
                 acc00 += w0 * va; acc01 += w0 * vb;
                 acc10 += w1 * va; acc11 += w1 * vb;
             }
