@@ -38,6 +38,11 @@ SIGNATURES = {
     "dsmil_abi_version": (ctypes.c_int, []),
     "dsmil_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "dsmil_agg_mlp_form": (ctypes.c_int, []),
+    "dsmil_agg_shard_argmax": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.POINTER(AggParams), c_f32p, c_f32p,
+                                              c_i64p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "dsmil_agg_shard_attend": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int64, ctypes.POINTER(AggParams), c_f32p,
+                                              c_f32p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t,
+                                              ctypes.c_void_p]),
     "dsmil_agg_tile_rows": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64]),
     "dsmil_agg_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int32,
                                                     ctypes.c_int32, ctypes.c_int32]),

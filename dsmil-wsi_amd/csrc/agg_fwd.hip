@@ -277,12 +277,14 @@ __device__ __forceinline__ void qmax_block(
     const float* __restrict__ q0_w, const float* __restrict__ q0_b,
     const float* __restrict__ q2_w, const float* __restrict__ q2_b,
     float* __restrict__ qmax, int64_t* __restrict__ idx_out, int K, int C, int nonlinear,
-    int bag, int c, float* s_v, long long* s_i, float* s_h) {
-    const long long off0 = offsets[bag];
-    const long long Nb = offsets[bag + 1] - off0;
+    int bag, int c, float* s_v, long long* s_i, float* s_h, int mode = 0, float* __restrict__ best_val_out = nullptr) {
+    // mode 0: arg-max + query of the critical row.  Instance-sharded bags (dsmil_agg_shard_*):
+    // mode 1 = arg-max only (index and value out), mode 2 = query of a GIVEN row (feats = [C,K] rows)
+    const long long off0 = mode == 2 ? 0 : offsets[bag];
+    const long long Nb = mode == 2 ? C : offsets[bag + 1] - off0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long slot0 = off0 / R0 + bag;
-    const long long ntile = (Nb + R0 - 1) / R0;
+    const long long ntile = mode == 2 ? 0 : (Nb + R0 - 1) / R0;
     float bv = -INFINITY;
     long long bi = 0x7fffffffffffffffLL;
     for (long long t = threadIdx.x; t < ntile; t += 256) {
@@ -302,9 +304,13 @@ __device__ __forceinline__ void qmax_block(
 #pragma unroll
     for (int w = 1; w < 4; ++w)
         if (better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
-    long long best = bi;
+    long long best = mode == 2 ? c : bi;
     if (best < 0 || best >= Nb) best = 0;  // all-NaN guard: stay in bounds
-    if (threadIdx.x == 0) idx_out[(long long)bag * C + c] = best;
+    if (threadIdx.x == 0 && mode != 2) {
+        idx_out[(long long)bag * C + c] = best;
+        if (best_val_out) best_val_out[(long long)bag * C + c] = bv;
+    }
+    if (mode == 1) return;
     const T* x = feats + (off0 + best) * (long long)K;
     // layer 1: wave w computes hidden units 32w..32w+31, 8 at a time; lanes stride k by 4
     for (int jb = 0; jb < 32; jb += 8) {
@@ -355,12 +361,13 @@ __global__ __launch_bounds__(256) void k_qmax(
     const float* __restrict__ part_val, const long long* __restrict__ part_idx,
     const float* __restrict__ q0_w, const float* __restrict__ q0_b,
     const float* __restrict__ q2_w, const float* __restrict__ q2_b,
-    float* __restrict__ qmax, int64_t* __restrict__ idx_out, int K, int C, int nonlinear, int bag0) {
+    float* __restrict__ qmax, int64_t* __restrict__ idx_out, int K, int C, int nonlinear, int bag0,
+    int mode = 0, float* __restrict__ best_val_out = nullptr) {
     __shared__ float s_v[4];
     __shared__ long long s_i[4];
     __shared__ float s_h[QD];
     qmax_block<VEC, T>(feats, offsets, part_val, part_idx, q0_w, q0_b, q2_w, q2_b, qmax, idx_out, K, C, nonlinear,
-                       bag0 + (int)blockIdx.x, (int)blockIdx.y, s_v, s_i, s_h);
+                       bag0 + (int)blockIdx.x, (int)blockIdx.y, s_v, s_i, s_h, mode, best_val_out);
 }
 
 template <int NW, int VEC>
@@ -609,7 +616,10 @@ template <int VEC>
 __global__ __launch_bounds__(256) void k_finish(
     const int64_t* __restrict__ offsets, const float* __restrict__ part_ml,
     const float* __restrict__ part_B, const float* __restrict__ fcc_w,
-    float* __restrict__ A, float* __restrict__ B, float* __restrict__ pred_part, int Kv, int C, int BM) {
+    float* __restrict__ A, float* __restrict__ B, float* __restrict__ pred_part, int Kv, int C, int BM,
+    float* __restrict__ ml_out = nullptr) {
+    // ml_out != null (instance-sharded bag): leave A and B relative to this shard's max, un-normalised
+    // (A = exp(s - m), B = sum exp(s - m) V) and hand (m, l) per class to the caller's cross-shard merge
     const int bag = blockIdx.y, nblk = gridDim.x;
     const long long off0 = offsets[bag];
     const long long Nb = offsets[bag + 1] - off0;
@@ -642,7 +652,8 @@ __global__ __launch_bounds__(256) void k_finish(
         if (lane == 0) s_red[4 + wave] = l;
         __syncthreads();
         l = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-        const float il = 1.f / l;
+        const float il = ml_out ? 1.f : 1.f / l;
+        if (ml_out && blockIdx.x == 0 && tid == 0) { ml_out[((long long)bag * C + c) * 2] = m; ml_out[((long long)bag * C + c) * 2 + 1] = l; }
         // A = exp(s - m) / l for this block's rows
         for (long long r = rbeg + tid; r < rend; r += 256) {
             float* p = A + (off0 + r) * (long long)C + c;
@@ -721,7 +732,7 @@ __global__ __launch_bounds__(256) void k_fc(const float* __restrict__ feats,
 
 // ---- host side ------------------------------------------------------------------------------
 struct WsLayout {
-    size_t part_val, part_idx, qmax, part_ml, part_B, pred_part, wsplit, total;
+    size_t part_val, part_idx, qmax, part_ml, part_B, pred_part, wsplit, off2, total;
     long long slots0, slots, nchunk_max;
 };
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -748,6 +759,7 @@ WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int K, 
     w.part_B = o; o = al(o + (size_t)w.slots * C * Kv * sizeof(float));
     w.pred_part = o; o = al(o + (size_t)n_bags * w.nchunk_max * C * C * sizeof(float));
     w.wsplit = o; o = al(o + (size_t)(2 * ((K + 31) / 32) + 8) * S3_CHUNK_F4 * 16);  // cut query weights
+    w.off2 = o; o = al(o + 2 * sizeof(int64_t));  // {0, N} of a lone shard (dsmil_agg_shard_*)
     w.total = o;
     return w;
 }
@@ -864,17 +876,29 @@ int dsmil_fc_forward(const float* feats, int64_t total_rows, int32_t K, int32_t 
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
+__global__ void k_set_offsets2(int64_t* off, long long N) { off[0] = 0; off[1] = N; }
+
+struct ShardCtl {
+    int phase = 0;                    // 0 whole forward; 1 logits + arg-max only; 2 attend against given rows
+    const float* crit_rows = nullptr; // phase 2: [C,K] feature rows of the bag-wide critical instances
+    float* best_val = nullptr;        // phase 1 out: [C]
+    float* ml_out = nullptr;          // phase 2 out: [C,2] (max, sum) of this shard
+};
+
 static int agg_forward_impl(const void* feats, const void* vals, const int64_t* offsets,
                             int32_t n_bags, int64_t total_rows, int64_t max_rows, const dsmil_agg_params* p,
                             const void* packed_bf16, bool bf16, const float* classes_in, float* classes_out,
                             float* A, float* B, float* pred, int64_t* idx, void* ws, size_t ws_bytes,
-                            void* stream) {
-    if (!feats || !offsets || !p || !A || !B || !pred || !idx || !ws) return DSMIL_E_INVALID;
+                            void* stream, const ShardCtl& sh = ShardCtl()) {
+    if (!feats || !p || !ws) return DSMIL_E_INVALID;
+    if (sh.phase == 0 && (!offsets || !A || !B || !pred || !idx)) return DSMIL_E_INVALID;
+    if (sh.phase == 1 && (!classes_out || !idx || !sh.best_val)) return DSMIL_E_INVALID;
+    if (sh.phase == 2 && (!A || !B || !sh.crit_rows || !sh.ml_out)) return DSMIL_E_INVALID;
     if (n_bags <= 0 || total_rows <= 0 || max_rows <= 0 || max_rows > total_rows) return DSMIL_E_INVALID;
     if (p->K <= 0 || p->Kv <= 0 || p->C <= 0) return DSMIL_E_INVALID;
     if (!p->q0_w || !p->q0_b || !p->fcc_w || !p->fcc_b) return DSMIL_E_INVALID;
     if (p->nonlinear && (!p->q2_w || !p->q2_b)) return DSMIL_E_INVALID;
-    if (!classes_in && (!p->fc_w || !p->fc_b || !classes_out)) return DSMIL_E_INVALID;
+    if (sh.phase != 2 && !classes_in && (!p->fc_w || !p->fc_b || !classes_out)) return DSMIL_E_INVALID;
     if (bf16 && !packed_bf16) return DSMIL_E_INVALID;
     if (n_bags > 65535) return DSMIL_E_UNSUPPORTED;
     if (!vals) vals = feats;
@@ -891,6 +915,11 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     if (ws_bytes < L.total) return DSMIL_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* w8 = (char*)ws;
+    if (sh.phase) {  // a lone shard: its {0, N} offsets live in the workspace
+        int64_t* off2 = (int64_t*)(w8 + L.off2);
+        hipLaunchKernelGGL(k_set_offsets2, dim3(1), dim3(1), 0, st, off2, (long long)total_rows);
+        offsets = off2;
+    }
     float* part_val = (float*)(w8 + L.part_val);
     long long* part_idx = (long long*)(w8 + L.part_idx);
     float* qmax = (float*)(w8 + L.qmax);
@@ -915,7 +944,8 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         const int b0 = 0, nb = n_bags;
         // 1. instance logits + arg-max partials
         dim3 grid((unsigned)((max_rows + R0 - 1) / R0), (unsigned)nb);
-        if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
+        if (sh.phase == 2) {}  // the caller already knows the bag-wide critical rows
+        else if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
         else if (bf16 && w4) hipLaunchKernelGGL((k_logits_argmax<4, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
         else if (bf16) hipLaunchKernelGGL((k_logits_argmax<1, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
         else if (v4 && !getenv("DSMIL_LOGITS_OLD")) {
@@ -928,7 +958,17 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         // 2. critical instance + its query
         dim3 gq((unsigned)nb, (unsigned)C);
-        if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), gq, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0);
+        if (sh.phase == 1) {
+            if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val);
+            else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val);
+            return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+        }
+        if (sh.phase == 2) {
+            const bool r4 = (K % 4 == 0) && ((uintptr_t)sh.crit_rows % 16 == 0) && (((uintptr_t)p->q0_w) % 16 == 0);
+            if (r4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(256), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
+            else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(256), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
+        }
+        else if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), gq, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0);
         else if (bf16) hipLaunchKernelGGL((k_qmax<1, bf16_t>), gq, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0);
         else if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0);
         else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0);
@@ -957,10 +997,11 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     if (!(a.expt & 64)) {
         dim3 grid((unsigned)L.nchunk_max, (unsigned)n_bags);
         if (Kv % 4 == 0)
-            hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM);
+            hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM, sh.ml_out);
         else
-            hipLaunchKernelGGL(k_finish<1>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM);
+            hipLaunchKernelGGL(k_finish<1>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM, sh.ml_out);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+        if (sh.phase == 2) return DSMIL_OK;  // the bag head runs after the cross-shard merge
         const int n = n_bags * C;
         hipLaunchKernelGGL(k_pred, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pred_part,
                            p->fcc_b, pred, C, (int)L.nchunk_max, n_bags);
@@ -976,6 +1017,26 @@ int dsmil_agg_forward(const float* feats, const float* vals, const int64_t* offs
                       void* stream) {
     return agg_forward_impl(feats, vals, offsets, n_bags, total_rows, max_rows, p, nullptr, false, classes_in,
                             classes_out, A, B, pred, idx, ws, ws_bytes, stream);
+}
+
+int dsmil_agg_shard_argmax(const float* feats, int64_t rows, const dsmil_agg_params* p, float* classes_out,
+                           float* best_val, int64_t* best_idx, void* ws, size_t ws_bytes, void* stream) {
+    ShardCtl sh;
+    sh.phase = 1;
+    sh.best_val = best_val;
+    return agg_forward_impl(feats, nullptr, nullptr, 1, rows, rows, p, nullptr, false, nullptr, classes_out, nullptr,
+                            nullptr, nullptr, best_idx, ws, ws_bytes, stream, sh);
+}
+
+int dsmil_agg_shard_attend(const float* feats, const float* vals, int64_t rows, const dsmil_agg_params* p,
+                           const float* crit_rows, float* A_unnorm, float* ml, float* B_unnorm, void* ws,
+                           size_t ws_bytes, void* stream) {
+    ShardCtl sh;
+    sh.phase = 2;
+    sh.crit_rows = crit_rows;
+    sh.ml_out = ml;
+    return agg_forward_impl(feats, vals, nullptr, 1, rows, rows, p, nullptr, false, nullptr, nullptr, A_unnorm,
+                            B_unnorm, nullptr, nullptr, ws, ws_bytes, stream, sh);
 }
 
 size_t dsmil_agg_packed_bf16_bytes(int32_t K) {

@@ -80,3 +80,85 @@ def embed_rows_sharded(embed_fn, n_total, group=None):
     lo, hi = shard_range(n_total, rank, world)
     local = embed_fn(lo, hi)
     return all_gather_rows(local, n_total, group)
+
+
+# ---------------------------------------------------------------------------------------------
+# ONE bag sharded by instances: exchange C*(2+K) floats twice instead of
+# all-gathering the [N,K] feature rows
+# ---------------------------------------------------------------------------------------------
+def _gather_list(t, group=None):
+    """All-gather equal-shape tensors into a python list (world 1: [t])."""
+    world, _ = world_rank(group)
+    if world == 1:
+        return [t]
+    bufs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(bufs, t.contiguous(), group=group)
+    return bufs
+
+
+def sharded_bag_forward(milnet, feats_local, row_offset, group=None, gather=_gather_list):
+    """MILNet.forward (dsmil.py:70-74) for a bag whose instance rows are spread over the ranks:
+    this rank holds ``feats_local`` = rows [row_offset, row_offset + n_local) of the bag.
+
+    Returns (classes_local [n_local,C], pred [1,C], A_local [n_local,C], B [1,C,K], idx [C]) — the local
+    slices of what the reference returns for the whole bag, plus the bag-wide critical indices;
+    ``pred``, ``B`` and ``idx`` are identical on every rank.  Two small exchanges (per class: the
+    shard's best logit, its global row index and that feature row; then the shard's softmax
+    statistics and un-normalised value sum).  CUDA tensors run dsmil_agg_shard_* natively; CPU tensors
+    (gloo tests) run the same arithmetic with torch ops.  ``gather`` is injectable for single-process
+    tests that play several ranks in turn."""
+    import torch.nn.functional as F
+    from . import ops
+    ic, bc = milnet.i_classifier, milnet.b_classifier
+    if bc.passing_v:
+        raise NotImplementedError("instance sharding is implemented for v = Identity (every reference script)")
+    x = feats_local
+    n_local, K = x.shape
+    lin = ic.fc[0]
+    w = {k: (v.detach() if v is not None else None) for k, v in bc._weights().items()}
+    w["fc_w"], w["fc_b"] = lin.weight.detach(), lin.bias.detach()
+    C = w["fcc_w"].shape[0]
+    native = x.is_cuda
+    with torch.no_grad():
+        # ---- 1. local instance logits and the shard's best row per class
+        if native:
+            classes, best_val, best_idx = ops.agg_shard_argmax(x, w, nonlinear=bc.nonlinear)
+        else:
+            classes = F.linear(x, w["fc_w"], w["fc_b"])
+            best_val, best_idx = classes.max(dim=0)
+            best_idx = torch.argmax(classes, dim=0)   # lowest index on ties
+            best_val = classes[best_idx, torch.arange(C)]
+        rows = x[best_idx]                                                    # [C,K]
+        msg = torch.cat([best_val[:, None], (best_idx + row_offset).to(x.dtype)[:, None], rows], dim=1)
+        allmsg = torch.stack(gather(msg, group))                              # [R, C, 2+K]
+        vals_, gidx = allmsg[:, :, 0], allmsg[:, :, 1]
+        # bag-wide winner per class: larger value, then lower global index (dsmil.py:52 + our tie rule)
+        best_r = torch.zeros(C, dtype=torch.long, device=x.device)
+        for r in range(1, allmsg.shape[0]):
+            cur_v = vals_[best_r, torch.arange(C)]
+            cur_i = gidx[best_r, torch.arange(C)]
+            better = (vals_[r] > cur_v) | ((vals_[r] == cur_v) & (gidx[r] < cur_i))
+            best_r = torch.where(better, torch.full_like(best_r, r), best_r)
+        crit_rows = allmsg[best_r, torch.arange(C), 2:].contiguous()          # [C,K]
+        idx = gidx[best_r, torch.arange(C)].to(torch.int64)
+        # ---- 2. this shard's attention against the bag-wide critical rows
+        if native:
+            A_un, ml, B_un = ops.agg_shard_attend(x, w, crit_rows, nonlinear=bc.nonlinear)
+        else:
+            q = bc.q
+            Q = q(x)
+            qmax = q(crit_rows)
+            s = Q.mm(qmax.t()) / (Q.shape[1] ** 0.5)
+            m = s.max(dim=0).values
+            A_un = torch.exp(s - m)
+            ml = torch.stack([m, A_un.sum(0)], dim=1)
+            B_un = A_un.t().mm(x)
+        stat = torch.stack(gather(torch.cat([ml, B_un], dim=1), group))       # [R, C, 2+K]
+        m_all, l_all, B_all = stat[:, :, 0], stat[:, :, 1], stat[:, :, 2:]
+        m = m_all.max(dim=0).values
+        wr = torch.exp(m_all - m)                                             # [R, C]
+        l = (l_all * wr).sum(0)
+        B = (B_all * wr[:, :, None]).sum(0) / l[:, None]                      # [C,K]
+        A = A_un * (torch.exp(ml[:, 0] - m) / l)[None, :]
+        pred = bc.fcc(B.unsqueeze(0)).view(1, -1)                             # dsmil.py:60-61
+    return classes, pred, A, B.unsqueeze(0), idx

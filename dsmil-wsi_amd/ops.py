@@ -174,6 +174,59 @@ def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, o
     return classes, pred, A, B, idx
 
 
+def _agg_params(w, K, Kv, nonlinear):
+    fcc_w = _f32c(w["fcc_w"], "fcc_w")
+    C = fcc_w.shape[0]
+    keep = [_f32c(w.get(k), k) for k in ("fc_w", "fc_b", "q0_w", "q0_b", "q2_w", "q2_b", "fcc_w", "fcc_b")]
+    p = _native.AggParams(*[(t.data_ptr() if t is not None else 0) for t in keep], K, Kv, C, 1 if nonlinear else 0)
+    return p, keep, C
+
+
+def agg_shard_argmax(feats, w, nonlinear=True):
+    """dsmil_agg_shard_argmax: one rank's row range of an instance-sharded bag.
+    Returns (classes [rows,C], best_val [C], best_idx [C] shard-local)."""
+    feats = _f32c(feats, "feats")
+    dev = feats.device
+    rows, K = feats.shape
+    p, keep, C = _agg_params(w, K, w["fcc_w"].shape[2], nonlinear)
+    classes = torch.empty((rows, C), dtype=torch.float32, device=dev)
+    best_val = torch.empty((C,), dtype=torch.float32, device=dev)
+    best_idx = torch.empty((C,), dtype=torch.int64, device=dev)
+    L = _native.lib()
+    ws = _workspace(dev, L.dsmil_agg_workspace_bytes(1, rows, K, w["fcc_w"].shape[2], C))
+    with torch.cuda.device(dev):
+        rc = L.dsmil_agg_shard_argmax(_ptr(feats), rows, ctypes.byref(p), _ptr(classes), _ptr(best_val),
+                                      _ptr(best_idx), _ptr(ws), ws.numel(), _stream(dev))
+    _native.check(rc, "dsmil_agg_shard_argmax")
+    del keep
+    return classes, best_val, best_idx
+
+
+def agg_shard_attend(feats, w, crit_rows, vals=None, nonlinear=True):
+    """dsmil_agg_shard_attend: attention of this shard's rows against the bag-wide critical rows.
+    Returns (A_unnorm [rows,C] = exp(s - m_shard), ml [C,2] = (m_shard, l_shard), B_unnorm [C,Kv])."""
+    feats = _f32c(feats, "feats")
+    dev = feats.device
+    rows, K = feats.shape
+    vals = feats if vals is None else _f32c(vals, "vals")
+    Kv = vals.shape[1]
+    p, keep, C = _agg_params(w, K, Kv, nonlinear)
+    crit_rows = _f32c(crit_rows, "crit_rows")
+    if tuple(crit_rows.shape) != (C, K):
+        raise ValueError(f"crit_rows must be [{C},{K}], got {tuple(crit_rows.shape)}")
+    A = torch.empty((rows, C), dtype=torch.float32, device=dev)
+    ml = torch.empty((C, 2), dtype=torch.float32, device=dev)
+    B = torch.empty((C, Kv), dtype=torch.float32, device=dev)
+    L = _native.lib()
+    ws = _workspace(dev, L.dsmil_agg_workspace_bytes(1, rows, K, Kv, C))
+    with torch.cuda.device(dev):
+        rc = L.dsmil_agg_shard_attend(_ptr(feats), _ptr(vals), rows, ctypes.byref(p), _ptr(crit_rows), _ptr(A),
+                                      _ptr(ml), _ptr(B), _ptr(ws), ws.numel(), _stream(dev))
+    _native.check(rc, "dsmil_agg_shard_attend")
+    del keep
+    return A, ml, B
+
+
 def agg_backward(feats, w, A, B, idx, g_pred, g_classes=None, g_A=None, g_B=None, vals=None, nonlinear=True,
                  want_g_vals=False):
     """dsmil_agg_backward: parameter gradients of FCLayer + BClassifier for ONE bag (what autograd

@@ -100,6 +100,26 @@ int dsmil_agg_forward_bf16(const void* feats_bf16, const void* vals_bf16, const 
                            float* classes_out, float* A, float* B, float* pred, int64_t* idx, void* ws,
                            size_t ws_bytes, void* stream);
 
+/* ---- one bag sharded by INSTANCES over several GPUs ----------------------
+ * Each rank holds a contiguous row range of ONE bag and exchanges C*(2+K) floats twice instead of
+ * all-gathering the feature rows.  Per rank:
+ *   1. dsmil_agg_shard_argmax: classes_out[rows,C] = FCLayer(feats) (dsmil.py:11) and, per class, the
+ *      shard's best (value, shard-local index) of dsmil.py:52 (lowest index on ties).
+ *      -> exchange (value, global index, the feature row feats[best_idx]) and keep, per class, the
+ *         bag-wide winner's row: crit_rows[C,K].
+ *   2. dsmil_agg_shard_attend: q_max = q(crit_rows) (dsmil.py:53-54), then the fused query/score/
+ *      value-sum kernel over this shard: A_unnorm[rows,C] = exp(s - m_shard), ml[C,2] = (m_shard,
+ *      sum_n exp(s - m_shard)), B_unnorm[C,Kv] = sum_n exp(s - m_shard) V[n].
+ *      -> merge over ranks: m = max m_r, w_r = exp(m_r - m), l = sum l_r w_r, B = sum B_r w_r / l,
+ *         A = A_unnorm w_r / l on each rank, pred = Conv1d head on B (dsmil.py:57-61).
+ * Workspace: dsmil_agg_workspace_bytes(1, rows, K, Kv, C).  fp32 only. */
+int dsmil_agg_shard_argmax(const float* feats, int64_t rows, const dsmil_agg_params* p,
+                           float* classes_out, float* best_val, int64_t* best_idx, void* ws,
+                           size_t ws_bytes, void* stream);
+int dsmil_agg_shard_attend(const float* feats, const float* vals, int64_t rows,
+                           const dsmil_agg_params* p, const float* crit_rows, float* A_unnorm,
+                           float* ml, float* B_unnorm, void* ws, size_t ws_bytes, void* stream);
+
 /* Which MFMA form dsmil_agg_forward uses for the fp32 query MLP (dsmil.py:31-33,49):
  *   9 (default) — bf16 MFMA over exact three-plane cuts of both fp32 operands, all 9 plane products
  *                 (every fp32 product formed exactly, fp32 accumulate; csrc/agg_split.h)

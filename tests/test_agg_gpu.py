@@ -187,3 +187,56 @@ def test_gradients_vs_reference_autograd(golden, tag, N):
         ref = golden[f"{name}/g_{keymap[k]}"]
         scale = max(1e-6, float(np.abs(ref).max()))
         np.testing.assert_allclose(prm.grad.cpu().numpy(), ref, atol=1e-4 * scale + 1e-7, rtol=1e-3, err_msg=k)
+
+
+class _Stop(Exception):
+    pass
+
+
+def _play_ranks(fn, R):
+    """Run ``fn(rank, gather)`` for R ranks inside ONE process: the function has two all-gather points;
+    pass p records every rank's message of exchange p (and stops there), the last pass replays all."""
+    msgs = []
+    for phase in range(3):
+        new, outs = [], []
+        for r in range(R):
+            k = {"i": 0}
+
+            def gather(t, group=None, _k=k):
+                i = _k["i"]
+                _k["i"] += 1
+                if i < len(msgs):
+                    return msgs[i]
+                new.append(t.clone())
+                raise _Stop
+            try:
+                outs.append(fn(r, gather))
+            except _Stop:
+                pass
+        if phase < 2:
+            assert len(new) == R
+            msgs.append(new)
+    assert len(outs) == R
+    return outs
+
+
+@pytest.mark.parametrize("tag,N,R", [("tcga", 10000, 3), ("c16", 70000, 2), ("musk", 333, 2)])
+def test_instance_sharded_bag_native(tag, N, R):
+    """dsmil_agg_shard_argmax / dsmil_agg_shard_attend: one process plays R ranks in turn (the exchange is
+    a python list); the merged result must equal the unsharded native forward and the fp64 oracle."""
+    from dsmil_wsi_amd import dist as dd
+    K = VARIANT[tag][0]
+    net = build_net(tag, "cuda")
+    x = torch.from_numpy(make_bag(555 + N, N, K)).cuda()
+    shards = [dd.shard_range(N, r, R) for r in range(R)]
+    outs = _play_ranks(lambda r, g: dd.sharded_bag_forward(net, x[shards[r][0]:shards[r][1]], shards[r][0], gather=g), R)
+    with torch.no_grad():
+        full = net(x)
+    ref = orc.milnet_forward(x.cpu().numpy(), load_weights(tag), dtype="f64")
+    classes = torch.cat([o[0] for o in outs])
+    A = torch.cat([o[2] for o in outs])
+    for o in outs:
+        assert np.array_equal(o[4].cpu().numpy(), np.asarray(ref[4]))
+        np.testing.assert_allclose(o[1].cpu().numpy(), full[1].cpu().numpy(), atol=2e-6)
+        np.testing.assert_allclose(o[3].cpu().numpy(), full[3].cpu().numpy(), atol=2e-6)
+    _cmp((classes, outs[0][1], A, outs[0][3]), ref[0], ref[1], ref[2], ref[3])

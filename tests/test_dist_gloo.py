@@ -95,3 +95,48 @@ def test_shard_range_partitions_exactly():
             assert all(ranges[i][1] == ranges[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in ranges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _shard_worker(rank, world, port, n_total, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "oracle")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dsmil  # noqa: F401
+    from dsmil_wsi_amd import dist as dd
+    from inputs import make_bag
+    from util import build_net
+    torch.set_num_threads(2)
+    net = build_net("tcga")
+    x = torch.from_numpy(make_bag(77, n_total, 512))
+    lo, hi = dd.shard_range(n_total, rank, world)
+    classes, pred, A, B, idx = dd.sharded_bag_forward(net, x[lo:hi], lo)
+    with torch.no_grad():
+        ref = net(x)
+    ok = (torch.allclose(classes, ref[0][lo:hi], atol=1e-6) and torch.allclose(pred, ref[1], atol=1e-5)
+          and torch.allclose(A, ref[2][lo:hi], atol=1e-7, rtol=1e-4) and torch.allclose(B, ref[3], atol=1e-5)
+          and torch.equal(idx, torch.argmax(ref[0], dim=0)))
+    q.put((rank, bool(ok), float((A.sum(0)).sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 301), (3, 1000)])
+def test_instance_sharded_bag_equals_unsharded(world, n_total):
+    """ONE bag spread over the ranks by rows: two exchanges of C*(2+K) floats reproduce MILNet.forward
+    of the whole bag (local slices of classes/A, identical pred/B/idx on every rank)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert abs(sum(s for _, _, s in res) - 2.0) < 1e-4   # the local attention slices sum to 1 per class
