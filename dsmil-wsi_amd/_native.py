@@ -63,6 +63,11 @@ SIGNATURES = {
     "dsmil_resnet18in_forward_u8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                    c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p,
                                                    c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "dsmil_resnet18_norm_channels": (ctypes.c_int32, []),
+    "dsmil_resnet18bn_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                                ctypes.c_int32, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t,
+                                                ctypes.c_void_p]),
     "dsmil_fc_forward": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                         c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
     "dsmil_agg_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,

@@ -833,7 +833,10 @@ __global__ __launch_bounds__(256) void k_norm_relu_maxpool(const float* __restri
         const int ox = (int)(p % Wo); p /= Wo;
         const int oy = (int)(p % Ho);
         const int n = (int)(p / Ho);
+        // max of the normalised window = normalised max (r >= 0: InstanceNorm always) or normalised
+        // min (r < 0: a frozen BatchNorm with negative weight), so both extremes of the raw window are kept
         f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        f32x4 mn = {INFINITY, INFINITY, INFINITY, INFINITY};
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int iy = oy * 2 - 1 + dy;
@@ -844,14 +847,14 @@ __global__ __launch_bounds__(256) void k_norm_relu_maxpool(const float* __restri
                 if (ix < 0 || ix >= Wi) continue;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(y + (((long long)n * Hi + iy) * Wi + ix) * C + c4 * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+                for (int e = 0; e < 4; ++e) { m[e] = fmaxf(m[e], v[e]); mn[e] = fminf(mn[e], v[e]); }
             }
         }
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (long long)n * C + c4 * 4);
         const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + (long long)n * C + c4 * 4);
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = fmaxf((m[e] - mu[e]) * rs[e], 0.f);
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(((rs[e] >= 0.f ? m[e] : mn[e]) - mu[e]) * rs[e], 0.f);
         *reinterpret_cast<f32x4*>(out + (((long long)n * Ho + oy) * Wo + ox) * C + c4 * 4) = o;
     }
 }
@@ -1012,8 +1015,23 @@ RWs rws_layout(int B, int H, int W) {
     return r;
 }
 
+// Frozen-statistics norm (eval-mode BatchNorm2d): y = (x - m[c]) * r[c] with m, r folded from the
+// running statistics and the affine by the caller.  The per-(image, channel) arrays the consumers
+// read are simply filled with the per-channel values — every other kernel stays as it is.
+__global__ void k_fill_stats(const float* __restrict__ m_c, const float* __restrict__ r_c, float* __restrict__ mean,
+                             float* __restrict__ rstd, int B, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * C) { mean[i] = m_c[i % C]; rstd[i] = r_c[i % C]; }
+}
+
+int fill_stats(hipStream_t st, const float* m_c, const float* r_c, float* mean, float* rstd, int B, int C) {
+    hipLaunchKernelGGL(k_fill_stats, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, st, m_c, r_c, mean, rstd, B, C);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
 int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_mean, const float* in_rstd,
-             float* y, float* part, float* mean, float* rstd, int B, int H, int W, const ConvSpec& s) {
+             float* y, float* part, float* mean, float* rstd, int B, int H, int W, const ConvSpec& s,
+             const float* bn_m = nullptr, const float* bn_r = nullptr) {
     if (use_wino(s)) {
         WinoArgs wa;
         wa.x = x; wa.u = wpk; wa.in_mean = in_mean; wa.in_rstd = in_rstd; wa.y = y; wa.part = part;
@@ -1030,6 +1048,7 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
         else hipLaunchKernelGGL((k_conv_wino<false>), grid, dim3(256), lds, st, wa);
         dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+        if (bn_m) return fill_stats(st, bn_m, bn_r, mean, rstd, B, s.cout);
         hipLaunchKernelGGL(k_in_finalize_cnt, dim3((unsigned)B), dim3(256), 0, st, part, mean, rstd, wa.PB * 2, s.cout);
         return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
     }
@@ -1075,6 +1094,7 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
     }
     dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    if (bn_m) return fill_stats(st, bn_m, bn_r, mean, rstd, B, s.cout);
     hipLaunchKernelGGL(k_in_finalize_flat, dim3((unsigned)B), dim3(256), 0, st, part, mean, rstd,
                        B, HW, s.cout, a.nslots, a.Mtot);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
@@ -1127,9 +1147,19 @@ size_t dsmil_resnet18_workspace_bytes(int32_t B, int32_t H, int32_t W) {
     return rws_layout(B, H, W).total;
 }
 
+// offset of conv i's norm in the concatenated per-channel arrays of the frozen-statistics variant
+static int norm_offset(int i) {
+    int o = 0;
+    for (int j = 0; j < i; ++j) o += kSpecs[j].cout;
+    return o;
+}
+
 static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32_t H, int32_t W, const float* conv1_w,
                                    const float* packed, const float* fc_w, const float* fc_b, int32_t C,
-                                   float* feats, float* classes, void* ws, size_t ws_bytes, void* stream) {
+                                   float* feats, float* classes, void* ws, size_t ws_bytes, void* stream,
+                                   const float* bn_m = nullptr, const float* bn_r = nullptr) {
+    auto bm = [&](int i) { return bn_m ? bn_m + norm_offset(i) : nullptr; };
+    auto br = [&](int i) { return bn_r ? bn_r + norm_offset(i) : nullptr; };
     if (!x_nchw || !conv1_w || !packed || !feats || !ws) return DSMIL_E_INVALID;
     if (B <= 0 || H < 32 || W < 32) return DSMIL_E_INVALID;
     if (classes && (!fc_w || !fc_b || C <= 0)) return DSMIL_E_INVALID;
@@ -1157,8 +1187,9 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
         else hipLaunchKernelGGL(k_stem<false>, dim3((unsigned)ty, (unsigned)B), dim3(256), 0, st, x_nchw, conv1_w, y0,
                                 part, B, H, W, d.H1, d.W1, tx, ty);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
-        hipLaunchKernelGGL(k_in_finalize_stem, dim3((unsigned)B), dim3(256), 0, st, part,
-                           mean[0], rstd[0], B, tx * ty * 4);
+        if (bn_m) { const int rcf = fill_stats(st, bm(0), br(0), mean[0], rstd[0], B, 64); if (rcf) return rcf; }
+        else hipLaunchKernelGGL(k_in_finalize_stem, dim3((unsigned)B), dim3(256), 0, st, part,
+                                mean[0], rstd[0], B, tx * ty * 4);
         const long long total = (long long)B * d.Hp * d.Wp * 16;
         long long blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
@@ -1180,12 +1211,12 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
             const ConvSpec& sa = kSpecs[ci];
             const ConvSpec& sb = kSpecs[ci + 1];
             const int Ho = outdim(Hc, sa.ks, sa.stride, sa.pad), Wo = outdim(Wc, sa.ks, sa.stride, sa.pad);
-            int rc = run_conv(st, cur, packed + pack_offset(ci), nullptr, nullptr, y1, part, mean[1], rstd[1], B, Hc, Wc, sa);
+            int rc = run_conv(st, cur, packed + pack_offset(ci), nullptr, nullptr, y1, part, mean[1], rstd[1], B, Hc, Wc, sa, bm(ci), br(ci));
             if (rc) return rc;
-            rc = run_conv(st, y1, packed + pack_offset(ci + 1), mean[1], rstd[1], y2, part, mean[2], rstd[2], B, Ho, Wo, sb);
+            rc = run_conv(st, y1, packed + pack_offset(ci + 1), mean[1], rstd[1], y2, part, mean[2], rstd[2], B, Ho, Wo, sb, bm(ci + 1), br(ci + 1));
             if (rc) return rc;
             if (down) {
-                rc = run_conv(st, cur, packed + pack_offset(ci + 2), nullptr, nullptr, yd, part, mean[3], rstd[3], B, Hc, Wc, kSpecs[ci + 2]);
+                rc = run_conv(st, cur, packed + pack_offset(ci + 2), nullptr, nullptr, yd, part, mean[3], rstd[3], B, Hc, Wc, kSpecs[ci + 2], bm(ci + 2), br(ci + 2));
                 if (rc) return rc;
             }
             const long long npix = (long long)B * Ho * Wo;
@@ -1221,6 +1252,17 @@ int dsmil_resnet18in_forward_u8(const uint8_t* x_nhwc, int32_t B, int32_t H, int
                                 float* feats, float* classes, void* ws, size_t ws_bytes, void* stream) {
     return resnet18in_forward_impl(x_nhwc, true, B, H, W, conv1_w, packed, fc_w, fc_b, C, feats, classes, ws,
                                    ws_bytes, stream);
+}
+
+int32_t dsmil_resnet18_norm_channels(void) { return norm_offset(20); }
+
+int dsmil_resnet18bn_forward(const void* x, int32_t x_is_u8_nhwc, int32_t B, int32_t H, int32_t W,
+                             const float* conv1_w, const float* packed, const float* bn_mean,
+                             const float* bn_rstd, const float* fc_w, const float* fc_b, int32_t C,
+                             float* feats, float* classes, void* ws, size_t ws_bytes, void* stream) {
+    if (!bn_mean || !bn_rstd) return DSMIL_E_INVALID;
+    return resnet18in_forward_impl(x, x_is_u8_nhwc != 0, B, H, W, conv1_w, packed, fc_w, fc_b, C, feats, classes, ws,
+                                   ws_bytes, stream, bn_mean, bn_rstd);
 }
 
 }  // extern "C"

@@ -34,12 +34,15 @@ class FCLayer(nn.Module):
 
 
 def resnet_convs_of(fe):
-    """The 20 conv weights when ``fe`` is a ResNet-18 + InstanceNorm trunk with fc = Identity, else None."""
-    from .resnet import resnet18_in_convs
+    """(convs, bn_norms) when ``fe`` is a ResNet-18 trunk with fc = Identity that the native embedder
+    covers — InstanceNorm (bn_norms None) or eval-mode BatchNorm — else None."""
+    from .resnet import resnet18_bn_parts, resnet18_in_convs
+    if not isinstance(getattr(fe, "fc", None), nn.Identity):
+        return None
     convs = resnet18_in_convs(fe)
-    if convs is not None and isinstance(getattr(fe, "fc", None), nn.Identity):
-        return convs
-    return None
+    if convs is not None:
+        return convs, None
+    return resnet18_bn_parts(fe)
 
 
 class IClassifier(nn.Module):
@@ -64,9 +67,9 @@ class IClassifier(nn.Module):
                 torch.is_grad_enabled() and any(p.requires_grad for p in fe.parameters())):
             # ResNet-18 + InstanceNorm with fc = Identity (ours or torchvision's, compute_feats.py:157,170):
             # features and instance logits come from one native launch sequence
-            convs = resnet_convs_of(fe)
-            if convs is not None:
-                return ops.resnet18in_forward(x, convs, self.fc.weight, self.fc.bias)
+            trunk = resnet_convs_of(fe)
+            if trunk is not None:
+                return ops.resnet18in_forward(x, trunk[0], self.fc.weight, self.fc.bias, bn_norms=trunk[1])
         feats = fe(x)
         feats = feats.view(feats.shape[0], -1)
         if feats.is_cuda:

@@ -303,10 +303,40 @@ RESNET18_SHAPES = [(64, 3, 7, 7)] + [(64, 64, 3, 3)] * 4 + \
     [(512, 256, 3, 3), (512, 512, 3, 3), (512, 256, 1, 1), (512, 512, 3, 3), (512, 512, 3, 3)]
 
 
-def resnet18in_forward(x, convs, fc_w=None, fc_b=None):
+_bn_cache = {}
+
+
+def _folded_bn(norms, dev):
+    """Fold 20 eval-mode BatchNorm2d into y = (x - m) * r, concatenated in conv order (cached on the
+    parameter / buffer versions)."""
+    key = tuple((id(n), n.running_mean._version, n.running_var._version,
+                 None if n.weight is None else n.weight._version,
+                 None if n.bias is None else n.bias._version) for n in norms)
+    hit = _bn_cache.get("k")
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    ms, rs = [], []
+    for n in norms:
+        var = n.running_var.detach().to(dev, torch.float64)
+        mean = n.running_mean.detach().to(dev, torch.float64)
+        w = n.weight.detach().to(dev, torch.float64) if n.weight is not None else torch.ones_like(var)
+        b = n.bias.detach().to(dev, torch.float64) if n.bias is not None else torch.zeros_like(var)
+        r = w / torch.sqrt(var + n.eps)
+        if bool((r == 0).any()):
+            raise NotImplementedError("a BatchNorm channel with weight 0 cannot be folded into (x - m) * r")
+        ms.append(mean - b / r)
+        rs.append(r)
+    m = torch.cat(ms).to(torch.float32).contiguous()
+    r = torch.cat(rs).to(torch.float32).contiguous()
+    _bn_cache["k"] = (key, m, r)
+    return m, r
+
+
+def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None):
     """x: [B,3,H,W] fp32 CUDA in [0,1] (what VF.to_tensor yields), OR decoded images as uint8
     [B,H,W,3] CUDA (the /255 + HWC->CHW of to_tensor is then fused into the stem, bit-identically);
-    convs: the 20 conv weights in torchvision state_dict order.
+    convs: the 20 conv weights in torchvision state_dict order.  ``bn_norms``: the 20 eval-mode
+    BatchNorm2d modules of a `--norm_layer batch` trunk (dsmil_resnet18bn_forward); None = InstanceNorm.
     Returns (feats [B,512], classes [B,C] or None)."""
     u8 = x.dtype == torch.uint8
     if u8:
@@ -338,6 +368,16 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None):
     if nbytes == 0:
         raise ValueError(f"unsupported patch size {H}x{W}")
     ws = _workspace(dev, nbytes)
+    if bn_norms is not None:
+        bn_m, bn_r = _folded_bn(bn_norms, dev)
+        if bn_m.numel() != L.dsmil_resnet18_norm_channels():
+            raise ValueError("BatchNorm channel counts do not match ResNet-18")
+        with torch.cuda.device(dev):
+            rc = L.dsmil_resnet18bn_forward(_ptr(x), 1 if u8 else 0, B, H, W, _ptr(conv1), _ptr(packed), _ptr(bn_m),
+                                            _ptr(bn_r), _ptr(fc_w), _ptr(fc_b), C, _ptr(feats), _ptr(classes),
+                                            _ptr(ws), ws.numel(), _stream(dev))
+        _native.check(rc, "dsmil_resnet18bn_forward")
+        return feats, classes
     fn = L.dsmil_resnet18in_forward_u8 if u8 else L.dsmil_resnet18in_forward
     with torch.cuda.device(dev):
         rc = fn(_ptr(x), B, H, W, _ptr(conv1), _ptr(packed), _ptr(fc_w), _ptr(fc_b),

@@ -6,8 +6,8 @@ tensors onto the model BY POSITION (compute_feats.py:226-231), so the registrati
 conv1, bn1, layer1..4 (block: conv1, bn1, conv2, bn2, downsample.0, downsample.1), fc is part
 of the contract.  torchvision is not installed in this image, so the entry points import this
 module instead; with InstanceNorm and a CUDA(HIP) input the forward runs in libdsmil_hip.so
-(dsmil_resnet18in_forward), otherwise (CPU tensors, BatchNorm, ResNet-34, autograd) it runs the
-plain torch ops of the same graph.
+(dsmil_resnet18in_forward; eval-mode BatchNorm: dsmil_resnet18bn_forward), otherwise (CPU tensors,
+training-mode BatchNorm, ResNet-34, autograd) it runs the plain torch ops of the same graph.
 """
 import torch
 import torch.nn as nn
@@ -76,24 +76,30 @@ class ResNet(nn.Module):
         return torch.flatten(self.avgpool(x), 1)
 
     # ---- native path ----------------------------------------------------------------------
-    def _native_ok(self, x):
+    def _native_trunk(self, x):
+        """(convs, bn_norms or None) when this forward can run in libdsmil_hip.so, else None."""
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3):
-            return False
+            return None
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return False  # embedder training (SimCLR) is outside the hot path
-        return resnet18_in_convs(self) is not None
+            return None  # embedder training (SimCLR) is outside the hot path
+        convs = resnet18_in_convs(self)
+        if convs is not None:
+            return convs, None
+        return resnet18_bn_parts(self)   # eval-mode BatchNorm (`--norm_layer batch`)
 
     def forward_with_head(self, x, fc_w, fc_b):
         """(feats, Linear(feats)) in one native call sequence — what IClassifier.forward needs."""
-        if self._native_ok(x) and isinstance(self.fc, nn.Identity):
-            return ops.resnet18in_forward(x, resnet18_in_convs(self), fc_w, fc_b)
+        trunk = self._native_trunk(x)
+        if trunk is not None and isinstance(self.fc, nn.Identity):
+            return ops.resnet18in_forward(x, trunk[0], fc_w, fc_b, bn_norms=trunk[1])
         feats = self.forward(x)
         feats = feats.view(feats.shape[0], -1)
         return feats, torch.nn.functional.linear(feats, fc_w, fc_b)
 
     def forward(self, x):
-        if self._native_ok(x):
-            feats, _ = ops.resnet18in_forward(x, resnet18_in_convs(self))
+        trunk = self._native_trunk(x)
+        if trunk is not None:
+            feats, _ = ops.resnet18in_forward(x, trunk[0], bn_norms=trunk[1])
         else:
             feats = self._features_torch(x)
         return self.fc(feats)
@@ -103,9 +109,8 @@ def _is_plain_instance_norm(m):
     return isinstance(m, nn.InstanceNorm2d) and not m.affine and not m.track_running_stats and abs(m.eps - 1e-5) < 1e-12
 
 
-def resnet18_in_convs(model):
-    """If ``model`` is structurally a ResNet-18 with plain InstanceNorm2d everywhere (ours or
-    torchvision's), return its 20 conv weights in state_dict order; else None."""
+def _resnet18_parts(model):
+    """(convs, norms) of a structurally ResNet-18 module (ours or torchvision's), else None."""
     try:
         convs = [model.conv1.weight]
         norms = [model.bn1]
@@ -123,11 +128,31 @@ def resnet18_in_convs(model):
                     norms.append(blk.downsample[1])
     except AttributeError:
         return None
-    if len(convs) != 20 or not all(_is_plain_instance_norm(n) for n in norms):
+    if len(convs) != 20 or any(tuple(w.shape) != s for w, s in zip(convs, ops.RESNET18_SHAPES)):
         return None
-    if any(tuple(w.shape) != s for w, s in zip(convs, ops.RESNET18_SHAPES)):
+    return convs, norms
+
+
+def resnet18_in_convs(model):
+    """If ``model`` is structurally a ResNet-18 with plain InstanceNorm2d everywhere (ours or
+    torchvision's), return its 20 conv weights in state_dict order; else None."""
+    parts = _resnet18_parts(model)
+    if parts is None or not all(_is_plain_instance_norm(n) for n in parts[1]):
         return None
-    return convs
+    return parts[0]
+
+
+def resnet18_bn_parts(model):
+    """If ``model`` is structurally a ResNet-18 whose 20 norms are BatchNorm2d with running statistics
+    in EVAL mode (the reference's `--norm_layer batch` extractor under i_classifier.eval(),
+    compute_feats.py:149-154), return (convs, norms); else None."""
+    parts = _resnet18_parts(model)
+    if parts is None:
+        return None
+    for n in parts[1]:
+        if not isinstance(n, nn.BatchNorm2d) or n.training or not n.track_running_stats or n.running_mean is None:
+            return None
+    return parts
 
 
 def resnet18(pretrained=False, weights=None, norm_layer=None, **kwargs):

@@ -192,6 +192,20 @@ int dsmil_resnet18in_forward_u8(const uint8_t* x_nhwc, int32_t B, int32_t H, int
                                 const float* fc_b, int32_t C, float* feats, float* classes, void* ws,
                                 size_t ws_bytes, void* stream);
 
+/* The same trunk with FROZEN-statistics norms — eval-mode nn.BatchNorm2d, i.e. the reference's
+ * `--norm_layer batch` / ImageNet-pretrained extractor (compute_feats.py:149-154, run under
+ * i_classifier.eval()).  Each of the 20 norms is y = (x - m[c]) * r[c] with
+ *   r = weight / sqrt(running_var + eps),  m = running_mean - bias / r        (r != 0)
+ * folded by the caller; bn_mean / bn_rstd are the 20 per-channel arrays concatenated in conv order
+ * (dsmil_resnet18_norm_channels() = 4800 floats each).  All conv / pool / residual kernels are the
+ * InstanceNorm ones; only the statistics step is replaced.  x is fp32 NCHW, or uint8 NHWC when
+ * x_is_u8_nhwc != 0 (see dsmil_resnet18in_forward_u8). */
+int32_t dsmil_resnet18_norm_channels(void);
+int dsmil_resnet18bn_forward(const void* x, int32_t x_is_u8_nhwc, int32_t B, int32_t H, int32_t W,
+                             const float* conv1_w, const float* packed, const float* bn_mean,
+                             const float* bn_rstd, const float* fc_w, const float* fc_b, int32_t C,
+                             float* feats, float* classes, void* ws, size_t ws_bytes, void* stream);
+
 const char* dsmil_strerror(int code);
 int dsmil_abi_version(void);
 /* Rows per workgroup the launcher picks for the dominant kernel (k_query_attend). */

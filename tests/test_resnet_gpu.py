@@ -104,3 +104,52 @@ def test_uint8_nhwc_ingest_is_bit_identical_to_fp32_entry(B, H, W):
     assert torch.equal(f8, f) and torch.equal(c8, c)
     np.testing.assert_allclose(f8.cpu().numpy(), ref_f, atol=1e-4, rtol=1e-4)
     np.testing.assert_allclose(c8.cpu().numpy(), ref_c, atol=1e-4, rtol=1e-4)
+
+
+def _build_bn(seed, C=2):
+    """`--norm_layer batch` extractor (compute_feats.py:149-154) with non-trivial frozen statistics and
+    affine parameters, including negative weights (max-pool then needs the window MIN)."""
+    res = resnet18(pretrained=False, norm_layer=nn.BatchNorm2d)
+    res.fc = nn.Identity()
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in res.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.2)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 1.5 + 0.25)
+                w = torch.rand(m.weight.shape, generator=g) * 0.8 + 0.6
+                sign = torch.where(torch.rand(m.weight.shape, generator=g) < 0.15, -1.0, 1.0)
+                m.weight.copy_(w * sign)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+    ic = dsmil.IClassifier(res, 512, output_class=C)
+    with torch.no_grad():
+        ic.fc.weight.copy_(torch.randn(ic.fc.weight.shape, generator=g) * 0.1)
+        ic.fc.bias.copy_(torch.randn(ic.fc.bias.shape, generator=g) * 0.1)
+    return ic.eval()
+
+
+@pytest.mark.parametrize("B,H,W,u8", [(3, 224, 224, False), (2, 96, 160, False), (2, 224, 224, True)])
+def test_frozen_batchnorm_trunk_vs_torch_fp64(B, H, W, u8):
+    """dsmil_resnet18bn_forward (eval-mode BatchNorm folded into the InstanceNorm kernels' (x-m)*r step)
+    against the same torch module evaluated on the CPU in fp64.  Tolerance 1e-4 abs + 1e-4 rel."""
+    import copy
+    ic = _build_bn(seed=17)
+    g = torch.Generator().manual_seed(5 + B)
+    if u8:
+        img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+        x = img.permute(0, 3, 1, 2).to(torch.float32).div(255).contiguous()
+    else:
+        x = torch.from_numpy(make_patches(9 + B, B, H, W))
+        img = None
+    ref = copy.deepcopy(ic).double()
+    with torch.no_grad():
+        rf, rc = ref(x.double())
+    icg = ic.cuda()
+    with torch.no_grad():
+        f, c = icg(img.cuda() if u8 else x.cuda())
+    np.testing.assert_allclose(f.cpu().numpy(), rf.numpy(), atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(c.cpu().numpy(), rc.numpy(), atol=1e-4, rtol=1e-4)
+    # training-mode BatchNorm is NOT the frozen-statistics trunk: it must take the torch graph
+    from dsmil_wsi_amd.modules import resnet_convs_of
+    icg.feature_extractor.train()
+    assert resnet_convs_of(icg.feature_extractor) is None

@@ -82,3 +82,40 @@ def test_structural_detection_rejects_other_norms():
     assert resnet18_in_convs(resnet18(norm_layer=nn.BatchNorm2d)) is None
     assert resnet18_in_convs(resnet18(norm_layer=nn.InstanceNorm2d)) is not None
     assert resnet18_in_convs(nn.Linear(3, 3)) is None
+
+
+def test_frozen_batchnorm_detection_and_fold():
+    """Eval-mode BatchNorm trunks are recognised (train-mode ones are not) and the (x - m) * r fold that
+    dsmil_resnet18bn_forward consumes reproduces nn.BatchNorm2d.eval()."""
+    from dsmil_wsi_amd import ops
+    from dsmil_wsi_amd.modules import resnet_convs_of
+    from dsmil_wsi_amd.resnet import resnet18_bn_parts
+    res = resnet18(norm_layer=nn.BatchNorm2d)
+    res.fc = nn.Identity()
+    assert resnet18_bn_parts(res) is None and resnet_convs_of(res) is None     # training mode
+    res.eval()
+    convs, norms = resnet_convs_of(res)
+    assert len(convs) == 20 and len(norms) == 20 and resnet18_in_convs(res) is None
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for n in norms:
+            n.running_mean.normal_(0, 0.3, generator=g)
+            n.running_var.uniform_(0.2, 2.0, generator=g)
+            n.weight.uniform_(-1.5, 1.5, generator=g)
+            n.weight[n.weight.abs() < 0.05] = 0.5
+            n.bias.normal_(0, 0.3, generator=g)
+    m, r = ops._folded_bn(norms, torch.device("cpu"))
+    assert m.numel() == r.numel() == sum(n.num_features for n in norms) == 4800
+    o = 0
+    for n in norms:
+        C = n.num_features
+        x = torch.randn(2, C, 3, 3, generator=g)
+        with torch.no_grad():
+            ref = n(x)
+        got = (x - m[o:o + C].view(1, C, 1, 1)) * r[o:o + C].view(1, C, 1, 1)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
+        o += C
+    with torch.no_grad():
+        norms[3].weight[7] = 0.0
+    with pytest.raises(NotImplementedError):
+        ops._folded_bn(norms, torch.device("cpu"))
