@@ -919,14 +919,35 @@ __global__ void k_pack_conv(const float* __restrict__ w, float* __restrict__ out
 
 // ---- host ----------------------------------------------------------------------------------
 struct ConvSpec { int cout, cin, ks, stride, pad; };
-// torchvision state_dict order of the 20 bias-free convolutions
-const ConvSpec kSpecs[20] = {
-    {64, 3, 7, 2, 3},
-    {64, 64, 3, 1, 1}, {64, 64, 3, 1, 1}, {64, 64, 3, 1, 1}, {64, 64, 3, 1, 1},
-    {128, 64, 3, 2, 1}, {128, 128, 3, 1, 1}, {128, 64, 1, 2, 0}, {128, 128, 3, 1, 1}, {128, 128, 3, 1, 1},
-    {256, 128, 3, 2, 1}, {256, 256, 3, 1, 1}, {256, 128, 1, 2, 0}, {256, 256, 3, 1, 1}, {256, 256, 3, 1, 1},
-    {512, 256, 3, 2, 1}, {512, 512, 3, 1, 1}, {512, 256, 1, 2, 0}, {512, 512, 3, 1, 1}, {512, 512, 3, 1, 1},
-};
+// torchvision state_dict order of the bias-free convolutions of a BasicBlock ResNet:
+// stem, then per block conv1, conv2 and — first block of layers 2..4 — downsample.0.
+// depth 18 = blocks [2,2,2,2] (20 convs), depth 34 = [3,4,6,3] (36 convs).
+struct Arch { int depth, nblk[4], nconv; ConvSpec specs[40]; };
+Arch make_arch(int depth) {
+    Arch a;
+    a.depth = depth;
+    const int n18[4] = {2, 2, 2, 2}, n34[4] = {3, 4, 6, 3};
+    for (int l = 0; l < 4; ++l) a.nblk[l] = depth == 34 ? n34[l] : n18[l];
+    int n = 0;
+    a.specs[n++] = ConvSpec{64, 3, 7, 2, 3};
+    int cin = 64;
+    for (int l = 0; l < 4; ++l) {
+        const int c = 64 << l;
+        for (int b = 0; b < a.nblk[l]; ++b) {
+            const bool down = l > 0 && b == 0;
+            a.specs[n++] = ConvSpec{c, cin, 3, down ? 2 : 1, 1};
+            a.specs[n++] = ConvSpec{c, c, 3, 1, 1};
+            if (down) a.specs[n++] = ConvSpec{c, cin, 1, 2, 0};
+            cin = c;
+        }
+    }
+    a.nconv = n;
+    return a;
+}
+const Arch* arch_of(int depth) {
+    static const Arch a18 = make_arch(18), a34 = make_arch(34);
+    return depth == 18 ? &a18 : depth == 34 ? &a34 : nullptr;
+}
 
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline bool use_wino(const ConvSpec& s) {  // 3x3 stride-1 convs run as Winograd F(2x2,3x3)
@@ -934,13 +955,19 @@ inline bool use_wino(const ConvSpec& s) {  // 3x3 stride-1 convs run as Winograd
     return !off && s.ks == 3 && s.stride == 1 && s.pad == 1 && s.cin % WK == 0 && s.cout % 64 == 0;
 }
 // floats of conv i in the packed buffer: 16 transform positions for Winograd convs, ks*ks taps otherwise
-inline long long wsize(int i) {
-    const ConvSpec& s = kSpecs[i];
+inline long long wsize(const Arch& A, int i) {
+    const ConvSpec& s = A.specs[i];
     return (long long)s.cout * s.cin * (use_wino(s) ? 16 : s.ks * s.ks);
 }
-inline size_t pack_offset(int i) {  // floats; conv 0 (stem) is used unpacked
+inline size_t pack_offset(const Arch& A, int i) {  // floats; conv 0 (stem) is used unpacked
     size_t o = 0;
-    for (int j = 1; j < i; ++j) o += (size_t)wsize(j);
+    for (int j = 1; j < i; ++j) o += (size_t)wsize(A, j);
+    return o;
+}
+// offset of conv i's norm in the concatenated per-channel arrays of the frozen-statistics variant
+inline int norm_offset(const Arch& A, int i) {
+    int o = 0;
+    for (int j = 0; j < i; ++j) o += A.specs[j].cout;
     return o;
 }
 inline int outdim(int x, int ks, int s, int p) { return (x + 2 * p - ks) / s + 1; }
@@ -1117,29 +1144,41 @@ void set_conv_attrs() {
 
 extern "C" {
 
-size_t dsmil_resnet18_packed_bytes(void) { return pack_offset(20) * sizeof(float); }
+int32_t dsmil_resnet_num_convs(int32_t depth) { const Arch* A = arch_of(depth); return A ? A->nconv : 0; }
+int32_t dsmil_resnet_norm_channels(int32_t depth) { const Arch* A = arch_of(depth); return A ? norm_offset(*A, A->nconv) : 0; }
+size_t dsmil_resnet_packed_bytes(int32_t depth) {
+    const Arch* A = arch_of(depth);
+    return A ? pack_offset(*A, A->nconv) * sizeof(float) : 0;
+}
 
-int dsmil_resnet18_pack(const float* const* conv_w, float* packed, void* stream) {
+int dsmil_resnet_pack(int32_t depth, const float* const* conv_w, float* packed, void* stream) {
+    const Arch* A = arch_of(depth);
+    if (!A) return DSMIL_E_UNSUPPORTED;
     if (!conv_w || !packed) return DSMIL_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    for (int i = 1; i < 20; ++i) {
+    for (int i = 1; i < A->nconv; ++i) {
         if (!conv_w[i]) return DSMIL_E_INVALID;
-        const ConvSpec& s = kSpecs[i];
+        const ConvSpec& s = A->specs[i];
         if (use_wino(s)) {
             long long blocks = ((long long)s.cout * s.cin + 255) / 256;
             if (blocks > 4096) blocks = 4096;
             hipLaunchKernelGGL(k_pack_wino, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
-                               packed + pack_offset(i), s.cout, s.cin);
+                               packed + pack_offset(*A, i), s.cout, s.cin);
         } else {
-            const long long total = wsize(i);
+            const long long total = wsize(*A, i);
             long long blocks = (total + 255) / 256;
             if (blocks > 4096) blocks = 4096;
             hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
-                               packed + pack_offset(i), s.cout, s.cin, s.ks * s.ks);
+                               packed + pack_offset(*A, i), s.cout, s.cin, s.ks * s.ks);
         }
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
     return DSMIL_OK;
+}
+
+size_t dsmil_resnet18_packed_bytes(void) { return dsmil_resnet_packed_bytes(18); }
+int dsmil_resnet18_pack(const float* const* conv_w, float* packed, void* stream) {
+    return dsmil_resnet_pack(18, conv_w, packed, stream);
 }
 
 size_t dsmil_resnet18_workspace_bytes(int32_t B, int32_t H, int32_t W) {
@@ -1147,19 +1186,15 @@ size_t dsmil_resnet18_workspace_bytes(int32_t B, int32_t H, int32_t W) {
     return rws_layout(B, H, W).total;
 }
 
-// offset of conv i's norm in the concatenated per-channel arrays of the frozen-statistics variant
-static int norm_offset(int i) {
-    int o = 0;
-    for (int j = 0; j < i; ++j) o += kSpecs[j].cout;
-    return o;
-}
-
 static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32_t H, int32_t W, const float* conv1_w,
                                    const float* packed, const float* fc_w, const float* fc_b, int32_t C,
                                    float* feats, float* classes, void* ws, size_t ws_bytes, void* stream,
-                                   const float* bn_m = nullptr, const float* bn_r = nullptr) {
-    auto bm = [&](int i) { return bn_m ? bn_m + norm_offset(i) : nullptr; };
-    auto br = [&](int i) { return bn_r ? bn_r + norm_offset(i) : nullptr; };
+                                   const float* bn_m = nullptr, const float* bn_r = nullptr, int depth = 18) {
+    const Arch* Ap = arch_of(depth);
+    if (!Ap) return DSMIL_E_UNSUPPORTED;
+    const Arch& A = *Ap;
+    auto bm = [&](int i) { return bn_m ? bn_m + norm_offset(A, i) : nullptr; };
+    auto br = [&](int i) { return bn_r ? bn_r + norm_offset(A, i) : nullptr; };
     if (!x_nchw || !conv1_w || !packed || !feats || !ws) return DSMIL_E_INVALID;
     if (B <= 0 || H < 32 || W < 32) return DSMIL_E_INVALID;
     if (classes && (!fc_w || !fc_b || C <= 0)) return DSMIL_E_INVALID;
@@ -1197,31 +1232,32 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
                            buf[0], B, d.H1, d.W1, d.Hp, d.Wp, 64);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
-    // ---- layers 1..4, two BasicBlocks each.  cur = block input (materialised, normalised)
+    // ---- layers 1..4, nblk[l] BasicBlocks each.  cur = block input (materialised, normalised)
     float* cur = buf[0];
     float* y1 = buf[1];
     float* y2 = buf[2];
     float* yd = buf[3];
     float* nxt = buf[4];
-    int ci = 1;  // index into kSpecs / packed weights
+    int ci = 1;  // index into A.specs / packed weights
     int Hc = d.Hp, Wc = d.Wp;
     for (int l = 1; l <= 4; ++l) {
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < A.nblk[l - 1]; ++b) {
             const bool down = (l > 1 && b == 0);
-            const ConvSpec& sa = kSpecs[ci];
-            const ConvSpec& sb = kSpecs[ci + 1];
+            const bool last = (l == 4 && b == A.nblk[3] - 1);
+            const ConvSpec& sa = A.specs[ci];
+            const ConvSpec& sb = A.specs[ci + 1];
             const int Ho = outdim(Hc, sa.ks, sa.stride, sa.pad), Wo = outdim(Wc, sa.ks, sa.stride, sa.pad);
-            int rc = run_conv(st, cur, packed + pack_offset(ci), nullptr, nullptr, y1, part, mean[1], rstd[1], B, Hc, Wc, sa, bm(ci), br(ci));
+            int rc = run_conv(st, cur, packed + pack_offset(A, ci), nullptr, nullptr, y1, part, mean[1], rstd[1], B, Hc, Wc, sa, bm(ci), br(ci));
             if (rc) return rc;
-            rc = run_conv(st, y1, packed + pack_offset(ci + 1), mean[1], rstd[1], y2, part, mean[2], rstd[2], B, Ho, Wo, sb, bm(ci + 1), br(ci + 1));
+            rc = run_conv(st, y1, packed + pack_offset(A, ci + 1), mean[1], rstd[1], y2, part, mean[2], rstd[2], B, Ho, Wo, sb, bm(ci + 1), br(ci + 1));
             if (rc) return rc;
             if (down) {
-                rc = run_conv(st, cur, packed + pack_offset(ci + 2), nullptr, nullptr, yd, part, mean[3], rstd[3], B, Hc, Wc, kSpecs[ci + 2], bm(ci + 2), br(ci + 2));
+                rc = run_conv(st, cur, packed + pack_offset(A, ci + 2), nullptr, nullptr, yd, part, mean[3], rstd[3], B, Hc, Wc, A.specs[ci + 2], bm(ci + 2), br(ci + 2));
                 if (rc) return rc;
             }
             const long long npix = (long long)B * Ho * Wo;
             const int Cc = sa.cout;
-            if (l == 4 && b == 1) {
+            if (last) {
                 hipLaunchKernelGGL(k_norm_add_relu_pool, dim3((unsigned)((B * Cc + 255) / 256)), dim3(256), 0, st, y2,
                                    mean[2], rstd[2], cur, feats, B, Ho * Wo, Cc);
             } else {
@@ -1254,7 +1290,16 @@ int dsmil_resnet18in_forward_u8(const uint8_t* x_nhwc, int32_t B, int32_t H, int
                                    ws_bytes, stream);
 }
 
-int32_t dsmil_resnet18_norm_channels(void) { return norm_offset(20); }
+int32_t dsmil_resnet18_norm_channels(void) { return dsmil_resnet_norm_channels(18); }
+
+int dsmil_resnet_forward(int32_t depth, const void* x, int32_t x_is_u8_nhwc, int32_t B, int32_t H, int32_t W,
+                         const float* conv1_w, const float* packed, const float* bn_mean, const float* bn_rstd,
+                         const float* fc_w, const float* fc_b, int32_t C, float* feats, float* classes, void* ws,
+                         size_t ws_bytes, void* stream) {
+    if ((bn_mean == nullptr) != (bn_rstd == nullptr)) return DSMIL_E_INVALID;
+    return resnet18in_forward_impl(x, x_is_u8_nhwc != 0, B, H, W, conv1_w, packed, fc_w, fc_b, C, feats, classes, ws,
+                                   ws_bytes, stream, bn_mean, bn_rstd, depth);
+}
 
 int dsmil_resnet18bn_forward(const void* x, int32_t x_is_u8_nhwc, int32_t B, int32_t H, int32_t W,
                              const float* conv1_w, const float* packed, const float* bn_mean,

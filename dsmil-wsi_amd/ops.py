@@ -277,37 +277,59 @@ def agg_backward(feats, w, A, B, idx, g_pred, g_classes=None, g_A=None, g_B=None
 _pack_cache = {}
 
 
-def _packed_resnet_weights(convs):
-    """Device buffer with the 19 non-stem conv weights re-laid-out as [tap][Cout][Cin]
-    (dsmil_resnet18_pack).  Cached per weight set; rebuilt when any tensor was modified in place
-    (``_version``), re-assigned or moved (``data_ptr``)."""
-    key = tuple((w.data_ptr(), w._version) for w in convs)
+def resnet_conv_shapes(depth):
+    """Shapes of the bias-free convs of a BasicBlock ResNet in torchvision state_dict order (mirror of
+    make_arch in csrc/resnet_fwd.hip): depth 18 -> 20 tensors, 34 -> 36."""
+    nblk = {18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}[depth]
+    shapes = [(64, 3, 7, 7)]
+    cin = 64
+    for l, n in enumerate(nblk):
+        c = 64 << l
+        for b in range(n):
+            shapes += [(c, cin, 3, 3), (c, c, 3, 3)]
+            if l > 0 and b == 0:
+                shapes.append((c, cin, 1, 1))
+            cin = c
+    return shapes
+
+
+RESNET18_SHAPES = resnet_conv_shapes(18)
+
+
+def resnet_depth_of(convs):
+    """18 / 34 when the conv list has exactly that architecture's shapes and order, else None."""
+    for depth in (18, 34):
+        sh = resnet_conv_shapes(depth)
+        if len(convs) == len(sh) and all(tuple(w.shape) == t for w, t in zip(convs, sh)):
+            return depth
+    return None
+
+
+def _packed_resnet_weights(convs, depth=18):
+    """Device buffer with the non-stem conv weights re-laid-out for the kernels (dsmil_resnet_pack:
+    Winograd-transformed or [tap][Cout][Cin]).  Cached per weight set; rebuilt when any tensor was
+    modified in place (``_version``), re-assigned or moved (``data_ptr``)."""
+    key = (depth,) + tuple((w.data_ptr(), w._version) for w in convs)
     dev = convs[0].device
     ent = _pack_cache.get(str(dev))
     if ent is not None and ent[0] == key:
         return ent[1]
     L = _native.lib()
-    buf = torch.empty(L.dsmil_resnet18_packed_bytes() // 4, dtype=torch.float32, device=dev)
+    buf = torch.empty(L.dsmil_resnet_packed_bytes(depth) // 4, dtype=torch.float32, device=dev)
     keep = [_f32c(w.detach(), "conv weight") for w in convs]
-    arr = (ctypes.c_void_p * 20)(*[t.data_ptr() for t in keep])
+    arr = (ctypes.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
     with torch.cuda.device(dev):
-        rc = L.dsmil_resnet18_pack(arr, _ptr(buf), _stream(dev))
-    _native.check(rc, "dsmil_resnet18_pack")
+        rc = L.dsmil_resnet_pack(depth, arr, _ptr(buf), _stream(dev))
+    _native.check(rc, "dsmil_resnet_pack")
     _pack_cache[str(dev)] = (key, buf)
     return buf
-
-
-RESNET18_SHAPES = [(64, 3, 7, 7)] + [(64, 64, 3, 3)] * 4 + \
-    [(128, 64, 3, 3), (128, 128, 3, 3), (128, 64, 1, 1), (128, 128, 3, 3), (128, 128, 3, 3)] + \
-    [(256, 128, 3, 3), (256, 256, 3, 3), (256, 128, 1, 1), (256, 256, 3, 3), (256, 256, 3, 3)] + \
-    [(512, 256, 3, 3), (512, 512, 3, 3), (512, 256, 1, 1), (512, 512, 3, 3), (512, 512, 3, 3)]
 
 
 _bn_cache = {}
 
 
 def _folded_bn(norms, dev):
-    """Fold 20 eval-mode BatchNorm2d into y = (x - m) * r, concatenated in conv order (cached on the
+    """Fold the trunk's eval-mode BatchNorm2d modules into y = (x - m) * r, concatenated in conv order (cached on the
     parameter / buffer versions)."""
     key = tuple((id(n), n.running_mean._version, n.running_var._version,
                  None if n.weight is None else n.weight._version,
@@ -335,8 +357,9 @@ def _folded_bn(norms, dev):
 def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None):
     """x: [B,3,H,W] fp32 CUDA in [0,1] (what VF.to_tensor yields), OR decoded images as uint8
     [B,H,W,3] CUDA (the /255 + HWC->CHW of to_tensor is then fused into the stem, bit-identically);
-    convs: the 20 conv weights in torchvision state_dict order.  ``bn_norms``: the 20 eval-mode
-    BatchNorm2d modules of a `--norm_layer batch` trunk (dsmil_resnet18bn_forward); None = InstanceNorm.
+    convs: the trunk's conv weights in torchvision state_dict order (20 for ResNet-18, 36 for ResNet-34).
+    ``bn_norms``: the eval-mode BatchNorm2d modules of a `--norm_layer batch` trunk, in the same order;
+    None = InstanceNorm.  One native launch sequence (dsmil_resnet_forward).
     Returns (feats [B,512], classes [B,C] or None)."""
     u8 = x.dtype == torch.uint8
     if u8:
@@ -351,8 +374,9 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None):
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f"expected [B,3,H,W] patches, got {tuple(x.shape)}")
         B, _, H, W = x.shape
-    if len(convs) != 20 or any(tuple(w.shape) != s for w, s in zip(convs, RESNET18_SHAPES)):
-        raise ValueError("conv weights do not have the ResNet-18 shapes / order")
+    depth = resnet_depth_of(convs)
+    if depth is None:
+        raise ValueError("conv weights do not have the ResNet-18 / ResNet-34 shapes and order")
     dev = x.device
     feats = torch.empty((B, 512), dtype=torch.float32, device=dev)
     if B == 0:
@@ -361,26 +385,21 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None):
     fc_b = _f32c(fc_b.detach(), "fc_b") if fc_b is not None else None
     C = fc_w.shape[0] if fc_w is not None else 0
     classes = torch.empty((B, C), dtype=torch.float32, device=dev) if fc_w is not None else None
-    packed = _packed_resnet_weights(convs)
+    packed = _packed_resnet_weights(convs, depth)
     conv1 = _f32c(convs[0].detach(), "conv1.weight")
     L = _native.lib()
     nbytes = L.dsmil_resnet18_workspace_bytes(B, H, W)
     if nbytes == 0:
         raise ValueError(f"unsupported patch size {H}x{W}")
     ws = _workspace(dev, nbytes)
+    bn_m = bn_r = None
     if bn_norms is not None:
         bn_m, bn_r = _folded_bn(bn_norms, dev)
-        if bn_m.numel() != L.dsmil_resnet18_norm_channels():
-            raise ValueError("BatchNorm channel counts do not match ResNet-18")
-        with torch.cuda.device(dev):
-            rc = L.dsmil_resnet18bn_forward(_ptr(x), 1 if u8 else 0, B, H, W, _ptr(conv1), _ptr(packed), _ptr(bn_m),
-                                            _ptr(bn_r), _ptr(fc_w), _ptr(fc_b), C, _ptr(feats), _ptr(classes),
-                                            _ptr(ws), ws.numel(), _stream(dev))
-        _native.check(rc, "dsmil_resnet18bn_forward")
-        return feats, classes
-    fn = L.dsmil_resnet18in_forward_u8 if u8 else L.dsmil_resnet18in_forward
+        if bn_m.numel() != L.dsmil_resnet_norm_channels(depth):
+            raise ValueError("BatchNorm channel counts do not match the trunk")
     with torch.cuda.device(dev):
-        rc = fn(_ptr(x), B, H, W, _ptr(conv1), _ptr(packed), _ptr(fc_w), _ptr(fc_b),
-                C, _ptr(feats), _ptr(classes), _ptr(ws), ws.numel(), _stream(dev))
-    _native.check(rc, "dsmil_resnet18in_forward_u8" if u8 else "dsmil_resnet18in_forward")
+        rc = L.dsmil_resnet_forward(depth, _ptr(x), 1 if u8 else 0, B, H, W, _ptr(conv1), _ptr(packed), _ptr(bn_m),
+                                    _ptr(bn_r), _ptr(fc_w), _ptr(fc_b), C, _ptr(feats), _ptr(classes), _ptr(ws),
+                                    ws.numel(), _stream(dev))
+    _native.check(rc, "dsmil_resnet_forward")
     return feats, classes

@@ -110,14 +110,13 @@ def _is_plain_instance_norm(m):
 
 
 def _resnet18_parts(model):
-    """(convs, norms) of a structurally ResNet-18 module (ours or torchvision's), else None."""
+    """(convs, norms) of a structurally BasicBlock ResNet-18 / ResNet-34 module (ours or torchvision's),
+    else None."""
     try:
         convs = [model.conv1.weight]
         norms = [model.bn1]
         for li in (1, 2, 3, 4):
             layer = getattr(model, f"layer{li}")
-            if len(layer) != 2:
-                return None
             for blk in layer:
                 if not hasattr(blk, "conv2") or hasattr(blk, "conv3"):
                     return None
@@ -128,14 +127,14 @@ def _resnet18_parts(model):
                     norms.append(blk.downsample[1])
     except AttributeError:
         return None
-    if len(convs) != 20 or any(tuple(w.shape) != s for w, s in zip(convs, ops.RESNET18_SHAPES)):
+    if ops.resnet_depth_of(convs) is None:
         return None
     return convs, norms
 
 
 def resnet18_in_convs(model):
-    """If ``model`` is structurally a ResNet-18 with plain InstanceNorm2d everywhere (ours or
-    torchvision's), return its 20 conv weights in state_dict order; else None."""
+    """If ``model`` is structurally a ResNet-18 / ResNet-34 with plain InstanceNorm2d everywhere (ours or
+    torchvision's), return its conv weights in state_dict order (20 / 36 tensors); else None."""
     parts = _resnet18_parts(model)
     if parts is None or not all(_is_plain_instance_norm(n) for n in parts[1]):
         return None

@@ -206,6 +206,22 @@ int dsmil_resnet18bn_forward(const void* x, int32_t x_is_u8_nhwc, int32_t B, int
                              const float* bn_rstd, const float* fc_w, const float* fc_b, int32_t C,
                              float* feats, float* classes, void* ws, size_t ws_bytes, void* stream);
 
+/* Generic BasicBlock trunk: depth 18 (blocks [2,2,2,2], 20 convs) or 34 ([3,4,6,3], 36 convs) — the
+ * reference's `--backbone resnet18|resnet34` (compute_feats.py:155-160).  conv_w is the trunk's
+ * dsmil_resnet_num_convs(depth) conv tensors in state_dict order; bn_mean / bn_rstd are NULL for
+ * InstanceNorm or the folded frozen-BatchNorm arrays (dsmil_resnet_norm_channels(depth) floats, see
+ * dsmil_resnet18bn_forward); x is fp32 NCHW or uint8 NHWC.  Workspace as dsmil_resnet18_workspace_bytes
+ * (the activation shapes do not depend on the depth).  The *18* entry points above are these with
+ * depth = 18.  feats is [B,512] for both depths. */
+int32_t dsmil_resnet_num_convs(int32_t depth);
+int32_t dsmil_resnet_norm_channels(int32_t depth);
+size_t dsmil_resnet_packed_bytes(int32_t depth);
+int dsmil_resnet_pack(int32_t depth, const float* const* conv_w, float* packed, void* stream);
+int dsmil_resnet_forward(int32_t depth, const void* x, int32_t x_is_u8_nhwc, int32_t B, int32_t H,
+                         int32_t W, const float* conv1_w, const float* packed, const float* bn_mean,
+                         const float* bn_rstd, const float* fc_w, const float* fc_b, int32_t C,
+                         float* feats, float* classes, void* ws, size_t ws_bytes, void* stream);
+
 const char* dsmil_strerror(int code);
 int dsmil_abi_version(void);
 /* Rows per workgroup the launcher picks for the dominant kernel (k_query_attend). */

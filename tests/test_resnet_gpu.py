@@ -153,3 +153,38 @@ def test_frozen_batchnorm_trunk_vs_torch_fp64(B, H, W, u8):
     from dsmil_wsi_amd.modules import resnet_convs_of
     icg.feature_extractor.train()
     assert resnet_convs_of(icg.feature_extractor) is None
+
+
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+def test_resnet34_trunk_vs_torch_fp64(norm):
+    """`--backbone resnet34` (compute_feats.py:158-160): the same kernels over blocks [3,4,6,3]
+    (dsmil_resnet_forward, depth 34) against the torch module on the CPU in fp64."""
+    import copy
+    from dsmil_wsi_amd.resnet import resnet34
+    from dsmil_wsi_amd.modules import resnet_convs_of
+    g = torch.Generator().manual_seed(41)
+    res = resnet34(norm_layer=nn.InstanceNorm2d if norm == "instance" else nn.BatchNorm2d)
+    res.fc = nn.Identity()
+    with torch.no_grad():
+        for m in res.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / (m.weight.shape[0] * m.weight.shape[2] ** 2)) ** 0.5)
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.5 + 0.6)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    ic = dsmil.IClassifier(res, 512, output_class=2).eval()
+    for p in ic.parameters():
+        p.requires_grad = False
+    trunk = resnet_convs_of(ic.feature_extractor)
+    assert trunk is not None and len(trunk[0]) == 36
+    x = torch.from_numpy(make_patches(77, 2, 224, 224))
+    with torch.no_grad():
+        rf, rc = copy.deepcopy(ic).double()(x.double())
+    icg = ic.cuda()
+    with torch.no_grad():
+        f, c = icg(x.cuda())
+    assert f.shape == (2, 512)
+    np.testing.assert_allclose(f.cpu().numpy(), rf.numpy(), atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(c.cpu().numpy(), rc.numpy(), atol=1e-4, rtol=1e-4)

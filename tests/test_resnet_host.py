@@ -119,3 +119,22 @@ def test_frozen_batchnorm_detection_and_fold():
         norms[3].weight[7] = 0.0
     with pytest.raises(NotImplementedError):
         ops._folded_bn(norms, torch.device("cpu"))
+
+
+def test_resnet34_is_recognised_with_36_convs():
+    from dsmil_wsi_amd import ops
+    from dsmil_wsi_amd.modules import resnet_convs_of
+    from dsmil_wsi_amd.resnet import resnet34
+    res = resnet34(norm_layer=nn.InstanceNorm2d)
+    res.fc = nn.Identity()
+    convs, norms = resnet_convs_of(res)
+    assert norms is None and len(convs) == 36 and ops.resnet_depth_of(convs) == 34
+    assert [tuple(w.shape) for w in convs] == ops.resnet_conv_shapes(34)
+    assert [k for k in res.state_dict() if "conv" in k or "downsample.0" in k] == \
+        [k for k, v in res.state_dict().items() if v.dim() == 4]
+    import dsmil_wsi_amd._native as nat
+    L = nat.lib()
+    assert L.dsmil_resnet_num_convs(18) == 20 and L.dsmil_resnet_num_convs(34) == 36 and L.dsmil_resnet_num_convs(50) == 0
+    assert L.dsmil_resnet_norm_channels(18) == 4800
+    assert L.dsmil_resnet_packed_bytes(18) == L.dsmil_resnet18_packed_bytes() > 0
+    assert L.dsmil_resnet_packed_bytes(34) > L.dsmil_resnet_packed_bytes(18)
