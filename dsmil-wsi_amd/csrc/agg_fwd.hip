@@ -10,15 +10,21 @@
 //   B    = A^T V,  pred = Conv1d(C,C,K)(B)         bag embedding / bag logits
 //
 // Launch sequence on one stream (no host sync, hipGraph-capturable):
-//   k_logits_argmax   HBM stream over x: c, per-tile (max,idx) partials        (VALU)
+//   k_logits_stream   HBM stream over x: c, per-tile (max,idx) partials (8 lanes per row, full-line
+//                     non-temporal loads; k_logits_argmax is the general form: bf16 rows, K % 4 != 0,
+//                     caller-supplied logits)
 //   k_qmax            per (bag,class): finish argmax, run the query MLP on the critical row
-//   k_query_attend    the dominant kernel: per 32-row wave tile the query MLP runs TRANSPOSED
-//                     on exact-f32 MFMA (v_mfma_f32_32x32x2_f32): H^T = W1 X^T keeps instances
-//                     on the MFMA column axis so the ReLU'd H^T accumulator registers are fed
-//                     straight back as the B operand of Q^T = W2 H^T (no LDS round trip);
-//                     scores, tile-local softmax statistics and the weighted value sum are
-//                     fused behind it.  Q is never written to memory.
-//   k_finish          combine tile partials: A = exp(s-m)/l, B, pred
+//   k_pack_agg_split  cut the query weights into three exact bf16 planes, MFMA-fragment order
+//   k_query_attend_split  the dominant kernel: per 32-row wave tile the query MLP runs TRANSPOSED
+//                     (H^T = W1 X^T keeps instances on the MFMA column axis, so the ReLU'd H^T
+//                     accumulator registers are fed straight back as the B operand of Q^T = W2 H^T:
+//                     no LDS round trip) on bf16 MFMA over exact three-plane cuts of the fp32
+//                     operands (agg_split.h; DSMIL_MLP=f32 selects k_query_attend on
+//                     v_mfma_f32_32x32x2_f32); scores, tile-local softmax statistics and the weighted
+//                     value sum are fused behind it.  Q is never written to memory.
+//   k_finish, k_pred  combine tile partials: A = exp(s-m)/l, B, pred
+// dsmil_agg_shard_* (one bag sharded by instances over several GPUs) run the same kernels in two
+// phases around the caller's exchanges.
 //
 // MFMA fragment maps used (cdna_hip_programming.md §3): 32x32x2 f32: A lane l = A[i=l&31][k=l>>5],
 // B lane l = B[k=l>>5][j=l&31], D lane l reg r = D[(r&3)+8*(r>>2)+4*(l>>5)][l&31].
@@ -918,6 +924,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     if (sh.phase) {  // a lone shard: its {0, N} offsets live in the workspace
         int64_t* off2 = (int64_t*)(w8 + L.off2);
         hipLaunchKernelGGL(k_set_offsets2, dim3(1), dim3(1), 0, st, off2, (long long)total_rows);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         offsets = off2;
     }
     float* part_val = (float*)(w8 + L.part_val);
