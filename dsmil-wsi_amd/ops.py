@@ -82,7 +82,8 @@ _bf16_cache = {}
 def _bf16_params(w, nonlinear, dev):
     """bf16 path: every weight/bias rounded to bf16 (what module.bfloat16() would hold), kept as
     fp32 tensors for the f32-accumulating stages + the packed bf16 MFMA operands.  Cached per
-    parameter set (data_ptr, _version)."""
+    parameter set (data_ptr, _version); the entry keeps the source tensors alive so that a freed
+    parameter's address can never be mistaken for a new one with the same version count."""
     names = ("fc_w", "fc_b", "q0_w", "q0_b", "q2_w", "q2_b", "fcc_w", "fcc_b")
     key = tuple((w[k].data_ptr(), w[k]._version) if w.get(k) is not None else None for k in names)
     ent = _bf16_cache.get(str(dev))
@@ -97,7 +98,7 @@ def _bf16_params(w, nonlinear, dev):
         rc = L.dsmil_agg_pack_bf16(_ptr(r["q0_w"]), _ptr(r["q2_w"] if nonlinear else None), K, _ptr(packed),
                                    _stream(dev))
     _native.check(rc, "dsmil_agg_pack_bf16")
-    _bf16_cache[str(dev)] = (key, r, packed)
+    _bf16_cache[str(dev)] = (key, r, packed, [w.get(k) for k in names])
     return r, packed
 
 
@@ -308,7 +309,8 @@ def resnet_depth_of(convs):
 def _packed_resnet_weights(convs, depth=18):
     """Device buffer with the non-stem conv weights re-laid-out for the kernels (dsmil_resnet_pack:
     Winograd-transformed or [tap][Cout][Cin]).  Cached per weight set; rebuilt when any tensor was
-    modified in place (``_version``), re-assigned or moved (``data_ptr``)."""
+    modified in place (``_version``), re-assigned or moved (``data_ptr``).  The entry keeps the source
+    tensors alive: a freed weight's address cannot come back as a different model's weight."""
     key = (depth,) + tuple((w.data_ptr(), w._version) for w in convs)
     dev = convs[0].device
     ent = _pack_cache.get(str(dev))
@@ -321,7 +323,7 @@ def _packed_resnet_weights(convs, depth=18):
     with torch.cuda.device(dev):
         rc = L.dsmil_resnet_pack(depth, arr, _ptr(buf), _stream(dev))
     _native.check(rc, "dsmil_resnet_pack")
-    _pack_cache[str(dev)] = (key, buf)
+    _pack_cache[str(dev)] = (key, buf, keep)
     return buf
 
 
@@ -350,7 +352,7 @@ def _folded_bn(norms, dev):
         rs.append(r)
     m = torch.cat(ms).to(torch.float32).contiguous()
     r = torch.cat(rs).to(torch.float32).contiguous()
-    _bn_cache["k"] = (key, m, r)
+    _bn_cache["k"] = (key, m, r, list(norms))   # the modules stay alive: their ids stay unique
     return m, r
 
 
