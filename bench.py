@@ -323,7 +323,7 @@ def main():
             line = dict(emb, n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True,
                         scaling="weak", vs_baseline=None, data="synthetic")
             emb = None
-        if not args.no_cpu_baseline and run_agg:
+        if not args.no_cpu_baseline and run_agg and world == 1:   # CPU baselines: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(wnp, N, K, C, args.cpu_seconds)
             if emb is not None:
                 emb["cpu_baseline"] = embedder_cpu_baseline(args.cpu_seconds)
