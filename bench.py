@@ -226,6 +226,7 @@ def main():
     N, K, nb = args.rows, args.feats, args.bags
     C = wnp["fc_w"].shape[0]
     dt, tot_ms, launches = 1.0, ctypes.c_double(0), ctypes.c_int64(0)
+    single_ms = None
     if run_agg:
         w = {k: torch.from_numpy(v).to(dev) for k, v in wnp.items()}
         if K != wnp["fc_w"].shape[1]:
@@ -260,7 +261,6 @@ def main():
             dt = float(t.item())
         # single-bag latency (SURVEY 8d config 2 asks for it beside the batched rate): one
         # MILNet.forward-sized call per iteration, outside the timed region, rank 0's number is reported
-        single_ms = None
         if not args.no_single_bag:
             one = feats[:N]
             for _ in range(5):
