@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--patches", type=int, default=256, help="patches per rank per embedder step")
     ap.add_argument("--workload", default="both", choices=["both", "aggregator", "embedder"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="aggregator leg: f32 (BASELINE configs[1], the headline) or bf16 storage (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-bag", action="store_true",
                     help="skip the single-bag latency probe (profiling runs: keeps per-kernel averages clean)")
@@ -233,6 +235,8 @@ def main():
             raise SystemExit("--feats must match the weight file (512)")
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
         feats = torch.randn((nb * N, K), generator=g, device=dev, dtype=torch.float32)
+        if args.dtype == "bf16":
+            feats = feats.to(torch.bfloat16)
         lengths = [N] * nb
         offsets = ops.offsets_tensor(lengths, dev)
 
@@ -291,13 +295,14 @@ def main():
         achieved = fl / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
         traffic = _pmc("pmc_k_query_attend.json", "hbm_bytes_per_launch") if (nb, N, K) == (64, 10000, 512) else None
         form = int(L.dsmil_agg_mlp_form())
+        bf16 = args.dtype == "bf16"
         line = {
             "metric": "bags/sec aggregated (10kx512)", "value": round(value, 1), "unit": "bags/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"DSMIL aggregator forward (FCLayer+BClassifier), {args.weights} weights C={C}, "
-                                   f"{nb} bags x {N} x {K} fp32 per GPU per step, HBM-resident",
+                                   f"{nb} bags x {N} x {K} {'bf16 storage, f32 accumulate' if bf16 else 'fp32'} per GPU per step, HBM-resident",
                        "bags_per_step_per_gpu": nb, "rows": N, "feats": K, "classes": C,
                        "tile_rows": int(L.dsmil_agg_tile_rows(nb, nb * N)), "parallelism": f"bag-sharded x{world}",
                        "single_bag_forward_ms": round(single_ms, 4) if single_ms is not None else None},
@@ -317,13 +322,25 @@ def main():
                              value / world / (1.0 / max(flops_per_bag(N, K, C) / (PEAK_F32_MFMA_TFLOPS * 1e12),
                                                              bytes_per_bag(N, K, C) / (PEAK_HBM_GBS * 1e9))), 4)},
         }
+        if bf16:
+            # bf16 storage: the MLP runs on bf16 MFMA (0.7 us/bag at 2.5 PF) and the feature stream
+            # (10.5 MB/bag) binds -> HBM roofline for the same dominant kernel
+            by = bytes_per_bag(N, K, C, s=2) * nb
+            gbs = by / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
+            line["roofline"] = {"kernel": "k_query_attend_bf16", "bound": "hbm", "achieved": round(gbs, 1) if gbs else None,
+                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4) if gbs else None,
+                                "traffic": None, "kernel_ms": round(kern_ms, 4), "launches": int(launches.value),
+                                "alg_bytes_per_launch": by,
+                                "whole_path_frac_of_roofline": round(
+                                    value / world / (1.0 / max(flops_per_bag(N, K, C) / (PEAK_BF16_MFMA_TFLOPS * 1e12),
+                                                                    bytes_per_bag(N, K, C, s=2) / (PEAK_HBM_GBS * 1e9))), 4)}
         if emb is not None:
             line["embedder"] = emb
         if not run_agg:   # embedder-only run (profiling): promote the embedder leg to the top level
             line = dict(emb, n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True,
                         scaling="weak", vs_baseline=None, data="synthetic")
             emb = None
-        if not args.no_cpu_baseline and run_agg and world == 1:   # CPU baselines: rank 0 at N = 1 only
+        if not args.no_cpu_baseline and run_agg and world == 1 and not bf16:   # CPU baselines: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(wnp, N, K, C, args.cpu_seconds)
             if emb is not None:
                 emb["cpu_baseline"] = embedder_cpu_baseline(args.cpu_seconds)

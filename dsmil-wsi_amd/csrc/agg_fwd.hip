@@ -165,15 +165,35 @@ __global__ __launch_bounds__(256) void k_logits_argmax(
 // only after it has all gone by).  The lane reduction is 3 xor-shuffles per 8 rows.
 // Same tile geometry and partial layout as k_logits_argmax (R0 rows per workgroup).
 // --------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x4 load4_stream(const float* p) {
-    return __builtin_nontemporal_load((const DSMIL_GLOBAL f32x4*)p);
-}
+// 16 bytes of a feature row, non-temporal, as EPL = 16 / sizeof(T) floats (4 fp32 or 8 bf16)
+template <typename T>
+struct StreamVec;
+template <>
+struct StreamVec<float> {
+    static constexpr int EPL = 4;
+    f32x4 v;
+    __device__ __forceinline__ void load(const float* p) { v = __builtin_nontemporal_load((const DSMIL_GLOBAL f32x4*)p); }
+    __device__ __forceinline__ float at(int e) const { return v[e]; }
+};
+template <>
+struct StreamVec<bf16_t> {
+    static constexpr int EPL = 8;
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = __builtin_nontemporal_load((const DSMIL_GLOBAL u32x4_t*)p); }
+    __device__ __forceinline__ float at(int e) const {
+        const unsigned w = v[e >> 1];
+        return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+    }
+};
 
-template <int CP>  // classes per pass: 1 or 2
+template <int CP, typename T>  // classes per pass: 1 or 2; T = float or bf16 feature rows
 __global__ __launch_bounds__(256) void k_logits_stream(
-    const float* __restrict__ feats, const int64_t* __restrict__ offsets,
+    const T* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ fc_w, const float* __restrict__ fc_b, float* __restrict__ classes_out,
     float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C, int bag0) {
+    constexpr int EPL = StreamVec<T>::EPL;   // elements per lane per 128-B segment
+    constexpr int SEG = 8 * EPL;             // elements per segment (32 fp32 / 64 bf16)
     extern __shared__ __attribute__((aligned(16))) float s_w[];  // [CP][Kpad]: weights, zero past K, plus one zero segment
     __shared__ float s_v[8];
     __shared__ long long s_i[8];
@@ -185,7 +205,7 @@ __global__ __launch_bounds__(256) void k_logits_stream(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 7, rr = lane >> 3;
     const long long slot = off0 / R0 + bag + tile;
-    const int nseg = (K + 31) / 32, Kpad = (nseg + 1) * 32;
+    const int nseg = (K + SEG - 1) / SEG, Kpad = (nseg + 1) * SEG;
 
     for (int c0 = 0; c0 < C; c0 += CP) {
         const int c1 = (CP == 2 && c0 + 1 < C) ? c0 + 1 : c0;
@@ -202,26 +222,29 @@ __global__ __launch_bounds__(256) void k_logits_stream(
             const long long rbase = row0 + wave * 32 + g * 8;
             if (rbase >= Nb) break;  // wave-uniform
             const long long r = (rbase + rr < Nb) ? rbase + rr : Nb - 1;
-            const float* x = feats + (off0 + r) * (long long)K;
+            const T* x = feats + (off0 + r) * (long long)K;
             float a0 = 0.f, a1 = 0.f;
             for (int s0 = 0; s0 < nseg; s0 += 8) {
-                f32x4 v[8];
+                StreamVec<T> v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    int k = (s0 + u) * 32 + j * 4;
-                    k = k < K ? k : K - 4;  // clamped re-read; its weight is zero
-                    v[u] = load4_stream(x + k);
+                    int k = (s0 + u) * SEG + j * EPL;
+                    k = k < K ? k : K - EPL;  // clamped re-read; its weight is zero
+                    v[u].load(x + k);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int ks = (s0 + u < nseg ? s0 + u : nseg) * 32 + j * 4;  // segment nseg is all zero
-                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_w + ks);
+                    const int ks = (s0 + u < nseg ? s0 + u : nseg) * SEG + j * EPL;  // segment nseg is all zero
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a0 = fmaf(v[u][e], w0[e], a0);
-                    if constexpr (CP == 2) {
-                        const f32x4 w1 = *reinterpret_cast<const f32x4*>(s_w + Kpad + ks);
+                    for (int q = 0; q < EPL / 4; ++q) {
+                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_w + ks + 4 * q);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) a1 = fmaf(v[u][e], w1[e], a1);
+                        for (int e = 0; e < 4; ++e) a0 = fmaf(v[u].at(4 * q + e), w0[e], a0);
+                        if constexpr (CP == 2) {
+                            const f32x4 w1 = *reinterpret_cast<const f32x4*>(s_w + Kpad + ks + 4 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a1 = fmaf(v[u].at(4 * q + e), w1[e], a1);
+                        }
                     }
                 }
             }
@@ -953,12 +976,17 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         dim3 grid((unsigned)((max_rows + R0 - 1) / R0), (unsigned)nb);
         if (sh.phase == 2) {}  // the caller already knows the bag-wide critical rows
         else if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
+        else if (bf16 && (K % 8 == 0) && !getenv("DSMIL_LOGITS_OLD")) {
+            const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 63) / 64 + 1) * 64) * sizeof(float);
+            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, bf16_t>), grid, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
+            else hipLaunchKernelGGL((k_logits_stream<1, bf16_t>), grid, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
+        }
         else if (bf16 && w4) hipLaunchKernelGGL((k_logits_argmax<4, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
         else if (bf16) hipLaunchKernelGGL((k_logits_argmax<1, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
         else if (v4 && !getenv("DSMIL_LOGITS_OLD")) {
             const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 31) / 32 + 1) * 32) * sizeof(float);
-            if (C >= 2) hipLaunchKernelGGL(k_logits_stream<2>, grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
-            else hipLaunchKernelGGL(k_logits_stream<1>, grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
+            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
+            else hipLaunchKernelGGL((k_logits_stream<1, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
         }
         else if (v4) hipLaunchKernelGGL((k_logits_argmax<4, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
         else hipLaunchKernelGGL((k_logits_argmax<1, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
