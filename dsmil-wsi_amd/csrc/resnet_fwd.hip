@@ -28,6 +28,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include "dsmil_hip.h"
 #include "prof.h"
 
@@ -334,6 +335,87 @@ struct WinoArgs {
     int expt;              // DSMIL_WINO_EXPT ablation knob (0 in production)
 };
 
+// Epilogue shared by the Winograd kernels: inverse transform of this wave's 8 positions, exchange of
+// the partner wave's output row through LDS (smem must be free: call behind a barrier), raw NHWC
+// store and the (cnt, mean, M2) statistics partials.  acc[p][r] = M[position 8wp+p][slot drow(r,hi)][cout].
+__device__ __forceinline__ void wino_epilogue(const WinoArgs& a, const f32x16 (&acc)[8], float* smem, int lane,
+                                              int wn, int wp, int n0, int img0, int ty0, int tx0, int tpi, int pb) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    // ---- inverse transform: partial outputs of this wave's two xi rows
+    //   ra[xi] = m[xi][0]+m[xi][1]+m[xi][2], rb[xi] = m[xi][1]-m[xi][2]-m[xi][3]
+    //   Y[0][.] = r.[0]+r.[1]+r.[2],  Y[1][.] = r.[1]-r.[2]-r.[3]
+    float y00[16], y01[16], y10[16], y11[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float raA = acc[0][r] + acc[1][r] + acc[2][r], rbA = acc[1][r] - acc[2][r] - acc[3][r];  // xi = 2wp
+        const float raB = acc[4][r] + acc[5][r] + acc[6][r], rbB = acc[5][r] - acc[6][r] - acc[7][r];  // xi = 2wp+1
+        if (wp == 0) { y00[r] = raA + raB; y01[r] = rbA + rbB; y10[r] = raB; y11[r] = rbB; }
+        else { y00[r] = raA; y01[r] = rbA; y10[r] = -raA - raB; y11[r] = -rbA - rbB; }
+    }
+    // exchange through LDS (the V buffers are free now): the wp = 0 wave finishes output row 0
+    // (y00, y01), the wp = 1 wave output row 1 (y10, y11); each sends the other row's partials
+    float* xch = smem + ((wn * 2 + wp) * 64 + lane) * 33;        // [2 wn][2 wp][64 lanes][32 (+1 pad)]
+    float* xpr = smem + ((wn * 2 + (wp ^ 1)) * 64 + lane) * 33;  // the partner's slot
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        xch[r] = wp == 0 ? y10[r] : y00[r];
+        xch[16 + r] = wp == 0 ? y11[r] : y01[r];
+    }
+    __syncthreads();
+    float ya[16], yb[16];  // this wave's output row: pixels (oy+wp, ox) and (oy+wp, ox+1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        ya[r] = (wp == 0 ? y00[r] : y10[r]) + xpr[r];
+        yb[r] = (wp == 0 ? y01[r] : y11[r]) + xpr[16 + r];
+    }
+    // ---- raw store + statistics partials
+    const int co = n0 + wn * 32 + l31;
+    unsigned vmask[16];  // 2 validity bits per accumulator row (tile slot)
+    int rimg[16];        // local image of the row's tile slot (or -1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int slot = drow(r, hi);
+        const int il = slot / tpi, rem = slot - il * tpi, tyl = rem / a.TXB, txl = rem - tyl * a.TXB;
+        const int n = img0 + il, ty = ty0 + tyl, tx = tx0 + txl;
+        unsigned vm = 0;
+        rimg[r] = -1;
+        const int oy = 2 * ty + wp, ox = 2 * tx;
+        if (slot < a.IB * tpi && n < a.B && ty < a.TY && tx < a.TX && oy < a.H) {
+            float* o = a.y + ((long long)(n * a.H + oy) * a.W + ox) * a.Cout + co;
+            o[0] = ya[r]; vm = 1u;
+            if (ox + 1 < a.W) { o[a.Cout] = yb[r]; vm |= 2u; }
+            rimg[r] = il;
+        }
+        vmask[r] = vm;
+    }
+    for (int il = 0; il < a.IB; ++il) {
+        const int n = img0 + il;
+        if (n >= a.B) break;
+        float sum = 0.f, cnt = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned vm = (rimg[r] == il) ? vmask[r] : 0u;
+            sum += ((vm & 1u) ? ya[r] : 0.f) + ((vm & 2u) ? yb[r] : 0.f);
+            cnt += (float)__popc(vm);
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        cnt += __shfl_xor(cnt, 32, 64);
+        const float mean = cnt > 0.f ? sum / cnt : 0.f;
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned vm = (rimg[r] == il) ? vmask[r] : 0u;
+            const float d0 = ya[r] - mean, d1 = yb[r] - mean;
+            q += ((vm & 1u) ? d0 * d0 : 0.f) + ((vm & 2u) ? d1 * d1 : 0.f);
+        }
+        q += __shfl_xor(q, 32, 64);
+        if (hi == 0) {
+            float* o = a.part + ((((long long)n * a.PB + pb) * 2 + wp) * a.Cout + co) * 3;
+            o[0] = cnt; o[1] = mean; o[2] = q;
+        }
+    }
+}
+
 template <bool NORM>
 __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -495,77 +577,253 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoArgs a) {
         if (keep == 123.456f) a.y[0] = keep;
         return;
     }
-    // ---- inverse transform: partial outputs of this wave's two xi rows
-    //   ra[xi] = m[xi][0]+m[xi][1]+m[xi][2], rb[xi] = m[xi][1]-m[xi][2]-m[xi][3]
-    //   Y[0][.] = r.[0]+r.[1]+r.[2],  Y[1][.] = r.[1]-r.[2]-r.[3]
-    float y00[16], y01[16], y10[16], y11[16];
+    wino_epilogue(a, acc, smem, lane, wn, wp, n0, img0, ty0, tx0, tpi, pb);
+}
+
+// --------------------------------------------------------------------------------------------
+// k_conv_wino_s3: the same Winograd F(2x2,3x3) unit on bf16 MFMA over EXACT three-plane cuts of the
+// fp32 operands (see agg_split.h): U is cut at pack time, V by the transform threads when they write
+// it; every fp32 product U*V is the sum of nine exact plane products accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16 (9/16 of the f32 MFMA time).  On gfx950 the f32 "MFMA" shares the VALU's
+// fp32 FMA rate, so the transform / staging VALU work of k_conv_wino costs MFMA throughput; the bf16
+// MFMA runs beside the VALU.  16-channel chunks (one MFMA k step); LDS is single-buffered so that two
+// workgroups still share a CU (the partner covers the serial phases):
+//   raw[256 px][16 ch (+4)] fp32  20 KB      V[16 pos][32 slots][3 planes x 16 bf16 (+16 B)]  56 KB
+//   per chunk:  MFMAs(cc) | raw(cc+1) regs -> LDS, global loads of raw(cc+2) | barrier |
+//               transform(cc+1): raw -> V planes | barrier
+// Weights U[16 pos][C/16][3 planes][Cout][16] bf16 are read by each lane straight from L2 in MFMA
+// B-operand order (1 KiB coalesced per wave instruction), one position ahead.
+// --------------------------------------------------------------------------------------------
+constexpr int SK = 16;                               // channels per chunk
+constexpr int SRLD = SK + 4;                         // raw LDS row stride (floats, 80 B)
+constexpr int SVLD = 28;                             // V LDS slot stride (dwords, 112 B)
+constexpr int SV_DW = 16 * WTT * SVLD;               // dwords of V
+constexpr int SRPT = (WRAW_MAX * 4 + 255) / 256;     // raw float4 per thread per chunk
+
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+
+// cut 4 fp32 values into three bf16 planes (truncation: exact), 2 packed dwords per plane
+__device__ __forceinline__ void cut4(const f32x4& x, u32x2_t& ph, u32x2_t& pm, u32x2_t& pl) {
+    unsigned xu[4], r1u[4], r2u[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float raA = acc[0][r] + acc[1][r] + acc[2][r], rbA = acc[1][r] - acc[2][r] - acc[3][r];  // xi = 2wp
-        const float raB = acc[4][r] + acc[5][r] + acc[6][r], rbB = acc[5][r] - acc[6][r] - acc[7][r];  // xi = 2wp+1
-        if (wp == 0) { y00[r] = raA + raB; y01[r] = rbA + rbB; y10[r] = raB; y11[r] = rbB; }
-        else { y00[r] = raA; y01[r] = rbA; y10[r] = -raA - raB; y11[r] = -rbA - rbB; }
+    for (int e = 0; e < 4; ++e) {
+        xu[e] = __float_as_uint(x[e]);
+        const float r1 = x[e] - __uint_as_float(xu[e] & 0xFFFF0000u);
+        r1u[e] = __float_as_uint(r1);
+        r2u[e] = __float_as_uint(r1 - __uint_as_float(r1u[e] & 0xFFFF0000u));
     }
-    // exchange through LDS (the V buffers are free now): the wp = 0 wave finishes output row 0
-    // (y00, y01), the wp = 1 wave output row 1 (y10, y11); each sends the other row's partials
-    float* xch = smem + ((wn * 2 + wp) * 64 + lane) * 33;        // [2 wn][2 wp][64 lanes][32 (+1 pad)]
-    float* xpr = smem + ((wn * 2 + (wp ^ 1)) * 64 + lane) * 33;  // the partner's slot
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        xch[r] = wp == 0 ? y10[r] : y00[r];
-        xch[16 + r] = wp == 0 ? y11[r] : y01[r];
+    for (int i = 0; i < 2; ++i) {
+        ph[i] = __builtin_amdgcn_perm(xu[2 * i + 1], xu[2 * i], 0x07060302u);
+        pm[i] = __builtin_amdgcn_perm(r1u[2 * i + 1], r1u[2 * i], 0x07060302u);
+        pl[i] = __builtin_amdgcn_perm(r2u[2 * i + 1], r2u[2 * i], 0x07060302u);
     }
+}
+
+template <bool NORM>
+__global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned* sV = reinterpret_cast<unsigned*>(smem);   // [16][WTT][SVLD] dwords
+    float* sR = smem + SV_DW;                           // [WRAW_MAX][SRLD]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wp = wave >> 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int n0 = blockIdx.y * 64;
+    const int nchunks = a.C / SK;
+    int bid = blockIdx.x;
+    const int bx = bid % a.nbx; bid /= a.nbx;
+    const int by = bid % a.nby; bid /= a.nby;
+    const int img0 = bid * a.IB;
+    const int ty0 = by * a.TYB, tx0 = bx * a.TXB;
+    const int pb = by * a.nbx + bx;
+    const int RH = 2 * a.TYB + 2, RW = 2 * a.TXB + 2, RP = RH * RW;
+    const int tpi = a.TYB * a.TXB;
+    const int iy_org = 2 * ty0 - 1, ix_org = 2 * tx0 - 1;
+
+    // ---- raw staging role: element e = tid + 256 q -> (pixel e>>2, channel group e&3)
+    int roff[SRPT], rlds[SRPT], rsto[SRPT];
+#pragma unroll
+    for (int q = 0; q < SRPT; ++q) {
+        const int e = tid + 256 * q, px = e >> 2, gg = e & 3;
+        roff[q] = -2; rlds[q] = 0; rsto[q] = gg * 4;
+        if (px < a.IB * RP) {
+            const int il = px / RP, rem = px - il * RP, ry = rem / RW, rx = rem - ry * RW;
+            const int n = img0 + il, iy = iy_org + ry, ix = ix_org + rx;
+            roff[q] = -1;
+            if (n < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                roff[q] = ((n * a.H + iy) * a.W + ix) * a.C + gg * 4;
+                rsto[q] = n * a.C + gg * 4;
+            }
+            rlds[q] = px * SRLD + gg * 4;
+        }
+    }
+    // ---- transform role: channel group g (4 channels), tile slot ts, column half h (nu in {2h,2h+1});
+    //      all four xi rows of the patch columns h..h+2
+    const int g = tid & 3, ts = (tid >> 2) & 31;
+    const int h = wave >> 1;   // wave-uniform
+    const int sil = ts / tpi, srem = ts - sil * tpi, styl = srem / a.TXB, stxl = srem - styl * a.TXB;
+    const int praw = (ts < a.IB * tpi) ? ((sil * RH + 2 * styl) * RW + 2 * stxl + h) * SRLD + g * 4 : g * 4;
+
+    f32x4 rreg[SRPT];
+    auto raw_load = [&](int cc) {
+#pragma unroll
+        for (int q = 0; q < SRPT; ++q) {
+            const int off = roff[q] < 0 ? 0 : roff[q];
+            rreg[q] = *reinterpret_cast<const f32x4*>(a.x + (long long)off + cc * SK);
+        }
+    };
+    auto raw_write = [&](int cc) {   // producer's IN + ReLU and the zero padding applied once per staged pixel
+#pragma unroll
+        for (int q = 0; q < SRPT; ++q) {
+            if (roff[q] == -2) continue;
+            f32x4 x = rreg[q];
+            const bool ok = roff[q] >= 0;
+            if constexpr (NORM) {
+                // (mean, rstd) are read here, not prefetched with the pixels: 32 more live registers
+                // across the MFMA phase spill (measured: 132 B of scratch)
+                const f32x4 mu = *reinterpret_cast<const f32x4*>(a.in_mean + rsto[q] + cc * SK);
+                const f32x4 rs = *reinterpret_cast<const f32x4*>(a.in_rstd + rsto[q] + cc * SK);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = fmaxf((x[e] - mu[e]) * rs[e], 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = ok ? x[e] : 0.f;
+            *reinterpret_cast<f32x4*>(sR + rlds[q]) = x;
+        }
+    };
+    // raw -> V planes: B^T d B of this role's 4x3 patch window, 8 outputs (4 xi x 2 nu), each cut and
+    // written as three 8-byte pieces (plane, k = 4g..4g+3) of slot ts
+    auto transform = [&]() {
+        const float* r = sR + praw;
+        f32x4 T[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f32x4 R0 = *reinterpret_cast<const f32x4*>(r + (0 * RW + c) * SRLD);
+            const f32x4 R1 = *reinterpret_cast<const f32x4*>(r + (1 * RW + c) * SRLD);
+            const f32x4 R2 = *reinterpret_cast<const f32x4*>(r + (2 * RW + c) * SRLD);
+            const f32x4 R3 = *reinterpret_cast<const f32x4*>(r + (3 * RW + c) * SRLD);
+            T[0][c] = R0 - R2; T[1][c] = R1 + R2; T[2][c] = R2 - R1; T[3][c] = R1 - R3;
+        }
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            f32x4 o0, o1;
+            if (h == 0) { o0 = T[xi][0] - T[xi][2]; o1 = T[xi][1] + T[xi][2]; }
+            else { o0 = T[xi][1] - T[xi][0]; o1 = T[xi][0] - T[xi][2]; }
+            const int pos = xi * 4 + 2 * h;
+            u32x2_t ph, pm, pl;
+            unsigned* d0 = sV + (pos * WTT + ts) * SVLD + g * 2;
+            cut4(o0, ph, pm, pl);
+            *reinterpret_cast<u32x2_t*>(d0) = ph;
+            *reinterpret_cast<u32x2_t*>(d0 + 8) = pm;
+            *reinterpret_cast<u32x2_t*>(d0 + 16) = pl;
+            unsigned* d1 = d0 + WTT * SVLD;
+            cut4(o1, ph, pm, pl);
+            *reinterpret_cast<u32x2_t*>(d1) = ph;
+            *reinterpret_cast<u32x2_t*>(d1 + 8) = pm;
+            *reinterpret_cast<u32x2_t*>(d1 + 16) = pl;
+        }
+    };
+    // weights: uniform base per (wave), lane offset inside the [Cout][16] bf16 slab of a (pos, chunk, plane)
+    const unsigned short* ub16 = reinterpret_cast<const unsigned short*>(a.u);
+    const long long uplane = (long long)a.Cout * SK;                 // bf16 between planes
+    const long long uchunk = 3 * uplane;                             // between channel chunks
+    const long long upos = (long long)nchunks * uchunk;              // between transform positions
+    const unsigned short* ubase = ub16 + (long long)(8 * wp) * upos + (long long)(n0 + wn * 32) * SK;
+    const int ulane = l31 * SK + 8 * hi;
+    auto uload = [&](int p, int cc, u32x4_t (&w)[3]) {
+        const unsigned short* q = ubase + p * upos + cc * uchunk + ulane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const u32x4_t*>(q + pl * uplane);
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    // ---- prologue: raw(0) -> LDS -> V(0); raw(1) in registers
+    raw_load(0);
+    raw_write(0);
+    if (nchunks > 1) raw_load(1);
     __syncthreads();
-    float ya[16], yb[16];  // this wave's output row: pixels (oy+wp, ox) and (oy+wp, ox+1)
+    transform();
+    __syncthreads();
+    const int vfo = ((8 * wp) * WTT + l31) * SVLD + 4 * hi;   // dwords
+    union Frag { u32x4_t u; bf16x8_t v; };
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const bool more = cc + 1 < nchunks, more2 = cc + 2 < nchunks;   // block-uniform
+        // ---- 8 positions x 9 plane products
+        u32x4_t w[2][3];
+        uload(0, cc, w[0]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        ya[r] = (wp == 0 ? y00[r] : y10[r]) + xpr[r];
-        yb[r] = (wp == 0 ? y01[r] : y11[r]) + xpr[16 + r];
+        for (int p = 0; p < 8; ++p) {
+            if (p < 7) uload(p + 1, cc, w[(p + 1) & 1]);
+            Frag va[3], wb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                va[pl].u = *reinterpret_cast<const u32x4_t*>(sV + vfo + p * WTT * SVLD + pl * 8);
+                wb[pl].u = w[p & 1][pl];
+            }
+            // smallest products first: (l,l) (m,l) (l,m) (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[2].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[2].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[1].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[0].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[2].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[1].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[0].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[1].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[0].v, acc[p], 0, 0, 0);
+        }
+        // ---- raw(cc+1): registers -> LDS (the raw buffer was consumed before the last barrier), then the
+        //      global loads of raw(cc+2)
+        if (more) raw_write(cc + 1);
+        if (more2) raw_load(cc + 2);
+        __syncthreads();                 // V(cc) is free, raw(cc+1) is in LDS
+        if (more) transform();
+        __syncthreads();                 // V(cc+1) is ready
     }
-    // ---- raw store + statistics partials
-    const int co = n0 + wn * 32 + l31;
-    unsigned vmask[16];  // 2 validity bits per accumulator row (tile slot)
-    int rimg[16];        // local image of the row's tile slot (or -1)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int slot = drow(r, hi);
-        const int il = slot / tpi, rem = slot - il * tpi, tyl = rem / a.TXB, txl = rem - tyl * a.TXB;
-        const int n = img0 + il, ty = ty0 + tyl, tx = tx0 + txl;
-        unsigned vm = 0;
-        rimg[r] = -1;
-        const int oy = 2 * ty + wp, ox = 2 * tx;
-        if (slot < a.IB * tpi && n < a.B && ty < a.TY && tx < a.TX && oy < a.H) {
-            float* o = a.y + ((long long)(n * a.H + oy) * a.W + ox) * a.Cout + co;
-            o[0] = ya[r]; vm = 1u;
-            if (ox + 1 < a.W) { o[a.Cout] = yb[r]; vm |= 2u; }
-            rimg[r] = il;
+    wino_epilogue(a, acc, smem, lane, wn, wp, n0, img0, ty0, tx0, tpi, pb);
+}
+
+// conv weight [O][I][3][3] -> U = G g G^T cut into three bf16 planes: [16 pos][I/16][3][O][16]
+__global__ void k_pack_wino_s3(const float* __restrict__ w, unsigned short* __restrict__ out, int O, int I) {
+    const long long total = (long long)O * I;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % I), o = (int)(i / I);
+        const float* gw = w + i * 9;
+        float gg[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) gg[r][c] = gw[r * 3 + c];
+        float tmp[4][3];  // G g
+        for (int c = 0; c < 3; ++c) {
+            tmp[0][c] = gg[0][c];
+            tmp[1][c] = 0.5f * (gg[0][c] + gg[1][c] + gg[2][c]);
+            tmp[2][c] = 0.5f * (gg[0][c] - gg[1][c] + gg[2][c]);
+            tmp[3][c] = gg[2][c];
         }
-        vmask[r] = vm;
-    }
-    for (int il = 0; il < a.IB; ++il) {
-        const int n = img0 + il;
-        if (n >= a.B) break;
-        float sum = 0.f, cnt = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned vm = (rimg[r] == il) ? vmask[r] : 0u;
-            sum += ((vm & 1u) ? ya[r] : 0.f) + ((vm & 2u) ? yb[r] : 0.f);
-            cnt += (float)__popc(vm);
-        }
-        sum += __shfl_xor(sum, 32, 64);
-        cnt += __shfl_xor(cnt, 32, 64);
-        const float mean = cnt > 0.f ? sum / cnt : 0.f;
-        float q = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned vm = (rimg[r] == il) ? vmask[r] : 0u;
-            const float d0 = ya[r] - mean, d1 = yb[r] - mean;
-            q += ((vm & 1u) ? d0 * d0 : 0.f) + ((vm & 2u) ? d1 * d1 : 0.f);
-        }
-        q += __shfl_xor(q, 32, 64);
-        if (hi == 0) {
-            float* o = a.part + ((((long long)n * a.PB + pb) * 2 + wp) * a.Cout + co) * 3;
-            o[0] = cnt; o[1] = mean; o[2] = q;
+        for (int xi = 0; xi < 4; ++xi) {
+            float u4[4];
+            u4[0] = tmp[xi][0];
+            u4[1] = 0.5f * (tmp[xi][0] + tmp[xi][1] + tmp[xi][2]);
+            u4[2] = 0.5f * (tmp[xi][0] - tmp[xi][1] + tmp[xi][2]);
+            u4[3] = tmp[xi][2];
+            for (int nu = 0; nu < 4; ++nu) {
+                const float v = u4[nu];
+                const unsigned hb = __float_as_uint(v) & 0xFFFF0000u;
+                const float r1 = v - __uint_as_float(hb);
+                const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
+                const unsigned lb = __float_as_uint(r1 - __uint_as_float(mb));
+                const long long base = ((((long long)(xi * 4 + nu) * (I / 16) + ci / 16) * 3) * O + o) * 16 + (ci & 15);
+                out[base] = (unsigned short)(hb >> 16);
+                out[base + (long long)O * 16] = (unsigned short)(mb >> 16);
+                out[base + 2LL * O * 16] = (unsigned short)(lb >> 16);
+            }
         }
     }
 }
@@ -954,10 +1212,21 @@ inline bool use_wino(const ConvSpec& s) {  // 3x3 stride-1 convs run as Winograd
     static const int off = getenv("DSMIL_NO_WINO") ? atoi(getenv("DSMIL_NO_WINO")) : 0;
     return !off && s.ks == 3 && s.stride == 1 && s.pad == 1 && s.cin % WK == 0 && s.cout % 64 == 0;
 }
-// floats of conv i in the packed buffer: 16 transform positions for Winograd convs, ks*ks taps otherwise
+// DSMIL_WINO = s3 (default) | f32: which MFMA form the Winograd convs use (read once per process; the packed
+// weights and the kernels must agree): s3 = bf16 MFMA over exact three-plane cuts, f32 = v_mfma_f32_32x32x2_f32
+inline bool wino_s3() {
+    static const bool on = [] {
+        const char* e = getenv("DSMIL_WINO");
+        return !(e && !strcmp(e, "f32"));   // default: s3
+    }();
+    return on;
+}
+// floats of conv i in the packed buffer: 16 transform positions for Winograd convs (x 3 bf16 planes = 1.5
+// floats per weight in the s3 form), ks*ks taps otherwise
 inline long long wsize(const Arch& A, int i) {
     const ConvSpec& s = A.specs[i];
-    return (long long)s.cout * s.cin * (use_wino(s) ? 16 : s.ks * s.ks);
+    if (use_wino(s)) return (long long)s.cout * s.cin * (wino_s3() ? 24 : 16);
+    return (long long)s.cout * s.cin * s.ks * s.ks;
 }
 inline size_t pack_offset(const Arch& A, int i) {  // floats; conv 0 (stem) is used unpacked
     size_t o = 0;
@@ -1068,10 +1337,15 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
         static const int wexpt = getenv("DSMIL_WINO_EXPT") ? atoi(getenv("DSMIL_WINO_EXPT")) : 0;
         wa.expt = wexpt;
         wa.nby = (wa.TY + wa.TYB - 1) / wa.TYB; wa.nbx = (wa.TX + wa.TXB - 1) / wa.TXB; wa.PB = wa.nby * wa.nbx;
-        const size_t lds = (size_t)(2 * WTILE + 2 * WRAW_MAX * WLD) * sizeof(float);
+        const size_t lds = wino_s3() ? (size_t)(SV_DW + WRAW_MAX * SRLD) * sizeof(float)
+                                     : (size_t)(2 * WTILE + 2 * WRAW_MAX * WLD) * sizeof(float);
         dim3 grid((unsigned)(((B + wa.IB - 1) / wa.IB) * wa.PB), (unsigned)(s.cout / 64));
         const int slot = dsmil_prof::begin(dsmil_prof::CH_CONV, st);
-        if (in_mean) hipLaunchKernelGGL((k_conv_wino<true>), grid, dim3(256), lds, st, wa);
+        if (wino_s3()) {
+            if (in_mean) hipLaunchKernelGGL((k_conv_wino_s3<true>), grid, dim3(256), lds, st, wa);
+            else hipLaunchKernelGGL((k_conv_wino_s3<false>), grid, dim3(256), lds, st, wa);
+        }
+        else if (in_mean) hipLaunchKernelGGL((k_conv_wino<true>), grid, dim3(256), lds, st, wa);
         else hipLaunchKernelGGL((k_conv_wino<false>), grid, dim3(256), lds, st, wa);
         dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
@@ -1137,6 +1411,8 @@ void set_conv_attrs() {
     (void)hipFuncSetAttribute((const void*)k_conv<4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
     (void)hipFuncSetAttribute((const void*)k_conv_wino<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * WTILE + 2 * WRAW_MAX * WLD) * 4);
     (void)hipFuncSetAttribute((const void*)k_conv_wino<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * WTILE + 2 * WRAW_MAX * WLD) * 4);
+    (void)hipFuncSetAttribute((const void*)k_conv_wino_s3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (SV_DW + WRAW_MAX * SRLD) * 4);
+    (void)hipFuncSetAttribute((const void*)k_conv_wino_s3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (SV_DW + WRAW_MAX * SRLD) * 4);
     g_attr_done = true;
 }
 
@@ -1162,8 +1438,12 @@ int dsmil_resnet_pack(int32_t depth, const float* const* conv_w, float* packed, 
         if (use_wino(s)) {
             long long blocks = ((long long)s.cout * s.cin + 255) / 256;
             if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(k_pack_wino, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
-                               packed + pack_offset(*A, i), s.cout, s.cin);
+            if (wino_s3())
+                hipLaunchKernelGGL(k_pack_wino_s3, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
+                                   (unsigned short*)(packed + pack_offset(*A, i)), s.cout, s.cin);
+            else
+                hipLaunchKernelGGL(k_pack_wino, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
+                                   packed + pack_offset(*A, i), s.cout, s.cin);
         } else {
             const long long total = wsize(*A, i);
             long long blocks = (total + 255) / 256;
