@@ -173,7 +173,8 @@ def embedder_leg(args, dev, rank, world, dist, L):
             "config": {"workload": f"IClassifier(ResNet-18 InstanceNorm, fc=Identity)+Linear(512,2), {Bp} synthetic "
                                    f"224x224 patches per GPU per step, kaiming(seed 11) weights",
                        "collective": "all_gather_into_tensor([%d,512] f32) per step" % Bp if world > 1 else "none"},
-            "roofline": {"kernel": "k_conv (19 implicit-GEMM convs per forward)", "bound": "mfma",
+            "roofline": {"kernel": "k_conv_wino_s3 (13 Winograd convs, bf16 MFMA over exact 3-plane cuts) + k_conv "
+                                   "(6 direct convs, f32 MFMA) per forward", "bound": "mfma",
                          "achieved": round(ach, 2) if ach else None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4) if ach else None,
                          "traffic": _pmc("pmc_k_conv.json", "hbm_bytes_per_forward"),
