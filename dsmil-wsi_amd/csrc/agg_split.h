@@ -3,8 +3,9 @@
 // each, truncation, no rounding: the cut is exact), and a product x*w is formed as the sum of the
 // plane products (each exact in fp32: 8 x 8 significand bits) accumulated in fp32 by
 // v_mfma_f32_32x32x16_bf16.  NP = 9 adds all nine plane products (the fp32 product exactly);
-// NP = 6 leaves out (m,l), (l,m), (l,l), each <= 2^-24 of |x*w| — the size of the one rounding an
-// fp32 FMA chain makes per term.  One bf16 MFMA moves 16x the MACs of v_mfma_f32_32x32x2_f32 per
+// NP = 6 leaves out (m,l), (l,m), (l,l): with truncating cuts |m| < 2^-7 |v| and |l| < 2^-14 |v|, so the
+// omission is below 2^-20 of |x*w| (typically ~2^-23, the size of one fp32 rounding).  The cut is exact
+// while no residual is subnormal (|v| >= 2^-100); smaller magnitudes lose their low plane.  One bf16 MFMA moves 16x the MACs of v_mfma_f32_32x32x2_f32 per
 // cycle, so the 9-product form costs 9/16 of the exact-f32 MFMA time (6/16 for NP = 6); the number
 // of fp32 accumulator roundings per 16 k is 9 (6) against 8 for the f32 MFMA chain.
 //
