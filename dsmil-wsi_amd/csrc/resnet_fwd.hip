@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "dsmil_hip.h"
@@ -1342,6 +1343,17 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
         dim3 grid((unsigned)(((B + wa.IB - 1) / wa.IB) * wa.PB), (unsigned)(s.cout / 64));
         const int slot = dsmil_prof::begin(dsmil_prof::CH_CONV, st);
         if (wino_s3()) {
+            static const bool dbg = getenv("DSMIL_WINO_DEBUG") != nullptr;
+            if (dbg) {
+                static bool once = false;
+                if (!once) {
+                    once = true;
+                    int nb0 = 0, nb1 = 0;
+                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, (const void*)k_conv_wino_s3<false>, 256, lds);
+                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, (const void*)k_conv_wino_s3<true>, 256, lds);
+                    fprintf(stderr, "[dsmil] k_conv_wino_s3: lds %zu B, %d / %d workgroups per CU\n", lds, nb0, nb1);
+                }
+            }
             if (in_mean) hipLaunchKernelGGL((k_conv_wino_s3<true>), grid, dim3(256), lds, st, wa);
             else hipLaunchKernelGGL((k_conv_wino_s3<false>), grid, dim3(256), lds, st, wa);
         }
