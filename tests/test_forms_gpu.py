@@ -1,0 +1,26 @@
+"""Every selectable MFMA form stays parity-green: the default suite runs the default forms (aggregator
+query MLP and Winograd convs on bf16 MFMA over exact three-plane cuts); this file re-runs a small
+aggregator + embedder check in subprocesses with the alternatives selected (the knobs are read once per
+process): DSMIL_MLP=f32 / s6 and DSMIL_WINO=f32."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("env,form", [({"DSMIL_MLP": "f32", "DSMIL_WINO": "f32"}, 0),
+                                      ({"DSMIL_MLP": "s6"}, 6), ({}, 9)])
+def test_alternative_mfma_forms(env, form):
+    e = dict(os.environ)
+    for k in ("DSMIL_MLP", "DSMIL_WINO"):
+        e.pop(k, None)
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "_form_check.py")], env=e, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("FORM-OK")]
+    assert line and int(line[0].split()[1]) == form
