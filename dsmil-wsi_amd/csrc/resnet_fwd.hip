@@ -44,6 +44,40 @@ constexpr float IN_EPS = 1e-5f;
 
 __device__ __forceinline__ int drow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// ---- exact three-plane bf16 cuts (see agg_split.h) ---------------------------------------------
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+
+// cut 4 fp32 values into three bf16 planes (truncation: exact), 2 packed dwords per plane
+__device__ __forceinline__ void cut4(const f32x4& x, u32x2_t& ph, u32x2_t& pm, u32x2_t& pl) {
+    unsigned xu[4], r1u[4], r2u[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        xu[e] = __float_as_uint(x[e]);
+        const float r1 = x[e] - __uint_as_float(xu[e] & 0xFFFF0000u);
+        r1u[e] = __float_as_uint(r1);
+        r2u[e] = __float_as_uint(r1 - __uint_as_float(r1u[e] & 0xFFFF0000u));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ph[i] = __builtin_amdgcn_perm(xu[2 * i + 1], xu[2 * i], 0x07060302u);
+        pm[i] = __builtin_amdgcn_perm(r1u[2 * i + 1], r1u[2 * i], 0x07060302u);
+        pl[i] = __builtin_amdgcn_perm(r2u[2 * i + 1], r2u[2 * i], 0x07060302u);
+    }
+}
+
+union Frag16 { u32x4_t u; bf16x8_t v; };
+// cut 8 consecutive-k fp32 values into three bf16x8 MFMA operands (plane h, m, l)
+__device__ __forceinline__ void cut8(const f32x4& a0, const f32x4& a1, Frag16 (&o)[3]) {
+    u32x2_t h0, m0, l0, h1, m1, l1;
+    cut4(a0, h0, m0, l0);
+    cut4(a1, h1, m1, l1);
+    o[0].u = u32x4_t{h0[0], h0[1], h1[0], h1[1]};
+    o[1].u = u32x4_t{m0[0], m0[1], m1[0], m1[1]};
+    o[2].u = u32x4_t{l0[0], l0[1], l1[0], l1[1]};
+}
+
 // ---------------------------------------------------------------------------------------------
 // statistics epilogue shared by the conv kernels: one wave holds a 32(pixel) x 32(channel)
 // accumulator tile; rows [lo, hi_) of it belong to one image.  Returns (mean, M2) of those rows
@@ -89,7 +123,10 @@ struct ConvArgs {
 // MW x (4/MW) grid, each wave owning 32 pixels x NT*32 channels.  <4,4>: 128x128, <4,2>: 128x64,
 // <2,1>: 64x64 (finer work units for the late layers, whose 128x128 tiling yields only 392
 // workgroups for 256 CUs).
-template <int MW, int NT, bool NORM, int NBUF = 2>
+// S3: the same tiles and staging, but each fp32 fragment is cut into three exact bf16 planes as it is
+// read from LDS and the products run on v_mfma_f32_32x32x16_bf16 (9 plane products per 16 k): 9/16 of
+// the f32 MFMA time, and the cut's VALU work runs beside the bf16 MFMA instead of on the f32 MFMA's pipe.
+template <int MW, int NT, bool NORM, int NBUF = 2, bool S3 = false>
 __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     constexpr int NWN = 4 / MW;
     constexpr int BM = MW * 32;
@@ -193,6 +230,26 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         if (st + 1 < nsteps) stage_load(st + 1);
         const float* x = sX + (st & (NBUF - 1)) * X_TILE + wm * 32 * LDK + frag;
         const float* w = sW + (st & (NBUF - 1)) * W_TILE + wn * NT * 32 * LDK + frag;
+        if constexpr (S3) {
+            // lane (row l31, hi) feeds k = 16 ks + 8 hi .. + 7 of its row: two 16-B reads, then the cut
+            const float* x2 = x + 4 * hi;   // frag already holds l31 * LDK + 4 * hi
+            const float* w2 = w + 4 * hi;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag16 xa[3];
+                cut8(*reinterpret_cast<const f32x4*>(x2 + ks * 16), *reinterpret_cast<const f32x4*>(x2 + ks * 16 + 4), xa);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    Frag16 wb[3];
+                    cut8(*reinterpret_cast<const f32x4*>(w2 + t * 32 * LDK + ks * 16),
+                         *reinterpret_cast<const f32x4*>(w2 + t * 32 * LDK + ks * 16 + 4), wb);
+                    constexpr int PA[9] = {2, 1, 2, 2, 0, 1, 1, 0, 0}, PB[9] = {2, 2, 1, 0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int i9 = 0; i9 < 9; ++i9)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PA[i9]].v, wb[PB[i9]].v, acc[t], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
             const f32x4 xa = *reinterpret_cast<const f32x4*>(x + kg * 8);
@@ -203,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
                 for (int j = 0; j < 4; ++j)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j], wb[j], acc[t], 0, 0, 0);
             }
+        }
         }
         if constexpr (NBUF == 1) __syncthreads();  // single LDS buffer: everyone done reading first
         if (st + 1 < nsteps) stage_write(st + 1);
@@ -600,28 +658,6 @@ constexpr int SRLD = SK + 4;                         // raw LDS row stride (floa
 constexpr int SVLD = 28;                             // V LDS slot stride (dwords, 112 B)
 constexpr int SV_DW = 16 * WTT * SVLD;               // dwords of V
 constexpr int SRPT = (WRAW_MAX * 4 + 255) / 256;     // raw float4 per thread per chunk
-
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-typedef short bf16x8_t __attribute__((ext_vector_type(8)));
-
-// cut 4 fp32 values into three bf16 planes (truncation: exact), 2 packed dwords per plane
-__device__ __forceinline__ void cut4(const f32x4& x, u32x2_t& ph, u32x2_t& pm, u32x2_t& pl) {
-    unsigned xu[4], r1u[4], r2u[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        xu[e] = __float_as_uint(x[e]);
-        const float r1 = x[e] - __uint_as_float(xu[e] & 0xFFFF0000u);
-        r1u[e] = __float_as_uint(r1);
-        r2u[e] = __float_as_uint(r1 - __uint_as_float(r1u[e] & 0xFFFF0000u));
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        ph[i] = __builtin_amdgcn_perm(xu[2 * i + 1], xu[2 * i], 0x07060302u);
-        pm[i] = __builtin_amdgcn_perm(r1u[2 * i + 1], r1u[2 * i], 0x07060302u);
-        pl[i] = __builtin_amdgcn_perm(r2u[2 * i + 1], r2u[2 * i], 0x07060302u);
-    }
-}
 
 template <bool NORM>
 __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
@@ -1222,6 +1258,14 @@ inline bool wino_s3() {
     }();
     return on;
 }
+// DSMIL_CONV = s3 | f32: MFMA form of the DIRECT convs (stride-2 3x3, 1x1 downsample); same weights either way
+inline bool conv_s3() {
+    static const bool on = [] {
+        const char* e = getenv("DSMIL_CONV");
+        return e && !strcmp(e, "s3");
+    }();
+    return on;
+}
 // floats of conv i in the packed buffer: 16 transform positions for Winograd convs (x 3 bf16 planes = 1.5
 // floats per weight in the s3 form), ks*ks taps otherwise
 inline long long wsize(const Arch& A, int i) {
@@ -1397,12 +1441,20 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
     } else if (blocks128 >= ((expt & 4) ? 256 : 1024)) {
         const size_t lds = (size_t)(2 * 128 * LDK + 2 * 128 * LDK) * 4;
         dim3 grid((unsigned)((a.Mtot + 127) / 128), (unsigned)(s.cout / 128));
-        if (norm) hipLaunchKernelGGL((k_conv<4, 4, true>), grid, dim3(256), lds, st, a);
+        if (conv_s3()) {
+            if (norm) hipLaunchKernelGGL((k_conv<4, 4, true, 2, true>), grid, dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((k_conv<4, 4, false, 2, true>), grid, dim3(256), lds, st, a);
+        }
+        else if (norm) hipLaunchKernelGGL((k_conv<4, 4, true>), grid, dim3(256), lds, st, a);
         else hipLaunchKernelGGL((k_conv<4, 4, false>), grid, dim3(256), lds, st, a);
     } else {
         const size_t lds = (size_t)(2 * 64 * LDK + 2 * 64 * LDK) * 4;
         dim3 grid((unsigned)((a.Mtot + 63) / 64), (unsigned)(s.cout / 64));
-        if (norm) hipLaunchKernelGGL((k_conv<2, 1, true>), grid, dim3(256), lds, st, a);
+        if (conv_s3()) {
+            if (norm) hipLaunchKernelGGL((k_conv<2, 1, true, 2, true>), grid, dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((k_conv<2, 1, false, 2, true>), grid, dim3(256), lds, st, a);
+        }
+        else if (norm) hipLaunchKernelGGL((k_conv<2, 1, true>), grid, dim3(256), lds, st, a);
         else hipLaunchKernelGGL((k_conv<2, 1, false>), grid, dim3(256), lds, st, a);
     }
     dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
@@ -1417,6 +1469,8 @@ bool g_attr_done = false;
 void set_conv_attrs() {
     if (g_attr_done) return;
     const int l4 = (2 * 128 * LDK + 2 * 128 * LDK) * 4, l2 = (2 * 128 * LDK + 2 * 64 * LDK) * 4;
+    (void)hipFuncSetAttribute((const void*)k_conv<4, 4, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
+    (void)hipFuncSetAttribute((const void*)k_conv<4, 4, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
     (void)hipFuncSetAttribute((const void*)k_conv<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
     (void)hipFuncSetAttribute((const void*)k_conv<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
     (void)hipFuncSetAttribute((const void*)k_conv<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
