@@ -41,6 +41,9 @@ def build_parser():
     p.add_argument("--weights_low", default=None, type=str)
     p.add_argument("--tree_fusion", default="cat", type=str, help="[cat|fusion]")
     p.add_argument("--dataset", default="TCGA-lung-single", type=str, help="Dataset folder name")
+    p.add_argument("--save_npy", action="store_true",
+                   help="(new) also write each bag's features as float32 <bag>.npy next to the '%%.4f' CSV: lossless "
+                        "and ~6x smaller/faster to load than the text detour of compute_feats.py:80-82")
     return p
 
 

@@ -122,12 +122,15 @@ def embed_files(i_classifier, files, batch_size=128, num_workers=4, device=None,
     return feats, classes
 
 
-def save_feats_csv(feats, path):
-    """compute_feats.py:80-82 — pandas CSV, header 0..F-1, '%.4f'."""
+def save_feats_csv(feats, path, npy=False):
+    """compute_feats.py:80-82 — pandas CSV, header 0..F-1, '%.4f'; with ``npy`` also the exact float32 rows
+    as <bag>.npy (the text format quantises to 1e-4 and dominates I/O time)."""
     import pandas as pd
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    pd.DataFrame(feats.detach().cpu().numpy() if torch.is_tensor(feats) else feats).to_csv(
-        path, index=False, float_format="%.4f")
+    arr = feats.detach().cpu().numpy() if torch.is_tensor(feats) else np.asarray(feats)
+    pd.DataFrame(arr).to_csv(path, index=False, float_format="%.4f")
+    if npy:
+        np.save(os.path.splitext(path)[0] + ".npy", np.ascontiguousarray(arr, dtype=np.float32))
 
 
 def _bag_csv_path(save_path, bag_dir):
@@ -147,7 +150,7 @@ def compute_feats(args, bags_list, i_classifier, save_path=None, magnification="
             if len(files) == 0:
                 print("No valid patch extracted from: " + bag)
             else:
-                save_feats_csv(feats, _bag_csv_path(save_path, bag))
+                save_feats_csv(feats, _bag_csv_path(save_path, bag), npy=getattr(args, "save_npy", False))
 
 
 @torch.no_grad()
@@ -179,7 +182,7 @@ def compute_tree_feats(args, bags_list, embedder_low, embedder_high, save_path=N
         low_of_high = low_feats.index_select(0, torch.as_tensor(parent, device=low_feats.device))
         tree = high_feats + 0.25 * low_of_high if args.tree_fusion == "fusion" else torch.cat([high_feats, low_of_high], dim=-1)
         if rank == 0:
-            save_feats_csv(tree, _bag_csv_path(save_path, bag))
+            save_feats_csv(tree, _bag_csv_path(save_path, bag), npy=getattr(args, "save_npy", False))
     if rank == 0:
         print("\n")
 

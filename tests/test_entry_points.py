@@ -48,7 +48,8 @@ def test_compute_feats_single_matches_oracle(workdir):
         for slide in ("s1", "s2"):
             for i in range(3):
                 _jpeg(f"WSI/toy/single/{cls}/{slide}/{i}_{i + 1}.jpeg", zlib.crc32(f'{cls}/{slide}/{i}'.encode()) % 10000)
-    cf.main(["--dataset", "toy", "--weights", "r0", "--batch_size", "2", "--num_workers", "0", "--num_classes", "1"])
+    cf.main(["--dataset", "toy", "--weights", "r0", "--batch_size", "2", "--num_workers", "0", "--num_classes", "1",
+             "--save_npy"])
     import pandas as pd
     csvs = sorted(glob.glob("datasets/toy/*/*.csv"))
     assert len(csvs) == 4
@@ -64,7 +65,11 @@ def test_compute_feats_single_matches_oracle(workdir):
         ref = ro.resnet18_in_features(x, w).numpy()
     got = pd.read_csv("datasets/toy/1_tumor/s2.csv").to_numpy()
     assert got.shape == (3, 512)
-    np.testing.assert_allclose(got, ref, atol=8e-5)  # half the '%.4f' CSV quantum + fp32 order effects
+    np.testing.assert_allclose(got, ref, atol=8e-5)
+    exact = np.load("datasets/toy/1_tumor/s2.npy")           # --save_npy: the unquantised rows
+    assert exact.dtype == np.float32 and exact.shape == (3, 512)
+    np.testing.assert_allclose(exact, ref, atol=3e-5)
+    np.testing.assert_allclose(got, exact, atol=5.1e-5)  # half the '%.4f' CSV quantum + fp32 order effects
 
 
 def test_compute_feats_tree_concat(workdir):
