@@ -7,7 +7,9 @@ import ctypes
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libdsmil_hip.so")
+# DSMIL_NATIVE_LIB: file name of an alternative in-tree build next to this module (profiling /
+# experiment builds made by build.py --variant, e.g. libdsmil_hip_expt.so); default = the product build
+LIB_PATH = os.path.join(PKG_DIR, os.path.basename(os.environ.get("DSMIL_NATIVE_LIB", "libdsmil_hip.so")))
 
 c_f32p = ctypes.c_void_p
 c_i64p = ctypes.c_void_p
@@ -38,6 +40,12 @@ SIGNATURES = {
     "dsmil_abi_version": (ctypes.c_int, []),
     "dsmil_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "dsmil_agg_mlp_form": (ctypes.c_int, []),
+    "dsmil_agg_packed_split_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
+    "dsmil_agg_pack_split": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "dsmil_agg_forward_packed": (ctypes.c_int, [c_f32p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int64,
+                                                ctypes.c_int64, ctypes.POINTER(AggParams), ctypes.c_void_p, c_f32p,
+                                                c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, ctypes.c_void_p,
+                                                ctypes.c_size_t, ctypes.c_void_p]),
     "dsmil_agg_shard_argmax": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.POINTER(AggParams), c_f32p, c_f32p,
                                               c_i64p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dsmil_agg_shard_attend": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int64, ctypes.POINTER(AggParams), c_f32p,

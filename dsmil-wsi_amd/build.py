@@ -2,6 +2,11 @@
 
 The shared object is git-ignored but travels to the GPU box with the gpurun snapshot.
 hipcc cross-compiles without a GPU, so this is also the driver's "does it build" check.
+
+    python dsmil-wsi_amd/build.py [--force]                       the product library
+    python dsmil-wsi_amd/build.py --variant expt -DDSMIL_EXPERIMENTS [-D...]
+        an instrumented build next to it (libdsmil_hip_expt.so, objects under csrc/_obj_expt/), selected at
+        run time with DSMIL_NATIVE_LIB=libdsmil_hip_expt.so — ablation knobs and tracing exist only there
 """
 import glob
 import os
@@ -13,47 +18,60 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB = os.path.join(PKG_DIR, "libdsmil_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("DSMIL_CFLAGS", "").split()
-# DSMIL_CFLAGS: extra compile flags for instrumented builds (e.g. -DDSMIL_TRACE, tools_stamp.py)
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
-        glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
 
 
-def build_native(force=False, verbose=True):
-    """Compile csrc/*.hip into libdsmil_hip.so if missing or older than its sources."""
-    if not force and not _stale():
-        return LIB
-    objs = []
+def build_native(force=False, verbose=True, variant=None, cflags=()):
+    """Compile csrc/*.hip into libdsmil_hip[_<variant>].so if missing or older than its sources."""
+    lib = LIB if not variant else os.path.join(PKG_DIR, f"libdsmil_hip_{variant}.so")
+    objdir = CSRC if not variant else os.path.join(CSRC, f"_obj_{variant}")
+    os.makedirs(objdir, exist_ok=True)
+    flags = BASE_FLAGS + list(cflags) + os.environ.get("DSMIL_CFLAGS", "").split()
+    stamp = os.path.join(objdir, ".flags")
+    if variant:  # a variant is rebuilt when its flag set changes
+        old = open(stamp).read() if os.path.exists(stamp) else None
+        if old != " ".join(flags):
+            force = True
+    newest_dep = max(os.path.getmtime(d) for d in _headers() + [os.path.abspath(__file__)])
+    objs, rebuilt = [], False
+    procs = []
     for src in sources():
-        obj = os.path.splitext(src)[0] + ".o"
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
-                os.path.getmtime(src), *[os.path.getmtime(h) for h in
-                                         glob.glob(os.path.join(CSRC, "*.h")) +
-                                         glob.glob(os.path.join(ROOT, "include", "*.h"))]):
-            cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_dep):
+            cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            procs.append((cmd, subprocess.Popen(cmd)))   # the translation units compile side by side
+            rebuilt = True
         objs.append(obj)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
-    if verbose:
-        print("[build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return LIB
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    if rebuilt or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    if variant:
+        open(stamp, "w").write(" ".join(flags))
+    return lib
 
 
 if __name__ == "__main__":
-    build_native(force="--force" in sys.argv)
-    print(LIB)
+    argv = sys.argv[1:]
+    variant = None
+    if "--variant" in argv:
+        i = argv.index("--variant")
+        variant = argv[i + 1]
+        del argv[i:i + 2]
+    extra = [a for a in argv if a.startswith("-D") or a.startswith("-f") or a.startswith("-m")]
+    print(build_native(force="--force" in argv, variant=variant, cflags=extra))

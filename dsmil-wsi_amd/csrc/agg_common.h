@@ -122,9 +122,17 @@ struct AttendArgs {
     float* part_ml;     // [slots, C, 2]
     float* part_B;      // [slots, C, Kv]
     int K, Kv, C, nonlinear;
-    int expt;  // DSMIL_EXPT debugging knob (0 in production): ablation switches for profiling
+    int expt;  // ablation switches of -DDSMIL_EXPERIMENTS builds (DSMIL_EXPT); always 0 in the product build
     int bag0;  // first bag of this launch (chunked pipelining over bags)
 };
+
+// Ablation / tracing branches exist only in experiment builds (DSMIL_CFLAGS=-DDSMIL_EXPERIMENTS): the
+// product kernels carry none of them.
+#ifdef DSMIL_EXPERIMENTS
+#define DSMIL_EXPT_ON(a, bit) (((a).expt & (bit)) != 0)
+#else
+#define DSMIL_EXPT_ON(a, bit) false
+#endif
 
 // --------------------------------------------------------------------------------------------
 // attend_tail: everything behind the query MLP, shared by the fp32 and bf16 kernels.  Q holds
@@ -211,7 +219,7 @@ __device__ __forceinline__ void attend_tail(const AttendArgs& a, const f32x16 (&
         }
         const float pp0 = p0 * f0, pp1 = p1 * f1;  // weights relative to the BLOCK max
         // ---- weighted value sum: Bpart[c][k] = sum_n p[n][c] * V[n][k], 512 k per sweep
-        for (int k0 = 0; k0 < ((a.expt & 1) ? 0 : Kv); k0 += 512) {
+        for (int k0 = 0; k0 < (DSMIL_EXPT_ON(a, 1) ? 0 : Kv); k0 += 512) {
             f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
             const int ka = k0 + lane * 4, kb = ka + 256;
             // VEC = 4: unconditional loads from a clamped column (a lane past Kv accumulates junk it

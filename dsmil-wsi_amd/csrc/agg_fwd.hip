@@ -408,7 +408,7 @@ __device__ __forceinline__ void attend_tile(const AttendArgs& a, int bag, int ti
     const long long Nb = a.offsets[bag + 1] - off0;
     const long long row0 = (long long)tile * BM;
     const long long slot = off0 / BM + bag + tile;
-    if (a.expt & 4) {  // ablation knob (DSMIL_EXPT): stop after the MLP, keep the accumulators live
+    if (DSMIL_EXPT_ON(a, 4)) {  // experiment builds: stop after the MLP, keep the accumulators live
         float keep = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend_spl
     }
     const long long off0 = a.offsets[bag];
     const long long Nb = a.offsets[bag + 1] - off0;
-    if (a.expt & 4) {  // ablation knob (DSMIL_EXPT): stop after the MLP, keep the accumulators live
+    if (DSMIL_EXPT_ON(a, 4)) {  // experiment builds: stop after the MLP, keep the accumulators live
         float keep = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -766,9 +766,20 @@ struct WsLayout {
 };
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Experiment builds (-DDSMIL_EXPERIMENTS) read ablation / geometry knobs from the environment, once per
+// process; the product build has none of them.
+#ifdef DSMIL_EXPERIMENTS
+int expt_env(const char* name) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+#endif
+
 int pick_nw(int n_bags, long long total_rows) {
-    static const int force = getenv("DSMIL_NW") ? atoi(getenv("DSMIL_NW")) : 0;  // experiments only
+#ifdef DSMIL_EXPERIMENTS
+    static const int force = expt_env("DSMIL_NW");
     if (force == 8 || force == 4 || force == 1) return force;
+#endif
     // 128-row workgroups (4 waves) once they alone give >= 2 workgroups per CU; otherwise
     // 32-row single-wave workgroups so that a lone bag still spreads over the chip.
     const long long tiles128 = total_rows / 128 + n_bags;
@@ -815,14 +826,17 @@ int launch_attend_split(const AttendArgs& a, long long max_rows, int n_bags, hip
     constexpr int BM = NW * 32;
     size_t lds = VEC == 4 ? (size_t)(3 * S3_CHUNK_F4 * 4 + 2 * BM * 32) * sizeof(float)
                           : (size_t)(2 * S3_CHUNK_F4 * 4 + 2 * BM * LDK) * sizeof(float);
-    if (const char* e = getenv("DSMIL_LDS_PAD")) lds += (size_t)atoi(e);  // experiments: force 1 block/CU
+#ifdef DSMIL_EXPERIMENTS
+    static const int lds_pad = expt_env("DSMIL_LDS_PAD");  // force 1 block/CU
+    lds += (size_t)lds_pad;
+#endif
     static bool attr_done = false;
     if (!attr_done) {
-        if (getenv("DSMIL_EXPT")) {
-            int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_query_attend_split<NW, VEC, NP>, NW * 64, lds);
-            fprintf(stderr, "[dsmil] k_query_attend_split<%d,%d,%d>: lds %zu B, %d blocks/CU\n", NW, VEC, NP, lds, nb);
-        }
+#ifdef DSMIL_EXPERIMENTS
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_query_attend_split<NW, VEC, NP>, NW * 64, lds);
+        fprintf(stderr, "[dsmil] k_query_attend_split<%d,%d,%d>: lds %zu B, %d blocks/CU\n", NW, VEC, NP, lds, nb);
+#endif
         (void)hipFuncSetAttribute((const void*)k_query_attend_split<NW, VEC, NP>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
@@ -834,14 +848,17 @@ int launch_attend_split(const AttendArgs& a, long long max_rows, int n_bags, hip
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
-// DSMIL_MLP = f32 | s9 | s6: which MFMA form the fp32 query MLP uses (see agg_split.h)
+// Which MFMA form the fp32 query MLP uses (see agg_split.h).  Default: 6 plane products — the three left
+// out are together below 2^-20 of |x*w|, i.e. below the fp32 accumulation rounding the reference's own
+// 512-long dot products carry (tests/accuracy_report.py: identical measured error for 0 / 9 / 6).
+// DSMIL_MLP = s9 | f32 selects the bit-exact-product forms; read once per process.
 int mlp_mode() {
     static const int mode = [] {
         const char* e = getenv("DSMIL_MLP");
-        if (!e) return 9;
+        if (!e) return 6;
         if (!strcmp(e, "f32")) return 0;
-        if (!strcmp(e, "s6")) return 6;
-        return 9;
+        if (!strcmp(e, "s9")) return 9;
+        return 6;
     }();
     return mode;
 }
@@ -918,7 +935,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
                             int32_t n_bags, int64_t total_rows, int64_t max_rows, const dsmil_agg_params* p,
                             const void* packed_bf16, bool bf16, const float* classes_in, float* classes_out,
                             float* A, float* B, float* pred, int64_t* idx, void* ws, size_t ws_bytes,
-                            void* stream, const ShardCtl& sh = ShardCtl()) {
+                            void* stream, const ShardCtl& sh = ShardCtl(), const void* packed_split = nullptr) {
     if (!feats || !p || !ws) return DSMIL_E_INVALID;
     if (sh.phase == 0 && (!offsets || !A || !B || !pred || !idx)) return DSMIL_E_INVALID;
     if (sh.phase == 1 && (!classes_out || !idx || !sh.best_val)) return DSMIL_E_INVALID;
@@ -965,7 +982,12 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     const bool w4 = (K % 4 == 0) && (((uintptr_t)p->q0_w | (uintptr_t)p->fc_w) % 16 == 0);
     AttendArgs a{feats, vals, (const bf16_t*)packed_bf16, offsets, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, A,
                  part_ml, part_B, K, Kv, C, p->nonlinear, 0, 0};
-    if (const char* e = getenv("DSMIL_EXPT")) a.expt = atoi(e);
+#ifdef DSMIL_EXPERIMENTS
+    static const int expt = expt_env("DSMIL_EXPT"), logits_old = expt_env("DSMIL_LOGITS_OLD");
+    a.expt = expt;
+#else
+    constexpr int logits_old = 0;
+#endif
     {
         // Tried and rejected here (round 1, numbers in DESIGN.md §3): (a) chunking the batch and running
         // chunk c+1's HBM-bound logits on a helper stream under chunk c's MFMA-bound attend, and (b) one
@@ -976,14 +998,14 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         dim3 grid((unsigned)((max_rows + R0 - 1) / R0), (unsigned)nb);
         if (sh.phase == 2) {}  // the caller already knows the bag-wide critical rows
         else if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
-        else if (bf16 && (K % 8 == 0) && !getenv("DSMIL_LOGITS_OLD")) {
+        else if (bf16 && (K % 8 == 0) && !logits_old) {
             const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 63) / 64 + 1) * 64) * sizeof(float);
             if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, bf16_t>), grid, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
             else hipLaunchKernelGGL((k_logits_stream<1, bf16_t>), grid, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
         }
         else if (bf16 && w4) hipLaunchKernelGGL((k_logits_argmax<4, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
         else if (bf16) hipLaunchKernelGGL((k_logits_argmax<1, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
-        else if (v4 && !getenv("DSMIL_LOGITS_OLD")) {
+        else if (v4 && !logits_old) {
             const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 31) / 32 + 1) * 32) * sizeof(float);
             if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
             else hipLaunchKernelGGL((k_logits_stream<1, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
@@ -1011,7 +1033,9 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         // 3. query MLP on MFMA + scores + tile softmax + weighted value sum
         int rc;
         const int mode = (NW == 8) ? 0 : mlp_mode();
-        if (!bf16 && mode) {
+        if (!bf16 && mode && packed_split) {
+            a.wpk = (const bf16_t*)packed_split;  // the caller cut the weights once (dsmil_agg_pack_split)
+        } else if (!bf16 && mode) {
             const int nks = 2 * ((K + 31) / 32);
             bf16_t* wsplit = (bf16_t*)(w8 + L.wsplit);
             hipLaunchKernelGGL(k_pack_agg_split, dim3(64), dim3(256), 0, st, p->q0_w, p->nonlinear ? p->q2_w : nullptr, wsplit, K, nks);
@@ -1029,7 +1053,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         if (rc != DSMIL_OK) return rc;
     }
     // 4. combine (skipped under the stamp-trace knob, which leaves its stamps in A)
-    if (!(a.expt & 64)) {
+    if (!DSMIL_EXPT_ON(a, 64)) {
         dim3 grid((unsigned)L.nchunk_max, (unsigned)n_bags);
         if (Kv % 4 == 0)
             hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM, sh.ml_out);
@@ -1052,6 +1076,29 @@ int dsmil_agg_forward(const float* feats, const float* vals, const int64_t* offs
                       void* stream) {
     return agg_forward_impl(feats, vals, offsets, n_bags, total_rows, max_rows, p, nullptr, false, classes_in,
                             classes_out, A, B, pred, idx, ws, ws_bytes, stream);
+}
+
+size_t dsmil_agg_packed_split_bytes(int32_t K, int32_t nonlinear) {
+    if (K <= 0) return 0;
+    return (size_t)(2 * ((K + 31) / 32) + (nonlinear ? 8 : 0)) * S3_CHUNK_F4 * 16;
+}
+
+int dsmil_agg_pack_split(const float* q0_w, const float* q2_w, int32_t K, void* packed, void* stream) {
+    if (!q0_w || !packed || K <= 0) return DSMIL_E_INVALID;
+    if ((uintptr_t)packed % 16) return DSMIL_E_ALIGN;
+    hipLaunchKernelGGL(k_pack_agg_split, dim3(64), dim3(256), 0, (hipStream_t)stream, q0_w, q2_w, (bf16_t*)packed, K,
+                       2 * ((K + 31) / 32));
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
+int dsmil_agg_forward_packed(const float* feats, const float* vals, const int64_t* offsets,
+                             int32_t n_bags, int64_t total_rows, int64_t max_rows,
+                             const dsmil_agg_params* p, const void* packed_split, const float* classes_in,
+                             float* classes_out, float* A, float* B, float* pred, int64_t* idx, void* ws,
+                             size_t ws_bytes, void* stream) {
+    if (packed_split && ((uintptr_t)packed_split % 16)) return DSMIL_E_ALIGN;
+    return agg_forward_impl(feats, vals, offsets, n_bags, total_rows, max_rows, p, nullptr, false, classes_in,
+                            classes_out, A, B, pred, idx, ws, ws_bytes, stream, ShardCtl(), packed_split);
 }
 
 int dsmil_agg_shard_argmax(const float* feats, int64_t rows, const dsmil_agg_params* p, float* classes_out,

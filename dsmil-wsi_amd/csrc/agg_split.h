@@ -301,7 +301,7 @@ __device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag,
     unsigned* stamp = reinterpret_cast<unsigned*>(a.scores + (off0 + row0) * (long long)a.C);
     int nstamp = 0;
     auto STAMP = [&]() {
-        if ((a.expt & 64) && tid == 0 && nstamp < 62) {
+        if (DSMIL_EXPT_ON(a, 64) && tid == 0 && nstamp < 62) {
             const unsigned long long tt = __builtin_readcyclecounter();
             stamp[2 * nstamp] = (unsigned)tt;
             stamp[2 * nstamp + 1] = (unsigned)(tt >> 32);

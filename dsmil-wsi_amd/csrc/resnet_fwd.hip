@@ -35,6 +35,17 @@
 
 namespace {
 
+// Experiment builds (-DDSMIL_EXPERIMENTS) read ablation knobs from the environment, once per process.
+#ifdef DSMIL_EXPERIMENTS
+inline int expt_env(const char* name) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+#define DSMIL_WEXPT_ON(a, bit) (((a).expt & (bit)) != 0)
+#else
+#define DSMIL_WEXPT_ON(a, bit) false
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoArgs a) {
     // whole iteration ago) and the global loads of raw(cc+3) into the same registers.
     for (int cc = 0; cc < nchunks; ++cc) {
         const bool more = cc + 1 < nchunks, more2 = cc + 2 < nchunks, more3 = cc + 3 < nchunks;   // block-uniform
-        if (more && !(a.expt & 1)) transform(cc + 1);
+        if (more && !DSMIL_WEXPT_ON(a, 1)) transform(cc + 1);
         const float* vb = sV + (cc & 1) * WTILE + vfo;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -619,15 +630,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(WinoArgs a) {
             const f32x4 w = ub[p];
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], w[j], acc[p], 0, 0, 0);
-            if (more && !(a.expt & 4)) { ub[p] = *reinterpret_cast<const f32x4*>(up[p]); up[p] += ustep; }
+            if (more && !DSMIL_WEXPT_ON(a, 4)) { ub[p] = *reinterpret_cast<const f32x4*>(up[p]); up[p] += ustep; }
         }
-        if (!(a.expt & 2)) {
+        if (!DSMIL_WEXPT_ON(a, 2)) {
             if (more2) raw_write(cc + 2);   // raw[cc&1] was consumed by transform(cc) an iteration ago
             if (more3) raw_load(cc + 3);
         }
         __syncthreads();
     }
-    if (a.expt & 8) {  // ablation: no epilogue
+    if (DSMIL_WEXPT_ON(a, 8)) {  // ablation: no epilogue
         float keep = 0.f;
 #pragma unroll
         for (int p = 0; p < 8; ++p)
@@ -1246,7 +1257,11 @@ const Arch* arch_of(int depth) {
 
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline bool use_wino(const ConvSpec& s) {  // 3x3 stride-1 convs run as Winograd F(2x2,3x3)
-    static const int off = getenv("DSMIL_NO_WINO") ? atoi(getenv("DSMIL_NO_WINO")) : 0;
+#ifdef DSMIL_EXPERIMENTS
+    static const int off = expt_env("DSMIL_NO_WINO");
+#else
+    constexpr int off = 0;
+#endif
     return !off && s.ks == 3 && s.stride == 1 && s.pad == 1 && s.cin % WK == 0 && s.cout % 64 == 0;
 }
 // DSMIL_WINO = s3 (default) | f32: which MFMA form the Winograd convs use (read once per process; the packed
@@ -1379,16 +1394,20 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
         wa.B = B; wa.H = H; wa.W = W; wa.C = s.cin; wa.Cout = s.cout;
         wa.TY = (H + 1) / 2; wa.TX = (W + 1) / 2;
         wino_shape(B, wa.TY, wa.TX, wa.IB, wa.TYB, wa.TXB);
-        static const int wexpt = getenv("DSMIL_WINO_EXPT") ? atoi(getenv("DSMIL_WINO_EXPT")) : 0;
+#ifdef DSMIL_EXPERIMENTS
+        static const int wexpt = expt_env("DSMIL_WINO_EXPT");
         wa.expt = wexpt;
+#else
+        wa.expt = 0;
+#endif
         wa.nby = (wa.TY + wa.TYB - 1) / wa.TYB; wa.nbx = (wa.TX + wa.TXB - 1) / wa.TXB; wa.PB = wa.nby * wa.nbx;
         const size_t lds = wino_s3() ? (size_t)(SV_DW + WRAW_MAX * SRLD) * sizeof(float)
                                      : (size_t)(2 * WTILE + 2 * WRAW_MAX * WLD) * sizeof(float);
         dim3 grid((unsigned)(((B + wa.IB - 1) / wa.IB) * wa.PB), (unsigned)(s.cout / 64));
         const int slot = dsmil_prof::begin(dsmil_prof::CH_CONV, st);
         if (wino_s3()) {
-            static const bool dbg = getenv("DSMIL_WINO_DEBUG") != nullptr;
-            if (dbg) {
+#ifdef DSMIL_EXPERIMENTS
+            {
                 static bool once = false;
                 if (!once) {
                     once = true;
@@ -1398,6 +1417,7 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
                     fprintf(stderr, "[dsmil] k_conv_wino_s3: lds %zu B, %d / %d workgroups per CU\n", lds, nb0, nb1);
                 }
             }
+#endif
             if (in_mean) hipLaunchKernelGGL((k_conv_wino_s3<true>), grid, dim3(256), lds, st, wa);
             else hipLaunchKernelGGL((k_conv_wino_s3<false>), grid, dim3(256), lds, st, wa);
         }
@@ -1422,7 +1442,11 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
     // tile choice: 128x64 for Cout = 64; 128x128 while that yields >= 4 workgroups per CU;
     // 64x64 (finer units, less tail quantisation) for the small late-layer maps
     const long long blocks128 = ((a.Mtot + 127) / 128) * (s.cout / 128 > 0 ? s.cout / 128 : 1);
-    static const int expt = getenv("DSMIL_CONV_EXPT") ? atoi(getenv("DSMIL_CONV_EXPT")) : 0;
+#ifdef DSMIL_EXPERIMENTS
+    static const int expt = expt_env("DSMIL_CONV_EXPT");
+#else
+    constexpr int expt = 0;
+#endif
     if (s.cout == 64 && (expt & 1)) {
         const size_t lds = (size_t)(128 * LDK + 64 * LDK) * 4;
         dim3 grid((unsigned)((a.Mtot + 127) / 128), 1);

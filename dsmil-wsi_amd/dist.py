@@ -119,30 +119,46 @@ def sharded_bag_forward(milnet, feats_local, row_offset, group=None, gather=_gat
     w["fc_w"], w["fc_b"] = lin.weight.detach(), lin.bias.detach()
     C = w["fcc_w"].shape[0]
     native = x.is_cuda
+    ar = torch.arange(C, device=x.device)
+    lanes = 8 // x.element_size()   # float lanes that carry one int64 index, bit for bit
     with torch.no_grad():
-        # ---- 1. local instance logits and the shard's best row per class
-        if native:
-            classes, best_val, best_idx = ops.agg_shard_argmax(x, w, nonlinear=bc.nonlinear)
+        # ---- 1. local instance logits and the shard's best row per class.  A rank with NO rows (a bag
+        #         smaller than the world size) contributes (-inf, index past every real row, zero row).
+        if n_local == 0:
+            classes = x.new_zeros((0, C))
+            best_val = x.new_full((C,), float("-inf"))
+            gbest = torch.full((C,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=x.device)
+            rows = x.new_zeros((C, K))
         else:
-            classes = F.linear(x, w["fc_w"], w["fc_b"])
-            best_val, best_idx = classes.max(dim=0)
-            best_idx = torch.argmax(classes, dim=0)   # lowest index on ties
-            best_val = classes[best_idx, torch.arange(C)]
-        rows = x[best_idx]                                                    # [C,K]
-        msg = torch.cat([best_val[:, None], (best_idx + row_offset).to(x.dtype)[:, None], rows], dim=1)
-        allmsg = torch.stack(gather(msg, group))                              # [R, C, 2+K]
-        vals_, gidx = allmsg[:, :, 0], allmsg[:, :, 1]
+            if native:
+                classes, best_val, best_idx = ops.agg_shard_argmax(x, w, nonlinear=bc.nonlinear)
+            else:
+                classes = F.linear(x, w["fc_w"], w["fc_b"])
+                best_idx = torch.argmax(classes, dim=0)   # lowest index on ties
+                best_val = classes[best_idx, ar]
+            gbest = best_idx.to(torch.int64) + int(row_offset)
+            rows = x[best_idx]                                                # [C,K]
+        # one message per class: best logit | global row index (int64 bits in float lanes: exact for any
+        # bag size, a float32 VALUE would round above 2^24 rows) | that feature row
+        msg = torch.cat([best_val[:, None], gbest.contiguous().view(x.dtype).view(C, lanes), rows], dim=1)
+        allmsg = torch.stack(gather(msg, group))                              # [R, C, 1+lanes+K]
+        vals_ = allmsg[:, :, 0]
+        gidx = allmsg[:, :, 1:1 + lanes].contiguous().view(torch.int64).view(allmsg.shape[0], C)
         # bag-wide winner per class: larger value, then lower global index (dsmil.py:52 + our tie rule)
         best_r = torch.zeros(C, dtype=torch.long, device=x.device)
         for r in range(1, allmsg.shape[0]):
-            cur_v = vals_[best_r, torch.arange(C)]
-            cur_i = gidx[best_r, torch.arange(C)]
+            cur_v = vals_[best_r, ar]
+            cur_i = gidx[best_r, ar]
             better = (vals_[r] > cur_v) | ((vals_[r] == cur_v) & (gidx[r] < cur_i))
             best_r = torch.where(better, torch.full_like(best_r, r), best_r)
-        crit_rows = allmsg[best_r, torch.arange(C), 2:].contiguous()          # [C,K]
-        idx = gidx[best_r, torch.arange(C)].to(torch.int64)
+        crit_rows = allmsg[best_r, ar, 1 + lanes:].contiguous()               # [C,K]
+        idx = gidx[best_r, ar]
         # ---- 2. this shard's attention against the bag-wide critical rows
-        if native:
+        if n_local == 0:
+            A_un = x.new_zeros((0, C))
+            ml = torch.stack([x.new_full((C,), float("-inf")), x.new_zeros((C,))], dim=1)
+            B_un = x.new_zeros((C, K))
+        elif native:
             A_un, ml, B_un = ops.agg_shard_attend(x, w, crit_rows, nonlinear=bc.nonlinear)
         else:
             q = bc.q

@@ -55,21 +55,28 @@ class IClassifier(nn.Module):
 
     def forward(self, x):
         fe = self.feature_extractor
-        if x.dtype == torch.uint8:
-            # decoded images, uint8 NHWC [B,H,W,3] (new ingest path): on the GPU the
-            # ToTensor step is fused into the native stem; elsewhere it is applied here, exactly as
-            # VF.to_tensor does (compute_feats.py:35-39)
-            if x.dim() != 4 or x.shape[3] != 3:
-                raise ValueError(f"uint8 patches must be NHWC [B,H,W,3], got {tuple(x.shape)}")
-            if not x.is_cuda or resnet_convs_of(fe) is None:
-                x = x.permute(0, 3, 1, 2).to(torch.float32).div(255)
+        if x.dtype == torch.uint8 and (x.dim() != 4 or x.shape[3] != 3):
+            # decoded images, uint8 NHWC [B,H,W,3] (new ingest path)
+            raise ValueError(f"uint8 patches must be NHWC [B,H,W,3], got {tuple(x.shape)}")
+        grad_on = torch.is_grad_enabled()
+        trunk = None
         if x.is_cuda and x.dtype in (torch.float32, torch.uint8) and x.dim() == 4 and not (
-                torch.is_grad_enabled() and any(p.requires_grad for p in fe.parameters())):
-            # ResNet-18 + InstanceNorm with fc = Identity (ours or torchvision's, compute_feats.py:157,170):
-            # features and instance logits come from one native launch sequence
+                grad_on and (x.requires_grad or any(p.requires_grad for p in fe.parameters()))):
+            # ResNet-18/34 + InstanceNorm / frozen BatchNorm with fc = Identity (ours or torchvision's,
+            # compute_feats.py:157,170): the trunk runs in one native launch sequence
             trunk = resnet_convs_of(fe)
-            if trunk is not None:
+        if trunk is not None:
+            head_trains = grad_on and (self.fc.weight.requires_grad or self.fc.bias.requires_grad)
+            if not head_trains:
+                # features and instance logits from the same launch sequence (uint8: ToTensor fused in the stem)
                 return ops.resnet18in_forward(x, trunk[0], self.fc.weight, self.fc.bias, bn_norms=trunk[1])
+            # frozen trunk + trainable linear head (what compute_feats.py:168-173 / attention_map.py set up):
+            # the reference differentiates through self.fc (dsmil.py:24), so the head goes through autograd
+            feats, _ = ops.resnet18in_forward(x, trunk[0], bn_norms=trunk[1])
+            return feats, _FCFunction.apply(feats, self.fc.weight, self.fc.bias)
+        if x.dtype == torch.uint8:
+            # no native stem will take the bytes: apply VF.to_tensor here (compute_feats.py:35-39)
+            x = x.permute(0, 3, 1, 2).to(torch.float32).div(255)
         feats = fe(x)
         feats = feats.view(feats.shape[0], -1)
         if feats.is_cuda:
@@ -200,9 +207,10 @@ class _FCFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        gx = g.mm(w) if ctx.needs_input_grad[0] else None
-        gw = g.t().mm(x) if ctx.needs_input_grad[1] else None
-        gb = g.sum(0) if ctx.needs_input_grad[2] else None
+        g32, x32 = g.float(), x.float()   # bf16-storage rows: gradients accumulate in f32 like the forward
+        gx = g32.mm(w.float()).to(x.dtype) if ctx.needs_input_grad[0] else None
+        gw = g32.t().mm(x32).to(w.dtype) if ctx.needs_input_grad[1] else None
+        gb = g32.sum(0).to(w.dtype) if ctx.needs_input_grad[2] else None
         return gx, gw, gb
 
 

@@ -18,6 +18,35 @@ _ws_cache = {}
 _off_cache = collections.OrderedDict()
 
 
+class _LRU:
+    """Tiny keyed cache for derived device buffers (packed / folded weights).  Keys carry the device and
+    the (data_ptr, _version) of every source tensor; each entry also holds the sources themselves, so a
+    freed tensor's address can never come back as a different model's weight while its entry lives.
+    A handful of entries: tree mode alternates two embedders, DDP-less multi-device processes hold one
+    model per device."""
+
+    def __init__(self, cap=8):
+        self.cap = cap
+        self.d = collections.OrderedDict()
+
+    def get(self, key):
+        v = self.d.get(key)
+        if v is not None:
+            self.d.move_to_end(key)
+        return v
+
+    def put(self, key, value):
+        self.d[key] = value
+        self.d.move_to_end(key)
+        while len(self.d) > self.cap:
+            self.d.popitem(last=False)
+        return value
+
+
+def _tkey(t):
+    return None if t is None else (t.data_ptr(), t._version)
+
+
 def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -76,7 +105,8 @@ def fc_forward(feats, fc_w, fc_b):
     return out
 
 
-_bf16_cache = {}
+_bf16_cache = _LRU()
+_split_cache = _LRU()
 
 
 def _bf16_params(w, nonlinear, dev):
@@ -85,10 +115,10 @@ def _bf16_params(w, nonlinear, dev):
     parameter set (data_ptr, _version); the entry keeps the source tensors alive so that a freed
     parameter's address can never be mistaken for a new one with the same version count."""
     names = ("fc_w", "fc_b", "q0_w", "q0_b", "q2_w", "q2_b", "fcc_w", "fcc_b")
-    key = tuple((w[k].data_ptr(), w[k]._version) if w.get(k) is not None else None for k in names)
-    ent = _bf16_cache.get(str(dev))
-    if ent is not None and ent[0] == key:
-        return ent[1], ent[2]
+    key = (str(dev), bool(nonlinear)) + tuple(_tkey(w.get(k)) for k in names)
+    ent = _bf16_cache.get(key)
+    if ent is not None:
+        return ent[0], ent[1]
     r = {k: (w[k].detach().to(torch.bfloat16).to(torch.float32).contiguous() if w.get(k) is not None else None)
          for k in names}
     L = _native.lib()
@@ -98,8 +128,28 @@ def _bf16_params(w, nonlinear, dev):
         rc = L.dsmil_agg_pack_bf16(_ptr(r["q0_w"]), _ptr(r["q2_w"] if nonlinear else None), K, _ptr(packed),
                                    _stream(dev))
     _native.check(rc, "dsmil_agg_pack_bf16")
-    _bf16_cache[str(dev)] = (key, r, packed, [w.get(k) for k in names])
+    _bf16_cache.put(key, (r, packed, [w.get(k) for k in names]))
     return r, packed
+
+
+def _split_params(q0_w, q2_w, nonlinear, dev):
+    """fp32 path, MFMA forms 6 / 9: the query weights cut into three bf16 planes in MFMA-fragment order
+    (dsmil_agg_pack_split), prepared once per weight set; None for form 0 (f32 MFMA reads the weights as
+    they are)."""
+    L = _native.lib()
+    if L.dsmil_agg_mlp_form() == 0:
+        return None
+    key = (str(dev), bool(nonlinear), _tkey(q0_w), _tkey(q2_w) if nonlinear else None)
+    ent = _split_cache.get(key)
+    if ent is not None:
+        return ent[0]
+    K = q0_w.shape[1]
+    packed = torch.empty(L.dsmil_agg_packed_split_bytes(K, 1 if nonlinear else 0), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.dsmil_agg_pack_split(_ptr(q0_w), _ptr(q2_w if nonlinear else None), K, _ptr(packed), _stream(dev))
+    _native.check(rc, "dsmil_agg_pack_split")
+    _split_cache.put(key, (packed, [q0_w, q2_w]))
+    return packed
 
 
 def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, offsets=None):
@@ -165,12 +215,13 @@ def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, o
                                           _ptr(A), _ptr(B), _ptr(pred), _ptr(idx), _ptr(ws), ws.numel(),
                                           _stream(dev))
         else:
-            rc = L.dsmil_agg_forward(_ptr(feats), _ptr(vals), _ptr(off), n_bags, total, max(lengths),
-                                     ctypes.byref(p), _ptr(classes_in),
-                                     _ptr(classes if classes_in is None else None),
-                                     _ptr(A), _ptr(B), _ptr(pred), _ptr(idx), _ptr(ws), ws.numel(),
-                                     _stream(dev))
-    _native.check(rc, "dsmil_agg_forward_bf16" if bf16 else "dsmil_agg_forward")
+            split = _split_params(keep[2], keep[4], nonlinear, dev)
+            rc = L.dsmil_agg_forward_packed(_ptr(feats), _ptr(vals), _ptr(off), n_bags, total, max(lengths),
+                                            ctypes.byref(p), _ptr(split), _ptr(classes_in),
+                                            _ptr(classes if classes_in is None else None),
+                                            _ptr(A), _ptr(B), _ptr(pred), _ptr(idx), _ptr(ws), ws.numel(),
+                                            _stream(dev))
+    _native.check(rc, "dsmil_agg_forward_bf16" if bf16 else "dsmil_agg_forward_packed")
     del keep
     return classes, pred, A, B, idx
 
@@ -275,7 +326,7 @@ def agg_backward(feats, w, A, B, idx, g_pred, g_classes=None, g_A=None, g_B=None
 # ---------------------------------------------------------------------------------------------
 # patch embedder (ResNet-18 + InstanceNorm) — compute_feats.py:146-170,211 / dsmil.py:21-25
 # ---------------------------------------------------------------------------------------------
-_pack_cache = {}
+_pack_cache = _LRU()
 
 
 def resnet_conv_shapes(depth):
@@ -311,11 +362,11 @@ def _packed_resnet_weights(convs, depth=18):
     Winograd-transformed or [tap][Cout][Cin]).  Cached per weight set; rebuilt when any tensor was
     modified in place (``_version``), re-assigned or moved (``data_ptr``).  The entry keeps the source
     tensors alive: a freed weight's address cannot come back as a different model's weight."""
-    key = (depth,) + tuple((w.data_ptr(), w._version) for w in convs)
     dev = convs[0].device
-    ent = _pack_cache.get(str(dev))
-    if ent is not None and ent[0] == key:
-        return ent[1]
+    key = (str(dev), depth) + tuple(_tkey(w) for w in convs)
+    ent = _pack_cache.get(key)
+    if ent is not None:
+        return ent[0]
     L = _native.lib()
     buf = torch.empty(L.dsmil_resnet_packed_bytes(depth) // 4, dtype=torch.float32, device=dev)
     keep = [_f32c(w.detach(), "conv weight") for w in convs]
@@ -323,22 +374,21 @@ def _packed_resnet_weights(convs, depth=18):
     with torch.cuda.device(dev):
         rc = L.dsmil_resnet_pack(depth, arr, _ptr(buf), _stream(dev))
     _native.check(rc, "dsmil_resnet_pack")
-    _pack_cache[str(dev)] = (key, buf, keep)
+    _pack_cache.put(key, (buf, keep, list(convs)))
     return buf
 
 
-_bn_cache = {}
+_bn_cache = _LRU()
 
 
 def _folded_bn(norms, dev):
     """Fold the trunk's eval-mode BatchNorm2d modules into y = (x - m) * r, concatenated in conv order (cached on the
     parameter / buffer versions)."""
-    key = tuple((id(n), n.running_mean._version, n.running_var._version,
-                 None if n.weight is None else n.weight._version,
-                 None if n.bias is None else n.bias._version) for n in norms)
-    hit = _bn_cache.get("k")
-    if hit is not None and hit[0] == key:
-        return hit[1], hit[2]
+    key = (str(dev),) + tuple((id(n), _tkey(n.running_mean), _tkey(n.running_var), _tkey(n.weight), _tkey(n.bias), n.eps)
+                              for n in norms)
+    hit = _bn_cache.get(key)
+    if hit is not None:
+        return hit[0], hit[1]
     ms, rs = [], []
     for n in norms:
         var = n.running_var.detach().to(dev, torch.float64)
@@ -352,7 +402,7 @@ def _folded_bn(norms, dev):
         rs.append(r)
     m = torch.cat(ms).to(torch.float32).contiguous()
     r = torch.cat(rs).to(torch.float32).contiguous()
-    _bn_cache["k"] = (key, m, r, list(norms))   # the modules stay alive: their ids stay unique
+    _bn_cache.put(key, (m, r, list(norms)))   # the modules stay alive: their ids stay unique
     return m, r
 
 

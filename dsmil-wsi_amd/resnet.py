@@ -109,23 +109,56 @@ def _is_plain_instance_norm(m):
     return isinstance(m, nn.InstanceNorm2d) and not m.affine and not m.track_running_stats and abs(m.eps - 1e-5) < 1e-12
 
 
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+def _conv_is(m, k, stride, pad):
+    """A plain bias-free nn.Conv2d with exactly the geometry the native kernels implement."""
+    return (isinstance(m, nn.Conv2d) and m.bias is None and m.groups == 1 and _pair(m.kernel_size) == (k, k)
+            and _pair(m.stride) == (stride, stride) and _pair(m.padding) == (pad, pad) and _pair(m.dilation) == (1, 1)
+            and getattr(m, "padding_mode", "zeros") == "zeros")
+
+
 def _resnet18_parts(model):
-    """(convs, norms) of a structurally BasicBlock ResNet-18 / ResNet-34 module (ours or torchvision's),
-    else None."""
+    """(convs, norms) of a structurally STOCK BasicBlock ResNet-18 / ResNet-34 module (ours or torchvision's),
+    else None.  Besides the tensor shapes, every conv's kernel / stride / padding / dilation / groups / bias,
+    the 3x3-s2-p1 max-pool, the ReLUs' presence and the global average pool are checked: a modified trunk
+    (maxpool = Identity, a changed stride — common in SimCLR variants) must take the torch graph, not be
+    silently computed as the stock architecture."""
     try:
+        if not _conv_is(model.conv1, 7, 2, 3):
+            return None
+        mp = model.maxpool
+        if not (isinstance(mp, nn.MaxPool2d) and _pair(mp.kernel_size) == (3, 3) and _pair(mp.stride) == (2, 2)
+                and _pair(mp.padding) == (1, 1) and _pair(mp.dilation) == (1, 1) and not mp.ceil_mode):
+            return None
+        ap = model.avgpool
+        if not (isinstance(ap, nn.AdaptiveAvgPool2d) and _pair(ap.output_size) == (1, 1)):
+            return None
+        if not isinstance(getattr(model, "relu", None), nn.ReLU):
+            return None
         convs = [model.conv1.weight]
         norms = [model.bn1]
         for li in (1, 2, 3, 4):
             layer = getattr(model, f"layer{li}")
-            for blk in layer:
+            for bi, blk in enumerate(layer):
                 if not hasattr(blk, "conv2") or hasattr(blk, "conv3"):
+                    return None
+                stride = 2 if (li > 1 and bi == 0) else 1
+                if not (_conv_is(blk.conv1, 3, stride, 1) and _conv_is(blk.conv2, 3, 1, 1)
+                        and isinstance(getattr(blk, "relu", None), nn.ReLU)):
                     return None
                 convs += [blk.conv1.weight, blk.conv2.weight]
                 norms += [blk.bn1, blk.bn2]
                 if blk.downsample is not None:
+                    if len(blk.downsample) != 2 or not _conv_is(blk.downsample[0], 1, stride, 0):
+                        return None
                     convs.append(blk.downsample[0].weight)
                     norms.append(blk.downsample[1])
-    except AttributeError:
+                elif stride != 1:
+                    return None
+    except (AttributeError, TypeError):
         return None
     if ops.resnet_depth_of(convs) is None:
         return None

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSMIL_ABI_VERSION 1
+#define DSMIL_ABI_VERSION 2
 #define DSMIL_Q_DIM 128 /* query width hard-coded at dsmil.py:31,33 */
 
 enum {
@@ -121,12 +121,27 @@ int dsmil_agg_shard_attend(const float* feats, const float* vals, int64_t rows,
                            float* ml, float* B_unnorm, void* ws, size_t ws_bytes, void* stream);
 
 /* Which MFMA form dsmil_agg_forward uses for the fp32 query MLP (dsmil.py:31-33,49):
- *   9 (default) — bf16 MFMA over exact three-plane cuts of both fp32 operands, all 9 plane products
- *                 (every fp32 product formed exactly, fp32 accumulate; csrc/agg_split.h)
- *   6           — the same with the three smallest plane products left out (env DSMIL_MLP=s6)
+ *   6 (default) — bf16 MFMA over exact three-plane cuts of both fp32 operands (csrc/agg_split.h), the six
+ *                 largest of the nine plane products; the three left out are together < 2^-20 of |x*w|,
+ *                 below the rounding an fp32 dot product of this length carries anyway
+ *   9           — all nine plane products: every fp32 product formed exactly (env DSMIL_MLP=s9)
  *   0           — v_mfma_f32_32x32x2_f32 (env DSMIL_MLP=f32)
  * The choice is read once per process from the environment variable DSMIL_MLP. */
 int dsmil_agg_mlp_form(void);
+
+/* The plane-cut query weights of forms 6 / 9 can be prepared ONCE per weight set instead of on every
+ * forward (BClassifier.q changes only at optimizer.step(), train_tcga.py:73): dsmil_agg_pack_split cuts
+ * q0_w [128,K] and q2_w [128,128] (NULL when nonlinear == 0) into `packed`
+ * (dsmil_agg_packed_split_bytes(K, nonlinear) bytes, 16-B aligned), and dsmil_agg_forward_packed is
+ * dsmil_agg_forward reading them from there (packed_split == NULL: cut into the workspace per call,
+ * exactly dsmil_agg_forward).  Ignored by form 0. */
+size_t dsmil_agg_packed_split_bytes(int32_t K, int32_t nonlinear);
+int dsmil_agg_pack_split(const float* q0_w, const float* q2_w, int32_t K, void* packed, void* stream);
+int dsmil_agg_forward_packed(const float* feats, const float* vals, const int64_t* offsets,
+                             int32_t n_bags, int64_t total_rows, int64_t max_rows,
+                             const dsmil_agg_params* p, const void* packed_split, const float* classes_in,
+                             float* classes_out, float* A, float* B, float* pred, int64_t* idx, void* ws,
+                             size_t ws_bytes, void* stream);
 
 /* FCLayer.forward alone (dsmil.py:10-12): classes[total_rows, C] = feats @ fc_w^T + fc_b. */
 int dsmil_fc_forward(const float* feats, int64_t total_rows, int32_t K, int32_t C,

@@ -15,6 +15,10 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+import dsmil  # noqa: E402,F401  the root shim registers the `dsmil_wsi_amd` package (the directory name
+#                          `dsmil-wsi_amd` is not importable by itself): tests may import it in any order / alone
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
