@@ -240,3 +240,113 @@ def test_instance_sharded_bag_native(tag, N, R):
         np.testing.assert_allclose(o[1].cpu().numpy(), full[1].cpu().numpy(), atol=2e-6)
         np.testing.assert_allclose(o[3].cpu().numpy(), full[3].cpu().numpy(), atol=2e-6)
     _cmp((classes, outs[0][1], A, outs[0][3]), ref[0], ref[1], ref[2], ref[3])
+
+
+# ---- shapes off the fast path and error paths --------------------------------------------------
+@pytest.mark.parametrize("N", [10000, 70000])
+def test_k_not_multiple_of_4_at_full_size(N):
+    """K = 166 (MUSK width): rows are not 16-B aligned, so the LDS-DMA kernels are out and the
+    register-staged forms run — at the BASELINE bag size and in the 4-wave launch, not only at N <= 333."""
+    p = load_weights("musk")
+    x = make_bag(9000 + N, N, 166)
+    ref = orc.milnet_forward(x, p, dtype="f64")
+    net = build_net("musk", "cuda")
+    with torch.no_grad():
+        out = net(torch.from_numpy(x).cuda())
+    _cmp(out, ref[0], ref[1], ref[2], ref[3], ref[4], np.argmax(out[0].cpu().numpy(), axis=0))
+
+
+def test_non_contiguous_and_offset_views_are_handled():
+    """A column slice of the stacked [N, K+C] bag tensor (train_tcga.py:63-64 `stacked[:, :feats_size]`) is
+    NOT contiguous, and a row slice starts at an address that is only 16-B aligned when K % 4 == 0: the
+    binding must hand the kernels a dense row-major copy (or the view itself when it is dense), never
+    compute on strided memory."""
+    net = build_net("tcga", "cuda")
+    stacked = torch.from_numpy(np.concatenate([make_bag(61, 3001, 512), np.ones((3001, 2), np.float32)], 1)).cuda()
+    view = stacked[:, :512]
+    assert not view.is_contiguous()
+    p = load_weights("tcga")
+    ref = orc.milnet_forward(view.cpu().numpy(), p, dtype="f64")
+    with torch.no_grad():
+        out = net(view)
+        out_rows = net(stacked[1:, :512].contiguous()[1:])   # dense, data_ptr offset by one row
+    _cmp(out, ref[0], ref[1], ref[2], ref[3])
+    ref2 = orc.milnet_forward(stacked[2:, :512].cpu().numpy(), p, dtype="f64")
+    _cmp(out_rows, ref2[0], ref2[1], ref2[2], ref2[3])
+
+
+def test_c_abi_rejects_misaligned_and_oversized_calls():
+    """Direct C-ABI calls: a workspace that is not 256-B aligned -> DSMIL_E_ALIGN, more than 65535 bags in
+    one call -> DSMIL_E_UNSUPPORTED (grid.y limit; callers split), a short workspace -> DSMIL_E_WORKSPACE,
+    an unaligned packed-weight buffer -> DSMIL_E_ALIGN.  Nothing is launched in any of these cases."""
+    import ctypes
+    import dsmil_wsi_amd._native as nat
+    from dsmil_wsi_amd import ops
+    L = nat.lib()
+    dev = torch.device("cuda")
+    wt = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in load_weights("c16").items()}
+    N, K, C = 256, 512, 1
+    x = torch.randn(N, K, device=dev)
+    keep = [wt[k] for k in ("fc_w", "fc_b", "q0_w", "q0_b", "q2_w", "q2_b", "fcc_w", "fcc_b")]
+    prm = nat.AggParams(*[t.data_ptr() for t in keep], K, K, C, 1)
+    off = ops.offsets_tensor([N], dev)
+    cls, A = torch.empty(N, C, device=dev), torch.empty(N, C, device=dev)
+    B, pred = torch.empty(1, C, K, device=dev), torch.empty(1, C, device=dev)
+    idx = torch.empty(1, C, dtype=torch.int64, device=dev)
+    need = L.dsmil_agg_workspace_bytes(1, N, K, K, C)
+    ws = torch.empty(need + 512, dtype=torch.uint8, device=dev)
+    base = ws.data_ptr()
+    aligned = base + (-base) % 256
+    vp = ctypes.c_void_p
+
+    def call(ws_ptr, ws_bytes, n_bags=1, packed=None):
+        return L.dsmil_agg_forward_packed(vp(x.data_ptr()), None, vp(off.data_ptr()), n_bags, N, N, ctypes.byref(prm),
+                                          packed, None, vp(cls.data_ptr()), vp(A.data_ptr()), vp(B.data_ptr()),
+                                          vp(pred.data_ptr()), vp(idx.data_ptr()), vp(ws_ptr), ws_bytes, None)
+    assert call(aligned, need) == 0
+    torch.cuda.synchronize()
+    assert call(aligned + 64, need) == -5             # DSMIL_E_ALIGN
+    assert call(aligned, need - 256) == -3            # DSMIL_E_WORKSPACE
+    assert call(aligned, need, n_bags=65536) in (-1, -2)   # rejected before any launch (sizes / grid limit)
+    assert call(aligned, need, packed=vp(aligned + 4)) == -5
+    # the python binding turns status codes into exceptions
+    with pytest.raises(ValueError):
+        ops.agg_forward(x, [N - 1], wt)               # lengths do not add up
+    with pytest.raises(ValueError):
+        ops.agg_forward(x, [N, 0], wt)                # empty bag: the reference fails there too (dsmil.py:52-53)
+    with pytest.raises(RuntimeError):
+        ops.agg_forward(x.cpu(), [N], wt)             # the native path takes device tensors only
+
+
+def test_many_small_bags_in_one_call():
+    """4000 bags of 1..40 rows in one varlen call (grid.y = n_bags): every bag equals its own forward."""
+    net = build_net("tcga", "cuda")
+    rng = np.random.default_rng(5)
+    lengths = [int(v) for v in rng.integers(1, 41, size=4000)]
+    feats = torch.from_numpy(make_bag(77, sum(lengths), 512)).cuda()
+    outs = net.forward_bags((feats, lengths))
+    p = load_weights("tcga")
+    o = 0
+    for i, n in enumerate(lengths):
+        if i % 500 == 0:
+            ref = orc.milnet_forward(feats[o:o + n].cpu().numpy(), p, dtype="f64")
+            _cmp(outs[i], ref[0], ref[1], ref[2], ref[3])
+        o += n
+
+
+def test_instance_sharded_bag_with_an_empty_rank():
+    """A bag smaller than the world size leaves some ranks without rows: they contribute (-inf, zero) statistics
+    instead of failing (dsmil_agg_shard_* are not called with rows = 0)."""
+    from dsmil_wsi_amd import dist as dd
+    net = build_net("tcga", "cuda")
+    N, R = 3, 5
+    x = torch.from_numpy(make_bag(31, N, 512)).cuda()
+    shards = [dd.shard_range(N, r, R) for r in range(R)]
+    assert any(hi == lo for lo, hi in shards)
+    outs = _play_ranks(lambda r, g: dd.sharded_bag_forward(net, x[shards[r][0]:shards[r][1]], shards[r][0], gather=g), R)
+    ref = orc.milnet_forward(x.cpu().numpy(), load_weights("tcga"), dtype="f64")
+    classes = torch.cat([o[0] for o in outs])
+    A = torch.cat([o[2] for o in outs])
+    for o in outs:
+        assert np.array_equal(o[4].cpu().numpy(), np.asarray(ref[4]))
+    _cmp((classes, outs[0][1], A, outs[0][3]), ref[0], ref[1], ref[2], ref[3])

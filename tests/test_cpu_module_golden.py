@@ -1,0 +1,63 @@
+"""BASELINE configs[0] (MUSK1 via train_mil.py: the DSMIL aggregator on the CPU, plumbing only) — the product's
+own CPU module path (dsmil.MILNet on CPU tensors, dsmil-wsi_amd/modules.py `_forward_cpu`) against vectors the
+reference itself produced (tests/golden/make_golden.py ran /root/reference/dsmil.py): SURVEY §8(d) config 1 asks
+for outputs identical to the reference module within 1e-6 on the same bags.  No oracle involved: product vs
+reference-generated golden, forward and autograd gradients.  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from inputs import make_bag
+from util import VARIANT, build_net
+
+FWD_CASES = [(t, n) for t in ("c16", "tcga") for n in (1, 2, 37, 128, 500, 2000)] + \
+            [("musk", 3), ("musk", 40), ("tree", 300), ("linq", 50), ("passv", 50)]
+GRAD_CASES = [("c16", 5), ("c16", 200), ("tcga", 5), ("tcga", 200), ("musk", 40), ("tree", 33)]
+
+
+def _input(golden, name, K, N):
+    x = make_bag(int(golden[f"{name}/seed"]), N, K)
+    assert hashlib.sha256(x.tobytes()).hexdigest() == str(golden[f"{name}/x_sha"])
+    return x
+
+
+@pytest.mark.parametrize("tag,N", FWD_CASES)
+def test_cpu_module_forward_equals_reference(golden, tag, N):
+    name = f"{tag}_N{N}"
+    net = build_net(tag, "cpu")
+    x = torch.from_numpy(_input(golden, name, VARIANT[tag][0], N))
+    with torch.no_grad():
+        classes, pred, A, B = net(x)
+    # same torch CPU kernels, same op sequence as dsmil.py:46-62 -> agreement at the 1e-6 level
+    np.testing.assert_allclose(classes.numpy(), golden[f"{name}/classes"], atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(pred.numpy(), golden[f"{name}/pred"], atol=2e-6, rtol=1e-6)
+    np.testing.assert_allclose(A.numpy(), golden[f"{name}/A"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(B.numpy(), golden[f"{name}/B"], atol=2e-6, rtol=1e-6)
+    assert tuple(pred.shape) == (1, VARIANT[tag][1]) and tuple(B.shape) == (1, VARIANT[tag][1], B.shape[2])
+    # dsmil.py:51-52: row 0 of the descending sort (our arg-max: lowest index on ties)
+    assert np.array_equal(torch.argmax(classes, 0).numpy(), golden[f"{name}/idx"])
+
+
+@pytest.mark.parametrize("tag,N", GRAD_CASES)
+def test_cpu_module_gradients_equal_reference_autograd(golden, tag, N):
+    """train_tcga.py:67-72 / train_mil.py objective on one bag, gradients through the CPU module."""
+    name = f"{tag}_grad_N{N}"
+    net = build_net(tag, "cpu").train()
+    x = torch.from_numpy(_input(golden, name, VARIANT[tag][0], N))
+    y = torch.from_numpy(np.asarray(golden[f"{name}/label"], np.float32))
+    crit = torch.nn.BCEWithLogitsLoss()
+    ins, bag, _, _ = net(x)
+    mx, _ = torch.max(ins, 0)
+    loss = 0.5 * crit(bag.view(1, -1), y.view(1, -1)) + 0.5 * crit(mx.view(1, -1), y.view(1, -1))
+    loss.backward()
+    assert abs(loss.item() - float(golden[f"{name}/loss"])) < 1e-6
+    got = {"fc_w": net.i_classifier.fc[0].weight.grad, "fc_b": net.i_classifier.fc[0].bias.grad,
+           "q0_w": net.b_classifier.q[0].weight.grad, "q0_b": net.b_classifier.q[0].bias.grad,
+           "q2_w": net.b_classifier.q[2].weight.grad, "q2_b": net.b_classifier.q[2].bias.grad,
+           "fcc_w": net.b_classifier.fcc.weight.grad, "fcc_b": net.b_classifier.fcc.bias.grad}
+    for k, g in got.items():
+        ref = golden[f"{name}/g_{k}"]
+        scale = max(1e-6, float(np.abs(ref).max()))
+        np.testing.assert_allclose(g.numpy(), ref, atol=2e-6 * scale + 1e-9, rtol=1e-4, err_msg=k)

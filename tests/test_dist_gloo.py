@@ -124,7 +124,7 @@ def _shard_worker(rank, world, port, n_total, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_total", [(2, 301), (3, 1000)])
+@pytest.mark.parametrize("world,n_total", [(2, 301), (3, 1000), (3, 2)])   # (3, 2): one rank holds no rows
 def test_instance_sharded_bag_equals_unsharded(world, n_total):
     """ONE bag spread over the ranks by rows: two exchanges of C*(2+K) floats reproduce MILNet.forward
     of the whole bag (local slices of classes/A, identical pred/B/idx on every rank)."""
@@ -140,3 +140,20 @@ def test_instance_sharded_bag_equals_unsharded(world, n_total):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     assert abs(sum(s for _, _, s in res) - 2.0) < 1e-4   # the local attention slices sum to 1 per class
+
+
+def test_global_row_index_survives_the_float_message_beyond_2_pow_24():
+    """The critical row's GLOBAL index travels inside the float message as raw int64 bits (two fp32 lanes): a row
+    offset above 2^24 (a float32 VALUE would round it) comes back exactly.  Single process, injected gather."""
+    import dsmil  # noqa: F401
+    from dsmil_wsi_amd import dist as dd
+    from inputs import make_bag
+    from util import build_net
+    net = build_net("tcga")
+    x = torch.from_numpy(make_bag(3, 50, 512))
+    off = (1 << 24) + 12345   # not representable in float32
+    with torch.no_grad():
+        ref = net(x)
+    out = dd.sharded_bag_forward(net, x, off, gather=lambda t, group=None: [t])
+    assert torch.equal(out[4], torch.argmax(ref[0], dim=0) + off)
+    assert torch.allclose(out[1], ref[1], atol=1e-5)

@@ -50,6 +50,41 @@ def test_embedder_vs_oracle(B, H, W):
     np.testing.assert_allclose(c.cpu().numpy(), ref_c, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,W", [(256, 224, 224), (7, 224, 224), (33, 224, 224), (255, 224, 224), (257, 224, 224),
+                                   (3, 250, 250), (2, 225, 231), (9, 231, 225)])
+def test_embedder_at_the_benchmarked_batch_and_odd_sizes(B, H, W):
+    """BASELINE configs[3] times bs = 256 at 224x224: at that size the Winograd host search picks different
+    unit shapes (several images per unit) and the direct convs' 128-pixel tiles straddle images differently
+    than at B <= 6 — parity is checked THERE, plus the batch sizes around it and odd patch sizes
+    (250 -> 125 -> 63 -> 32 -> 16 -> 8; 225x231 -> 113x116 -> 57x58 -> 29x29 -> 15x15 -> 8x8).
+    Oracle: the torch restatement in fp64 (cross-checked against the numpy restatement on the CPU,
+    tests/test_resnet_host.py).  Same 1e-4 bar (compute_feats.py:82)."""
+    ic, w = _build(seed=11)
+    x = torch.from_numpy(make_patches(700 + B, B, H, W))
+    ref_f, ref_c = _ref(x, w, ic)
+    icg = ic.cuda()
+    with torch.no_grad():
+        feats, c = icg(x.cuda())
+    assert feats.shape == (B, 512) and c.shape == (B, 2)
+    err = np.abs(feats.cpu().numpy() - ref_f).max()
+    np.testing.assert_allclose(feats.cpu().numpy(), ref_f, atol=1e-4, rtol=1e-4, err_msg=f"max abs err {err:.3e}")
+    np.testing.assert_allclose(c.cpu().numpy(), ref_c, atol=1e-4, rtol=1e-4)
+
+
+def test_embedder_rows_at_bs256_equal_the_rows_of_small_batches():
+    """Row i of a 256-patch batch is the row a 3-patch batch containing patch i produces (per-image
+    statistics): ties the benchmarked batch to the small-batch parity cases bit-for-bit-close."""
+    ic, w = _build(seed=11)
+    x = torch.from_numpy(make_patches(956, 256, 224, 224)).cuda()
+    icg = ic.cuda()
+    with torch.no_grad():
+        full, cfull = icg(x)
+        for lo in (0, 101, 253):
+            part, cpart = icg(x[lo:lo + 3])
+            np.testing.assert_allclose(part.cpu().numpy(), full[lo:lo + 3].cpu().numpy(), atol=2e-6, rtol=1e-5)
+            np.testing.assert_allclose(cpart.cpu().numpy(), cfull[lo:lo + 3].cpu().numpy(), atol=2e-6, rtol=1e-5)
+
+
 def test_images_are_independent_of_batch_composition():
     """InstanceNorm uses per-image statistics: sharding a slide's patches over ranks must not
     change any row.  Tiles of 128 flattened pixels straddle images in layers 2-4."""
@@ -128,7 +163,9 @@ def _build_bn(seed, C=2):
     return ic.eval()
 
 
-@pytest.mark.parametrize("B,H,W,u8", [(3, 224, 224, False), (2, 96, 160, False), (2, 224, 224, True)])
+@pytest.mark.parametrize("B,H,W,u8", [(3, 224, 224, False), (2, 96, 160, False), (2, 224, 224, True),
+                                      (256, 224, 224, False), (33, 224, 224, True), (3, 250, 250, False),
+                                      (2, 225, 231, True)])
 def test_frozen_batchnorm_trunk_vs_torch_fp64(B, H, W, u8):
     """dsmil_resnet18bn_forward (eval-mode BatchNorm folded into the InstanceNorm kernels' (x-m)*r step)
     against the same torch module evaluated on the CPU in fp64.  Tolerance 1e-4 abs + 1e-4 rel."""

@@ -138,3 +138,42 @@ def test_resnet34_is_recognised_with_36_convs():
     assert L.dsmil_resnet_norm_channels(18) == 4800
     assert L.dsmil_resnet_packed_bytes(18) == L.dsmil_resnet18_packed_bytes() > 0
     assert L.dsmil_resnet_packed_bytes(34) > L.dsmil_resnet_packed_bytes(18)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 96, 96), (1, 125, 131), (2, 64, 70), (1, 250, 250)])
+def test_two_independent_restatements_agree(B, H, W):
+    """oracle/resnet_oracle.py leans on torch's CPU operators (F.conv2d, F.instance_norm, F.max_pool2d);
+    oracle/resnet_numpy.py restates the same network from the definitions in plain numpy (tap-by-tap
+    convolution, explicit statistics, window walks).  The embedder oracle is parity-UNPINNED by the reference
+    (no vectors ship), so this cross-check is what keeps it from being self-consistent by construction:
+    odd sizes included (250 -> 125 -> 63 -> 32 -> 16 -> 8)."""
+    import resnet_numpy as rn
+    w = ro.make_weights(seed=23)
+    x = make_patches(40 + B, B, H, W)
+    g = torch.Generator().manual_seed(5)
+    fc_w, fc_b = torch.randn((2, 512), generator=g) * 0.1, torch.randn((2,), generator=g) * 0.1
+    f_np, c_np = rn.iclassifier_forward(x, {k: v.numpy() for k, v in w.items()}, fc_w.numpy(), fc_b.numpy())
+    with torch.no_grad():
+        f_t, c_t = ro.iclassifier_forward(torch.from_numpy(x).double(), {k: v.double() for k, v in w.items()},
+                                          fc_w.double(), fc_b.double())
+        f32, _ = ro.iclassifier_forward(torch.from_numpy(x), w, fc_w, fc_b)
+    np.testing.assert_allclose(f_np, f_t.numpy(), atol=1e-11, rtol=1e-10)
+    np.testing.assert_allclose(c_np, c_t.numpy(), atol=1e-11, rtol=1e-10)
+    # and the fp32 evaluation of the torch restatement sits well inside the 1e-4 parity bar
+    np.testing.assert_allclose(f32.numpy(), f_np, atol=2e-5, rtol=1e-4)
+
+
+def test_numpy_restatement_building_blocks_against_hand_computed_values():
+    """Known-answer checks of the numpy pieces themselves (values worked out by hand)."""
+    import resnet_numpy as rn
+    x = np.arange(16, dtype=np.float64).reshape(1, 1, 4, 4)
+    # 3x3 all-ones kernel, stride 1, pad 1: corner = 0+1+4+5, centre (1,1) = sum of the 3x3 block at the origin
+    y = rn.conv2d(x, np.ones((1, 1, 3, 3)), 1, 1)
+    assert y[0, 0, 0, 0] == 10 and y[0, 0, 1, 1] == 45 and y[0, 0, 3, 3] == 10 + 11 + 14 + 15
+    # stride 2, pad 0, 1x1 kernel = subsampling
+    assert np.array_equal(rn.conv2d(x, np.full((1, 1, 1, 1), 2.0), 2, 0)[0, 0], 2 * x[0, 0, ::2, ::2])
+    # max-pool 3x3 s2 p1 of 0..15: windows centred on (0,0),(0,2),(2,0),(2,2)
+    assert np.array_equal(rn.max_pool_3x3_s2_p1(x)[0, 0], np.array([[5., 7.], [13., 15.]]))
+    # instance norm: zero mean, biased unit variance (up to eps)
+    z = rn.instance_norm(x)
+    assert abs(z.mean()) < 1e-12 and abs((z ** 2).mean() - 21.25 / (21.25 + 1e-5)) < 1e-12
