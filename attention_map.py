@@ -33,6 +33,13 @@ def build_parser():
     p.add_argument("--map_path", type=str, default="test/output")
     p.add_argument("--export_scores", type=int, default=0)
     p.add_argument("--score_path", type=str, default="test/score")
+    # new (BASELINE configs[4]): multi-scale maps over the pyramid layout compute_feats.py --magnification tree reads
+    p.add_argument("--magnification", type=str, default="single", help="single | tree (low tiles + one folder of "
+                   "high-magnification children per tile; needs --embedder_weights_low / --embedder_weights_high and "
+                   "an aggregator trained on the 1024-d tree features, --feats_size 1024)")
+    p.add_argument("--embedder_weights_low", type=str, default=None)
+    p.add_argument("--embedder_weights_high", type=str, default=None)
+    p.add_argument("--tree_fusion", type=str, default="cat", help="[cat|fusion]")
     return p
 
 
@@ -57,11 +64,35 @@ def build_milnet(args, device):
     return milnet
 
 
+def build_tree_models(args, device):
+    """Two ResNet-18-IN embedders (low / high magnification, compute_feats.py:198-209) and the aggregator the
+    reference trains on tree features: MILNet(FCLayer(feats_size), BClassifier(feats_size)) (train_tcga.py:236-238)."""
+    embs = []
+    for path in (args.embedder_weights_low, args.embedder_weights_high):
+        resnet = models.resnet18(pretrained=False, norm_layer=nn.InstanceNorm2d)
+        for prm in resnet.parameters():
+            prm.requires_grad = False
+        resnet.fc = nn.Identity()
+        ic = mil.IClassifier(resnet, 512, output_class=args.num_classes).to(device)
+        pipeline.load_simclr_weights(ic, torch.load(path, map_location=device))
+        embs.append(ic.eval())
+    milnet = mil.MILNet(mil.FCLayer(in_size=args.feats_size, out_size=args.num_classes),
+                        mil.BClassifier(input_size=args.feats_size, output_class=args.num_classes)).to(device)
+    milnet.load_state_dict(torch.load(args.aggregator_weights, map_location=device), strict=True)
+    return embs[0], embs[1], milnet
+
+
 def main(argv=None):
     warnings.filterwarnings("ignore")
     args = build_parser().parse_args(argv)
     device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-    milnet = build_milnet(args, device)
+    emb_low = emb_high = None
+    if args.magnification == "tree":
+        if not (args.embedder_weights_low and args.embedder_weights_high):
+            raise ValueError("--magnification tree needs --embedder_weights_low and --embedder_weights_high")
+        emb_low, emb_high, milnet = build_tree_models(args, device)
+    else:
+        milnet = build_milnet(args, device)
     bags_list = glob.glob(os.path.join(args.bag_path, "*"))
     os.makedirs(args.map_path, exist_ok=True)
     if args.export_scores:
@@ -70,7 +101,7 @@ def main(argv=None):
         args.class_name = ["class {}".format(c) for c in range(args.num_classes)]
     if len(args.thres) != args.num_classes:
         raise ValueError("Number of thresholds does not match classes.")
-    pipeline.attention_maps(args, bags_list, milnet)
+    pipeline.attention_maps(args, bags_list, milnet, embedder_low=emb_low, embedder_high=emb_high)
 
 
 if __name__ == "__main__":

@@ -1,32 +1,39 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the two DSMIL hot paths on MI355X: the aggregator (BASELINE.json
-configs[1], the headline `value`) and the ResNet-18-IN patch embedder (`embedder` sub-object).
+"""bench.py — throughput of the DSMIL hot paths on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: re-launches itself as N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (dsmil_agg_forward: instance logits + critical-instance
-arg-max, query MLP on f32 MFMA, attention softmax over instances, weighted value sum, Conv1d bag
-head) over one batch of --bags synthetic 10 000 x 512 fp32 bags that are already resident in
-HBM.  The batch (default 64 distinct bags = 1.31 GB) is larger than the 256 MiB Infinity Cache,
-so every step streams its features from HBM.  Bags are independent units: with N ranks each rank
-owns its own --bags bags (weak scaling), there is no data-path collective.
+Headline (`value`): bags/s of the aggregator on BASELINE.json configs[1] — Camelyon16 weights (C=1), fp32, bags of
+10 000 x 512.  One "step" = `passes_per_step` passes of the hot path (dsmil_agg_forward: instance logits +
+critical-instance arg-max, query MLP on MFMA, attention softmax over instances, weighted value sum, Conv1d bag head)
+over one batch of --bags synthetic bags already resident in HBM; the batch (64 bags = 1.31 GB) is larger than the
+256 MiB Infinity Cache, so every pass streams its features from HBM.  `passes_per_step` is chosen after the warm-up so
+that the timed region (EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks) lasts at
+least --min-seconds (1 s): a 22 ms region cannot be corroborated from outside.  Bags are independent units: with N
+ranks each rank owns its own --bags bags (weak scaling), no data-path collective.
 
-The embedder leg (same run, reported under "embedder") times IClassifier over --patches synthetic
-224x224 patches per rank per step (ResNet-18 + InstanceNorm on f32 MFMA, then Linear(512,C));
-with N ranks each rank embeds its own shard of the slide and ONE RCCL all-gather of the
-[--patches, 512] feature rows follows inside the timed step.
+Sub-objects of the same JSON line (each measured the same way):
+  aggregator_bf16  BASELINE configs[2]: TCGA weights (C=2), bf16 feature storage, f32 accumulate
+  embedder         configs[3]: IClassifier(ResNet-18-IN) over --patches synthetic 224x224 patches per rank per step;
+                   with N ranks ONE RCCL all-gather of the [--patches,512] rows follows inside the step (weak)
+  slide            configs[3] per-slide strong scaling: a slide of --slide-patches uint8 tiles
+                   cut contiguously over the ranks, embedded in batches, ONE all-gather of feature rows, aggregated
+  e2e              configs[4]: synthetic two-level WSI -> tiles -> two embedders -> [high||low] -> MILNet(1024) ->
+                   attention map, sharded by low tile, one all-gather of tree rows
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_query_attend), timed
-live with HIP events on its launch stream inside the library; `cpu_baseline` is the numpy oracle
-(oracle/agg_oracle.py, a port of the reference arithmetic) on this box's host cores over a
-bounded sample of the same workload.
+`roofline` is for the dominant kernel of the headline leg (k_query_attend_split), timed live with HIP events on its
+launch stream inside the library over the timed region; `cpu_baseline` is the same forward on this box's host cores.
+Prints ONE JSON line (rank 0).
 """
 import argparse
 import ctypes
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,11 +42,8 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md:42: ~2.5 PF dense bf16 MFMA (no sparsity)
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-f32 MFMA (no xf32 on gfx950)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA (no sparsity)
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: exact-f32 MFMA (no xf32 on gfx950)
 PEAK_HBM_GBS = 8000.0
 Q = 128
 
@@ -54,53 +58,343 @@ def attend_flops_per_bag(N, K, C):
     return 2 * N * K * Q + 2 * N * Q * Q + 2 * N * Q * C + 2 * N * K * C
 
 
+def mlp_flops_per_bag(N, K):
+    """The part of it that runs on the matrix pipe (the two GEMMs of the query MLP)."""
+    return 2 * N * K * Q + 2 * N * Q * Q
+
+
 def bytes_per_bag(N, K, C, s=4):
     return N * K * s + (K * Q + Q + Q * Q + Q + C * K + C + C * C * K + C) * s + (2 * N * C + C * K + C) * 4
 
 
-def cpu_baseline(weights, N, K, C, budget_s):
-    """The oracle (a numpy port of dsmil.py) on the host cores, bounded to ~budget_s seconds."""
-    import agg_oracle as orc
-    from inputs import make_bag
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    bags = [make_bag(50 + i, N, K) for i in range(4)]
-    for b in bags[:2]:
-        orc.milnet_forward(b, weights)  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        orc.milnet_forward(bags[n % len(bags)], weights)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 2000:
-            break
-    return {"value": round(n / el, 2), "unit": "bags/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n} forwards of a {N}x{K} fp32 bag (C={C}) by oracle/agg_oracle.py (numpy/BLAS) in {el:.1f}s"}
+FLOPS_PER_PATCH = 3627122688          # 2 x 1 813 561 344 MAC, 20 convs (SURVEY.md §8d)
+STEM_FLOPS_PER_PATCH = 2 * 12544 * 64 * 147
+# direct-form FLOPs per patch by conv class (ResNet-18 @224): 13 stride-1 3x3 convs (Winograd), 3 stride-2 3x3 + 3 1x1
+WINO_FLOPS_PER_PATCH = 2 * (4 * 3136 * 64 * 64 * 9 + 3 * 784 * 128 * 128 * 9 + 3 * 196 * 256 * 256 * 9 + 3 * 49 * 512 * 512 * 9)
+DIRECT_FLOPS_PER_PATCH = FLOPS_PER_PATCH - STEM_FLOPS_PER_PATCH - WINO_FLOPS_PER_PATCH
 
 
 def _pmc(name, key):
     """HBM bytes from the committed PMC summary (profiles/): (2*FETCH_SIZE + WRITE_SIZE), or None."""
-    path = os.path.join(ROOT, "profiles", name)
     try:
-        return json.load(open(path)).get(key)
+        return json.load(open(os.path.join(ROOT, "profiles", name))).get(key)
     except Exception:
         return None
 
 
-FLOPS_PER_PATCH = 3627122688          # 2 x 1 813 561 344 MAC, 20 convs (SURVEY.md §8d)
-STEM_FLOPS_PER_PATCH = 2 * 12544 * 64 * 147
+# ---------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with no torchrun around it becomes N ranks
+# ---------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
-def embedder_cpu_baseline(budget_s):
-    """oracle/resnet_oracle.py (torch CPU ops, fp32) on the host cores, bounded."""
+def maybe_self_launch(args):
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+class Ctx:
+    """Per-process bench context: device, ranks, the native library."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+        if self.local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {self.rank}: no GPU {self.local_rank} on this node ({torch.cuda.device_count()} visible)")
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=self.dev)
+            assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+            self.dist = dist
+        import dsmil  # noqa: F401
+        import dsmil_wsi_amd._native as nat
+        self.L = nat.lib()
+
+    def fence(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], device=self.dev, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, step, steps, warmup, min_seconds, channel=None, fixed_passes=None):
+        """Warm up, pick passes_per_step so the region lasts >= min_seconds, then time EXACTLY `steps` steps
+        (each = passes_per_step calls of `step`) between fences; returns (seconds [max over ranks], passes_per_step,
+        kernel_ms_total, launches) — the last two from the library's HIP-event channel when given."""
+        torch = self.torch
+        for _ in range(max(1, warmup)):
+            step()
+        self.fence()
+        if fixed_passes is not None:
+            inner = fixed_passes
+        else:
+            t0 = time.perf_counter()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t_pass = self.max_over_ranks((time.perf_counter() - t0) / 2)
+            inner = max(1, int(math.ceil(min_seconds / max(1e-9, steps * t_pass))))
+            if channel is not None:   # the library's event ring holds 4096 launches per channel
+                inner = max(1, min(inner, 4000 // max(1, steps * self._launches_per_pass(step, channel))))
+        self.fence()
+        if channel is not None:
+            self.L.dsmil_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for _ in range(inner):
+                step()
+        self.fence()
+        dt = self.max_over_ranks(time.perf_counter() - t0)
+        tot_ms, launches = ctypes.c_double(0), ctypes.c_int64(0)
+        if channel is not None:
+            self.L.dsmil_profile_collect(channel, ctypes.byref(tot_ms), ctypes.byref(launches))
+            self.L.dsmil_profile_enable(0)
+        return dt, inner, tot_ms.value, int(launches.value)
+
+    def _launches_per_pass(self, step, channel):
+        self.L.dsmil_profile_enable(1)
+        step()
+        self.torch.cuda.synchronize()
+        tot_ms, launches = ctypes.c_double(0), ctypes.c_int64(0)
+        self.L.dsmil_profile_collect(channel, ctypes.byref(tot_ms), ctypes.byref(launches))
+        self.L.dsmil_profile_enable(0)
+        return max(1, int(launches.value))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# aggregator legs (configs[1] fp32 headline, configs[2] bf16 storage)
+# ---------------------------------------------------------------------------------------------------------------
+def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
+    torch, args, dev = cx.torch, cx.args, cx.dev
+    import dsmil_wsi_amd.ops as ops
+    from conftest import load_weights
+    wnp = load_weights(weights_tag)
+    N, K, nb = args.rows, args.feats, args.bags
+    C = wnp["fc_w"].shape[0]
+    if K != wnp["fc_w"].shape[1]:
+        raise SystemExit("--feats must match the weight file (512)")
+    w = {k: torch.from_numpy(v).to(dev) for k, v in wnp.items()}
+    g = torch.Generator(device=dev).manual_seed(1234 + cx.rank)
+    feats = torch.randn((nb * N, K), generator=g, device=dev, dtype=torch.float32)
+    bf16 = dtype == "bf16"
+    if bf16:
+        feats = feats.to(torch.bfloat16)
+    lengths = [N] * nb
+    offsets = ops.offsets_tensor(lengths, dev)
+    out = []
+
+    def step():
+        out[:] = ops.agg_forward(feats, lengths, w, offsets=offsets)
+
+    dt, inner, kern_ms_tot, launches = cx.timed(step, args.steps, args.warmup, args.min_seconds, channel=0)
+    single_ms = None
+    if single_bag:   # one MILNet.forward-sized call per iteration (SURVEY §8d config 2), outside the timed region
+        one = feats[:N]
+        for _ in range(5):
+            ops.agg_forward(one, [N], w)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            ops.agg_forward(one, [N], w)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t1) / 50 * 1e3
+    A = out[2]
+    s = A.view(nb, N, C).sum(1)
+    assert torch.isfinite(out[1]).all() and torch.allclose(s, torch.ones_like(s), atol=1e-4), "attention does not sum to 1"
+    del feats, out[:], A, s
+    torch.cuda.empty_cache()
+
+    world = cx.world
+    value = world * nb * inner * args.steps / dt
+    kern_ms = kern_ms_tot / max(1, launches)
+    form = int(cx.L.dsmil_agg_mlp_form())
+    line = {"metric": "bags/sec aggregated (10kx512)", "value": round(value, 1), "unit": "bags/s",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_pass": round(dt / (args.steps * inner) * 1e3, 4),
+            "dtype": dtype,
+            "config": {"workload": f"DSMIL aggregator forward (FCLayer+BClassifier), {weights_tag} weights C={C}, "
+                                   f"{nb} bags x {N} x {K} {'bf16 storage, f32 accumulate' if bf16 else 'fp32'} per GPU per pass, "
+                                   f"HBM-resident", "passes_per_step": inner, "bags_per_pass_per_gpu": nb, "rows": N,
+                       "feats": K, "classes": C, "tile_rows": int(cx.L.dsmil_agg_tile_rows(nb, nb * N)),
+                       "parallelism": f"bag-sharded x{world}", "timed_region_s": round(dt, 3),
+                       "single_bag_forward_ms": round(single_ms, 4) if single_ms is not None else None}}
+    if bf16:
+        # bf16 storage: the MLP runs on bf16 MFMA (0.7 us/bag at 2.5 PF) and the feature stream (10.5 MB/bag) binds
+        by = bytes_per_bag(N, K, C, s=2) * nb
+        gbs = by / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
+        t_roof = max(flops_per_bag(N, K, C) / (PEAK_BF16_MFMA_TFLOPS * 1e12), bytes_per_bag(N, K, C, s=2) / (PEAK_HBM_GBS * 1e9))
+        line["roofline"] = {"kernel": "k_query_attend_bf16", "bound": "hbm", "achieved": round(gbs, 1) if gbs else None,
+                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4) if gbs else None,
+                            "traffic": _pmc("pmc_k_query_attend_bf16.json", "hbm_bytes_per_launch") if (nb, N, K) == (64, 10000, 512) else None,
+                            "kernel_ms": round(kern_ms, 4), "launches": launches, "alg_bytes_per_launch": by,
+                            "whole_path_frac_of_roofline": round(value / world * t_roof, 4)}
+        return line
+    fl = attend_flops_per_bag(N, K, C) * nb
+    achieved = fl / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
+    # The peak that bounds the kernel AS EXECUTED: forms 6 / 9 run every fp32 MAC as 6 / 9 bf16 plane products on the
+    # bf16 matrix pipe, so the bound is (bf16 dense peak) / (plane products per MAC) in algorithmic (fp32) FLOP/s;
+    # form 0 runs on the f32 MFMA pipe.  `frac` is therefore the utilisation of the pipe the kernel runs on (<= 1);
+    # the fp32-MFMA figure of SURVEY §8(d) is kept beside it (it is not a bound for the split forms).
+    peak_exec = PEAK_BF16_MFMA_TFLOPS / form if form else PEAK_F32_MFMA_TFLOPS
+    t_roof_f32 = max(flops_per_bag(N, K, C) / (PEAK_F32_MFMA_TFLOPS * 1e12), bytes_per_bag(N, K, C) / (PEAK_HBM_GBS * 1e9))
+    t_roof_exec = max(flops_per_bag(N, K, C) / (peak_exec * 1e12), bytes_per_bag(N, K, C) / (PEAK_HBM_GBS * 1e9))
+    line["roofline"] = {
+        "kernel": "k_query_attend_split" if form else "k_query_attend", "bound": "mfma",
+        "achieved": round(achieved, 2) if achieved else None, "peak": round(peak_exec, 1), "unit": "TFLOP/s",
+        "frac": round(achieved / peak_exec, 4) if achieved else None,
+        "peak_is": ("bf16 dense MFMA peak 2500 TF / %d plane products per fp32 MAC (exact 3-plane cuts, f32 accumulate)" % form)
+                   if form else "f32 MFMA peak (v_mfma_f32_32x32x2_f32)",
+        "mfma_form": {0: "v_mfma_f32_32x32x2_f32", 9: "bf16 MFMA, exact 3-plane cut, 9 plane products",
+                      6: "bf16 MFMA, exact 3-plane cut, 6 largest plane products"}[form],
+        "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4) if achieved else None,
+        "traffic": _pmc("pmc_k_query_attend.json", "hbm_bytes_per_launch") if (nb, N, K) == (64, 10000, 512) else None,
+        "alg_bytes_per_launch": bytes_per_bag(N, K, C) * nb,
+        "kernel_ms": round(kern_ms, 4), "launches": launches, "alg_flops_per_launch": fl,
+        "whole_path_frac_of_roofline": round(value / world * t_roof_f32, 4),
+        "whole_path_roofline_is": "SURVEY §8(d): max(bytes / 8 TB/s, FLOPs / 157.3 TF f32 MFMA) per bag",
+        "whole_path_frac_of_executed_form_roofline": round(value / world * t_roof_exec, 4)}
+    return line
+
+
+def cpu_baseline_aggregator(weights_tag, N, K, budget_s):
+    """The reference's forward on the host cores: the product's own CPU module path (dsmil-wsi_amd/modules.py
+    `_forward_cpu` + FCLayer), op for op the torch sequence of dsmil.py:6-12,46-62 (and checked against vectors the
+    reference produced, tests/test_cpu_module_golden.py), all cores."""
+    import torch
+    from inputs import make_bag
+    from util import build_net
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = build_net(weights_tag, "cpu")
+    bags = [torch.from_numpy(make_bag(50 + i, N, K)) for i in range(4)]
+    with torch.no_grad():
+        for b in bags[:3]:
+            net(b)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            net(bags[n % len(bags)])
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or n >= 5000:
+                break
+    C = net.i_classifier.fc[0].out_features
+    return {"value": round(n / el, 2), "unit": "bags/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{n} forwards of a {N}x{K} fp32 bag (C={C}) through the torch-CPU module path (op for op "
+                      f"dsmil.py:46-62; reference sources are not on this box) in {el:.1f}s"}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# embedder legs
+# ---------------------------------------------------------------------------------------------------------------
+def _build_iclassifier(cx, seed=11, C=2):
+    import torch.nn as nn
+    import dsmil
+    import resnet_oracle as ro   # weight fixture only (seeded kaiming init, SURVEY §8d config 4)
+    from dsmil_wsi_amd.resnet import resnet18
+    from conftest import load_weights
+    torch = cx.torch
+    res = resnet18(pretrained=False, norm_layer=nn.InstanceNorm2d)
+    for p in res.parameters():
+        p.requires_grad = False
+    res.fc = nn.Identity()
+    res.load_state_dict(ro.make_weights(seed=seed), strict=True)
+    wt = load_weights("tcga")
+    ic = dsmil.IClassifier(res, 512, output_class=C)
+    with torch.no_grad():
+        ic.fc.weight.copy_(torch.from_numpy(wt["fc_w"][:C]))
+        ic.fc.bias.copy_(torch.from_numpy(wt["fc_b"][:C]))
+    return ic.to(cx.dev).eval()
+
+
+def embedder_leg(cx):
+    torch, args, dev, world, dist = cx.torch, cx.args, cx.dev, cx.world, cx.dist
+    ic = _build_iclassifier(cx)
+    Bp = args.patches
+    g = torch.Generator(device=dev).manual_seed(7 + cx.rank)
+    x = torch.rand((Bp, 3, 224, 224), generator=g, device=dev, dtype=torch.float32)
+    gathered = torch.empty((world * Bp, 512), device=dev) if world > 1 else None
+    keep = []
+
+    def step():
+        with torch.no_grad():
+            feats, c = ic(x)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, feats)
+        keep[:] = [feats]
+
+    dt, inner, kern_ms_tot, launches = cx.timed(step, args.steps, args.warmup, args.min_seconds, channel=1)
+    assert torch.isfinite(keep[0]).all()
+    passes = args.steps * inner
+    value = world * Bp * passes / dt
+    # ideal time of the conv kernels on the pipes they run on: Winograd convs = direct FLOPs / 2.25 x 9 plane products
+    # on the bf16 pipe; direct convs on the f32 MFMA pipe (or 9 products on the bf16 pipe when built that way)
+    forms = json.loads(ctypes.c_char_p(cx.L.dsmil_resnet_forms()).value.decode()) if hasattr(cx.L, "dsmil_resnet_forms") else {}
+    wino_np = forms.get("wino_products", 9)
+    direct_np = forms.get("direct_products", 0)
+    t_wino = WINO_FLOPS_PER_PATCH / 2.25 * (wino_np / (PEAK_BF16_MFMA_TFLOPS * 1e12) if wino_np else 1 / (PEAK_F32_MFMA_TFLOPS * 1e12))
+    t_direct = DIRECT_FLOPS_PER_PATCH * (direct_np / (PEAK_BF16_MFMA_TFLOPS * 1e12) if direct_np else 1 / (PEAK_F32_MFMA_TFLOPS * 1e12))
+    kern_s = kern_ms_tot * 1e-3
+    conv_flops = (FLOPS_PER_PATCH - STEM_FLOPS_PER_PATCH) * Bp * passes
+    ach = conv_flops / kern_s / 1e12 if kern_s > 0 else None
+    frac_pipe = (t_wino + t_direct) * Bp * passes / kern_s if kern_s > 0 else None
+    return {"metric": "patches/sec embedded (ResNet-18-IN, 224x224, bs=%d)" % Bp, "value": round(value, 1),
+            "unit": "patches/s", "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_pass": round(dt / passes * 1e3, 3),
+            "dtype": "f32",
+            "config": {"workload": f"IClassifier(ResNet-18 InstanceNorm, fc=Identity)+Linear(512,2), {Bp} synthetic "
+                                   f"224x224 patches per GPU per pass, kaiming(seed 11) weights",
+                       "passes_per_step": inner, "timed_region_s": round(dt, 3),
+                       "collective": "all_gather_into_tensor([%d,512] f32) per pass" % Bp if world > 1 else "none"},
+            "roofline": {"kernel": "conv kernels of one forward: 13 x k_conv_wino_s3 (Winograd F(2x2,3x3), bf16 MFMA over exact "
+                                   "3-plane cuts) + 6 direct convs", "bound": "mfma",
+                         # algorithmic (direct-form) rate of the conv kernels; NOT compared with a peak: Winograd does
+                         # 2.25x fewer multiplies than the direct form, so this rate may exceed the f32 MFMA peak
+                         "achieved": round(ach, 2) if ach else None, "unit": "TFLOP/s",
+                         # the fraction that IS bounded by 1: ideal time of the executed MFMA work on the pipe each conv
+                         # class runs on / measured conv-kernel time
+                         "frac": round(frac_pipe, 4) if frac_pipe else None,
+                         "frac_is": "sum over conv classes of (executed MFMA FLOPs / peak of the pipe they run on) / kernel time",
+                         "peak": PEAK_BF16_MFMA_TFLOPS, "executed_forms": forms or {"wino_products": 9, "direct_products": 0},
+                         "traffic": _pmc("pmc_k_conv.json", "hbm_bytes_per_forward"),
+                         "kernel_ms_total": round(kern_ms_tot, 3), "launches": launches, "alg_flops_total": conv_flops,
+                         # the figure the >= 60 % target of BASELINE.json refers to: whole forward vs SURVEY §8(d)'s
+                         # direct-form fp32 roofline (3.627 GFLOP/patch at 157.3 TF = 43 368 patches/s)
+                         "whole_path_frac_of_roofline": round(value / world / (PEAK_F32_MFMA_TFLOPS * 1e12 / FLOPS_PER_PATCH), 4)}}
+
+
+def cpu_baseline_embedder(budget_s):
+    """oracle/resnet_oracle.py (the torch-CPU restatement of the torchvision backbone, fp32) on the host cores, bounded."""
+    import torch
     import resnet_oracle as ro
     from inputs import make_patches
+    torch.set_num_threads(os.cpu_count() or 1)
     w = ro.make_weights(seed=11)
-    x = torch.from_numpy(make_patches(7, 8))
-    threads = torch.get_num_threads()
+    x = torch.from_numpy(make_patches(7, 16))
     with torch.no_grad():
         ro.resnet18_in_features(x[:2], w)
         n, t0 = 0, time.perf_counter()
@@ -110,77 +404,88 @@ def embedder_cpu_baseline(budget_s):
             el = time.perf_counter() - t0
             if el >= budget_s:
                 break
-    return {"value": round(n / el, 2), "unit": "patches/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n} patches (batches of 8, 224x224) through oracle/resnet_oracle.py (torch CPU fp32) in {el:.1f}s"}
+    return {"value": round(n / el, 2), "unit": "patches/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{n} patches (batches of 16, 224x224) through oracle/resnet_oracle.py (torch CPU fp32) in {el:.1f}s"}
 
 
-def embedder_leg(args, dev, rank, world, dist, L):
-    import torch.nn as nn
-    import dsmil
-    import resnet_oracle as ro
-    from dsmil_wsi_amd.resnet import resnet18
-    from conftest import load_weights
-    res = resnet18(pretrained=False, norm_layer=nn.InstanceNorm2d)
-    for p in res.parameters():
-        p.requires_grad = False
-    res.fc = nn.Identity()
-    res.load_state_dict(ro.make_weights(seed=11), strict=True)
-    wt = load_weights("tcga")
-    ic = dsmil.IClassifier(res, 512, output_class=2)
-    with torch.no_grad():
-        ic.fc.weight.copy_(torch.from_numpy(wt["fc_w"]))
-        ic.fc.bias.copy_(torch.from_numpy(wt["fc_b"]))
-    ic = ic.to(dev).eval()
-    Bp = args.patches
-    g = torch.Generator(device=dev).manual_seed(7 + rank)
-    x = torch.rand((Bp, 3, 224, 224), generator=g, device=dev, dtype=torch.float32)
-    gathered = torch.empty((world * Bp, 512), device=dev) if world > 1 else None
+def slide_leg(cx, n_patches):
+    """ONE slide of n_patches ordered tiles (uint8 NHWC, resident), cut contiguously over the
+    ranks, embedded in batches of --patches, ONE all-gather of the [N_r,512] rows, then the aggregator on the bag.
+    Strong scaling: the slide is fixed, per-rank work shrinks with N."""
+    torch, args, dev, world, dist = cx.torch, cx.args, cx.dev, cx.world, cx.dist
+    from dsmil_wsi_amd import dist as dd
+    from dsmil_wsi_amd import pipeline as pl
+    from util import build_net
+    ic = _build_iclassifier(cx)
+    net = build_net("tcga", dev)
+    lo, hi = dd.shard_range(n_patches, cx.rank, world)
+    g = torch.Generator(device=dev).manual_seed(99)   # every rank draws the same slide and keeps its rows
+    tiles = torch.empty((hi - lo, 224, 224, 3), dtype=torch.uint8, device=dev)
+    chunk = 512
+    for s in range(0, n_patches, chunk):   # same stream on every rank: rows [lo, hi) are this rank's
+        e = min(n_patches, s + chunk)
+        blk = torch.randint(0, 256, (e - s, 224, 224, 3), generator=g, device=dev, dtype=torch.uint8)
+        a, b = max(s, lo), min(e, hi)
+        if b > a:
+            tiles[a - lo:b - lo] = blk[a - s:b - s]
+    del blk
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    res = {}
 
     def step():
         with torch.no_grad():
-            feats, c = ic(x)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, feats)
-        return feats
+            ev[0].record()
+            feats, _ = pl.embed_tiles(ic, tiles, args.patches)
+            ev[1].record()
+            bag = dd.all_gather_rows(feats, n_patches) if world > 1 else feats
+            ev[2].record()
+            res["out"] = net(bag)
+            ev[3].record()
 
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    dt, inner, _, _ = cx.timed(step, max(2, min(args.steps, 5)), 1, 0.0, fixed_passes=1)
+    steps = max(2, min(args.steps, 5))
+    torch.cuda.synchronize()
+    out = res["out"]
+    assert out[2].shape[0] == n_patches and torch.isfinite(out[1]).all()
+    return {"metric": "patches/sec, one slide embedded + gathered + aggregated", "value": round(n_patches * steps / dt, 1),
+            "unit": "patches/s", "scaling": "strong", "ms_per_slide": round(dt / steps * 1e3, 3),
+            "last_slide_ms": {"embed": round(ev[0].elapsed_time(ev[1]), 3), "all_gather": round(ev[1].elapsed_time(ev[2]), 3),
+                              "aggregate": round(ev[2].elapsed_time(ev[3]), 3)},
+            "config": {"workload": f"one slide = {n_patches} uint8 224x224 tiles (ToTensor fused in the stem), contiguous row "
+                                   f"shards over {world} rank(s), batches of {args.patches}, one all-gather of [N_r,512] f32, "
+                                   f"MILNet(tcga) on the gathered bag", "slides_timed": steps, "rccl_ranks": world,
+                       "rows_this_rank": hi - lo}}
 
-    for _ in range(max(1, args.warmup)):
-        feats = step()
-    fence()
-    L.dsmil_profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        feats = step()
-    fence()
-    dt = time.perf_counter() - t0
-    tot_ms, launches = ctypes.c_double(0), ctypes.c_int64(0)
-    L.dsmil_profile_collect(1, ctypes.byref(tot_ms), ctypes.byref(launches))
-    L.dsmil_profile_enable(0)
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert torch.isfinite(feats).all()
-    value = world * Bp * args.steps / dt
-    conv_flops = (FLOPS_PER_PATCH - STEM_FLOPS_PER_PATCH) * Bp * args.steps
-    ach = conv_flops / (tot_ms.value * 1e-3) / 1e12 if tot_ms.value > 0 else None
-    return {"metric": "patches/sec embedded (ResNet-18-IN, 224x224, bs=%d)" % Bp, "value": round(value, 1),
-            "unit": "patches/s", "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "f32",
-            "config": {"workload": f"IClassifier(ResNet-18 InstanceNorm, fc=Identity)+Linear(512,2), {Bp} synthetic "
-                                   f"224x224 patches per GPU per step, kaiming(seed 11) weights",
-                       "collective": "all_gather_into_tensor([%d,512] f32) per step" % Bp if world > 1 else "none"},
-            "roofline": {"kernel": "k_conv_wino_s3 (13 Winograd convs, bf16 MFMA over exact 3-plane cuts) + k_conv "
-                                   "(6 direct convs, f32 MFMA) per forward", "bound": "mfma",
-                         "achieved": round(ach, 2) if ach else None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4) if ach else None,
-                         "traffic": _pmc("pmc_k_conv.json", "hbm_bytes_per_forward"),
-                         "kernel_ms_total": round(tot_ms.value, 3), "launches": int(launches.value),
-                         "alg_flops_total": conv_flops,
-                         "whole_path_frac_of_roofline": round(value / world / (PEAK_F32_MFMA_TFLOPS * 1e12 / FLOPS_PER_PATCH), 4)}}
+
+def e2e_leg(cx, low_grid):
+    """BASELINE configs[4]: synthetic two-level slide -> attention map (pipeline.multiscale_attention_map)."""
+    torch, args, dev, world = cx.torch, cx.args, cx.dev, cx.world
+    import numpy as np
+    from dsmil_wsi_amd import pipeline as pl
+    from util import build_net
+    gy, gx = low_grid
+    e_lo, e_hi = _build_iclassifier(cx, seed=11), _build_iclassifier(cx, seed=12)
+    net = build_net("tree", dev)
+    g = torch.Generator(device=dev).manual_seed(2024)
+    wsi = torch.randint(0, 256, (gy * 896, gx * 896, 3), generator=g, device=dev, dtype=torch.uint8)
+    colors = [np.array([255, 40, 0]), np.array([0, 90, 255])]
+    res, tm = {}, {}
+
+    def step():
+        res["out"] = pl.multiscale_attention_map(wsi, e_lo, e_hi, net, [0.5, 0.5], colors, batch_size=args.patches, timings=tm)
+
+    steps = max(2, min(args.steps, 3))
+    dt, _, _, _ = cx.timed(step, steps, 1, 0.0, fixed_passes=1)
+    out = res["out"]
+    n_high, n_low = gy * gx * 16, gy * gx
+    assert out["feats"].shape == (n_high, 1024) and torch.isfinite(out["pred"]).all()
+    return {"metric": "slides/sec, multi-scale end to end (tile -> 2-scale embed -> concat -> aggregate -> attention map)",
+            "value": round(steps / dt, 4), "unit": "slides/s", "scaling": "strong", "ms_per_slide": round(dt / steps * 1e3, 2),
+            "patches_per_s": round((n_high + n_low) * steps / dt, 1),
+            "config": {"workload": f"synthetic uint8 slide {gy * 896}x{gx * 896}: {n_low} low tiles + {n_high} high tiles (224x224), "
+                                   f"two ResNet-18-IN embedders, [high||low] 1024-d, MILNet(FCLayer(1024,2), BClassifier(1024,2)), "
+                                   f"32x colour map on the host", "slides_timed": steps, "rccl_ranks": world,
+                       "all_gather_s_total": round(tm.get("allgather_s", 0.0), 4)}}
 
 
 def main():
@@ -188,167 +493,55 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--bags", type=int, default=64, help="bags per rank per step")
+    ap.add_argument("--bags", type=int, default=64, help="bags per rank per pass")
     ap.add_argument("--rows", type=int, default=10000)
     ap.add_argument("--feats", type=int, default=512)
-    ap.add_argument("--weights", default="c16", choices=["c16", "tcga"],
-                    help="c16: Camelyon16 aggregator (C=1, BASELINE configs[1]); tcga: C=2")
-    ap.add_argument("--patches", type=int, default=256, help="patches per rank per embedder step")
-    ap.add_argument("--workload", default="both", choices=["both", "aggregator", "embedder"])
+    ap.add_argument("--patches", type=int, default=256, help="patches per rank per embedder pass (batch size)")
+    ap.add_argument("--workload", default="all",
+                    help="comma list of aggregator, aggregator_bf16, embedder, slide, e2e; or all / both (= aggregator,embedder)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on each timed region")
+    ap.add_argument("--slide-patches", type=int, default=10000)
+    ap.add_argument("--e2e-grid", type=int, nargs=2, default=(24, 26), help="low-magnification tile grid of the e2e slide")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="aggregator leg: f32 (BASELINE configs[1], the headline) or bf16 storage (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-bag", action="store_true",
                     help="skip the single-bag latency probe (profiling runs: keeps per-kernel averages clean)")
     args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    import dsmil  # noqa: F401
-    import dsmil_wsi_amd._native as nat
-    import dsmil_wsi_amd.ops as ops
-    from conftest import load_weights
-
-    L = nat.lib()
-    run_agg = args.workload in ("both", "aggregator")
-    wnp = load_weights(args.weights)
-    N, K, nb = args.rows, args.feats, args.bags
-    C = wnp["fc_w"].shape[0]
-    dt, tot_ms, launches = 1.0, ctypes.c_double(0), ctypes.c_int64(0)
-    single_ms = None
-    if run_agg:
-        w = {k: torch.from_numpy(v).to(dev) for k, v in wnp.items()}
-        if K != wnp["fc_w"].shape[1]:
-            raise SystemExit("--feats must match the weight file (512)")
-        g = torch.Generator(device=dev).manual_seed(1234 + rank)
-        feats = torch.randn((nb * N, K), generator=g, device=dev, dtype=torch.float32)
-        if args.dtype == "bf16":
-            feats = feats.to(torch.bfloat16)
-        lengths = [N] * nb
-        offsets = ops.offsets_tensor(lengths, dev)
-
-        def step():
-            return ops.agg_forward(feats, lengths, w, offsets=offsets)
-
-        def fence():
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        for _ in range(max(1, args.warmup)):
-            out = step()
-        fence()
-        L.dsmil_profile_enable(1)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        fence()
-        dt = time.perf_counter() - t0
-        L.dsmil_profile_collect(0, ctypes.byref(tot_ms), ctypes.byref(launches))
-        L.dsmil_profile_enable(0)
-        if dist is not None:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        # single-bag latency (SURVEY 8d config 2 asks for it beside the batched rate): one
-        # MILNet.forward-sized call per iteration, outside the timed region, rank 0's number is reported
-        if not args.no_single_bag:
-            one = feats[:N]
-            for _ in range(5):
-                ops.agg_forward(one, [N], w)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(50):
-                ops.agg_forward(one, [N], w)
-            torch.cuda.synchronize()
-            single_ms = (time.perf_counter() - t1) / 50 * 1e3
-        # sanity: outputs finite, attention sums to 1 per bag (cheap, outside the timed region)
-        A = out[2]
-        s = A.view(nb, N, C).sum(1)
-        if not os.environ.get("DSMIL_EXPT"):
-            assert torch.isfinite(out[1]).all() and torch.allclose(s, torch.ones_like(s), atol=1e-4)
-        del feats, out, A, s
-        torch.cuda.empty_cache()
-
-    emb = None
-    if args.workload in ("both", "embedder"):
-        emb = embedder_leg(args, dev, rank, world, dist, L)
-
-    if rank == 0:
-        bags_total = world * nb * args.steps
-        value = bags_total / dt
-        kern_ms = tot_ms.value / max(1, launches.value)
-        fl = attend_flops_per_bag(N, K, C) * nb
-        achieved = fl / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
-        traffic = _pmc("pmc_k_query_attend.json", "hbm_bytes_per_launch") if (nb, N, K) == (64, 10000, 512) else None
-        form = int(L.dsmil_agg_mlp_form())
-        bf16 = args.dtype == "bf16"
-        line = {
-            "metric": "bags/sec aggregated (10kx512)", "value": round(value, 1), "unit": "bags/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"DSMIL aggregator forward (FCLayer+BClassifier), {args.weights} weights C={C}, "
-                                   f"{nb} bags x {N} x {K} {'bf16 storage, f32 accumulate' if bf16 else 'fp32'} per GPU per step, HBM-resident",
-                       "bags_per_step_per_gpu": nb, "rows": N, "feats": K, "classes": C,
-                       "tile_rows": int(L.dsmil_agg_tile_rows(nb, nb * N)), "parallelism": f"bag-sharded x{world}",
-                       "single_bag_forward_ms": round(single_ms, 4) if single_ms is not None else None},
-            "roofline": {"kernel": "k_query_attend" + ("_split" if form else ""), "bound": "mfma",
-                         "achieved": round(achieved, 2) if achieved else None,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4) if achieved else None,
-                         "mfma_form": {0: "v_mfma_f32_32x32x2_f32", 9: "bf16 MFMA, exact 3-plane cut, 9 plane products",
-                                       6: "bf16 MFMA, exact 3-plane cut, 6 plane products"}[form],
-                         # the pipe the kernel actually runs on: bf16 dense peak / plane products per MAC
-                         "peak_executed_form": round(PEAK_BF16_MFMA_TFLOPS / form, 1) if form else PEAK_F32_MFMA_TFLOPS,
-                         "frac_executed_form": (round(achieved / (PEAK_BF16_MFMA_TFLOPS / form if form else PEAK_F32_MFMA_TFLOPS), 4)
-                                                if achieved else None),
-                         "traffic": traffic, "kernel_ms": round(kern_ms, 4), "launches": int(launches.value),
-                         "alg_flops_per_launch": fl,
-                         "whole_path_frac_of_roofline": round(
-                             value / world / (1.0 / max(flops_per_bag(N, K, C) / (PEAK_F32_MFMA_TFLOPS * 1e12),
-                                                             bytes_per_bag(N, K, C) / (PEAK_HBM_GBS * 1e9))), 4)},
-        }
-        if bf16:
-            # bf16 storage: the MLP runs on bf16 MFMA (0.7 us/bag at 2.5 PF) and the feature stream
-            # (10.5 MB/bag) binds -> HBM roofline for the same dominant kernel
-            by = bytes_per_bag(N, K, C, s=2) * nb
-            gbs = by / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
-            line["roofline"] = {"kernel": "k_query_attend_bf16", "bound": "hbm", "achieved": round(gbs, 1) if gbs else None,
-                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4) if gbs else None,
-                                "traffic": None, "kernel_ms": round(kern_ms, 4), "launches": int(launches.value),
-                                "alg_bytes_per_launch": by,
-                                "whole_path_frac_of_roofline": round(
-                                    value / world / (1.0 / max(flops_per_bag(N, K, C) / (PEAK_BF16_MFMA_TFLOPS * 1e12),
-                                                                    bytes_per_bag(N, K, C, s=2) / (PEAK_HBM_GBS * 1e9))), 4)}
-        if emb is not None:
-            line["embedder"] = emb
-        if not run_agg:   # embedder-only run (profiling): promote the embedder leg to the top level
-            line = dict(emb, n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True,
-                        scaling="weak", vs_baseline=None, data="synthetic")
-            emb = None
-        if not args.no_cpu_baseline and run_agg and world == 1 and not bf16:   # CPU baselines: rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(wnp, N, K, C, args.cpu_seconds)
-            if emb is not None:
-                emb["cpu_baseline"] = embedder_cpu_baseline(args.cpu_seconds)
+    maybe_self_launch(args)
+    wl = {"all": "aggregator,aggregator_bf16,embedder,slide,e2e", "both": "aggregator,embedder"}.get(args.workload, args.workload)
+    wl = [w for w in wl.split(",") if w]
+    cx = Ctx(args)
+    line = {}
+    if "aggregator" in wl:
+        line = aggregator_leg(cx, "c16", "f32", single_bag=not args.no_single_bag)
+    subs = {}
+    if "aggregator_bf16" in wl:
+        subs["aggregator_bf16"] = aggregator_leg(cx, "tcga", "bf16", single_bag=False)
+    if "embedder" in wl:
+        subs["embedder"] = embedder_leg(cx)
+    if "slide" in wl:
+        subs["slide"] = slide_leg(cx, args.slide_patches)
+    if "e2e" in wl:
+        subs["e2e"] = e2e_leg(cx, tuple(args.e2e_grid))
+    if cx.rank == 0:
+        if not line:   # a run without the headline leg (profiling): promote the first sub-object
+            k0 = next(iter(subs))
+            line = subs.pop(k0)
+        line.update({"n_gpus": cx.world, "rccl_ranks": cx.world, "steps": args.steps, "warmup": args.warmup,
+                     "higher_is_better": True, "scaling": line.get("scaling", "weak"), "vs_baseline": None, "data": "synthetic"})
+        line.update(subs)
+        if not args.no_cpu_baseline and cx.world == 1:   # CPU baselines: rank 0 at N = 1 only
+            if "aggregator" in wl:
+                line["cpu_baseline"] = cpu_baseline_aggregator("c16", args.rows, args.feats, args.cpu_seconds)
+            if "embedder" in line:
+                line["embedder"]["cpu_baseline"] = cpu_baseline_embedder(args.cpu_seconds)
+        order = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+        line = {**{k: line[k] for k in order if k in line}, **{k: v for k, v in line.items() if k not in order}}
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if cx.dist is not None:
+        cx.dist.barrier()
+        cx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -52,10 +52,18 @@ def all_gather_rows(local, n_total, group=None):
     if world == 1:
         assert local.shape[0] == n_total
         return local
-    D = local.shape[1]
     sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
-    assert local.shape[0] == sizes[rank], (local.shape, sizes, rank)
-    mx = max(sizes)
+    return all_gather_rows_sized(local, sizes, group)
+
+
+def all_gather_rows_sized(local, sizes, group=None):
+    """all_gather_rows for arbitrary per-rank row counts (`sizes[r]` rows on rank r, rank order = row order):
+    still ONE equal-size collective, shards padded to the largest."""
+    world, rank = world_rank(group)
+    if world == 1:
+        return local
+    assert len(sizes) == world and local.shape[0] == sizes[rank], (local.shape, sizes, rank)
+    D, mx = local.shape[1], max(sizes)
     padded = local
     if local.shape[0] < mx:
         padded = torch.zeros((mx, D), dtype=local.dtype, device=local.device)
@@ -64,14 +72,12 @@ def all_gather_rows(local, n_total, group=None):
     if dist.get_backend(group) == "nccl":
         out = torch.empty((world * mx, D), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, padded, group=group)
-        parts = [out[r * mx: r * mx + sizes[r]] for r in range(world)]
-    else:
-        bufs = [torch.empty_like(padded) for _ in range(world)]
-        dist.all_gather(bufs, padded, group=group)
-        parts = [bufs[r][: sizes[r]] for r in range(world)]
-    if all(s == mx for s in sizes) and dist.get_backend(group) == "nccl":
-        return out
-    return torch.cat(parts, dim=0)
+        if all(s == mx for s in sizes):
+            return out
+        return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
+    bufs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded, group=group)
+    return torch.cat([bufs[r][: sizes[r]] for r in range(world)], dim=0)
 
 
 def embed_rows_sharded(embed_fn, n_total, group=None):

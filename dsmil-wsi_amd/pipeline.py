@@ -154,33 +154,49 @@ def compute_feats(args, bags_list, i_classifier, save_path=None, magnification="
 
 
 @torch.no_grad()
+def tree_feats_of_bag(bag, embedder_low, embedder_high, tree_fusion="cat", batch_size=128, num_workers=4, ext=("jpg", "jpeg")):
+    """One pyramid bag folder -> (tree feats [N_high, 1024 | 512] on the device, high patch files, #low files).
+    compute_feats.py:91-114: every high-magnification patch (folder named after its low-magnification parent)
+    is paired with its parent: 'cat' -> [high(512) || low(512)], 'fusion' -> high + 0.25*low.  The high patches
+    are embedded in batches (the reference runs one forward per patch, :106-109; InstanceNorm is per image)."""
+    if tree_fusion not in ("fusion", "cat"):
+        raise NotImplementedError(f"{tree_fusion} is not an excepted option for --tree_fusion. "
+                                  "This argument accepts 2 options: 'fusion' and 'cat'.")
+    low_files = []
+    for e in ext:
+        low_files += glob.glob(os.path.join(bag, "*." + e))
+    low_feats, _ = embed_files(embedder_low, low_files, batch_size, num_workers)
+    high_files, parent = [], []
+    for idx, lp in enumerate(low_files):
+        folder = os.path.join(os.path.dirname(lp), os.path.splitext(os.path.basename(lp))[0])
+        hp = []
+        for e in ext:
+            hp += glob.glob(folder + os.sep + "*." + e)
+        high_files += hp
+        parent += [idx] * len(hp)
+    if not high_files:
+        return None, [], len(low_files)
+    high_feats, _ = embed_files(embedder_high, high_files, batch_size, num_workers)
+    low_of_high = low_feats.index_select(0, torch.as_tensor(parent, device=low_feats.device))
+    tree = high_feats + 0.25 * low_of_high if tree_fusion == "fusion" else torch.cat([high_feats, low_of_high], dim=-1)
+    return tree, high_files, len(low_files)
+
+
+@torch.no_grad()
 def compute_tree_feats(args, bags_list, embedder_low, embedder_high, save_path=None):
-    """compute_feats.py:84-126 — every high-magnification patch is paired with its low-mag parent:
-    'cat' -> [high(512) || low(512)], 'fusion' -> high + 0.25*low."""
+    """compute_feats.py:84-126."""
     embedder_low.eval()
     embedder_high.eval()
-    if args.tree_fusion not in ("fusion", "cat"):
-        raise NotImplementedError(f"{args.tree_fusion} is not an excepted option for --tree_fusion. "
-                                  "This argument accepts 2 options: 'fusion' and 'cat'.")
     _, rank = ddist.world_rank()
     for i, bag in enumerate(bags_list):
-        low_files = glob_patches(bag, "low")
-        low_feats, _ = embed_files(embedder_low, low_files, args.batch_size, args.num_workers)
-        high_files, parent = [], []
-        for idx, lp in enumerate(low_files):
-            folder = os.path.join(os.path.dirname(lp), os.path.splitext(os.path.basename(lp))[0])
-            hp = glob.glob(folder + os.sep + "*.jpg") + glob.glob(folder + os.sep + "*.jpeg")
-            high_files += hp
-            parent += [idx] * len(hp)
+        tree, high_files, n_low = tree_feats_of_bag(bag, embedder_low, embedder_high, args.tree_fusion,
+                                                    args.batch_size, args.num_workers)
         if rank == 0:
-            sys.stdout.write("\r Computed: {}/{} -- {} low / {} high".format(i + 1, len(bags_list), len(low_files), len(high_files)))
-        if not high_files:
+            sys.stdout.write("\r Computed: {}/{} -- {} low / {} high".format(i + 1, len(bags_list), n_low, len(high_files)))
+        if tree is None:
             if rank == 0:
                 print("No valid patch extracted from: " + bag)
             continue
-        high_feats, _ = embed_files(embedder_high, high_files, args.batch_size, args.num_workers)
-        low_of_high = low_feats.index_select(0, torch.as_tensor(parent, device=low_feats.device))
-        tree = high_feats + 0.25 * low_of_high if args.tree_fusion == "fusion" else torch.cat([high_feats, low_of_high], dim=-1)
         if rank == 0:
             save_feats_csv(tree, _bag_csv_path(save_path, bag), npy=getattr(args, "save_npy", False))
     if rank == 0:
@@ -246,22 +262,39 @@ def attention_colormap(A, pos_arr, bag_prediction, thres, colors, class_names=No
 
 
 @torch.no_grad()
-def attention_maps(args, bags_list, milnet, colors=None, rng=None):
+def attention_maps(args, bags_list, milnet, colors=None, rng=None, embedder_low=None, embedder_high=None):
     """attention_map.test (:59-118): embed -> aggregate (features never leave the device) ->
-    threshold -> colour map PNG (+ optional attention CSV)."""
+    threshold -> colour map PNG (+ optional attention CSV).
+
+    Multi-scale (new: ``args.magnification == "tree"`` with the two embedders): the bag folder holds the
+    low-magnification tiles and one sub-folder of high-magnification children per tile (the layout
+    compute_tree_feats reads, compute_feats.py:91-101); the [high || low] tree features go through
+    ``milnet`` = MILNet(FCLayer(feats_size), BClassifier(feats_size)) and the map is painted at the high tiles'
+    positions."""
     from PIL import Image
     milnet.eval()
     rng = rng or np.random
     colors = colors or [rng.choice(range(256), size=3) for _ in range(args.num_classes)]
     _, rank = ddist.world_rank()
+    tree = getattr(args, "magnification", "single") == "tree"
+    if tree and (embedder_low is None or embedder_high is None):
+        raise ValueError("multi-scale attention maps need the low- and the high-magnification embedder")
     out = []
     for bag in bags_list:
-        files = glob.glob(os.path.join(bag, "*." + args.patch_ext))
-        if not files:
-            continue
-        feats, classes, pos_arr = embed_files(milnet.i_classifier, files, args.batch_size, args.num_workers,
-                                              want_position=True)
-        bag_prediction, A, _ = milnet.b_classifier(feats, classes)
+        if tree:
+            feats, files, _ = tree_feats_of_bag(bag, embedder_low, embedder_high, getattr(args, "tree_fusion", "cat"),
+                                                args.batch_size, args.num_workers, ext=(args.patch_ext,))
+            if feats is None:
+                continue
+            pos_arr = np.vstack([patch_position(f) for f in files])
+            _, bag_prediction, A, _ = milnet(feats)
+        else:
+            files = glob.glob(os.path.join(bag, "*." + args.patch_ext))
+            if not files:
+                continue
+            feats, classes, pos_arr = embed_files(milnet.i_classifier, files, args.batch_size, args.num_workers,
+                                                  want_position=True)
+            bag_prediction, A, _ = milnet.b_classifier(feats, classes)
         pred = np.atleast_1d(torch.sigmoid(bag_prediction).squeeze().cpu().numpy())
         cmap = attention_colormap(A.cpu().numpy(), pos_arr, pred, args.thres, colors, args.class_name, bag)
         slide = bag.rstrip(os.sep).split(os.sep)[-1]
@@ -274,3 +307,124 @@ def attention_maps(args, bags_list, milnet, colors=None, rng=None):
                 df.to_csv(os.path.join(args.score_path, slide + ".csv"), index=False)
         out.append((slide, pred, cmap))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-scale end to end (BASELINE configs[4]): WSI array -> tiles at two magnifications -> embed both ->
+# [high || low] tree features (compute_feats.py:84-126, 113-114) -> MILNet(feats_size=1024) -> attention map
+# (attention_map.py:86-113).  Everything between the decoded slide array and the colour map stays on the
+# device; with torch.distributed initialised the LOW tiles (each with its 16 children) are sharded
+# contiguously over the ranks, the concatenation happens where both halves were embedded, and ONE all-gather
+# of the [N_r, 1024] tree rows precedes aggregation.
+# ---------------------------------------------------------------------------------------------
+def box_downsample_u8(img, factor=4):
+    """[H,W,3] uint8 -> [H/f, W/f, 3] uint8: mean over f x f boxes, round half up — the lower pyramid level of a
+    synthetic slide (a real slide's levels come from the scanner / deepzoom_tiler.py:214,226-227; the tiler is
+    out of scope, so this is only the data generator of the synthetic two-level WSI)."""
+    H, W, C = img.shape
+    assert H % factor == 0 and W % factor == 0 and factor * factor * 255 < 32768
+    v = img.view(H // factor, factor, W // factor, factor, C)
+    s = torch.zeros((H // factor, W // factor, C), dtype=torch.int16, device=img.device)
+    for dy in range(factor):           # f*f strided byte reads, one int16 accumulator: no 4x-sized temporary
+        for dx in range(factor):
+            s += v[:, dy, :, dx, :]
+    n = factor * factor
+    return ((s + n // 2) // n).to(torch.uint8)
+
+
+def tile_grid(img, tile=224):
+    """[H,W,3] uint8 -> ([gy*gx, tile, tile, 3] uint8 contiguous tiles in row-major grid order, gy, gx)."""
+    H, W, C = img.shape
+    gy, gx = H // tile, W // tile
+    t = img[: gy * tile, : gx * tile].view(gy, tile, gx, tile, C).permute(0, 2, 1, 3, 4)
+    return t.reshape(gy * gx, tile, tile, C).contiguous(), gy, gx
+
+
+def pyramid_tiles(wsi, tile=224, factor=4, lo=0, hi=None):
+    """Two-level tiling of a slide array [H,W,3] uint8 (H, W multiples of tile*factor): every low-magnification
+    tile covers factor x factor high-magnification tiles (20x / 5x: factor 4, deepzoom_tiler.py:214,226-227).
+    For the low tiles [lo, hi) of the row-major low grid (default: all) returns
+    (low [n,t,t,3], high [n*f*f,t,t,3] ordered parent-major then row-major inside the parent — the order
+    compute_tree_feats walks, compute_feats.py:98-109 —, parent [n*f*f] long (index into `low`),
+    pos_high [n*f*f,2] (row, col) in the high-magnification grid).  One gather copy per level."""
+    H, W, C = wsi.shape
+    assert H % (tile * factor) == 0 and W % (tile * factor) == 0, "slide sides must be multiples of tile*factor"
+    gy, gx = H // (tile * factor), W // (tile * factor)
+    hi = gy * gx if hi is None else hi
+    dev = wsi.device
+    li = torch.arange(lo, hi, device=dev)
+    ly, lx = li // gx, li % gx
+    low_img = box_downsample_u8(wsi, factor)
+    low = low_img.view(gy, tile, gx, tile, C).permute(0, 2, 1, 3, 4)[ly, lx].contiguous()
+    # [gy, gx, f(row), f(col), tile, tile, C] view of the slide; advanced indexing copies only this range's tiles
+    hv = wsi.view(gy, factor, tile, gx, factor, tile, C).permute(0, 3, 1, 4, 2, 5, 6)
+    high = hv[ly, lx].reshape((hi - lo) * factor * factor, tile, tile, C)
+    cy = torch.arange(factor, device=dev).repeat_interleave(factor)  # child offsets, row-major
+    cx = torch.arange(factor, device=dev).repeat(factor)
+    rows = (ly[:, None] * factor + cy[None, :]).reshape(-1)
+    cols = (lx[:, None] * factor + cx[None, :]).reshape(-1)
+    parent = torch.arange(hi - lo, device=dev).repeat_interleave(factor * factor)
+    return low, high, parent, torch.stack([rows, cols], dim=1)
+
+
+@torch.no_grad()
+def embed_tiles(i_classifier, tiles, batch_size=256):
+    """IClassifier over resident uint8 NHWC tiles in batches (compute_feats.py:70-76 without the loader: the
+    tiles are already decoded and on the device).  Returns (feats [N,F], classes [N,C])."""
+    fl, cl = [], []
+    for lo in range(0, tiles.shape[0], batch_size):
+        f, c = i_classifier(tiles[lo:lo + batch_size])
+        fl.append(f)
+        cl.append(c)
+    if not fl:
+        dev = tiles.device
+        return (torch.zeros((0, i_classifier.fc.in_features), device=dev),
+                torch.zeros((0, i_classifier.fc.out_features), device=dev))
+    return torch.cat(fl), torch.cat(cl)
+
+
+@torch.no_grad()
+def multiscale_bag(wsi, embedder_low, embedder_high, tree_fusion="cat", tile=224, factor=4, batch_size=256,
+                   timings=None):
+    """Slide array -> tree features [N_high, 1024] ('cat': [high || low], compute_feats.py:113-114) or
+    [N_high, 512] ('fusion': high + 0.25 low, :111-112), plus the high tiles' grid positions [N_high, 2].
+    Sharded by LOW tile over the ranks of the default process group; one all-gather of tree rows."""
+    if tree_fusion not in ("fusion", "cat"):
+        raise NotImplementedError(f"{tree_fusion} is not an excepted option for --tree_fusion. "
+                                  "This argument accepts 2 options: 'fusion' and 'cat'.")
+    world, rank = ddist.world_rank()
+    ch = factor * factor
+    L = (wsi.shape[0] // (tile * factor)) * (wsi.shape[1] // (tile * factor))
+    lo, hi = ddist.shard_range(L, rank, world)
+    low, high, parent, pos = pyramid_tiles(wsi, tile, factor, lo, hi)   # this rank's low tiles and their children
+    f_low, _ = embed_tiles(embedder_low, low, batch_size)
+    f_high, _ = embed_tiles(embedder_high, high, batch_size)
+    low_of_high = f_low.index_select(0, parent)
+    tree = f_high + 0.25 * low_of_high if tree_fusion == "fusion" else torch.cat([f_high, low_of_high], dim=-1)
+    if world > 1:
+        # shards are whole low tiles: rows per rank = f*f x its low-tile count; ONE collective for the tree rows,
+        # a second small one for the (row, col) positions the map needs
+        import time
+        t0 = time.perf_counter()
+        sizes = [(ddist.shard_range(L, r, world)[1] - ddist.shard_range(L, r, world)[0]) * ch for r in range(world)]
+        tree = ddist.all_gather_rows_sized(tree, sizes)
+        pos = ddist.all_gather_rows_sized(pos, sizes)
+        if timings is not None:
+            if tree.is_cuda:
+                torch.cuda.synchronize()
+            timings["allgather_s"] = timings.get("allgather_s", 0.0) + time.perf_counter() - t0
+    return tree, pos
+
+
+@torch.no_grad()
+def multiscale_attention_map(wsi, embedder_low, embedder_high, milnet, thres, colors, tree_fusion="cat", tile=224,
+                             factor=4, batch_size=256, class_names=None, log=lambda *_: None, timings=None):
+    """configs[4] end to end for ONE slide array: tile -> two-scale embed -> concat -> MILNet(FCLayer(1024, C),
+    BClassifier(1024, C)) -> sigmoid(bag logits) vs thresholds -> colour map at high-tile resolution.
+    Returns dict(feats, classes, pred, A, B, prob, cmap, pos); only `prob` [C] and the final map leave the device
+    (attention_map.py:86-113 does the map on the host too)."""
+    feats, pos = multiscale_bag(wsi, embedder_low, embedder_high, tree_fusion, tile, factor, batch_size, timings)
+    classes, pred, A, B = milnet(feats)
+    prob = np.atleast_1d(torch.sigmoid(pred).squeeze().cpu().numpy())
+    cmap = attention_colormap(A.cpu().numpy(), pos.cpu().numpy(), prob, thres, colors, class_names, "slide", log)
+    return dict(feats=feats, classes=classes, pred=pred, A=A, B=B, prob=prob, cmap=cmap, pos=pos)

@@ -157,3 +157,56 @@ def test_global_row_index_survives_the_float_message_beyond_2_pow_24():
     out = dd.sharded_bag_forward(net, x, off, gather=lambda t, group=None: [t])
     assert torch.equal(out[4], torch.argmax(ref[0], dim=0) + off)
     assert torch.allclose(out[1], ref[1], atol=1e-5)
+
+
+def _ms_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "oracle")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import torch.nn as nn
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dsmil
+    import resnet_oracle as ro
+    from dsmil_wsi_amd import pipeline as pl
+    from dsmil_wsi_amd.resnet import resnet18
+    torch.set_num_threads(2)
+
+    def emb(seed):
+        res = resnet18(norm_layer=nn.InstanceNorm2d)
+        res.fc = nn.Identity()
+        res.load_state_dict(ro.make_weights(seed=seed), strict=True)
+        return dsmil.IClassifier(res, 512, output_class=2).eval()
+    e_lo, e_hi = emb(81), emb(82)
+    T = 64   # 64 -> 2x2 in layer4 (torch's instance_norm refuses a 1x1 map)
+    g = torch.Generator().manual_seed(6)
+    wsi = torch.randint(0, 256, (1 * T * 4, 3 * T * 4, 3), generator=g, dtype=torch.uint8)   # 3 low / 48 high tiles
+    tree, pos = pl.multiscale_bag(wsi, e_lo, e_hi, "cat", tile=T, batch_size=8)              # sharded 2 + 1 low tiles
+    low, high, parent, pos_all = pl.pyramid_tiles(wsi, T)
+    with torch.no_grad():
+        f_lo, _ = e_lo(low)
+        f_hi, _ = e_hi(high)
+    full = torch.cat([f_hi, f_lo[parent]], dim=1)
+    q.put((rank, bool(torch.allclose(tree, full, atol=2e-6, rtol=1e-5)), bool(torch.equal(pos, pos_all)), tuple(tree.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multiscale_bag_sharded_by_low_tile_equals_unsharded():
+    """configs[4] over 2 ranks: low tiles (with their 16 children) are cut contiguously over the ranks, the
+    [high || low] concatenation happens locally, ONE all-gather of tree rows: the unsharded bag (up to the batch-
+    composition effects of torch's CPU convolutions; the native kernels are batch-independent, test_resnet_gpu.py)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ms_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, same_pos, shape in res:
+        assert same and same_pos and shape == (48, 1024)

@@ -150,6 +150,124 @@ def test_attention_map_end_to_end(workdir):
     assert sc.shape == (6, 3) and abs(sc["0"].sum() - 1.0) < 1e-4
 
 
+def test_attention_map_multiscale_from_files(workdir):
+    """attention_map.py --magnification tree (new): low tiles + a folder of high children per tile -> [high || low]
+    1024-d tree features (compute_feats.py:113-114) -> MILNet(FCLayer(1024), BClassifier(1024)) -> map at the high
+    tiles' positions.  The attention CSV must equal the product modules applied to the same tree features."""
+    import attention_map as am
+    import pandas as pd
+    from util import state_dict_from_npz
+    from conftest import load_weights
+    from dsmil_wsi_amd import pipeline as pl
+    for name, seed in (("low", 61), ("high", 62)):
+        emb = collections.OrderedDict(ro.make_weights(seed=seed))
+        for n in ("l1.weight", "l1.bias", "l2.weight", "l2.bias"):
+            emb[n] = torch.zeros(1)
+        os.makedirs("test/weights", exist_ok=True)
+        torch.save(emb, f"test/weights/embedder_{name}.pth")
+    torch.save(state_dict_from_npz(load_weights("tree")), "test/weights/aggregator_tree.pth")
+    for lr in range(2):
+        for lc in range(2):
+            _jpeg(f"test/pyr/slideT/{lr}_{lc}.jpg", 400 + 10 * lr + lc)
+            for hr in range(2):
+                for hc in range(2):
+                    _jpeg(f"test/pyr/slideT/{lr}_{lc}/{2 * lr + hr}_{2 * lc + hc}.jpg", 500 + 100 * lr + 40 * lc + 2 * hr + hc)
+    am.main(["--magnification", "tree", "--feats_size", "1024", "--embedder_weights_low", "test/weights/embedder_low.pth",
+             "--embedder_weights_high", "test/weights/embedder_high.pth", "--aggregator_weights",
+             "test/weights/aggregator_tree.pth", "--bag_path", "test/pyr", "--num_workers", "0", "--thres", "0.0", "0.0",
+             "--export_scores", "1", "--batch_size", "8"])
+    from PIL import Image
+    img = np.asarray(Image.open("test/output/slideT.png"))
+    assert img.shape == (4 * 32, 4 * 32, 3)
+    sc = pd.read_csv("test/score/slideT.csv")
+    assert sc.shape == (16, 3) and abs(sc["0"].sum() - 1.0) < 1e-4 and abs(sc["1"].sum() - 1.0) < 1e-4
+    # the same through the library functions: tree features -> product MILNet on CPU
+    args = am.build_parser().parse_args(["--magnification", "tree", "--feats_size", "1024",
+                                         "--embedder_weights_low", "test/weights/embedder_low.pth",
+                                         "--embedder_weights_high", "test/weights/embedder_high.pth",
+                                         "--aggregator_weights", "test/weights/aggregator_tree.pth"])
+    lo, hi, net = am.build_tree_models(args, torch.device("cpu"))
+    tree, files, n_low = pl.tree_feats_of_bag("test/pyr/slideT", lo, hi, "cat", 8, 0, ext=("jpg",))
+    assert tree.shape == (16, 1024) and n_low == 4
+    with torch.no_grad():
+        _, _, A, _ = net.eval()(tree)
+    order = [str(pl.patch_position(f)) for f in files]
+    assert list(sc["pos"]) == order
+    np.testing.assert_allclose(sc[["0", "1"]].to_numpy(), A.numpy(), atol=1e-6)
+
+
+def test_pyramid_tiles_of_a_synthetic_slide():
+    """configs[4] data generator: every low tile covers 4 x 4 high tiles; children are listed parent-major and
+    row-major inside the parent (the walk of compute_feats.py:98-109)."""
+    from dsmil_wsi_amd import pipeline as pl
+    g = torch.Generator().manual_seed(0)
+    T = 16
+    wsi = torch.randint(0, 256, (2 * T * 4, 3 * T * 4, 3), generator=g, dtype=torch.uint8)
+    low, high, parent, pos = pl.pyramid_tiles(wsi, tile=T, factor=4)
+    assert low.shape == (6, T, T, 3) and high.shape == (96, T, T, 3)
+    assert parent.tolist() == [i // 16 for i in range(96)]
+    for k in (0, 5, 37, 95):
+        r, c = pos[k].tolist()
+        assert torch.equal(high[k], wsi[r * T:(r + 1) * T, c * T:(c + 1) * T])
+        li = int(parent[k])
+        ly, lx = divmod(li, 3)
+        assert (r // 4, c // 4) == (ly, lx)
+        box = wsi[ly * 4 * T:(ly + 1) * 4 * T, lx * 4 * T:(lx + 1) * 4 * T].view(T, 4, T, 4, 3).double().mean((1, 3))
+        assert torch.equal(low[li], torch.floor(box + 0.5).to(torch.uint8))
+    assert len({tuple(p) for p in pos.tolist()}) == 96
+
+
+@pytest.mark.gpu
+def test_multiscale_end_to_end_on_gpu():
+    """BASELINE configs[4] on the device: seeded uint8 slide array -> tiles at two magnifications -> both embedders
+    (uint8 ingest, native trunks) -> [high || low] -> MILNet(feats_size=1024) (native aggregator) -> attention map.
+    Checks: tree features vs the fp64 embedder oracle on the same tiles; aggregator outputs vs the fp64 aggregator
+    oracle ON THE GATHERED FEATURES; the colour map vs pipeline.attention_colormap applied to the oracle's attention."""
+    import agg_oracle as orc
+    from conftest import load_weights
+    from util import build_net
+    from dsmil_wsi_amd import pipeline as pl
+    from dsmil_wsi_amd.resnet import resnet18
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(4)
+    wsi = torch.randint(0, 256, (2 * 896, 2 * 896, 3), generator=g, dtype=torch.uint8)     # 4 low / 64 high tiles
+
+    def emb(seed):
+        res = resnet18(norm_layer=nn.InstanceNorm2d)
+        res.fc = nn.Identity()
+        w = ro.make_weights(seed=seed)
+        res.load_state_dict(w, strict=True)
+        for p_ in res.parameters():
+            p_.requires_grad = False
+        return dsmil.IClassifier(res, 512, output_class=2).eval().to(dev), w
+    (e_lo, w_lo), (e_hi, w_hi) = emb(71), emb(72)
+    net = build_net("tree", dev)
+    colors = [np.array([255, 40, 0]), np.array([0, 90, 255])]
+    out = pl.multiscale_attention_map(wsi.to(dev), e_lo, e_hi, net, [0.0, 0.0], colors, batch_size=16)
+    assert out["feats"].shape == (64, 1024) and out["A"].shape == (64, 2) and out["cmap"].shape == (8 * 32, 8 * 32, 3)
+    # embedder halves vs the fp64 oracle on the very tiles the pipeline cut
+    low, high, parent, pos = pl.pyramid_tiles(wsi)
+    to_f = lambda t: t.permute(0, 3, 1, 2).double().div(255)
+    with torch.no_grad():
+        f_lo = ro.resnet18_in_features(to_f(low), {k: v.double() for k, v in w_lo.items()})
+        f_hi = ro.resnet18_in_features(to_f(high), {k: v.double() for k, v in w_hi.items()})
+    tree_ref = torch.cat([f_hi, f_lo[parent]], dim=1).numpy()
+    feats = out["feats"].cpu().numpy()
+    np.testing.assert_allclose(feats, tree_ref, atol=1e-4, rtol=1e-4)
+    assert np.array_equal(out["pos"].cpu().numpy(), pos.numpy())
+    # aggregator vs the fp64 oracle on the gathered features
+    r = orc.milnet_forward(feats, load_weights("tree"), dtype="f64")
+    np.testing.assert_allclose(out["classes"].cpu().numpy(), r[0], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(out["pred"].cpu().numpy(), r[1], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(out["A"].cpu().numpy(), r[2], atol=1e-6, rtol=1e-3)
+    np.testing.assert_allclose(out["B"].cpu().numpy(), r[3], atol=1e-4, rtol=1e-5)
+    # map bytes vs the host colour-map function on the oracle's attention (a byte may differ where rint() sits on .5)
+    prob = 1.0 / (1.0 + np.exp(-np.asarray(r[1], np.float64).ravel()))
+    cm = pl.attention_colormap(np.asarray(r[2], np.float64), pos.numpy(), prob, [0.0, 0.0], colors)
+    assert cm.shape == out["cmap"].shape
+    assert np.abs(cm.astype(int) - out["cmap"].astype(int)).max() <= 1
+
+
 @pytest.mark.gpu
 def test_entry_points_on_gpu_use_native_path(tmp_path, monkeypatch):
     """compute_feats.py, attention_map.py and train_tcga.py on a real GPU: same tiny datasets, the
