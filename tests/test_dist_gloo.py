@@ -189,7 +189,7 @@ def _ms_worker(rank, world, port, q):
         f_lo, _ = e_lo(low)
         f_hi, _ = e_hi(high)
     full = torch.cat([f_hi, f_lo[parent]], dim=1)
-    q.put((rank, bool(torch.allclose(tree, full, atol=2e-6, rtol=1e-5)), bool(torch.equal(pos, pos_all)), tuple(tree.shape)))
+    q.put((rank, bool(torch.allclose(tree, full, atol=5e-5, rtol=1e-4)), bool(torch.equal(pos, pos_all)), tuple(tree.shape)))
     dist.barrier()
     dist.destroy_process_group()
 
