@@ -354,9 +354,10 @@ def embedder_leg(cx):
     value = world * Bp * passes / dt
     # ideal time of the conv kernels on the pipes they run on: Winograd convs = direct FLOPs / 2.25 x 9 plane products
     # on the bf16 pipe; direct convs on the f32 MFMA pipe (or 9 products on the bf16 pipe when built that way)
-    forms = json.loads(ctypes.c_char_p(cx.L.dsmil_resnet_forms()).value.decode()) if hasattr(cx.L, "dsmil_resnet_forms") else {}
-    wino_np = forms.get("wino_products", 9)
-    direct_np = forms.get("direct_products", 0)
+    wp_, dp_ = ctypes.c_int32(0), ctypes.c_int32(0)
+    cx.L.dsmil_resnet_mfma_forms(ctypes.byref(wp_), ctypes.byref(dp_))
+    wino_np, direct_np = int(wp_.value), int(dp_.value)
+    forms = {"wino_products": wino_np, "direct_products": direct_np}
     t_wino = WINO_FLOPS_PER_PATCH / 2.25 * (wino_np / (PEAK_BF16_MFMA_TFLOPS * 1e12) if wino_np else 1 / (PEAK_F32_MFMA_TFLOPS * 1e12))
     t_direct = DIRECT_FLOPS_PER_PATCH * (direct_np / (PEAK_BF16_MFMA_TFLOPS * 1e12) if direct_np else 1 / (PEAK_F32_MFMA_TFLOPS * 1e12))
     kern_s = kern_ms_tot * 1e-3
@@ -379,7 +380,7 @@ def embedder_leg(cx):
                          # class runs on / measured conv-kernel time
                          "frac": round(frac_pipe, 4) if frac_pipe else None,
                          "frac_is": "sum over conv classes of (executed MFMA FLOPs / peak of the pipe they run on) / kernel time",
-                         "peak": PEAK_BF16_MFMA_TFLOPS, "executed_forms": forms or {"wino_products": 9, "direct_products": 0},
+                         "peak": PEAK_BF16_MFMA_TFLOPS, "executed_forms": forms,
                          "traffic": _pmc("pmc_k_conv.json", "hbm_bytes_per_forward"),
                          "kernel_ms_total": round(kern_ms_tot, 3), "launches": launches, "alg_flops_total": conv_flops,
                          # the figure the >= 60 % target of BASELINE.json refers to: whole forward vs SURVEY §8(d)'s

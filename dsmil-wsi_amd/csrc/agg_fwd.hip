@@ -427,14 +427,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
 }
 
 // fp32 in / fp32 out with the query MLP on bf16 MFMA over exact three-plane cuts (agg_split.h)
-template <int NW, int VEC, int NP>
+template <int NW, int VEC, int NP, bool XE = false>
 __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend_split(AttendArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BM = NW * 32;
     const int bag = a.bag0 + (int)blockIdx.y, tile = (int)blockIdx.x;
     f32x16 Q[4];
     if constexpr (VEC == 4) {
-        if (!mlp_tile_split_dma<NW, NP>(a, bag, tile, smem, Q)) return;
+        if (!mlp_tile_split_dma<NW, NP, XE>(a, bag, tile, smem, Q)) return;
     } else {
         if (!mlp_tile_split<NW, VEC, NP>(a, bag, tile, smem, Q)) return;
     }
@@ -821,7 +821,7 @@ int launch_attend(const AttendArgs& a, long long max_rows, int n_bags, hipStream
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
-template <int NW, int VEC, int NP>
+template <int NW, int VEC, int NP, bool XE = false>
 int launch_attend_split(const AttendArgs& a, long long max_rows, int n_bags, hipStream_t st) {
     constexpr int BM = NW * 32;
     size_t lds = VEC == 4 ? (size_t)(3 * S3_CHUNK_F4 * 4 + 2 * BM * 32) * sizeof(float)
@@ -834,16 +834,16 @@ int launch_attend_split(const AttendArgs& a, long long max_rows, int n_bags, hip
     if (!attr_done) {
 #ifdef DSMIL_EXPERIMENTS
         int nb = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_query_attend_split<NW, VEC, NP>, NW * 64, lds);
-        fprintf(stderr, "[dsmil] k_query_attend_split<%d,%d,%d>: lds %zu B, %d blocks/CU\n", NW, VEC, NP, lds, nb);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_query_attend_split<NW, VEC, NP, XE>, NW * 64, lds);
+        fprintf(stderr, "[dsmil] k_query_attend_split<%d,%d,%d,%d>: lds %zu B, %d blocks/CU\n", NW, VEC, NP, (int)XE, lds, nb);
 #endif
-        (void)hipFuncSetAttribute((const void*)k_query_attend_split<NW, VEC, NP>,
+        (void)hipFuncSetAttribute((const void*)k_query_attend_split<NW, VEC, NP, XE>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 grid((unsigned)((max_rows + BM - 1) / BM), (unsigned)n_bags);
     const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
-    hipLaunchKernelGGL((k_query_attend_split<NW, VEC, NP>), grid, dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((k_query_attend_split<NW, VEC, NP, XE>), grid, dim3(NW * 64), lds, st, a);
     dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
@@ -1045,6 +1045,10 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, nb, st) : launch_attend_bf16<1>(a, max_rows, nb, st);
         else if (mode == 9 && NW == 4) rc = v4 ? launch_attend_split<4, 4, 9>(a, max_rows, nb, st) : launch_attend_split<4, 1, 9>(a, max_rows, nb, st);
         else if (mode == 9) rc = v4 ? launch_attend_split<1, 4, 9>(a, max_rows, nb, st) : launch_attend_split<1, 1, 9>(a, max_rows, nb, st);
+#ifdef DSMIL_EXPERIMENTS
+        else if (mode == 6 && NW == 4 && v4 && (a.expt & 8)) rc = launch_attend_split<4, 4, 6, true>(a, max_rows, nb, st);
+        else if (mode == 6 && NW == 1 && v4 && (a.expt & 8)) rc = launch_attend_split<1, 4, 6, true>(a, max_rows, nb, st);
+#endif
         else if (mode == 6 && NW == 4) rc = v4 ? launch_attend_split<4, 4, 6>(a, max_rows, nb, st) : launch_attend_split<4, 1, 6>(a, max_rows, nb, st);
         else if (mode == 6) rc = v4 ? launch_attend_split<1, 4, 6>(a, max_rows, nb, st) : launch_attend_split<1, 1, 6>(a, max_rows, nb, st);
         else if (NW == 8) rc = launch_attend<8, 4>(a, max_rows, nb, st);

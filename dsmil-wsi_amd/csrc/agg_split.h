@@ -225,14 +225,21 @@ __device__ __forceinline__ void s3_wait_vm_dyn(int n) {  // n is wave-uniform
         case 0: S3_WAIT_VM(0); break;
         case 3: S3_WAIT_VM(3); break;
         case 4: S3_WAIT_VM(4); break;
+        case 6: S3_WAIT_VM(6); break;
         case 7: S3_WAIT_VM(7); break;
+        case 10: S3_WAIT_VM(10); break;
         case 12: S3_WAIT_VM(12); break;
         case 16: S3_WAIT_VM(16); break;
+        case 24: S3_WAIT_VM(24); break;
+        case 28: S3_WAIT_VM(28); break;
         default: S3_WAIT_VM(0); break;
     }
 }
 
-template <int NW, int NP>
+// XE ("x early"): feature chunk c+2 is issued at the ODD step 2c+1 (its buffer, chunk c's, was last read in the
+// middle of step 2c by this very wave) instead of chunk c+1 at the even step 2c: the HBM-sourced pieces get a full
+// extra step (~1000+ cycles) of flight before their first read.
+template <int NW, int NP, bool XE = false>
 __device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag, int tile, float* smem, f32x16 (&Q)[4]) {
     static_assert(NP == 6 || NP == 9, "plane products");
     constexpr int BM = NW * 32;
@@ -315,7 +322,12 @@ __device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag,
     issue_w(0);
     issue_x(0);
     issue_w(1);  // nst >= 2 always
-    S3_WAIT_VM(WPW);
+    if (XE && a.nonlinear && nk1 > 1) {
+        issue_x(1);
+        S3_WAIT_VM(WPW + 4);
+    } else {
+        S3_WAIT_VM(WPW);
+    }
     __builtin_amdgcn_s_barrier();
     STAMP();
     // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] X[n][k], 16 k per step.
@@ -336,10 +348,13 @@ __device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag,
     // one 16-k step; PARITY / NEXT_X / CUT_NEXT are literals at every call site so that the whole
     // step is ONE basic block (the compiler then interleaves the cut with the MFMAs) and every
     // wait count is an immediate
-    auto step = [&](int s, auto parity, auto next_x, auto cut_next) {
+    // XE: NEXT_X on an ODD step issues chunk (s>>1)+2; HAS_X1 says whether chunk (s>>1)+1 exists (and is then in
+    // flight or landed): it sets how many younger pieces each counted wait may leave outstanding
+    auto step = [&](int s, auto parity, auto next_x, auto cut_next, auto has_x1) {
         constexpr bool ODD = decltype(parity)::value, NEXT_X = decltype(next_x)::value, CUT = decltype(cut_next)::value;
+        constexpr bool HAS_X1 = decltype(has_x1)::value;
         issue_w(s + 2);
-        if constexpr (NEXT_X) issue_x((s >> 1) + 1);
+        if constexpr (NEXT_X) issue_x((s >> 1) + (XE ? 2 : 1));
         const f32x4* w = sW + (s % 3) * S3_CHUNK_F4 + lane;
         // hand-placed issue order (sched_barrier after every MFMA slot): the compiler otherwise
         // clumps the ~45 VALU ops of the cut, and the MFMA pipe idles behind the clump
@@ -363,7 +378,10 @@ __device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag,
                 }
                 if constexpr (CUT) {
                     if (k == 1) {
-                        if constexpr (ODD) s3_wait_vm_dyn(WPW);  // own pieces of chunk c+1 (issued a step ago) landed
+                        // own pieces of chunk c+1 landed.  Plain: issued a step ago, only this step's weight pieces are
+                        // younger.  XE: issued two steps ago; younger = w(s+1), w(s+2) and, if issued, x(c+2)
+                        if constexpr (ODD && !XE) s3_wait_vm_dyn(WPW);
+                        if constexpr (ODD && XE) s3_wait_vm_dyn(2 * WPW + (NEXT_X ? 4 : 0));
                         xr0 = *reinterpret_cast<const f32x4*>(xnp + jn * 4);
                         xr1 = *reinterpret_cast<const f32x4*>(xnp + (jn ^ 1) * 4);
                     }
@@ -391,19 +409,33 @@ __device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag,
 #pragma unroll
             for (int p = 0; p < 3; ++p) xb[p] = xn[p];
         }
-        s3_wait_vm_dyn(WPW + (NEXT_X ? 4 : 0));  // everything issued BEFORE this step has landed
+        // w(s+1) has landed.  Plain: everything issued BEFORE this step has landed.  XE: the feature chunk issued
+        // at the previous odd step (even steps) or at this one (odd steps) may stay in flight
+        if constexpr (!XE) s3_wait_vm_dyn(WPW + (NEXT_X ? 4 : 0));
+        else s3_wait_vm_dyn(WPW + ((ODD ? NEXT_X : HAS_X1) ? 4 : 0));
         __builtin_amdgcn_s_barrier();
         STAMP();
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    if (a.nonlinear) {  // a weight chunk is due two steps ahead throughout GEMM 1
-        for (int c = 0; c + 1 < nk1; ++c) {
-            step(2 * c, F_{}, T_{}, T_{});
-            step(2 * c + 1, T_{}, F_{}, T_{});
+    if (a.nonlinear && XE) {
+        for (int c = 0; c + 2 < nk1; ++c) {
+            step(2 * c, F_{}, F_{}, T_{}, T_{});
+            step(2 * c + 1, T_{}, T_{}, T_{}, T_{});
         }
-        step(nks - 2, F_{}, F_{}, T_{});
-        step(nks - 1, T_{}, F_{}, F_{});
+        if (nk1 > 1) {
+            step(nks - 4, F_{}, F_{}, T_{}, T_{});
+            step(nks - 3, T_{}, F_{}, T_{}, T_{});
+        }
+        step(nks - 2, F_{}, F_{}, T_{}, F_{});
+        step(nks - 1, T_{}, F_{}, F_{}, F_{});
+    } else if (a.nonlinear) {  // a weight chunk is due two steps ahead throughout GEMM 1
+        for (int c = 0; c + 1 < nk1; ++c) {
+            step(2 * c, F_{}, T_{}, T_{}, F_{});
+            step(2 * c + 1, T_{}, F_{}, T_{}, F_{});
+        }
+        step(nks - 2, F_{}, F_{}, T_{}, F_{});
+        step(nks - 1, T_{}, F_{}, F_{}, F_{});
     } else
     for (int s = 0; s < nks; ++s) {
         // feature chunk c+1 goes out on the even step 2c; its first use is the mid-step read of step 2c+1

@@ -1510,6 +1510,12 @@ void set_conv_attrs() {
 
 extern "C" {
 
+int dsmil_resnet_mfma_forms(int32_t* wino_products, int32_t* direct_products) {
+    if (wino_products) *wino_products = wino_s3() ? 9 : 0;
+    if (direct_products) *direct_products = conv_s3() ? 9 : 0;
+    return DSMIL_OK;
+}
+
 int32_t dsmil_resnet_num_convs(int32_t depth) { const Arch* A = arch_of(depth); return A ? A->nconv : 0; }
 int32_t dsmil_resnet_norm_channels(int32_t depth) { const Arch* A = arch_of(depth); return A ? norm_offset(*A, A->nconv) : 0; }
 size_t dsmil_resnet_packed_bytes(int32_t depth) {

@@ -229,6 +229,10 @@ int dsmil_resnet18bn_forward(const void* x, int32_t x_is_u8_nhwc, int32_t B, int
  * (the activation shapes do not depend on the depth).  The *18* entry points above are these with
  * depth = 18.  feats is [B,512] for both depths. */
 int32_t dsmil_resnet_num_convs(int32_t depth);
+/* Which matrix pipe the trunk's convolutions run on (for roofline accounting): bf16 plane products per fp32 MAC
+ * of the Winograd convs (3x3 stride 1) and of the direct convs (3x3 stride 2, 1x1) — 9 / 6 = bf16 MFMA over exact
+ * three-plane cuts, 0 = v_mfma_f32_32x32x2_f32.  Read once per process from DSMIL_WINO / DSMIL_CONV. */
+int dsmil_resnet_mfma_forms(int32_t* wino_products, int32_t* direct_products);
 int32_t dsmil_resnet_norm_channels(int32_t depth);
 size_t dsmil_resnet_packed_bytes(int32_t depth);
 int dsmil_resnet_pack(int32_t depth, const float* const* conv_w, float* packed, void* stream);
