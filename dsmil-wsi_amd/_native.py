@@ -29,6 +29,11 @@ class AggParams(ctypes.Structure):
                 ("C", ctypes.c_int32), ("nonlinear", ctypes.c_int32)]
 
 
+class AggOpts(ctypes.Structure):
+    """struct dsmil_agg_opts (include/dsmil_hip.h)."""
+    _fields_ = [("packed_split", ctypes.c_void_p), ("row_map", ctypes.c_void_p)]
+
+
 class AggGrads(ctypes.Structure):
     """struct dsmil_agg_grads (include/dsmil_hip.h)."""
     _fields_ = [(n, ctypes.c_void_p) for n in
@@ -42,10 +47,16 @@ SIGNATURES = {
     "dsmil_agg_mlp_form": (ctypes.c_int, []),
     "dsmil_agg_packed_split_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "dsmil_agg_pack_split": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
-    "dsmil_agg_forward_packed": (ctypes.c_int, [c_f32p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int64,
-                                                ctypes.c_int64, ctypes.POINTER(AggParams), ctypes.c_void_p, c_f32p,
-                                                c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, ctypes.c_void_p,
-                                                ctypes.c_size_t, ctypes.c_void_p]),
+    "dsmil_agg_forward_ex": (ctypes.c_int, [c_f32p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int64,
+                                            ctypes.c_int64, ctypes.POINTER(AggParams), ctypes.POINTER(AggOpts), c_f32p,
+                                            c_f32p, c_f32p, c_f32p, c_f32p, c_i64p, ctypes.c_void_p,
+                                            ctypes.c_size_t, ctypes.c_void_p]),
+    "dsmil_agg_loss_head": (ctypes.c_int, [c_f32p, c_f32p, c_i64p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p,
+                                           c_f32p, ctypes.c_void_p]),
+    "dsmil_agg_backward_ex": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int64, ctypes.POINTER(AggParams), c_f32p,
+                                             c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                             ctypes.POINTER(AggGrads), c_f32p, c_i64p, ctypes.c_void_p, ctypes.c_size_t,
+                                             ctypes.c_void_p]),
     "dsmil_agg_shard_argmax": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.POINTER(AggParams), c_f32p, c_f32p,
                                               c_i64p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dsmil_agg_shard_attend": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int64, ctypes.POINTER(AggParams), c_f32p,

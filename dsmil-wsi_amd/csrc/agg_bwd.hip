@@ -84,11 +84,11 @@ template <int VEC>
 __global__ __launch_bounds__(256) void k_bwd_qrow(
     const float* __restrict__ feats, const int64_t* __restrict__ idx, const float* __restrict__ q0_w,
     const float* __restrict__ q0_b, const float* __restrict__ q2_w, const float* __restrict__ q2_b,
-    float* __restrict__ qmax, int K, int nonlinear) {
+    float* __restrict__ qmax, int K, int nonlinear, const int64_t* __restrict__ rowmap) {
     const int c = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ float s_h[QD];
-    const float* x = feats + idx[c] * (long long)K;
+    const float* x = feats + phys_row(rowmap, idx[c]) * (long long)K;
     for (int jb = 0; jb < 32; jb += 8) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float* wr = q0_w + (long long)(wave * 32 + jb) * K;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_bwd_gh(GhArgs g)
 template <int VEC>
 __global__ __launch_bounds__(256, 2) void k_tn_gemm(const float* __restrict__ Am, const float* __restrict__ Bm,
                                                     float* __restrict__ part, float* __restrict__ part_b,
-                                                    long long N, int Kc, int TNR) {
+                                                    long long N, int Kc, int TNR, const int64_t* __restrict__ bmap) {
     __shared__ __attribute__((aligned(16))) float sA[32 * QD];
     __shared__ __attribute__((aligned(16))) float sB[32 * QD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void k_tn_gemm(const float* __restrict__ Am
             f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
             if (row < rend) {
                 va = *reinterpret_cast<const f32x4*>(Am + row * QD + c4 * 4);
-                vb = load4<VEC, float>(Bm + row * (long long)Kc, k0 + c4 * 4, Kc);
+                vb = load4<VEC, float>(Bm + phys_row(bmap, row) * (long long)Kc, k0 + c4 * 4, Kc);
             }
             *reinterpret_cast<f32x4*>(sA + r * QD + c4 * 4) = va;
             *reinterpret_cast<f32x4*>(sB + r * QD + c4 * 4) = vb;
@@ -311,7 +311,7 @@ __global__ void k_reduce_parts(const float* __restrict__ part, float* __restrict
 template <int VEC>
 __global__ __launch_bounds__(256) void k_tn_small(const float* __restrict__ a, const float* __restrict__ bm,
                                                   float* __restrict__ part, float* __restrict__ part_a,
-                                                  long long N, int M, int Kc, int TNR) {
+                                                  long long N, int M, int Kc, int TNR, const int64_t* __restrict__ bmap) {
     __shared__ __attribute__((aligned(16))) float sacc[4][4][256];
     __shared__ float ssum[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void k_tn_small(const float* __restrict__ a, c
         for (int j = 0; j < 4; ++j) { acc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; asum[j] = 0.f; }
 #pragma unroll 4
         for (long long r = rbeg + wave; r < rend; r += 4) {
-            const f32x4 bv = load4<VEC, float>(bm + r * (long long)Kc, k, Kc);
+            const f32x4 bv = load4<VEC, float>(bm + phys_row(bmap, r) * (long long)Kc, k, Kc);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float av = (m0 + j < M) ? a[r * M + m0 + j] : 0.f;
@@ -375,6 +375,21 @@ __global__ void k_bwd_gvals(const float* __restrict__ A, const float* __restrict
     }
 }
 
+// Sparse instance-stream gradient of the training objective (train_tcga.py:68,70: max over instances): only the
+// critical rows carry gradient, g_fc_w[c] (+)= g_max[c] x[idx_c], g_fc_b[c] (+)= g_max[c].  grid = C.
+__global__ void k_bwd_fc_sparse(const float* __restrict__ feats, const int64_t* __restrict__ idx,
+                                const float* __restrict__ g_max, float* __restrict__ g_fc_w, float* __restrict__ g_fc_b,
+                                int K, int accumulate, const int64_t* __restrict__ rowmap) {
+    const int c = blockIdx.x;
+    const float g = g_max[c];
+    const float* x = feats + phys_row(rowmap, idx[c]) * (long long)K;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float v = g * x[k];
+        g_fc_w[(long long)c * K + k] = accumulate ? g_fc_w[(long long)c * K + k] + v : v;
+    }
+    if (threadIdx.x == 0) g_fc_b[c] = accumulate ? g_fc_b[c] + g : g;
+}
+
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 struct BwdWs {
     size_t gB, Dv, zero, W2T, qmax, gq, gA, gs, gz2, Hb, Qb, gH, part, part_b, off, total;
@@ -418,10 +433,10 @@ int launch_tile_kernel(KernelT kern, const ArgT& arg, int nw, long long N, hipSt
 }
 
 int tn_gemm(const float* Am, const float* Bm, long long N, int Kc, float* part, float* part_b, float* out,
-            float* out_b, int splits, bool v4, hipStream_t st) {
+            float* out_b, int splits, bool v4, hipStream_t st, const int64_t* bmap = nullptr) {
     dim3 grid((unsigned)((Kc + QD - 1) / QD), (unsigned)splits);
-    if (v4) hipLaunchKernelGGL(k_tn_gemm<4>, grid, dim3(256), 0, st, Am, Bm, part, part_b, N, Kc, tn_rows(N));
-    else hipLaunchKernelGGL(k_tn_gemm<1>, grid, dim3(256), 0, st, Am, Bm, part, part_b, N, Kc, tn_rows(N));
+    if (v4) hipLaunchKernelGGL(k_tn_gemm<4>, grid, dim3(256), 0, st, Am, Bm, part, part_b, N, Kc, tn_rows(N), bmap);
+    else hipLaunchKernelGGL(k_tn_gemm<1>, grid, dim3(256), 0, st, Am, Bm, part, part_b, N, Kc, tn_rows(N), bmap);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     const long long n = (long long)QD * Kc;
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, out, splits, n);
@@ -430,10 +445,10 @@ int tn_gemm(const float* Am, const float* Bm, long long N, int Kc, float* part, 
 }
 
 int tn_small(const float* a, const float* bm, long long N, int M, int Kc, float* part, float* part_a, float* out,
-             float* out_a, int splits, bool v4, hipStream_t st) {
+             float* out_a, int splits, bool v4, hipStream_t st, const int64_t* bmap = nullptr) {
     const dim3 grid((unsigned)splits, (unsigned)((Kc + 255) / 256));
-    if (v4) hipLaunchKernelGGL(k_tn_small<4>, grid, dim3(256), 0, st, a, bm, part, part_a, N, M, Kc, tn_rows(N));
-    else hipLaunchKernelGGL(k_tn_small<1>, grid, dim3(256), 0, st, a, bm, part, part_a, N, M, Kc, tn_rows(N));
+    if (v4) hipLaunchKernelGGL(k_tn_small<4>, grid, dim3(256), 0, st, a, bm, part, part_a, N, M, Kc, tn_rows(N), bmap);
+    else hipLaunchKernelGGL(k_tn_small<1>, grid, dim3(256), 0, st, a, bm, part, part_a, N, M, Kc, tn_rows(N), bmap);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     const long long n = (long long)M * Kc;
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, out, splits, n);
@@ -454,7 +469,17 @@ int dsmil_agg_backward(const float* feats, const float* vals, int64_t N, const d
                        const float* A, const float* Bm, const int64_t* idx, const float* g_classes,
                        const float* g_pred, const float* g_A, const float* g_B, const dsmil_agg_grads* g,
                        float* g_vals, void* ws, size_t ws_bytes, void* stream) {
+    return dsmil_agg_backward_ex(feats, vals, N, p, A, Bm, idx, g_classes, nullptr, g_pred, g_A, g_B, g, g_vals, nullptr,
+                                 ws, ws_bytes, stream);
+}
+
+int dsmil_agg_backward_ex(const float* feats, const float* vals, int64_t N, const dsmil_agg_params* p,
+                          const float* A, const float* Bm, const int64_t* idx, const float* g_classes,
+                          const float* g_max, const float* g_pred, const float* g_A, const float* g_B,
+                          const dsmil_agg_grads* g, float* g_vals, const int64_t* rowmap, void* ws, size_t ws_bytes,
+                          void* stream) {
     if (!feats || !p || !A || !Bm || !idx || !g_pred || !g || !ws) return DSMIL_E_INVALID;
+    if (g_max && (!g->fc_w || !g->fc_b)) return DSMIL_E_INVALID;
     if (N <= 0 || p->K <= 0 || p->Kv <= 0 || p->C <= 0) return DSMIL_E_INVALID;
     if (!p->q0_w || !p->q0_b || !p->fcc_w || (p->nonlinear && (!p->q2_w || !p->q2_b))) return DSMIL_E_INVALID;
     if (!g->q0_w || !g->q0_b || !g->fcc_w || !g->fcc_b || (p->nonlinear && (!g->q2_w || !g->q2_b))) return DSMIL_E_INVALID;
@@ -483,17 +508,17 @@ int dsmil_agg_backward(const float* feats, const float* vals, int64_t N, const d
                        g->fcc_w, g->fcc_b, W2T, zero, (long long)N, Kv, C, p->nonlinear);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     // 2. gA = V gB^T  (the forward's FCLayer kernel with W := gB, b := 0)
-    rc = dsmil_fc_forward(vals, N, Kv, C, gB, zero, gA, stream);
+    rc = dsmil_fc_forward_rows(vals, N, Kv, C, gB, zero, gA, rowmap, stream);
     if (rc) return rc;
     // 3. critical queries
-    if (v4) hipLaunchKernelGGL(k_bwd_qrow<4>, dim3((unsigned)C), dim3(256), 0, st, feats, idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, K, p->nonlinear);
-    else hipLaunchKernelGGL(k_bwd_qrow<1>, dim3((unsigned)C), dim3(256), 0, st, feats, idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, K, p->nonlinear);
+    if (v4) hipLaunchKernelGGL(k_bwd_qrow<4>, dim3((unsigned)C), dim3(256), 0, st, feats, idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, K, p->nonlinear, rowmap);
+    else hipLaunchKernelGGL(k_bwd_qrow<1>, dim3((unsigned)C), dim3(256), 0, st, feats, idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, K, p->nonlinear, rowmap);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     // 4. per-row part on MFMA
     const int nw = (N / 128 >= 512) ? 4 : 1;
     BwdRowsArgs br{};
     br.at = AttendArgs{feats, feats, nullptr, off, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, nullptr, nullptr, nullptr,
-                       K, K, C, p->nonlinear, 0, 0};
+                       K, K, C, p->nonlinear, 0, 0, rowmap};
     br.A = A; br.gA = gA; br.g_A = g_A; br.Dv = Dv; br.gs = gs; br.gz2 = gz2; br.Hbuf = Hb; br.Qbuf = Qb;
     if (nw == 4) rc = v4 ? launch_tile_kernel(k_bwd_rows<4, 4>, br, 4, N, st) : launch_tile_kernel(k_bwd_rows<4, 1>, br, 4, N, st);
     else rc = v4 ? launch_tile_kernel(k_bwd_rows<1, 4>, br, 1, N, st) : launch_tile_kernel(k_bwd_rows<1, 1>, br, 1, N, st);
@@ -507,23 +532,28 @@ int dsmil_agg_backward(const float* feats, const float* vals, int64_t N, const d
         // 6. gH = (gz2 W2) [H > 0]
         GhArgs gh{};
         gh.at = AttendArgs{gz2, gz2, nullptr, off, W2T, zero, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           QD, QD, C, 0, 0, 0};
+                           QD, QD, C, 0, 0, 0, nullptr};
         gh.Hbuf = Hb; gh.gH = gH;
         rc = (nw == 4) ? launch_tile_kernel(k_bwd_gh<4>, gh, 4, N, st) : launch_tile_kernel(k_bwd_gh<1>, gh, 1, N, st);
         if (rc) return rc;
         // 7. weight gradients: contractions over instances
         rc = tn_gemm(gz2, Hb, N, QD, part, part_b, g->q2_w, g->q2_b, L.splits, true, st);
         if (rc) return rc;
-        rc = tn_gemm(gH, feats, N, K, part, part_b, g->q0_w, g->q0_b, L.splits, v4, st);
+        rc = tn_gemm(gH, feats, N, K, part, part_b, g->q0_w, g->q0_b, L.splits, v4, st, rowmap);
         if (rc) return rc;
     } else {
-        rc = tn_gemm(gz2, feats, N, K, part, part_b, g->q0_w, g->q0_b, L.splits, v4, st);
+        rc = tn_gemm(gz2, feats, N, K, part, part_b, g->q0_w, g->q0_b, L.splits, v4, st, rowmap);
         if (rc) return rc;
     }
     // 8. instance stream (FCLayer)
     if (g_classes) {
-        rc = tn_small(g_classes, feats, N, C, K, part, part_b, g->fc_w, g->fc_b, L.splits, v4, st);
+        rc = tn_small(g_classes, feats, N, C, K, part, part_b, g->fc_w, g->fc_b, L.splits, v4, st, rowmap);
         if (rc) return rc;
+    }
+    if (g_max) {   // the max-over-instances stream of the training objective: one row per class
+        hipLaunchKernelGGL(k_bwd_fc_sparse, dim3((unsigned)C), dim3(256), 0, st, feats, idx, g_max, g->fc_w, g->fc_b, K,
+                           g_classes ? 1 : 0, rowmap);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
     // 9. gradient of the value rows (only when v is a trainable layer of the caller)
     if (g_vals) {

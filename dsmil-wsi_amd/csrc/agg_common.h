@@ -6,6 +6,10 @@
 #include <math.h>
 #include "dsmil_hip.h"
 
+// library-internal (defined in agg_fwd.hip): FCLayer over logical rows, physical row = rowmap[r] (nullptr = identity)
+int dsmil_fc_forward_rows(const float* feats, int64_t total_rows, int32_t K, int32_t C, const float* fc_w,
+                          const float* fc_b, float* classes, const int64_t* rowmap, void* stream);
+
 namespace {
 
 
@@ -124,7 +128,14 @@ struct AttendArgs {
     int K, Kv, C, nonlinear;
     int expt;  // ablation switches of -DDSMIL_EXPERIMENTS builds (DSMIL_EXPT); always 0 in the product build
     int bag0;  // first bag of this launch (chunked pipelining over bags)
+    // Row indirection (train_tcga.py:78-83 dropout_patches as an index list instead of a gathered copy): logical row i
+    // of the batch lives at physical row rowmap[i] of feats / vals; nullptr = identity.  Outputs stay logical.
+    const int64_t* rowmap;
 };
+
+__device__ __forceinline__ long long phys_row(const int64_t* __restrict__ rowmap, long long logical) {
+    return rowmap ? (long long)rowmap[logical] : logical;
+}
 
 // Ablation / tracing branches exist only in experiment builds (DSMIL_CFLAGS=-DDSMIL_EXPERIMENTS): the
 // product kernels carry none of them.
@@ -139,7 +150,7 @@ struct AttendArgs {
 // Q^T in the MFMA D layout: lane (l31, hi), tile t, reg 4g+e  <->  Q[row l31][32t + 8g + 4hi + e].
 // Scores (dsmil.py:55-56), tile softmax statistics, weighted value sum (dsmil.py:57).
 // --------------------------------------------------------------------------------------------
-template <int NW, int VEC, typename T>
+template <int NW, int VEC, typename T, int TU = 8>   // TU: value rows in flight per lane-pair of loads
 __device__ __forceinline__ void attend_tail(const AttendArgs& a, const f32x16 (&Q)[4], float* smem, int bag,
                                             long long off0, long long Nb, long long row0, long long slot) {
     constexpr int T_ = NW * 64;
@@ -152,7 +163,9 @@ __device__ __forceinline__ void attend_tail(const AttendArgs& a, const f32x16 (&
     const bool valid = myrow < Nb;
     const float scale = 0.08838834764831845f;           // 1/sqrt(128), dsmil.py:56
     const int Kv = a.Kv;
-    const T* vbase = reinterpret_cast<const T*>(a.vals) + off0 * (long long)Kv;
+    const T* vbase = reinterpret_cast<const T*>(a.vals);
+    // physical value row of this lane's instance (rows past the bag end: the last row, weight 0)
+    const long long myphys = phys_row(a.rowmap, off0 + (valid ? myrow : Nb - 1));
     float* sRed = smem;                                  // [NW][4]: m0,l0,m1,l1 per wave
     float* sB = smem + 64;                               // [NW][2][512]
     for (int c0 = 0; c0 < a.C; c0 += 2) {
@@ -225,10 +238,9 @@ __device__ __forceinline__ void attend_tail(const AttendArgs& a, const f32x16 (&
             // VEC = 4: unconditional loads from a clamped column (a lane past Kv accumulates junk it
             // never stores) — a load behind a per-lane branch is issued alone and waited for at once
             const int kac = ka < Kv ? ka : Kv - 4, kbc = kb < Kv ? kb : Kv - 4;
-#pragma unroll 8
+#pragma unroll TU
             for (int n = 0; n < 32; ++n) {
-                long long r = wrow0 + n;
-                if (r >= Nb) r = Nb - 1;  // weight is 0 there
+                const long long r = __shfl(myphys, n, 64);   // rows past the bag end were clamped (weight 0)
                 const float w0 = __shfl(pp0, n, 64), w1 = __shfl(pp1, n, 64);
                 const T* vr = vbase + r * (long long)Kv;
                 f32x4 va, vb;
@@ -313,7 +325,7 @@ __device__ __forceinline__ bool mlp_tile(const AttendArgs& a, int bag, int tile,
     for (int i = 0; i < XPT; ++i) {
         long long gr = row0 + ((tid + T * i) >> 3);
         if (gr >= Nb) gr = Nb - 1;   // clamp: rows past the bag end are masked later
-        xrow[i] = feats + (off0 + gr) * (long long)K;
+        xrow[i] = feats + phys_row(a.rowmap, off0 + gr) * (long long)K;
     }
     auto chunk_src = [&](int ci, const float*& wb, int& ld, int& k, int& klim) {
         int k0;

@@ -55,7 +55,7 @@ __device__ __forceinline__ void logits_tile(
     const float* __restrict__ fc_w, const float* __restrict__ fc_b,
     const float* __restrict__ classes_in, float* __restrict__ classes_out,
     float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C,
-    int bag, int tile, float* s_v, long long* s_i) {
+    int bag, int tile, float* s_v, long long* s_i, const int64_t* __restrict__ rowmap) {
     const long long off0 = offsets[bag];
     const long long Nb = offsets[bag + 1] - off0;
     const long long row0 = (long long)tile * R0;
@@ -74,10 +74,10 @@ __device__ __forceinline__ void logits_tile(
             const long long ra = rbase, rb = (rbase + 1 < Nb) ? rbase + 1 : Nb - 1,
                             rc = (rbase + 2 < Nb) ? rbase + 2 : Nb - 1, rd = (rbase + 3 < Nb) ? rbase + 3 : Nb - 1;
             if constexpr (!GIVEN) {
-                const T* xa = feats + (off0 + ra) * (long long)K;
-                const T* xb = feats + (off0 + rb) * (long long)K;
-                const T* xc = feats + (off0 + rc) * (long long)K;
-                const T* xd = feats + (off0 + rd) * (long long)K;
+                const T* xa = feats + phys_row(rowmap, off0 + ra) * (long long)K;
+                const T* xb = feats + phys_row(rowmap, off0 + rb) * (long long)K;
+                const T* xc = feats + phys_row(rowmap, off0 + rc) * (long long)K;
+                const T* xd = feats + phys_row(rowmap, off0 + rd) * (long long)K;
                 const float* w0p = fc_w + (long long)c0 * K;
                 const float* w1p = fc_w + (long long)c1 * K;
                 va0 = va1 = vb0 = vb1 = vc0 = vc1 = vd0 = vd1 = 0.f;
@@ -148,11 +148,12 @@ __global__ __launch_bounds__(256) void k_logits_argmax(
     const T* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ fc_w, const float* __restrict__ fc_b,
     const float* __restrict__ classes_in, float* __restrict__ classes_out,
-    float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C, int bag0) {
+    float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C, int bag0,
+    const int64_t* __restrict__ rowmap) {
     __shared__ float s_v[8];
     __shared__ long long s_i[8];
     logits_tile<VEC, GIVEN, T>(feats, offsets, fc_w, fc_b, classes_in, classes_out, part_val, part_idx, K, C,
-                               bag0 + (int)blockIdx.y, (int)blockIdx.x, s_v, s_i);
+                               bag0 + (int)blockIdx.y, (int)blockIdx.x, s_v, s_i, rowmap);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -191,7 +192,8 @@ template <int CP, typename T>  // classes per pass: 1 or 2; T = float or bf16 fe
 __global__ __launch_bounds__(256) void k_logits_stream(
     const T* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ fc_w, const float* __restrict__ fc_b, float* __restrict__ classes_out,
-    float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C, int bag0) {
+    float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C, int bag0,
+    const int64_t* __restrict__ rowmap) {
     constexpr int EPL = StreamVec<T>::EPL;   // elements per lane per 128-B segment
     constexpr int SEG = 8 * EPL;             // elements per segment (32 fp32 / 64 bf16)
     extern __shared__ __attribute__((aligned(16))) float s_w[];  // [CP][Kpad]: weights, zero past K, plus one zero segment
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void k_logits_stream(
             const long long rbase = row0 + wave * 32 + g * 8;
             if (rbase >= Nb) break;  // wave-uniform
             const long long r = (rbase + rr < Nb) ? rbase + rr : Nb - 1;
-            const T* x = feats + (off0 + r) * (long long)K;
+            const T* x = feats + phys_row(rowmap, off0 + r) * (long long)K;
             float a0 = 0.f, a1 = 0.f;
             for (int s0 = 0; s0 < nseg; s0 += 8) {
                 StreamVec<T> v[8];
@@ -306,7 +308,8 @@ __device__ __forceinline__ void qmax_block(
     const float* __restrict__ q0_w, const float* __restrict__ q0_b,
     const float* __restrict__ q2_w, const float* __restrict__ q2_b,
     float* __restrict__ qmax, int64_t* __restrict__ idx_out, int K, int C, int nonlinear,
-    int bag, int c, float* s_v, long long* s_i, float* s_h, int mode = 0, float* __restrict__ best_val_out = nullptr) {
+    int bag, int c, float* s_v, long long* s_i, float* s_h, int mode = 0, float* __restrict__ best_val_out = nullptr,
+    const int64_t* __restrict__ rowmap = nullptr) {
     // mode 0: arg-max + query of the critical row.  Instance-sharded bags (dsmil_agg_shard_*):
     // mode 1 = arg-max only (index and value out), mode 2 = query of a GIVEN row (feats = [C,K] rows)
     const long long off0 = mode == 2 ? 0 : offsets[bag];
@@ -340,7 +343,7 @@ __device__ __forceinline__ void qmax_block(
         if (best_val_out) best_val_out[(long long)bag * C + c] = bv;
     }
     if (mode == 1) return;
-    const T* x = feats + (off0 + best) * (long long)K;
+    const T* x = feats + (mode == 2 ? best : phys_row(rowmap, off0 + best)) * (long long)K;
     // layer 1: wave w computes hidden units 32w..32w+31, 8 at a time; lanes stride k by 4
     for (int jb = 0; jb < 32; jb += 8) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -391,12 +394,12 @@ __global__ __launch_bounds__(256) void k_qmax(
     const float* __restrict__ q0_w, const float* __restrict__ q0_b,
     const float* __restrict__ q2_w, const float* __restrict__ q2_b,
     float* __restrict__ qmax, int64_t* __restrict__ idx_out, int K, int C, int nonlinear, int bag0,
-    int mode = 0, float* __restrict__ best_val_out = nullptr) {
+    int mode = 0, float* __restrict__ best_val_out = nullptr, const int64_t* __restrict__ rowmap = nullptr) {
     __shared__ float s_v[4];
     __shared__ long long s_i[4];
     __shared__ float s_h[QD];
     qmax_block<VEC, T>(feats, offsets, part_val, part_idx, q0_w, q0_b, q2_w, q2_b, qmax, idx_out, K, C, nonlinear,
-                       bag0 + (int)blockIdx.x, (int)blockIdx.y, s_v, s_i, s_h, mode, best_val_out);
+                       bag0 + (int)blockIdx.x, (int)blockIdx.y, s_v, s_i, s_h, mode, best_val_out, rowmap);
 }
 
 template <int NW, int VEC>
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend(Att
 }
 
 // fp32 in / fp32 out with the query MLP on bf16 MFMA over exact three-plane cuts (agg_split.h)
-template <int NW, int VEC, int NP, bool XE = false>
+template <int NW, int VEC, int NP, bool XE = false, int TU = 8>
 __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend_split(AttendArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BM = NW * 32;
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend_spl
         if (keep == 12345.678f) a.scores[0] = keep;
         return;
     }
-    attend_tail<NW, VEC, float>(a, Q, smem, bag, off0, Nb, (long long)tile * BM, off0 / BM + bag + tile);
+    attend_tail<NW, VEC, float, TU>(a, Q, smem, bag, off0, Nb, (long long)tile * BM, off0 / BM + bag + tile);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend_bf1
                 const int r = (tid + T * i) >> 3;
                 long long gr = row0 + r;
                 if (gr >= Nb) gr = Nb - 1;
-                xreg[i] = *reinterpret_cast<const f32x4*>(feats + (off0 + gr) * (long long)K + kc);
+                xreg[i] = *reinterpret_cast<const f32x4*>(feats + phys_row(a.rowmap, off0 + gr) * (long long)K + kc);
             }
         }
     };
@@ -738,12 +741,13 @@ template <int VEC>
 __global__ __launch_bounds__(256) void k_fc(const float* __restrict__ feats,
                                             const float* __restrict__ fc_w,
                                             const float* __restrict__ fc_b,
-                                            float* __restrict__ classes, long long N, int K, int C) {
+                                            float* __restrict__ classes, long long N, int K, int C,
+                                            const int64_t* __restrict__ rowmap) {
     const int lane = threadIdx.x & 63;
     const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long nw = (long long)gridDim.x * 4;
     for (long long r = wid; r < N; r += nw) {
-        const float* x = feats + r * K;
+        const float* x = feats + phys_row(rowmap, r) * K;
         for (int c = 0; c < C; ++c) {
             float acc = 0.f;
             for (int k0 = 0; k0 < K; k0 += 256) {
@@ -821,7 +825,7 @@ int launch_attend(const AttendArgs& a, long long max_rows, int n_bags, hipStream
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
-template <int NW, int VEC, int NP, bool XE = false>
+template <int NW, int VEC, int NP, bool XE = false, int TU = 8>
 int launch_attend_split(const AttendArgs& a, long long max_rows, int n_bags, hipStream_t st) {
     constexpr int BM = NW * 32;
     size_t lds = VEC == 4 ? (size_t)(3 * S3_CHUNK_F4 * 4 + 2 * BM * 32) * sizeof(float)
@@ -834,16 +838,16 @@ int launch_attend_split(const AttendArgs& a, long long max_rows, int n_bags, hip
     if (!attr_done) {
 #ifdef DSMIL_EXPERIMENTS
         int nb = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_query_attend_split<NW, VEC, NP, XE>, NW * 64, lds);
-        fprintf(stderr, "[dsmil] k_query_attend_split<%d,%d,%d,%d>: lds %zu B, %d blocks/CU\n", NW, VEC, NP, (int)XE, lds, nb);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_query_attend_split<NW, VEC, NP, XE, TU>, NW * 64, lds);
+        fprintf(stderr, "[dsmil] k_query_attend_split<%d,%d,%d,%d,%d>: lds %zu B, %d blocks/CU\n", NW, VEC, NP, (int)XE, TU, lds, nb);
 #endif
-        (void)hipFuncSetAttribute((const void*)k_query_attend_split<NW, VEC, NP, XE>,
+        (void)hipFuncSetAttribute((const void*)k_query_attend_split<NW, VEC, NP, XE, TU>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 grid((unsigned)((max_rows + BM - 1) / BM), (unsigned)n_bags);
     const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
-    hipLaunchKernelGGL((k_query_attend_split<NW, VEC, NP, XE>), grid, dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((k_query_attend_split<NW, VEC, NP, XE, TU>), grid, dim3(NW * 64), lds, st, a);
     dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
@@ -882,6 +886,19 @@ int launch_attend_bf16(const AttendArgs& a, long long max_rows, int n_bags, hipS
 
 }  // namespace
 
+// library-internal: FCLayer over logical rows (row r of the output reads physical row rowmap[r]; nullptr = identity)
+int dsmil_fc_forward_rows(const float* feats, int64_t total_rows, int32_t K, int32_t C, const float* fc_w,
+                          const float* fc_b, float* classes, const int64_t* rowmap, void* stream) {
+    if (!feats || !fc_w || !fc_b || !classes || total_rows <= 0 || K <= 0 || C <= 0) return DSMIL_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    long long blocks = (total_rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    const bool v4 = (K % 4 == 0) && (((uintptr_t)feats | (uintptr_t)fc_w) % 16 == 0);
+    if (v4) hipLaunchKernelGGL(k_fc<4>, dim3((unsigned)blocks), dim3(256), 0, st, feats, fc_w, fc_b, classes, (long long)total_rows, K, C, rowmap);
+    else hipLaunchKernelGGL(k_fc<1>, dim3((unsigned)blocks), dim3(256), 0, st, feats, fc_w, fc_b, classes, (long long)total_rows, K, C, rowmap);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
 extern "C" {
 
 int dsmil_abi_version(void) { return DSMIL_ABI_VERSION; }
@@ -912,14 +929,7 @@ size_t dsmil_agg_workspace_bytes(int32_t n_bags, int64_t total_rows, int32_t K, 
 
 int dsmil_fc_forward(const float* feats, int64_t total_rows, int32_t K, int32_t C,
                      const float* fc_w, const float* fc_b, float* classes, void* stream) {
-    if (!feats || !fc_w || !fc_b || !classes || total_rows <= 0 || K <= 0 || C <= 0) return DSMIL_E_INVALID;
-    hipStream_t st = (hipStream_t)stream;
-    long long blocks = (total_rows + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
-    const bool v4 = (K % 4 == 0) && (((uintptr_t)feats | (uintptr_t)fc_w) % 16 == 0);
-    if (v4) hipLaunchKernelGGL(k_fc<4>, dim3((unsigned)blocks), dim3(256), 0, st, feats, fc_w, fc_b, classes, (long long)total_rows, K, C);
-    else hipLaunchKernelGGL(k_fc<1>, dim3((unsigned)blocks), dim3(256), 0, st, feats, fc_w, fc_b, classes, (long long)total_rows, K, C);
-    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+    return dsmil_fc_forward_rows(feats, total_rows, K, C, fc_w, fc_b, classes, nullptr, stream);
 }
 
 __global__ void k_set_offsets2(int64_t* off, long long N) { off[0] = 0; off[1] = N; }
@@ -935,7 +945,8 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
                             int32_t n_bags, int64_t total_rows, int64_t max_rows, const dsmil_agg_params* p,
                             const void* packed_bf16, bool bf16, const float* classes_in, float* classes_out,
                             float* A, float* B, float* pred, int64_t* idx, void* ws, size_t ws_bytes,
-                            void* stream, const ShardCtl& sh = ShardCtl(), const void* packed_split = nullptr) {
+                            void* stream, const ShardCtl& sh = ShardCtl(), const void* packed_split = nullptr,
+                            const int64_t* rowmap = nullptr) {
     if (!feats || !p || !ws) return DSMIL_E_INVALID;
     if (sh.phase == 0 && (!offsets || !A || !B || !pred || !idx)) return DSMIL_E_INVALID;
     if (sh.phase == 1 && (!classes_out || !idx || !sh.best_val)) return DSMIL_E_INVALID;
@@ -981,7 +992,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
                                (uintptr_t)(p->nonlinear ? p->q2_w : p->q0_w)) % 16 == 0));
     const bool w4 = (K % 4 == 0) && (((uintptr_t)p->q0_w | (uintptr_t)p->fc_w) % 16 == 0);
     AttendArgs a{feats, vals, (const bf16_t*)packed_bf16, offsets, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, A,
-                 part_ml, part_B, K, Kv, C, p->nonlinear, 0, 0};
+                 part_ml, part_B, K, Kv, C, p->nonlinear, 0, 0, rowmap};
 #ifdef DSMIL_EXPERIMENTS
     static const int expt = expt_env("DSMIL_EXPT"), logits_old = expt_env("DSMIL_LOGITS_OLD");
     a.expt = expt;
@@ -997,27 +1008,27 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         // 1. instance logits + arg-max partials
         dim3 grid((unsigned)((max_rows + R0 - 1) / R0), (unsigned)nb);
         if (sh.phase == 2) {}  // the caller already knows the bag-wide critical rows
-        else if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
+        else if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else if (bf16 && (K % 8 == 0) && !logits_old) {
             const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 63) / 64 + 1) * 64) * sizeof(float);
-            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, bf16_t>), grid, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
-            else hipLaunchKernelGGL((k_logits_stream<1, bf16_t>), grid, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
+            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, bf16_t>), grid, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap);
+            else hipLaunchKernelGGL((k_logits_stream<1, bf16_t>), grid, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap);
         }
-        else if (bf16 && w4) hipLaunchKernelGGL((k_logits_argmax<4, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
-        else if (bf16) hipLaunchKernelGGL((k_logits_argmax<1, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
+        else if (bf16 && w4) hipLaunchKernelGGL((k_logits_argmax<4, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
+        else if (bf16) hipLaunchKernelGGL((k_logits_argmax<1, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else if (v4 && !logits_old) {
             const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 31) / 32 + 1) * 32) * sizeof(float);
-            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
-            else hipLaunchKernelGGL((k_logits_stream<1, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0);
+            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap);
+            else hipLaunchKernelGGL((k_logits_stream<1, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap);
         }
-        else if (v4) hipLaunchKernelGGL((k_logits_argmax<4, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
-        else hipLaunchKernelGGL((k_logits_argmax<1, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0);
+        else if (v4) hipLaunchKernelGGL((k_logits_argmax<4, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
+        else hipLaunchKernelGGL((k_logits_argmax<1, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         // 2. critical instance + its query
         dim3 gq((unsigned)nb, (unsigned)C);
         if (sh.phase == 1) {
-            if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val);
-            else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val);
+            if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap);
+            else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap);
             return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
         }
         if (sh.phase == 2) {
@@ -1025,10 +1036,10 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
             if (r4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(256), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
             else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(256), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
         }
-        else if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), gq, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0);
-        else if (bf16) hipLaunchKernelGGL((k_qmax<1, bf16_t>), gq, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0);
-        else if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0);
-        else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0);
+        else if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), gq, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
+        else if (bf16) hipLaunchKernelGGL((k_qmax<1, bf16_t>), gq, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
+        else if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
+        else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         // 3. query MLP on MFMA + scores + tile softmax + weighted value sum
         int rc;
@@ -1046,6 +1057,8 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         else if (mode == 9 && NW == 4) rc = v4 ? launch_attend_split<4, 4, 9>(a, max_rows, nb, st) : launch_attend_split<4, 1, 9>(a, max_rows, nb, st);
         else if (mode == 9) rc = v4 ? launch_attend_split<1, 4, 9>(a, max_rows, nb, st) : launch_attend_split<1, 1, 9>(a, max_rows, nb, st);
 #ifdef DSMIL_EXPERIMENTS
+        else if (mode == 6 && NW == 4 && v4 && (a.expt & 16)) rc = launch_attend_split<4, 4, 6, false, 16>(a, max_rows, nb, st);
+        else if (mode == 6 && NW == 4 && v4 && (a.expt & 32)) rc = launch_attend_split<4, 4, 6, false, 32>(a, max_rows, nb, st);
         else if (mode == 6 && NW == 4 && v4 && (a.expt & 8)) rc = launch_attend_split<4, 4, 6, true>(a, max_rows, nb, st);
         else if (mode == 6 && NW == 1 && v4 && (a.expt & 8)) rc = launch_attend_split<1, 4, 6, true>(a, max_rows, nb, st);
 #endif
@@ -1095,14 +1108,51 @@ int dsmil_agg_pack_split(const float* q0_w, const float* q2_w, int32_t K, void* 
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
-int dsmil_agg_forward_packed(const float* feats, const float* vals, const int64_t* offsets,
-                             int32_t n_bags, int64_t total_rows, int64_t max_rows,
-                             const dsmil_agg_params* p, const void* packed_split, const float* classes_in,
-                             float* classes_out, float* A, float* B, float* pred, int64_t* idx, void* ws,
-                             size_t ws_bytes, void* stream) {
+int dsmil_agg_forward_ex(const float* feats, const float* vals, const int64_t* offsets,
+                         int32_t n_bags, int64_t total_rows, int64_t max_rows,
+                         const dsmil_agg_params* p, const dsmil_agg_opts* opts, const float* classes_in,
+                         float* classes_out, float* A, float* B, float* pred, int64_t* idx, void* ws,
+                         size_t ws_bytes, void* stream) {
+    const void* packed_split = opts ? opts->packed_split : nullptr;
+    const int64_t* row_map = opts ? opts->row_map : nullptr;
     if (packed_split && ((uintptr_t)packed_split % 16)) return DSMIL_E_ALIGN;
     return agg_forward_impl(feats, vals, offsets, n_bags, total_rows, max_rows, p, nullptr, false, classes_in,
-                            classes_out, A, B, pred, idx, ws, ws_bytes, stream, ShardCtl(), packed_split);
+                            classes_out, A, B, pred, idx, ws, ws_bytes, stream, ShardCtl(), packed_split, row_map);
+}
+
+// ---- fused training objective of one bag (train_tcga.py:67-71) -----------------------------------------
+// loss = 0.5 BCEWithLogits(pred, y) + 0.5 BCEWithLogits(max_n classes[n,:], y)   (mean over the C classes each),
+// the max over instances IS classes[idx_c, c] (idx = the forward's critical-instance index), so the gradient of
+// the instance stream is sparse: one row per class.
+static __global__ void k_loss_head(const float* __restrict__ classes, const float* __restrict__ pred,
+                            const int64_t* __restrict__ idx, const float* __restrict__ label, int C,
+                            float* __restrict__ loss, float* __restrict__ max_pred, float* __restrict__ g_pred,
+                            float* __restrict__ g_max) {
+    const int c = threadIdx.x;
+    float l = 0.f;
+    if (c < C) {
+        const float y = label[c];
+        const float zb = pred[c], zm = classes[idx[c] * (long long)C + c];
+        // BCEWithLogits(z, y) = max(z,0) - z y + log1p(exp(-|z|))  (torch's stable form)
+        const float lb = fmaxf(zb, 0.f) - zb * y + log1pf(expf(-fabsf(zb)));
+        const float lm = fmaxf(zm, 0.f) - zm * y + log1pf(expf(-fabsf(zm)));
+        l = 0.5f * (lb + lm) / (float)C;
+        const float sb = 1.f / (1.f + expf(-zb)), sm = 1.f / (1.f + expf(-zm));
+        if (max_pred) max_pred[c] = zm;
+        if (g_pred) g_pred[c] = 0.5f * (sb - y) / (float)C;
+        if (g_max) g_max[c] = 0.5f * (sm - y) / (float)C;
+    }
+    l = wave_sum(l);   // C <= 64: one wave
+    if (threadIdx.x == 0) *loss = l;
+}
+
+int dsmil_agg_loss_head(const float* classes, const float* pred, const int64_t* idx, const float* label,
+                        int32_t C, float* loss, float* max_pred, float* g_pred, float* g_max, void* stream) {
+    if (!classes || !pred || !idx || !label || !loss || C <= 0) return DSMIL_E_INVALID;
+    if (C > 64) return DSMIL_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_loss_head, dim3(1), dim3(64), 0, (hipStream_t)stream, classes, pred, idx, label, C, loss,
+                       max_pred, g_pred, g_max);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
 int dsmil_agg_shard_argmax(const float* feats, int64_t rows, const dsmil_agg_params* p, float* classes_out,

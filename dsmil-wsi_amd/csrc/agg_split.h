@@ -87,7 +87,7 @@ __device__ __forceinline__ bool mlp_tile_split(const AttendArgs& a, int bag, int
     for (int i = 0; i < XPT; ++i) {
         long long gr = row0 + ((tid + T * i) >> 3);
         if (gr >= Nb) gr = Nb - 1;  // rows past the bag end are masked in attend_tail
-        xrow[i] = feats + (off0 + gr) * (long long)K;
+        xrow[i] = feats + phys_row(a.rowmap, off0 + gr) * (long long)K;
     }
     // branch-free loads: past the end the last chunk is re-read (and written to a dead buffer)
     auto load_w = [&](int s) {
@@ -270,7 +270,7 @@ __device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag,
         const int r = p * 8 + (lane >> 3);
         long long gr = row0 + wave * 32 + r;
         if (gr >= Nb) gr = Nb - 1;  // rows past the bag end are masked in attend_tail
-        xsrc[p] = feats + (off0 + gr) * (long long)K;
+        xsrc[p] = feats + phys_row(a.rowmap, off0 + gr) * (long long)K;
         xslot[p] = ((lane & 7) ^ ((r & 6) | ((r >> 4) & 1))) * 4;
     }
     // one 1 KiB piece per call: the pieces of a step are spread behind its MFMA groups (issued in a

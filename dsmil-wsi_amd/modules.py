@@ -163,6 +163,30 @@ class MILNet(nn.Module):
         prediction_bag, A, B = bc(feats, classes)
         return classes, prediction_bag, A, B
 
+    def bag_loss(self, feats, label, row_map=None):
+        """The training objective of one bag, train_tcga.py:64-71 / train_mil.py, as ONE native forward + loss head
+        (and one native backward under autograd):
+            bag_feats = feats[row_map]                      (dropout_patches :78-83, folded into the row loads)
+            ins, bag, _, _ = milnet(bag_feats);  mx = max(ins, 0)
+            loss = 0.5 BCEWithLogitsLoss(bag, y) + 0.5 BCEWithLogitsLoss(mx, y)
+        Returns (loss [], bag_prediction [1,C], max_prediction [C]).  CUDA fp32 bags with FCLayer + BClassifier
+        (v = Identity) take the fused path; everything else composes the same objective from torch ops."""
+        ic, bc = self.i_classifier, self.b_classifier
+        if (feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 2 and isinstance(ic, FCLayer)
+                and isinstance(bc, BClassifier) and not bc.passing_v and not feats.requires_grad):
+            w = bc._weights()
+            lin = ic.fc[0]
+            loss, pred, mx = _BagLossFunction.apply(feats, label, row_map, lin.weight, lin.bias, w["q0_w"], w["q0_b"],
+                                                    w["q2_w"], w["q2_b"], w["fcc_w"], w["fcc_b"], bc.nonlinear)
+            return loss, pred, mx
+        x = feats if row_map is None else feats.index_select(0, row_map)
+        ins, bag, _, _ = self(x)
+        mx, _ = torch.max(ins, 0)
+        y = label.view(1, -1).to(bag.dtype)
+        loss = 0.5 * F.binary_cross_entropy_with_logits(bag.view(1, -1), y) + \
+            0.5 * F.binary_cross_entropy_with_logits(mx.view(1, -1), y)
+        return loss, bag, mx
+
     @torch.no_grad()
     def forward_bags(self, bags):
         """Batched inference over many independent bags in ONE native call sequence ("varlen").
@@ -212,6 +236,36 @@ class _FCFunction(torch.autograd.Function):
         gw = g32.t().mm(x32).to(w.dtype) if ctx.needs_input_grad[1] else None
         gb = g32.sum(0).to(w.dtype) if ctx.needs_input_grad[2] else None
         return gx, gw, gb
+
+
+class _BagLossFunction(torch.autograd.Function):
+    """Forward = dsmil_agg_forward_ex (row map) + dsmil_agg_loss_head; backward = dsmil_agg_backward_ex with the sparse
+    max-stream gradient.  Replaces, per training step, the row gather, torch.max, two BCEWithLogitsLoss graphs and the
+    dense [N,C] instance-logit gradient of train_tcga.py:64-72."""
+
+    @staticmethod
+    def forward(ctx, feats, label, row_map, fc_w, fc_b, q0_w, q0_b, q2_w, q2_b, fcc_w, fcc_b, nonlinear):
+        det = lambda t: t.detach() if t is not None else None
+        w = {"fc_w": det(fc_w), "fc_b": det(fc_b), "q0_w": det(q0_w), "q0_b": det(q0_b),
+             "q2_w": det(q2_w), "q2_b": det(q2_b), "fcc_w": det(fcc_w), "fcc_b": det(fcc_b)}
+        N = int(row_map.numel()) if row_map is not None else feats.shape[0]
+        classes, pred, A, B, idx = ops.agg_forward(feats.detach(), [N], w, nonlinear=nonlinear, row_map=row_map)
+        loss, max_pred, g_pred, g_max = ops.agg_loss_head(classes, pred, idx, label.detach())
+        ctx.nonlinear = nonlinear
+        ctx.save_for_backward(feats, row_map, fc_w, q0_w, q0_b, q2_w, q2_b, fcc_w, A, B, idx, g_pred, g_max)
+        ctx.mark_non_differentiable(pred, max_pred)
+        return loss, pred, max_pred
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_pred, _g_max):
+        feats, row_map, fc_w, q0_w, q0_b, q2_w, q2_b, fcc_w, A, B, idx, g_pred, g_max = ctx.saved_tensors
+        w = {"fc_w": fc_w, "fc_b": None, "q0_w": q0_w, "q0_b": q0_b, "q2_w": q2_w, "q2_b": q2_b,
+             "fcc_w": fcc_w, "fcc_b": None}
+        # every parameter gradient is linear in (g_pred, g_max): the upstream scalar scales those two [C] vectors
+        g = ops.agg_backward(feats, w, A, B, idx, g_pred * g_loss, g_max=g_max * g_loss, row_map=row_map,
+                             nonlinear=ctx.nonlinear)
+        return (None, None, None, g["fc_w"], g["fc_b"], g["q0_w"], g["q0_b"], g.get("q2_w"), g.get("q2_b"),
+                g["fcc_w"], g["fcc_b"], None)
 
 
 class _AggFunction(torch.autograd.Function):

@@ -152,13 +152,23 @@ def _split_params(q0_w, q2_w, nonlinear, dev):
     return packed
 
 
-def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, offsets=None):
+def _i64c(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.int64:
+        raise RuntimeError(f"{name} must be an int64 CUDA(HIP) tensor")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, offsets=None, row_map=None):
     """dsmil_agg_forward / dsmil_agg_forward_bf16 over a batch of bags stored back to back.
 
     feats [total,K] fp32 or bf16 CUDA; lengths: python ints (bag sizes); w: dict of CUDA tensors with
     keys fc_w fc_b q0_w q0_b q2_w q2_b fcc_w fcc_b (fc_* may be None when classes_in is given).
     A bf16 `feats` selects the bf16-storage path (BASELINE config 2): weights are rounded to bf16,
     accumulation stays f32, outputs are fp32.
+    ``row_map`` (int64 [total], fp32 path): logical row i lives at physical row row_map[i] of feats / vals —
+    train_tcga.py:78-83's `feats[random_indices]` without the gathered copy; `lengths` then count LOGICAL rows.
     Returns (classes [total,C], pred [n_bags,C], A [total,C], B [n_bags,C,Kv], idx int64 [n_bags,C]).
     """
     bf16 = feats.dtype == torch.bfloat16
@@ -170,6 +180,11 @@ def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, o
         feats = _f32c(feats, "feats")
     dev = feats.device
     total, K = feats.shape
+    row_map = _i64c(row_map, "row_map")
+    if row_map is not None:
+        if bf16:
+            raise ValueError("row_map is implemented for the fp32 path")
+        total = int(row_map.numel())
     lengths = [int(n) for n in lengths]
     if sum(lengths) != total:
         raise ValueError(f"bag lengths sum to {sum(lengths)} but feats has {total} rows")
@@ -216,12 +231,14 @@ def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, o
                                           _stream(dev))
         else:
             split = _split_params(keep[2], keep[4], nonlinear, dev)
-            rc = L.dsmil_agg_forward_packed(_ptr(feats), _ptr(vals), _ptr(off), n_bags, total, max(lengths),
-                                            ctypes.byref(p), _ptr(split), _ptr(classes_in),
-                                            _ptr(classes if classes_in is None else None),
-                                            _ptr(A), _ptr(B), _ptr(pred), _ptr(idx), _ptr(ws), ws.numel(),
-                                            _stream(dev))
-    _native.check(rc, "dsmil_agg_forward_bf16" if bf16 else "dsmil_agg_forward_packed")
+            opts = _native.AggOpts(split.data_ptr() if split is not None else 0,
+                                   row_map.data_ptr() if row_map is not None else 0)
+            rc = L.dsmil_agg_forward_ex(_ptr(feats), _ptr(vals), _ptr(off), n_bags, total, max(lengths),
+                                        ctypes.byref(p), ctypes.byref(opts), _ptr(classes_in),
+                                        _ptr(classes if classes_in is None else None),
+                                        _ptr(A), _ptr(B), _ptr(pred), _ptr(idx), _ptr(ws), ws.numel(),
+                                        _stream(dev))
+    _native.check(rc, "dsmil_agg_forward_bf16" if bf16 else "dsmil_agg_forward_ex")
     del keep
     return classes, pred, A, B, idx
 
@@ -279,16 +296,37 @@ def agg_shard_attend(feats, w, crit_rows, vals=None, nonlinear=True):
     return A, ml, B
 
 
+def agg_loss_head(classes, pred, idx, label):
+    """dsmil_agg_loss_head: the training objective of one bag (train_tcga.py:67-71) and its logit gradients in one
+    launch.  Returns (loss [] , max_pred [C], g_pred [C], g_max [C])."""
+    classes = _f32c(classes, "classes"); pred = _f32c(pred.reshape(-1), "pred")
+    label = _f32c(label.reshape(-1).to(torch.float32), "label")
+    idx = _i64c(idx.reshape(-1), "idx")
+    C = classes.shape[1]
+    dev = classes.device
+    out = torch.empty((1 + 3 * C,), dtype=torch.float32, device=dev)
+    loss, max_pred, g_pred, g_max = out[0:1], out[1:1 + C], out[1 + C:1 + 2 * C], out[1 + 2 * C:]
+    with torch.cuda.device(dev):
+        rc = _native.lib().dsmil_agg_loss_head(_ptr(classes), _ptr(pred), _ptr(idx), _ptr(label), C, _ptr(loss),
+                                               _ptr(max_pred), _ptr(g_pred), _ptr(g_max), _stream(dev))
+    _native.check(rc, "dsmil_agg_loss_head")
+    return loss.reshape(()), max_pred, g_pred, g_max
+
+
 def agg_backward(feats, w, A, B, idx, g_pred, g_classes=None, g_A=None, g_B=None, vals=None, nonlinear=True,
-                 want_g_vals=False):
+                 want_g_vals=False, g_max=None, row_map=None):
     """dsmil_agg_backward: parameter gradients of FCLayer + BClassifier for ONE bag (what autograd
     derives for train_tcga.py:67-72).  feats [N,K] fp32 CUDA, w as in agg_forward, A [N,C], B [1,C,Kv],
     idx [1,C] = the forward's outputs; g_* = upstream gradients (None = zero).  Returns a dict with the
-    gradient of every key of ``w`` (fc_* only when g_classes is given, q2_* only when nonlinear) and
-    ``vals`` (when want_g_vals)."""
+    gradient of every key of ``w`` (fc_* only when g_classes or g_max is given, q2_* only when nonlinear) and
+    ``vals`` (when want_g_vals).  ``g_max`` [C]: the sparse gradient of max_n classes[n,:] (the training objective's
+    instance stream); ``row_map``: see agg_forward (N = its length)."""
     feats = _f32c(feats, "feats")
     dev = feats.device
     N, K = feats.shape
+    row_map = _i64c(row_map, "row_map")
+    if row_map is not None:
+        N = int(row_map.numel())
     vals = feats if vals is None else _f32c(vals, "vals")
     Kv = vals.shape[1]
     fcc_w = _f32c(w["fcc_w"], "fcc_w")
@@ -300,11 +338,12 @@ def agg_backward(feats, w, A, B, idx, g_pred, g_classes=None, g_A=None, g_B=None
     idx = idx.contiguous()
     g_pred = _f32c(g_pred.reshape(-1), "g_pred")
     g_classes = _f32c(g_classes, "g_classes"); g_A = _f32c(g_A, "g_A"); g_B = _f32c(g_B, "g_B")
+    g_max = _f32c(g_max.reshape(-1), "g_max") if g_max is not None else None
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     out = {"q0_w": new(Q_DIM, K), "q0_b": new(Q_DIM), "fcc_w": new(C, C, Kv), "fcc_b": new(C)}
     if nonlinear:
         out["q2_w"], out["q2_b"] = new(Q_DIM, Q_DIM), new(Q_DIM)
-    if g_classes is not None:
+    if g_classes is not None or g_max is not None:
         out["fc_w"], out["fc_b"] = new(C, K), new(C)
     g = _native.AggGrads(*[(out[k].data_ptr() if k in out else 0)
                            for k in ("fc_w", "fc_b", "q0_w", "q0_b", "q2_w", "q2_b", "fcc_w", "fcc_b")])
@@ -313,10 +352,10 @@ def agg_backward(feats, w, A, B, idx, g_pred, g_classes=None, g_A=None, g_B=None
     nbytes = L.dsmil_agg_backward_workspace_bytes(N, K, Kv, C)
     ws = _workspace(dev, nbytes)
     with torch.cuda.device(dev):
-        rc = L.dsmil_agg_backward(_ptr(feats), _ptr(vals), N, ctypes.byref(p), _ptr(A), _ptr(B), _ptr(idx),
-                                  _ptr(g_classes), _ptr(g_pred), _ptr(g_A), _ptr(g_B), ctypes.byref(g),
-                                  _ptr(g_vals), _ptr(ws), ws.numel(), _stream(dev))
-    _native.check(rc, "dsmil_agg_backward")
+        rc = L.dsmil_agg_backward_ex(_ptr(feats), _ptr(vals), N, ctypes.byref(p), _ptr(A), _ptr(B), _ptr(idx),
+                                     _ptr(g_classes), _ptr(g_max), _ptr(g_pred), _ptr(g_A), _ptr(g_B), ctypes.byref(g),
+                                     _ptr(g_vals), _ptr(row_map), _ptr(ws), ws.numel(), _stream(dev))
+    _native.check(rc, "dsmil_agg_backward_ex")
     del keep
     if want_g_vals:
         out["vals"] = g_vals

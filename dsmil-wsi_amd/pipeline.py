@@ -257,8 +257,10 @@ def attention_colormap(A, pos_arr, bag_prediction, thres, colors, class_names=No
     H, W = int(pos_arr[:, 0].max()) + 1, int(pos_arr[:, 1].max()) + 1
     cmap = np.zeros((H, W, 3))
     cmap[pos_arr[:, 0], pos_arr[:, 1]] = colored
-    cmap = np.repeat(np.repeat(cmap, 32, axis=0), 32, axis=1)   # transform.resize(order=0)
-    return np.clip(np.rint(cmap * 255.0), 0, 255).astype(np.uint8)
+    # transform.resize(order=0) x32 then img_as_ubyte: nearest-neighbour upsampling commutes with the per-pixel
+    # conversion, so convert at tile resolution and repeat the bytes (32*32 = 1024x less float work)
+    small = np.clip(np.rint(cmap * 255.0), 0, 255).astype(np.uint8)
+    return np.repeat(np.repeat(small, 32, axis=0), 32, axis=1)
 
 
 @torch.no_grad()

@@ -54,34 +54,57 @@ def generate_pt_files(args, df, temp_train_dir="temp_train"):
 
 
 class BagCache:
-    """path -> stacked [N, feats+C] tensor resident on the training device."""
+    """path -> (feats [N,K] contiguous, label [1,C]) resident on the training device.  The reference re-reads the
+    stacked [N, K+C] tensor from disk every iteration and slices it (train_tcga.py:62-64: a strided view that the
+    following gather densifies); here the split happens once per bag, when it is first loaded."""
 
-    def __init__(self, device):
+    def __init__(self, device, feats_size=None):
         self.device = device
+        self.feats_size = feats_size
         self.store = {}
 
-    def get(self, item):
+    def _split(self, stacked, feats_size):
+        return (stacked[:, :feats_size].contiguous().float(), stacked[0, feats_size:].unsqueeze(0).float())
+
+    def get(self, item, feats_size=None):
+        feats_size = feats_size or self.feats_size
         if torch.is_tensor(item):
-            return item.to(self.device)
+            return self._split(item.to(self.device), feats_size)
         t = self.store.get(item)
         if t is None:
-            t = torch.load(item, map_location=self.device)
+            t = self._split(torch.load(item, map_location=self.device), feats_size)
             self.store[item] = t
         return t
 
 
-def dropout_patches(feats, p):
-    """train_tcga.py:78-83 — keep int(N*p) randomly chosen rows (p = 1 - dropout rate)."""
-    n = feats.size(0)
+def dropout_rows(n, p, device):
+    """train_tcga.py:78-83 as an index list: the int(n*p) randomly chosen rows of a bag (p = 1 - dropout rate) in the
+    reference's random order, or None when every row is kept (the aggregator is permutation-invariant)."""
     keep = int(n * p)
     if keep >= n:
-        return feats
-    idx = torch.randperm(n, device=feats.device)[:keep]
-    return feats.index_select(0, idx)
+        return None
+    return torch.randperm(n, device=device)[:keep]
 
 
-def bag_loss(milnet, criterion, bag_feats, bag_label):
-    """train_tcga.py:67-71."""
+def dropout_patches(feats, p):
+    """train_tcga.py:78-83 — keep int(N*p) randomly chosen rows (p = 1 - dropout rate), as a gathered copy."""
+    idx = dropout_rows(feats.size(0), p, feats.device)
+    return feats if idx is None else feats.index_select(0, idx)
+
+
+def _is_plain_bce(criterion):
+    return (isinstance(criterion, nn.BCEWithLogitsLoss) and criterion.reduction == "mean"
+            and criterion.weight is None and criterion.pos_weight is None)
+
+
+def bag_loss(milnet, criterion, bag_feats, bag_label, row_map=None):
+    """train_tcga.py:64-71.  ``row_map``: dropout_patches as an index list (rows of bag_feats that enter the bag).
+    With the stock criterion and a MILNet(FCLayer, BClassifier) the whole objective is one native forward + loss
+    head (MILNet.bag_loss); otherwise the same expression from torch ops."""
+    if _is_plain_bce(criterion) and hasattr(milnet, "bag_loss"):
+        return milnet.bag_loss(bag_feats, bag_label, row_map)
+    if row_map is not None:
+        bag_feats = bag_feats.index_select(0, row_map)
     ins_prediction, bag_prediction, _, _ = milnet(bag_feats)
     max_prediction, _ = torch.max(ins_prediction, 0)
     loss = 0.5 * criterion(bag_prediction.view(1, -1), bag_label.view(1, -1)) + \
@@ -97,17 +120,19 @@ def train(args, train_df, milnet, criterion, optimizer, cache=None, log=True):
     cache = cache or BagCache(device)
     total_loss = 0.0
     dirs = shuffle(list(train_df))
+    losses = []
     for i, item in enumerate(dirs):
         optimizer.zero_grad()
-        stacked = cache.get(item)
-        bag_label = stacked[0, args.feats_size:].unsqueeze(0).float()
-        bag_feats = dropout_patches(stacked[:, :args.feats_size], 1 - args.dropout_patch).reshape(-1, args.feats_size)
-        loss, _, _ = bag_loss(milnet, criterion, bag_feats, bag_label)
+        bag_feats, bag_label = cache.get(item, args.feats_size)
+        rows = dropout_rows(bag_feats.size(0), 1 - args.dropout_patch, bag_feats.device)
+        loss, _, _ = bag_loss(milnet, criterion, bag_feats, bag_label, rows)
         loss.backward()
         optimizer.step()
-        total_loss += loss.item()
-        if log:
+        losses.append(loss.detach())
+        if log:   # the progress line is the only host sync of a step (train_tcga.py:74-75 syncs twice per step)
             sys.stdout.write("\r Training bag [%d/%d] bag loss: %.4f" % (i, len(dirs), loss.item()))
+    if losses:
+        total_loss = float(torch.stack(losses).sum().item())
     return total_loss / max(1, len(dirs))
 
 
@@ -149,10 +174,9 @@ def test(args, test_df, milnet, criterion, thresholds=None, return_predictions=F
     cache = cache or BagCache(device)
     total_loss, labels, preds = 0.0, [], []
     for i, item in enumerate(test_df):
-        stacked = cache.get(item)
-        bag_label = stacked[0, args.feats_size:].unsqueeze(0).float()
-        bag_feats = dropout_patches(stacked[:, :args.feats_size], 1 - args.dropout_patch).reshape(-1, args.feats_size)
-        loss, bag_prediction, max_prediction = bag_loss(milnet, criterion, bag_feats, bag_label)
+        bag_feats, bag_label = cache.get(item, args.feats_size)
+        rows = dropout_rows(bag_feats.size(0), 1 - args.dropout_patch, bag_feats.device)   # train_tcga.py:96
+        loss, bag_prediction, max_prediction = bag_loss(milnet, criterion, bag_feats, bag_label, rows)
         total_loss += loss.item()
         if log:
             sys.stdout.write("\r Testing bag [%d/%d] bag loss: %.4f" % (i, len(test_df), loss.item()))

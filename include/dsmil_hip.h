@@ -129,19 +129,37 @@ int dsmil_agg_shard_attend(const float* feats, const float* vals, int64_t rows,
  * The choice is read once per process from the environment variable DSMIL_MLP. */
 int dsmil_agg_mlp_form(void);
 
-/* The plane-cut query weights of forms 6 / 9 can be prepared ONCE per weight set instead of on every
- * forward (BClassifier.q changes only at optimizer.step(), train_tcga.py:73): dsmil_agg_pack_split cuts
- * q0_w [128,K] and q2_w [128,128] (NULL when nonlinear == 0) into `packed`
- * (dsmil_agg_packed_split_bytes(K, nonlinear) bytes, 16-B aligned), and dsmil_agg_forward_packed is
- * dsmil_agg_forward reading them from there (packed_split == NULL: cut into the workspace per call,
- * exactly dsmil_agg_forward).  Ignored by form 0. */
+/* Options of dsmil_agg_forward_ex (all optional; a NULL opts or an all-zero struct = dsmil_agg_forward):
+ *   packed_split  the plane-cut query weights of forms 6 / 9 prepared ONCE per weight set instead of on every
+ *                 forward (BClassifier.q changes only at optimizer.step(), train_tcga.py:73): dsmil_agg_pack_split
+ *                 cuts q0_w [128,K] and q2_w [128,128] (NULL when nonlinear == 0) into a buffer of
+ *                 dsmil_agg_packed_split_bytes(K, nonlinear) bytes, 16-B aligned.  Ignored by form 0.
+ *   row_map       int64 [total_rows]: logical row i of the batch (bag b, instance i - offsets[b]) lives at physical
+ *                 row row_map[i] of feats / vals.  This is train_tcga.py:78-83 `dropout_patches` (a random subset /
+ *                 permutation of a bag's rows, `feats[random_indices]`) as an index list folded into the kernels' row
+ *                 loads instead of a gathered 20 MB copy.  classes_out / A / idx stay in LOGICAL order (= the order of
+ *                 the reference's gathered tensor). */
+typedef struct dsmil_agg_opts {
+    const void* packed_split;
+    const int64_t* row_map;
+} dsmil_agg_opts;
 size_t dsmil_agg_packed_split_bytes(int32_t K, int32_t nonlinear);
 int dsmil_agg_pack_split(const float* q0_w, const float* q2_w, int32_t K, void* packed, void* stream);
-int dsmil_agg_forward_packed(const float* feats, const float* vals, const int64_t* offsets,
-                             int32_t n_bags, int64_t total_rows, int64_t max_rows,
-                             const dsmil_agg_params* p, const void* packed_split, const float* classes_in,
-                             float* classes_out, float* A, float* B, float* pred, int64_t* idx, void* ws,
-                             size_t ws_bytes, void* stream);
+int dsmil_agg_forward_ex(const float* feats, const float* vals, const int64_t* offsets,
+                         int32_t n_bags, int64_t total_rows, int64_t max_rows,
+                         const dsmil_agg_params* p, const dsmil_agg_opts* opts, const float* classes_in,
+                         float* classes_out, float* A, float* B, float* pred, int64_t* idx, void* ws,
+                         size_t ws_bytes, void* stream);
+
+/* The training objective of ONE bag, train_tcga.py:67-71 (also train_mil.py):
+ *   max_prediction = max_n ins_prediction[n,:]  (= classes[idx_c, c], idx = the forward's critical instances)
+ *   loss = 0.5 BCEWithLogitsLoss(bag_prediction, y) + 0.5 BCEWithLogitsLoss(max_prediction, y)   (mean over C)
+ * and its gradients with respect to the two logit vectors, in one launch (the reference spends ~10 small kernels
+ * and their autograd nodes on it):  loss[1], max_pred[C], g_pred[C] = dloss/dpred, g_max[C] = dloss/dmax_pred
+ * (each may be NULL except loss).  `classes` / `pred` / `idx` are the forward's outputs for this bag, `label` [C]
+ * fp32 0/1.  C <= 64. */
+int dsmil_agg_loss_head(const float* classes, const float* pred, const int64_t* idx, const float* label,
+                        int32_t C, float* loss, float* max_pred, float* g_pred, float* g_max, void* stream);
 
 /* FCLayer.forward alone (dsmil.py:10-12): classes[total_rows, C] = feats @ fc_w^T + fc_b. */
 int dsmil_fc_forward(const float* feats, int64_t total_rows, int32_t K, int32_t C,
@@ -170,6 +188,15 @@ typedef struct dsmil_agg_grads {
 } dsmil_agg_grads;
 
 size_t dsmil_agg_backward_workspace_bytes(int64_t N, int32_t K, int32_t Kv, int32_t C);
+/* dsmil_agg_backward_ex adds: g_max [C] — the SPARSE instance-stream gradient of the training objective (the max
+ * over instances touches one row per class: g_fc_w[c] += g_max[c] * feats[idx_c], g_fc_b[c] += g_max[c]; may be
+ * combined with a dense g_classes or replace it) and row_map (see dsmil_agg_opts; N logical rows).  A, g_A, g_vals,
+ * g_classes are in logical row order. */
+int dsmil_agg_backward_ex(const float* feats, const float* vals, int64_t N, const dsmil_agg_params* p,
+                          const float* A, const float* B, const int64_t* idx, const float* g_classes,
+                          const float* g_max, const float* g_pred, const float* g_A, const float* g_B,
+                          const dsmil_agg_grads* g, float* g_vals, const int64_t* row_map, void* ws,
+                          size_t ws_bytes, void* stream);
 int dsmil_agg_backward(const float* feats, const float* vals, int64_t N, const dsmil_agg_params* p,
                        const float* A, const float* B, const int64_t* idx, const float* g_classes,
                        const float* g_pred, const float* g_A, const float* g_B,

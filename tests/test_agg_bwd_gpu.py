@@ -136,3 +136,107 @@ def test_training_step_matches_dense_backward():
         ref = grads[1][k]
         scale = float(ref.abs().max()) + 1e-12
         assert float((grads[0][k] - ref).abs().max()) <= 2e-4 * scale, k
+
+
+# ---- fused training objective + dropout_patches as a row map --------------------------------
+@pytest.mark.parametrize("tag,N", [("c16", 5), ("c16", 200), ("tcga", 5), ("tcga", 200), ("musk", 40), ("tree", 33)])
+def test_fused_bag_loss_vs_reference_autograd(golden, tag, N):
+    """MILNet.bag_loss (dsmil_agg_forward_ex + dsmil_agg_loss_head + dsmil_agg_backward_ex with the SPARSE max-stream
+    gradient) against the reference's own loss and autograd gradients for train_tcga.py:67-72 (tests/golden)."""
+    from util import build_net
+    name = f"{tag}_grad_N{N}"
+    net = build_net(tag, "cuda").train()
+    x = torch.from_numpy(make_bag(int(golden[f"{name}/seed"]), N, VARIANT[tag][0])).cuda()
+    y = torch.from_numpy(golden[f"{name}/label"]).cuda()
+    loss, bag, mx = net.bag_loss(x, y)
+    loss.backward()
+    assert abs(loss.item() - float(golden[f"{name}/loss"])) < 1e-5
+    keymap = {"i_classifier.fc.0.weight": "fc_w", "i_classifier.fc.0.bias": "fc_b",
+              "b_classifier.q.0.weight": "q0_w", "b_classifier.q.0.bias": "q0_b",
+              "b_classifier.q.2.weight": "q2_w", "b_classifier.q.2.bias": "q2_b",
+              "b_classifier.fcc.weight": "fcc_w", "b_classifier.fcc.bias": "fcc_b"}
+    for k, prm in net.named_parameters():
+        ref = golden[f"{name}/g_{keymap[k]}"]
+        scale = max(1e-6, float(np.abs(ref).max()))
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), ref, atol=1e-4 * scale + 1e-7, rtol=1e-3, err_msg=k)
+    # the two extra outputs are the forward's bag logits and the max over instances
+    with torch.no_grad():
+        ins, bag2, _, _ = net(x)
+    assert torch.equal(bag, bag2) and torch.equal(mx, ins.max(0).values)
+
+
+@pytest.mark.parametrize("tag,N,keep", [("tcga", 3000, 0.7), ("c16", 70000, 0.5), ("musk", 333, 0.9)])
+def test_row_map_equals_gathered_rows(tag, N, keep):
+    """dropout_patches (train_tcga.py:78-83: `feats[randperm(N)[:int(N*p)]]`) as an index list: forward outputs, loss
+    and every parameter gradient equal those of the gathered copy (same kernels, same logical row order)."""
+    from util import build_net
+    from dsmil_wsi_amd import ops
+    K, C = VARIANT[tag][0], VARIANT[tag][1]
+    x = torch.from_numpy(make_bag(31 + N, N, K)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(N)
+    rows = torch.randperm(N, device="cuda", generator=g)[: int(N * keep)]
+    p = _params(tag, "cuda", torch.float32)
+    a = ops.agg_forward(x, [rows.numel()], p, row_map=rows)
+    b = ops.agg_forward(x.index_select(0, rows), [rows.numel()], p)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    y = torch.zeros(C, device="cuda")
+    y[0] = 1.0
+    grads = []
+    for mapped in (True, False):
+        net = build_net(tag, "cuda").train()
+        if mapped:
+            loss, _, _ = net.bag_loss(x, y, rows)
+        else:
+            loss, _, _ = net.bag_loss(x.index_select(0, rows), y)
+        loss.backward()
+        grads.append((loss.item(), {k: q.grad.clone() for k, q in net.named_parameters()}))
+    assert grads[0][0] == grads[1][0]
+    for k in grads[0][1]:
+        assert torch.equal(grads[0][1][k], grads[1][1][k]), k
+
+
+def test_loss_head_matches_torch_bce():
+    """dsmil_agg_loss_head against torch's BCEWithLogitsLoss composition (train_tcga.py:68-71), incl. its gradients."""
+    from dsmil_wsi_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for C in (1, 2, 5):
+        N = 50
+        classes = (torch.randn(N, C, generator=g) * 3).cuda()
+        pred = (torch.randn(1, C, generator=g) * 3).cuda().requires_grad_(True)
+        y = (torch.rand(C, generator=g) > 0.5).float().cuda()
+        idx = classes.argmax(0)
+        mxv = classes[idx, torch.arange(C, device="cuda")].detach().requires_grad_(True)
+        crit = torch.nn.BCEWithLogitsLoss()
+        ref = 0.5 * crit(pred.view(1, -1), y.view(1, -1)) + 0.5 * crit(mxv.view(1, -1), y.view(1, -1))
+        ref.backward()
+        loss, mx, g_pred, g_max = ops.agg_loss_head(classes, pred.detach(), idx, y)
+        assert abs(loss.item() - ref.item()) < 1e-6
+        assert torch.equal(mx, mxv.detach())
+        np.testing.assert_allclose(g_pred.cpu().numpy(), pred.grad.view(-1).cpu().numpy(), atol=1e-7, rtol=1e-5)
+        np.testing.assert_allclose(g_max.cpu().numpy(), mxv.grad.view(-1).cpu().numpy(), atol=1e-7, rtol=1e-5)
+
+
+def test_train_loop_uses_fused_objective_and_learns():
+    """training.train over resident bags with dropout_patch > 0: the fused path (row maps, one progress sync per step)
+    reduces the loss on a separable toy set."""
+    import argparse
+    from dsmil_wsi_amd import training as T
+    import dsmil as mil
+    rng = np.random.default_rng(0)
+    direction = rng.standard_normal(64).astype(np.float32)
+    bags = []
+    for b in range(16):
+        lab = b % 2
+        X = rng.standard_normal((150 + 11 * b, 64)).astype(np.float32)
+        if lab:
+            X[:6] += 2.5 * direction
+        bags.append(torch.from_numpy(np.concatenate([X, np.full((X.shape[0], 1), lab, np.float32)], 1)).cuda())
+    args = argparse.Namespace(feats_size=64, num_classes=1, dropout_patch=0.3, dropout_node=0.0, non_linearity=1,
+                              lr=2e-3, weight_decay=1e-4, num_epochs=8, average=False)
+    torch.manual_seed(0)
+    net, crit, opt, sched = T.init_model(args, mil, torch.device("cuda"))
+    losses = [T.train(args, bags, net, crit, opt, log=False) for _ in range(8)]
+    assert losses[-1] < 0.8 * losses[0], losses
+    tl, score, aucs, th = T.test(args, bags, net, crit, log=False)
+    assert aucs[0] > 0.9

@@ -300,15 +300,16 @@ def test_c_abi_rejects_misaligned_and_oversized_calls():
     vp = ctypes.c_void_p
 
     def call(ws_ptr, ws_bytes, n_bags=1, packed=None):
-        return L.dsmil_agg_forward_packed(vp(x.data_ptr()), None, vp(off.data_ptr()), n_bags, N, N, ctypes.byref(prm),
-                                          packed, None, vp(cls.data_ptr()), vp(A.data_ptr()), vp(B.data_ptr()),
-                                          vp(pred.data_ptr()), vp(idx.data_ptr()), vp(ws_ptr), ws_bytes, None)
+        opts = nat.AggOpts(packed, None)
+        return L.dsmil_agg_forward_ex(vp(x.data_ptr()), None, vp(off.data_ptr()), n_bags, N, N, ctypes.byref(prm),
+                                      ctypes.byref(opts), None, vp(cls.data_ptr()), vp(A.data_ptr()), vp(B.data_ptr()),
+                                      vp(pred.data_ptr()), vp(idx.data_ptr()), vp(ws_ptr), ws_bytes, None)
     assert call(aligned, need) == 0
     torch.cuda.synchronize()
     assert call(aligned + 64, need) == -5             # DSMIL_E_ALIGN
     assert call(aligned, need - 256) == -3            # DSMIL_E_WORKSPACE
     assert call(aligned, need, n_bags=65536) in (-1, -2)   # rejected before any launch (sizes / grid limit)
-    assert call(aligned, need, packed=vp(aligned + 4)) == -5
+    assert call(aligned, need, packed=aligned + 4) == -5
     # the python binding turns status codes into exceptions
     with pytest.raises(ValueError):
         ops.agg_forward(x, [N - 1], wt)               # lengths do not add up

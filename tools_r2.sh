@@ -14,6 +14,11 @@ bench)
   timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 3000 $OUT/bench.json; tail -5 $OUT/bench.err;;
 variants)
   DSMIL_NATIVE_LIB=libdsmil_hip_expt.so timeout 900 python tools_variants.py aggregator base: xe:DSMIL_EXPT=8 mlponly:DSMIL_EXPT=4 xe_mlponly:DSMIL_EXPT=12 novsum:DSMIL_EXPT=1 s9:DSMIL_MLP=s9 > $OUT/variants_agg.log 2>&1; cat $OUT/variants_agg.log;;
+variants2)
+  DSMIL_NATIVE_LIB=libdsmil_hip_expt.so timeout 900 python tools_variants.py aggregator base: tu16:DSMIL_EXPT=16 tu32:DSMIL_EXPT=32 > $OUT/variants_agg2.log 2>&1; cat $OUT/variants_agg2.log
+  DSMIL_NATIVE_LIB=libdsmil_hip_expt.so VARIANT_ROUNDS=1 timeout 900 python tools_variants.py embedder base: noxform:DSMIL_WINO_EXPT=1 noraw:DSMIL_WINO_EXPT=2 nou:DSMIL_WINO_EXPT=4 noepi:DSMIL_WINO_EXPT=8 nomfma:DSMIL_WINO_EXPT=16 onlymfma:DSMIL_WINO_EXPT=15 > $OUT/variants_emb.log 2>&1; cat $OUT/variants_emb.log;;
+tests_new)
+  timeout 900 python -m pytest tests/test_agg_bwd_gpu.py tests/test_agg_gpu.py tests/test_entry_points.py -m gpu -x -q > $OUT/pytest_new.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_new.log;;
 stamps)
   for e in 68 76; do DSMIL_NATIVE_LIB=libdsmil_hip_trace.so DSMIL_EXPT=$e timeout 300 python tools_stamp.py > $OUT/stamps_$e.log 2>&1; tail -12 $OUT/stamps_$e.log; done;;
 prof_agg)

@@ -36,6 +36,14 @@ print("GEMM1 step mean", d[:, 1:33].mean(), "median", np.median(d[:, 1:33]), "p9
 print("  even steps", d[:, 1:33:2].mean(), "odd steps", d[:, 2:33:2].mean())
 print("GEMM2 step mean", d[:, 33:41].mean(), "first", d[:, 33].mean(), "rest", d[:, 34:41].mean())
 print("per-step means:", np.round(d.mean(axis=0)).astype(int).tolist())
+good = (np.abs(d) < 1e6).all(axis=1)
+dg = d[good]
+print("tiles with sane stamps:", int(good.sum()))
+print("per-step medians:", np.round(np.median(dg, axis=0)).astype(int).tolist())
+print("per-step p10:", np.round(np.percentile(dg, 10, axis=0)).astype(int).tolist())
+print("per-step p90:", np.round(np.percentile(dg, 90, axis=0)).astype(int).tolist())
+tot = dg.sum(axis=1)
+print("tile total (sane): median", np.median(tot), "p10", np.percentile(tot, 10), "p90", np.percentile(tot, 90))
 import time
 ok = (T[:, -1] - T[:, 0] > 0) & (T[:, -1] - T[:, 0] < 1e6)
 print("valid tiles", ok.sum())
