@@ -403,6 +403,7 @@ struct WinoArgs {
     int IB, TYB, TXB;      // unit shape: images x tile rows x tile cols (IB*TYB*TXB <= 32)
     int nby, nbx, PB;      // units per image along y / x, PB = nby*nbx
     int expt;              // DSMIL_WINO_EXPT ablation knob (0 in production)
+    int skew;              // start-up delay (x64 cycles) of the second workgroup of a CU, see k_conv_wino_s3
 };
 
 // Epilogue shared by the Winograd kernels: inverse transform of this wave's 8 positions, exchange of
@@ -670,11 +671,15 @@ constexpr int SVLD = 28;                             // V LDS slot stride (dword
 constexpr int SV_DW = 16 * WTT * SVLD;               // dwords of V
 constexpr int SRPT = (WRAW_MAX * 4 + 255) / 256;     // raw float4 per thread per chunk
 
-template <bool NORM>
+// UD: how many transform positions ahead the weight fragments are requested (1 or 2); LS: the producer's
+// (mean, rstd) of the next chunk are staged through LDS by a few threads instead of being loaded by every staging
+// thread right before use.
+template <bool NORM, int UD = 1, bool LS = false>
 __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned* sV = reinterpret_cast<unsigned*>(smem);   // [16][WTT][SVLD] dwords
     float* sR = smem + SV_DW;                           // [WRAW_MAX][SRLD]
+    float* sS = sR + WRAW_MAX * SRLD;                   // LS: [2 buffers][16 images][2 (mean, rstd)][16 ch]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wp = wave >> 1;
@@ -691,6 +696,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
     const int tpi = a.TYB * a.TXB;
     const int iy_org = 2 * ty0 - 1, ix_org = 2 * tx0 - 1;
 
+#ifdef DSMIL_EXPERIMENTS
+    // start-up skew: the two workgroups of a CU otherwise run their MFMA and their staging/transform phases in
+    // lockstep (same work, same start) and contend for the same pipe at the same time; delaying the one in the
+    // odd wave slot by about half a chunk period makes the phases complementary.  Unit durations are equal, so
+    // the offset persists through later workgroups of the same slot.
+    if (a.skew > 0 && (int)(blockIdx.x + blockIdx.y * gridDim.x) < 512) {
+        if (tid == 0) {
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            sV[0] = hwid & 1u;
+        }
+        __syncthreads();
+        const unsigned odd = sV[0];
+        __syncthreads();
+        if (odd)
+            for (int i = 0; i < a.skew; i += 64) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
     // ---- raw staging role: element e = tid + 256 q -> (pixel e>>2, channel group e&3)
     int roff[SRPT], rlds[SRPT], rsto[SRPT];
 #pragma unroll
@@ -703,11 +726,30 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
             roff[q] = -1;
             if (n < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
                 roff[q] = ((n * a.H + iy) * a.W + ix) * a.C + gg * 4;
-                rsto[q] = n * a.C + gg * 4;
+                rsto[q] = LS ? il * 32 + gg * 4 : n * a.C + gg * 4;
             }
             rlds[q] = px * SRLD + gg * 4;
         }
     }
+    // LS: thread t < 128 fetches 4 channels of (mean | rstd) of local image t>>3 for the chunk two ahead
+    f32x4 sreg = {0.f, 0.f, 0.f, 0.f};
+    auto stat_load = [&](int cc) {
+        if constexpr (NORM && LS) {
+            if (tid < 128) {
+                const int il = tid >> 3, which = (tid >> 2) & 1, c4 = tid & 3;
+                const int n = img0 + il < a.B ? img0 + il : a.B - 1;
+                sreg = *reinterpret_cast<const f32x4*>((which ? a.in_rstd : a.in_mean) + (long long)n * a.C + cc * SK + c4 * 4);
+            }
+        }
+    };
+    auto stat_write = [&](int cc) {
+        if constexpr (NORM && LS) {
+            if (tid < 128) {
+                const int il = tid >> 3, which = (tid >> 2) & 1, c4 = tid & 3;
+                *reinterpret_cast<f32x4*>(sS + (cc & 1) * 512 + il * 32 + which * 16 + c4 * 4) = sreg;
+            }
+        }
+    };
     // ---- transform role: channel group g (4 channels), tile slot ts, column half h (nu in {2h,2h+1});
     //      all four xi rows of the patch columns h..h+2
     const int g = tid & 3, ts = (tid >> 2) & 31;
@@ -732,8 +774,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
             if constexpr (NORM) {
                 // (mean, rstd) are read here, not prefetched with the pixels: 32 more live registers
                 // across the MFMA phase spill (measured: 132 B of scratch)
-                const f32x4 mu = *reinterpret_cast<const f32x4*>(a.in_mean + rsto[q] + cc * SK);
-                const f32x4 rs = *reinterpret_cast<const f32x4*>(a.in_rstd + rsto[q] + cc * SK);
+                f32x4 mu, rs;
+                if constexpr (LS) {
+                    mu = *reinterpret_cast<const f32x4*>(sS + (cc & 1) * 512 + rsto[q]);
+                    rs = *reinterpret_cast<const f32x4*>(sS + (cc & 1) * 512 + rsto[q] + 16);
+                } else {
+                    mu = *reinterpret_cast<const f32x4*>(a.in_mean + rsto[q] + cc * SK);
+                    rs = *reinterpret_cast<const f32x4*>(a.in_rstd + rsto[q] + cc * SK);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = fmaxf((x[e] - mu[e]) * rs[e], 0.f);
             }
@@ -795,26 +843,32 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
 
     // ---- prologue: raw(0) -> LDS -> V(0); raw(1) in registers
     raw_load(0);
+    stat_load(0);
+    stat_write(0);
+    if constexpr (NORM && LS) __syncthreads();
     raw_write(0);
-    if (nchunks > 1) raw_load(1);
+    if (nchunks > 1) { raw_load(1); stat_load(1); }
     __syncthreads();
     transform();
+    if (nchunks > 1) stat_write(1);
     __syncthreads();
     const int vfo = ((8 * wp) * WTT + l31) * SVLD + 4 * hi;   // dwords
     union Frag { u32x4_t u; bf16x8_t v; };
     for (int cc = 0; cc < nchunks; ++cc) {
         const bool more = cc + 1 < nchunks, more2 = cc + 2 < nchunks;   // block-uniform
         // ---- 8 positions x 9 plane products
-        u32x4_t w[2][3];
+        u32x4_t w[UD + 1][3];
         uload(0, cc, w[0]);
+        if constexpr (UD == 2) uload(1, cc, w[1]);
+        if (more2) stat_load(cc + 2);
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            if (p < 7 && !DSMIL_WEXPT_ON(a, 4)) uload(p + 1, cc, w[(p + 1) & 1]);
+            if (p + UD < 8 && !DSMIL_WEXPT_ON(a, 4)) uload(p + UD, cc, w[(p + UD) % (UD + 1)]);
             Frag va[3], wb[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
                 va[pl].u = *reinterpret_cast<const u32x4_t*>(sV + vfo + p * WTT * SVLD + pl * 8);
-                wb[pl].u = w[DSMIL_WEXPT_ON(a, 4) ? 0 : (p & 1)][pl];
+                wb[pl].u = w[DSMIL_WEXPT_ON(a, 4) ? 0 : (p % (UD + 1))][pl];
             }
             if (DSMIL_WEXPT_ON(a, 16)) {   // ablation: no MFMAs (operands kept live)
                 asm volatile("" ::"v"(va[0].u), "v"(va[1].u), "v"(va[2].u), "v"(wb[0].u), "v"(wb[1].u), "v"(wb[2].u));
@@ -839,6 +893,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
         }
         __syncthreads();                 // V(cc) is free, raw(cc+1) is in LDS
         if (more && !DSMIL_WEXPT_ON(a, 1)) transform();
+        if (more2) stat_write(cc + 2);   // read by raw_write(cc+2) in the next iteration, behind the barrier below
         __syncthreads();                 // V(cc+1) is ready
     }
     if (DSMIL_WEXPT_ON(a, 8)) {  // ablation: no epilogue
@@ -1411,9 +1466,12 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
         wino_shape(B, wa.TY, wa.TX, wa.IB, wa.TYB, wa.TXB);
 #ifdef DSMIL_EXPERIMENTS
         static const int wexpt = expt_env("DSMIL_WINO_EXPT");
+        static const int wskew = expt_env("DSMIL_WINO_SKEW");
         wa.expt = wexpt;
+        wa.skew = wskew;
 #else
         wa.expt = 0;
+        wa.skew = 0;
 #endif
         wa.nby = (wa.TY + wa.TYB - 1) / wa.TYB; wa.nbx = (wa.TX + wa.TXB - 1) / wa.TXB; wa.PB = wa.nby * wa.nbx;
         const size_t lds = wino_s3() ? (size_t)(SV_DW + WRAW_MAX * SRLD) * sizeof(float)
@@ -1432,6 +1490,23 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
                     fprintf(stderr, "[dsmil] k_conv_wino_s3: lds %zu B, %d / %d workgroups per CU\n", lds, nb0, nb1);
                 }
             }
+#endif
+#ifdef DSMIL_EXPERIMENTS
+            const size_t lds_ls = lds + 4096;
+            static bool attr2 = false;
+            if (!attr2) {
+                attr2 = true;
+                (void)hipFuncSetAttribute((const void*)k_conv_wino_s3<true, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute((const void*)k_conv_wino_s3<false, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute((const void*)k_conv_wino_s3<true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ls);
+                (void)hipFuncSetAttribute((const void*)k_conv_wino_s3<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ls);
+            }
+            const bool ud2 = (wa.expt & 64) != 0, ls = (wa.expt & 128) != 0;
+            if (in_mean && ud2 && ls) hipLaunchKernelGGL((k_conv_wino_s3<true, 2, true>), grid, dim3(256), lds_ls, st, wa);
+            else if (in_mean && ls) hipLaunchKernelGGL((k_conv_wino_s3<true, 1, true>), grid, dim3(256), lds_ls, st, wa);
+            else if (in_mean && ud2) hipLaunchKernelGGL((k_conv_wino_s3<true, 2, false>), grid, dim3(256), lds, st, wa);
+            else if (ud2) hipLaunchKernelGGL((k_conv_wino_s3<false, 2, false>), grid, dim3(256), lds, st, wa);
+            else
 #endif
             if (in_mean) hipLaunchKernelGGL((k_conv_wino_s3<true>), grid, dim3(256), lds, st, wa);
             else hipLaunchKernelGGL((k_conv_wino_s3<false>), grid, dim3(256), lds, st, wa);

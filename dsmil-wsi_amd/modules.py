@@ -163,6 +163,23 @@ class MILNet(nn.Module):
         prediction_bag, A, B = bc(feats, classes)
         return classes, prediction_bag, A, B
 
+    def graphed(self, n_rows):
+        """A hipGraph-replayed forward for bags of exactly ``n_rows`` rows (inference; weights frozen): returns a
+        callable feats -> (classes, pred [1,C], A, B [1,C,K]).  Single-bag latency is launch-bound otherwise."""
+        ic, bc = self.i_classifier, self.b_classifier
+        if not (isinstance(ic, FCLayer) and isinstance(bc, BClassifier) and not bc.passing_v):
+            raise NotImplementedError("graphed forward: FCLayer + BClassifier with v = Identity")
+        w = {k: (v.detach() if v is not None else None) for k, v in bc._weights().items()}
+        lin = ic.fc[0]
+        w["fc_w"], w["fc_b"] = lin.weight.detach(), lin.bias.detach()
+        g = ops.GraphedAggForward(w, n_rows, lin.in_features, nonlinear=bc.nonlinear, device=lin.weight.device)
+
+        def run(feats):
+            classes, pred, A, B, _ = g(feats)
+            return classes, pred, A, B
+        run.graph = g
+        return run
+
     def bag_loss(self, feats, label, row_map=None):
         """The training objective of one bag, train_tcga.py:64-71 / train_mil.py, as ONE native forward + loss head
         (and one native backward under autograd):

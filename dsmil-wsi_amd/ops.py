@@ -243,6 +243,42 @@ def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, o
     return classes, pred, A, B, idx
 
 
+class GraphedAggForward:
+    """MILNet.forward of ONE bag shape captured into a hipGraph and replayed (the library enqueues on the
+    caller's stream, allocates nothing and never synchronises, so the whole 5-launch forward is capturable).  A single
+    10 000-row bag is launch-bound (5 dependent launches for ~30 us of device work); replay issues them with one call.
+
+        g = GraphedAggForward(w, n_rows, K)          # captures once (weights are read from `w`'s tensors in place)
+        classes, pred, A, B, idx = g(feats)          # copies feats into the static input, replays, returns the
+                                                     # static output tensors (valid until the next call)
+    Inference only: the capture holds the addresses of the weights and of their packed plane cuts, so the weights
+    must stay as they are — build a new object after an optimizer step or a load_state_dict."""
+
+    def __init__(self, w, n_rows, K, nonlinear=True, device=None, dtype=torch.float32):
+        dev = torch.device(device) if device is not None else w["q0_w"].device
+        self.w, self.n, self.nonlinear, self.dev = w, int(n_rows), nonlinear, dev
+        self.x = torch.zeros((self.n, K), dtype=dtype, device=dev)
+        self.offsets = offsets_tensor([self.n], dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):   # warm-up outside capture: workspace, packed weights, function attributes
+            for _ in range(2):
+                agg_forward(self.x, [self.n], w, nonlinear=nonlinear, offsets=self.offsets)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        # the captured launches read these buffers by address: keep them alive as long as the graph
+        self._keep = [_split_params(_f32c(w["q0_w"], "q0_w"), _f32c(w.get("q2_w"), "q2_w"), nonlinear, dev)
+                      if dtype == torch.float32 else _bf16_params(w, nonlinear, dev), _ws_cache.get(dev)]
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = agg_forward(self.x, [self.n], w, nonlinear=nonlinear, offsets=self.offsets)
+
+    def __call__(self, feats):
+        self.x.copy_(feats)
+        self.graph.replay()
+        return self.out
+
+
 def _agg_params(w, K, Kv, nonlinear):
     fcc_w = _f32c(w["fcc_w"], "fcc_w")
     C = fcc_w.shape[0]

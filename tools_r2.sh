@@ -17,6 +17,8 @@ variants)
 variants2)
   DSMIL_NATIVE_LIB=libdsmil_hip_expt.so timeout 900 python tools_variants.py aggregator base: tu16:DSMIL_EXPT=16 tu32:DSMIL_EXPT=32 > $OUT/variants_agg2.log 2>&1; cat $OUT/variants_agg2.log
   DSMIL_NATIVE_LIB=libdsmil_hip_expt.so VARIANT_ROUNDS=1 timeout 900 python tools_variants.py embedder base: noxform:DSMIL_WINO_EXPT=1 noraw:DSMIL_WINO_EXPT=2 nou:DSMIL_WINO_EXPT=4 noepi:DSMIL_WINO_EXPT=8 nomfma:DSMIL_WINO_EXPT=16 onlymfma:DSMIL_WINO_EXPT=15 > $OUT/variants_emb.log 2>&1; cat $OUT/variants_emb.log;;
+variants3)
+  DSMIL_NATIVE_LIB=libdsmil_hip_expt.so VARIANT_ROUNDS=2 timeout 1200 python tools_variants.py embedder base: skew1536:DSMIL_WINO_SKEW=1536 skew3072:DSMIL_WINO_SKEW=3072 skew4608:DSMIL_WINO_SKEW=4608 ud2:DSMIL_WINO_EXPT=64 ls:DSMIL_WINO_EXPT=128 ud2ls:DSMIL_WINO_EXPT=192 ud2ls_skew:DSMIL_WINO_EXPT=192,DSMIL_WINO_SKEW=3072 > $OUT/variants_emb3.log 2>&1; cat $OUT/variants_emb3.log;;
 tests_new)
   timeout 900 python -m pytest tests/test_agg_bwd_gpu.py tests/test_agg_gpu.py tests/test_entry_points.py -m gpu -x -q > $OUT/pytest_new.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_new.log;;
 stamps)
