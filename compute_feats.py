@@ -54,7 +54,7 @@ def build_backbone(args):
             "resnet50": (getattr(models, "resnet50", None), 2048), "resnet101": (getattr(models, "resnet101", None), 2048)}
     fn, num_feats = ctor[args.backbone]
     if fn is None:
-        raise ValueError(f"backbone {args.backbone} needs torchvision")
+        raise ValueError(f"unknown backbone {args.backbone}")
     resnet = fn(pretrained=pretrain, norm_layer=norm)
     for prm in resnet.parameters():
         prm.requires_grad = False

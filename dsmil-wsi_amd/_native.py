@@ -88,6 +88,8 @@ SIGNATURES = {
                                                 ctypes.c_int32, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t,
                                                 ctypes.c_void_p]),
     "dsmil_resnet_num_convs": (ctypes.c_int32, [ctypes.c_int32]),
+    "dsmil_resnet_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "dsmil_resnet_feature_dim": (ctypes.c_int32, [ctypes.c_int32]),
     "dsmil_resnet_mfma_forms": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "dsmil_resnet_norm_channels": (ctypes.c_int32, [ctypes.c_int32]),
     "dsmil_resnet_packed_bytes": (ctypes.c_size_t, [ctypes.c_int32]),

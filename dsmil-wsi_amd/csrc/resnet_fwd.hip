@@ -1298,31 +1298,45 @@ struct ConvSpec { int cout, cin, ks, stride, pad; };
 // torchvision state_dict order of the bias-free convolutions of a BasicBlock ResNet:
 // stem, then per block conv1, conv2 and — first block of layers 2..4 — downsample.0.
 // depth 18 = blocks [2,2,2,2] (20 convs), depth 34 = [3,4,6,3] (36 convs).
-struct Arch { int depth, nblk[4], nconv; ConvSpec specs[40]; };
+// depth 50 = Bottleneck blocks [3,4,6,3] (53 convs), depth 101 = [3,4,23,3] (104 convs): per block conv1 1x1,
+// conv2 3x3 (stride on conv2: torchvision's ResNet v1.5), conv3 1x1 to 4x the width, and — first block of every
+// layer — downsample.0 1x1; feature width 2048 (compute_feats.py:161-167).
+struct Arch { int depth, nblk[4], nconv, bottleneck, feat; ConvSpec specs[112]; };
 Arch make_arch(int depth) {
     Arch a;
     a.depth = depth;
-    const int n18[4] = {2, 2, 2, 2}, n34[4] = {3, 4, 6, 3};
-    for (int l = 0; l < 4; ++l) a.nblk[l] = depth == 34 ? n34[l] : n18[l];
+    const int n18[4] = {2, 2, 2, 2}, n34[4] = {3, 4, 6, 3}, n101[4] = {3, 4, 23, 3};
+    a.bottleneck = depth >= 50;
+    for (int l = 0; l < 4; ++l) a.nblk[l] = depth == 18 ? n18[l] : depth == 101 ? n101[l] : n34[l];
     int n = 0;
     a.specs[n++] = ConvSpec{64, 3, 7, 2, 3};
     int cin = 64;
     for (int l = 0; l < 4; ++l) {
         const int c = 64 << l;
         for (int b = 0; b < a.nblk[l]; ++b) {
-            const bool down = l > 0 && b == 0;
-            a.specs[n++] = ConvSpec{c, cin, 3, down ? 2 : 1, 1};
-            a.specs[n++] = ConvSpec{c, c, 3, 1, 1};
-            if (down) a.specs[n++] = ConvSpec{c, cin, 1, 2, 0};
-            cin = c;
+            if (a.bottleneck) {
+                const int stride = (l > 0 && b == 0) ? 2 : 1;
+                a.specs[n++] = ConvSpec{c, cin, 1, 1, 0};
+                a.specs[n++] = ConvSpec{c, c, 3, stride, 1};
+                a.specs[n++] = ConvSpec{4 * c, c, 1, 1, 0};
+                if (b == 0) a.specs[n++] = ConvSpec{4 * c, cin, 1, stride, 0};
+                cin = 4 * c;
+            } else {
+                const bool down = l > 0 && b == 0;
+                a.specs[n++] = ConvSpec{c, cin, 3, down ? 2 : 1, 1};
+                a.specs[n++] = ConvSpec{c, c, 3, 1, 1};
+                if (down) a.specs[n++] = ConvSpec{c, cin, 1, 2, 0};
+                cin = c;
+            }
         }
     }
     a.nconv = n;
+    a.feat = cin;
     return a;
 }
 const Arch* arch_of(int depth) {
-    static const Arch a18 = make_arch(18), a34 = make_arch(34);
-    return depth == 18 ? &a18 : depth == 34 ? &a34 : nullptr;
+    static const Arch a18 = make_arch(18), a34 = make_arch(34), a50 = make_arch(50), a101 = make_arch(101);
+    return depth == 18 ? &a18 : depth == 34 ? &a34 : depth == 50 ? &a50 : depth == 101 ? &a101 : nullptr;
 }
 
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1405,34 +1419,38 @@ struct RWs {
     size_t y0, buf[5], stat[4][2], part, total;  // stat[k] = {mean, rstd}
     long long act_elems, part_elems;
 };
-RWs rws_layout(int B, int H, int W) {
+RWs rws_layout(int B, int H, int W, int depth = 18) {
     const Dims d = dims_for(H, W);
+    const Arch& A = *arch_of(depth);
+    const int exp = A.bottleneck ? 4 : 1;   // channel expansion of a block's output
     RWs r;
     size_t o = 0;
     const long long y0e = (long long)B * d.H1 * d.W1 * 64;
-    r.act_elems = (long long)B * d.Hp * d.Wp * 64;  // largest post-pool activation
+    r.act_elems = (long long)B * d.Hp * d.Wp * 64 * exp;  // largest activation behind the pool (layer-1 block output)
     r.y0 = o; o = al256(o + (size_t)y0e * 4);
     for (int i = 0; i < 5; ++i) { r.buf[i] = o; o = al256(o + (size_t)r.act_elems * 4); }
     for (int k = 0; k < 4; ++k)
-        for (int j = 0; j < 2; ++j) { r.stat[k][j] = o; o = al256(o + (size_t)B * 512 * 4); }
+        for (int j = 0; j < 2; ++j) { r.stat[k][j] = o; o = al256(o + (size_t)B * 512 * exp * 4); }
     // partials: stem (n, tiles*4, 64, 3) or flat (tiles32, nslots, C, 2); take the max over layers
     const long long stem_parts = (long long)B * ((d.H1 + 7) / 8) * ((d.W1 + 15) / 16) * 4 * 64 * 3;
     long long mx = stem_parts;
     for (int l = 1; l <= 4; ++l) {
-        const int HW = d.h[l] * d.w[l];
-        const int C = 64 << (l - 1);
-        const long long M = (long long)B * HW;
-        const int nslots = 31 / HW + 2;
-        const long long e = ((M + 31) / 32) * nslots * C * 2;
-        if (e > mx) mx = e;
-        const int HWt = ((d.h[l] + 1) / 2) * ((d.w[l] + 1) / 2);
-        const long long Tt = (long long)B * HWt;
-        (void)Tt;
+        const int Cw = 64 << (l - 1);
+        // direct convs of layer l: outputs at this layer's resolution (up to Cw*exp channels) and, for a Bottleneck's
+        // conv1 in a strided block, at the previous layer's resolution (Cw channels)
+        for (int prev = 0; prev < (A.bottleneck && l > 1 ? 2 : 1); ++prev) {
+            const int HW = d.h[l - prev] * d.w[l - prev];
+            const int C = prev ? Cw : Cw * exp;
+            const long long M = (long long)B * HW;
+            const int nslots = 31 / HW + 2;
+            const long long e = ((M + 31) / 32) * nslots * C * 2;
+            if (e > mx) mx = e;
+        }
         int ib, tyb, txb;
         const int TYl = (d.h[l] + 1) / 2, TXl = (d.w[l] + 1) / 2;
         wino_shape(B, TYl, TXl, ib, tyb, txb);
         const long long PBl = (long long)((TYl + tyb - 1) / tyb) * ((TXl + txb - 1) / txb);
-        const long long ew = (long long)B * PBl * 2 * C * 3;  // Winograd (cnt, mean, M2) partials
+        const long long ew = (long long)B * PBl * 2 * Cw * 3;  // Winograd (cnt, mean, M2) partials
         if (ew > mx) mx = ew;
     }
     r.part_elems = mx;
@@ -1652,6 +1670,13 @@ size_t dsmil_resnet18_workspace_bytes(int32_t B, int32_t H, int32_t W) {
     return rws_layout(B, H, W).total;
 }
 
+size_t dsmil_resnet_workspace_bytes(int32_t depth, int32_t B, int32_t H, int32_t W) {
+    if (!arch_of(depth) || B <= 0 || H < 32 || W < 32) return 0;
+    return rws_layout(B, H, W, depth).total;
+}
+
+int32_t dsmil_resnet_feature_dim(int32_t depth) { const Arch* A = arch_of(depth); return A ? A->feat : 0; }
+
 static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32_t H, int32_t W, const float* conv1_w,
                                    const float* packed, const float* fc_w, const float* fc_b, int32_t C,
                                    float* feats, float* classes, void* ws, size_t ws_bytes, void* stream,
@@ -1665,7 +1690,7 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
     if (B <= 0 || H < 32 || W < 32) return DSMIL_E_INVALID;
     if (classes && (!fc_w || !fc_b || C <= 0)) return DSMIL_E_INVALID;
     if (((uintptr_t)ws % 256) || ((uintptr_t)packed % 16)) return DSMIL_E_ALIGN;
-    const RWs L = rws_layout(B, H, W);
+    const RWs L = rws_layout(B, H, W, depth);
     if (ws_bytes < L.total) return DSMIL_E_WORKSPACE;
     const Dims d = dims_for(H, W);
     if (d.h[4] < 1 || d.w[4] < 1) return DSMIL_E_UNSUPPORTED;
@@ -1708,37 +1733,63 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
     int Hc = d.Hp, Wc = d.Wp;
     for (int l = 1; l <= 4; ++l) {
         for (int b = 0; b < A.nblk[l - 1]; ++b) {
-            const bool down = (l > 1 && b == 0);
             const bool last = (l == 4 && b == A.nblk[3] - 1);
-            const ConvSpec& sa = A.specs[ci];
-            const ConvSpec& sb = A.specs[ci + 1];
-            const int Ho = outdim(Hc, sa.ks, sa.stride, sa.pad), Wo = outdim(Wc, sa.ks, sa.stride, sa.pad);
-            int rc = run_conv(st, cur, packed + pack_offset(A, ci), nullptr, nullptr, y1, part, mean[1], rstd[1], B, Hc, Wc, sa, bm(ci), br(ci));
-            if (rc) return rc;
-            rc = run_conv(st, y1, packed + pack_offset(A, ci + 1), mean[1], rstd[1], y2, part, mean[2], rstd[2], B, Ho, Wo, sb, bm(ci + 1), br(ci + 1));
-            if (rc) return rc;
-            if (down) {
-                rc = run_conv(st, cur, packed + pack_offset(A, ci + 2), nullptr, nullptr, yd, part, mean[3], rstd[3], B, Hc, Wc, A.specs[ci + 2], bm(ci + 2), br(ci + 2));
+            int rc, Ho, Wo, Cc;
+            bool down;
+            float* yout;   // raw output of the block's last conv
+            int sout;      // its statistics slot
+            if (A.bottleneck) {
+                // conv1 1x1 -> IN -> ReLU -> conv2 3x3 (stride) -> IN -> ReLU -> conv3 1x1 -> IN, + identity | downsample
+                down = b == 0;
+                const ConvSpec& s1 = A.specs[ci];
+                const ConvSpec& s2 = A.specs[ci + 1];
+                const ConvSpec& s3 = A.specs[ci + 2];
+                Ho = outdim(Hc, 3, s2.stride, 1); Wo = outdim(Wc, 3, s2.stride, 1);
+                rc = run_conv(st, cur, packed + pack_offset(A, ci), nullptr, nullptr, y1, part, mean[1], rstd[1], B, Hc, Wc, s1, bm(ci), br(ci));
                 if (rc) return rc;
+                rc = run_conv(st, y1, packed + pack_offset(A, ci + 1), mean[1], rstd[1], y2, part, mean[2], rstd[2], B, Hc, Wc, s2, bm(ci + 1), br(ci + 1));
+                if (rc) return rc;
+                // y1 and statistics slot 1 are free again: conv3 writes there
+                rc = run_conv(st, y2, packed + pack_offset(A, ci + 2), mean[2], rstd[2], y1, part, mean[1], rstd[1], B, Ho, Wo, s3, bm(ci + 2), br(ci + 2));
+                if (rc) return rc;
+                if (down) {
+                    rc = run_conv(st, cur, packed + pack_offset(A, ci + 3), nullptr, nullptr, yd, part, mean[3], rstd[3], B, Hc, Wc, A.specs[ci + 3], bm(ci + 3), br(ci + 3));
+                    if (rc) return rc;
+                }
+                yout = y1; sout = 1; Cc = s3.cout;
+                ci += down ? 4 : 3;
+            } else {
+                down = (l > 1 && b == 0);
+                const ConvSpec& sa = A.specs[ci];
+                const ConvSpec& sb = A.specs[ci + 1];
+                Ho = outdim(Hc, sa.ks, sa.stride, sa.pad); Wo = outdim(Wc, sa.ks, sa.stride, sa.pad);
+                rc = run_conv(st, cur, packed + pack_offset(A, ci), nullptr, nullptr, y1, part, mean[1], rstd[1], B, Hc, Wc, sa, bm(ci), br(ci));
+                if (rc) return rc;
+                rc = run_conv(st, y1, packed + pack_offset(A, ci + 1), mean[1], rstd[1], y2, part, mean[2], rstd[2], B, Ho, Wo, sb, bm(ci + 1), br(ci + 1));
+                if (rc) return rc;
+                if (down) {
+                    rc = run_conv(st, cur, packed + pack_offset(A, ci + 2), nullptr, nullptr, yd, part, mean[3], rstd[3], B, Hc, Wc, A.specs[ci + 2], bm(ci + 2), br(ci + 2));
+                    if (rc) return rc;
+                }
+                yout = y2; sout = 2; Cc = sa.cout;
+                ci += down ? 3 : 2;
             }
             const long long npix = (long long)B * Ho * Wo;
-            const int Cc = sa.cout;
             if (last) {
-                hipLaunchKernelGGL(k_norm_add_relu_pool, dim3((unsigned)((B * Cc + 255) / 256)), dim3(256), 0, st, y2,
-                                   mean[2], rstd[2], cur, feats, B, Ho * Wo, Cc);
+                hipLaunchKernelGGL(k_norm_add_relu_pool, dim3((unsigned)((B * Cc + 255) / 256)), dim3(256), 0, st, yout,
+                                   mean[sout], rstd[sout], cur, feats, B, Ho * Wo, Cc);
             } else {
                 long long blocks = (npix * (Cc / 4) + 255) / 256;
                 if (blocks > 8192) blocks = 8192;
-                if (down) hipLaunchKernelGGL(k_norm_add_relu<true>, dim3((unsigned)blocks), dim3(256), 0, st, y2, mean[2], rstd[2], yd, mean[3], rstd[3], nxt, npix, Ho * Wo, Cc);
-                else hipLaunchKernelGGL(k_norm_add_relu<false>, dim3((unsigned)blocks), dim3(256), 0, st, y2, mean[2], rstd[2], cur, nullptr, nullptr, nxt, npix, Ho * Wo, Cc);
+                if (down) hipLaunchKernelGGL(k_norm_add_relu<true>, dim3((unsigned)blocks), dim3(256), 0, st, yout, mean[sout], rstd[sout], yd, mean[3], rstd[3], nxt, npix, Ho * Wo, Cc);
+                else hipLaunchKernelGGL(k_norm_add_relu<false>, dim3((unsigned)blocks), dim3(256), 0, st, yout, mean[sout], rstd[sout], cur, nullptr, nullptr, nxt, npix, Ho * Wo, Cc);
             }
             if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
             float* t = cur; cur = nxt; nxt = t;
-            ci += down ? 3 : 2;
             Hc = Ho; Wc = Wo;
         }
     }
-    if (classes) return dsmil_fc_forward(feats, B, 512, C, fc_w, fc_b, classes, stream);
+    if (classes) return dsmil_fc_forward(feats, B, A.feat, C, fc_w, fc_b, classes, stream);
     return DSMIL_OK;
 }
 

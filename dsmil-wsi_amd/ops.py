@@ -405,27 +405,34 @@ _pack_cache = _LRU()
 
 
 def resnet_conv_shapes(depth):
-    """Shapes of the bias-free convs of a BasicBlock ResNet in torchvision state_dict order (mirror of
-    make_arch in csrc/resnet_fwd.hip): depth 18 -> 20 tensors, 34 -> 36."""
-    nblk = {18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}[depth]
+    """Shapes of the bias-free convs of a torchvision ResNet in state_dict order (mirror of make_arch in
+    csrc/resnet_fwd.hip): BasicBlock depth 18 -> 20 tensors, 34 -> 36; Bottleneck depth 50 -> 53, 101 -> 104."""
+    nblk = {18: (2, 2, 2, 2), 34: (3, 4, 6, 3), 50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[depth]
     shapes = [(64, 3, 7, 7)]
     cin = 64
     for l, n in enumerate(nblk):
         c = 64 << l
         for b in range(n):
-            shapes += [(c, cin, 3, 3), (c, c, 3, 3)]
-            if l > 0 and b == 0:
-                shapes.append((c, cin, 1, 1))
-            cin = c
+            if depth >= 50:
+                shapes += [(c, cin, 1, 1), (c, c, 3, 3), (4 * c, c, 1, 1)]
+                if b == 0:
+                    shapes.append((4 * c, cin, 1, 1))
+                cin = 4 * c
+            else:
+                shapes += [(c, cin, 3, 3), (c, c, 3, 3)]
+                if l > 0 and b == 0:
+                    shapes.append((c, cin, 1, 1))
+                cin = c
     return shapes
 
 
 RESNET18_SHAPES = resnet_conv_shapes(18)
+RESNET_DEPTHS = (18, 34, 50, 101)
 
 
 def resnet_depth_of(convs):
-    """18 / 34 when the conv list has exactly that architecture's shapes and order, else None."""
-    for depth in (18, 34):
+    """18 / 34 / 50 / 101 when the conv list has exactly that architecture's shapes and order, else None."""
+    for depth in RESNET_DEPTHS:
         sh = resnet_conv_shapes(depth)
         if len(convs) == len(sh) and all(tuple(w.shape) == t for w, t in zip(convs, sh)):
             return depth
@@ -484,10 +491,11 @@ def _folded_bn(norms, dev):
 def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None):
     """x: [B,3,H,W] fp32 CUDA in [0,1] (what VF.to_tensor yields), OR decoded images as uint8
     [B,H,W,3] CUDA (the /255 + HWC->CHW of to_tensor is then fused into the stem, bit-identically);
-    convs: the trunk's conv weights in torchvision state_dict order (20 for ResNet-18, 36 for ResNet-34).
+    convs: the trunk's conv weights in torchvision state_dict order (20 for ResNet-18, 36 for ResNet-34, 53 for
+    ResNet-50, 104 for ResNet-101).
     ``bn_norms``: the eval-mode BatchNorm2d modules of a `--norm_layer batch` trunk, in the same order;
     None = InstanceNorm.  One native launch sequence (dsmil_resnet_forward).
-    Returns (feats [B,512], classes [B,C] or None)."""
+    Returns (feats [B,512 | 2048], classes [B,C] or None)."""
     u8 = x.dtype == torch.uint8
     if u8:
         if not x.is_cuda:
@@ -503,9 +511,10 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None):
         B, _, H, W = x.shape
     depth = resnet_depth_of(convs)
     if depth is None:
-        raise ValueError("conv weights do not have the ResNet-18 / ResNet-34 shapes and order")
+        raise ValueError("conv weights do not have the ResNet-18 / 34 / 50 / 101 shapes and order")
     dev = x.device
-    feats = torch.empty((B, 512), dtype=torch.float32, device=dev)
+    L = _native.lib()
+    feats = torch.empty((B, L.dsmil_resnet_feature_dim(depth)), dtype=torch.float32, device=dev)
     if B == 0:
         return feats, (torch.empty((0, fc_w.shape[0]), device=dev) if fc_w is not None else None)
     fc_w = _f32c(fc_w.detach(), "fc_w") if fc_w is not None else None
@@ -514,8 +523,7 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None):
     classes = torch.empty((B, C), dtype=torch.float32, device=dev) if fc_w is not None else None
     packed = _packed_resnet_weights(convs, depth)
     conv1 = _f32c(convs[0].detach(), "conv1.weight")
-    L = _native.lib()
-    nbytes = L.dsmil_resnet18_workspace_bytes(B, H, W)
+    nbytes = L.dsmil_resnet_workspace_bytes(depth, B, H, W)
     if nbytes == 0:
         raise ValueError(f"unsupported patch size {H}x{W}")
     ws = _workspace(dev, nbytes)

@@ -36,11 +36,37 @@ class BasicBlock(nn.Module):
         return self.relu(out + idn)
 
 
+class Bottleneck(nn.Module):
+    """torchvision's Bottleneck (ResNet v1.5: the stride sits on the 3x3 conv2)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, stride=1, bias=False)
+        self.bn3 = norm_layer(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        idn = x if self.downsample is None else self.downsample(x)
+        return self.relu(out + idn)
+
+
 class ResNet(nn.Module):
-    def __init__(self, layers, num_classes=1000, norm_layer=None):
+    def __init__(self, layers, num_classes=1000, norm_layer=None, block=BasicBlock):
         super().__init__()
         norm_layer = norm_layer or nn.BatchNorm2d
         self._norm_layer = norm_layer
+        self._block = block
         self.inplanes = 64
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = norm_layer(64)
@@ -51,7 +77,7 @@ class ResNet(nn.Module):
         self.layer3 = self._make_layer(256, layers[2], 2)
         self.layer4 = self._make_layer(512, layers[3], 2)
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
-        self.fc = nn.Linear(512, num_classes)
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -60,13 +86,13 @@ class ResNet(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def _make_layer(self, planes, blocks, stride):
-        down = None
-        if stride != 1 or self.inplanes != planes:
-            down = nn.Sequential(nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride, bias=False),
-                                 self._norm_layer(planes))
-        seq = [BasicBlock(self.inplanes, planes, stride, down, self._norm_layer)]
-        self.inplanes = planes
-        seq += [BasicBlock(planes, planes, norm_layer=self._norm_layer) for _ in range(1, blocks)]
+        block, down = self._block, None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                                 self._norm_layer(planes * block.expansion))
+        seq = [block(self.inplanes, planes, stride, down, self._norm_layer)]
+        self.inplanes = planes * block.expansion
+        seq += [block(self.inplanes, planes, norm_layer=self._norm_layer) for _ in range(1, blocks)]
         return nn.Sequential(*seq)
 
     # ---- torch-op graph (CPU tensors, BatchNorm, training) --------------------------------
@@ -143,20 +169,27 @@ def _resnet18_parts(model):
         for li in (1, 2, 3, 4):
             layer = getattr(model, f"layer{li}")
             for bi, blk in enumerate(layer):
-                if not hasattr(blk, "conv2") or hasattr(blk, "conv3"):
+                if not hasattr(blk, "conv2") or not isinstance(getattr(blk, "relu", None), nn.ReLU):
                     return None
                 stride = 2 if (li > 1 and bi == 0) else 1
-                if not (_conv_is(blk.conv1, 3, stride, 1) and _conv_is(blk.conv2, 3, 1, 1)
-                        and isinstance(getattr(blk, "relu", None), nn.ReLU)):
-                    return None
-                convs += [blk.conv1.weight, blk.conv2.weight]
-                norms += [blk.bn1, blk.bn2]
+                if hasattr(blk, "conv3"):   # Bottleneck: 1x1, 3x3 (stride), 1x1; downsample in the first block of EVERY layer
+                    if not (_conv_is(blk.conv1, 1, 1, 0) and _conv_is(blk.conv2, 3, stride, 1) and _conv_is(blk.conv3, 1, 1, 0)):
+                        return None
+                    convs += [blk.conv1.weight, blk.conv2.weight, blk.conv3.weight]
+                    norms += [blk.bn1, blk.bn2, blk.bn3]
+                    need_down = bi == 0
+                else:
+                    if not (_conv_is(blk.conv1, 3, stride, 1) and _conv_is(blk.conv2, 3, 1, 1)):
+                        return None
+                    convs += [blk.conv1.weight, blk.conv2.weight]
+                    norms += [blk.bn1, blk.bn2]
+                    need_down = stride != 1
                 if blk.downsample is not None:
                     if len(blk.downsample) != 2 or not _conv_is(blk.downsample[0], 1, stride, 0):
                         return None
                     convs.append(blk.downsample[0].weight)
                     norms.append(blk.downsample[1])
-                elif stride != 1:
+                elif need_down:
                     return None
     except (AttributeError, TypeError):
         return None
@@ -199,3 +232,17 @@ def resnet34(pretrained=False, weights=None, norm_layer=None, **kwargs):
     if pretrained or weights is not None:
         raise ValueError("pretrained ImageNet weights need torchvision and a download; not available offline")
     return ResNet([3, 4, 6, 3], norm_layer=norm_layer, **kwargs)
+
+
+def resnet50(pretrained=False, weights=None, norm_layer=None, **kwargs):
+    """compute_feats.py:161-163 (`--backbone resnet50`, 2048-d features)."""
+    if pretrained or weights is not None:
+        raise ValueError("pretrained ImageNet weights need torchvision and a download; not available offline")
+    return ResNet([3, 4, 6, 3], norm_layer=norm_layer, block=Bottleneck, **kwargs)
+
+
+def resnet101(pretrained=False, weights=None, norm_layer=None, **kwargs):
+    """compute_feats.py:164-167 (`--backbone resnet101`, 2048-d features)."""
+    if pretrained or weights is not None:
+        raise ValueError("pretrained ImageNet weights need torchvision and a download; not available offline")
+    return ResNet([3, 4, 23, 3], norm_layer=norm_layer, block=Bottleneck, **kwargs)

@@ -248,13 +248,17 @@ int dsmil_resnet18bn_forward(const void* x, int32_t x_is_u8_nhwc, int32_t B, int
                              const float* bn_rstd, const float* fc_w, const float* fc_b, int32_t C,
                              float* feats, float* classes, void* ws, size_t ws_bytes, void* stream);
 
-/* Generic BasicBlock trunk: depth 18 (blocks [2,2,2,2], 20 convs) or 34 ([3,4,6,3], 36 convs) — the
- * reference's `--backbone resnet18|resnet34` (compute_feats.py:155-160).  conv_w is the trunk's
+/* Generic trunk: BasicBlock depth 18 (blocks [2,2,2,2], 20 convs) or 34 ([3,4,6,3], 36 convs), Bottleneck depth 50
+ * ([3,4,6,3], 53 convs) or 101 ([3,4,23,3], 104 convs; stride on the 3x3 conv, torchvision's v1.5) — the
+ * reference's `--backbone resnet18|resnet34|resnet50|resnet101` (compute_feats.py:155-167).  conv_w is the trunk's
  * dsmil_resnet_num_convs(depth) conv tensors in state_dict order; bn_mean / bn_rstd are NULL for
  * InstanceNorm or the folded frozen-BatchNorm arrays (dsmil_resnet_norm_channels(depth) floats, see
  * dsmil_resnet18bn_forward); x is fp32 NCHW or uint8 NHWC.  Workspace as dsmil_resnet18_workspace_bytes
  * (the activation shapes do not depend on the depth).  The *18* entry points above are these with
- * depth = 18.  feats is [B,512] for both depths. */
+ * depth = 18.  feats is [B, dsmil_resnet_feature_dim(depth)] (512 for BasicBlock trunks, 2048 for Bottleneck trunks); the
+ * workspace of a Bottleneck trunk is larger: dsmil_resnet_workspace_bytes(depth, B, H, W). */
+size_t dsmil_resnet_workspace_bytes(int32_t depth, int32_t B, int32_t H, int32_t W);
+int32_t dsmil_resnet_feature_dim(int32_t depth);
 int32_t dsmil_resnet_num_convs(int32_t depth);
 /* Which matrix pipe the trunk's convolutions run on (for roofline accounting): bf16 plane products per fp32 MAC
  * of the Winograd convs (3x3 stride 1) and of the direct convs (3x3 stride 2, 1x1) — 9 / 6 = bf16 MFMA over exact

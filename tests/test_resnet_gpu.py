@@ -225,3 +225,47 @@ def test_resnet34_trunk_vs_torch_fp64(norm):
     assert f.shape == (2, 512)
     np.testing.assert_allclose(f.cpu().numpy(), rf.numpy(), atol=1e-4, rtol=1e-4)
     np.testing.assert_allclose(c.cpu().numpy(), rc.numpy(), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("depth,norm,B,H,W", [(50, "instance", 2, 224, 224), (50, "batch", 3, 224, 224), (50, "instance", 5, 96, 160),
+                                              (101, "instance", 2, 224, 224), (50, "instance", 33, 224, 224)])
+def test_bottleneck_trunks_vs_torch_fp64(depth, norm, B, H, W):
+    """`--backbone resnet50 | resnet101` (compute_feats.py:161-167: Bottleneck blocks, 2048-d features): the native
+    trunk (dsmil_resnet_forward, depth 50 / 101: 1x1 and strided 3x3 convs on the direct MFMA kernel, stride-1 3x3 convs
+    on the Winograd kernel, fused InstanceNorm / folded frozen BatchNorm) against the same torch module evaluated on the
+    CPU in fp64.  Tolerance 1e-4 abs + 1e-4 rel on features and instance logits."""
+    import copy
+    from dsmil_wsi_amd.resnet import resnet50, resnet101
+    from dsmil_wsi_amd.modules import resnet_convs_of
+    g = torch.Generator().manual_seed(500 + depth)
+    ctor = resnet50 if depth == 50 else resnet101
+    res = ctor(norm_layer=nn.InstanceNorm2d if norm == "instance" else nn.BatchNorm2d)
+    res.fc = nn.Identity()
+    with torch.no_grad():
+        for m in res.modules():
+            if isinstance(m, nn.Conv2d):   # kaiming(fan_out), torchvision's init, seeded
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / (m.weight.shape[0] * m.weight.shape[2] ** 2)) ** 0.5)
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                m.weight.copy_((torch.rand(m.weight.shape, generator=g) * 0.5 + 0.6) *
+                               torch.where(torch.rand(m.weight.shape, generator=g) < 0.1, -1.0, 1.0))
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    ic = dsmil.IClassifier(res, 2048, output_class=2).eval()
+    with torch.no_grad():
+        ic.fc.weight.copy_(torch.randn(ic.fc.weight.shape, generator=g) * 0.05)
+        ic.fc.bias.copy_(torch.randn(ic.fc.bias.shape, generator=g) * 0.1)
+    for p in ic.parameters():
+        p.requires_grad = False
+    trunk = resnet_convs_of(ic.feature_extractor)
+    assert trunk is not None and len(trunk[0]) == (53 if depth == 50 else 104)
+    x = torch.from_numpy(make_patches(80 + B, B, H, W))
+    with torch.no_grad():
+        rf, rc = copy.deepcopy(ic).double()(x.double())
+    icg = ic.cuda()
+    with torch.no_grad():
+        f, c = icg(x.cuda())
+    assert f.shape == (B, 2048) and c.shape == (B, 2)
+    err = float((f.cpu().double() - rf).abs().max())
+    np.testing.assert_allclose(f.cpu().numpy(), rf.numpy(), atol=1e-4, rtol=1e-4, err_msg=f"max abs err {err:.3e}")
+    np.testing.assert_allclose(c.cpu().numpy(), rc.numpy(), atol=1e-4, rtol=1e-4)

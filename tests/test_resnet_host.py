@@ -134,7 +134,7 @@ def test_resnet34_is_recognised_with_36_convs():
         [k for k, v in res.state_dict().items() if v.dim() == 4]
     import dsmil_wsi_amd._native as nat
     L = nat.lib()
-    assert L.dsmil_resnet_num_convs(18) == 20 and L.dsmil_resnet_num_convs(34) == 36 and L.dsmil_resnet_num_convs(50) == 0
+    assert L.dsmil_resnet_num_convs(18) == 20 and L.dsmil_resnet_num_convs(34) == 36 and L.dsmil_resnet_num_convs(77) == 0
     assert L.dsmil_resnet_norm_channels(18) == 4800
     assert L.dsmil_resnet_packed_bytes(18) == L.dsmil_resnet18_packed_bytes() > 0
     assert L.dsmil_resnet_packed_bytes(34) > L.dsmil_resnet_packed_bytes(18)
@@ -177,3 +177,30 @@ def test_numpy_restatement_building_blocks_against_hand_computed_values():
     # instance norm: zero mean, biased unit variance (up to eps)
     z = rn.instance_norm(x)
     assert abs(z.mean()) < 1e-12 and abs((z ** 2).mean() - 21.25 / (21.25 + 1e-5)) < 1e-12
+
+
+@pytest.mark.parametrize("depth,nconv,params", [(50, 53, 23454912), (101, 104, 42394816)])
+def test_bottleneck_trunks_are_recognised(depth, nconv, params):
+    """`--backbone resnet50|resnet101` (compute_feats.py:161-167): torchvision's Bottleneck wiring (stride on the 3x3
+    conv, downsample in the first block of EVERY layer), state_dict order conv1, conv2, conv3, downsample.0; the native
+    library agrees on conv count, feature width and per-norm channel total; a modified block falls back to torch."""
+    from dsmil_wsi_amd import ops
+    from dsmil_wsi_amd.modules import resnet_convs_of
+    from dsmil_wsi_amd import resnet as R
+    import dsmil_wsi_amd._native as nat
+    res = getattr(R, f"resnet{depth}")(norm_layer=nn.InstanceNorm2d)
+    res.fc = nn.Identity()
+    assert sum(p.numel() for p in res.parameters()) == params          # torchvision's count without the fc layer
+    convs, norms = resnet_convs_of(res)
+    assert norms is None and len(convs) == nconv and ops.resnet_depth_of(convs) == depth
+    assert [tuple(w.shape) for w in convs] == ops.resnet_conv_shapes(depth)
+    assert [tuple(v.shape) for v in res.state_dict().values() if v.dim() == 4] == ops.resnet_conv_shapes(depth)
+    L = nat.lib()
+    assert L.dsmil_resnet_num_convs(depth) == nconv and L.dsmil_resnet_feature_dim(depth) == 2048
+    assert L.dsmil_resnet_norm_channels(depth) == sum(s[0] for s in ops.resnet_conv_shapes(depth))
+    assert L.dsmil_resnet_workspace_bytes(depth, 4, 224, 224) > L.dsmil_resnet_workspace_bytes(18, 4, 224, 224)
+    x = torch.from_numpy(make_patches(3, 1, 64, 64))
+    with torch.no_grad():
+        assert res(x).shape == (1, 2048)
+    res.layer3[0].conv2.stride = (1, 1)                                  # not the stock architecture any more
+    assert resnet_convs_of(res) is None
