@@ -538,3 +538,22 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None):
                                     ws.numel(), _stream(dev))
     _native.check(rc, "dsmil_resnet_forward")
     return feats, classes
+
+
+# ---------------------------------------------------------------------------------------------
+# background filters of the tilers (deepzoom_tiler.py:56-61, test_crop_single.py:17-24)
+# ---------------------------------------------------------------------------------------------
+def tile_stats(tiles):
+    """dsmil_tile_stats: uint8 NHWC tiles [B,H,W,3] on the device -> int64 [B,4] = per tile the three band sums of
+    PIL's FIND_EDGES image and the sum of the ubyte HSV saturation (exact integers)."""
+    if not tiles.is_cuda or tiles.dtype != torch.uint8 or tiles.dim() != 4 or tiles.shape[3] != 3:
+        raise RuntimeError("tiles must be a CUDA(HIP) uint8 tensor [B,H,W,3]")
+    tiles = tiles if tiles.is_contiguous() else tiles.contiguous()
+    B, H, W, _ = tiles.shape
+    out = torch.empty((B, 4), dtype=torch.int64, device=tiles.device)
+    if B == 0:
+        return out
+    with torch.cuda.device(tiles.device):
+        rc = _native.lib().dsmil_tile_stats(_ptr(tiles), B, H, W, _ptr(out), _stream(tiles.device))
+    _native.check(rc, "dsmil_tile_stats")
+    return out

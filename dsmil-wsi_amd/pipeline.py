@@ -369,6 +369,46 @@ def pyramid_tiles(wsi, tile=224, factor=4, lo=0, hi=None):
     return low, high, parent, torch.stack([rows, cols], dim=1)
 
 
+def tile_stats_reference(tiles):
+    """CPU restatement (numpy, exact integers / float64) of the two tiler filters' per-tile sums — see
+    csrc/tile_filter.hip; used for CPU tensors and as the checker of the HIP kernel.  tiles: uint8 [B,H,W,3]."""
+    a = np.asarray(tiles.cpu() if torch.is_tensor(tiles) else tiles).astype(np.int64)
+    B, H, W, _ = a.shape
+    edge = a.copy()                                   # borders are copied from the input (Pillow Filter.c)
+    if H > 2 and W > 2:
+        nb = sum(a[:, 1 + dy:H - 1 + dy, 1 + dx:W - 1 + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1))
+        edge[:, 1:-1, 1:-1] = np.clip(9 * a[:, 1:-1, 1:-1] - nb, 0, 255)       # 8*c - 8 neighbours
+    M, m = a.max(-1), a.min(-1)
+    f = a.astype(np.float64) / 255.0                  # skimage img_as_float
+    v, delta = f.max(-1), f.max(-1) - f.min(-1)       # rgb2hsv: out_v, delta = ptp
+    with np.errstate(invalid="ignore", divide="ignore"):
+        s = np.where(delta == 0.0, 0.0, delta / v)
+    sat = np.rint(s * 255.0).astype(np.int64)         # img_as_ubyte of a float image in [0,1]
+    del M, m
+    return np.concatenate([edge.sum((1, 2)), sat.sum((1, 2))[:, None]], axis=1)
+
+
+def background_keep_mask(tiles, edge_threshold=15, sat_threshold=None):
+    """Which tiles the reference's tilers would keep: deepzoom_tiler.py:56-61 (mean of the FIND_EDGES band sums /
+    tile_size^2 > edge_threshold, default 15 = `-t`) and / or test_crop_single.py:17-24 (mean ubyte saturation >=
+    sat_threshold, 30 at its call site).  Device tiles run dsmil_tile_stats; the decisions are made in float64 from
+    the exact integer sums, as numpy does.  Returns a bool tensor [B] on the tiles' device."""
+    if torch.is_tensor(tiles) and tiles.is_cuda:
+        from . import ops
+        st = ops.tile_stats(tiles).cpu().numpy()
+    else:
+        st = tile_stats_reference(tiles)
+    B, H, W = tiles.shape[0], tiles.shape[1], tiles.shape[2]
+    keep = np.ones(B, bool)
+    if edge_threshold is not None:
+        edge = st[:, :3].astype(np.float64).mean(axis=1) / float(H ** 2)   # np.mean(edge) / tile_size**2
+        keep &= edge > edge_threshold
+    if sat_threshold is not None:
+        keep &= st[:, 3].astype(np.float64) / float(H * W) >= sat_threshold
+    dev = tiles.device if torch.is_tensor(tiles) else "cpu"
+    return torch.from_numpy(keep).to(dev)
+
+
 @torch.no_grad()
 def embed_tiles(i_classifier, tiles, batch_size=256):
     """IClassifier over resident uint8 NHWC tiles in batches (compute_feats.py:70-76 without the loader: the

@@ -272,6 +272,14 @@ int dsmil_resnet_forward(int32_t depth, const void* x, int32_t x_is_u8_nhwc, int
                          const float* bn_rstd, const float* fc_w, const float* fc_b, int32_t C,
                          float* feats, float* classes, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- background filters of the reference's tilers on decoded tiles -------------------------
+ * tiles_nhwc: device uint8 [B,H,W,3] (W <= 1024).  out: device uint64 [B,4] = per tile
+ *   {sum over band 0, band 1, band 2 of PIL's ImageFilter.FIND_EDGES image, sum of img_as_ubyte(rgb2hsv(img)[...,1])}.
+ * deepzoom_tiler.py:56-61 keeps a tile when mean(out[0..2]) / tile_size^2 > threshold (default 15);
+ * test_crop_single.py:17-24 keeps it when out[3] / (H*W) >= t (t = 30 at its call site).  The sums are exact
+ * integers: forming the ratios in float64 on the host reproduces the reference's decisions bit for bit. */
+int dsmil_tile_stats(const uint8_t* tiles_nhwc, int32_t B, int32_t H, int32_t W, uint64_t* out, void* stream);
+
 const char* dsmil_strerror(int code);
 int dsmil_abi_version(void);
 /* Rows per workgroup the launcher picks for the dominant kernel (k_query_attend). */
