@@ -674,7 +674,10 @@ constexpr int SRPT = (WRAW_MAX * 4 + 255) / 256;     // raw float4 per thread pe
 // UD: how many transform positions ahead the weight fragments are requested (1 or 2); LS: the producer's
 // (mean, rstd) of the next chunk are staged through LDS by a few threads instead of being loaded by every staging
 // thread right before use.
-template <bool NORM, int UD = 1, bool LS = false>
+// NP: plane products per fp32 product (9 = every product formed exactly; 6 = the three smallest, together < 2^-20 of
+// |u*v|, left out — see agg_split.h).  UC: the weight fragments of the first UD positions of the NEXT chunk are
+// requested right behind this chunk's last MFMAs, so they fly across the staging / transform phase.
+template <bool NORM, int UD = 1, bool LS = false, int NP = 9, bool UC = false>
 __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned* sV = reinterpret_cast<unsigned*>(smem);   // [16][WTT][SVLD] dwords
@@ -854,12 +857,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
     __syncthreads();
     const int vfo = ((8 * wp) * WTT + l31) * SVLD + 4 * hi;   // dwords
     union Frag { u32x4_t u; bf16x8_t v; };
+    u32x4_t w[UD + 1][3];
     for (int cc = 0; cc < nchunks; ++cc) {
         const bool more = cc + 1 < nchunks, more2 = cc + 2 < nchunks;   // block-uniform
-        // ---- 8 positions x 9 plane products
-        u32x4_t w[UD + 1][3];
-        uload(0, cc, w[0]);
-        if constexpr (UD == 2) uload(1, cc, w[1]);
+        // ---- 8 positions x NP plane products
+        if (!UC || cc == 0) {
+            uload(0, cc, w[0]);
+            if constexpr (UD == 2) uload(1, cc, w[1]);
+        }
         if (more2) stat_load(cc + 2);
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -874,16 +879,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
                 asm volatile("" ::"v"(va[0].u), "v"(va[1].u), "v"(va[2].u), "v"(wb[0].u), "v"(wb[1].u), "v"(wb[2].u));
                 continue;
             }
-            // smallest products first: (l,l) (m,l) (l,m) (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[2].v, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[2].v, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[1].v, acc[p], 0, 0, 0);
+            // smallest products first: (l,l) (m,l) (l,m) | (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+            if constexpr (NP == 9) {
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[2].v, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[2].v, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[1].v, acc[p], 0, 0, 0);
+            }
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[0].v, acc[p], 0, 0, 0);
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[2].v, acc[p], 0, 0, 0);
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[1].v, acc[p], 0, 0, 0);
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[0].v, acc[p], 0, 0, 0);
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[1].v, acc[p], 0, 0, 0);
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[0].v, acc[p], 0, 0, 0);
+        }
+        if constexpr (UC) {
+            if (more) {   // slots 0 / 1 were last read by the MFMAs of positions 6 / 7 (UD = 2), already issued
+                uload(0, cc + 1, w[0]);
+                if constexpr (UD == 2) uload(1, cc + 1, w[1]);
+            }
         }
         // ---- raw(cc+1): registers -> LDS (the raw buffer was consumed before the last barrier), then the
         //      global loads of raw(cc+2)
@@ -1348,15 +1361,19 @@ inline bool use_wino(const ConvSpec& s) {  // 3x3 stride-1 convs run as Winograd
 #endif
     return !off && s.ks == 3 && s.stride == 1 && s.pad == 1 && s.cin % WK == 0 && s.cout % 64 == 0;
 }
-// DSMIL_WINO = s3 (default) | f32: which MFMA form the Winograd convs use (read once per process; the packed
-// weights and the kernels must agree): s3 = bf16 MFMA over exact three-plane cuts, f32 = v_mfma_f32_32x32x2_f32
-inline bool wino_s3() {
-    static const bool on = [] {
+// DSMIL_WINO = s6 (default) | s9 | f32: which MFMA form the Winograd convs use (read once per process; the packed
+// weights and the kernels must agree): s6 / s9 = bf16 MFMA over exact three-plane cuts with the 6 largest / all 9
+// plane products, f32 = v_mfma_f32_32x32x2_f32
+inline int wino_form() {
+    static const int form = [] {
         const char* e = getenv("DSMIL_WINO");
-        return !(e && !strcmp(e, "f32"));   // default: s3
+        if (e && !strcmp(e, "f32")) return 0;
+        if (e && (!strcmp(e, "s9") || !strcmp(e, "s3"))) return 9;
+        return 6;
     }();
-    return on;
+    return form;
 }
+inline bool wino_s3() { return wino_form() != 0; }
 // DSMIL_CONV = s3 | f32: MFMA form of the DIRECT convs (stride-2 3x3, 1x1 downsample); same weights either way
 inline bool conv_s3() {
     static const bool on = [] {
@@ -1497,37 +1514,32 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
         dim3 grid((unsigned)(((B + wa.IB - 1) / wa.IB) * wa.PB), (unsigned)(s.cout / 64));
         const int slot = dsmil_prof::begin(dsmil_prof::CH_CONV, st);
         if (wino_s3()) {
-#ifdef DSMIL_EXPERIMENTS
-            {
-                static bool once = false;
-                if (!once) {
-                    once = true;
-                    int nb0 = 0, nb1 = 0;
-                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, (const void*)k_conv_wino_s3<false>, 256, lds);
-                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, (const void*)k_conv_wino_s3<true>, 256, lds);
-                    fprintf(stderr, "[dsmil] k_conv_wino_s3: lds %zu B, %d / %d workgroups per CU\n", lds, nb0, nb1);
-                }
-            }
-#endif
-#ifdef DSMIL_EXPERIMENTS
+            // product configuration: weights two positions ahead (UD = 2), producer statistics staged through LDS (LS,
+            // +4 KiB: 80 KiB per workgroup, still two per CU), NP = 6 | 9 by DSMIL_WINO
             const size_t lds_ls = lds + 4096;
-            static bool attr2 = false;
-            if (!attr2) {
-                attr2 = true;
-                (void)hipFuncSetAttribute((const void*)k_conv_wino_s3<true, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                (void)hipFuncSetAttribute((const void*)k_conv_wino_s3<false, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                (void)hipFuncSetAttribute((const void*)k_conv_wino_s3<true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ls);
-                (void)hipFuncSetAttribute((const void*)k_conv_wino_s3<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ls);
-            }
-            const bool ud2 = (wa.expt & 64) != 0, ls = (wa.expt & 128) != 0;
-            if (in_mean && ud2 && ls) hipLaunchKernelGGL((k_conv_wino_s3<true, 2, true>), grid, dim3(256), lds_ls, st, wa);
-            else if (in_mean && ls) hipLaunchKernelGGL((k_conv_wino_s3<true, 1, true>), grid, dim3(256), lds_ls, st, wa);
-            else if (in_mean && ud2) hipLaunchKernelGGL((k_conv_wino_s3<true, 2, false>), grid, dim3(256), lds, st, wa);
-            else if (ud2) hipLaunchKernelGGL((k_conv_wino_s3<false, 2, false>), grid, dim3(256), lds, st, wa);
-            else
+            int variant = 0;   // bit 0: UC (carry the weight prefetch across the barrier phase)
+#ifdef DSMIL_EXPERIMENTS
+            variant = (wa.expt >> 8) & 1;
 #endif
-            if (in_mean) hipLaunchKernelGGL((k_conv_wino_s3<true>), grid, dim3(256), lds, st, wa);
-            else hipLaunchKernelGGL((k_conv_wino_s3<false>), grid, dim3(256), lds, st, wa);
+            const bool np9 = wino_form() == 9;
+            auto go = [&](auto kern, size_t l) {
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
+                hipLaunchKernelGGL(kern, grid, dim3(256), l, st, wa);
+            };
+#ifdef DSMIL_EXPERIMENTS
+            // UC costs 28-54 spilled VGPRs (the fragments stay live across the transform's temporaries): measured, not shipped
+            if (variant & 1) {
+                if (in_mean) go(k_conv_wino_s3<true, 2, true, 6, true>, lds_ls);
+                else go(k_conv_wino_s3<false, 2, false, 6, true>, lds);
+            } else
+#endif
+            if (in_mean) {
+                if (np9) go(k_conv_wino_s3<true, 2, true, 9, false>, lds_ls);
+                else go(k_conv_wino_s3<true, 2, true, 6, false>, lds_ls);
+            } else {
+                if (np9) go(k_conv_wino_s3<false, 2, false, 9, false>, lds);
+                else go(k_conv_wino_s3<false, 2, false, 6, false>, lds);
+            }
         }
         else if (in_mean) hipLaunchKernelGGL((k_conv_wino<true>), grid, dim3(256), lds, st, wa);
         else hipLaunchKernelGGL((k_conv_wino<false>), grid, dim3(256), lds, st, wa);
@@ -1609,8 +1621,6 @@ void set_conv_attrs() {
     (void)hipFuncSetAttribute((const void*)k_conv<4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
     (void)hipFuncSetAttribute((const void*)k_conv_wino<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * WTILE + 2 * WRAW_MAX * WLD) * 4);
     (void)hipFuncSetAttribute((const void*)k_conv_wino<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * WTILE + 2 * WRAW_MAX * WLD) * 4);
-    (void)hipFuncSetAttribute((const void*)k_conv_wino_s3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (SV_DW + WRAW_MAX * SRLD) * 4);
-    (void)hipFuncSetAttribute((const void*)k_conv_wino_s3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (SV_DW + WRAW_MAX * SRLD) * 4);
     g_attr_done = true;
 }
 
@@ -1619,7 +1629,7 @@ void set_conv_attrs() {
 extern "C" {
 
 int dsmil_resnet_mfma_forms(int32_t* wino_products, int32_t* direct_products) {
-    if (wino_products) *wino_products = wino_s3() ? 9 : 0;
+    if (wino_products) *wino_products = wino_form();
     if (direct_products) *direct_products = conv_s3() ? 9 : 0;
     return DSMIL_OK;
 }
