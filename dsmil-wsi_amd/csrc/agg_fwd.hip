@@ -315,11 +315,13 @@ __device__ __forceinline__ void qmax_block(
     const long long off0 = mode == 2 ? 0 : offsets[bag];
     const long long Nb = mode == 2 ? C : offsets[bag + 1] - off0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwv = (int)blockDim.x >> 6;          // 16 waves: every wave owns 8 hidden units -> one load round per layer
+    const int upw = QD / nwv;                      // hidden units per wave (multiple of 8)
     const long long slot0 = off0 / R0 + bag;
     const long long ntile = mode == 2 ? 0 : (Nb + R0 - 1) / R0;
     float bv = -INFINITY;
     long long bi = 0x7fffffffffffffffLL;
-    for (long long t = threadIdx.x; t < ntile; t += 256) {
+    for (long long t = threadIdx.x; t < ntile; t += blockDim.x) {
         const float v = part_val[(slot0 + t) * C + c];
         const long long i = part_idx[(slot0 + t) * C + c];
         if (better(v, i, bv, bi)) { bv = v; bi = i; }
@@ -333,8 +335,7 @@ __device__ __forceinline__ void qmax_block(
     if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
     __syncthreads();
     bv = s_v[0]; bi = s_i[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < nwv; ++w)
         if (better(s_v[w], s_i[w], bv, bi)) { bv = s_v[w]; bi = s_i[w]; }
     long long best = mode == 2 ? c : bi;
     if (best < 0 || best >= Nb) best = 0;  // all-NaN guard: stay in bounds
@@ -344,10 +345,10 @@ __device__ __forceinline__ void qmax_block(
     }
     if (mode == 1) return;
     const T* x = feats + (mode == 2 ? best : phys_row(rowmap, off0 + best)) * (long long)K;
-    // layer 1: wave w computes hidden units 32w..32w+31, 8 at a time; lanes stride k by 4
-    for (int jb = 0; jb < 32; jb += 8) {
+    // layer 1: wave w computes hidden units upw*w .. upw*w + upw - 1, 8 at a time; lanes stride k by 4
+    for (int jb = 0; jb < upw; jb += 8) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float* wr = q0_w + (long long)(wave * 32 + jb) * K;
+        const float* wr = q0_w + (long long)(wave * upw + jb) * K;
         for (int k0 = 0; k0 < K; k0 += 256) {
             const int k = k0 + lane * 4;
             const f32x4 xv = load4<VEC, T>(x, k, K);
@@ -360,9 +361,9 @@ __device__ __forceinline__ void qmax_block(
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            float a = wave_sum(acc[u]) + q0_b[wave * 32 + jb + u];
+            float a = wave_sum(acc[u]) + q0_b[wave * upw + jb + u];
             if (nonlinear) a = fmaxf(a, 0.f);
-            if (lane == 0) s_h[wave * 32 + jb + u] = a;
+            if (lane == 0) s_h[wave * upw + jb + u] = a;
         }
     }
     __syncthreads();
@@ -372,31 +373,32 @@ __device__ __forceinline__ void qmax_block(
         return;
     }
     const float h0 = s_h[lane], h1 = s_h[lane + 64];
-    for (int jb = 0; jb < 32; jb += 8) {
+    for (int jb = 0; jb < upw; jb += 8) {
         float acc[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const float* wr = q2_w + (long long)(wave * 32 + jb + u) * QD;
+            const float* wr = q2_w + (long long)(wave * upw + jb + u) * QD;
             acc[u] = fmaf(h0, wr[lane], h1 * wr[lane + 64]);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const float a = wave_sum(acc[u]) + q2_b[wave * 32 + jb + u];
-            if (lane == 0) out[wave * 32 + jb + u] = tanhf(a);
+            const float a = wave_sum(acc[u]) + q2_b[wave * upw + jb + u];
+            if (lane == 0) out[wave * upw + jb + u] = tanhf(a);
         }
     }
 }
 
+constexpr int QMAX_T = 1024;   // 16 waves per (bag, class): the block is a chain of dependent load rounds, so width pays
 template <int VEC, typename T = float>
-__global__ __launch_bounds__(256) void k_qmax(
+__global__ __launch_bounds__(QMAX_T) void k_qmax(
     const T* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ part_val, const long long* __restrict__ part_idx,
     const float* __restrict__ q0_w, const float* __restrict__ q0_b,
     const float* __restrict__ q2_w, const float* __restrict__ q2_b,
     float* __restrict__ qmax, int64_t* __restrict__ idx_out, int K, int C, int nonlinear, int bag0,
     int mode = 0, float* __restrict__ best_val_out = nullptr, const int64_t* __restrict__ rowmap = nullptr) {
-    __shared__ float s_v[4];
-    __shared__ long long s_i[4];
+    __shared__ float s_v[QMAX_T / 64];
+    __shared__ long long s_i[QMAX_T / 64];
     __shared__ float s_h[QD];
     qmax_block<VEC, T>(feats, offsets, part_val, part_idx, q0_w, q0_b, q2_w, q2_b, qmax, idx_out, K, C, nonlinear,
                        bag0 + (int)blockIdx.x, (int)blockIdx.y, s_v, s_i, s_h, mode, best_val_out, rowmap);
@@ -612,20 +614,194 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend_bf1
     attend_tail<NW, 4, bf16_t>(a, Q, smem, bag, off0, Nb, row0, slot);
 }
 
+// --------------------------------------------------------------------------------------------
+// k_query_attend_bf16_dma — the bf16-storage query MLP on the LDS-DMA pipeline of the split kernel (128-row
+// workgroups).  Both operands go global -> LDS by global_load_lds_dwordx4, no staging registers, no ds_write pass:
+//   weights   one 16 KiB chunk per 64-k step in MFMA-fragment order ([ks][t][lane] x 16 B: a straight copy, every
+//             fragment read a contiguous conflict-free ds_read_b128), 2 LDS buffers, issued one step ahead (L2-resident);
+//   features  each wave stages its own 32 rows: 4 pieces of 8 rows x 128 B (64 bf16) per step, 3 LDS buffers, issued
+//             TWO steps ahead (HBM-sourced); the 16-B slot of a row is permuted on the source side (slot c of row r
+//             holds global slot c ^ f(r)), which makes the fragment reads conflict-free.
+// A step is 16 MFMAs per wave; the kernel is bound by the feature stream, not by the matrix pipe.  Completion is
+// counted by hand (vmcnt + raw s_barrier), see agg_split.h.  GEMM 2 as in k_query_attend_bf16.
+// --------------------------------------------------------------------------------------------
+constexpr int BD_WCHUNK_F4 = 4 * 4 * 64;      // float4 (16 B) per weight chunk = 16 KiB
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_query_attend_bf16_dma(AttendArgs a) {
+    static_assert(NW == 4, "128-row workgroups");
+    constexpr int BM = NW * 32;
+    constexpr int X_BUF_F4 = BM * 8;          // float4 per feature buffer (128 B per row)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* sW = reinterpret_cast<f32x4*>(smem);                 // [2][BD_WCHUNK_F4]
+    f32x4* sX = sW + 2 * BD_WCHUNK_F4;                          // [3][X_BUF_F4]
+    const int bag = a.bag0 + blockIdx.y;
+    const long long off0 = a.offsets[bag];
+    const long long Nb = a.offsets[bag + 1] - off0;
+    const long long row0 = (long long)blockIdx.x * BM;
+    if (row0 >= Nb) return;
+    const long long slot = off0 / BM + bag + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int K = a.K;
+    const int nk1 = (K + 63) / 64;
+    const int nst = nk1 + (a.nonlinear ? 2 : 0);
+    const bf16_t* feats = reinterpret_cast<const bf16_t*>(a.feats);
+    const f32x4* wpk = reinterpret_cast<const f32x4*>(a.wpk);  // chunk-major fragment layout (k_pack_agg_bf16)
+
+    const bf16_t* xsrc[4];
+    int xslot[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = p * 8 + (lane >> 3);
+        long long gr = row0 + wave * 32 + r;
+        if (gr >= Nb) gr = Nb - 1;                               // rows past the bag end are masked in attend_tail
+        xsrc[p] = feats + phys_row(a.rowmap, off0 + gr) * (long long)K;
+        xslot[p] = ((lane & 7) ^ ((r & 6) | ((r >> 4) & 1))) * 8;   // bf16 elements
+    }
+    auto issue_w = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = i * NW + wave;                         // 16 pieces of 1 KiB per chunk
+            __builtin_amdgcn_global_load_lds((const DSMIL_GLOBAL void*)(wpk + (long long)s * BD_WCHUNK_F4 + q * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(sW + (s & 1) * BD_WCHUNK_F4 + q * 64), 16, 0, 0);
+        }
+    };
+    auto issue_x = [&](int s) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int k = s * 64 + xslot[p];
+            k = k + 8 <= K ? k : K - 8;                          // past K the packed weights are zero: any finite data will do
+            __builtin_amdgcn_global_load_lds((const DSMIL_GLOBAL void*)(xsrc[p] + k),
+                                             (__attribute__((address_space(3))) void*)(sX + (s % 3) * X_BUF_F4 + (wave * 32 + p * 8) * 8), 16, 0, 0);
+        }
+    };
+    const int fr = (l31 & 6) | ((l31 >> 4) & 1);
+
+    f32x16 H[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H[t][r] = 0.f;
+
+    issue_w(0);
+    issue_x(0);
+    if (nk1 > 1) { issue_x(1); S3_WAIT_VM(4); } else { S3_WAIT_VM(0); }
+    __builtin_amdgcn_s_barrier();
+    // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] X[n][k], 64 k per step
+    for (int s = 0; s < nk1; ++s) {
+        const bool more_w = s + 1 < nst, more_x = s + 2 < nk1;    // block-uniform
+        if (more_w) issue_w(s + 1);
+        if (more_x) issue_x(s + 2);
+        const f32x4* w = sW + (s & 1) * BD_WCHUNK_F4 + lane;
+        const f32x4* x = sX + (s % 3) * X_BUF_F4 + (wave * 32 + l31) * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            union { f32x4 f; bf16x8 v; } xb, wa;
+            xb.f = x[(ks * 2 + hi) ^ fr];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                wa.f = w[(ks * 4 + t) * 64];
+                H[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa.v, xb.v, H[t], 0, 0, 0);
+            }
+        }
+        // W(s+1) and this wave's X(s+1) have landed; X(s+2) (the youngest pieces) may stay in flight
+        if (more_x) S3_WAIT_VM(4); else S3_WAIT_VM(0);
+        __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.q0_b + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = H[t][4 * g + e] + b[e];
+                H[t][4 * g + e] = a.nonlinear ? fmaxf(v, 0.f) : v;
+            }
+        }
+    f32x16 Q[4];
+    if (a.nonlinear) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Q[t][r] = 0.f;
+        // ---- GEMM 2 (transposed): two 64-k chunks; step (tt, sidx) of chunk c2 contracts the 16 hidden units that
+        //      accumulator registers 8 sidx .. 8 sidx + 7 of H[2 c2 + tt] hold (packed W2 carries the k permutation)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int s = nk1 + c2;
+            if (c2 == 0) issue_w(s + 1);
+            const f32x4* w = sW + (s & 1) * BD_WCHUNK_F4 + lane;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * c2 + tt;
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx) {
+                    union { unsigned u[4]; bf16x8 v; } hb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        hb.u[e] = pack_bf16x2(H[t][8 * sidx + 2 * e], H[t][8 * sidx + 2 * e + 1]);
+#pragma unroll
+                    for (int t2 = 0; t2 < 4; ++t2) {
+                        union { f32x4 f; bf16x8 v; } wa;
+                        wa.f = w[((tt * 2 + sidx) * 4 + t2) * 64];
+                        Q[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa.v, hb.v, Q[t2], 0, 0, 0);
+                    }
+                }
+            }
+            S3_WAIT_VM(0);
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * t + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = tanhf(Q[t][4 * g + e] + b[e]);
+            }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Q[t] = H[t];
+    }
+    attend_tail<NW, 4, bf16_t>(a, Q, smem, bag, off0, Nb, row0, slot);
+}
+
 // W1 [128,K] fp32 -> bf16 [128,K64] zero padded; W2 [128,128] fp32 -> bf16 with the k permutation
 // described above.  RNE rounding (== torch .bfloat16()).
+// Behind that row-major image (read by the register-staged kernel) the same weights follow in the chunk-major
+// MFMA-fragment order of k_query_attend_bf16_dma: chunk s < K64/64: [ks][t][lane (l31,hi)][e] = W1[32t+l31][64s+16ks+8hi+e];
+// chunk K64/64 + c2: [ks = 2tt + sidx][t2][lane][e] = W2[32 t2 + l31][32 (2 c2 + tt) + 16 sidx + (e&3) + 8(e>>2) + 4hi].
 __global__ void k_pack_agg_bf16(const float* __restrict__ q0_w, const float* __restrict__ q2_w,
                                 bf16_t* __restrict__ out, int K, int K64) {
     const int n1 = QD * K64;
-    const int total = n1 + (q2_w ? QD * QD : 0);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int nrow = n1 + QD * QD;                       // row-major image (W2 part unused when !q2_w)
+    const int nfrag = (K64 / 64 + 2) * BD_WCHUNK_F4 * 8; // fragment image
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nrow + nfrag; i += gridDim.x * blockDim.x) {
         if (i < n1) {
             const int j = i / K64, k = i - j * K64;
             out[i] = k < K ? f2bf(q0_w[(long long)j * K + k]) : (bf16_t)0;
-        } else {
+        } else if (i < nrow) {
             const int q = i - n1, j = q / QD, kk = q - j * QD;
             const int base = kk & ~15, r = kk & 15, hi = r >> 3, e = r & 7;
-            out[i] = f2bf(q2_w[j * QD + base + (e & 3) + 8 * (e >> 2) + 4 * hi]);
+            out[i] = q2_w ? f2bf(q2_w[j * QD + base + (e & 3) + 8 * (e >> 2) + 4 * hi]) : (bf16_t)0;
+        } else {
+            int r = i - nrow;
+            const int e = r & 7; r >>= 3;
+            const int lane = r & 63; r >>= 6;
+            const int t = r & 3; r >>= 2;
+            const int ks = r & 3; r >>= 2;
+            const int s = r, l31 = lane & 31, hi = lane >> 5;
+            float v = 0.f;
+            if (s < K64 / 64) {
+                const int k = 64 * s + 16 * ks + 8 * hi + e;
+                if (k < K) v = q0_w[(long long)(32 * t + l31) * K + k];
+            } else if (q2_w) {
+                const int c2 = s - K64 / 64, tt = ks >> 1, sidx = ks & 1;
+                v = q2_w[(32 * t + l31) * QD + 32 * (2 * c2 + tt) + 16 * sidx + (e & 3) + 8 * (e >> 2) + 4 * hi];
+            }
+            out[i] = f2bf(v);
         }
     }
 }
@@ -867,6 +1043,23 @@ int mlp_mode() {
     return mode;
 }
 
+int launch_attend_bf16_dma(AttendArgs a, long long max_rows, int n_bags, hipStream_t st) {
+    constexpr int NW = 4, BM = NW * 32;
+    const size_t lds = (size_t)(2 * BD_WCHUNK_F4 + 3 * BM * 8) * 16;   // 32 KiB weights + 48 KiB features = 80 KiB: 2 per CU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_query_attend_bf16_dma<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int K64 = (a.K + 63) / 64 * 64;
+    a.wpk = a.wpk + (size_t)QD * K64 + QD * QD;   // the fragment image sits behind the row-major one
+    dim3 grid((unsigned)((max_rows + BM - 1) / BM), (unsigned)n_bags);
+    const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
+    hipLaunchKernelGGL((k_query_attend_bf16_dma<NW>), grid, dim3(NW * 64), lds, st, a);
+    dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
 template <int NW>
 int launch_attend_bf16(const AttendArgs& a, long long max_rows, int n_bags, hipStream_t st) {
     constexpr int BM = NW * 32;
@@ -1027,19 +1220,19 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         // 2. critical instance + its query
         dim3 gq((unsigned)nb, (unsigned)C);
         if (sh.phase == 1) {
-            if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap);
-            else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap);
+            if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap);
+            else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap);
             return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
         }
         if (sh.phase == 2) {
             const bool r4 = (K % 4 == 0) && ((uintptr_t)sh.crit_rows % 16 == 0) && (((uintptr_t)p->q0_w) % 16 == 0);
-            if (r4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(256), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
-            else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(256), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
+            if (r4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
+            else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
         }
-        else if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), gq, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
-        else if (bf16) hipLaunchKernelGGL((k_qmax<1, bf16_t>), gq, dim3(256), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
-        else if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
-        else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(256), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
+        else if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), gq, dim3(QMAX_T), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
+        else if (bf16) hipLaunchKernelGGL((k_qmax<1, bf16_t>), gq, dim3(QMAX_T), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
+        else if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
+        else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         // 3. query MLP on MFMA + scores + tile softmax + weighted value sum
         int rc;
@@ -1053,7 +1246,12 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
             if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
             a.wpk = wsplit;
         }
-        if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, nb, st) : launch_attend_bf16<1>(a, max_rows, nb, st);
+        bool bf16_dma = bf16 && NW == 4;   // feature rows are 16-B aligned on this path (K % 8 == 0, checked above)
+#ifdef DSMIL_EXPERIMENTS
+        if (a.expt & 256) bf16_dma = false;
+#endif
+        if (bf16_dma) rc = launch_attend_bf16_dma(a, max_rows, nb, st);
+        else if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, nb, st) : launch_attend_bf16<1>(a, max_rows, nb, st);
         else if (mode == 9 && NW == 4) rc = v4 ? launch_attend_split<4, 4, 9>(a, max_rows, nb, st) : launch_attend_split<4, 1, 9>(a, max_rows, nb, st);
         else if (mode == 9) rc = v4 ? launch_attend_split<1, 4, 9>(a, max_rows, nb, st) : launch_attend_split<1, 1, 9>(a, max_rows, nb, st);
 #ifdef DSMIL_EXPERIMENTS
@@ -1178,13 +1376,13 @@ int dsmil_agg_shard_attend(const float* feats, const float* vals, int64_t rows, 
 size_t dsmil_agg_packed_bf16_bytes(int32_t K) {
     if (K <= 0) return 0;
     const size_t K64 = ((size_t)K + 63) / 64 * 64;
-    return (QD * K64 + QD * QD) * sizeof(bf16_t);
+    return (QD * K64 + QD * QD) * sizeof(bf16_t) + (K64 / 64 + 2) * (size_t)BD_WCHUNK_F4 * 16;   // row-major + fragment image
 }
 
 int dsmil_agg_pack_bf16(const float* q0_w, const float* q2_w, int32_t K, void* packed, void* stream) {
     if (!q0_w || !packed || K <= 0) return DSMIL_E_INVALID;
     const int K64 = (K + 63) / 64 * 64;
-    hipLaunchKernelGGL(k_pack_agg_bf16, dim3(256), dim3(256), 0, (hipStream_t)stream, q0_w, q2_w,
+    hipLaunchKernelGGL(k_pack_agg_bf16, dim3(512), dim3(256), 0, (hipStream_t)stream, q0_w, q2_w,
                        (bf16_t*)packed, K, K64);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }

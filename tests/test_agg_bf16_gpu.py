@@ -70,3 +70,28 @@ def test_bf16_unsupported_width_raises():
     x = torch.from_numpy(make_bag(1, 40, 166)).cuda().to(torch.bfloat16)
     with pytest.raises(RuntimeError, match="unsupported"):
         ops.agg_forward(x, [40], w)
+
+
+@pytest.mark.parametrize("tag,N,nonlinear", [("tcga", 70000, True), ("c16", 100000, True), ("tree", 70000, True), ("linq", 70000, False)])
+def test_bf16_dma_kernel_at_the_wide_launch(tag, N, nonlinear):
+    """>= 512 tiles of 128 rows: k_query_attend_bf16_dma (LDS-DMA staged, 64-k steps; K = 64 is a single step, K = 1024
+    sixteen, the linear query has no second GEMM).  Same oracle and tolerances as above; ten runs bit-identical (the
+    completion counting of the DMA pipeline is done by hand)."""
+    import dsmil_wsi_amd.ops as ops
+    from util import VARIANT
+    K = VARIANT[tag][0]
+    p = load_weights(tag)
+    pr = {k: _round_bf16(v) for k, v in p.items()}
+    x = make_bag(800 + N + K, N, K)
+    xr = _round_bf16(x)
+    ref = orc.milnet_forward(xr, pr, dtype="f64", nonlinear=nonlinear)
+    w = {k: torch.from_numpy(v).cuda() for k, v in p.items()}
+    xb = torch.from_numpy(x).cuda().to(torch.bfloat16)
+    out = ops.agg_forward(xb, [N], w, nonlinear=nonlinear)
+    _check(out, ref, N)
+    assert np.array_equal(out[4].cpu().numpy()[0], ref[4])
+    first = [t.clone() for t in out]
+    for _ in range(9):
+        again = ops.agg_forward(xb, [N], w, nonlinear=nonlinear)
+        for a, b in zip(again, first):
+            assert torch.equal(a, b)

@@ -233,7 +233,10 @@ def test_bottleneck_trunks_vs_torch_fp64(depth, norm, B, H, W):
     """`--backbone resnet50 | resnet101` (compute_feats.py:161-167: Bottleneck blocks, 2048-d features): the native
     trunk (dsmil_resnet_forward, depth 50 / 101: 1x1 and strided 3x3 convs on the direct MFMA kernel, stride-1 3x3 convs
     on the Winograd kernel, fused InstanceNorm / folded frozen BatchNorm) against the same torch module evaluated on the
-    CPU in fp64.  Tolerance 1e-4 abs + 1e-4 rel on features and instance logits."""
+    CPU in fp64.  Tolerance 1e-4 abs + 1e-4 rel on features and instance logits — except where the reference's OWN
+    fp32 evaluation (the same torch module in fp32 on the CPU) is further than that from fp64: 104 fp32 conv + norm
+    layers drift by ~3e-4 on random weights (depth 101), and no fp32 implementation can be closer to fp64 than fp32
+    arithmetic allows; there the bar is 1.5x the reference's own fp32 error, measured in the test."""
     import copy
     from dsmil_wsi_amd.resnet import resnet50, resnet101
     from dsmil_wsi_amd.modules import resnet_convs_of
@@ -262,10 +265,16 @@ def test_bottleneck_trunks_vs_torch_fp64(depth, norm, B, H, W):
     x = torch.from_numpy(make_patches(80 + B, B, H, W))
     with torch.no_grad():
         rf, rc = copy.deepcopy(ic).double()(x.double())
+        f32_ref, _ = ic(x)                                     # the reference's arithmetic: torch fp32 on the CPU
+    ref_err = float((f32_ref.double() - rf).abs().max())
     icg = ic.cuda()
     with torch.no_grad():
         f, c = icg(x.cuda())
     assert f.shape == (B, 2048) and c.shape == (B, 2)
     err = float((f.cpu().double() - rf).abs().max())
-    np.testing.assert_allclose(f.cpu().numpy(), rf.numpy(), atol=1e-4, rtol=1e-4, err_msg=f"max abs err {err:.3e}")
-    np.testing.assert_allclose(c.cpu().numpy(), rc.numpy(), atol=1e-4, rtol=1e-4)
+    tol = max(1e-4, 1.5 * ref_err)
+    np.testing.assert_allclose(f.cpu().numpy(), rf.numpy(), atol=tol, rtol=1e-4,
+                               err_msg=f"max abs err {err:.3e}; reference fp32 vs fp64 {ref_err:.3e}")
+    np.testing.assert_allclose(c.cpu().numpy(), rc.numpy(), atol=tol, rtol=1e-4)
+    if depth == 50:
+        assert tol == 1e-4   # at depth 50 the 1e-4 bar itself holds
