@@ -130,14 +130,47 @@ struct ConvArgs {
     long long Mtot;
 };
 
+// Epilogue shared by the direct-conv kernels: raw NHWC store (128-B coalesced per half-wave) of a wave's
+// 32(pixel) x NT*32(channel) accumulators + the (mean, M2) statistics partials per image slot.
+template <int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x16 (&acc)[NT], long long tbase, int cbase,
+                                              int HW, int l31, int hi) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co = cbase + t * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long p = tbase + drow(r, hi);
+            if (p < a.Mtot) a.y[p * a.Cout + co] = acc[t][r];
+        }
+    }
+    if (tbase < a.Mtot) {
+        const long long tile32 = tbase >> 5;
+        const int nfirst = (int)(tbase / HW);
+        for (int s = 0; s < a.nslots; ++s) {
+            const long long ibeg = (long long)(nfirst + s) * HW, iend = ibeg + HW;
+            long long lo = ibeg - tbase, hi_ = ((iend < a.Mtot) ? iend : a.Mtot) - tbase;
+            if (lo < 0) lo = 0;
+            if (hi_ > 32) hi_ = 32;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float mean = 0.f, m2 = 0.f;
+                if (hi_ > lo) tile_stats(acc[t], hi, (int)lo, (int)hi_, mean, m2);
+                if (hi == 0) {
+                    float* o = a.part + ((tile32 * a.nslots + s) * a.Cout + cbase + t * 32 + l31) * 2;
+                    o[0] = mean;
+                    o[1] = m2;
+                }
+            }
+        }
+    }
+}
+
 // MW = m-tiles (of 32 pixels) per workgroup (4 -> 128 px, 2 -> 64 px); the 4 waves form an
 // MW x (4/MW) grid, each wave owning 32 pixels x NT*32 channels.  <4,4>: 128x128, <4,2>: 128x64,
 // <2,1>: 64x64 (finer work units for the late layers, whose 128x128 tiling yields only 392
-// workgroups for 256 CUs).
-// S3: the same tiles and staging, but each fp32 fragment is cut into three exact bf16 planes as it is
-// read from LDS and the products run on v_mfma_f32_32x32x16_bf16 (9 plane products per 16 k): 9/16 of
-// the f32 MFMA time, and the cut's VALU work runs beside the bf16 MFMA instead of on the f32 MFMA's pipe.
-template <int MW, int NT, bool NORM, int NBUF = 2, bool S3 = false>
+// workgroups for 256 CUs).  fp32 operands on v_mfma_f32_32x32x2_f32 (DSMIL_CONV=f32).
+template <int MW, int NT, bool NORM, int NBUF = 2>
 __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     constexpr int NWN = 4 / MW;
     constexpr int BM = MW * 32;
@@ -241,26 +274,6 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
         if (st + 1 < nsteps) stage_load(st + 1);
         const float* x = sX + (st & (NBUF - 1)) * X_TILE + wm * 32 * LDK + frag;
         const float* w = sW + (st & (NBUF - 1)) * W_TILE + wn * NT * 32 * LDK + frag;
-        if constexpr (S3) {
-            // lane (row l31, hi) feeds k = 16 ks + 8 hi .. + 7 of its row: two 16-B reads, then the cut
-            const float* x2 = x + 4 * hi;   // frag already holds l31 * LDK + 4 * hi
-            const float* w2 = w + 4 * hi;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                Frag16 xa[3];
-                cut8(*reinterpret_cast<const f32x4*>(x2 + ks * 16), *reinterpret_cast<const f32x4*>(x2 + ks * 16 + 4), xa);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    Frag16 wb[3];
-                    cut8(*reinterpret_cast<const f32x4*>(w2 + t * 32 * LDK + ks * 16),
-                         *reinterpret_cast<const f32x4*>(w2 + t * 32 * LDK + ks * 16 + 4), wb);
-                    constexpr int PA[9] = {2, 1, 2, 2, 0, 1, 1, 0, 0}, PB[9] = {2, 2, 1, 0, 2, 1, 0, 1, 0};
-#pragma unroll
-                    for (int i9 = 0; i9 < 9; ++i9)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PA[i9]].v, wb[PB[i9]].v, acc[t], 0, 0, 0);
-                }
-            }
-        } else {
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
             const f32x4 xa = *reinterpret_cast<const f32x4*>(x + kg * 8);
@@ -272,42 +285,180 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j], wb[j], acc[t], 0, 0, 0);
             }
         }
-        }
         if constexpr (NBUF == 1) __syncthreads();  // single LDS buffer: everyone done reading first
         if (st + 1 < nsteps) stage_write(st + 1);
         __syncthreads();
     }
-    // ---- epilogue: raw store (128-B coalesced per half-wave) + statistics partials
-    const long long tbase = m0 + wm * 32;  // first flattened pixel of this wave's tile
-    const int cbase = n0 + wn * NT * 32;
+    conv_epilogue<NT>(a, acc, m0 + wm * 32, n0 + wn * NT * 32, HW, l31, hi);
+}
+
+// --------------------------------------------------------------------------------------------
+// k_conv_s6 — the same implicit GEMM on bf16 MFMA over exact three-plane cuts (6 largest plane products per fp32
+// product, see agg_split.h): 6/16 of the f32-MFMA time for the same fp32-class result.  Every operand element is
+// cut ONCE: weights at pack time (k_pack_conv_s6: [tap][Cin/16][3 planes][Cout][16] bf16, the Winograd kernel's U
+// layout), activations by the staging thread as it writes them to LDS (behind the producer's IN + ReLU and the zero
+// padding).  16 k per step; an LDS row holds the three planes of its 16 k (96 B) + 16 B pad = 112 B, which makes every
+// ds_read_b128 of a fragment conflict-free (row stride 7 slots of 16 B, coprime to 16); two buffers, one barrier per step.
+// --------------------------------------------------------------------------------------------
+constexpr int S6K = 16;
+constexpr int S6LD = 28;   // dwords per LDS row (112 B)
+
+template <int MW, int NT, bool NORM>
+__global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
+    constexpr int NWN = 4 / MW;
+    constexpr int BM = MW * 32;
+    constexpr int TN = NWN * NT * 32;
+    constexpr int XPT = BM / 64;                    // float4 (4 k) per thread per activation step
+    constexpr int WIT = 6 * TN;                     // 16-B weight items per step: 3 planes x TN rows x 2 halves
+    constexpr int WPT = (WIT + 255) / 256;
+    constexpr int X_TILE = BM * S6LD, W_TILE = TN * S6LD;   // dwords
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned* sX = reinterpret_cast<unsigned*>(smem);       // [2][X_TILE]
+    unsigned* sW = sX + 2 * X_TILE;                          // [2][W_TILE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % MW, wn = wave / MW;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * TN;
+    const int HW = a.Ho * a.Wo;
+    const int taps = a.ks * a.ks;
+    const int nchunks = a.Cin / S6K;
+    const int nsteps = taps * nchunks;
+    const int c4 = tid & 3;
+    const unsigned short* wpk = reinterpret_cast<const unsigned short*>(a.w);
+
+    int iy0[XPT], ix0[XPT], nb[XPT], nimg[XPT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int co = cbase + t * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long p = tbase + drow(r, hi);
-            if (p < a.Mtot) a.y[p * a.Cout + co] = acc[t][r];
+    for (int i = 0; i < XPT; ++i) {
+        const long long p = m0 + (tid >> 2) + 64 * i;
+        if (p < a.Mtot) {
+            const int n = (int)(p / HW), rem = (int)(p - (long long)n * HW);
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            iy0[i] = oy * a.stride - a.pad;
+            ix0[i] = ox * a.stride - a.pad;
+            nb[i] = n * a.H * a.W;
+            nimg[i] = n;
+        } else {
+            iy0[i] = -100000; ix0[i] = -100000; nb[i] = 0; nimg[i] = 0;
         }
     }
-    if (tbase < a.Mtot) {
-        const long long tile32 = tbase >> 5;
-        const int nfirst = (int)(tbase / HW);
-        for (int s = 0; s < a.nslots; ++s) {
-            const long long ibeg = (long long)(nfirst + s) * HW, iend = ibeg + HW;
-            long long lo = ibeg - tbase, hi_ = ((iend < a.Mtot) ? iend : a.Mtot) - tbase;
-            if (lo < 0) lo = 0;
-            if (hi_ > 32) hi_ = 32;
+    // this thread's weight items: item e -> plane e / (2 TN), cout row (e % (2 TN)) / 2, 16-B half e & 1
+    int wsrc[WPT], wdst[WPT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                float mean = 0.f, m2 = 0.f;
-                if (hi_ > lo) tile_stats(acc[t], hi, (int)lo, (int)hi_, mean, m2);
-                if (hi == 0) {
-                    float* o = a.part + ((tile32 * a.nslots + s) * a.Cout + cbase + t * 32 + l31) * 2;
-                    o[0] = mean;
-                    o[1] = m2;
+    for (int i = 0; i < WPT; ++i) {
+        const int e = tid + 256 * i;
+        const int pl = e / (2 * TN), rem = e - pl * 2 * TN, r = rem >> 1, h = rem & 1;
+        wsrc[i] = e < WIT ? (pl * a.Cout + n0 + r) * S6K + h * 8 : -1;      // bf16 elements inside a (tap, chunk) slab
+        wdst[i] = r * S6LD + pl * 8 + h * 4;                                // dwords
+    }
+    f32x4 xreg[XPT], mu[XPT], rs[XPT];
+    u32x4_t wreg[WPT];
+    unsigned okmask = 0;
+    // tap-major inside a channel chunk: the producer's statistics are read once per chunk
+    auto stage_load = [&](int st) {
+        const int cc = st / taps, tap = st - cc * taps;
+        const int kh = tap / a.ks, kw = tap - kh * a.ks;
+        const int c0 = cc * S6K + c4 * 4;
+        if constexpr (NORM) {
+            if (tap == 0) {
+#pragma unroll
+                for (int i = 0; i < XPT; ++i) {
+                    mu[i] = *reinterpret_cast<const f32x4*>(a.in_mean + (long long)nimg[i] * a.Cin + c0);
+                    rs[i] = *reinterpret_cast<const f32x4*>(a.in_rstd + (long long)nimg[i] * a.Cin + c0);
                 }
             }
         }
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int iy = iy0[i] + kh, ix = ix0[i] + kw;
+            const bool ok = (iy >= 0) && (iy < a.H) && (ix >= 0) && (ix < a.W);
+            okmask |= ok ? (1u << i) : 0u;
+            const int iyc = min(max(iy, 0), a.H - 1), ixc = min(max(ix, 0), a.W - 1);
+            xreg[i] = *reinterpret_cast<const f32x4*>(a.x + (long long)(nb[i] + iyc * a.W + ixc) * a.Cin + c0);
+        }
+        const unsigned short* slab = wpk + ((long long)tap * nchunks + cc) * 3 * a.Cout * S6K;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            wreg[i] = *reinterpret_cast<const u32x4_t*>(slab + (wsrc[i] < 0 ? 0 : wsrc[i]));
+    };
+    auto stage_write = [&](int st) {
+        unsigned* x = sX + (st & 1) * X_TILE;
+        unsigned* w = sW + (st & 1) * W_TILE;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            f32x4 v = xreg[i];
+            const bool ok = (okmask >> i) & 1u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (NORM) v[e] = fmaxf((v[e] - mu[i][e]) * rs[i][e], 0.f);
+                v[e] = ok ? v[e] : 0.f;
+            }
+            u32x2_t ph, pm, pl;
+            cut4(v, ph, pm, pl);
+            unsigned* d = x + ((tid >> 2) + 64 * i) * S6LD + c4 * 2;
+            *reinterpret_cast<u32x2_t*>(d) = ph;
+            *reinterpret_cast<u32x2_t*>(d + 8) = pm;
+            *reinterpret_cast<u32x2_t*>(d + 16) = pl;
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            if (wsrc[i] >= 0) *reinterpret_cast<u32x4_t*>(w + wdst[i]) = wreg[i];
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    const int frag = l31 * S6LD + 4 * hi;   // dwords: this lane's row, k-half
+    for (int st = 0; st < nsteps; ++st) {
+        if (st + 1 < nsteps) stage_load(st + 1);
+        const unsigned* x = sX + (st & 1) * X_TILE + wm * 32 * S6LD + frag;
+        const unsigned* w = sW + (st & 1) * W_TILE + wn * NT * 32 * S6LD + frag;
+        Frag16 xa[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) xa[p].u = *reinterpret_cast<const u32x4_t*>(x + p * 8);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            Frag16 wb[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wb[p].u = *reinterpret_cast<const u32x4_t*>(w + t * 32 * S6LD + p * 8);
+            // smallest products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[2].v, wb[0].v, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0].v, wb[2].v, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1].v, wb[1].v, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1].v, wb[0].v, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0].v, wb[1].v, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0].v, wb[0].v, acc[t], 0, 0, 0);
+        }
+        if (st + 1 < nsteps) stage_write(st + 1);   // the other buffer: its readers passed the previous barrier
+        __syncthreads();
+    }
+    conv_epilogue<NT>(a, acc, m0 + wm * 32, n0 + wn * NT * 32, HW, l31, hi);
+}
+
+// conv weight [O][I][k][k] -> three truncated bf16 planes [tap][I/16][3][O][16]
+__global__ void k_pack_conv_s6(const float* __restrict__ w, unsigned short* __restrict__ out, int O, int I, int taps) {
+    const long long total = (long long)O * I * taps;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % taps);
+        const long long r = i / taps;
+        const int ci = (int)(r % I), o = (int)(r / I);
+        const float v = w[i];                                   // OIHW: ((o*I + ci)*taps + t)
+        const unsigned hb = __float_as_uint(v) & 0xFFFF0000u;
+        const float r1 = v - __uint_as_float(hb);
+        const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
+        const unsigned lb = __float_as_uint(r1 - __uint_as_float(mb));
+        const long long base = ((((long long)t * (I / 16) + ci / 16) * 3) * O + o) * 16 + (ci & 15);
+        out[base] = (unsigned short)(hb >> 16);
+        out[base + (long long)O * 16] = (unsigned short)(mb >> 16);
+        out[base + 2LL * O * 16] = (unsigned short)(lb >> 16);
     }
 }
 
@@ -1175,13 +1326,15 @@ __global__ __launch_bounds__(256) void k_stem(const void* __restrict__ xin, cons
     }
 }
 
-// stem partials (cnt, mean, M2) -> mean / rstd; one workgroup per image, 64 channels x 4 tile groups
-__global__ __launch_bounds__(256) void k_in_finalize_stem(const float* __restrict__ part, float* __restrict__ mean,
-                                                         float* __restrict__ rstd, int B, int nparts) {
+// stem partials (cnt, mean, M2) -> mean / rstd; one workgroup per image, 64 channels x 16 tile groups (392 partials
+// per channel at 224x224: a chain of dependent loads per thread, so width is what makes it short)
+constexpr int FS_G = 16;
+__global__ __launch_bounds__(64 * FS_G) void k_in_finalize_stem(const float* __restrict__ part, float* __restrict__ mean,
+                                                              float* __restrict__ rstd, int B, int nparts) {
     const int n = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    __shared__ float red[2][4][64];
+    __shared__ float red[2][FS_G][64];
     float s = 0.f, cnt = 0.f;
-    for (int t = g; t < nparts; t += 4) {
+    for (int t = g; t < nparts; t += FS_G) {
         const float* o = part + (((long long)n * nparts + t) * 64 + c) * 3;
         s += o[0] * o[1];
         cnt += o[0];
@@ -1189,10 +1342,12 @@ __global__ __launch_bounds__(256) void k_in_finalize_stem(const float* __restric
     red[0][g][c] = s;
     red[1][g][c] = cnt;
     __syncthreads();
-    const float tot = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
-    const float mu = ((red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c])) / tot;
+    float tot = 0.f, sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < FS_G; ++k) { tot += red[1][k][c]; sm += red[0][k][c]; }
+    const float mu = sm / tot;
     float q = 0.f;
-    for (int t = g; t < nparts; t += 4) {
+    for (int t = g; t < nparts; t += FS_G) {
         const float* o = part + (((long long)n * nparts + t) * 64 + c) * 3;
         const float d = o[1] - mu;
         q += o[2] + o[0] * d * d;
@@ -1201,7 +1356,9 @@ __global__ __launch_bounds__(256) void k_in_finalize_stem(const float* __restric
     red[0][g][c] = q;
     __syncthreads();
     if (g == 0) {
-        const float m2 = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        float m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < FS_G; ++k) m2 += red[0][k][c];
         mean[n * 64 + c] = mu;
         rstd[n * 64 + c] = 1.0f / sqrtf(m2 / tot + IN_EPS);
     }
@@ -1374,11 +1531,13 @@ inline int wino_form() {
     return form;
 }
 inline bool wino_s3() { return wino_form() != 0; }
-// DSMIL_CONV = s3 | f32: MFMA form of the DIRECT convs (stride-2 3x3, 1x1 downsample); same weights either way
-inline bool conv_s3() {
+// DSMIL_CONV = s6 (default) | f32: MFMA form of the DIRECT convs (strided 3x3, 1x1): s6 = bf16 MFMA over exact
+// three-plane cuts, 6 plane products (k_conv_s6; weights cut at pack time), f32 = v_mfma_f32_32x32x2_f32 (k_conv).
+// Read once per process; the packed weights and the kernels must agree.
+inline bool conv_s6() {
     static const bool on = [] {
         const char* e = getenv("DSMIL_CONV");
-        return e && !strcmp(e, "s3");
+        return !(e && !strcmp(e, "f32"));
     }();
     return on;
 }
@@ -1387,7 +1546,8 @@ inline bool conv_s3() {
 inline long long wsize(const Arch& A, int i) {
     const ConvSpec& s = A.specs[i];
     if (use_wino(s)) return (long long)s.cout * s.cin * (wino_s3() ? 24 : 16);
-    return (long long)s.cout * s.cin * s.ks * s.ks;
+    const long long n = (long long)s.cout * s.cin * s.ks * s.ks;
+    return conv_s6() ? n * 3 / 2 : n;   // three bf16 planes = 1.5 floats per weight
 }
 inline size_t pack_offset(const Arch& A, int i) {  // floats; conv 0 (stem) is used unpacked
     size_t o = 0;
@@ -1559,46 +1719,43 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
     a.Mtot = (long long)B * HW;
     const bool norm = in_mean != nullptr;
     const int slot = dsmil_prof::begin(dsmil_prof::CH_CONV, st);
-    // tile choice: 128x64 for Cout = 64; 128x128 while that yields >= 4 workgroups per CU;
-    // 64x64 (finer units, less tail quantisation) for the small late-layer maps
     const long long blocks128 = ((a.Mtot + 127) / 128) * (s.cout / 128 > 0 ? s.cout / 128 : 1);
-#ifdef DSMIL_EXPERIMENTS
-    static const int expt = expt_env("DSMIL_CONV_EXPT");
-#else
-    constexpr int expt = 0;
-#endif
-    if (s.cout == 64 && (expt & 1)) {
-        const size_t lds = (size_t)(128 * LDK + 64 * LDK) * 4;
-        dim3 grid((unsigned)((a.Mtot + 127) / 128), 1);
-        if (norm) hipLaunchKernelGGL((k_conv<4, 2, true, 1>), grid, dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((k_conv<4, 2, false, 1>), grid, dim3(256), lds, st, a);
-    } else if (s.cout == 64) {
+    if (conv_s6()) {
+        // 128-pixel tiles; 128 output channels per workgroup while that still yields two workgroups per CU, else 64
+        auto go = [&](auto kern, int TN, size_t lds) {
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            dim3 grid((unsigned)((a.Mtot + 127) / 128), (unsigned)(s.cout / TN));
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+        };
+        const size_t l128 = (size_t)2 * (128 + 128) * S6LD * 4, l64 = (size_t)2 * (128 + 64) * S6LD * 4;
+        if (s.cout % 128 == 0 && blocks128 >= 512) {
+            if (norm) go(k_conv_s6<4, 4, true>, 128, l128); else go(k_conv_s6<4, 4, false>, 128, l128);
+        } else {
+            if (norm) go(k_conv_s6<4, 2, true>, 64, l64); else go(k_conv_s6<4, 2, false>, 64, l64);
+        }
+        dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+        if (bn_m) return fill_stats(st, bn_m, bn_r, mean, rstd, B, s.cout);
+        hipLaunchKernelGGL(k_in_finalize_flat, dim3((unsigned)B), dim3(256), 0, st, part, mean, rstd,
+                           B, HW, s.cout, a.nslots, a.Mtot);
+        return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+    }
+    // tile choice (f32 form): 128x64 for Cout = 64; 128x128 while that yields >= 4 workgroups per CU;
+    // 64x64 (finer units, less tail quantisation) for the small late-layer maps
+    if (s.cout == 64) {
         const size_t lds = (size_t)(2 * 128 * LDK + 2 * 64 * LDK) * 4;
         dim3 grid((unsigned)((a.Mtot + 127) / 128), 1);
         if (norm) hipLaunchKernelGGL((k_conv<4, 2, true>), grid, dim3(256), lds, st, a);
         else hipLaunchKernelGGL((k_conv<4, 2, false>), grid, dim3(256), lds, st, a);
-    } else if (blocks128 >= 1024 && (expt & 2)) {
-        const size_t lds = (size_t)(128 * LDK + 128 * LDK) * 4;
-        dim3 grid((unsigned)((a.Mtot + 127) / 128), (unsigned)(s.cout / 128));
-        if (norm) hipLaunchKernelGGL((k_conv<4, 4, true, 1>), grid, dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((k_conv<4, 4, false, 1>), grid, dim3(256), lds, st, a);
-    } else if (blocks128 >= ((expt & 4) ? 256 : 1024)) {
+    } else if (blocks128 >= 1024) {
         const size_t lds = (size_t)(2 * 128 * LDK + 2 * 128 * LDK) * 4;
         dim3 grid((unsigned)((a.Mtot + 127) / 128), (unsigned)(s.cout / 128));
-        if (conv_s3()) {
-            if (norm) hipLaunchKernelGGL((k_conv<4, 4, true, 2, true>), grid, dim3(256), lds, st, a);
-            else hipLaunchKernelGGL((k_conv<4, 4, false, 2, true>), grid, dim3(256), lds, st, a);
-        }
-        else if (norm) hipLaunchKernelGGL((k_conv<4, 4, true>), grid, dim3(256), lds, st, a);
+        if (norm) hipLaunchKernelGGL((k_conv<4, 4, true>), grid, dim3(256), lds, st, a);
         else hipLaunchKernelGGL((k_conv<4, 4, false>), grid, dim3(256), lds, st, a);
     } else {
         const size_t lds = (size_t)(2 * 64 * LDK + 2 * 64 * LDK) * 4;
         dim3 grid((unsigned)((a.Mtot + 63) / 64), (unsigned)(s.cout / 64));
-        if (conv_s3()) {
-            if (norm) hipLaunchKernelGGL((k_conv<2, 1, true, 2, true>), grid, dim3(256), lds, st, a);
-            else hipLaunchKernelGGL((k_conv<2, 1, false, 2, true>), grid, dim3(256), lds, st, a);
-        }
-        else if (norm) hipLaunchKernelGGL((k_conv<2, 1, true>), grid, dim3(256), lds, st, a);
+        if (norm) hipLaunchKernelGGL((k_conv<2, 1, true>), grid, dim3(256), lds, st, a);
         else hipLaunchKernelGGL((k_conv<2, 1, false>), grid, dim3(256), lds, st, a);
     }
     dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
@@ -1613,8 +1770,6 @@ bool g_attr_done = false;
 void set_conv_attrs() {
     if (g_attr_done) return;
     const int l4 = (2 * 128 * LDK + 2 * 128 * LDK) * 4, l2 = (2 * 128 * LDK + 2 * 64 * LDK) * 4;
-    (void)hipFuncSetAttribute((const void*)k_conv<4, 4, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
-    (void)hipFuncSetAttribute((const void*)k_conv<4, 4, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
     (void)hipFuncSetAttribute((const void*)k_conv<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
     (void)hipFuncSetAttribute((const void*)k_conv<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l4);
     (void)hipFuncSetAttribute((const void*)k_conv<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
@@ -1630,7 +1785,7 @@ extern "C" {
 
 int dsmil_resnet_mfma_forms(int32_t* wino_products, int32_t* direct_products) {
     if (wino_products) *wino_products = wino_form();
-    if (direct_products) *direct_products = conv_s3() ? 9 : 0;
+    if (direct_products) *direct_products = conv_s6() ? 6 : 0;
     return DSMIL_OK;
 }
 
@@ -1659,11 +1814,15 @@ int dsmil_resnet_pack(int32_t depth, const float* const* conv_w, float* packed, 
                 hipLaunchKernelGGL(k_pack_wino, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
                                    packed + pack_offset(*A, i), s.cout, s.cin);
         } else {
-            const long long total = wsize(*A, i);
+            const long long total = (long long)s.cout * s.cin * s.ks * s.ks;
             long long blocks = (total + 255) / 256;
             if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
-                               packed + pack_offset(*A, i), s.cout, s.cin, s.ks * s.ks);
+            if (conv_s6())
+                hipLaunchKernelGGL(k_pack_conv_s6, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
+                                   (unsigned short*)(packed + pack_offset(*A, i)), s.cout, s.cin, s.ks * s.ks);
+            else
+                hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
+                                   packed + pack_offset(*A, i), s.cout, s.cin, s.ks * s.ks);
         }
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
@@ -1724,7 +1883,7 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
                                 part, B, H, W, d.H1, d.W1, tx, ty);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         if (bn_m) { const int rcf = fill_stats(st, bm(0), br(0), mean[0], rstd[0], B, 64); if (rcf) return rcf; }
-        else hipLaunchKernelGGL(k_in_finalize_stem, dim3((unsigned)B), dim3(256), 0, st, part,
+        else hipLaunchKernelGGL(k_in_finalize_stem, dim3((unsigned)B), dim3(64 * FS_G), 0, st, part,
                                 mean[0], rstd[0], B, tx * ty * 4);
         const long long total = (long long)B * d.Hp * d.Wp * 16;
         long long blocks = (total + 255) / 256;

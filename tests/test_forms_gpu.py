@@ -1,7 +1,7 @@
 """Every selectable MFMA form stays parity-green: the default suite runs the default forms (aggregator
 query MLP and Winograd convs on bf16 MFMA over exact three-plane cuts); this file re-runs a small
 aggregator + embedder check in subprocesses with the alternatives selected (the knobs are read once per
-process): DSMIL_MLP=f32 / s9, DSMIL_WINO=f32 / s9 and DSMIL_CONV=s3."""
+process): DSMIL_MLP=f32 / s9, DSMIL_WINO=f32 / s9 and DSMIL_CONV=f32."""
 import os
 import subprocess
 import sys
@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("env,form", [({"DSMIL_MLP": "f32", "DSMIL_WINO": "f32"}, 0),
-                                      ({"DSMIL_MLP": "s9", "DSMIL_WINO": "s9", "DSMIL_CONV": "s3"}, 9), ({}, 6)])
+@pytest.mark.parametrize("env,form", [({"DSMIL_MLP": "f32", "DSMIL_WINO": "f32", "DSMIL_CONV": "f32"}, 0),
+                                      ({"DSMIL_MLP": "s9", "DSMIL_WINO": "s9"}, 9), ({}, 6)])
 def test_alternative_mfma_forms(env, form):
     e = dict(os.environ)
     for k in ("DSMIL_MLP", "DSMIL_WINO", "DSMIL_CONV"):
