@@ -30,6 +30,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include "dsmil_hip.h"
 #include "prof.h"
 
@@ -351,47 +352,51 @@ __global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
         wsrc[i] = e < WIT ? (pl * a.Cout + n0 + r) * S6K + h * 8 : -1;      // bf16 elements inside a (tap, chunk) slab
         wdst[i] = r * S6LD + pl * 8 + h * 4;                                // dwords
     }
-    f32x4 xreg[XPT], mu[XPT], rs[XPT];
-    u32x4_t wreg[WPT];
-    unsigned okmask = 0;
+    // Two register sets: the global loads of step st+2 are issued while step st computes (the 24 bf16 MFMAs of a step
+    // are ~770 cycles per wave — shorter than an L2 / HBM round trip, so one step of distance leaves the wave waiting
+    // for its loads at every stage_write: measured 305 us for the layer-2 strided conv against 71 us of MFMA time).
+    struct Regs {
+        f32x4 x[XPT], mu[XPT], rs[XPT];
+        u32x4_t w[WPT];
+        unsigned okmask;
+    };
+    Regs ra, rb;
     // tap-major inside a channel chunk: the producer's statistics are read once per chunk
-    auto stage_load = [&](int st) {
+    auto stage_load = [&](int st, Regs& R) {
         const int cc = st / taps, tap = st - cc * taps;
         const int kh = tap / a.ks, kw = tap - kh * a.ks;
         const int c0 = cc * S6K + c4 * 4;
         if constexpr (NORM) {
-            if (tap == 0) {
 #pragma unroll
-                for (int i = 0; i < XPT; ++i) {
-                    mu[i] = *reinterpret_cast<const f32x4*>(a.in_mean + (long long)nimg[i] * a.Cin + c0);
-                    rs[i] = *reinterpret_cast<const f32x4*>(a.in_rstd + (long long)nimg[i] * a.Cin + c0);
-                }
+            for (int i = 0; i < XPT; ++i) {   // L1/L2-resident [B, Cin] arrays; re-read per step keeps the sets independent
+                R.mu[i] = *reinterpret_cast<const f32x4*>(a.in_mean + (long long)nimg[i] * a.Cin + c0);
+                R.rs[i] = *reinterpret_cast<const f32x4*>(a.in_rstd + (long long)nimg[i] * a.Cin + c0);
             }
         }
-        okmask = 0;
+        R.okmask = 0;
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
             const int iy = iy0[i] + kh, ix = ix0[i] + kw;
             const bool ok = (iy >= 0) && (iy < a.H) && (ix >= 0) && (ix < a.W);
-            okmask |= ok ? (1u << i) : 0u;
+            R.okmask |= ok ? (1u << i) : 0u;
             const int iyc = min(max(iy, 0), a.H - 1), ixc = min(max(ix, 0), a.W - 1);
-            xreg[i] = *reinterpret_cast<const f32x4*>(a.x + (long long)(nb[i] + iyc * a.W + ixc) * a.Cin + c0);
+            R.x[i] = *reinterpret_cast<const f32x4*>(a.x + (long long)(nb[i] + iyc * a.W + ixc) * a.Cin + c0);
         }
         const unsigned short* slab = wpk + ((long long)tap * nchunks + cc) * 3 * a.Cout * S6K;
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
-            wreg[i] = *reinterpret_cast<const u32x4_t*>(slab + (wsrc[i] < 0 ? 0 : wsrc[i]));
+            R.w[i] = *reinterpret_cast<const u32x4_t*>(slab + (wsrc[i] < 0 ? 0 : wsrc[i]));
     };
-    auto stage_write = [&](int st) {
+    auto stage_write = [&](int st, const Regs& R) {
         unsigned* x = sX + (st & 1) * X_TILE;
         unsigned* w = sW + (st & 1) * W_TILE;
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
-            f32x4 v = xreg[i];
-            const bool ok = (okmask >> i) & 1u;
+            f32x4 v = R.x[i];
+            const bool ok = (R.okmask >> i) & 1u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if constexpr (NORM) v[e] = fmaxf((v[e] - mu[i][e]) * rs[i][e], 0.f);
+                if constexpr (NORM) v[e] = fmaxf((v[e] - R.mu[i][e]) * R.rs[i][e], 0.f);
                 v[e] = ok ? v[e] : 0.f;
             }
             u32x2_t ph, pm, pl;
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
-            if (wsrc[i] >= 0) *reinterpret_cast<u32x4_t*>(w + wdst[i]) = wreg[i];
+            if (wsrc[i] >= 0) *reinterpret_cast<u32x4_t*>(w + wdst[i]) = R.w[i];
     };
 
     f32x16 acc[NT];
@@ -412,12 +417,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    stage_load(0);
-    stage_write(0);
-    __syncthreads();
     const int frag = l31 * S6LD + 4 * hi;   // dwords: this lane's row, k-half
-    for (int st = 0; st < nsteps; ++st) {
-        if (st + 1 < nsteps) stage_load(st + 1);
+    auto mfmas = [&](int st) {
         const unsigned* x = sX + (st & 1) * X_TILE + wm * 32 * S6LD + frag;
         const unsigned* w = sW + (st & 1) * W_TILE + wn * NT * 32 * S6LD + frag;
         Frag16 xa[3];
@@ -436,8 +437,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0].v, wb[1].v, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0].v, wb[0].v, acc[t], 0, 0, 0);
         }
-        if (st + 1 < nsteps) stage_write(st + 1);   // the other buffer: its readers passed the previous barrier
+    };
+    // step st: [issue loads of st+2 -> the set st's data just left] [MFMAs on LDS buffer st&1] [set of st+1 -> buffer (st+1)&1]
+    stage_load(0, ra);
+    stage_write(0, ra);
+    if (nsteps > 1) stage_load(1, rb);
+    __syncthreads();
+    for (int st = 0; st < nsteps; st += 2) {
+        if (st + 2 < nsteps) stage_load(st + 2, ra);
+        mfmas(st);
+        if (st + 1 < nsteps) stage_write(st + 1, rb);   // the other buffer: its readers passed the previous barrier
         __syncthreads();
+        if (st + 1 < nsteps) {
+            if (st + 3 < nsteps) stage_load(st + 3, rb);
+            mfmas(st + 1);
+            if (st + 2 < nsteps) stage_write(st + 2, ra);
+            __syncthreads();
+        }
     }
     conv_epilogue<NT>(a, acc, m0 + wm * 32, n0 + wn * NT * 32, HW, l31, hi);
 }
@@ -1072,6 +1088,233 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
     wino_epilogue(a, acc, smem, lane, wn, wp, n0, img0, ty0, tx0, tpi, pb);
 }
 
+// --------------------------------------------------------------------------------------------
+// k_conv_wino_pc — the same Winograd unit with the work split by ROLE inside one 512-thread workgroup:
+//   waves 0-3  consumers: the MFMAs of chunk cc (8 positions x NP plane products each, V fragments from LDS, weight
+//              fragments straight from L2 four positions ahead and carried across chunks — they own no staging
+//              registers, so the deeper prefetch fits) and the epilogue;
+//   waves 4-7  producers: raw(cc+1) registers -> IN + ReLU + padding -> LDS, global loads of raw(cc+2), transform of
+//              chunk cc+1 into the OTHER V buffer — all of it while the consumers multiply.
+// In k_conv_wino_s3 every wave does both jobs in turn and the two phases do not overlap (ablations: the phase times
+// ADD; two lockstepped workgroups per CU hide nothing of a latency-bound staging phase).  Here V is double buffered
+// (2 x 56 KB + 20 KB raw + 4 KB statistics = 136 KB, one workgroup per CU, still two waves per SIMD: one of each
+// role), two workgroup barriers per chunk (raw written | V written), the same count on both paths.
+// --------------------------------------------------------------------------------------------
+template <bool NORM, int NP>
+__global__ __launch_bounds__(512, 2) void k_conv_wino_pc(WinoArgs a) {
+    constexpr int UD = 4;                               // weight prefetch distance in positions
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned* sV = reinterpret_cast<unsigned*>(smem);   // [2][16][WTT][SVLD] dwords
+    float* sR = smem + 2 * SV_DW;                       // [WRAW_MAX][SRLD]
+    float* sS = sR + WRAW_MAX * SRLD;                   // [2 buffers][16 images][2 (mean, rstd)][16 ch]
+    const int tid = threadIdx.x & 255, lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool producer = wave8 >= 4;
+    const int wave = wave8 & 3;
+    const int wn = wave & 1, wp = wave >> 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int n0 = blockIdx.y * 64;
+    const int nchunks = a.C / SK;
+    int bid = blockIdx.x;
+    const int bx = bid % a.nbx; bid /= a.nbx;
+    const int by = bid % a.nby; bid /= a.nby;
+    const int img0 = bid * a.IB;
+    const int ty0 = by * a.TYB, tx0 = bx * a.TXB;
+    const int pb = by * a.nbx + bx;
+    const int RH = 2 * a.TYB + 2, RW = 2 * a.TXB + 2, RP = RH * RW;
+    const int tpi = a.TYB * a.TXB;
+    const int iy_org = 2 * ty0 - 1, ix_org = 2 * tx0 - 1;
+
+    // ================= producer state (threads 256..511, indexed by tid = 0..255 like k_conv_wino_s3) ==========
+    int roff[SRPT], rlds[SRPT], rsto[SRPT];
+    f32x4 rreg[SRPT];
+    f32x4 sreg = {0.f, 0.f, 0.f, 0.f};
+    const int g = tid & 3, ts = (tid >> 2) & 31;
+    const int h = wave >> 1;   // wave-uniform column half of the transform role
+    int praw = 0;
+    if (producer) {
+#pragma unroll
+        for (int q = 0; q < SRPT; ++q) {
+            const int e = tid + 256 * q, px = e >> 2, gg = e & 3;
+            roff[q] = -2; rlds[q] = 0; rsto[q] = gg * 4;
+            if (px < a.IB * RP) {
+                const int il = px / RP, rem = px - il * RP, ry = rem / RW, rx = rem - ry * RW;
+                const int n = img0 + il, iy = iy_org + ry, ix = ix_org + rx;
+                roff[q] = -1;
+                if (n < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                    roff[q] = ((n * a.H + iy) * a.W + ix) * a.C + gg * 4;
+                    rsto[q] = il * 32 + gg * 4;
+                }
+                rlds[q] = px * SRLD + gg * 4;
+            }
+        }
+        const int sil = ts / tpi, srem = ts - sil * tpi, styl = srem / a.TXB, stxl = srem - styl * a.TXB;
+        praw = (ts < a.IB * tpi) ? ((sil * RH + 2 * styl) * RW + 2 * stxl + h) * SRLD + g * 4 : g * 4;
+    }
+    auto raw_load = [&](int cc) {
+#pragma unroll
+        for (int q = 0; q < SRPT; ++q) {
+            const int off = roff[q] < 0 ? 0 : roff[q];
+            rreg[q] = *reinterpret_cast<const f32x4*>(a.x + (long long)off + cc * SK);
+        }
+    };
+    auto stat_load = [&](int cc) {
+        if constexpr (NORM) {
+            if (tid < 128) {
+                const int il = tid >> 3, which = (tid >> 2) & 1, c4 = tid & 3;
+                const int n = img0 + il < a.B ? img0 + il : a.B - 1;
+                sreg = *reinterpret_cast<const f32x4*>((which ? a.in_rstd : a.in_mean) + (long long)n * a.C + cc * SK + c4 * 4);
+            }
+        }
+    };
+    auto stat_write = [&](int cc) {
+        if constexpr (NORM) {
+            if (tid < 128) {
+                const int il = tid >> 3, which = (tid >> 2) & 1, c4 = tid & 3;
+                *reinterpret_cast<f32x4*>(sS + (cc & 1) * 512 + il * 32 + which * 16 + c4 * 4) = sreg;
+            }
+        }
+    };
+    auto raw_write = [&](int cc) {   // producer's IN + ReLU and the zero padding applied once per staged pixel
+#pragma unroll
+        for (int q = 0; q < SRPT; ++q) {
+            if (roff[q] == -2) continue;
+            f32x4 x = rreg[q];
+            const bool ok = roff[q] >= 0;
+            if constexpr (NORM) {
+                const f32x4 mu = *reinterpret_cast<const f32x4*>(sS + (cc & 1) * 512 + rsto[q]);
+                const f32x4 rs = *reinterpret_cast<const f32x4*>(sS + (cc & 1) * 512 + rsto[q] + 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = fmaxf((x[e] - mu[e]) * rs[e], 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = ok ? x[e] : 0.f;
+            *reinterpret_cast<f32x4*>(sR + rlds[q]) = x;
+        }
+    };
+    auto transform = [&](int cc) {   // raw -> V[cc & 1] planes (see k_conv_wino_s3)
+        const float* r = sR + praw;
+        unsigned* vdst = sV + (cc & 1) * SV_DW;
+        f32x4 T[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f32x4 R0 = *reinterpret_cast<const f32x4*>(r + (0 * RW + c) * SRLD);
+            const f32x4 R1 = *reinterpret_cast<const f32x4*>(r + (1 * RW + c) * SRLD);
+            const f32x4 R2 = *reinterpret_cast<const f32x4*>(r + (2 * RW + c) * SRLD);
+            const f32x4 R3 = *reinterpret_cast<const f32x4*>(r + (3 * RW + c) * SRLD);
+            T[0][c] = R0 - R2; T[1][c] = R1 + R2; T[2][c] = R2 - R1; T[3][c] = R1 - R3;
+        }
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            f32x4 o0, o1;
+            if (h == 0) { o0 = T[xi][0] - T[xi][2]; o1 = T[xi][1] + T[xi][2]; }
+            else { o0 = T[xi][1] - T[xi][0]; o1 = T[xi][0] - T[xi][2]; }
+            const int pos = xi * 4 + 2 * h;
+            u32x2_t ph, pm, pl;
+            unsigned* d0 = vdst + (pos * WTT + ts) * SVLD + g * 2;
+            cut4(o0, ph, pm, pl);
+            *reinterpret_cast<u32x2_t*>(d0) = ph;
+            *reinterpret_cast<u32x2_t*>(d0 + 8) = pm;
+            *reinterpret_cast<u32x2_t*>(d0 + 16) = pl;
+            unsigned* d1 = d0 + WTT * SVLD;
+            cut4(o1, ph, pm, pl);
+            *reinterpret_cast<u32x2_t*>(d1) = ph;
+            *reinterpret_cast<u32x2_t*>(d1 + 8) = pm;
+            *reinterpret_cast<u32x2_t*>(d1 + 16) = pl;
+        }
+    };
+
+    // ================= consumer state =====================================================================
+    const unsigned short* ub16 = reinterpret_cast<const unsigned short*>(a.u);
+    const long long uplane = (long long)a.Cout * SK;
+    const long long uchunk = 3 * uplane;
+    const long long upos = (long long)nchunks * uchunk;
+    const unsigned short* ubase = ub16 + (long long)(8 * wp) * upos + (long long)(n0 + wn * 32) * SK;
+    const int ulane = l31 * SK + 8 * hi;
+    auto uload = [&](int p, int cc, u32x4_t (&w)[3]) {
+        const unsigned short* q = ubase + p * upos + cc * uchunk + ulane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const u32x4_t*>(q + pl * uplane);
+    };
+    f32x16 acc[8];
+    u32x4_t w[UD][3];
+    const int vfo = ((8 * wp) * WTT + l31) * SVLD + 4 * hi;   // dwords
+    union Frag { u32x4_t u; bf16x8_t v; };
+    // positions [p0, p0+4) of chunk cc; fragment ring slot of position p of ANY chunk is p % UD (8 % UD == 0)
+    auto mfma_half = [&](int cc, auto p0c) {
+        constexpr int p0 = decltype(p0c)::value;
+        const unsigned* vsrc = sV + (cc & 1) * SV_DW + vfo;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            const int p = p0 + pp;
+            Frag va[3], wb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                va[pl].u = *reinterpret_cast<const u32x4_t*>(vsrc + p * WTT * SVLD + pl * 8);
+                wb[pl].u = w[p % UD][pl];
+            }
+            if constexpr (NP == 9) {
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[2].v, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[2].v, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[1].v, acc[p], 0, 0, 0);
+            }
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[0].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[2].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[1].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[0].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[1].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[0].v, acc[p], 0, 0, 0);
+            // the slot this position used is free: request the fragments UD positions on (next chunk past position 7)
+            const int pn = p + UD;
+            if (pn < 8) uload(pn, cc, w[pn % UD]);
+            else if (cc + 1 < nchunks) uload(pn - 8, cc + 1, w[pn % UD]);
+        }
+    };
+
+    // The two roles run as two SEPARATE straight-line programs (no control-flow joins between them, so the register
+    // allocator sees max(), not the sum, of their live ranges); each executes the same barrier sequence:
+    //   P0 statistics(0) | P1 raw(0) in LDS | P2 V[0] ready | per chunk: X raw(cc+1) in LDS, Y V[(cc+1)&1] ready | E epilogue
+    if (producer) {
+        raw_load(0);
+        stat_load(0);
+        stat_write(0);
+        __syncthreads();                    // P0
+        raw_write(0);
+        if (nchunks > 1) { raw_load(1); stat_load(1); }
+        __syncthreads();                    // P1
+        transform(0);
+        if (nchunks > 1) stat_write(1);
+        __syncthreads();                    // P2
+        for (int cc = 0; cc < nchunks; ++cc) {
+            const bool more = cc + 1 < nchunks, more2 = cc + 2 < nchunks;   // block-uniform
+            if (more) raw_write(cc + 1);             // raw LDS was consumed by transform(cc) before the last barrier
+            if (more2) { raw_load(cc + 2); stat_load(cc + 2); }
+            __syncthreads();                // X
+            if (more) transform(cc + 1);             // V[(cc+1)&1] was last read in iteration cc-1
+            if (more2) stat_write(cc + 2);
+            __syncthreads();                // Y
+        }
+        __syncthreads();                    // E (the consumers' exchange barrier inside wino_epilogue)
+        return;
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+#pragma unroll
+    for (int p = 0; p < UD; ++p) uload(p, 0, w[p]);
+    __syncthreads();                        // P0
+    __syncthreads();                        // P1
+    __syncthreads();                        // P2
+    for (int cc = 0; cc < nchunks; ++cc) {
+        mfma_half(cc, std::integral_constant<int, 0>{});
+        __syncthreads();                    // X
+        mfma_half(cc, std::integral_constant<int, 4>{});
+        __syncthreads();                    // Y
+    }
+    wino_epilogue(a, acc, smem, lane, wn, wp, n0, img0, ty0, tx0, tpi, pb);
+}
+
 // conv weight [O][I][3][3] -> U = G g G^T cut into three bf16 planes: [16 pos][I/16][3][O][16]
 __global__ void k_pack_wino_s3(const float* __restrict__ w, unsigned short* __restrict__ out, int O, int I) {
     const long long total = (long long)O * I;
@@ -1686,6 +1929,20 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
                 (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
                 hipLaunchKernelGGL(kern, grid, dim3(256), l, st, wa);
             };
+            // producer / consumer form: 512 threads, V double buffered
+            const size_t lds_pc = (size_t)(2 * SV_DW + WRAW_MAX * SRLD + 1024) * sizeof(float);
+            auto go_pc = [&](auto kern) {
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pc);
+                hipLaunchKernelGGL(kern, grid, dim3(512), lds_pc, st, wa);
+            };
+            bool use_pc = true;
+#ifdef DSMIL_EXPERIMENTS
+            if (wa.expt & 512) use_pc = false;
+#endif
+            if (use_pc) {
+                if (in_mean) { if (np9) go_pc(k_conv_wino_pc<true, 9>); else go_pc(k_conv_wino_pc<true, 6>); }
+                else { if (np9) go_pc(k_conv_wino_pc<false, 9>); else go_pc(k_conv_wino_pc<false, 6>); }
+            } else
 #ifdef DSMIL_EXPERIMENTS
             // UC costs 28-54 spilled VGPRs (the fragments stay live across the transform's temporaries): measured, not shipped
             if (variant & 1) {
