@@ -570,7 +570,6 @@ struct WinoArgs {
     int IB, TYB, TXB;      // unit shape: images x tile rows x tile cols (IB*TYB*TXB <= 32)
     int nby, nbx, PB;      // units per image along y / x, PB = nby*nbx
     int expt;              // DSMIL_WINO_EXPT ablation knob (0 in production)
-    int skew;              // start-up delay (x64 cycles) of the second workgroup of a CU, see k_conv_wino_s3
 };
 
 // Epilogue shared by the Winograd kernels: inverse transform of this wave's 8 positions, exchange of
@@ -842,9 +841,8 @@ constexpr int SRPT = (WRAW_MAX * 4 + 255) / 256;     // raw float4 per thread pe
 // (mean, rstd) of the next chunk are staged through LDS by a few threads instead of being loaded by every staging
 // thread right before use.
 // NP: plane products per fp32 product (9 = every product formed exactly; 6 = the three smallest, together < 2^-20 of
-// |u*v|, left out — see agg_split.h).  UC: the weight fragments of the first UD positions of the NEXT chunk are
-// requested right behind this chunk's last MFMAs, so they fly across the staging / transform phase.
-template <bool NORM, int UD = 1, bool LS = false, int NP = 9, bool UC = false>
+// |u*v|, left out — see agg_split.h).
+template <bool NORM, int UD = 1, bool LS = false, int NP = 9>
 __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned* sV = reinterpret_cast<unsigned*>(smem);   // [16][WTT][SVLD] dwords
@@ -866,24 +864,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
     const int tpi = a.TYB * a.TXB;
     const int iy_org = 2 * ty0 - 1, ix_org = 2 * tx0 - 1;
 
-#ifdef DSMIL_EXPERIMENTS
-    // start-up skew: the two workgroups of a CU otherwise run their MFMA and their staging/transform phases in
-    // lockstep (same work, same start) and contend for the same pipe at the same time; delaying the one in the
-    // odd wave slot by about half a chunk period makes the phases complementary.  Unit durations are equal, so
-    // the offset persists through later workgroups of the same slot.
-    if (a.skew > 0 && (int)(blockIdx.x + blockIdx.y * gridDim.x) < 512) {
-        if (tid == 0) {
-            unsigned hwid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            sV[0] = hwid & 1u;
-        }
-        __syncthreads();
-        const unsigned odd = sV[0];
-        __syncthreads();
-        if (odd)
-            for (int i = 0; i < a.skew; i += 64) __builtin_amdgcn_s_sleep(64);
-    }
-#endif
     // ---- raw staging role: element e = tid + 256 q -> (pixel e>>2, channel group e&3)
     int roff[SRPT], rlds[SRPT], rsto[SRPT];
 #pragma unroll
@@ -1028,10 +1008,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
     for (int cc = 0; cc < nchunks; ++cc) {
         const bool more = cc + 1 < nchunks, more2 = cc + 2 < nchunks;   // block-uniform
         // ---- 8 positions x NP plane products
-        if (!UC || cc == 0) {
-            uload(0, cc, w[0]);
-            if constexpr (UD == 2) uload(1, cc, w[1]);
-        }
+        uload(0, cc, w[0]);
+        if constexpr (UD == 2) uload(1, cc, w[1]);
         if (more2) stat_load(cc + 2);
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -1059,12 +1037,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[1].v, acc[p], 0, 0, 0);
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[0].v, acc[p], 0, 0, 0);
         }
-        if constexpr (UC) {
-            if (more) {   // slots 0 / 1 were last read by the MFMAs of positions 6 / 7 (UD = 2), already issued
-                uload(0, cc + 1, w[0]);
-                if constexpr (UD == 2) uload(1, cc + 1, w[1]);
-            }
-        }
         // ---- raw(cc+1): registers -> LDS (the raw buffer was consumed before the last barrier), then the
         //      global loads of raw(cc+2)
         if (!DSMIL_WEXPT_ON(a, 2)) {
@@ -1084,233 +1056,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
             for (int r = 0; r < 16; ++r) keep += acc[p][r];
         if (keep == 123.456f) a.y[0] = keep;
         return;
-    }
-    wino_epilogue(a, acc, smem, lane, wn, wp, n0, img0, ty0, tx0, tpi, pb);
-}
-
-// --------------------------------------------------------------------------------------------
-// k_conv_wino_pc — the same Winograd unit with the work split by ROLE inside one 512-thread workgroup:
-//   waves 0-3  consumers: the MFMAs of chunk cc (8 positions x NP plane products each, V fragments from LDS, weight
-//              fragments straight from L2 four positions ahead and carried across chunks — they own no staging
-//              registers, so the deeper prefetch fits) and the epilogue;
-//   waves 4-7  producers: raw(cc+1) registers -> IN + ReLU + padding -> LDS, global loads of raw(cc+2), transform of
-//              chunk cc+1 into the OTHER V buffer — all of it while the consumers multiply.
-// In k_conv_wino_s3 every wave does both jobs in turn and the two phases do not overlap (ablations: the phase times
-// ADD; two lockstepped workgroups per CU hide nothing of a latency-bound staging phase).  Here V is double buffered
-// (2 x 56 KB + 20 KB raw + 4 KB statistics = 136 KB, one workgroup per CU, still two waves per SIMD: one of each
-// role), two workgroup barriers per chunk (raw written | V written), the same count on both paths.
-// --------------------------------------------------------------------------------------------
-template <bool NORM, int NP>
-__global__ __launch_bounds__(512, 2) void k_conv_wino_pc(WinoArgs a) {
-    constexpr int UD = 4;                               // weight prefetch distance in positions
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned* sV = reinterpret_cast<unsigned*>(smem);   // [2][16][WTT][SVLD] dwords
-    float* sR = smem + 2 * SV_DW;                       // [WRAW_MAX][SRLD]
-    float* sS = sR + WRAW_MAX * SRLD;                   // [2 buffers][16 images][2 (mean, rstd)][16 ch]
-    const int tid = threadIdx.x & 255, lane = threadIdx.x & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const bool producer = wave8 >= 4;
-    const int wave = wave8 & 3;
-    const int wn = wave & 1, wp = wave >> 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int n0 = blockIdx.y * 64;
-    const int nchunks = a.C / SK;
-    int bid = blockIdx.x;
-    const int bx = bid % a.nbx; bid /= a.nbx;
-    const int by = bid % a.nby; bid /= a.nby;
-    const int img0 = bid * a.IB;
-    const int ty0 = by * a.TYB, tx0 = bx * a.TXB;
-    const int pb = by * a.nbx + bx;
-    const int RH = 2 * a.TYB + 2, RW = 2 * a.TXB + 2, RP = RH * RW;
-    const int tpi = a.TYB * a.TXB;
-    const int iy_org = 2 * ty0 - 1, ix_org = 2 * tx0 - 1;
-
-    // ================= producer state (threads 256..511, indexed by tid = 0..255 like k_conv_wino_s3) ==========
-    int roff[SRPT], rlds[SRPT], rsto[SRPT];
-    f32x4 rreg[SRPT];
-    f32x4 sreg = {0.f, 0.f, 0.f, 0.f};
-    const int g = tid & 3, ts = (tid >> 2) & 31;
-    const int h = wave >> 1;   // wave-uniform column half of the transform role
-    int praw = 0;
-    if (producer) {
-#pragma unroll
-        for (int q = 0; q < SRPT; ++q) {
-            const int e = tid + 256 * q, px = e >> 2, gg = e & 3;
-            roff[q] = -2; rlds[q] = 0; rsto[q] = gg * 4;
-            if (px < a.IB * RP) {
-                const int il = px / RP, rem = px - il * RP, ry = rem / RW, rx = rem - ry * RW;
-                const int n = img0 + il, iy = iy_org + ry, ix = ix_org + rx;
-                roff[q] = -1;
-                if (n < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-                    roff[q] = ((n * a.H + iy) * a.W + ix) * a.C + gg * 4;
-                    rsto[q] = il * 32 + gg * 4;
-                }
-                rlds[q] = px * SRLD + gg * 4;
-            }
-        }
-        const int sil = ts / tpi, srem = ts - sil * tpi, styl = srem / a.TXB, stxl = srem - styl * a.TXB;
-        praw = (ts < a.IB * tpi) ? ((sil * RH + 2 * styl) * RW + 2 * stxl + h) * SRLD + g * 4 : g * 4;
-    }
-    auto raw_load = [&](int cc) {
-#pragma unroll
-        for (int q = 0; q < SRPT; ++q) {
-            const int off = roff[q] < 0 ? 0 : roff[q];
-            rreg[q] = *reinterpret_cast<const f32x4*>(a.x + (long long)off + cc * SK);
-        }
-    };
-    auto stat_load = [&](int cc) {
-        if constexpr (NORM) {
-            if (tid < 128) {
-                const int il = tid >> 3, which = (tid >> 2) & 1, c4 = tid & 3;
-                const int n = img0 + il < a.B ? img0 + il : a.B - 1;
-                sreg = *reinterpret_cast<const f32x4*>((which ? a.in_rstd : a.in_mean) + (long long)n * a.C + cc * SK + c4 * 4);
-            }
-        }
-    };
-    auto stat_write = [&](int cc) {
-        if constexpr (NORM) {
-            if (tid < 128) {
-                const int il = tid >> 3, which = (tid >> 2) & 1, c4 = tid & 3;
-                *reinterpret_cast<f32x4*>(sS + (cc & 1) * 512 + il * 32 + which * 16 + c4 * 4) = sreg;
-            }
-        }
-    };
-    auto raw_write = [&](int cc) {   // producer's IN + ReLU and the zero padding applied once per staged pixel
-#pragma unroll
-        for (int q = 0; q < SRPT; ++q) {
-            if (roff[q] == -2) continue;
-            f32x4 x = rreg[q];
-            const bool ok = roff[q] >= 0;
-            if constexpr (NORM) {
-                const f32x4 mu = *reinterpret_cast<const f32x4*>(sS + (cc & 1) * 512 + rsto[q]);
-                const f32x4 rs = *reinterpret_cast<const f32x4*>(sS + (cc & 1) * 512 + rsto[q] + 16);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = fmaxf((x[e] - mu[e]) * rs[e], 0.f);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = ok ? x[e] : 0.f;
-            *reinterpret_cast<f32x4*>(sR + rlds[q]) = x;
-        }
-    };
-    auto transform = [&](int cc) {   // raw -> V[cc & 1] planes (see k_conv_wino_s3)
-        const float* r = sR + praw;
-        unsigned* vdst = sV + (cc & 1) * SV_DW;
-        f32x4 T[4][3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const f32x4 R0 = *reinterpret_cast<const f32x4*>(r + (0 * RW + c) * SRLD);
-            const f32x4 R1 = *reinterpret_cast<const f32x4*>(r + (1 * RW + c) * SRLD);
-            const f32x4 R2 = *reinterpret_cast<const f32x4*>(r + (2 * RW + c) * SRLD);
-            const f32x4 R3 = *reinterpret_cast<const f32x4*>(r + (3 * RW + c) * SRLD);
-            T[0][c] = R0 - R2; T[1][c] = R1 + R2; T[2][c] = R2 - R1; T[3][c] = R1 - R3;
-        }
-#pragma unroll
-        for (int xi = 0; xi < 4; ++xi) {
-            f32x4 o0, o1;
-            if (h == 0) { o0 = T[xi][0] - T[xi][2]; o1 = T[xi][1] + T[xi][2]; }
-            else { o0 = T[xi][1] - T[xi][0]; o1 = T[xi][0] - T[xi][2]; }
-            const int pos = xi * 4 + 2 * h;
-            u32x2_t ph, pm, pl;
-            unsigned* d0 = vdst + (pos * WTT + ts) * SVLD + g * 2;
-            cut4(o0, ph, pm, pl);
-            *reinterpret_cast<u32x2_t*>(d0) = ph;
-            *reinterpret_cast<u32x2_t*>(d0 + 8) = pm;
-            *reinterpret_cast<u32x2_t*>(d0 + 16) = pl;
-            unsigned* d1 = d0 + WTT * SVLD;
-            cut4(o1, ph, pm, pl);
-            *reinterpret_cast<u32x2_t*>(d1) = ph;
-            *reinterpret_cast<u32x2_t*>(d1 + 8) = pm;
-            *reinterpret_cast<u32x2_t*>(d1 + 16) = pl;
-        }
-    };
-
-    // ================= consumer state =====================================================================
-    const unsigned short* ub16 = reinterpret_cast<const unsigned short*>(a.u);
-    const long long uplane = (long long)a.Cout * SK;
-    const long long uchunk = 3 * uplane;
-    const long long upos = (long long)nchunks * uchunk;
-    const unsigned short* ubase = ub16 + (long long)(8 * wp) * upos + (long long)(n0 + wn * 32) * SK;
-    const int ulane = l31 * SK + 8 * hi;
-    auto uload = [&](int p, int cc, u32x4_t (&w)[3]) {
-        const unsigned short* q = ubase + p * upos + cc * uchunk + ulane;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const u32x4_t*>(q + pl * uplane);
-    };
-    f32x16 acc[8];
-    u32x4_t w[UD][3];
-    const int vfo = ((8 * wp) * WTT + l31) * SVLD + 4 * hi;   // dwords
-    union Frag { u32x4_t u; bf16x8_t v; };
-    // positions [p0, p0+4) of chunk cc; fragment ring slot of position p of ANY chunk is p % UD (8 % UD == 0)
-    auto mfma_half = [&](int cc, auto p0c) {
-        constexpr int p0 = decltype(p0c)::value;
-        const unsigned* vsrc = sV + (cc & 1) * SV_DW + vfo;
-#pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
-            const int p = p0 + pp;
-            Frag va[3], wb[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                va[pl].u = *reinterpret_cast<const u32x4_t*>(vsrc + p * WTT * SVLD + pl * 8);
-                wb[pl].u = w[p % UD][pl];
-            }
-            if constexpr (NP == 9) {
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[2].v, acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[2].v, acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[1].v, acc[p], 0, 0, 0);
-            }
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[0].v, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[2].v, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[1].v, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[0].v, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[1].v, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[0].v, acc[p], 0, 0, 0);
-            // the slot this position used is free: request the fragments UD positions on (next chunk past position 7)
-            const int pn = p + UD;
-            if (pn < 8) uload(pn, cc, w[pn % UD]);
-            else if (cc + 1 < nchunks) uload(pn - 8, cc + 1, w[pn % UD]);
-        }
-    };
-
-    // The two roles run as two SEPARATE straight-line programs (no control-flow joins between them, so the register
-    // allocator sees max(), not the sum, of their live ranges); each executes the same barrier sequence:
-    //   P0 statistics(0) | P1 raw(0) in LDS | P2 V[0] ready | per chunk: X raw(cc+1) in LDS, Y V[(cc+1)&1] ready | E epilogue
-    if (producer) {
-        raw_load(0);
-        stat_load(0);
-        stat_write(0);
-        __syncthreads();                    // P0
-        raw_write(0);
-        if (nchunks > 1) { raw_load(1); stat_load(1); }
-        __syncthreads();                    // P1
-        transform(0);
-        if (nchunks > 1) stat_write(1);
-        __syncthreads();                    // P2
-        for (int cc = 0; cc < nchunks; ++cc) {
-            const bool more = cc + 1 < nchunks, more2 = cc + 2 < nchunks;   // block-uniform
-            if (more) raw_write(cc + 1);             // raw LDS was consumed by transform(cc) before the last barrier
-            if (more2) { raw_load(cc + 2); stat_load(cc + 2); }
-            __syncthreads();                // X
-            if (more) transform(cc + 1);             // V[(cc+1)&1] was last read in iteration cc-1
-            if (more2) stat_write(cc + 2);
-            __syncthreads();                // Y
-        }
-        __syncthreads();                    // E (the consumers' exchange barrier inside wino_epilogue)
-        return;
-    }
-#pragma unroll
-    for (int p = 0; p < 8; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-#pragma unroll
-    for (int p = 0; p < UD; ++p) uload(p, 0, w[p]);
-    __syncthreads();                        // P0
-    __syncthreads();                        // P1
-    __syncthreads();                        // P2
-    for (int cc = 0; cc < nchunks; ++cc) {
-        mfma_half(cc, std::integral_constant<int, 0>{});
-        __syncthreads();                    // X
-        mfma_half(cc, std::integral_constant<int, 4>{});
-        __syncthreads();                    // Y
     }
     wino_epilogue(a, acc, smem, lane, wn, wp, n0, img0, ty0, tx0, tpi, pb);
 }
@@ -1753,6 +1498,16 @@ const Arch* arch_of(int depth) {
 }
 
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize once per kernel (keyed by its address), not once per launch
+inline void allow_lds(const void* kern, size_t bytes) {
+    static const void* seen[64];
+    static int n = 0;
+    for (int i = 0; i < n; ++i)
+        if (seen[i] == kern) return;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (n < 64) seen[n++] = kern;
+}
 inline bool use_wino(const ConvSpec& s) {  // 3x3 stride-1 convs run as Winograd F(2x2,3x3)
 #ifdef DSMIL_EXPERIMENTS
     static const int off = expt_env("DSMIL_NO_WINO");
@@ -1904,12 +1659,9 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
         wino_shape(B, wa.TY, wa.TX, wa.IB, wa.TYB, wa.TXB);
 #ifdef DSMIL_EXPERIMENTS
         static const int wexpt = expt_env("DSMIL_WINO_EXPT");
-        static const int wskew = expt_env("DSMIL_WINO_SKEW");
         wa.expt = wexpt;
-        wa.skew = wskew;
 #else
         wa.expt = 0;
-        wa.skew = 0;
 #endif
         wa.nby = (wa.TY + wa.TYB - 1) / wa.TYB; wa.nbx = (wa.TX + wa.TXB - 1) / wa.TXB; wa.PB = wa.nby * wa.nbx;
         const size_t lds = wino_s3() ? (size_t)(SV_DW + WRAW_MAX * SRLD) * sizeof(float)
@@ -1920,42 +1672,17 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
             // product configuration: weights two positions ahead (UD = 2), producer statistics staged through LDS (LS,
             // +4 KiB: 80 KiB per workgroup, still two per CU), NP = 6 | 9 by DSMIL_WINO
             const size_t lds_ls = lds + 4096;
-            int variant = 0;   // bit 0: UC (carry the weight prefetch across the barrier phase)
-#ifdef DSMIL_EXPERIMENTS
-            variant = (wa.expt >> 8) & 1;
-#endif
             const bool np9 = wino_form() == 9;
             auto go = [&](auto kern, size_t l) {
-                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
+                allow_lds((const void*)kern, l);
                 hipLaunchKernelGGL(kern, grid, dim3(256), l, st, wa);
             };
-            // producer / consumer form: 512 threads, V double buffered
-            const size_t lds_pc = (size_t)(2 * SV_DW + WRAW_MAX * SRLD + 1024) * sizeof(float);
-            auto go_pc = [&](auto kern) {
-                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pc);
-                hipLaunchKernelGGL(kern, grid, dim3(512), lds_pc, st, wa);
-            };
-            bool use_pc = true;
-#ifdef DSMIL_EXPERIMENTS
-            if (wa.expt & 512) use_pc = false;
-#endif
-            if (use_pc) {
-                if (in_mean) { if (np9) go_pc(k_conv_wino_pc<true, 9>); else go_pc(k_conv_wino_pc<true, 6>); }
-                else { if (np9) go_pc(k_conv_wino_pc<false, 9>); else go_pc(k_conv_wino_pc<false, 6>); }
-            } else
-#ifdef DSMIL_EXPERIMENTS
-            // UC costs 28-54 spilled VGPRs (the fragments stay live across the transform's temporaries): measured, not shipped
-            if (variant & 1) {
-                if (in_mean) go(k_conv_wino_s3<true, 2, true, 6, true>, lds_ls);
-                else go(k_conv_wino_s3<false, 2, false, 6, true>, lds);
-            } else
-#endif
             if (in_mean) {
-                if (np9) go(k_conv_wino_s3<true, 2, true, 9, false>, lds_ls);
-                else go(k_conv_wino_s3<true, 2, true, 6, false>, lds_ls);
+                if (np9) go(k_conv_wino_s3<true, 2, true, 9>, lds_ls);
+                else go(k_conv_wino_s3<true, 2, true, 6>, lds_ls);
             } else {
-                if (np9) go(k_conv_wino_s3<false, 2, false, 9, false>, lds);
-                else go(k_conv_wino_s3<false, 2, false, 6, false>, lds);
+                if (np9) go(k_conv_wino_s3<false, 2, false, 9>, lds);
+                else go(k_conv_wino_s3<false, 2, false, 6>, lds);
             }
         }
         else if (in_mean) hipLaunchKernelGGL((k_conv_wino<true>), grid, dim3(256), lds, st, wa);
@@ -1980,7 +1707,7 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
     if (conv_s6()) {
         // 128-pixel tiles; 128 output channels per workgroup while that still yields two workgroups per CU, else 64
         auto go = [&](auto kern, int TN, size_t lds) {
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            allow_lds((const void*)kern, lds);
             dim3 grid((unsigned)((a.Mtot + 127) / 128), (unsigned)(s.cout / TN));
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
         };
