@@ -768,180 +768,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_query_attend_bf16_dma(AttendArgs
     attend_tail<NW, 4, bf16_t>(a, Q, smem, bag, off0, Nb, row0, slot);
 }
 
-// --------------------------------------------------------------------------------------------
-// k_query_attend_bf16_dma8 — the same pipeline for 256-row workgroups (8 waves, one workgroup per CU) with the DMA
-// issue split by ROLE, because s_waitcnt vmcnt is an in-order count per wave: a wave that waits for the weight chunk
-// it issued this step also waits for every feature piece it issued before it, so one wave cannot keep HBM-sourced
-// feature chunks in flight across the per-step weight hand-off.  Waves 0-3 issue ONLY feature pieces (the rows of
-// compute waves w and w+4, three chunks ahead, counted vmcnt leaves two chunks in flight), waves 4-7 ONLY weight pieces
-// (one step ahead, vmcnt(0)); the per-step workgroup barrier publishes both.  Every wave computes its own 32 rows.
-// LDS: weights 2 x 16 KiB + features 4 x 32 KiB = 160 KiB.  Weight traffic per row halves against the 128-row form.
-// --------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bd_wait_vm(int n) {   // n is wave-uniform
-    switch (n) {
-        case 0: S3_WAIT_VM(0); break;
-        case 8: S3_WAIT_VM(8); break;
-        case 16: S3_WAIT_VM(16); break;
-        default: S3_WAIT_VM(0); break;
-    }
-}
-
-__global__ __launch_bounds__(512, 2) void k_query_attend_bf16_dma8(AttendArgs a) {
-    constexpr int NW = 8, BM = 256, XR = 4;
-    constexpr int X_BUF_F4 = BM * 8;          // float4 per feature buffer (128 B per row)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x4* sW = reinterpret_cast<f32x4*>(smem);                 // [2][BD_WCHUNK_F4]
-    f32x4* sX = sW + 2 * BD_WCHUNK_F4;                          // [XR][X_BUF_F4]
-    const int bag = a.bag0 + blockIdx.y;
-    const long long off0 = a.offsets[bag];
-    const long long Nb = a.offsets[bag + 1] - off0;
-    const long long row0 = (long long)blockIdx.x * BM;
-    if (row0 >= Nb) return;
-    const long long slot = off0 / BM + bag + blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool xrole = wave < 4;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int K = a.K;
-    const int nk1 = (K + 63) / 64;
-    const int nst = nk1 + (a.nonlinear ? 2 : 0);
-    const bf16_t* feats = reinterpret_cast<const bf16_t*>(a.feats);
-    const f32x4* wpk = reinterpret_cast<const f32x4*>(a.wpk);
-
-    // feature-role waves: 8 pieces per chunk = the 32 rows of compute wave `wave` (pieces 0-3) and of `wave + 4` (4-7)
-    const bf16_t* xsrc[8];
-    int xslot[8];
-    if (xrole) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int cw = wave + 4 * (p >> 2), r = (p & 3) * 8 + (lane >> 3);
-            long long gr = row0 + cw * 32 + r;
-            if (gr >= Nb) gr = Nb - 1;                           // rows past the bag end are masked in attend_tail
-            xsrc[p] = feats + phys_row(a.rowmap, off0 + gr) * (long long)K;
-            xslot[p] = ((lane & 7) ^ ((r & 6) | ((r >> 4) & 1))) * 8;
-        }
-    }
-    auto issue_w = [&](int s) {   // weight-role waves 4..7: 4 of the chunk's 16 pieces each
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = i * 4 + (wave - 4);
-            __builtin_amdgcn_global_load_lds((const DSMIL_GLOBAL void*)(wpk + (long long)s * BD_WCHUNK_F4 + q * 64 + lane),
-                                             (__attribute__((address_space(3))) void*)(sW + (s & 1) * BD_WCHUNK_F4 + q * 64), 16, 0, 0);
-        }
-    };
-    auto issue_x = [&](int s) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int cw = wave + 4 * (p >> 2);
-            int k = s * 64 + xslot[p];
-            k = k + 8 <= K ? k : K - 8;                          // past K the packed weights are zero
-            __builtin_amdgcn_global_load_lds((const DSMIL_GLOBAL void*)(xsrc[p] + k),
-                                             (__attribute__((address_space(3))) void*)(sX + (s % XR) * X_BUF_F4 + (cw * 32 + (p & 3) * 8) * 8), 16, 0, 0);
-        }
-    };
-    const int fr = (l31 & 6) | ((l31 >> 4) & 1);
-
-    f32x16 H[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) H[t][r] = 0.f;
-
-    // prologue: W(0); X(0 .. XR-2)
-    if (xrole) {
-        int issued = 0;
-        for (int c = 0; c < XR - 1 && c < nk1; ++c) { issue_x(c); ++issued; }
-        bd_wait_vm(8 * (issued - 1));                            // X(0) landed
-    } else {
-        issue_w(0);
-        S3_WAIT_VM(0);
-    }
-    __builtin_amdgcn_s_barrier();
-    for (int s = 0; s < nk1; ++s) {
-        if (xrole) {
-            if (s + XR - 1 < nk1) issue_x(s + XR - 1);           // its buffer held chunk s-1: every wave is past that step
-        } else {
-            if (s + 1 < nst) issue_w(s + 1);
-        }
-        const f32x4* w = sW + (s & 1) * BD_WCHUNK_F4 + lane;
-        const f32x4* x = sX + (s % XR) * X_BUF_F4 + (wave * 32 + l31) * 8;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            union { f32x4 f; bf16x8 v; } xb, wa;
-            xb.f = x[(ks * 2 + hi) ^ fr];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                wa.f = w[(ks * 4 + t) * 64];
-                H[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa.v, xb.v, H[t], 0, 0, 0);
-            }
-        }
-        if (xrole) {
-            // chunks issued so far: 0 .. min(nk1-1, s+XR-1); X(s+1) must have landed, the younger ones may fly
-            const int last = (s + XR - 1 < nk1 - 1) ? s + XR - 1 : nk1 - 1;
-            const int inflight = last - (s + 1);
-            bd_wait_vm(inflight > 0 ? 8 * inflight : 0);
-        } else {
-            S3_WAIT_VM(0);
-        }
-        __builtin_amdgcn_s_barrier();
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(a.q0_b + 32 * t + 8 * g + 4 * hi);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = H[t][4 * g + e] + b[e];
-                H[t][4 * g + e] = a.nonlinear ? fmaxf(v, 0.f) : v;
-            }
-        }
-    f32x16 Q[4];
-    if (a.nonlinear) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Q[t][r] = 0.f;
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-            const int s = nk1 + c2;
-            if (!xrole && c2 == 0) issue_w(s + 1);
-            const f32x4* w = sW + (s & 1) * BD_WCHUNK_F4 + lane;
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int t = 2 * c2 + tt;
-#pragma unroll
-                for (int sidx = 0; sidx < 2; ++sidx) {
-                    union { unsigned u[4]; bf16x8 v; } hb;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        hb.u[e] = pack_bf16x2(H[t][8 * sidx + 2 * e], H[t][8 * sidx + 2 * e + 1]);
-#pragma unroll
-                    for (int t2 = 0; t2 < 4; ++t2) {
-                        union { f32x4 f; bf16x8 v; } wa;
-                        wa.f = w[((tt * 2 + sidx) * 4 + t2) * 64];
-                        Q[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa.v, hb.v, Q[t2], 0, 0, 0);
-                    }
-                }
-            }
-            S3_WAIT_VM(0);
-            __builtin_amdgcn_s_barrier();
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * t + 8 * g + 4 * hi);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = tanhf(Q[t][4 * g + e] + b[e]);
-            }
-    } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) Q[t] = H[t];
-    }
-    attend_tail<NW, 4, bf16_t>(a, Q, smem, bag, off0, Nb, row0, slot);
-}
-
 // W1 [128,K] fp32 -> bf16 [128,K64] zero padded; W2 [128,128] fp32 -> bf16 with the k permutation
 // described above.  RNE rounding (== torch .bfloat16()).
 // Behind that row-major image (read by the register-staged kernel) the same weights follow in the chunk-major
@@ -1234,23 +1060,6 @@ int launch_attend_bf16_dma(AttendArgs a, long long max_rows, int n_bags, hipStre
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
-int launch_attend_bf16_dma8(AttendArgs a, long long max_rows, int n_bags, hipStream_t st) {
-    constexpr int BM = 256;
-    const size_t lds = (size_t)(2 * BD_WCHUNK_F4 + 4 * BM * 8) * 16;   // 32 KiB weights + 128 KiB features: the whole LDS
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_query_attend_bf16_dma8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    const int K64 = (a.K + 63) / 64 * 64;
-    a.wpk = a.wpk + (size_t)QD * K64 + QD * QD;
-    dim3 grid((unsigned)((max_rows + BM - 1) / BM), (unsigned)n_bags);
-    const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
-    hipLaunchKernelGGL(k_query_attend_bf16_dma8, grid, dim3(512), lds, st, a);
-    dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
-    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
-}
-
 template <int NW>
 int launch_attend_bf16(const AttendArgs& a, long long max_rows, int n_bags, hipStream_t st) {
     constexpr int BM = NW * 32;
@@ -1350,13 +1159,8 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     if (bf16 && ((K % 8) || (Kv % 4) || ((uintptr_t)feats % 16) || ((uintptr_t)vals % 8) ||
                  ((uintptr_t)packed_bf16 % 16)))
         return DSMIL_E_UNSUPPORTED;
-    int NW = pick_nw(n_bags, total_rows);
-    // bf16 storage, wide launch: 256-row workgroups (k_query_attend_bf16_dma8) once they alone fill the chip
-    bool bf16_wide = bf16 && NW == 4 && (total_rows / 256 + n_bags) >= 256;
-#ifdef DSMIL_EXPERIMENTS
-    if (expt_env("DSMIL_EXPT") & 512) bf16_wide = false;
-#endif
-    const int BM = bf16_wide ? 256 : NW * 32;
+    const int NW = pick_nw(n_bags, total_rows);
+    const int BM = NW * 32;
     const WsLayout L = ws_layout(n_bags, total_rows, max_rows, K, Kv, C, BM);
     if (ws_bytes < L.total) return DSMIL_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1446,8 +1250,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
 #ifdef DSMIL_EXPERIMENTS
         if (a.expt & 256) bf16_dma = false;
 #endif
-        if (bf16_wide) rc = launch_attend_bf16_dma8(a, max_rows, nb, st);
-        else if (bf16_dma) rc = launch_attend_bf16_dma(a, max_rows, nb, st);
+        if (bf16_dma) rc = launch_attend_bf16_dma(a, max_rows, nb, st);
         else if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, nb, st) : launch_attend_bf16<1>(a, max_rows, nb, st);
         else if (mode == 9 && NW == 4) rc = v4 ? launch_attend_split<4, 4, 9>(a, max_rows, nb, st) : launch_attend_split<4, 1, 9>(a, max_rows, nb, st);
         else if (mode == 9) rc = v4 ? launch_attend_split<1, 4, 9>(a, max_rows, nb, st) : launch_attend_split<1, 1, 9>(a, max_rows, nb, st);

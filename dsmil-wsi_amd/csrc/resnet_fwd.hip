@@ -325,13 +325,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
     const int taps = a.ks * a.ks;
     const int nchunks = a.Cin / S6K;
     const int nsteps = taps * nchunks;
-    const int c4 = tid & 3;
+    // staging thread -> (row, 4-channel group): 16 consecutive lanes cover 8 rows x 2 groups, so their ds_write_b64 hit 32
+    // distinct banks (row stride 28 dwords = -4 mod 32; the plain (tid >> 2, tid & 3) map had 4 rows x 4 groups per 16 lanes,
+    // 2-way conflicts: 30 % of the LDS cycles in profiles/r02_emb were bank conflicts)
+    const int c4 = (tid & 1) | (((tid >> 4) & 1) << 1);
+    const int xrow = ((tid >> 1) & 7) | ((tid >> 5) << 3);
     const unsigned short* wpk = reinterpret_cast<const unsigned short*>(a.w);
 
     int iy0[XPT], ix0[XPT], nb[XPT], nimg[XPT];
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
-        const long long p = m0 + (tid >> 2) + 64 * i;
+        const long long p = m0 + xrow + 64 * i;
         if (p < a.Mtot) {
             const int n = (int)(p / HW), rem = (int)(p - (long long)n * HW);
             const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
@@ -343,12 +347,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
             iy0[i] = -100000; ix0[i] = -100000; nb[i] = 0; nimg[i] = 0;
         }
     }
-    // this thread's weight items: item e -> plane e / (2 TN), cout row (e % (2 TN)) / 2, 16-B half e & 1
+    // this thread's weight items: item e -> plane e / (2 TN); inside a plane 8 consecutive lanes take 8 consecutive cout
+    // rows of the same 16-B half (their ds_write_b128 cover all 32 banks once)
     int wsrc[WPT], wdst[WPT];
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
         const int e = tid + 256 * i;
-        const int pl = e / (2 * TN), rem = e - pl * 2 * TN, r = rem >> 1, h = rem & 1;
+        const int pl = e / (2 * TN), rem = e - pl * 2 * TN, r = (rem & 7) | ((rem >> 4) << 3), h = (rem >> 3) & 1;
         wsrc[i] = e < WIT ? (pl * a.Cout + n0 + r) * S6K + h * 8 : -1;      // bf16 elements inside a (tap, chunk) slab
         wdst[i] = r * S6LD + pl * 8 + h * 4;                                // dwords
     }
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
             }
             u32x2_t ph, pm, pl;
             cut4(v, ph, pm, pl);
-            unsigned* d = x + ((tid >> 2) + 64 * i) * S6LD + c4 * 2;
+            unsigned* d = x + (xrow + 64 * i) * S6LD + c4 * 2;
             *reinterpret_cast<u32x2_t*>(d) = ph;
             *reinterpret_cast<u32x2_t*>(d + 8) = pm;
             *reinterpret_cast<u32x2_t*>(d + 16) = pl;
@@ -570,6 +575,9 @@ struct WinoArgs {
     int IB, TYB, TXB;      // unit shape: images x tile rows x tile cols (IB*TYB*TXB <= 32)
     int nby, nbx, PB;      // units per image along y / x, PB = nby*nbx
     int expt;              // DSMIL_WINO_EXPT ablation knob (0 in production)
+#ifdef DSMIL_TRACE
+    unsigned long long* trace;   // trace builds: s_memtime stamps of workgroups 0-3 (waves 0 and 4), [wg][role][step][8]
+#endif
 };
 
 // Epilogue shared by the Winograd kernels: inverse transform of this wave's 8 positions, exchange of
@@ -864,11 +872,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
     const int tpi = a.TYB * a.TXB;
     const int iy_org = 2 * ty0 - 1, ix_org = 2 * tx0 - 1;
 
-    // ---- raw staging role: element e = tid + 256 q -> (pixel e>>2, channel group e&3)
+    // ---- raw staging role: element e = tid + 256 q -> (pixel, channel group); 8 consecutive lanes take 8 consecutive
+    //      pixels of one group, so that a ds_write_b128 lane group (8 lanes, 80-B rows) covers the 32 banks once
     int roff[SRPT], rlds[SRPT], rsto[SRPT];
 #pragma unroll
     for (int q = 0; q < SRPT; ++q) {
-        const int e = tid + 256 * q, px = e >> 2, gg = e & 3;
+        const int e = tid + 256 * q, px = (e & 7) | ((e >> 5) << 3), gg = (e >> 3) & 3;
         roff[q] = -2; rlds[q] = 0; rsto[q] = gg * 4;
         if (px < a.IB * RP) {
             const int il = px / RP, rem = px - il * RP, ry = rem / RW, rx = rem - ry * RW;
@@ -902,7 +911,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
     };
     // ---- transform role: channel group g (4 channels), tile slot ts, column half h (nu in {2h,2h+1});
     //      all four xi rows of the patch columns h..h+2
-    const int g = tid & 3, ts = (tid >> 2) & 31;
+    //      Lane -> (g, ts): 16 consecutive lanes hold 4 groups x the EVEN (or odd) slots of 8, which makes the 8-byte plane
+    //      writes below conflict-free (slot stride 28 dwords) and the window reads 1.5-way instead of 2-way (LDS simulation
+    //      over all lane-bit assignments; profiles/r02_emb had 38 % of this kernel's LDS cycles in bank conflicts)
+    const int g = tid & 3, ts = ((lane >> 5) & 1) | (((lane >> 2) & 7) << 1) | ((wave & 1) << 4);
     const int h = wave >> 1;   // wave-uniform
     const int sil = ts / tpi, srem = ts - sil * tpi, styl = srem / a.TXB, stxl = srem - styl * a.TXB;
     const int praw = (ts < a.IB * tpi) ? ((sil * RH + 2 * styl) * RW + 2 * stxl + h) * SRLD + g * 4 : g * 4;
@@ -1058,6 +1070,303 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
         return;
     }
     wino_epilogue(a, acc, smem, lane, wn, wp, n0, img0, ty0, tx0, tpi, pb);
+}
+
+// --------------------------------------------------------------------------------------------
+// k_conv_wino_pp — the Winograd unit as a PERSISTENT, role-split, software-pipelined workgroup (512 threads, one per CU):
+//   waves 0-3  multiply: the MFMAs of step s (8 positions x NP plane products, V fragments from LDS one position
+//              ahead, weight fragments straight from L2 UD positions ahead in a register ring that runs on across
+//              chunk, unit and cout-tile boundaries) and the unit epilogue; their s_waitcnt vmcnt stream holds
+//              nothing but weight loads, so no activation load with HBM latency ever queues in front of a fragment;
+//   waves 4-7  stage: transform(s+1) raw -> V planes, raw(s+2) registers -> IN + ReLU + padding -> LDS, global loads of
+//              raw(s+3), the producer's statistics of step s+3 — a whole step of slack on every dependent chain.
+// A step is one 16-channel chunk of one (unit, cout tile) item; each workgroup walks items first, first+G, ... so the
+// stream of steps never drains between units: the per-unit prologue (two global round trips + a transform) that
+// k_conv_wino_s3 pays with the MFMA pipe idle exists once per LAUNCH here.  V and raw are double buffered
+// (2 x 56 KB + 2 x 20 KB + 4 KB statistics = 156 KB); ONE workgroup barrier per step; at the end of a unit two more
+// around the epilogue's cross-wave exchange (it borrows the V buffer the step just finished with).
+// --------------------------------------------------------------------------------------------
+#ifndef PP_UD
+#define PP_UD 3
+#endif
+#ifdef DSMIL_TRACE
+#define PP_STAMP(slot)                                                                                              \
+    do {                                                                                                            \
+        if (a.trace && blockIdx.x < 4 && lane == 0 && (wave8 & 3) == 0 && s < 256)                                  \
+            a.trace[(((long long)blockIdx.x * 2 + (wave8 >> 2)) * 256 + s) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PP_STAMP(slot) do { } while (0)
+#endif
+template <bool NORM, int NP, int UD>
+__global__ __launch_bounds__(512, 2) void k_conv_wino_pp(WinoArgs a, int nunits, int nitems) {
+    static_assert(UD == 3 || UD == 7, "the fragment ring (UD + 1 slots) must divide the 8 positions of a step");
+    constexpr int RING = UD + 1;                        // weight prefetch distance in positions: ring of UD + 1 slots
+    constexpr int R_DW = WRAW_MAX * SRLD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned* sV = reinterpret_cast<unsigned*>(smem);   // [2][SV_DW]
+    float* sR = smem + 2 * SV_DW;                       // [2][R_DW]
+    float* sS = sR + 2 * R_DW;                          // [2][16 images][2 (mean, rstd)][16 ch]
+    const int tid = threadIdx.x & 255, lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool stager = wave8 >= 4;
+    const int wave = wave8 & 3;
+    const int nchunks = a.C / SK;
+    const int first = blockIdx.x, stride = gridDim.x;
+    const int nmine = (nitems - first + stride - 1) / stride;
+    const int S = nmine * nchunks;                      // steps of this workgroup
+    const int RH = 2 * a.TYB + 2, RW = 2 * a.TXB + 2, RP = RH * RW;
+    const int tpi = a.TYB * a.TXB;
+    struct Item { int img0, ty0, tx0, pb, n0; };
+    auto decode = [&](int j) {                          // j-th item of this workgroup (uniform)
+        j = j < nmine ? j : nmine - 1;
+        const int i = first + j * stride;
+        const int ct = i / nunits;
+        int u = i - ct * nunits;
+        const int bx = u % a.nbx; u /= a.nbx;
+        const int by = u % a.nby; u /= a.nby;
+        return Item{u * a.IB, by * a.TYB, bx * a.TXB, by * a.nbx + bx, ct * 64};
+    };
+
+    if (stager) {
+        // ---- raw staging role: element e = tid + 256 q -> (pixel, channel group), as in k_conv_wino_s3
+        int rgeo[SRPT], rlds[SRPT], rsto[SRPT], roff[SRPT];
+#pragma unroll
+        for (int q = 0; q < SRPT; ++q) {
+            const int e = tid + 256 * q, px = (e & 7) | ((e >> 5) << 3), gg = (e >> 3) & 3;
+            rgeo[q] = -1; rlds[q] = px * SRLD + gg * 4; rsto[q] = gg * 4;
+            if (px < a.IB * RP) {
+                const int il = px / RP, rem = px - il * RP, ry = rem / RW, rx = rem - ry * RW;
+                rgeo[q] = (il << 20) | (ry << 10) | rx;
+                rsto[q] = il * 32 + gg * 4;
+            }
+        }
+        auto set_item = [&](const Item& it) {           // global element offsets of this thread's pixels in the item's region
+#pragma unroll
+            for (int q = 0; q < SRPT; ++q) {
+                const int e = tid + 256 * q, gg = (e >> 3) & 3;
+                roff[q] = -1;
+                if (rgeo[q] >= 0) {
+                    const int n = it.img0 + (rgeo[q] >> 20), iy = 2 * it.ty0 - 1 + ((rgeo[q] >> 10) & 1023),
+                              ix = 2 * it.tx0 - 1 + (rgeo[q] & 1023);
+                    if (n < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) roff[q] = ((n * a.H + iy) * a.W + ix) * a.C + gg * 4;
+                }
+            }
+        };
+        // transform role (see k_conv_wino_s3 for the lane -> (g, ts) assignment)
+        const int g = tid & 3, ts = ((lane >> 5) & 1) | (((lane >> 2) & 7) << 1) | ((wave & 1) << 4);
+        const int h = wave >> 1;
+        const int sil = ts / tpi, srem = ts - sil * tpi, styl = srem / a.TXB, stxl = srem - styl * a.TXB;
+        const int praw = (ts < a.IB * tpi) ? ((sil * RH + 2 * styl) * RW + 2 * stxl + h) * SRLD + g * 4 : g * 4;
+
+        f32x4 rreg[SRPT];
+        unsigned rok = 0;                               // validity of rreg's pixels (captured when they were requested)
+        f32x4 sreg = {0.f, 0.f, 0.f, 0.f};
+        int jL = 0, ccL = 0;                            // item / chunk of the step the NEXT raw_load requests
+        Item itL = decode(0);
+        set_item(itL);
+        auto advance = [&]() {                          // to the next step of the stream (stays on the last one at the end)
+            if (ccL + 1 < nchunks) { ++ccL; return; }
+            if (jL + 1 < nmine) { ++jL; ccL = 0; itL = decode(jL); set_item(itL); }
+        };
+        auto raw_load = [&]() {
+            rok = 0;
+#pragma unroll
+            for (int q = 0; q < SRPT; ++q) {
+                const int off = roff[q] < 0 ? 0 : roff[q];
+                rok |= roff[q] >= 0 ? (1u << q) : 0u;
+                rreg[q] = *reinterpret_cast<const f32x4*>(a.x + (long long)off + ccL * SK);
+            }
+        };
+        auto stat_load = [&]() {
+            if constexpr (NORM) {
+                if (tid < 128) {
+                    const int il = tid >> 3, which = (tid >> 2) & 1, c4 = tid & 3;
+                    const int n = itL.img0 + il < a.B ? itL.img0 + il : a.B - 1;
+                    sreg = *reinterpret_cast<const f32x4*>((which ? a.in_rstd : a.in_mean) + (long long)n * a.C + ccL * SK + c4 * 4);
+                }
+            }
+        };
+        auto stat_write = [&](int b) {
+            if constexpr (NORM) {
+                if (tid < 128) {
+                    const int il = tid >> 3, which = (tid >> 2) & 1, c4 = tid & 3;
+                    *reinterpret_cast<f32x4*>(sS + b * 512 + il * 32 + which * 16 + c4 * 4) = sreg;
+                }
+            }
+        };
+        auto raw_write = [&](int rb, int sb) {          // rreg -> IN + ReLU + zero padding -> raw buffer rb (statistics buffer sb)
+            float* dst = sR + rb * R_DW;
+#pragma unroll
+            for (int q = 0; q < SRPT; ++q) {
+                f32x4 x = rreg[q];
+                if constexpr (NORM) {
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(sS + sb * 512 + rsto[q]);
+                    const f32x4 rs = *reinterpret_cast<const f32x4*>(sS + sb * 512 + rsto[q] + 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = fmaxf((x[e] - mu[e]) * rs[e], 0.f);
+                }
+                const bool ok = (rok >> q) & 1u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = ok ? x[e] : 0.f;
+                if (rgeo[q] >= 0) *reinterpret_cast<f32x4*>(dst + rlds[q]) = x;
+            }
+        };
+        auto transform = [&](int rb, int vb) {          // raw buffer rb -> V buffer vb (planes)
+            const float* r = sR + rb * R_DW + praw;
+            unsigned* vdst = sV + vb * SV_DW;
+            f32x4 T[4][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f32x4 R0 = *reinterpret_cast<const f32x4*>(r + (0 * RW + c) * SRLD);
+                const f32x4 R1 = *reinterpret_cast<const f32x4*>(r + (1 * RW + c) * SRLD);
+                const f32x4 R2 = *reinterpret_cast<const f32x4*>(r + (2 * RW + c) * SRLD);
+                const f32x4 R3 = *reinterpret_cast<const f32x4*>(r + (3 * RW + c) * SRLD);
+                T[0][c] = R0 - R2; T[1][c] = R1 + R2; T[2][c] = R2 - R1; T[3][c] = R1 - R3;
+            }
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                f32x4 o0, o1;
+                if (h == 0) { o0 = T[xi][0] - T[xi][2]; o1 = T[xi][1] + T[xi][2]; }
+                else { o0 = T[xi][1] - T[xi][0]; o1 = T[xi][0] - T[xi][2]; }
+                const int pos = xi * 4 + 2 * h;
+                u32x2_t ph, pm, pl;
+                unsigned* d0 = vdst + (pos * WTT + ts) * SVLD + g * 2;
+                cut4(o0, ph, pm, pl);
+                *reinterpret_cast<u32x2_t*>(d0) = ph;
+                *reinterpret_cast<u32x2_t*>(d0 + 8) = pm;
+                *reinterpret_cast<u32x2_t*>(d0 + 16) = pl;
+                unsigned* d1 = d0 + WTT * SVLD;
+                cut4(o1, ph, pm, pl);
+                *reinterpret_cast<u32x2_t*>(d1) = ph;
+                *reinterpret_cast<u32x2_t*>(d1 + 8) = pm;
+                *reinterpret_cast<u32x2_t*>(d1 + 16) = pl;
+            }
+        };
+        // ---- prologue: state at the top of step 0 = { V[0] = T(0), R[1] = raw(1), rreg = raw(2), S[0] = statistics(2) }
+        raw_load(); stat_load(); stat_write(0);
+        __syncthreads();                                // P0
+        raw_write(0, 0);
+        advance(); raw_load(); stat_load(); stat_write(1);
+        __syncthreads();                                // P1
+        transform(0, 0);
+        raw_write(1, 1);
+        advance(); raw_load(); stat_load(); stat_write(0);   // S[0] was last read before P1
+        __syncthreads();                                // P2
+        int ccC = 0;
+        for (int s = 0; s < S; ++s) {
+            const int b = s & 1;
+            PP_STAMP(0);
+            advance();                                  // -> step s+3
+            stat_load();
+            transform(b ^ 1, b ^ 1);                    // raw(s+1) -> V[(s+1)&1]
+            PP_STAMP(1);
+            raw_write(b, b);                            // raw(s+2): R[s&1], statistics S[s&1]
+            PP_STAMP(2);
+            raw_load();                                 // raw(s+3)
+            stat_write(b ^ 1);                          // statistics(s+3) -> S[(s+1)&1] (last read in step s-1)
+            PP_STAMP(3);
+            __syncthreads();
+            PP_STAMP(4);
+            if (++ccC == nchunks) {                     // the multiply waves' epilogue exchange
+                ccC = 0;
+                __syncthreads();
+                __syncthreads();
+            }
+        }
+        return;
+    }
+
+    // ================= multiply waves =========================================================================
+    const int wn = wave & 1, wp = wave >> 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const unsigned short* ub16 = reinterpret_cast<const unsigned short*>(a.u);
+    const long long uplane = (long long)a.Cout * SK;
+    const long long uchunk = 3 * uplane;
+    const long long upos = (long long)nchunks * uchunk;
+    const int ulane = l31 * SK + 8 * hi;
+    auto ustep = [&](const Item& it, int cc) {          // this wave's fragment base of a step
+        return ub16 + (long long)(8 * wp) * upos + (long long)(it.n0 + wn * 32) * SK + cc * uchunk + ulane;
+    };
+    auto uload = [&](const unsigned short* base, int p, u32x4_t (&w)[3]) {
+        const unsigned short* q = base + p * upos;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const u32x4_t*>(q + pl * uplane);
+    };
+    f32x16 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    u32x4_t w[RING][3];
+    int jC = 0, ccC = 0;
+    Item itC = decode(0);
+    const unsigned short* up0 = ustep(itC, 0);
+#pragma unroll
+    for (int p = 0; p < UD; ++p) uload(up0, p, w[p]);
+    const int vfo = ((8 * wp) * WTT + l31) * SVLD + 4 * hi;   // dwords
+    union Frag { u32x4_t u; bf16x8_t v; };
+    __syncthreads();                                    // P0
+    __syncthreads();                                    // P1
+    __syncthreads();                                    // P2
+    for (int s = 0; s < S; ++s) {
+        // the step after this one (for the fragments requested late in this one); stays on the last step at the end
+        int jN = jC, ccN = ccC + 1;
+        Item itN = itC;
+        if (ccN == nchunks) {
+            if (jC + 1 < nmine) { jN = jC + 1; ccN = 0; itN = decode(jN); } else ccN = ccC;
+        }
+        PP_STAMP(0);
+        const unsigned short* up1 = ustep(itN, ccN);
+        const unsigned* vsrc = sV + (s & 1) * SV_DW + vfo;
+        Frag va[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) va[0][pl].u = *reinterpret_cast<const u32x4_t*>(vsrc + pl * 8);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            // ring slot (p + UD) % RING = the one position p - 1 just released
+            if (p + UD < 8) uload(up0, p + UD, w[(p + UD) % RING]); else uload(up1, p + UD - 8, w[(p + UD) % RING]);
+            if (p < 7) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) va[(p + 1) & 1][pl].u = *reinterpret_cast<const u32x4_t*>(vsrc + (p + 1) * WTT * SVLD + pl * 8);
+            }
+            // keep the requests where they are written: left alone, the scheduler sinks each load to just before its use
+            // (prefetch distance ~1 position, every MFMA group behind an s_waitcnt)
+            __builtin_amdgcn_sched_barrier(0);
+            Frag wb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wb[pl].u = w[p % RING][pl];
+            const Frag (&v)[3] = va[p & 1];
+            // smallest products first: (l,l) (m,l) (l,m) | (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+            if constexpr (NP == 9) {
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2].v, wb[2].v, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1].v, wb[2].v, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2].v, wb[1].v, acc[p], 0, 0, 0);
+            }
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2].v, wb[0].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0].v, wb[2].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1].v, wb[1].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1].v, wb[0].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0].v, wb[1].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0].v, wb[0].v, acc[p], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (p == 3) PP_STAMP(1);
+        }
+        PP_STAMP(2);
+        __syncthreads();
+        PP_STAMP(3);
+        if (ccC + 1 == nchunks) {                       // unit done: inverse transform, exchange through V[s&1], store
+            wino_epilogue(a, acc, reinterpret_cast<float*>(sV + (s & 1) * SV_DW), lane, wn, wp, itC.n0, itC.img0, itC.ty0, itC.tx0,
+                          tpi, itC.pb);
+            __syncthreads();                            // the exchange buffer is V again
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+            PP_STAMP(4);
+        }
+        jC = jN; ccC = ccN; itC = itN; up0 = up1;
+    }
 }
 
 // conv weight [O][I][3][3] -> U = G g G^T cut into three bf16 planes: [16 pos][I/16][3][O][16]
@@ -1529,6 +1838,26 @@ inline int wino_form() {
     return form;
 }
 inline bool wino_s3() { return wino_form() != 0; }
+// DSMIL_WINO_KERNEL = unit (default: one workgroup per unit, k_conv_wino_s3) | pp (persistent role-split k_conv_wino_pp)
+inline int wino_unit_kernel() {
+    static const int unit = [] {
+        const char* e = getenv("DSMIL_WINO_KERNEL");
+        return (e && !strcmp(e, "pp")) ? 0 : 1;
+    }();
+    return unit;
+}
+#ifdef DSMIL_TRACE
+constexpr size_t WINO_TRACE_WORDS = 4 * 2 * 256 * 8;
+inline unsigned long long* wino_trace_buffer() {
+    static unsigned long long* buf = [] {
+        unsigned long long* p = nullptr;
+        (void)hipMalloc(&p, WINO_TRACE_WORDS * 8);
+        (void)hipMemset(p, 0, WINO_TRACE_WORDS * 8);
+        return p;
+    }();
+    return buf;
+}
+#endif
 // DSMIL_CONV = s6 (default) | f32: MFMA form of the DIRECT convs (strided 3x3, 1x1): s6 = bf16 MFMA over exact
 // three-plane cuts, 6 plane products (k_conv_s6; weights cut at pack time), f32 = v_mfma_f32_32x32x2_f32 (k_conv).
 // Read once per process; the packed weights and the kernels must agree.
@@ -1664,6 +1993,13 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
         wa.expt = 0;
 #endif
         wa.nby = (wa.TY + wa.TYB - 1) / wa.TYB; wa.nbx = (wa.TX + wa.TXB - 1) / wa.TXB; wa.PB = wa.nby * wa.nbx;
+#ifdef DSMIL_TRACE
+        {   // DSMIL_WINO_TRACE = k: the k-th Winograd launch of the process records stamps (tools_stamp_wino.py)
+            static const int want = expt_env("DSMIL_WINO_TRACE");
+            static int launch = 0;
+            wa.trace = (++launch == want) ? wino_trace_buffer() : nullptr;
+        }
+#endif
         const size_t lds = wino_s3() ? (size_t)(SV_DW + WRAW_MAX * SRLD) * sizeof(float)
                                      : (size_t)(2 * WTILE + 2 * WRAW_MAX * WLD) * sizeof(float);
         dim3 grid((unsigned)(((B + wa.IB - 1) / wa.IB) * wa.PB), (unsigned)(s.cout / 64));
@@ -1677,7 +2013,22 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
                 allow_lds((const void*)kern, l);
                 hipLaunchKernelGGL(kern, grid, dim3(256), l, st, wa);
             };
-            if (in_mean) {
+            static const int ncu = [] {
+                int dev = 0, n = 0;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+                return n > 0 ? n : 256;
+            }();
+            const int nunits = (int)grid.x, nitems = (int)(grid.x * grid.y);
+            const size_t lds_pp = (size_t)(2 * SV_DW + 2 * WRAW_MAX * SRLD + 1024) * sizeof(float);
+            auto go_pp = [&](auto kern) {   // persistent: one workgroup per CU walks the (unit, cout tile) items
+                allow_lds((const void*)kern, lds_pp);
+                hipLaunchKernelGGL(kern, dim3((unsigned)(nitems < ncu ? nitems : ncu)), dim3(512), lds_pp, st, wa, nunits, nitems);
+            };
+            if (wino_unit_kernel() == 0) {
+                if (in_mean) { if (np9) go_pp(k_conv_wino_pp<true, 9, PP_UD>); else go_pp(k_conv_wino_pp<true, 6, PP_UD>); }
+                else { if (np9) go_pp(k_conv_wino_pp<false, 9, PP_UD>); else go_pp(k_conv_wino_pp<false, 6, PP_UD>); }
+            } else if (in_mean) {
                 if (np9) go(k_conv_wino_s3<true, 2, true, 9>, lds_ls);
                 else go(k_conv_wino_s3<true, 2, true, 6>, lds_ls);
             } else {
@@ -1981,3 +2332,12 @@ int dsmil_resnet18bn_forward(const void* x, int32_t x_is_u8_nhwc, int32_t B, int
 }
 
 }  // extern "C"
+
+#ifdef DSMIL_TRACE
+// trace builds only (not part of the ABI): copies the stamp buffer of the traced Winograd launch to the host
+extern "C" int dsmil_debug_wino_trace(unsigned long long* out, int words) {
+    if (!out || words < (int)WINO_TRACE_WORDS) return DSMIL_E_INVALID;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out, wino_trace_buffer(), WINO_TRACE_WORDS * 8, hipMemcpyDeviceToHost) == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+#endif

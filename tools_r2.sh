@@ -19,6 +19,16 @@ variants2)
   DSMIL_NATIVE_LIB=libdsmil_hip_expt.so VARIANT_ROUNDS=1 timeout 900 python tools_variants.py embedder base: noxform:DSMIL_WINO_EXPT=1 noraw:DSMIL_WINO_EXPT=2 nou:DSMIL_WINO_EXPT=4 noepi:DSMIL_WINO_EXPT=8 nomfma:DSMIL_WINO_EXPT=16 onlymfma:DSMIL_WINO_EXPT=15 > $OUT/variants_emb.log 2>&1; cat $OUT/variants_emb.log;;
 variants3)
   DSMIL_NATIVE_LIB=libdsmil_hip_expt.so VARIANT_ROUNDS=2 timeout 1200 python tools_variants.py embedder base: skew1536:DSMIL_WINO_SKEW=1536 skew3072:DSMIL_WINO_SKEW=3072 skew4608:DSMIL_WINO_SKEW=4608 ud2:DSMIL_WINO_EXPT=64 ls:DSMIL_WINO_EXPT=128 ud2ls:DSMIL_WINO_EXPT=192 ud2ls_skew:DSMIL_WINO_EXPT=192,DSMIL_WINO_SKEW=3072 > $OUT/variants_emb3.log 2>&1; cat $OUT/variants_emb3.log;;
+tests_bf16)
+  timeout 900 python -m pytest tests/test_agg_bf16_gpu.py tests/test_resnet_gpu.py tests/test_forms_gpu.py -m gpu -x -q > $OUT/pytest_bf16.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_bf16.log;;
+variants_bf16)
+  DSMIL_NATIVE_LIB=libdsmil_hip_expt.so timeout 900 python tools_variants.py aggregator_bf16 dma8: dma4:DSMIL_EXPT=512 old:DSMIL_EXPT=256 > $OUT/variants_bf16.log 2>&1; cat $OUT/variants_bf16.log;;
+tests_emb)
+  timeout 900 python -m pytest tests/test_resnet_gpu.py tests/test_forms_gpu.py -m gpu -x -q > $OUT/pytest_emb.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_emb.log;;
+variants_pp)
+  VARIANT_ROUNDS=${VARIANT_ROUNDS:-2} timeout 900 python tools_variants.py embedder pp: unit:DSMIL_WINO_KERNEL=unit > $OUT/variants_pp.log 2>&1; cat $OUT/variants_pp.log;;
+stamps_wino)
+  for k in ${STAMP_K:-1 12}; do DSMIL_NATIVE_LIB=libdsmil_hip_trace.so DSMIL_WINO_TRACE=$k timeout 300 python tools_stamp_wino.py > $OUT/stamps_wino_$k.log 2>&1; echo "== launch $k"; tail -14 $OUT/stamps_wino_$k.log | cut -c1-400; done;;
 tests_new)
   timeout 900 python -m pytest tests/test_agg_bwd_gpu.py tests/test_agg_gpu.py tests/test_entry_points.py -m gpu -x -q > $OUT/pytest_new.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_new.log;;
 stamps)
