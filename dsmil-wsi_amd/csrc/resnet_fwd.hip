@@ -429,19 +429,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
         Frag16 xa[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) xa[p].u = *reinterpret_cast<const u32x4_t*>(x + p * 8);
+        Frag16 wb[NT][3];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            Frag16 wb[3];
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) wb[p].u = *reinterpret_cast<const u32x4_t*>(w + t * 32 * S6LD + p * 8);
-            // smallest products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[2].v, wb[0].v, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0].v, wb[2].v, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1].v, wb[1].v, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[1].v, wb[0].v, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0].v, wb[1].v, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0].v, wb[0].v, acc[t], 0, 0, 0);
-        }
+            for (int p = 0; p < 3; ++p) wb[t][p].u = *reinterpret_cast<const u32x4_t*>(w + t * 32 * S6LD + p * 8);
+        // smallest products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h).  The N-tiles ALTERNATE inside each product, so
+        // no MFMA accumulates into the tile the previous one is still writing (a dependent 32x32x16 chain issues every
+        // ~48 cycles instead of 32: MI355X_MICROARCH.md, measured constants)
+        constexpr int PX[6] = {2, 0, 1, 1, 0, 0}, PW[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PX[k]].v, wb[t][PW[k]].v, acc[t], 0, 0, 0);
     };
     // step st: [issue loads of st+2 -> the set st's data just left] [MFMAs on LDS buffer st&1] [set of st+1 -> buffer (st+1)&1]
     stage_load(0, ra);
@@ -850,17 +851,46 @@ constexpr int SRPT = (WRAW_MAX * 4 + 255) / 256;     // raw float4 per thread pe
 // thread right before use.
 // NP: plane products per fp32 product (9 = every product formed exactly; 6 = the three smallest, together < 2^-20 of
 // |u*v|, left out — see agg_split.h).
-template <bool NORM, int UD = 1, bool LS = false, int NP = 9>
-__global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
+#ifdef DSMIL_TRACE
+#define PP_STAMP(slot)                                                                                              \
+    do {                                                                                                            \
+        if (a.trace && blockIdx.x < 4 && lane == 0 && (wave8 & 3) == 0 && s < 256)                                  \
+            a.trace[(((long long)blockIdx.x * 2 + (wave8 >> 2)) * 256 + s) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PP_STAMP(slot) do { } while (0)
+#endif
+#ifdef DSMIL_TRACE
+#define UNIT_STAMP(slot)                                                                                            \
+    do {                                                                                                            \
+        if (a.trace && blockIdx.x < 4 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == NT / 64 - 1) && cc < 256) \
+            a.trace[(((long long)blockIdx.x * 2 + (wave != 0)) * 256 + cc) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define UNIT_STAMP(slot) do { } while (0)
+#endif
+// WNN: cout tiles of 32 per workgroup (2: 64 couts, 256 threads, two workgroups per CU; 4: 128 couts, 512 threads, one
+// workgroup per CU): the staged + transformed input of a unit serves WNN x 32 couts, so the wide form does HALF the
+// staging / transform / cut work per MFMA (that work, not the MFMAs, bounds the narrow form: stamps in profiles/README.md).
+// UC: the weight-fragment ring runs on ACROSS chunks (needs a ring that divides the 8 positions: UD = 3): the first
+// positions of a chunk find their fragments already there instead of paying an L2 round trip behind the barrier.
+// Measured on the 128-cout form: 39.98k patches/s against 40.78k without (8-15 registers spill into the staging phase);
+// compiled only with -DWIDE_UC=true.
+template <bool NORM, int UD = 1, bool LS = false, int NP = 9, int WNN = 2, bool UC = false>
+__global__ __launch_bounds__(WNN * 128, 2) void k_conv_wino_s3(WinoArgs a) {
+    constexpr int NT = WNN * 128;                       // threads
+    static_assert(!UC || UD == 3, "carrying the ring needs (UD + 1) | 8");
+    constexpr int RPT = (WRAW_MAX * 4 + NT - 1) / NT;   // raw float4 per thread per chunk
+    constexpr int XH = NT / 256;                        // threads sharing one (g, ts, h) transform role: 4 / XH xi rows each
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned* sV = reinterpret_cast<unsigned*>(smem);   // [16][WTT][SVLD] dwords
     float* sR = smem + SV_DW;                           // [WRAW_MAX][SRLD]
     float* sS = sR + WRAW_MAX * SRLD;                   // LS: [2 buffers][16 images][2 (mean, rstd)][16 ch]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 1, wp = wave >> 1;
+    const int wn = wave % WNN, wp = wave / WNN;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int n0 = blockIdx.y * 64;
+    const int n0 = blockIdx.y * (WNN * 32);
     const int nchunks = a.C / SK;
     int bid = blockIdx.x;
     const int bx = bid % a.nbx; bid /= a.nbx;
@@ -874,10 +904,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
 
     // ---- raw staging role: element e = tid + 256 q -> (pixel, channel group); 8 consecutive lanes take 8 consecutive
     //      pixels of one group, so that a ds_write_b128 lane group (8 lanes, 80-B rows) covers the 32 banks once
-    int roff[SRPT], rlds[SRPT], rsto[SRPT];
+    int roff[RPT], rlds[RPT], rsto[RPT];
 #pragma unroll
-    for (int q = 0; q < SRPT; ++q) {
-        const int e = tid + 256 * q, px = (e & 7) | ((e >> 5) << 3), gg = (e >> 3) & 3;
+    for (int q = 0; q < RPT; ++q) {
+        const int e = tid + NT * q, px = (e & 7) | ((e >> 5) << 3), gg = (e >> 3) & 3;
         roff[q] = -2; rlds[q] = 0; rsto[q] = gg * 4;
         if (px < a.IB * RP) {
             const int il = px / RP, rem = px - il * RP, ry = rem / RW, rx = rem - ry * RW;
@@ -915,21 +945,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
     //      writes below conflict-free (slot stride 28 dwords) and the window reads 1.5-way instead of 2-way (LDS simulation
     //      over all lane-bit assignments; profiles/r02_emb had 38 % of this kernel's LDS cycles in bank conflicts)
     const int g = tid & 3, ts = ((lane >> 5) & 1) | (((lane >> 2) & 7) << 1) | ((wave & 1) << 4);
-    const int h = wave >> 1;   // wave-uniform
+    const int h = (wave >> 1) & 1;   // wave-uniform
+    const int xh = wave >> 2;        // XH == 2: which pair of xi rows (0 when XH == 1)
     const int sil = ts / tpi, srem = ts - sil * tpi, styl = srem / a.TXB, stxl = srem - styl * a.TXB;
     const int praw = (ts < a.IB * tpi) ? ((sil * RH + 2 * styl) * RW + 2 * stxl + h) * SRLD + g * 4 : g * 4;
 
-    f32x4 rreg[SRPT];
+    f32x4 rreg[RPT];
     auto raw_load = [&](int cc) {
 #pragma unroll
-        for (int q = 0; q < SRPT; ++q) {
+        for (int q = 0; q < RPT; ++q) {
             const int off = roff[q] < 0 ? 0 : roff[q];
             rreg[q] = *reinterpret_cast<const f32x4*>(a.x + (long long)off + cc * SK);
         }
     };
     auto raw_write = [&](int cc) {   // producer's IN + ReLU and the zero padding applied once per staged pixel
 #pragma unroll
-        for (int q = 0; q < SRPT; ++q) {
+        for (int q = 0; q < RPT; ++q) {
             if (roff[q] == -2) continue;
             f32x4 x = rreg[q];
             const bool ok = roff[q] >= 0;
@@ -967,6 +998,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
         }
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) {
+            if (XH == 2 && (xi >> 1) != xh) continue;   // the other thread of this role does these rows
             f32x4 o0, o1;
             if (h == 0) { o0 = T[xi][0] - T[xi][2]; o1 = T[xi][1] + T[xi][2]; }
             else { o0 = T[xi][1] - T[xi][0]; o1 = T[xi][0] - T[xi][2]; }
@@ -1017,21 +1049,45 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
     const int vfo = ((8 * wp) * WTT + l31) * SVLD + 4 * hi;   // dwords
     union Frag { u32x4_t u; bf16x8_t v; };
     u32x4_t w[UD + 1][3];
+    if constexpr (UC) {
+#pragma unroll
+        for (int p = 0; p < UD; ++p) uload(p, 0, w[p]);
+    }
     for (int cc = 0; cc < nchunks; ++cc) {
         const bool more = cc + 1 < nchunks, more2 = cc + 2 < nchunks;   // block-uniform
+        UNIT_STAMP(0);
         // ---- 8 positions x NP plane products
-        uload(0, cc, w[0]);
-        if constexpr (UD == 2) uload(1, cc, w[1]);
+        if constexpr (!UC) {
+            uload(0, cc, w[0]);
+            if constexpr (UD >= 2) uload(1, cc, w[1]);
+            if constexpr (UD >= 3) uload(2, cc, w[2]);
+        }
         if (more2) stat_load(cc + 2);
+        // V fragments: one position ahead where the registers allow it (the 512-thread form), else read at use
+        constexpr bool VA2 = WNN == 4;
+        Frag vq[2][3];
+        if constexpr (VA2) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) vq[0][pl].u = *reinterpret_cast<const u32x4_t*>(sV + vfo + pl * 8);
+        }
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            if (p + UD < 8 && !DSMIL_WEXPT_ON(a, 4)) uload(p + UD, cc, w[(p + UD) % (UD + 1)]);
+            if (p + UD < 8) { if (!DSMIL_WEXPT_ON(a, 4)) uload(p + UD, cc, w[(p + UD) % (UD + 1)]); }
+            else if (UC) uload(p + UD - 8, more ? cc + 1 : cc, w[(p + UD) % (UD + 1)]);   // next chunk's first positions
             Frag va[3], wb[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                va[pl].u = *reinterpret_cast<const u32x4_t*>(sV + vfo + p * WTT * SVLD + pl * 8);
+                if constexpr (VA2) {
+                    if (p < 7) vq[(p + 1) & 1][pl].u = *reinterpret_cast<const u32x4_t*>(sV + vfo + (p + 1) * WTT * SVLD + pl * 8);
+                    va[pl] = vq[p & 1][pl];
+                } else {
+                    va[pl].u = *reinterpret_cast<const u32x4_t*>(sV + vfo + p * WTT * SVLD + pl * 8);
+                }
                 wb[pl].u = w[DSMIL_WEXPT_ON(a, 4) ? 0 : (p % (UD + 1))][pl];
             }
+            // the requests stay where they are written: left alone, the scheduler of the 512-thread form sinks every
+            // weight load to just before its use (an s_waitcnt vmcnt(0) in front of each MFMA group: 413 us against 257)
+            __builtin_amdgcn_sched_barrier(0);
             if (DSMIL_WEXPT_ON(a, 16)) {   // ablation: no MFMAs (operands kept live)
                 asm volatile("" ::"v"(va[0].u), "v"(va[1].u), "v"(va[2].u), "v"(wb[0].u), "v"(wb[1].u), "v"(wb[2].u));
                 continue;
@@ -1048,17 +1104,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[0].v, acc[p], 0, 0, 0);
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[1].v, acc[p], 0, 0, 0);
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[0].v, acc[p], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- raw(cc+1): registers -> LDS (the raw buffer was consumed before the last barrier), then the
         //      global loads of raw(cc+2)
+        UNIT_STAMP(1);
         if (!DSMIL_WEXPT_ON(a, 2)) {
             if (more) raw_write(cc + 1);
             if (more2) raw_load(cc + 2);
         }
+        UNIT_STAMP(2);
         __syncthreads();                 // V(cc) is free, raw(cc+1) is in LDS
+        UNIT_STAMP(3);
         if (more && !DSMIL_WEXPT_ON(a, 1)) transform();
         if (more2) stat_write(cc + 2);   // read by raw_write(cc+2) in the next iteration, behind the barrier below
+        UNIT_STAMP(4);
         __syncthreads();                 // V(cc+1) is ready
+        UNIT_STAMP(5);
     }
     if (DSMIL_WEXPT_ON(a, 8)) {  // ablation: no epilogue
         float keep = 0.f;
@@ -1068,6 +1130,270 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
             for (int r = 0; r < 16; ++r) keep += acc[p][r];
         if (keep == 123.456f) a.y[0] = keep;
         return;
+    }
+    wino_epilogue(a, acc, smem, lane, wn, wp, n0, img0, ty0, tx0, tpi, pb);
+}
+
+#ifdef DSMIL_EXPERIMENTS   // the two measured-and-lost restructurings of the Winograd unit (profiles/README.md); experiment builds only
+// --------------------------------------------------------------------------------------------
+// k_conv_wino_alt — the 128-cout Winograd unit with the two HALVES of the workgroup out of phase: 512 threads, waves 0-3
+// (positions 0-7, group A) and waves 4-7 (positions 8-15, group B) alternate between the MFMA job and the staging job,
+// half a step apart, so at every moment each SIMD holds one wave that multiplies and one that stages:
+//     half-step 2c   : A  MFMAs of chunk c on V[c&1]           | B  stages: its half of transform(c+1) -> V[(c+1)&1],
+//     half-step 2c+1 : A  stages (the same, its half)          |            raw(c+2) regs -> R[c&1], loads raw(c+3)
+//                                                              | B  MFMAs of chunk c
+// The transform splits by xi rows (A: xi = 0, 1; B: xi = 2, 3), the raw staging by element; V and raw are double buffered
+// (2 x 56 KB + 2 x 20 KB + 4 KB statistics = 156 KB, one workgroup per CU); one workgroup barrier per half-step.
+// Why: stamps of the in-phase forms (profiles/README.md) — every wave of k_conv_wino_s3 spends ~48 % of a step in its
+// MFMA phase and ~47 % staging, and the phases of co-resident waves do not overlap; the role-split k_conv_wino_pp
+// overlaps them but leaves ALL the staging to four waves (4300 cycles against 2320 of MFMAs).  Here the two jobs are
+// the same size on every wave, and each wave's activation loads are issued a whole staging job before it next waits on
+// a weight fragment.
+// --------------------------------------------------------------------------------------------
+template <bool NORM, int NP>
+__global__ __launch_bounds__(512, 2) void k_conv_wino_alt(WinoArgs a) {
+    constexpr int UD = 2;                               // (UD = 3 spills inside the staging job: 9500-cycle steps against 7700)
+    constexpr int R_DW = WRAW_MAX * SRLD;
+    constexpr int RPT = 2;                              // raw float4 per thread per chunk (1024 elements / 512 threads)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned* sV = reinterpret_cast<unsigned*>(smem);   // [2][SV_DW]
+    float* sR = smem + 2 * SV_DW;                       // [2][R_DW]
+    float* sS = sR + 2 * R_DW;                          // [2][16 images][2 (mean, rstd)][16 ch]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                          // 0 = A, 1 = B: position half of the MFMAs, xi half of the transform
+    const int wn = wave & 3, wp = grp;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int n0 = blockIdx.y * 128;
+    const int nchunks = a.C / SK;
+    int bid = blockIdx.x;
+    const int bx = bid % a.nbx; bid /= a.nbx;
+    const int by = bid % a.nby; bid /= a.nby;
+    const int img0 = bid * a.IB;
+    const int ty0 = by * a.TYB, tx0 = bx * a.TXB;
+    const int pb = by * a.nbx + bx;
+    const int RH = 2 * a.TYB + 2, RW = 2 * a.TXB + 2, RP = RH * RW;
+    const int tpi = a.TYB * a.TXB;
+    const int iy_org = 2 * ty0 - 1, ix_org = 2 * tx0 - 1;
+
+    // ---- raw staging role: element e = tid + 512 q -> (pixel, channel group), as in k_conv_wino_s3
+    int roff[RPT], rlds[RPT], rsto[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int e = tid + 512 * q, px = (e & 7) | ((e >> 5) << 3), gg = (e >> 3) & 3;
+        roff[q] = -2; rlds[q] = 0; rsto[q] = gg * 4;
+        if (px < a.IB * RP) {
+            const int il = px / RP, rem = px - il * RP, ry = rem / RW, rx = rem - ry * RW;
+            const int n = img0 + il, iy = iy_org + ry, ix = ix_org + rx;
+            roff[q] = -1;
+            if (n < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) roff[q] = ((n * a.H + iy) * a.W + ix) * a.C + gg * 4;
+            rsto[q] = il * 32 + gg * 4;
+            rlds[q] = px * SRLD + gg * 4;
+        }
+    }
+    f32x4 sreg = {0.f, 0.f, 0.f, 0.f};
+    auto stat_load = [&](int cc) {                      // threads 0..127 (group A)
+        if constexpr (NORM) {
+            if (tid < 128) {
+                const int il = tid >> 3, which = (tid >> 2) & 1, c4 = tid & 3;
+                const int n = img0 + il < a.B ? img0 + il : a.B - 1;
+                const int c = cc < nchunks ? cc : nchunks - 1;
+                sreg = *reinterpret_cast<const f32x4*>((which ? a.in_rstd : a.in_mean) + (long long)n * a.C + c * SK + c4 * 4);
+            }
+        }
+    };
+    auto stat_write = [&](int cc) {
+        if constexpr (NORM) {
+            if (tid < 128) {
+                const int il = tid >> 3, which = (tid >> 2) & 1, c4 = tid & 3;
+                *reinterpret_cast<f32x4*>(sS + (cc & 1) * 512 + il * 32 + which * 16 + c4 * 4) = sreg;
+            }
+        }
+    };
+    // ---- transform role (g, ts, h) of the thread inside its group; the group is the xi half
+    const int w4 = wave & 3;
+    const int g = tid & 3, ts = ((lane >> 5) & 1) | (((lane >> 2) & 7) << 1) | ((w4 & 1) << 4);
+    const int h = w4 >> 1;
+    const int sil = ts / tpi, srem = ts - sil * tpi, styl = srem / a.TXB, stxl = srem - styl * a.TXB;
+    const int praw = (ts < a.IB * tpi) ? ((sil * RH + 2 * styl) * RW + 2 * stxl + h) * SRLD + g * 4 : g * 4;
+
+    f32x4 rreg[RPT];
+    auto raw_load = [&](int cc) {
+        const int c = cc < nchunks ? cc : nchunks - 1;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int off = roff[q] < 0 ? 0 : roff[q];
+            rreg[q] = *reinterpret_cast<const f32x4*>(a.x + (long long)off + c * SK);
+        }
+    };
+    auto raw_write = [&](int cc) {                      // -> R[cc & 1], statistics S[cc & 1]
+        float* dst = sR + (cc & 1) * R_DW;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            f32x4 x = rreg[q];
+            if constexpr (NORM) {
+                const f32x4 mu = *reinterpret_cast<const f32x4*>(sS + (cc & 1) * 512 + rsto[q]);
+                const f32x4 rs = *reinterpret_cast<const f32x4*>(sS + (cc & 1) * 512 + rsto[q] + 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = fmaxf((x[e] - mu[e]) * rs[e], 0.f);
+            }
+            const bool ok = roff[q] >= 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = ok ? x[e] : 0.f;
+            if (roff[q] != -2) *reinterpret_cast<f32x4*>(dst + rlds[q]) = x;
+        }
+    };
+    auto xi_out = [&](unsigned* vdst, int xi, const f32x4 (&T)[3]) {
+        f32x4 o0, o1;
+        if (h == 0) { o0 = T[0] - T[2]; o1 = T[1] + T[2]; }
+        else { o0 = T[1] - T[0]; o1 = T[0] - T[2]; }
+        const int pos = xi * 4 + 2 * h;
+        u32x2_t ph, pm, pl;
+        unsigned* d0 = vdst + (pos * WTT + ts) * SVLD + g * 2;
+        cut4(o0, ph, pm, pl);
+        *reinterpret_cast<u32x2_t*>(d0) = ph;
+        *reinterpret_cast<u32x2_t*>(d0 + 8) = pm;
+        *reinterpret_cast<u32x2_t*>(d0 + 16) = pl;
+        unsigned* d1 = d0 + WTT * SVLD;
+        cut4(o1, ph, pm, pl);
+        *reinterpret_cast<u32x2_t*>(d1) = ph;
+        *reinterpret_cast<u32x2_t*>(d1 + 8) = pm;
+        *reinterpret_cast<u32x2_t*>(d1 + 16) = pl;
+    };
+    // half (xi rows {2 half, 2 half + 1}) of the transform of chunk cc: R[cc & 1] -> V[cc & 1]; column by column, so only
+    // the two rows' column sums stay live (24 registers), not the 3 x 3 window
+    auto transform_half = [&](int cc, int half) {
+        const float* r = sR + (cc & 1) * R_DW + praw;
+        unsigned* vdst = sV + (cc & 1) * SV_DW;
+        f32x4 TA[3], TB[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                   // rows half, half+1, half+2 of the 4 x 3 window
+            const f32x4 Ra = *reinterpret_cast<const f32x4*>(r + ((half + 0) * RW + c) * SRLD);
+            const f32x4 Rb = *reinterpret_cast<const f32x4*>(r + ((half + 1) * RW + c) * SRLD);
+            const f32x4 Rc = *reinterpret_cast<const f32x4*>(r + ((half + 2) * RW + c) * SRLD);
+            if (half == 0) { TA[c] = Ra - Rc; TB[c] = Rb + Rc; }     // xi 0: R0 - R2, xi 1: R1 + R2
+            else { TA[c] = Rb - Ra; TB[c] = Ra - Rc; }               // xi 2: R2 - R1, xi 3: R1 - R3
+        }
+        xi_out(vdst, 2 * half, TA);
+        xi_out(vdst, 2 * half + 1, TB);
+    };
+    // ---- MFMA job
+    const unsigned short* ub16 = reinterpret_cast<const unsigned short*>(a.u);
+    const long long uplane = (long long)a.Cout * SK;
+    const long long uchunk = 3 * uplane;
+    const long long upos = (long long)nchunks * uchunk;
+    const unsigned short* ubase = ub16 + (long long)(8 * wp) * upos + (long long)(n0 + wn * 32) * SK;
+    const int ulane = l31 * SK + 8 * hi;
+    auto uload = [&](int p, int cc, u32x4_t (&w)[3]) {
+        const unsigned short* q = ubase + p * upos + cc * uchunk + ulane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const u32x4_t*>(q + pl * uplane);
+    };
+    f32x16 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    const int vfo = ((8 * wp) * WTT + l31) * SVLD + 4 * hi;   // dwords
+    union Frag { u32x4_t u; bf16x8_t v; };
+    u32x4_t w[UD + 1][3];
+    auto mfma_job = [&](int cc) {                       // the first UD fragments of chunk cc were requested at the end of the staging job
+        const unsigned* vsrc = sV + (cc & 1) * SV_DW + vfo;
+        Frag vq[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) vq[0][pl].u = *reinterpret_cast<const u32x4_t*>(vsrc + pl * 8);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            if (p + UD < 8) uload(p + UD, cc, w[(p + UD) % (UD + 1)]);
+            Frag wb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                if (p < 7) vq[(p + 1) & 1][pl].u = *reinterpret_cast<const u32x4_t*>(vsrc + (p + 1) * WTT * SVLD + pl * 8);
+                wb[pl].u = w[p % (UD + 1)][pl];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const Frag (&v)[3] = vq[p & 1];
+            if constexpr (NP == 9) {
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2].v, wb[2].v, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1].v, wb[2].v, acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2].v, wb[1].v, acc[p], 0, 0, 0);
+            }
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[2].v, wb[0].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0].v, wb[2].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1].v, wb[1].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[1].v, wb[0].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0].v, wb[1].v, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[0].v, wb[0].v, acc[p], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // staging job of chunk index c: raw(c+2) registers -> R[c&1] first (frees the registers), the loads of raw(c+3) next
+    // (they have the whole transform to land), this group's half of transform(c+1), group A's statistics hand-over, and
+    // last the first UD weight fragments of the MFMA job that follows (chunk unext)
+    auto stage_job = [&](int c, int unext) {
+        if (c + 2 < nchunks) raw_write(c + 2);
+        if (c + 3 < nchunks) raw_load(c + 3);
+        if (c + 1 < nchunks) transform_half(c + 1, grp);
+        if (grp == 0) {                                  // statistics(c+3) -> S[(c+3)&1] (last read by raw_write(c+1)), request (c+4)
+            if (c + 3 < nchunks) stat_write(c + 3);
+            if (c + 4 < nchunks) stat_load(c + 4);
+        }
+        if (unext < nchunks) {
+#pragma unroll
+            for (int p = 0; p < UD; ++p) uload(p, unext, w[p]);
+        }
+    };
+
+    // ---- prologue (both groups in phase): V[0] = T(0), R[1] = raw(1), registers = raw(2), S[0] = statistics(2), A: (3) pending
+    raw_load(0); stat_load(0); stat_write(0);
+    __syncthreads();
+    raw_write(0);
+    if (nchunks > 1) { raw_load(1); stat_load(1); stat_write(1); }
+    __syncthreads();
+    transform_half(0, grp);
+    if (nchunks > 1) raw_write(1);
+    if (nchunks > 2) { raw_load(2); stat_load(2); stat_write(2); }   // S[0] was last read before the barrier above
+    if (nchunks > 3) stat_load(3);
+    if (grp == 0) {
+#pragma unroll
+        for (int p = 0; p < UD; ++p) uload(p, 0, w[p]);
+    }
+    __syncthreads();
+    // two straight-line programs (no control-flow join inside the loop: joined once per half-step the register allocator
+    // sees the SUM of both jobs' live ranges and spills ~400 registers), the same barrier sequence on both
+#ifdef DSMIL_TRACE
+#define ALT_STAMP(slot)                                                                                             \
+    do {                                                                                                            \
+        if (a.trace && blockIdx.x < 4 && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0 && c < 256)                \
+            a.trace[(((long long)blockIdx.x * 2 + grp) * 256 + c) * 8 + (slot)] = __builtin_amdgcn_s_memtime();     \
+    } while (0)
+#else
+#define ALT_STAMP(slot) do { } while (0)
+#endif
+    if (grp == 0) {
+        for (int c = 0; c < nchunks; ++c) {
+            ALT_STAMP(0);
+            mfma_job(c);                // half-step 2c
+            ALT_STAMP(1);
+            __syncthreads();
+            ALT_STAMP(2);
+            stage_job(c, c + 1);        // half-step 2c+1
+            ALT_STAMP(3);
+            __syncthreads();
+            ALT_STAMP(4);
+        }
+    } else {
+        for (int c = 0; c < nchunks; ++c) {
+            ALT_STAMP(0);
+            stage_job(c, c);            // half-step 2c
+            ALT_STAMP(1);
+            __syncthreads();
+            ALT_STAMP(2);
+            mfma_job(c);                // half-step 2c+1
+            ALT_STAMP(3);
+            __syncthreads();
+            ALT_STAMP(4);
+        }
     }
     wino_epilogue(a, acc, smem, lane, wn, wp, n0, img0, ty0, tx0, tpi, pb);
 }
@@ -1088,15 +1414,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino_s3(WinoArgs a) {
 // --------------------------------------------------------------------------------------------
 #ifndef PP_UD
 #define PP_UD 3
-#endif
-#ifdef DSMIL_TRACE
-#define PP_STAMP(slot)                                                                                              \
-    do {                                                                                                            \
-        if (a.trace && blockIdx.x < 4 && lane == 0 && (wave8 & 3) == 0 && s < 256)                                  \
-            a.trace[(((long long)blockIdx.x * 2 + (wave8 >> 2)) * 256 + s) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define PP_STAMP(slot) do { } while (0)
 #endif
 template <bool NORM, int NP, int UD>
 __global__ __launch_bounds__(512, 2) void k_conv_wino_pp(WinoArgs a, int nunits, int nitems) {
@@ -1368,6 +1685,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_wino_pp(WinoArgs a, int nunits,
         jC = jN; ccC = ccN; itC = itN; up0 = up1;
     }
 }
+
+#endif  // DSMIL_EXPERIMENTS
 
 // conv weight [O][I][3][3] -> U = G g G^T cut into three bf16 planes: [16 pos][I/16][3][O][16]
 __global__ void k_pack_wino_s3(const float* __restrict__ w, unsigned short* __restrict__ out, int O, int I) {
@@ -1838,14 +2157,28 @@ inline int wino_form() {
     return form;
 }
 inline bool wino_s3() { return wino_form() != 0; }
-// DSMIL_WINO_KERNEL = unit (default: one workgroup per unit, k_conv_wino_s3) | pp (persistent role-split k_conv_wino_pp)
-inline int wino_unit_kernel() {
-    static const int unit = [] {
-        const char* e = getenv("DSMIL_WINO_KERNEL");
-        return (e && !strcmp(e, "pp")) ? 0 : 1;
-    }();
-    return unit;
+#ifndef WIDE_UC
+#define WIDE_UC false
+#endif
+#define WIDE_UD (WIDE_UC ? 3 : 2)
+inline bool wino_wide() {   // expt builds: DSMIL_WINO_NARROW=1 keeps the 64-cout workgroups everywhere (A/B)
+#ifdef DSMIL_EXPERIMENTS
+    static const int narrow = expt_env("DSMIL_WINO_NARROW");
+    return !narrow;
+#else
+    return true;
+#endif
 }
+#ifdef DSMIL_EXPERIMENTS
+// experiment builds: DSMIL_WINO_KERNEL = pp (persistent role-split k_conv_wino_pp) | alt (k_conv_wino_alt, 128-cout layers)
+inline int wino_expt_kernel() {
+    static const int k = [] {
+        const char* e = getenv("DSMIL_WINO_KERNEL");
+        return (e && !strcmp(e, "pp")) ? 1 : (e && !strcmp(e, "alt")) ? 2 : 0;
+    }();
+    return k;
+}
+#endif
 #ifdef DSMIL_TRACE
 constexpr size_t WINO_TRACE_WORDS = 4 * 2 * 256 * 8;
 inline unsigned long long* wino_trace_buffer() {
@@ -2013,6 +2346,7 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
                 allow_lds((const void*)kern, l);
                 hipLaunchKernelGGL(kern, grid, dim3(256), l, st, wa);
             };
+#ifdef DSMIL_EXPERIMENTS
             static const int ncu = [] {
                 int dev = 0, n = 0;
                 (void)hipGetDevice(&dev);
@@ -2025,9 +2359,39 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
                 allow_lds((const void*)kern, lds_pp);
                 hipLaunchKernelGGL(kern, dim3((unsigned)(nitems < ncu ? nitems : ncu)), dim3(512), lds_pp, st, wa, nunits, nitems);
             };
-            if (wino_unit_kernel() == 0) {
+            const dim3 grida(grid.x, (unsigned)(s.cout / 128));
+            auto goa = [&](auto kern) {
+                allow_lds((const void*)kern, lds_pp);
+                hipLaunchKernelGGL(kern, grida, dim3(512), lds_pp, st, wa);
+            };
+            const int which = wino_expt_kernel();   // DSMIL_WINO_KERNEL = pp | alt
+#else
+            constexpr int which = 0;
+#endif
+            if (which == 1) {
+#ifdef DSMIL_EXPERIMENTS
                 if (in_mean) { if (np9) go_pp(k_conv_wino_pp<true, 9, PP_UD>); else go_pp(k_conv_wino_pp<true, 6, PP_UD>); }
                 else { if (np9) go_pp(k_conv_wino_pp<false, 9, PP_UD>); else go_pp(k_conv_wino_pp<false, 6, PP_UD>); }
+#endif
+            } else if (which == 2 && s.cout % 128 == 0) {
+#ifdef DSMIL_EXPERIMENTS
+                if (in_mean) { if (np9) goa(k_conv_wino_alt<true, 9>); else goa(k_conv_wino_alt<true, 6>); }
+                else { if (np9) goa(k_conv_wino_alt<false, 9>); else goa(k_conv_wino_alt<false, 6>); }
+#endif
+            } else if (s.cout % 128 == 0 && wino_wide()) {
+                // 128 couts per workgroup (512 threads, one workgroup per CU): half the staging work per MFMA
+                const dim3 gridw(grid.x, (unsigned)(s.cout / 128));
+                auto gow = [&](auto kern, size_t l) {
+                    allow_lds((const void*)kern, l);
+                    hipLaunchKernelGGL(kern, gridw, dim3(512), l, st, wa);
+                };
+                if (in_mean) {
+                    if (np9) gow(k_conv_wino_s3<true, WIDE_UD, true, 9, 4, WIDE_UC>, lds_ls);
+                    else gow(k_conv_wino_s3<true, WIDE_UD, true, 6, 4, WIDE_UC>, lds_ls);
+                } else {
+                    if (np9) gow(k_conv_wino_s3<false, WIDE_UD, false, 9, 4, WIDE_UC>, lds);
+                    else gow(k_conv_wino_s3<false, WIDE_UD, false, 6, 4, WIDE_UC>, lds);
+                }
             } else if (in_mean) {
                 if (np9) go(k_conv_wino_s3<true, 2, true, 9>, lds_ls);
                 else go(k_conv_wino_s3<true, 2, true, 6>, lds_ls);

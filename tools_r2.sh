@@ -24,11 +24,17 @@ tests_bf16)
 variants_bf16)
   DSMIL_NATIVE_LIB=libdsmil_hip_expt.so timeout 900 python tools_variants.py aggregator_bf16 dma8: dma4:DSMIL_EXPT=512 old:DSMIL_EXPT=256 > $OUT/variants_bf16.log 2>&1; cat $OUT/variants_bf16.log;;
 tests_emb)
-  timeout 900 python -m pytest tests/test_resnet_gpu.py tests/test_forms_gpu.py -m gpu -x -q > $OUT/pytest_emb.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_emb.log;;
+  timeout 900 env DSMIL_WINO_KERNEL=${WINO_KERNEL:-unit} python -m pytest tests/test_resnet_gpu.py tests/test_forms_gpu.py -m gpu -x -q > $OUT/pytest_emb.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_emb.log;;
 variants_pp)
-  VARIANT_ROUNDS=${VARIANT_ROUNDS:-2} timeout 900 python tools_variants.py embedder pp: unit:DSMIL_WINO_KERNEL=unit > $OUT/variants_pp.log 2>&1; cat $OUT/variants_pp.log;;
+  VARIANT_ROUNDS=${VARIANT_ROUNDS:-2} timeout 900 python tools_variants.py embedder pp:DSMIL_WINO_KERNEL=pp unit:DSMIL_WINO_KERNEL=unit > $OUT/variants_pp.log 2>&1; cat $OUT/variants_pp.log;;
 stamps_wino)
-  for k in ${STAMP_K:-1 12}; do DSMIL_NATIVE_LIB=libdsmil_hip_trace.so DSMIL_WINO_TRACE=$k timeout 300 python tools_stamp_wino.py > $OUT/stamps_wino_$k.log 2>&1; echo "== launch $k"; tail -14 $OUT/stamps_wino_$k.log | cut -c1-400; done;;
+  for k in ${STAMP_K:-1 12}; do DSMIL_WINO_KERNEL=${WINO_KERNEL:-unit} DSMIL_NATIVE_LIB=libdsmil_hip_trace.so DSMIL_WINO_TRACE=$k timeout 300 python tools_stamp_wino.py > $OUT/stamps_wino_$k.log 2>&1; echo "== launch $k"; tail -14 $OUT/stamps_wino_$k.log | cut -c1-400; done;;
+variants_wide)
+  DSMIL_NATIVE_LIB=libdsmil_hip_expt.so VARIANT_ROUNDS=${VARIANT_ROUNDS:-2} timeout 900 python tools_variants.py embedder wide: narrow:DSMIL_WINO_NARROW=1 > $OUT/variants_wide.log 2>&1; cat $OUT/variants_wide.log;;
+variants_uc)
+  VARIANT_ROUNDS=${VARIANT_ROUNDS:-2} timeout 900 python tools_variants.py embedder uc: nouc:DSMIL_NATIVE_LIB=libdsmil_hip_nouc.so > $OUT/variants_uc.log 2>&1; cat $OUT/variants_uc.log;;
+variants_alt)
+  VARIANT_ROUNDS=${VARIANT_ROUNDS:-2} timeout 900 python tools_variants.py embedder alt: wide:DSMIL_WINO_ALT=0 > $OUT/variants_alt.log 2>&1; cat $OUT/variants_alt.log;;
 tests_new)
   timeout 900 python -m pytest tests/test_agg_bwd_gpu.py tests/test_agg_gpu.py tests/test_entry_points.py -m gpu -x -q > $OUT/pytest_new.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_new.log;;
 stamps)

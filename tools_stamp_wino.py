@@ -3,7 +3,9 @@
     python dsmil-wsi_amd/build.py --variant trace -DDSMIL_EXPERIMENTS -DDSMIL_TRACE
     DSMIL_NATIVE_LIB=libdsmil_hip_trace.so DSMIL_WINO_TRACE=<k> python tools_stamp_wino.py
 k = which Winograd launch of the process records (1 = first conv of the first forward; one forward of ResNet-18 has 13).
-Multiply wave (role 0) slots: 0 step top, 1 after position 3, 2 after position 7, 3 after the barrier, 4 after the epilogue.
+k_conv_wino_s3 (unit kernel; wave 0 = role 0, last wave = role 1; a step = one chunk): 0 top, 1 after the MFMAs, 2 after
+raw_write + raw_load, 3 after barrier 1, 4 after the transform, 5 after barrier 2.
+k_conv_wino_pp: multiply wave (role 0) slots: 0 step top, 1 after position 3, 2 after position 7, 3 after the barrier, 4 after the epilogue.
 Staging wave (role 1) slots: 0 top, 1 after the transform, 2 after raw_write, 3 after raw_load + statistics, 4 after the barrier."""
 import ctypes
 import os
@@ -41,7 +43,7 @@ for wg in range(2):
         t = t[:n]
         step = np.diff(t[:, 0])
         print(f"wg {wg} {name}: steps {n}, step period median {np.median(step):.0f} mean {step.mean():.0f} ticks")
-        segs = np.diff(t[:, :5], axis=1)
-        print("   segment medians (slot k -> k+1):", np.median(segs, axis=0).astype(int).tolist(), " (slot 4 only at unit ends for multiply)")
+        ns = 6 if (t[:, 5] > 0).any() else 5
+        segs = np.diff(t[:, :ns], axis=1)
+        print("   segment medians (slot k -> k+1):", np.median(segs, axis=0).astype(int).tolist())
         print("   first 24 step periods:", step[:24].tolist())
-        print("   first 12 rows of segments:", segs[:12].tolist())
