@@ -25,6 +25,7 @@
 // the NHWC store is 128-B coalesced.
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include <math.h>
 #include <stdio.h>
@@ -1942,6 +1943,187 @@ __global__ __launch_bounds__(256) void k_stem(const void* __restrict__ xin, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_stem_s6: the same 7x7 stride-2 conv on bf16 MFMA over exact three-plane cuts (6 plane products, see agg_split.h).
+// K is laid out (c, kh, kw padded to 8): 21 rows of 8 = 168, padded to 176 = 11 steps of 16, so the 8 k of a lane are
+// 8 CONSECUTIVE columns of one window row — the A fragment is read straight from the input window in LDS (4 dwords per
+// plane), no im2col.  Every input element is cut ONCE when its window is staged (the 49/4 windows that overlap it
+// share the planes); the weights are cut at pack time (k_pack_stem_s6: [3 planes][64][184] bf16, 368-B rows =
+// conflict-free ds_read_b128).  Workgroup = 16 x 16 output pixels x 64 channels, 8 waves (two rows each), walking a
+// row of tiles with the next window prefetched into registers; the two cout halves alternate inside each plane
+// product, so no MFMA accumulates into the tile the previous one is still writing.
+//   LDS: window 2 buffers x 3 planes x 3 x 37 x 40 bf16 = 52 KB, weights 3 x 64 x 184 bf16 = 69 KB.
+// ---------------------------------------------------------------------------------------------
+constexpr int SS_TR = 16;                                   // output rows per tile
+constexpr int SS_ROWS = 2 * SS_TR + 5, SS_LW = 40, SS_PLANE = SS_ROWS * SS_LW, SS_WIN = 3 * SS_PLANE;
+constexpr int SS_KP = 176, SS_LDW = 184;                    // padded K, weight row stride (bf16)
+constexpr int SS_WIMG = 3 * 64 * SS_LDW;                    // bf16 elements of the packed stem image
+constexpr int SS_PPT = (SS_WIN / 2 + 511) / 512;            // window element PAIRS per thread
+constexpr size_t SS_LDS = (size_t)(2 * 3 * SS_WIN + SS_WIMG) * 2;
+
+// conv1 weight [64][3][7][7] -> three truncated bf16 planes [3][64][184], k' = (c*7 + kh)*8 + kw
+__global__ void k_pack_stem_s6(const float* __restrict__ w, unsigned short* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * SS_LDW; i += gridDim.x * blockDim.x) {
+        const int co = i / SS_LDW, k = i - co * SS_LDW;
+        const int row = k >> 3, kw = k & 7;
+        float v = 0.f;
+        if (row < 21 && kw < 7) v = w[co * 147 + (row / 7) * 49 + (row % 7) * 7 + kw];
+        const unsigned hb = __float_as_uint(v) & 0xFFFF0000u;
+        const float r1 = v - __uint_as_float(hb);
+        const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
+        const unsigned lb = __float_as_uint(r1 - __uint_as_float(mb));
+        out[i] = (unsigned short)(hb >> 16);
+        out[64 * SS_LDW + i] = (unsigned short)(mb >> 16);
+        out[2 * 64 * SS_LDW + i] = (unsigned short)(lb >> 16);
+    }
+}
+
+__host__ __device__ constexpr int stem6_off(int row) {      // window element offset of K row (c, kh); row 21 is padding
+    return row >= 21 ? 0 : (row / 7) * SS_PLANE + (row % 7) * SS_LW;
+}
+
+template <bool U8>
+__global__ __launch_bounds__(512, 2) void k_stem_s6(const void* __restrict__ xin, const unsigned short* __restrict__ wimg,
+                                                    float* __restrict__ y, float* __restrict__ part, int B, int H, int W,
+                                                    int Ho, int Wo, int tiles_x, int tiles_y) {
+    const float* x = reinterpret_cast<const float*>(xin);
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(xin);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* sIn = reinterpret_cast<unsigned short*>(smem);         // [2][3 planes][SS_WIN]
+    unsigned short* sW = sIn + 2 * 3 * SS_WIN;                              // [3][64][SS_LDW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int ty = blockIdx.x, n = blockIdx.y;
+    const int oy0 = ty * SS_TR;
+    const int iy00 = oy0 * 2 - 3;
+    // per-thread window pairs (two adjacent columns of one row): row base offset in x (or -1) and the first column
+    int wrow[SS_PPT], wcol[SS_PPT];
+#pragma unroll
+    for (int q = 0; q < SS_PPT; ++q) {
+        const int e = 2 * (tid + 512 * q);
+        wrow[q] = -1; wcol[q] = 0;
+        if (e < SS_WIN) {
+            const int c = e / SS_PLANE, r = (e - c * SS_PLANE) / SS_LW, col = e - c * SS_PLANE - r * SS_LW;
+            const int iy = iy00 + r;
+            wcol[q] = col;
+            if (iy >= 0 && iy < H) wrow[q] = U8 ? ((n * H + iy) * W) * 3 + c : ((n * 3 + c) * H + iy) * W;
+        }
+    }
+    float wreg[SS_PPT][2];
+    auto win_load = [&](int tx) {
+        const int ix00 = tx * 32 - 3;
+#pragma unroll
+        for (int q = 0; q < SS_PPT; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ix = ix00 + wcol[q] + j;
+                const bool ok = wrow[q] >= 0 && ix >= 0 && ix < W && wcol[q] + j < 39;
+                float v;
+                if constexpr (U8) v = __fdiv_rn((float)xb[ok ? (long long)wrow[q] + 3 * ix : 0], 255.f);
+                else v = x[ok ? (long long)wrow[q] + ix : 0];
+                wreg[q][j] = ok ? v : 0.f;
+            }
+    };
+    auto win_write = [&](int buf) {                         // cut once, three 4-byte plane writes per pair
+        unsigned* dst = reinterpret_cast<unsigned*>(sIn + buf * 3 * SS_WIN);
+#pragma unroll
+        for (int q = 0; q < SS_PPT; ++q) {
+            const int e2 = tid + 512 * q;                   // pair index
+            if (2 * e2 < SS_WIN) {
+                unsigned xu[2], r1u[2], r2u[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    xu[j] = __float_as_uint(wreg[q][j]);
+                    const float r1 = wreg[q][j] - __uint_as_float(xu[j] & 0xFFFF0000u);
+                    r1u[j] = __float_as_uint(r1);
+                    r2u[j] = __float_as_uint(r1 - __uint_as_float(r1u[j] & 0xFFFF0000u));
+                }
+                dst[e2] = __builtin_amdgcn_perm(xu[1], xu[0], 0x07060302u);
+                dst[SS_WIN / 2 + e2] = __builtin_amdgcn_perm(r1u[1], r1u[0], 0x07060302u);
+                dst[SS_WIN + e2] = __builtin_amdgcn_perm(r2u[1], r2u[0], 0x07060302u);
+            }
+        }
+    };
+    win_load(0);
+    {   // the packed weight image -> LDS (16-B pieces)
+        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(wimg);
+        u32x4_t* dstw = reinterpret_cast<u32x4_t*>(sW);
+        for (int e = tid; e < SS_WIMG / 8; e += 512) dstw[e] = src[e];
+    }
+    win_write(0);
+    __syncthreads();
+    const int py = 2 * wave + (l31 >> 4), px = l31 & 15;
+    const int pixbase = (2 * py) * SS_LW + 2 * px;          // window element of this lane's pixel (even: 4-byte aligned)
+    const int wfrag = l31 * SS_LDW + 8 * hi;                // bf16 elements inside a plane's [64][184]
+    for (int tx = 0; tx < tiles_x; ++tx) {
+        const int ox0 = tx * 16;
+        if (tx + 1 < tiles_x) win_load(tx + 1);
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        const unsigned short* win = sIn + (tx & 1) * 3 * SS_WIN + pixbase;
+#pragma unroll
+        for (int st = 0; st < SS_KP / 16; ++st) {
+            const int off = hi ? stem6_off(2 * st + 1) : stem6_off(2 * st);
+            Frag16 xa[3], wb[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const unsigned* a4 = reinterpret_cast<const unsigned*>(win + pl * SS_WIN + off);
+                xa[pl].u = u32x4_t{a4[0], a4[1], a4[2], a4[3]};
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    wb[t][pl].u = *reinterpret_cast<const u32x4_t*>(sW + (pl * 64 + t * 32) * SS_LDW + wfrag + st * 16);
+            }
+            // smallest products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+            constexpr int PX[6] = {2, 0, 1, 1, 0, 0}, PW[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PX[k]].v, wb[t][PW[k]].v, acc[t], 0, 0, 0);
+        }
+        if (tx + 1 < tiles_x) win_write((tx + 1) & 1);
+        // store raw NHWC + statistics partial (cnt, mean, M2) per (image, tile, wave, channel)
+        int cnt = 0;
+        float s0 = 0.f, s1 = 0.f;
+        bool okr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = drow(r, hi);
+            const int oy = oy0 + 2 * wave + (q >> 4), ox = ox0 + (q & 15);
+            okr[r] = (oy < Ho) && (ox < Wo);
+            if (okr[r]) {
+                float* o = y + (((long long)n * Ho + oy) * Wo + ox) * 64;
+                o[l31] = acc[0][r];
+                o[32 + l31] = acc[1][r];
+                s0 += acc[0][r];
+                s1 += acc[1][r];
+                ++cnt;
+            }
+        }
+        cnt += __shfl_xor(cnt, 32, 64);
+        s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        const float fc = (float)cnt;
+        const float m0 = cnt ? s0 / fc : 0.f, m1 = cnt ? s1 / fc : 0.f;
+        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (okr[r]) {
+                const float d0 = acc[0][r] - m0, d1 = acc[1][r] - m1;
+                q0 += d0 * d0;
+                q1 += d1 * d1;
+            }
+        q0 += __shfl_xor(q0, 32, 64);
+        q1 += __shfl_xor(q1, 32, 64);
+        if (hi == 0) {
+            float* o = part + ((((long long)n * tiles_x * tiles_y + ty * tiles_x + tx) * 8 + wave) * 64) * 3;
+            o[l31 * 3 + 0] = fc; o[l31 * 3 + 1] = m0; o[l31 * 3 + 2] = q0;
+            o[(32 + l31) * 3 + 0] = fc; o[(32 + l31) * 3 + 1] = m1; o[(32 + l31) * 3 + 2] = q1;
+        }
+        __syncthreads();
+    }
+}
+
 // stem partials (cnt, mean, M2) -> mean / rstd; one workgroup per image, 64 channels x 16 tile groups (392 partials
 // per channel at 224x224: a chain of dependent loads per thread, so width is what makes it short)
 constexpr int FS_G = 16;
@@ -2269,7 +2451,9 @@ RWs rws_layout(int B, int H, int W, int depth = 18) {
     for (int k = 0; k < 4; ++k)
         for (int j = 0; j < 2; ++j) { r.stat[k][j] = o; o = al256(o + (size_t)B * 512 * exp * 4); }
     // partials: stem (n, tiles*4, 64, 3) or flat (tiles32, nslots, C, 2); take the max over layers
-    const long long stem_parts = (long long)B * ((d.H1 + 7) / 8) * ((d.W1 + 15) / 16) * 4 * 64 * 3;
+    // per (image, tile, wave): 8 x 16-pixel tiles x 4 waves (k_stem) or 16 x 16 x 8 waves (k_stem_s6), whichever is more
+    const long long stem_rows = std::max<long long>(((d.H1 + 7) / 8) * 4, ((d.H1 + SS_TR - 1) / SS_TR) * 8);
+    const long long stem_parts = (long long)B * stem_rows * ((d.W1 + 15) / 16) * 64 * 3;
     long long mx = stem_parts;
     for (int l = 1; l <= 4; ++l) {
         const int Cw = 64 << (l - 1);
@@ -2490,9 +2674,10 @@ int dsmil_resnet_mfma_forms(int32_t* wino_products, int32_t* direct_products) {
 
 int32_t dsmil_resnet_num_convs(int32_t depth) { const Arch* A = arch_of(depth); return A ? A->nconv : 0; }
 int32_t dsmil_resnet_norm_channels(int32_t depth) { const Arch* A = arch_of(depth); return A ? norm_offset(*A, A->nconv) : 0; }
+// the packed image ends with the stem's three bf16 planes (k_stem_s6; conv 0 keeps its raw OIHW argument for the f32 form)
 size_t dsmil_resnet_packed_bytes(int32_t depth) {
     const Arch* A = arch_of(depth);
-    return A ? pack_offset(*A, A->nconv) * sizeof(float) : 0;
+    return A ? (pack_offset(*A, A->nconv) + SS_WIMG / 2) * sizeof(float) : 0;
 }
 
 int dsmil_resnet_pack(int32_t depth, const float* const* conv_w, float* packed, void* stream) {
@@ -2500,6 +2685,10 @@ int dsmil_resnet_pack(int32_t depth, const float* const* conv_w, float* packed, 
     if (!A) return DSMIL_E_UNSUPPORTED;
     if (!conv_w || !packed) return DSMIL_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    if (!conv_w[0]) return DSMIL_E_INVALID;
+    hipLaunchKernelGGL(k_pack_stem_s6, dim3(46), dim3(256), 0, st, conv_w[0],
+                       (unsigned short*)(packed + pack_offset(*A, A->nconv)));
+    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     for (int i = 1; i < A->nconv; ++i) {
         if (!conv_w[i]) return DSMIL_E_INVALID;
         const ConvSpec& s = A->specs[i];
@@ -2575,15 +2764,25 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
 
     // ---- stem: conv1 -> IN -> ReLU -> maxpool
     {
-        const int tx = (d.W1 + 15) / 16, ty = (d.H1 + 7) / 8;
-        if (u8) hipLaunchKernelGGL(k_stem<true>, dim3((unsigned)ty, (unsigned)B), dim3(256), 0, st, x_nchw, conv1_w, y0,
-                                   part, B, H, W, d.H1, d.W1, tx, ty);
+        const bool s6 = conv_s6();   // DSMIL_CONV: the stem follows the direct convs' MFMA form
+        const int tx = (d.W1 + 15) / 16, ty = s6 ? (d.H1 + SS_TR - 1) / SS_TR : (d.H1 + 7) / 8;
+        if (s6) {
+            const unsigned short* wimg = (const unsigned short*)(packed + pack_offset(A, A.nconv));
+            allow_lds((const void*)k_stem_s6<true>, SS_LDS);
+            allow_lds((const void*)k_stem_s6<false>, SS_LDS);
+            if (u8) hipLaunchKernelGGL(k_stem_s6<true>, dim3((unsigned)ty, (unsigned)B), dim3(512), SS_LDS, st, x_nchw, wimg, y0,
+                                       part, B, H, W, d.H1, d.W1, tx, ty);
+            else hipLaunchKernelGGL(k_stem_s6<false>, dim3((unsigned)ty, (unsigned)B), dim3(512), SS_LDS, st, x_nchw, wimg, y0,
+                                    part, B, H, W, d.H1, d.W1, tx, ty);
+        }
+        else if (u8) hipLaunchKernelGGL(k_stem<true>, dim3((unsigned)ty, (unsigned)B), dim3(256), 0, st, x_nchw, conv1_w, y0,
+                                        part, B, H, W, d.H1, d.W1, tx, ty);
         else hipLaunchKernelGGL(k_stem<false>, dim3((unsigned)ty, (unsigned)B), dim3(256), 0, st, x_nchw, conv1_w, y0,
                                 part, B, H, W, d.H1, d.W1, tx, ty);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         if (bn_m) { const int rcf = fill_stats(st, bm(0), br(0), mean[0], rstd[0], B, 64); if (rcf) return rcf; }
         else hipLaunchKernelGGL(k_in_finalize_stem, dim3((unsigned)B), dim3(64 * FS_G), 0, st, part,
-                                mean[0], rstd[0], B, tx * ty * 4);
+                                mean[0], rstd[0], B, tx * ty * (s6 ? 8 : 4));
         const long long total = (long long)B * d.Hp * d.Wp * 16;
         long long blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
