@@ -55,3 +55,30 @@ for k, v in out.items():
 json.dump(out, open(os.path.join(dst, "pmc_per_launch.json"), "w"), indent=1, sort_keys=True)
 for k, v in out.items():
     print(k, {c: v[c] for c in ("hbm_bytes_per_launch", "mfma_util", "lds_conflict_frac") if c in v})
+
+# the files bench.py reads for roofline.traffic
+prof = os.path.dirname(os.path.abspath(dst))
+rel = os.path.relpath(os.path.join(dst, "pmc_per_launch.json"), os.path.dirname(prof))
+how = "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate rocprofv3 --pmc passes (tools_r2.sh pmc_%s)" % which
+if which == "agg":
+    for fname, pref, alg in (("pmc_k_query_attend.json", "k_query_attend_split", 1337271040),
+                             ("pmc_k_query_attend_bf16.json", "k_query_attend_bf16", 676774912)):
+        ks = [k for k in out if k.startswith(pref) and "hbm_bytes_per_launch" in out[k]]
+        if ks:
+            k = max(ks, key=lambda n: out[n].get("launches_sampled", 0))
+            json.dump({"kernel": k, "hbm_bytes_per_launch": out[k]["hbm_bytes_per_launch"],
+                       "mfma_util": out[k].get("mfma_util"), "source": rel + ": " + how,
+                       "algorithmic_bytes_per_launch": alg}, open(os.path.join(prof, fname), "w"), indent=1)
+if which == "emb" and stats:
+    calls = {short(r[0]): int(r[1]) for r in rows[1:]}
+    fwd = max([c for k, c in calls.items() if k.startswith("k_stem")] or [1])
+    tot, n, names = 0, 0, []
+    for k, v in out.items():
+        if (k.startswith("k_conv_wino") or k.startswith("k_conv_s6") or k.startswith("k_conv<")) and "hbm_bytes_per_launch" in v:
+            per_fwd = calls.get(k, 0) / fwd
+            tot += v["hbm_bytes_per_launch"] * per_fwd
+            n += per_fwd
+            names.append("%s x %g" % (k, per_fwd))
+    json.dump({"kernel": "conv kernels of one forward (bs = 256): " + "; ".join(names), "hbm_bytes_per_forward": int(tot),
+               "launches_per_forward": n, "source": rel + ": sum over the conv launches of one forward of " + how},
+              open(os.path.join(prof, "pmc_k_conv.json"), "w"), indent=1)
