@@ -1952,10 +1952,11 @@ __global__ __launch_bounds__(256) void k_stem(const void* __restrict__ xin, cons
 // conflict-free ds_read_b128).  Workgroup = 16 x 16 output pixels x 64 channels, 8 waves (two rows each), walking a
 // row of tiles with the next window prefetched into registers; the two cout halves alternate inside each plane
 // product, so no MFMA accumulates into the tile the previous one is still writing.
-//   LDS: window 2 buffers x 3 planes x 3 x 37 x 40 bf16 = 52 KB, weights 3 x 64 x 184 bf16 = 69 KB.
+//   LDS: window 2 buffers x 3 planes x 3 x 37 x 48 bf16 = 62 KB (48-column rows: the two pixel rows of a wave's A read
+//   are 16 banks apart, its 32 lanes cover the 32 banks once), weights 3 x 64 x 184 bf16 = 69 KB.
 // ---------------------------------------------------------------------------------------------
 constexpr int SS_TR = 16;                                   // output rows per tile
-constexpr int SS_ROWS = 2 * SS_TR + 5, SS_LW = 40, SS_PLANE = SS_ROWS * SS_LW, SS_WIN = 3 * SS_PLANE;
+constexpr int SS_ROWS = 2 * SS_TR + 5, SS_LW = 48, SS_PLANE = SS_ROWS * SS_LW, SS_WIN = 3 * SS_PLANE;
 constexpr int SS_KP = 176, SS_LDW = 184;                    // padded K, weight row stride (bf16)
 constexpr int SS_WIMG = 3 * 64 * SS_LDW;                    // bf16 elements of the packed stem image
 constexpr int SS_PPT = (SS_WIN / 2 + 511) / 512;            // window element PAIRS per thread
