@@ -1952,11 +1952,12 @@ __global__ __launch_bounds__(256) void k_stem(const void* __restrict__ xin, cons
 // conflict-free ds_read_b128).  Workgroup = 16 x 16 output pixels x 64 channels, 8 waves (two rows each), walking a
 // row of tiles with the next window prefetched into registers; the two cout halves alternate inside each plane
 // product, so no MFMA accumulates into the tile the previous one is still writing.
-//   LDS: window 2 buffers x 3 planes x 3 x 37 x 48 bf16 = 62 KB (48-column rows: the two pixel rows of a wave's A read
-//   are 16 banks apart, its 32 lanes cover the 32 banks once), weights 3 x 64 x 184 bf16 = 69 KB.
+//   LDS: window 2 buffers x 3 planes x 3 x 37 x 40 bf16 = 52 KB, weights 3 x 64 x 184 bf16 = 69 KB.  (48-column window
+//   rows would put the two pixel rows of a wave's A read 16 banks apart — conflict-free — but cost 20 % more staging:
+//   470 us against 433; the 31 % of LDS cycles spent in conflicts are not what bounds this kernel.)
 // ---------------------------------------------------------------------------------------------
 constexpr int SS_TR = 16;                                   // output rows per tile
-constexpr int SS_ROWS = 2 * SS_TR + 5, SS_LW = 48, SS_PLANE = SS_ROWS * SS_LW, SS_WIN = 3 * SS_PLANE;
+constexpr int SS_ROWS = 2 * SS_TR + 5, SS_LW = 40, SS_PLANE = SS_ROWS * SS_LW, SS_WIN = 3 * SS_PLANE;
 constexpr int SS_KP = 176, SS_LDW = 184;                    // padded K, weight row stride (bf16)
 constexpr int SS_WIMG = 3 * 64 * SS_LDW;                    // bf16 elements of the packed stem image
 constexpr int SS_PPT = (SS_WIN / 2 + 511) / 512;            // window element PAIRS per thread
@@ -2169,15 +2170,14 @@ __global__ __launch_bounds__(256) void k_norm_relu_maxpool(const float* __restri
                                                            const float* __restrict__ rstd,
                                                            float* __restrict__ out, int B, int Hi, int Wi,
                                                            int Ho, int Wo, int C) {
-    const int c4n = C / 4;
-    const long long total = (long long)B * Ho * Wo * c4n;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % c4n);
-        long long p = i / c4n;
-        const int ox = (int)(p % Wo); p /= Wo;
-        const int oy = (int)(p % Ho);
-        const int n = (int)(p / Ho);
+    const int c4n = C / 4;                                  // 16: a thread keeps its channel group (256 % 16 == 0)
+    const int c4 = threadIdx.x % c4n;
+    const unsigned tpb = 256 / c4n, np = (unsigned)B * Ho * Wo;
+    for (unsigned pp = blockIdx.x * tpb + threadIdx.x / c4n; pp < np; pp += gridDim.x * tpb) {
+        unsigned p = pp;
+        const int ox = (int)(p % (unsigned)Wo); p /= (unsigned)Wo;
+        const int oy = (int)(p % (unsigned)Ho);
+        const int n = (int)(p / (unsigned)Ho);
         // max of the normalised window = normalised max (r >= 0: InstanceNorm always) or normalised
         // min (r < 0: a frozen BatchNorm with negative weight), so both extremes of the raw window are kept
         f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -2204,33 +2204,47 @@ __global__ __launch_bounds__(256) void k_norm_relu_maxpool(const float* __restri
     }
 }
 
-// out = relu(IN(y2) + (DOWN ? IN(yd) : idn))   NHWC
+// out = relu(IN(y2) + (DOWN ? IN(yd) : idn))   NHWC.  HBM-bound streaming: a thread keeps ONE 4-channel group (256 is a
+// multiple of C/4 for every ResNet width, so the grid stride preserves it) and walks pixels with 32-bit arithmetic —
+// the first version spent three 64-bit divisions per 48 bytes of traffic (4.9 TB/s).
 template <bool DOWN>
 __global__ __launch_bounds__(256) void k_norm_add_relu(const float* __restrict__ y2, const float* __restrict__ m2,
                                                        const float* __restrict__ r2, const float* __restrict__ idn,
                                                        const float* __restrict__ md, const float* __restrict__ rd,
                                                        float* __restrict__ out, long long npix, int HW, int C) {
     const int c4n = C / 4;
-    const long long total = npix * c4n;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % c4n);
-        const long long p = i / c4n;
-        const int n = (int)(p / HW);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(y2 + p * C + c4 * 4);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(m2 + (long long)n * C + c4 * 4);
-        const f32x4 rs = *reinterpret_cast<const f32x4*>(r2 + (long long)n * C + c4 * 4);
-        f32x4 id = *reinterpret_cast<const f32x4*>(idn + p * C + c4 * 4);
-        if constexpr (DOWN) {
-            const f32x4 mud = *reinterpret_cast<const f32x4*>(md + (long long)n * C + c4 * 4);
-            const f32x4 rsd = *reinterpret_cast<const f32x4*>(rd + (long long)n * C + c4 * 4);
+    const int lanes_c = c4n < 256 ? c4n : 256;              // threads across the channel groups of one pixel
+    const int cpt = (c4n + 255) / 256;                      // channel groups per thread (2 only for the 2048-wide Bottleneck tail)
+    const int tpb = 256 / lanes_c;                          // pixels per workgroup per iteration
+    const int c40 = threadIdx.x % lanes_c, pl = threadIdx.x / lanes_c;
+    const unsigned np = (unsigned)npix, pstep = gridDim.x * (unsigned)tpb;
+    int ncur = -1;
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = mu, mud = mu, rsd = mu;
+    for (unsigned p = blockIdx.x * (unsigned)tpb + pl; p < np; p += pstep) {
+        const int n = (int)(p / (unsigned)HW);
+        for (int j = 0; j < cpt; ++j) {
+            const int c4 = c40 + 256 * j;
+            const size_t o = (size_t)p * C + c4 * 4;
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y2 + o));
+            f32x4 id = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(idn + o));
+            if (n != ncur || cpt > 1) {                     // the image changes every HW pixels: reload its statistics
+                mu = *reinterpret_cast<const f32x4*>(m2 + (size_t)n * C + c4 * 4);
+                rs = *reinterpret_cast<const f32x4*>(r2 + (size_t)n * C + c4 * 4);
+                if constexpr (DOWN) {
+                    mud = *reinterpret_cast<const f32x4*>(md + (size_t)n * C + c4 * 4);
+                    rsd = *reinterpret_cast<const f32x4*>(rd + (size_t)n * C + c4 * 4);
+                }
+            }
+            if constexpr (DOWN) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) id[e] = (id[e] - mud[e]) * rsd[e];
+                for (int e = 0; e < 4; ++e) id[e] = (id[e] - mud[e]) * rsd[e];
+            }
+            f32x4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = fmaxf((v[e] - mu[e]) * rs[e] + id[e], 0.f);
+            *reinterpret_cast<f32x4*>(out + o) = o4;
         }
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = fmaxf((v[e] - mu[e]) * rs[e] + id[e], 0.f);
-        *reinterpret_cast<f32x4*>(out + p * C + c4 * 4) = o;
+        ncur = n;
     }
 }
 
@@ -2847,7 +2861,8 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
                 hipLaunchKernelGGL(k_norm_add_relu_pool, dim3((unsigned)((B * Cc + 255) / 256)), dim3(256), 0, st, yout,
                                    mean[sout], rstd[sout], cur, feats, B, Ho * Wo, Cc);
             } else {
-                long long blocks = (npix * (Cc / 4) + 255) / 256;
+                const int c4n = Cc / 4, tpb = 256 / (c4n < 256 ? c4n : 256);
+                long long blocks = (npix + tpb - 1) / tpb;
                 if (blocks > 8192) blocks = 8192;
                 if (down) hipLaunchKernelGGL(k_norm_add_relu<true>, dim3((unsigned)blocks), dim3(256), 0, st, yout, mean[sout], rstd[sout], yd, mean[3], rstd[3], nxt, npix, Ho * Wo, Cc);
                 else hipLaunchKernelGGL(k_norm_add_relu<false>, dim3((unsigned)blocks), dim3(256), 0, st, yout, mean[sout], rstd[sout], cur, nullptr, nullptr, nxt, npix, Ho * Wo, Cc);
