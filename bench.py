@@ -130,7 +130,28 @@ class Ctx:
             self.dist = dist
         import dsmil  # noqa: F401
         import dsmil_wsi_amd._native as nat
+        import dsmil_wsi_amd.ops as ops
         self.L = nat.lib()
+        # independent passes are dealt round-robin to --streams HIP streams (ops.StreamPool, one workspace per stream)
+        self.pool = ops.StreamPool(args.streams, self.dev) if args.streams > 1 else None
+
+    def run(self, fn, *a, **k):
+        return self.pool.run(fn, *a, **k) if self.pool is not None else fn(*a, **k)
+
+    def kernel_alone(self, fn, channel, passes=6):
+        """Average per-launch time of the channel's kernel with ONE pass in flight (no co-running stream)."""
+        torch = self.torch
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        self.L.dsmil_profile_enable(1)
+        for _ in range(passes):
+            fn()
+        torch.cuda.synchronize()
+        tot_ms, launches = ctypes.c_double(0), ctypes.c_int64(0)
+        self.L.dsmil_profile_collect(channel, ctypes.byref(tot_ms), ctypes.byref(launches))
+        self.L.dsmil_profile_enable(0)
+        return tot_ms.value / max(1, launches.value), tot_ms.value / passes
 
     def fence(self):
         if self.dist is not None:
@@ -211,10 +232,14 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
     offsets = ops.offsets_tensor(lengths, dev)
     out = []
 
+    def one():
+        return ops.agg_forward(feats, lengths, w, offsets=offsets)
+
     def step():
-        out[:] = ops.agg_forward(feats, lengths, w, offsets=offsets)
+        out[:] = cx.run(one)
 
     dt, inner, kern_ms_tot, launches = cx.timed(step, args.steps, args.warmup, args.min_seconds, channel=0)
+    kern_alone_ms, _ = cx.kernel_alone(one, 0)
     single_ms = None
     if single_bag:   # one MILNet.forward-sized call per iteration, outside the timed region
         one = feats[:N]
@@ -245,6 +270,7 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
                                    f"HBM-resident", "passes_per_step": inner, "bags_per_pass_per_gpu": nb, "rows": N,
                        "feats": K, "classes": C, "tile_rows": int(cx.L.dsmil_agg_tile_rows(nb, nb * N)),
                        "parallelism": f"bag-sharded x{world}", "timed_region_s": round(dt, 3),
+                       "streams": args.streams,
                        "single_bag_forward_ms": round(single_ms, 4) if single_ms is not None else None}}
     if bf16:
         # bf16 storage: the MLP runs on bf16 MFMA (0.7 us/bag at 2.5 PF) and the feature stream (10.5 MB/bag) binds
@@ -255,6 +281,9 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4) if gbs else None,
                             "traffic": _pmc("pmc_k_query_attend_bf16.json", "hbm_bytes_per_launch") if (nb, N, K) == (64, 10000, 512) else None,
                             "kernel_ms": round(kern_ms, 4), "launches": launches, "alg_bytes_per_launch": by,
+                            "kernel_ms_alone": round(kern_alone_ms, 4),
+                            "frac_alone": round(by / (kern_alone_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if kern_alone_ms > 0 else None,
+                            "kernel_ms_is": "average HIP-event duration of the kernel inside the timed region, i.e. WITH the other streams' kernels co-running (config.streams); kernel_ms_alone = the same kernel with one pass in flight",
                             "whole_path_frac_of_roofline": round(value / world * t_roof, 4)}
         return line
     fl = attend_flops_per_bag(N, K, C) * nb
@@ -278,6 +307,9 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
         "traffic": _pmc("pmc_k_query_attend.json", "hbm_bytes_per_launch") if (nb, N, K) == (64, 10000, 512) else None,
         "alg_bytes_per_launch": bytes_per_bag(N, K, C) * nb,
         "kernel_ms": round(kern_ms, 4), "launches": launches, "alg_flops_per_launch": fl,
+        "kernel_ms_alone": round(kern_alone_ms, 4),
+        "frac_alone": round(fl / (kern_alone_ms * 1e-3) / 1e12 / peak_exec, 4) if kern_alone_ms > 0 else None,
+        "kernel_ms_is": "average HIP-event duration of the kernel inside the timed region, i.e. WITH the other streams' kernels co-running (config.streams); kernel_ms_alone = the same kernel with one pass in flight",
         "whole_path_frac_of_roofline": round(value / world * t_roof_f32, 4),
         "whole_path_roofline_is": "SURVEY §8(d): max(bytes / 8 TB/s, FLOPs / 157.3 TF f32 MFMA) per bag",
         "whole_path_frac_of_executed_form_roofline": round(value / world * t_roof_exec, 4)}
@@ -378,17 +410,21 @@ def embedder_leg(cx):
     Bp = args.patches
     g = torch.Generator(device=dev).manual_seed(7 + cx.rank)
     x = torch.rand((Bp, 3, 224, 224), generator=g, device=dev, dtype=torch.float32)
-    gathered = torch.empty((world * Bp, 512), device=dev) if world > 1 else None
     keep = []
 
-    def step():
+    def one():
         with torch.no_grad():
             feats, c = ic(x)
         if world > 1:
+            gathered = torch.empty((world * Bp, 512), device=dev)
             dist.all_gather_into_tensor(gathered, feats)
-        keep[:] = [feats]
+        return feats
+
+    def step():
+        keep[:] = [cx.run(one)]
 
     dt, inner, kern_ms_tot, launches = cx.timed(step, args.steps, args.warmup, args.min_seconds, channel=1)
+    _, conv_alone_ms = cx.kernel_alone(one, 1, passes=3)
     if not os.environ.get("DSMIL_WINO_EXPT"):
         assert torch.isfinite(keep[0]).all()
     passes = args.steps * inner
@@ -410,7 +446,7 @@ def embedder_leg(cx):
             "dtype": "f32",
             "config": {"workload": f"IClassifier(ResNet-18 InstanceNorm, fc=Identity)+Linear(512,2), {Bp} synthetic "
                                    f"224x224 patches per GPU per pass, kaiming(seed 11) weights",
-                       "passes_per_step": inner, "timed_region_s": round(dt, 3),
+                       "passes_per_step": inner, "timed_region_s": round(dt, 3), "streams": args.streams,
                        "collective": "all_gather_into_tensor([%d,512] f32) per pass" % Bp if world > 1 else "none"},
             "roofline": {"kernel": "conv kernels of one forward: 13 x k_conv_wino_s3 (Winograd F(2x2,3x3), bf16 MFMA over exact "
                                    "3-plane cuts) + 6 direct convs", "bound": "mfma",
@@ -424,6 +460,9 @@ def embedder_leg(cx):
                          "peak": PEAK_BF16_MFMA_TFLOPS, "executed_forms": forms,
                          "traffic": _pmc("pmc_k_conv.json", "hbm_bytes_per_forward"),
                          "kernel_ms_total": round(kern_ms_tot, 3), "launches": launches, "alg_flops_total": conv_flops,
+                         "conv_ms_per_forward": round(kern_ms_tot / passes, 3), "conv_ms_per_forward_alone": round(conv_alone_ms, 3),
+                         "frac_alone": round((t_wino + t_direct) * Bp / (conv_alone_ms * 1e-3), 4) if conv_alone_ms > 0 else None,
+                         "kernel_ms_is": "HIP-event durations inside the timed region, with the other streams' kernels co-running (config.streams); *_alone = one forward in flight",
                          # the figure the >= 60 % target of BASELINE.json refers to: whole forward vs SURVEY §8(d)'s
                          # direct-form fp32 roofline (3.627 GFLOP/patch at 157.3 TF = 43 368 patches/s)
                          "whole_path_frac_of_roofline": round(value / world / (PEAK_F32_MFMA_TFLOPS * 1e12 / FLOPS_PER_PATCH), 4)}}
@@ -478,7 +517,7 @@ def slide_leg(cx, n_patches):
     def step():
         with torch.no_grad():
             ev[0].record()
-            feats, _ = pl.embed_tiles(ic, tiles, args.patches)
+            feats, _ = pl.embed_tiles(ic, tiles, args.patches, streams=args.streams)
             ev[1].record()
             bag = dd.all_gather_rows(feats, n_patches) if world > 1 else feats
             ev[2].record()
@@ -497,7 +536,7 @@ def slide_leg(cx, n_patches):
             "config": {"workload": f"one slide = {n_patches} uint8 224x224 tiles (ToTensor fused in the stem), contiguous row "
                                    f"shards over {world} rank(s), batches of {args.patches}, one all-gather of [N_r,512] f32, "
                                    f"MILNet(tcga) on the gathered bag", "slides_timed": steps, "rccl_ranks": world,
-                       "rows_this_rank": hi - lo}}
+                       "streams": args.streams, "rows_this_rank": hi - lo}}
 
 
 def e2e_leg(cx, low_grid):
@@ -527,7 +566,7 @@ def e2e_leg(cx, low_grid):
             "patches_per_s": round((n_high + n_low) * steps / dt, 1),
             "config": {"workload": f"synthetic uint8 slide {gy * 896}x{gx * 896}: {n_low} low tiles + {n_high} high tiles (224x224), "
                                    f"two ResNet-18-IN embedders, [high||low] 1024-d, MILNet(FCLayer(1024,2), BClassifier(1024,2)), "
-                                   f"32x colour map on the host", "slides_timed": steps, "rccl_ranks": world,
+                                   f"32x colour map on the host", "slides_timed": steps, "rccl_ranks": world, "streams": 3,
                        "all_gather_s_total": round(tm.get("allgather_s", 0.0), 4)}}
 
 
@@ -543,6 +582,8 @@ def main():
     ap.add_argument("--workload", default="all",
                     help="comma list of aggregator, aggregator_bf16, embedder, slide, e2e; or all / both (= aggregator,embedder)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on each timed region")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams independent passes are dealt to (ops.StreamPool); 1 = one pass in flight")
     ap.add_argument("--slide-patches", type=int, default=10000)
     ap.add_argument("--e2e-grid", type=int, nargs=2, default=(24, 26), help="low-magnification tile grid of the e2e slide")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)

@@ -51,12 +51,77 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_ws_last = [None]
+
+
 def _workspace(device, nbytes):
-    buf = _ws_cache.get(device)
+    """Scratch for one native call, cached per (device, HIP stream): calls on different streams may run concurrently
+    (StreamPool) and must not share partial buffers.  Allocated while that stream is current, so the caching
+    allocator ties its lifetime to the stream's work."""
+    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
+    buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if len(_ws_cache) >= 16:   # transient streams: forget the oldest entries (their memory returns to the allocator)
+            for k in list(_ws_cache)[:8]:
+                del _ws_cache[k]
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
-        _ws_cache[device] = buf
+        _ws_cache[key] = buf
+    _ws_last[0] = buf
     return buf
+
+
+class _Ready:
+    """Marks device data produced on one stream (a packed weight image) so that OTHER streams wait for it before use —
+    an event wait enqueued on the consumer's stream, no host sync (the packing of a training step stays asynchronous)."""
+
+    def __init__(self, dev):
+        self.ev = None
+        if torch.device(dev).type != "cuda":   # host data (the CPU module path folds BatchNorms too): nothing to wait for
+            return
+        self.sid = int(torch.cuda.current_stream(dev).cuda_stream)
+        self.ev = torch.cuda.Event()
+        self.ev.record(torch.cuda.current_stream(dev))
+
+    def wait(self, dev):
+        if self.ev is None:
+            return
+        cur = torch.cuda.current_stream(dev)
+        if int(cur.cuda_stream) != self.sid:
+            cur.wait_event(self.ev)
+
+
+class StreamPool:
+    """Round-robin dispatch of INDEPENDENT native calls over n HIP streams of one device.
+
+    The aggregator forward is a chain of kernels with complementary bounds — `k_logits_stream` streams the bag at
+    HBM speed with idle matrix cores, `k_query_attend_split` is MFMA-bound at half the HBM rate — and a batch of bags
+    cannot overlap them (the critical instance must be known before any score).  Two INDEPENDENT batches can: dealt to
+    different streams, the logits pass of one runs under the attend kernel of the other (measured on 64 x 10 000 x 512
+    bags: 73.4 k bags/s on one stream, 78.2 k on two, 80.0 k on three).  Each stream has its own workspace
+    (`_workspace`); outputs are allocated on the stream that produces them; `join()` makes the caller's stream wait
+    for everything submitted.
+
+        pool = ops.StreamPool(3)
+        outs = [pool.run(ops.agg_forward, feats_b, lengths_b, w) for (feats_b, lengths_b) in batches]
+        pool.join()
+    """
+
+    def __init__(self, n=3, device=None):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(n)))]
+        self._i = 0
+
+    def run(self, fn, *args, **kwargs):
+        s = self.streams[self._i % len(self.streams)]
+        self._i += 1
+        s.wait_stream(torch.cuda.current_stream(self.device))   # inputs may have been produced on the caller's stream
+        with torch.cuda.stream(s):
+            return fn(*args, **kwargs)
+
+    def join(self):
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            cur.wait_stream(s)
 
 
 def offsets_tensor(lengths, device):
@@ -118,6 +183,7 @@ def _bf16_params(w, nonlinear, dev):
     key = (str(dev), bool(nonlinear)) + tuple(_tkey(w.get(k)) for k in names)
     ent = _bf16_cache.get(key)
     if ent is not None:
+        ent[3].wait(dev)
         return ent[0], ent[1]
     r = {k: (w[k].detach().to(torch.bfloat16).to(torch.float32).contiguous() if w.get(k) is not None else None)
          for k in names}
@@ -128,7 +194,7 @@ def _bf16_params(w, nonlinear, dev):
         rc = L.dsmil_agg_pack_bf16(_ptr(r["q0_w"]), _ptr(r["q2_w"] if nonlinear else None), K, _ptr(packed),
                                    _stream(dev))
     _native.check(rc, "dsmil_agg_pack_bf16")
-    _bf16_cache.put(key, (r, packed, [w.get(k) for k in names]))
+    _bf16_cache.put(key, (r, packed, [w.get(k) for k in names], _Ready(dev)))
     return r, packed
 
 
@@ -142,13 +208,14 @@ def _split_params(q0_w, q2_w, nonlinear, dev):
     key = (str(dev), bool(nonlinear), _tkey(q0_w), _tkey(q2_w) if nonlinear else None)
     ent = _split_cache.get(key)
     if ent is not None:
+        ent[2].wait(dev)
         return ent[0]
     K = q0_w.shape[1]
     packed = torch.empty(L.dsmil_agg_packed_split_bytes(K, 1 if nonlinear else 0), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = L.dsmil_agg_pack_split(_ptr(q0_w), _ptr(q2_w if nonlinear else None), K, _ptr(packed), _stream(dev))
     _native.check(rc, "dsmil_agg_pack_split")
-    _split_cache.put(key, (packed, [q0_w, q2_w]))
+    _split_cache.put(key, (packed, [q0_w, q2_w], _Ready(dev)))
     return packed
 
 
@@ -268,10 +335,11 @@ class GraphedAggForward:
         torch.cuda.synchronize(dev)
         # the captured launches read these buffers by address: keep them alive as long as the graph
         self._keep = [_split_params(_f32c(w["q0_w"], "q0_w"), _f32c(w.get("q2_w"), "q2_w"), nonlinear, dev)
-                      if dtype == torch.float32 else _bf16_params(w, nonlinear, dev), _ws_cache.get(dev)]
+                      if dtype == torch.float32 else _bf16_params(w, nonlinear, dev)]
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = agg_forward(self.x, [self.n], w, nonlinear=nonlinear, offsets=self.offsets)
+        self._keep.append(_ws_last[0])   # the workspace of the capture stream
 
     def __call__(self, feats):
         self.x.copy_(feats)
@@ -448,6 +516,7 @@ def _packed_resnet_weights(convs, depth=18):
     key = (str(dev), depth) + tuple(_tkey(w) for w in convs)
     ent = _pack_cache.get(key)
     if ent is not None:
+        ent[3].wait(dev)
         return ent[0]
     L = _native.lib()
     buf = torch.empty(L.dsmil_resnet_packed_bytes(depth) // 4, dtype=torch.float32, device=dev)
@@ -456,7 +525,7 @@ def _packed_resnet_weights(convs, depth=18):
     with torch.cuda.device(dev):
         rc = L.dsmil_resnet_pack(depth, arr, _ptr(buf), _stream(dev))
     _native.check(rc, "dsmil_resnet_pack")
-    _pack_cache.put(key, (buf, keep, list(convs)))
+    _pack_cache.put(key, (buf, keep, list(convs), _Ready(dev)))
     return buf
 
 
@@ -470,6 +539,7 @@ def _folded_bn(norms, dev):
                               for n in norms)
     hit = _bn_cache.get(key)
     if hit is not None:
+        hit[3].wait(dev)
         return hit[0], hit[1]
     ms, rs = [], []
     for n in norms:
@@ -484,7 +554,7 @@ def _folded_bn(norms, dev):
         rs.append(r)
     m = torch.cat(ms).to(torch.float32).contiguous()
     r = torch.cat(rs).to(torch.float32).contiguous()
-    _bn_cache.put(key, (m, r, list(norms)))   # the modules stay alive: their ids stay unique
+    _bn_cache.put(key, (m, r, list(norms), _Ready(dev)))   # the modules stay alive: their ids stay unique
     return m, r
 
 

@@ -20,6 +20,7 @@ import torch
 from torch.utils.data import DataLoader, Dataset
 
 from . import dist as ddist
+from . import ops
 
 
 def to_tensor(img):
@@ -409,15 +410,38 @@ def background_keep_mask(tiles, edge_threshold=15, sat_threshold=None):
     return torch.from_numpy(keep).to(dev)
 
 
+_pools = {}
+
+
+def stream_pool(device, streams):
+    """The StreamPool of a device (one per (device, width), created on first use)."""
+    key = (str(device), int(streams))
+    if key not in _pools:
+        _pools[key] = ops.StreamPool(streams, device)
+    return _pools[key]
+
+
 @torch.no_grad()
-def embed_tiles(i_classifier, tiles, batch_size=256):
+def embed_tiles(i_classifier, tiles, batch_size=256, streams=3):
     """IClassifier over resident uint8 NHWC tiles in batches (compute_feats.py:70-76 without the loader: the
-    tiles are already decoded and on the device).  Returns (feats [N,F], classes [N,C])."""
+    tiles are already decoded and on the device).  Returns (feats [N,F], classes [N,C]).
+    Batches are independent (InstanceNorm is per image), so on the GPU they are dealt round-robin to `streams` HIP
+    streams (ops.StreamPool): the kernels of one forward have few workgroup rounds each and latency-bound phases that
+    a second batch fills (41.8 k -> 46.4 k patches/s with two streams, 47.0 k with three, bs 256)."""
     fl, cl = [], []
+    pool = stream_pool(tiles.device, streams) if (tiles.is_cuda and streams > 1 and tiles.shape[0] > batch_size) else None
     for lo in range(0, tiles.shape[0], batch_size):
-        f, c = i_classifier(tiles[lo:lo + batch_size])
+        if pool is not None:
+            f, c = pool.run(i_classifier, tiles[lo:lo + batch_size])
+        else:
+            f, c = i_classifier(tiles[lo:lo + batch_size])
         fl.append(f)
         cl.append(c)
+    if pool is not None:
+        pool.join()
+        cur = torch.cuda.current_stream(tiles.device)
+        for t in fl + cl:                               # produced on a pool stream, consumed (and freed) on this one
+            t.record_stream(cur)
     if not fl:
         dev = tiles.device
         return (torch.zeros((0, i_classifier.fc.in_features), device=dev),
