@@ -23,9 +23,16 @@ Sub-objects of the same JSON line (each measured the same way):
   e2e              configs[4]: synthetic two-level WSI -> tiles -> two embedders -> [high||low] -> MILNet(1024) ->
                    attention map, sharded by low tile, one all-gather of tree rows
 
+Passes are independent (different batches of bags / patches in a real job), so they are dealt round-robin to --streams
+HIP streams (ops.StreamPool, default 3: one workspace per stream): the HBM-bound logits pass of one batch runs under the
+MFMA-bound attend kernel of another, and the few-round kernels of one embedder forward fill each other's tails.
+`--streams 1` keeps one pass in flight.
+
 `roofline` is for the dominant kernel of the headline leg (k_query_attend_split), timed live with HIP events on its
-launch stream inside the library over the timed region; `cpu_baseline` is the same forward on this box's host cores.
-Prints ONE JSON line (rank 0).
+launch stream inside the library.  With several streams a launch's start-to-end interval inside the timed region also
+contains the kernels co-running with it, so the kernel's OWN duration is measured in a second region right after the
+timed one (same inputs, one pass in flight, 300 passes); the in-region interval is reported beside it.
+`cpu_baseline` is the same forward on this box's host cores.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import ctypes
@@ -239,7 +246,7 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
         out[:] = cx.run(one)
 
     dt, inner, kern_ms_tot, launches = cx.timed(step, args.steps, args.warmup, args.min_seconds, channel=0)
-    kern_alone_ms, _ = cx.kernel_alone(one, 0)
+    kern_alone_ms, _ = cx.kernel_alone(one, 0, passes=300)
     single_ms = None
     if single_bag:   # one MILNet.forward-sized call per iteration, outside the timed region
         one = feats[:N]
@@ -275,18 +282,19 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
     if bf16:
         # bf16 storage: the MLP runs on bf16 MFMA (0.7 us/bag at 2.5 PF) and the feature stream (10.5 MB/bag) binds
         by = bytes_per_bag(N, K, C, s=2) * nb
+        kern_region_ms, kern_ms = kern_ms, (kern_alone_ms if cx.pool is not None else kern_ms)
         gbs = by / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
         t_roof = max(flops_per_bag(N, K, C) / (PEAK_BF16_MFMA_TFLOPS * 1e12), bytes_per_bag(N, K, C, s=2) / (PEAK_HBM_GBS * 1e9))
         line["roofline"] = {"kernel": "k_query_attend_bf16", "bound": "hbm", "achieved": round(gbs, 1) if gbs else None,
                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4) if gbs else None,
                             "traffic": _pmc("pmc_k_query_attend_bf16.json", "hbm_bytes_per_launch") if (nb, N, K) == (64, 10000, 512) else None,
                             "kernel_ms": round(kern_ms, 4), "launches": launches, "alg_bytes_per_launch": by,
-                            "kernel_ms_alone": round(kern_alone_ms, 4),
-                            "frac_alone": round(by / (kern_alone_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if kern_alone_ms > 0 else None,
-                            "kernel_ms_is": "average HIP-event duration of the kernel inside the timed region, i.e. WITH the other streams' kernels co-running (config.streams); kernel_ms_alone = the same kernel with one pass in flight",
+                            "kernel_ms_in_timed_region": round(kern_region_ms, 4),
+                            "kernel_ms_is": "average HIP-event duration of the kernel with ONE pass in flight (300 passes on one stream right after the timed region, same inputs): the kernel's own time. Inside the timed region config.streams passes overlap, so a launch's start-to-end interval (kernel_ms_in_timed_region) also contains the co-running streams' kernels and is not a measure of the kernel",
                             "whole_path_frac_of_roofline": round(value / world * t_roof, 4)}
         return line
     fl = attend_flops_per_bag(N, K, C) * nb
+    kern_region_ms, kern_ms = kern_ms, (kern_alone_ms if cx.pool is not None else kern_ms)
     achieved = fl / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else None
     # The peak that bounds the kernel AS EXECUTED: forms 6 / 9 run every fp32 MAC as 6 / 9 bf16 plane products on the
     # bf16 matrix pipe, so the bound is (bf16 dense peak) / (plane products per MAC) in algorithmic (fp32) FLOP/s;
@@ -307,9 +315,8 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
         "traffic": _pmc("pmc_k_query_attend.json", "hbm_bytes_per_launch") if (nb, N, K) == (64, 10000, 512) else None,
         "alg_bytes_per_launch": bytes_per_bag(N, K, C) * nb,
         "kernel_ms": round(kern_ms, 4), "launches": launches, "alg_flops_per_launch": fl,
-        "kernel_ms_alone": round(kern_alone_ms, 4),
-        "frac_alone": round(fl / (kern_alone_ms * 1e-3) / 1e12 / peak_exec, 4) if kern_alone_ms > 0 else None,
-        "kernel_ms_is": "average HIP-event duration of the kernel inside the timed region, i.e. WITH the other streams' kernels co-running (config.streams); kernel_ms_alone = the same kernel with one pass in flight",
+        "kernel_ms_in_timed_region": round(kern_region_ms, 4),
+        "kernel_ms_is": "average HIP-event duration of the kernel with ONE pass in flight (300 passes on one stream right after the timed region, same inputs): the kernel's own time. Inside the timed region config.streams passes overlap, so a launch's start-to-end interval (kernel_ms_in_timed_region) also contains the co-running streams' kernels and is not a measure of the kernel",
         "whole_path_frac_of_roofline": round(value / world * t_roof_f32, 4),
         "whole_path_roofline_is": "SURVEY §8(d): max(bytes / 8 TB/s, FLOPs / 157.3 TF f32 MFMA) per bag",
         "whole_path_frac_of_executed_form_roofline": round(value / world * t_roof_exec, 4)}
@@ -424,7 +431,7 @@ def embedder_leg(cx):
         keep[:] = [cx.run(one)]
 
     dt, inner, kern_ms_tot, launches = cx.timed(step, args.steps, args.warmup, args.min_seconds, channel=1)
-    _, conv_alone_ms = cx.kernel_alone(one, 1, passes=3)
+    _, conv_alone_ms = cx.kernel_alone(one, 1, passes=40)
     if not os.environ.get("DSMIL_WINO_EXPT"):
         assert torch.isfinite(keep[0]).all()
     passes = args.steps * inner
@@ -437,6 +444,11 @@ def embedder_leg(cx):
     forms = {"wino_products": wino_np, "direct_products": direct_np}
     t_wino = WINO_FLOPS_PER_PATCH / 2.25 * (wino_np / (PEAK_BF16_MFMA_TFLOPS * 1e12) if wino_np else 1 / (PEAK_F32_MFMA_TFLOPS * 1e12))
     t_direct = DIRECT_FLOPS_PER_PATCH * (direct_np / (PEAK_BF16_MFMA_TFLOPS * 1e12) if direct_np else 1 / (PEAK_F32_MFMA_TFLOPS * 1e12))
+    # conv-kernel time: with several streams the in-region event intervals overlap each other (they contain the other
+    # streams' kernels), so the kernels' own time is taken from 40 forwards with one in flight, right after the region
+    kern_region_ms_tot = kern_ms_tot
+    if cx.pool is not None:
+        kern_ms_tot = conv_alone_ms * passes
     kern_s = kern_ms_tot * 1e-3
     conv_flops = (FLOPS_PER_PATCH - STEM_FLOPS_PER_PATCH) * Bp * passes
     ach = conv_flops / kern_s / 1e12 if kern_s > 0 else None
@@ -460,9 +472,9 @@ def embedder_leg(cx):
                          "peak": PEAK_BF16_MFMA_TFLOPS, "executed_forms": forms,
                          "traffic": _pmc("pmc_k_conv.json", "hbm_bytes_per_forward"),
                          "kernel_ms_total": round(kern_ms_tot, 3), "launches": launches, "alg_flops_total": conv_flops,
-                         "conv_ms_per_forward": round(kern_ms_tot / passes, 3), "conv_ms_per_forward_alone": round(conv_alone_ms, 3),
-                         "frac_alone": round((t_wino + t_direct) * Bp / (conv_alone_ms * 1e-3), 4) if conv_alone_ms > 0 else None,
-                         "kernel_ms_is": "HIP-event durations inside the timed region, with the other streams' kernels co-running (config.streams); *_alone = one forward in flight",
+                         "conv_ms_per_forward": round(kern_ms_tot / passes, 3),
+                         "conv_ms_per_forward_in_timed_region": round(kern_region_ms_tot / passes, 3),
+                         "kernel_ms_is": "HIP-event durations of the conv kernels with ONE forward in flight (40 forwards on one stream right after the timed region); inside the region config.streams forwards overlap and a launch's interval contains the co-running kernels (conv_ms_per_forward_in_timed_region)",
                          # the figure the >= 60 % target of BASELINE.json refers to: whole forward vs SURVEY §8(d)'s
                          # direct-form fp32 roofline (3.627 GFLOP/patch at 157.3 TF = 43 368 patches/s)
                          "whole_path_frac_of_roofline": round(value / world / (PEAK_F32_MFMA_TFLOPS * 1e12 / FLOPS_PER_PATCH), 4)}}

@@ -393,6 +393,7 @@ def test_stream_pool_results_equal_single_stream():
     DIFFERENT bags per call, submitted back to back so that they really overlap, and embedder batches through
     pipeline.embed_tiles."""
     import torch.nn as nn
+    import dsmil
     from dsmil_wsi_amd import ops, pipeline as pl
     from dsmil_wsi_amd.resnet import resnet18
     w = {k: torch.from_numpy(v).cuda() for k, v in load_weights("tcga").items()}
