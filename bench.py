@@ -79,6 +79,14 @@ STEM_FLOPS_PER_PATCH = 2 * 12544 * 64 * 147
 # direct-form FLOPs per patch by conv class (ResNet-18 @224): 13 stride-1 3x3 convs (Winograd), 3 stride-2 3x3 + 3 1x1
 WINO_FLOPS_PER_PATCH = 2 * (4 * 3136 * 64 * 64 * 9 + 3 * 784 * 128 * 128 * 9 + 3 * 196 * 256 * 256 * 9 + 3 * 49 * 512 * 512 * 9)
 DIRECT_FLOPS_PER_PATCH = FLOPS_PER_PATCH - STEM_FLOPS_PER_PATCH - WINO_FLOPS_PER_PATCH
+# algorithmic HBM traffic of one 224x224 patch through ResNet-18-IN with fp32 NHWC activations: every conv reads its input
+# and writes its raw output once, the max-pool and the 8 residual kernels read their operands and write their result once
+_A = {56: 56 * 56 * 64 * 4, 28: 28 * 28 * 128 * 4, 14: 14 * 14 * 256 * 4, 7: 7 * 7 * 512 * 4}
+ACT_BYTES_PER_PATCH = (3 * 224 * 224 * 4 + 112 * 112 * 64 * 4          # stem
+                       + 112 * 112 * 64 * 4 + _A[56]                   # IN + ReLU + max-pool
+                       + 4 * 2 * _A[56] + 2 * 3 * _A[56]               # layer 1: 4 convs, 2 residual kernels
+                       + sum((_A[p] + _A[h]) * 2 + 3 * 2 * _A[h] + 2 * 3 * _A[h]   # layers 2-4: strided conv + downsample,
+                             for p, h in ((56, 28), (28, 14), (14, 7))))           # 3 stride-1 convs, 2 residual kernels
 
 
 def _pmc(name, key):
@@ -449,6 +457,8 @@ def embedder_leg(cx):
     kern_region_ms_tot = kern_ms_tot
     if cx.pool is not None:
         kern_ms_tot = conv_alone_ms * passes
+    t_stem = STEM_FLOPS_PER_PATCH * (direct_np / (PEAK_BF16_MFMA_TFLOPS * 1e12) if direct_np else 1 / (PEAK_F32_MFMA_TFLOPS * 1e12))
+    t_exec_patch = max(t_wino + t_direct + t_stem, ACT_BYTES_PER_PATCH / (PEAK_HBM_GBS * 1e9))
     kern_s = kern_ms_tot * 1e-3
     conv_flops = (FLOPS_PER_PATCH - STEM_FLOPS_PER_PATCH) * Bp * passes
     ach = conv_flops / kern_s / 1e12 if kern_s > 0 else None
@@ -477,7 +487,16 @@ def embedder_leg(cx):
                          "kernel_ms_is": "HIP-event durations of the conv kernels with ONE forward in flight (40 forwards on one stream right after the timed region); inside the region config.streams forwards overlap and a launch's interval contains the co-running kernels (conv_ms_per_forward_in_timed_region)",
                          # the figure the >= 60 % target of BASELINE.json refers to: whole forward vs SURVEY §8(d)'s
                          # direct-form fp32 roofline (3.627 GFLOP/patch at 157.3 TF = 43 368 patches/s)
-                         "whole_path_frac_of_roofline": round(value / world / (PEAK_F32_MFMA_TFLOPS * 1e12 / FLOPS_PER_PATCH), 4)}}
+                         # >= 1 is possible and expected: that roofline prices 3.627 GFLOP of direct-form fp32 MACs on the f32
+                         # MFMA pipe, while the forward executes 2.25x fewer multiplies (Winograd) on the bf16 pipe — it is a
+                         # RATIO to the reference formulation, not a utilisation
+                         "ratio_to_f32_direct_form_roofline": round(value / world / (PEAK_F32_MFMA_TFLOPS * 1e12 / FLOPS_PER_PATCH), 4),
+                         # the bound of the forward AS EXECUTED: max(MFMA time of every conv on the pipe it runs on,
+                         # activation bytes / 8 TB/s) per patch — this one is <= 1
+                         "whole_path_frac_of_roofline": round(value / world * t_exec_patch, 4),
+                         "whole_path_roofline_is": "max(executed MFMA FLOPs / pipe peak summed over stem, Winograd and direct convs, "
+                                                   "%.1f MB of fp32 NHWC activation traffic / 8 TB/s) = %.2f us per patch"
+                                                   % (ACT_BYTES_PER_PATCH / 1e6, t_exec_patch * 1e6)}}
 
 
 def cpu_baseline_embedder(budget_s):

@@ -40,14 +40,14 @@ tests_new)
 stamps)
   for e in 68 76; do DSMIL_NATIVE_LIB=libdsmil_hip_trace.so DSMIL_EXPT=$e timeout 300 python tools_stamp.py > $OUT/stamps_$e.log 2>&1; tail -12 $OUT/stamps_$e.log; done;;
 prof_agg)
-  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_agg -o t -- python $R/bench.py --workload aggregator,aggregator_bf16 --steps 4 --warmup 1 --min-seconds 0.1 --no-cpu-baseline --no-single-bag > $OUT/trace_agg.log 2>&1); find $OUT/trace_agg -name "*kernel_stats.csv" | head -2 | xargs -I{} sh -c 'head -12 {}';;
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_agg -o t -- python $R/bench.py --workload aggregator,aggregator_bf16 --streams 1 --steps 4 --warmup 1 --min-seconds 0.1 --no-cpu-baseline --no-single-bag > $OUT/trace_agg.log 2>&1); find $OUT/trace_agg -name "*kernel_stats.csv" | head -2 | xargs -I{} sh -c 'head -12 {}';;
 prof_emb)
-  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_emb -o t -- python $R/bench.py --workload embedder --steps 3 --warmup 1 --min-seconds 0.1 --no-cpu-baseline > $OUT/trace_emb.log 2>&1); find $OUT/trace_emb -name "*kernel_stats.csv" | head -2 | xargs -I{} sh -c 'head -24 {}';;
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_emb -o t -- python $R/bench.py --workload embedder --streams 1 --steps 3 --warmup 1 --min-seconds 0.1 --no-cpu-baseline > $OUT/trace_emb.log 2>&1); find $OUT/trace_emb -name "*kernel_stats.csv" | head -2 | xargs -I{} sh -c 'head -24 {}';;
 pmc_agg|pmc_emb)
   W=aggregator,aggregator_bf16; [ $stage = pmc_emb ] && W=embedder
   for c in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
     n=$(echo $c | tr ' ' '_' | cut -c1-40)
-    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -f csv -d $OUT/${stage}_$n -o p -- python $R/bench.py --workload $W --steps 3 --warmup 1 --min-seconds 0.05 --no-cpu-baseline --no-single-bag > $OUT/${stage}_$n.log 2>&1)
+    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -f csv -d $OUT/${stage}_$n -o p -- python $R/bench.py --workload $W --streams 1 --steps 3 --warmup 1 --min-seconds 0.05 --no-cpu-baseline --no-single-bag > $OUT/${stage}_$n.log 2>&1)
   done; find $OUT -name "*counter_collection.csv" | head;;
 esac
 done
