@@ -20,6 +20,7 @@ Sub-objects of the same JSON line (each measured the same way):
                    with N ranks ONE RCCL all-gather of the [--patches,512] rows follows inside the step (weak)
   slide            configs[3] per-slide strong scaling: a slide of --slide-patches uint8 tiles
                    cut contiguously over the ranks, embedded in batches, ONE all-gather of feature rows, aggregated
+  slide_100k       the same with 100 000 tiles (2 slides timed)
   e2e              configs[4]: synthetic two-level WSI -> tiles -> two embedders -> [high||low] -> MILNet(1024) ->
                    attention map, sharded by low tile, one all-gather of tree rows
 
@@ -521,7 +522,7 @@ def cpu_baseline_embedder(budget_s):
                       f"at the thread count that ran fastest in a short trial"}
 
 
-def slide_leg(cx, n_patches):
+def slide_leg(cx, n_patches, n_steps=None):
     """ONE slide of n_patches ordered tiles (uint8 NHWC, resident), cut contiguously over the
     ranks, embedded in batches of --patches, ONE all-gather of the [N_r,512] rows, then the aggregator on the bag.
     Strong scaling: the slide is fixed, per-rank work shrinks with N."""
@@ -555,8 +556,8 @@ def slide_leg(cx, n_patches):
             res["out"] = net(bag)
             ev[3].record()
 
-    dt, inner, _, _ = cx.timed(step, max(2, min(args.steps, 5)), 1, 0.0, fixed_passes=1)
-    steps = max(2, min(args.steps, 5))
+    steps = n_steps if n_steps else max(2, min(args.steps, 5))
+    dt, inner, _, _ = cx.timed(step, steps, 1, 0.0, fixed_passes=1)
     torch.cuda.synchronize()
     out = res["out"]
     assert out[2].shape[0] == n_patches and torch.isfinite(out[1]).all()
@@ -611,7 +612,7 @@ def main():
     ap.add_argument("--feats", type=int, default=512)
     ap.add_argument("--patches", type=int, default=256, help="patches per rank per embedder pass (batch size)")
     ap.add_argument("--workload", default="all",
-                    help="comma list of aggregator, aggregator_bf16, embedder, slide, e2e; or all / both (= aggregator,embedder)")
+                    help="comma list of aggregator, aggregator_bf16, embedder, slide, slide100k, e2e; or all / both (= aggregator,embedder)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on each timed region")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams independent passes are dealt to (ops.StreamPool); 1 = one pass in flight")
@@ -623,7 +624,7 @@ def main():
                     help="skip the single-bag latency probe (profiling runs: keeps per-kernel averages clean)")
     args = ap.parse_args()
     maybe_self_launch(args)
-    wl = {"all": "aggregator,aggregator_bf16,embedder,slide,e2e", "both": "aggregator,embedder"}.get(args.workload, args.workload)
+    wl = {"all": "aggregator,aggregator_bf16,embedder,slide,slide100k,e2e", "both": "aggregator,embedder"}.get(args.workload, args.workload)
     wl = [w for w in wl.split(",") if w]
     cx = Ctx(args)
     line = {}
@@ -636,6 +637,8 @@ def main():
         subs["embedder"] = embedder_leg(cx)
     if "slide" in wl:
         subs["slide"] = slide_leg(cx, args.slide_patches)
+    if "slide100k" in wl:   # the large slide of SURVEY §8(d) config 4 (15 GB of uint8 tiles over the ranks)
+        subs["slide_100k"] = slide_leg(cx, 100000, n_steps=2)
     if "e2e" in wl:
         subs["e2e"] = e2e_leg(cx, tuple(args.e2e_grid))
     if cx.rank == 0:
