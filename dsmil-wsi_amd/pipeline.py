@@ -230,7 +230,8 @@ def rescale_intensity01(img):
     return (img - lo) / (hi - lo)
 
 
-def attention_colormap(A, pos_arr, bag_prediction, thres, colors, class_names=None, bag_name="", log=print):
+def attention_colormap(A, pos_arr, bag_prediction, thres, colors, class_names=None, bag_name="", log=print,
+                       upsample_device=None):
     """attention_map.py:86-113.  A [N,C] numpy, pos_arr [N,2] (row,col), bag_prediction [C]
     (sigmoid).  Returns the uint8 colour map (32x nearest-neighbour upsampled)."""
     C = A.shape[1]
@@ -261,6 +262,11 @@ def attention_colormap(A, pos_arr, bag_prediction, thres, colors, class_names=No
     # transform.resize(order=0) x32 then img_as_ubyte: nearest-neighbour upsampling commutes with the per-pixel
     # conversion, so convert at tile resolution and repeat the bytes (32*32 = 1024x less float work)
     small = np.clip(np.rint(cmap * 255.0), 0, 255).astype(np.uint8)
+    if upsample_device is not None and torch.device(upsample_device).type == "cuda":
+        # the 32 x 32 byte replication on the GPU + one D2H copy of the finished map (np.repeat twice: 18 ms for a
+        # 3072 x 3328 map, a broadcast + reshape copy 35 ms)
+        t = torch.from_numpy(small).to(upsample_device)
+        return t.repeat_interleave(32, dim=0).repeat_interleave(32, dim=1).cpu().numpy()
     return np.repeat(np.repeat(small, 32, axis=0), 32, axis=1)
 
 
@@ -449,9 +455,44 @@ def embed_tiles(i_classifier, tiles, batch_size=256, streams=3):
     return torch.cat(fl), torch.cat(cl)
 
 
+def _multiscale_embed_pooled(wsi, embedder_low, embedder_high, tile, factor, lo, hi, batch_size, streams):
+    """The two embedding passes of multiscale_bag with every batch — low or high — dealt to ONE stream pool and a
+    single join: the high-magnification tiles are gathered from the slide per batch INSIDE the pooled call (the 3 GB
+    of copy traffic of a whole-slide gather then runs under other batches' conv kernels instead of in front of them),
+    and the few low-magnification batches overlap with the high ones.  Same tiles, same order, same batches as
+    pyramid_tiles + embed_tiles (bit-identical features)."""
+    H, W, C = wsi.shape
+    gy, gx = H // (tile * factor), W // (tile * factor)
+    dev = wsi.device
+    ch = factor * factor
+    li = torch.arange(lo, hi, device=dev)
+    ly, lx = li // gx, li % gx
+    low_img = box_downsample_u8(wsi, factor)
+    low = low_img.view(gy, tile, gx, tile, C).permute(0, 2, 1, 3, 4)[ly, lx].contiguous()
+    hv = wsi.view(gy, factor, tile, gx, factor, tile, C).permute(0, 3, 1, 4, 2, 5, 6)   # [gy, gx, f, f, t, t, C]
+    pool = stream_pool(dev, streams)
+    ppb = max(1, batch_size // ch)                      # parents per high batch: the same 256-tile batches as before
+
+    def high_batch(a, b):
+        return embedder_high(hv[ly[a:b], lx[a:b]].reshape((b - a) * ch, tile, tile, C))[0]
+
+    fh = [pool.run(high_batch, a, min(a + ppb, hi - lo)) for a in range(0, hi - lo, ppb)]
+    fl = [pool.run(lambda a=a: embedder_low(low[a:a + batch_size])[0]) for a in range(0, hi - lo, batch_size)]
+    pool.join()
+    cur = torch.cuda.current_stream(dev)
+    for t in fh + fl:
+        t.record_stream(cur)
+    cy = torch.arange(factor, device=dev).repeat_interleave(factor)
+    cx = torch.arange(factor, device=dev).repeat(factor)
+    rows = (ly[:, None] * factor + cy[None, :]).reshape(-1)
+    cols = (lx[:, None] * factor + cx[None, :]).reshape(-1)
+    parent = torch.arange(hi - lo, device=dev).repeat_interleave(ch)
+    return torch.cat(fl), torch.cat(fh), parent, torch.stack([rows, cols], dim=1)
+
+
 @torch.no_grad()
 def multiscale_bag(wsi, embedder_low, embedder_high, tree_fusion="cat", tile=224, factor=4, batch_size=256,
-                   timings=None):
+                   timings=None, streams=3):
     """Slide array -> tree features [N_high, 1024] ('cat': [high || low], compute_feats.py:113-114) or
     [N_high, 512] ('fusion': high + 0.25 low, :111-112), plus the high tiles' grid positions [N_high, 2].
     Sharded by LOW tile over the ranks of the default process group; one all-gather of tree rows."""
@@ -462,9 +503,13 @@ def multiscale_bag(wsi, embedder_low, embedder_high, tree_fusion="cat", tile=224
     ch = factor * factor
     L = (wsi.shape[0] // (tile * factor)) * (wsi.shape[1] // (tile * factor))
     lo, hi = ddist.shard_range(L, rank, world)
-    low, high, parent, pos = pyramid_tiles(wsi, tile, factor, lo, hi)   # this rank's low tiles and their children
-    f_low, _ = embed_tiles(embedder_low, low, batch_size)
-    f_high, _ = embed_tiles(embedder_high, high, batch_size)
+    if wsi.is_cuda and streams > 1 and hi - lo > 0:
+        f_low, f_high, parent, pos = _multiscale_embed_pooled(wsi, embedder_low, embedder_high, tile, factor, lo, hi,
+                                                              batch_size, streams)
+    else:
+        low, high, parent, pos = pyramid_tiles(wsi, tile, factor, lo, hi)   # this rank's low tiles and their children
+        f_low, _ = embed_tiles(embedder_low, low, batch_size, streams)
+        f_high, _ = embed_tiles(embedder_high, high, batch_size, streams)
     low_of_high = f_low.index_select(0, parent)
     tree = f_high + 0.25 * low_of_high if tree_fusion == "fusion" else torch.cat([f_high, low_of_high], dim=-1)
     if world > 1:
@@ -492,5 +537,6 @@ def multiscale_attention_map(wsi, embedder_low, embedder_high, milnet, thres, co
     feats, pos = multiscale_bag(wsi, embedder_low, embedder_high, tree_fusion, tile, factor, batch_size, timings)
     classes, pred, A, B = milnet(feats)
     prob = np.atleast_1d(torch.sigmoid(pred).squeeze().cpu().numpy())
-    cmap = attention_colormap(A.cpu().numpy(), pos.cpu().numpy(), prob, thres, colors, class_names, "slide", log)
+    cmap = attention_colormap(A.cpu().numpy(), pos.cpu().numpy(), prob, thres, colors, class_names, "slide", log,
+                              upsample_device=A.device if A.is_cuda else None)
     return dict(feats=feats, classes=classes, pred=pred, A=A, B=B, prob=prob, cmap=cmap, pos=pos)
