@@ -586,7 +586,7 @@ def e2e_leg(cx, low_grid):
     res, tm = {}, {}
 
     def step():
-        res["out"] = pl.multiscale_attention_map(wsi, e_lo, e_hi, net, [0.5, 0.5], colors, batch_size=args.patches, timings=tm)
+        res["out"] = pl.multiscale_attention_map(wsi, e_lo, e_hi, net, [0.5, 0.5], colors, batch_size=args.patches, timings=tm, streams=args.streams)
 
     steps = max(2, min(args.steps, 3))
     dt, _, _, _ = cx.timed(step, steps, 1, 0.0, fixed_passes=1)
@@ -598,7 +598,7 @@ def e2e_leg(cx, low_grid):
             "patches_per_s": round((n_high + n_low) * steps / dt, 1),
             "config": {"workload": f"synthetic uint8 slide {gy * 896}x{gx * 896}: {n_low} low tiles + {n_high} high tiles (224x224), "
                                    f"two ResNet-18-IN embedders, [high||low] 1024-d, MILNet(FCLayer(1024,2), BClassifier(1024,2)), "
-                                   f"32x colour map on the host", "slides_timed": steps, "rccl_ranks": world, "streams": 3,
+                                   f"32x colour map replicated on the GPU", "slides_timed": steps, "rccl_ranks": world, "streams": args.streams,
                        "all_gather_s_total": round(tm.get("allgather_s", 0.0), 4)}}
 
 

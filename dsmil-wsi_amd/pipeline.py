@@ -529,12 +529,12 @@ def multiscale_bag(wsi, embedder_low, embedder_high, tree_fusion="cat", tile=224
 
 @torch.no_grad()
 def multiscale_attention_map(wsi, embedder_low, embedder_high, milnet, thres, colors, tree_fusion="cat", tile=224,
-                             factor=4, batch_size=256, class_names=None, log=lambda *_: None, timings=None):
+                             factor=4, batch_size=256, class_names=None, log=lambda *_: None, timings=None, streams=3):
     """configs[4] end to end for ONE slide array: tile -> two-scale embed -> concat -> MILNet(FCLayer(1024, C),
     BClassifier(1024, C)) -> sigmoid(bag logits) vs thresholds -> colour map at high-tile resolution.
     Returns dict(feats, classes, pred, A, B, prob, cmap, pos); only `prob` [C] and the final map leave the device
     (attention_map.py:86-113 does the map on the host too)."""
-    feats, pos = multiscale_bag(wsi, embedder_low, embedder_high, tree_fusion, tile, factor, batch_size, timings)
+    feats, pos = multiscale_bag(wsi, embedder_low, embedder_high, tree_fusion, tile, factor, batch_size, timings, streams)
     classes, pred, A, B = milnet(feats)
     prob = np.atleast_1d(torch.sigmoid(pred).squeeze().cpu().numpy())
     cmap = attention_colormap(A.cpu().numpy(), pos.cpu().numpy(), prob, thres, colors, class_names, "slide", log,
