@@ -1,6 +1,8 @@
 #!/bin/bash
 # GPU-box driver script of round 2 (run through gpurun from the repo root): bash tools_r2.sh <stage> ...
-# stages: tests | bench | variants | stamps | prof_agg | prof_emb | pmc_agg | pmc_emb
+# stages: tests | tests_emb | tests_bf16 | tests_new | bench | variants | variants2 | variants_pp | variants_alt | variants_wide |
+#         stamps | stamps_wino | prof_agg | prof_emb | pmc_agg | pmc_emb    (variants* and stamps* need the expt / trace builds:
+#         python dsmil-wsi_amd/build.py --variant expt -DDSMIL_EXPERIMENTS ; --variant trace -DDSMIL_EXPERIMENTS -DDSMIL_TRACE)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${TAG:-r2}
@@ -17,24 +19,18 @@ variants)
 variants2)
   DSMIL_NATIVE_LIB=libdsmil_hip_expt.so timeout 900 python tools_variants.py aggregator base: tu16:DSMIL_EXPT=16 tu32:DSMIL_EXPT=32 > $OUT/variants_agg2.log 2>&1; cat $OUT/variants_agg2.log
   DSMIL_NATIVE_LIB=libdsmil_hip_expt.so VARIANT_ROUNDS=1 timeout 900 python tools_variants.py embedder base: noxform:DSMIL_WINO_EXPT=1 noraw:DSMIL_WINO_EXPT=2 nou:DSMIL_WINO_EXPT=4 noepi:DSMIL_WINO_EXPT=8 nomfma:DSMIL_WINO_EXPT=16 onlymfma:DSMIL_WINO_EXPT=15 > $OUT/variants_emb.log 2>&1; cat $OUT/variants_emb.log;;
-variants3)
-  DSMIL_NATIVE_LIB=libdsmil_hip_expt.so VARIANT_ROUNDS=2 timeout 1200 python tools_variants.py embedder base: skew1536:DSMIL_WINO_SKEW=1536 skew3072:DSMIL_WINO_SKEW=3072 skew4608:DSMIL_WINO_SKEW=4608 ud2:DSMIL_WINO_EXPT=64 ls:DSMIL_WINO_EXPT=128 ud2ls:DSMIL_WINO_EXPT=192 ud2ls_skew:DSMIL_WINO_EXPT=192,DSMIL_WINO_SKEW=3072 > $OUT/variants_emb3.log 2>&1; cat $OUT/variants_emb3.log;;
 tests_bf16)
   timeout 900 python -m pytest tests/test_agg_bf16_gpu.py tests/test_resnet_gpu.py tests/test_forms_gpu.py -m gpu -x -q > $OUT/pytest_bf16.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_bf16.log;;
-variants_bf16)
-  DSMIL_NATIVE_LIB=libdsmil_hip_expt.so timeout 900 python tools_variants.py aggregator_bf16 dma8: dma4:DSMIL_EXPT=512 old:DSMIL_EXPT=256 > $OUT/variants_bf16.log 2>&1; cat $OUT/variants_bf16.log;;
 tests_emb)
   timeout 900 env DSMIL_WINO_KERNEL=${WINO_KERNEL:-unit} python -m pytest tests/test_resnet_gpu.py tests/test_forms_gpu.py -m gpu -x -q > $OUT/pytest_emb.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_emb.log;;
 variants_pp)
-  VARIANT_ROUNDS=${VARIANT_ROUNDS:-2} timeout 900 python tools_variants.py embedder pp:DSMIL_WINO_KERNEL=pp unit:DSMIL_WINO_KERNEL=unit > $OUT/variants_pp.log 2>&1; cat $OUT/variants_pp.log;;
+  DSMIL_NATIVE_LIB=libdsmil_hip_expt.so VARIANT_ROUNDS=${VARIANT_ROUNDS:-2} timeout 900 python tools_variants.py embedder unit: pp:DSMIL_WINO_KERNEL=pp alt:DSMIL_WINO_KERNEL=alt > $OUT/variants_pp.log 2>&1; cat $OUT/variants_pp.log;;
 stamps_wino)
   for k in ${STAMP_K:-1 12}; do DSMIL_WINO_KERNEL=${WINO_KERNEL:-unit} DSMIL_NATIVE_LIB=libdsmil_hip_trace.so DSMIL_WINO_TRACE=$k timeout 300 python tools_stamp_wino.py > $OUT/stamps_wino_$k.log 2>&1; echo "== launch $k"; tail -14 $OUT/stamps_wino_$k.log | cut -c1-400; done;;
 variants_wide)
   DSMIL_NATIVE_LIB=libdsmil_hip_expt.so VARIANT_ROUNDS=${VARIANT_ROUNDS:-2} timeout 900 python tools_variants.py embedder wide: narrow:DSMIL_WINO_NARROW=1 > $OUT/variants_wide.log 2>&1; cat $OUT/variants_wide.log;;
-variants_uc)
-  VARIANT_ROUNDS=${VARIANT_ROUNDS:-2} timeout 900 python tools_variants.py embedder uc: nouc:DSMIL_NATIVE_LIB=libdsmil_hip_nouc.so > $OUT/variants_uc.log 2>&1; cat $OUT/variants_uc.log;;
 variants_alt)
-  VARIANT_ROUNDS=${VARIANT_ROUNDS:-2} timeout 900 python tools_variants.py embedder alt: wide:DSMIL_WINO_ALT=0 > $OUT/variants_alt.log 2>&1; cat $OUT/variants_alt.log;;
+  DSMIL_NATIVE_LIB=libdsmil_hip_expt.so VARIANT_ROUNDS=${VARIANT_ROUNDS:-2} timeout 900 python tools_variants.py embedder wide: alt:DSMIL_WINO_KERNEL=alt > $OUT/variants_alt.log 2>&1; cat $OUT/variants_alt.log;;
 tests_new)
   timeout 900 python -m pytest tests/test_agg_bwd_gpu.py tests/test_agg_gpu.py tests/test_entry_points.py -m gpu -x -q > $OUT/pytest_new.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_new.log;;
 stamps)

@@ -21,7 +21,7 @@ for r in range(rounds):   # interleaved rounds: box drift hits every variant ali
         e = dict(os.environ)
         e.update(env)
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--no-cpu-baseline",
-                              "--no-single-bag", "--steps", "5", "--warmup", "2", "--min-seconds", "0.4"],
+                              "--no-single-bag", "--streams", "1", "--steps", "5", "--warmup", "2", "--min-seconds", "0.4"],
                              env=e, capture_output=True, text=True, timeout=600)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if out.returncode != 0 or not line:
