@@ -49,6 +49,16 @@ __device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even, lik
     return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16 (lo in bits 0..15), round to nearest even: ONE v_cvt_pk_bf16_f32 on gfx950 (the integer
+// form above costs ~8 VALU ops per value); identical results for every finite input
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2_hw(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    const bf16x2_hw r = __builtin_convertvector(v, bf16x2_hw);
+    return __builtin_bit_cast(unsigned, r);
+}
+
 // 4 consecutive elements at p[k..k+3] as floats, zero beyond klim.  VEC=4 needs rows aligned to
 // 4 elements (16 B for fp32, 8 B for bf16).
 template <int VEC, typename T = float>

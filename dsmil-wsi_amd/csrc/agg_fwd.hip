@@ -40,6 +40,8 @@
 
 #include "agg_common.h"
 #include "agg_split.h"
+#include "agg_res.h"
+#include "lds_attr.h"
 
 namespace {
 
@@ -465,9 +467,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend_spl
 // accumulator registers 8s..8s+7 of tile t hold:  W2p[j][32t+16s+8hi+e] = W2[j][32t+16s+(e&3)+8(e>>2)+4hi].
 // 64 bf16 (128 B) per staged row, so LDS geometry and fragment addressing equal the fp32 kernel's.
 // --------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
-}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) { return pack_bf16x2_hw(lo, hi); }
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend_bf16(AttendArgs a) {
@@ -1060,6 +1060,31 @@ int launch_attend_bf16_dma(AttendArgs a, long long max_rows, int n_bags, hipStre
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
+// The tile-resident kernel (agg_res.h): persistent, one 320-thread workgroup per CU.  Needs the whole K of a
+// 128-row tile in LDS (K % 64 == 0, K <= 512), values == features, C <= 2; everything else keeps the ring kernels.
+bool bf16_res_ok(const AttendArgs& a) {
+    return a.K % 64 == 0 && a.K <= 64 * RS_MAXCH && a.Kv == a.K && a.vals == a.feats && a.C <= 2;
+}
+int launch_attend_bf16_res(AttendArgs a, long long max_rows, int n_bags, hipStream_t st) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return DSMIL_E_LAUNCH;
+    typedef void (*res_fn)(AttendArgs, int, int);
+    const res_fn fn = a.C == 2 ? (a.nonlinear ? k_attend_bf16_res<true, true> : k_attend_bf16_res<true, false>)
+                               : (a.nonlinear ? k_attend_bf16_res<false, true> : k_attend_bf16_res<false, false>);
+    if (!dsmil_lds::allow((const void*)fn, RS_LDS_BYTES)) return DSMIL_E_LAUNCH;
+    const int K64 = (a.K + 63) / 64 * 64;
+    a.wpk = a.wpk + (size_t)QD * K64 + QD * QD;   // the fragment image sits behind the row-major one
+    const long long tiles_per_bag = (max_rows + RS_BM - 1) / RS_BM;
+    const long long n_items = tiles_per_bag * n_bags;
+    if (n_items > 0x7fffffffLL) return DSMIL_E_UNSUPPORTED;
+    const unsigned grid = (unsigned)(n_items < cus ? n_items : cus);
+    const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(RS_THREADS), RS_LDS_BYTES, st, a, (int)tiles_per_bag, (int)n_items);
+    dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
 template <int NW>
 int launch_attend_bf16(const AttendArgs& a, long long max_rows, int n_bags, hipStream_t st) {
     constexpr int BM = NW * 32;
@@ -1250,7 +1275,12 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
 #ifdef DSMIL_EXPERIMENTS
         if (a.expt & 256) bf16_dma = false;
 #endif
-        if (bf16_dma) rc = launch_attend_bf16_dma(a, max_rows, nb, st);
+        bool bf16_res = bf16_dma && bf16_res_ok(a);
+#ifdef DSMIL_EXPERIMENTS
+        if (a.expt & 512) bf16_res = false;
+#endif
+        if (bf16_res) rc = launch_attend_bf16_res(a, max_rows, nb, st);
+        else if (bf16_dma) rc = launch_attend_bf16_dma(a, max_rows, nb, st);
         else if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, nb, st) : launch_attend_bf16<1>(a, max_rows, nb, st);
         else if (mode == 9 && NW == 4) rc = v4 ? launch_attend_split<4, 4, 9>(a, max_rows, nb, st) : launch_attend_split<4, 1, 9>(a, max_rows, nb, st);
         else if (mode == 9) rc = v4 ? launch_attend_split<1, 4, 9>(a, max_rows, nb, st) : launch_attend_split<1, 1, 9>(a, max_rows, nb, st);

@@ -232,6 +232,8 @@ __device__ __forceinline__ void s3_wait_vm_dyn(int n) {  // n is wave-uniform
         case 16: S3_WAIT_VM(16); break;
         case 24: S3_WAIT_VM(24); break;
         case 28: S3_WAIT_VM(28); break;
+        case 32: S3_WAIT_VM(32); break;
+        case 48: S3_WAIT_VM(48); break;
         default: S3_WAIT_VM(0); break;
     }
 }

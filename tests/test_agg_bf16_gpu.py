@@ -95,3 +95,53 @@ def test_bf16_dma_kernel_at_the_wide_launch(tag, N, nonlinear):
         again = ops.agg_forward(xb, [N], w, nonlinear=nonlinear)
         for a, b in zip(again, first):
             assert torch.equal(a, b)
+
+
+def _oracle_bags(bags, p, nonlinear=True):
+    pr = {k: _round_bf16(v) for k, v in p.items()}
+    return [orc.milnet_forward(_round_bf16(b), pr, dtype="f64", nonlinear=nonlinear) for b in bags]
+
+
+@pytest.mark.parametrize("K,C,nonlinear,lengths", [
+    (512, 2, True, [1, 2, 127, 128, 129, 255, 256, 257, 1000, 31, 4097] * 6 + [70000]),   # ragged, one long bag
+    (512, 1, True, [10000] * 8),                                                          # configs[2]'s shape, C = 1
+    (256, 2, True, [3000 + 37 * i for i in range(30)]),                                   # 4 feature chunks
+    (64, 2, False, [2500 + 11 * i for i in range(40)]),                                   # 1 chunk, linear query
+    (448, 1, False, [9000] * 9),                                                          # 7 chunks (odd), linear query
+])
+def test_bf16_resident_tile_kernel(K, C, nonlinear, lengths):
+    """k_attend_bf16_res (agg_res.h): the persistent kernel with the 128-row tile resident in LDS — taken for
+    >= 512 tiles of 128 rows when K % 64 == 0, K <= 512, C <= 2.  Ragged bags (tiles past a bag's end are skipped by every
+    wave alike, partial last tiles, 1-row bags), 1 / 4 / 7 / 8 feature chunks, linear query; oracle and tolerances as
+    above; five runs bit-identical (hand-counted DMA completion, wave-specialised barrier protocol)."""
+    import dsmil_wsi_amd.ops as ops
+    rng = np.random.default_rng(K + C)
+    p = {"fc_w": rng.standard_normal((C, K), dtype=np.float32) * 0.05, "fc_b": rng.standard_normal(C, dtype=np.float32) * 0.1,
+         "q0_w": rng.standard_normal((128, K), dtype=np.float32) * np.float32(1.0 / np.sqrt(K)),
+         "q0_b": rng.standard_normal(128, dtype=np.float32) * 0.1,
+         "q2_w": rng.standard_normal((128, 128), dtype=np.float32) * np.float32(1.0 / np.sqrt(128)),
+         "q2_b": rng.standard_normal(128, dtype=np.float32) * 0.1,
+         "fcc_w": rng.standard_normal((C, C, K), dtype=np.float32) * 0.05, "fcc_b": rng.standard_normal(C, dtype=np.float32) * 0.1}
+    bags = [make_bag(9000 + i, n, K) for i, n in enumerate(lengths)]
+    w = {k: torch.from_numpy(v).cuda() for k, v in p.items()}
+    x = torch.from_numpy(np.concatenate(bags)).cuda().to(torch.bfloat16)
+    assert sum(n // 128 + 1 for n in lengths) >= 512
+    out = ops.agg_forward(x, lengths, w, nonlinear=nonlinear)
+    torch.cuda.synchronize()
+    classes, pred, A, B, idx = [o.float().cpu().numpy() if o.dtype != torch.int64 else o.cpu().numpy() for o in out]
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    check = sorted(set([0, 1, 2, 5, len(lengths) - 1, len(lengths) // 2]))
+    refs = _oracle_bags([bags[i] for i in check], p, nonlinear)
+    for i, ref in zip(check, refs):
+        sl = slice(off[i], off[i + 1])
+        np.testing.assert_allclose(classes[sl], ref[0], atol=1e-4, rtol=1e-5)
+        np.testing.assert_allclose(A[sl], ref[2], atol=1e-6, rtol=3e-2)
+        np.testing.assert_allclose(B[i].reshape(ref[3].shape), ref[3], atol=2e-3, rtol=2e-2)
+        np.testing.assert_allclose(pred[i:i + 1], ref[1], atol=2e-3, rtol=2e-2)
+        assert np.array_equal(idx[i], ref[4])
+    for i in range(len(lengths)):
+        np.testing.assert_allclose(A[off[i]:off[i + 1]].sum(axis=0), 1.0, atol=1e-4)
+    for _ in range(4):
+        again = ops.agg_forward(x, lengths, w, nonlinear=nonlinear)
+        for a_, b_ in zip(again, out):
+            assert torch.equal(a_, b_)

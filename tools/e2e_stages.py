@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Stage times of the multi-scale end-to-end path (bench.py e2e leg) on one GPU."""
+import _path  # noqa: F401  (repo root on sys.path)
 import time
 import numpy as np
 import torch
@@ -7,7 +8,6 @@ import torch.nn as nn
 import dsmil
 from dsmil_wsi_amd import pipeline as pl
 import sys
-sys.path.insert(0, "tests")
 from util import build_net
 from dsmil_wsi_amd.resnet import resnet18
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (on the GPU box, from the repo root): bash tools_prof.sh <tag> -- <bench args>
+# Usage (on the GPU box, from the repo root): bash tools/prof.sh <tag> -- <bench args>
 # Writes rocprofv3 kernel-trace stats and separate PMC passes under gpurun_out/<tag>/.
 set -u
 TAG=$1; shift; shift

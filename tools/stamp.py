@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Phase timeline of k_query_attend_split from in-kernel s_memtime stamps.
 Needs a trace build of the library:  python dsmil-wsi_amd/build.py --variant trace -DDSMIL_EXPERIMENTS -DDSMIL_TRACE
-Run:  DSMIL_NATIVE_LIB=libdsmil_hip_trace.so DSMIL_EXPT=68 python tools_stamp.py   (64 = stamps, 4 = stop after the MLP so the tail does not overwrite them; +8: the XE variant)"""
+Run:  DSMIL_NATIVE_LIB=libdsmil_hip_trace.so DSMIL_EXPT=68 python tools/stamp.py   (64 = stamps, 4 = stop after the MLP so the tail does not overwrite them; +8: the XE variant)"""
+import _path  # noqa: F401  (repo root on sys.path)
 import os
 import numpy as np
 import torch

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Step timeline of k_conv_wino_pp from in-kernel s_memtime stamps (trace build only):
     python dsmil-wsi_amd/build.py --variant trace -DDSMIL_EXPERIMENTS -DDSMIL_TRACE
-    DSMIL_NATIVE_LIB=libdsmil_hip_trace.so DSMIL_WINO_TRACE=<k> python tools_stamp_wino.py
+    DSMIL_NATIVE_LIB=libdsmil_hip_trace.so DSMIL_WINO_TRACE=<k> python tools/stamp_wino.py
 k = which Winograd launch of the process records (1 = first conv of the first forward; one forward of ResNet-18 has 13).
 k_conv_wino_s3 (unit kernel; wave 0 = role 0, last wave = role 1; a step = one chunk): 0 top, 1 after the MFMAs, 2 after
 raw_write + raw_load, 3 after barrier 1, 4 after the transform, 5 after barrier 2.
 k_conv_wino_pp: multiply wave (role 0) slots: 0 step top, 1 after position 3, 2 after position 7, 3 after the barrier, 4 after the epilogue.
 Staging wave (role 1) slots: 0 top, 1 after the transform, 2 after raw_write, 3 after raw_load + statistics, 4 after the barrier."""
+import _path  # noqa: F401  (repo root on sys.path)
 import ctypes
 import os
 import numpy as np

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Experiment: independent passes dealt round-robin to S HIP streams (ops.StreamPool, one workspace per stream).
-    python tools_streams.py agg|bf16|emb"""
+    python tools/streams.py agg|bf16|emb"""
+import _path  # noqa: F401  (repo root on sys.path)
 import sys
 import time
 import torch
 import torch.nn as nn
 import dsmil
 from dsmil_wsi_amd import ops
-sys.path.insert(0, "tests")
 from conftest import load_weights  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "agg"

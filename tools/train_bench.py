@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Time one DSMIL training step (train_tcga.py:60-74: forward, loss, backward, Adam step) per bag on
 the GPU: native backward (dsmil_agg_backward) vs the dense-product backward, plus the parts.
-Usage: python tools_train_bench.py [--rows 10000] [--feats 512] [--classes 2] [--steps 50]"""
+Usage: python tools/train_bench.py [--rows 10000] [--feats 512] [--classes 2] [--steps 50]"""
+import _path  # noqa: F401  (repo root on sys.path)
 import argparse
 import json
 import time

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """A/B of kernel variants on the GPU box: runs bench.py legs in subprocesses under different environment settings
 (experiment builds read their knobs once per process) and prints one line per variant.
-Usage: python tools_variants.py <workload> NAME:K=V,K=V ...   (NAME: alone = product build, no knobs)"""
+Usage: python tools/variants.py <workload> NAME:K=V,K=V ...   (NAME: alone = product build, no knobs)"""
 import json
 import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 workload = sys.argv[1]
 rounds = int(os.environ.get("VARIANT_ROUNDS", "2"))
 specs = []
