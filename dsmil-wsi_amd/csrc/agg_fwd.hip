@@ -1061,17 +1061,22 @@ int launch_attend_bf16_dma(AttendArgs a, long long max_rows, int n_bags, hipStre
 }
 
 // The tile-resident kernel (agg_res.h): persistent, one 320-thread workgroup per CU.  Needs the whole K of a
-// 128-row tile in LDS (K % 64 == 0, K <= 512), values == features, C <= 2; everything else keeps the ring kernels.
+// 128-row tile in LDS and this wave's weight slice in registers: instantiated for K = 512 and K = 256, values == features,
+// C <= 2; everything else keeps the ring kernels.
 bool bf16_res_ok(const AttendArgs& a) {
-    return a.K % 64 == 0 && a.K <= 64 * RS_MAXCH && a.Kv == a.K && a.vals == a.feats && a.C <= 2;
+    return (a.K == 512 || a.K == 256) && a.Kv == a.K && a.vals == a.feats && a.C <= 2;
+}
+template <int NCH>
+void (*bf16_res_fn(const AttendArgs& a))(AttendArgs, int, int) {
+    return a.C == 2 ? (a.nonlinear ? k_attend_bf16_res<NCH, true, true> : k_attend_bf16_res<NCH, true, false>)
+                    : (a.nonlinear ? k_attend_bf16_res<NCH, false, true> : k_attend_bf16_res<NCH, false, false>);
 }
 int launch_attend_bf16_res(AttendArgs a, long long max_rows, int n_bags, hipStream_t st) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         return DSMIL_E_LAUNCH;
     typedef void (*res_fn)(AttendArgs, int, int);
-    const res_fn fn = a.C == 2 ? (a.nonlinear ? k_attend_bf16_res<true, true> : k_attend_bf16_res<true, false>)
-                               : (a.nonlinear ? k_attend_bf16_res<false, true> : k_attend_bf16_res<false, false>);
+    const res_fn fn = a.K == 512 ? bf16_res_fn<8>(a) : bf16_res_fn<4>(a);
     if (!dsmil_lds::allow((const void*)fn, RS_LDS_BYTES)) return DSMIL_E_LAUNCH;
     const int K64 = (a.K + 63) / 64 * 64;
     a.wpk = a.wpk + (size_t)QD * K64 + QD * QD;   // the fragment image sits behind the row-major one

@@ -1,28 +1,34 @@
-// agg_res.h — k_attend_bf16_res: the bf16-storage query / attend kernel with its 128-row tile RESIDENT in LDS.
+// agg_res.h — k_attend_bf16_res: the bf16-storage query / attend kernel with its 128-row tile RESIDENT in LDS and
+// the query weights RESIDENT in registers (dsmil.py:46-62 behind the instance logits, BASELINE configs[2]).
 //
-// What it replaces: k_query_attend_bf16_dma streamed each 64-k chunk of the tile through a 3-slot LDS ring for the
-// query MLP and then read the whole tile a SECOND time from L2 / HBM for the value sum  B = sum_n p[n] x[n,:]
-// (dsmil.py:57) once the attention of every row was known — 1.34 GB of fabric traffic per 64 bags against 0.68 GB
-// algorithmic, and every tile paid a cold start.  Here:
-//   * the tile (128 rows x K <= 512 bf16 = up to 128 KiB) stays in LDS from its first use by GEMM 1 until the value
-//     sum has consumed it: ONE read of every feature byte;
-//   * the workgroup is PERSISTENT (one per CU, 160 KiB of LDS) and walks (bag, tile) work items; a fifth wave does
-//     nothing but issue the feature stream (global_load_lds, 1 KiB pieces) and wait for it, so the HBM-sourced
-//     pieces never sit in front of the L2-sourced weight pieces in a compute wave's in-order vmcnt queue, and the
-//     next tile's chunks are requested as soon as the value sum has released their slots;
-//   * the value sum is split by FEATURE CHUNK over the four compute waves (wave w owns chunks w and 4 + w, all 128
-//     rows), so no cross-wave reduction of B is needed and slots are released four at a time.
-// LDS map: sX [8 chunks][128 rows][128 B] (slot c of row r holds global 16-B slot c ^ f(r), as in the DMA kernel:
-// conflict-free ds_read_b128 for the MFMA fragments AND for the row-major reads of the value sum), then the weight
-// ring sW [2][16 KiB]; the 2 KiB of softmax scratch (tile max / sum exchange, p[128][2]) alias the END of sW[1],
-// which is dead between the last step of GEMM 2 and step 1 of the next tile.
-// Barrier protocol (all 5 waves execute the same sequence per tile):
-//   B_s (s = 0 .. nst-1)  before step s: W(s) landed (each compute wave waited for its own pieces), X(s) landed
-//                         (loader waited), everyone is past step s-1 (so W buffer (s+1)&1 may be refilled)
-//   E0                    GEMM 2 done: the weight ring is free (scratch may be written, W(0) of the next tile issued)
-//   E1                    wave maxima published          E2   p[row][class] and wave sums published
-//   E3                    value-sum step 0 done: chunks 0..3 released (loader issues chunks 0, 1 of the next tile)
-//   E4                    value-sum step 1 done: chunks 4..7 released (loader issues chunks 2, 3; chunk s + 4 follows B_s)
+// What it replaces: k_query_attend_bf16_dma streamed each 64-k chunk of the tile through a 3-slot LDS ring next to
+// a ring of weight chunks (as many L2 -> LDS bytes for weights as HBM -> LDS bytes for features, both in one in-order
+// vmcnt queue), then read the whole tile a SECOND time from L2 / HBM for the value sum B = sum_n p[n] x[n,:]
+// (dsmil.py:57) on the VALU.  In-kernel stamps of a first tile-resident form (weights still ringed, one extra wave
+// issuing the features) showed where a tile's 30 k cycles went: every 64-k step waited ~1300 cycles for its 16 KiB
+// of weights to come through L2 -> LDS behind 512 cycles of MFMA, and the VALU value sum took 5 k cycles.  Hence:
+//   * one PERSISTENT 256-thread workgroup per CU (one wave per SIMD, up to 512 VGPRs each) walks (bag, tile) items;
+//   * wave w keeps ITS slice of the weights in VGPRs for the whole launch: W1 rows [32w, 32w+32) x K (<= 128 VGPRs)
+//     and W2 rows [32w, 32w+32) x 128 (32 VGPRs) as ready MFMA A-fragments.  GEMM 1 gives wave w the hidden units
+//     [32w, 32w+32) of ALL 128 rows (B operand = any row of the tile, read from LDS); the ReLU'd bf16 hidden layer is
+//     exchanged through 32 KiB of LDS (one write + one barrier) and GEMM 2 gives wave w the query units [32w, 32w+32)
+//     of all rows.  No weight byte moves after the prologue;
+//   * the tile (128 rows x K <= 512 bf16 = up to 128 KiB) stays in LDS from GEMM 1 until the value sum has consumed
+//     it: ONE read of every feature byte.  Each wave issues the LDS-DMA pieces of its own 32 rows; the only VMEM
+//     traffic between them is a handful of loads / stores that are older or younger than every piece that matters;
+//   * the value sum runs on the matrix pipe: out[c][k] = sum_n p[n][c] x[n][k] with the row-major tile as the B operand
+//     through ds_read_b64_tr_b16 (two transposed reads per 32 rows x 16 features) and the attention weights as the A
+//     operand, cut into three bf16 planes (exact fp32 p) that sit in DIFFERENT ROWS of the same 16-row A fragment —
+//     one v_mfma_f32_16x16x32_bf16 per 32 x 16 block does all three plane products; the planes are added at the end.
+//     Wave w owns the features of chunks w and 4 + w for all 128 rows, so B needs no cross-wave reduction and the
+//     LDS slots are released four chunks at a time for the next tile's stream.
+// LDS map: sX [8 chunks][128 rows][128 B] (16-B slot c of row r holds global slot c ^ f(r), f(r) = (r&6)|((r>>4)&1)
+// on the row's index inside its 32-row group: conflict-free ds_read_b128 of the MFMA fragments and conflict-free
+// transposed reads), then 32 KiB sH: the hidden layer [128 rows][16 blocks x 16 B] (block b of row n at b ^ (n & 15));
+// after GEMM 2 the same 32 KiB hold the softmax scratch (partial scores, tile max / sum, p[class][row]).
+// Barriers per tile (all four waves): one per feature chunk (its pieces have landed for everybody), Bh (hidden layer
+// written), E0 (GEMM 2 done, sH free), E1 (partial scores), E2 (tile max), E3 (p and sums), T0 (value-sum step 0 done:
+// chunks 0..3 released), T1 (chunks 4..7 released).
 #pragma once
 #include "agg_common.h"
 #include "agg_split.h"
@@ -30,19 +36,36 @@
 namespace {
 
 constexpr int RS_BM = 128;                  // rows per tile
-constexpr int RS_CH_F4 = 1024;              // float4 (16 B) per 16 KiB chunk (features: 128 rows x 128 B; weights: 128 units x 64 k)
-constexpr int RS_MAXCH = 8;                 // K <= 512
-constexpr int RS_THREADS = 320;             // 4 compute waves + 1 feature-stream wave
+constexpr int RS_CH_F4 = 1024;              // float4 (16 B) per 16 KiB feature chunk (128 rows x 128 B)
+constexpr int RS_MAXCH = 8;                 // K <= 512 (the kernel is instantiated for K = 512 and K = 256)
+constexpr int RS_THREADS = 256;             // one wave per SIMD
 constexpr int RS_LDS_BYTES = (RS_MAXCH + 2) * RS_CH_F4 * 16;   // 163 840 = all of a CU's LDS
-constexpr int RS_SCRATCH_F4 = 2 * RS_CH_F4 - 128;              // last 2 KiB of sW[1], in float4 units from sW
+
+typedef short rs_v4s __attribute__((ext_vector_type(4)));
 
 // tanh x = 1 - 2 / (1 + e^{2x}) on v_exp_f32 / v_rcp_f32 (5 VALU ops against ~31 + branches for tanhf): abs error
 // ~1e-7, exact saturation (e -> inf gives 1, e -> 0 gives -1).  64 of these per lane and tile: with tanhf they cost
-// more issue slots than the tile's 160 MFMAs.
+// more issue slots than the tile's MFMAs.
 __device__ __forceinline__ float rs_tanh(float x) {
     const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
     return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
 }
+
+// v_mfma_f32_32x32x16_bf16 with the A operand AND the accumulator in the accumulator half of the register file.  A wave
+// may hold 512 registers, but only 256 of them are addressable as VGPRs; the resident weight fragments (160 registers)
+// left hipcc ~90 VGPRs for everything else and it serialised every read -> use chain.  "a" operands keep the weights in
+// AGPRs for the whole launch (hipcc itself never places an MFMA A/B operand there).  Inside an asm statement the compiler
+// pads no hazards: callers put s_nop states between a compiler-written accumulator and the first MFMA, and between the
+// last MFMA and any compiler read of its result (RS_NOP).
+// The accumulators stay in VGPRs ("+v"): every v_accvgpr_read / _write between the matrix pipe and the VALU phases is an
+// issue slot this one-wave-per-SIMD kernel does not have.  rs_mfma0 starts a chain from the inline constant 0.
+__device__ __forceinline__ void rs_mfma(f32x16& acc, const f32x4& a_agpr, const f32x4& b_vgpr) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(a_agpr), "v"(b_vgpr));
+}
+__device__ __forceinline__ void rs_mfma0(f32x16& acc, const f32x4& a_agpr, const f32x4& b_vgpr) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(a_agpr), "v"(b_vgpr));
+}
+#define RS_NOP() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
 struct RsWork {
     int bag;
@@ -67,18 +90,19 @@ __device__ __forceinline__ bool rs_fetch(const AttendArgs& a, int tiles_per_bag,
     return false;
 }
 
-template <bool TWO, bool NL>   // TWO: C == 2 (else C == 1); NL: the two-layer (nonlinear) query of dsmil.py:31-32
-__global__ __launch_bounds__(RS_THREADS) void k_attend_bf16_res(AttendArgs a, int tiles_per_bag, int n_items) {
+template <int NCH, bool TWO, bool NL>   // NCH: K / 64; TWO: C == 2 (else C == 1); NL: the two-layer query of dsmil.py:31-32
+__global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a, int tiles_per_bag, int n_items) {
+    static_assert(NCH >= 1 && NCH <= RS_MAXCH, "feature chunks");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* sX = reinterpret_cast<f32x4*>(smem);              // [8][RS_CH_F4]
-    f32x4* sW = sX + RS_MAXCH * RS_CH_F4;                    // [2][RS_CH_F4]
-    float* sRed = reinterpret_cast<float*>(sW + RS_SCRATCH_F4);   // [4 waves][2 classes] max, then [8..15] sums
-    float* sP = sRed + 16;                                   // [128 rows][2 classes]
+    f32x4* sH = sX + RS_MAXCH * RS_CH_F4;                    // [128 rows][16 blocks]: hidden layer, bf16
+    float* sS = reinterpret_cast<float*>(sH);                // scratch after GEMM 2: [4 waves][2 classes][128 rows] partial scores
+    unsigned short* sPl = reinterpret_cast<unsigned short*>(sS + 4 * 2 * RS_BM);   // [3 planes][2 classes][128 rows] bf16 planes of p
+    float* sRed = reinterpret_cast<float*>(sPl + 3 * 2 * RS_BM);                   // [0..3] wave maxima, [4..7] wave sums
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int K = a.K;
-    const int nk1 = K >> 6;                                  // feature chunks (K % 64 == 0, K <= 512: checked by the launcher)
-    const int nst = nk1 + (NL ? 2 : 0);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int K = a.K, C = a.C;
     const bf16_t* feats = reinterpret_cast<const bf16_t*>(a.feats);
     const f32x4* wpk = reinterpret_cast<const f32x4*>(a.wpk);   // chunk-major fragment image (k_pack_agg_bf16)
 
@@ -86,304 +110,353 @@ __global__ __launch_bounds__(RS_THREADS) void k_attend_bf16_res(AttendArgs a, in
     RsWork cur, nxt;
     if (!rs_fetch(a, tiles_per_bag, n_items, item, cur)) return;
 #ifdef DSMIL_TRACE
-    // trace builds, DSMIL_EXPT & 64: lane 0 of compute wave 0 (slots 0..31) and of the feature-stream wave (slots 32..63)
-    // stamp s_memtime after every barrier into the tile's rows of A (tools/stamp_res.py); k_finish is skipped.
+    // trace builds, DSMIL_EXPT & 64: lane 0 of wave 0 stamps s_memtime at the phase boundaries into the tile's rows of A
+    // (tools/stamp_res.py); k_finish is skipped.  Stamps are LDS-buffered and stored at the end of the tile (a global
+    // store per stamp would sit in the vmcnt queue that the chunk waits count).
+    unsigned long long stamps[20];
     int nstamp = 0;
-    auto STAMP = [&](const RsWork& w) {
-        if (DSMIL_EXPT_ON(a, 64) && lane == 0 && (wave == 0 || wave == 4) && nstamp < 32 && w.row0 + RS_BM <= w.Nb) {
-            const unsigned long long tt = __builtin_readcyclecounter();
-            unsigned long long* o = reinterpret_cast<unsigned long long*>(a.scores + (w.off0 + w.row0) * (long long)a.C);
-            o[(wave == 4 ? 32 : 0) + nstamp] = tt;
-        }
-        ++nstamp;
-    };
-#define RS_STAMP(w) STAMP(w)
-#define RS_STAMP_RESET() nstamp = 0
+#define RS_STAMP() do { if (nstamp < 20) stamps[nstamp] = __builtin_readcyclecounter(); ++nstamp; } while (0)
+#define RS_STAMP_FLUSH(w) do { if (DSMIL_EXPT_ON(a, 64) && tid == 0 && (w).row0 + RS_BM <= (w).Nb) { \
+        unsigned long long* o_ = reinterpret_cast<unsigned long long*>(a.scores + ((w).off0 + (w).row0) * (long long)C); \
+        _Pragma("unroll") for (int i_ = 0; i_ < 20; ++i_) o_[i_] = stamps[i_]; } nstamp = 0; } while (0)
 #else
-#define RS_STAMP(w)
-#define RS_STAMP_RESET()
+#define RS_STAMP()
+#define RS_STAMP_FLUSH(w)
 #endif
 
-    if (wave == 4) {
-        // ------------------------------------------------------------------ feature-stream wave
-        const bf16_t* src[16];
-        auto set_rows = [&](const RsWork& w) {
+    // ---- the feature stream: this wave's 32 rows of every chunk, 4 pieces of 8 rows x 128 B
+    const bf16_t* src[4];
+    auto set_rows = [&](const RsWork& w) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int r32 = (q & 3) * 8 + (lane >> 3);                  // row inside its compute wave's 32
-                long long gr = w.row0 + (q >> 2) * 32 + r32;
-                if (gr >= w.Nb) gr = w.Nb - 1;                              // rows past the bag end get weight 0 later
-                const int gslot = (lane & 7) ^ ((r32 & 6) | ((r32 >> 4) & 1));
-                src[q] = feats + phys_row(a.rowmap, w.off0 + gr) * (long long)K + gslot * 8;
-            }
-        };
-        auto issue_chunk = [&](int c) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-                __builtin_amdgcn_global_load_lds((const DSMIL_GLOBAL void*)(src[q] + c * 64),
-                                                 (__attribute__((address_space(3))) void*)(sX + c * RS_CH_F4 + q * 64), 16, 0, 0);
-        };
-        set_rows(cur);
-        for (int c = 0; c < 4 && c < nk1; ++c) issue_chunk(c);
-        for (;;) {
-            int in = item + (int)gridDim.x;
-            const bool has_next = rs_fetch(a, tiles_per_bag, n_items, in, nxt);
-            RS_STAMP_RESET();
-            RS_STAMP(cur);                                                  // 0: tile start
-            for (int s = 0; s < nk1; ++s) {
-                // chunk s has landed; chunks issued after it may stay in flight
-                const int issued = (s + 4 < nk1 ? s + 4 : nk1);
-                s3_wait_vm_dyn(16 * (issued - (s + 1)));
-                RS_STAMP(cur);                                              // 1 + 2s: chunk s landed
-                __builtin_amdgcn_s_barrier();                               // B_s
-                RS_STAMP(cur);                                              // 2 + 2s: past B_s
-                if (s + 4 < nk1) issue_chunk(s + 4);
-            }
-            for (int s = nk1; s < nst; ++s) __builtin_amdgcn_s_barrier();   // B_s of GEMM 2
-            __builtin_amdgcn_s_barrier();                                   // E0
-            RS_STAMP(cur);
-            __builtin_amdgcn_s_barrier();                                   // E1
-            __builtin_amdgcn_s_barrier();                                   // E2
-            RS_STAMP(cur);
-            if (has_next) set_rows(nxt);
-            __builtin_amdgcn_s_barrier();                                   // E3: chunks 0..3 released
-            RS_STAMP(cur);
-            if (has_next) {
-                issue_chunk(0);
-                if (nk1 > 1) issue_chunk(1);
-            }
-            RS_STAMP(cur);
-            __builtin_amdgcn_s_barrier();                                   // E4: chunks 4..7 released
-            RS_STAMP(cur);
-            if (!has_next) break;
-            if (nk1 > 2) issue_chunk(2);
-            if (nk1 > 3) issue_chunk(3);
-            cur = nxt;
-            item = in;
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- compute waves
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int fr = (l31 & 6) | ((l31 >> 4) & 1);
-    auto issue_w = [&](int s) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = i * 4 + wave;                                     // 16 pieces of 1 KiB per chunk
-            __builtin_amdgcn_global_load_lds((const DSMIL_GLOBAL void*)(wpk + (long long)s * RS_CH_F4 + q * 64 + lane),
-                                             (__attribute__((address_space(3))) void*)(sW + (s & 1) * RS_CH_F4 + q * 64), 16, 0, 0);
+        for (int p = 0; p < 4; ++p) {
+            const int r32 = p * 8 + (lane >> 3);
+            long long gr = w.row0 + wave * 32 + r32;
+            if (gr >= w.Nb) gr = w.Nb - 1;                                  // rows past the bag end get weight 0 later
+            const int gslot = (lane & 7) ^ ((r32 & 6) | ((r32 >> 4) & 1));
+            src[p] = feats + phys_row(a.rowmap, w.off0 + gr) * (long long)K + gslot * 8;
         }
     };
+    auto issue_chunk = [&](int c) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            __builtin_amdgcn_global_load_lds((const DSMIL_GLOBAL void*)(src[p] + c * 64),
+                                             (__attribute__((address_space(3))) void*)(sX + c * RS_CH_F4 + (wave * 32 + p * 8) * 8), 16, 0, 0);
+    };
+    set_rows(cur);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) issue_chunk(c);
+
+    // ---- resident weights: A fragments of this wave's 32 hidden / query units (fragment image of k_pack_agg_bf16:
+    //      chunk s: [ks][t][lane] x 16 B; W2 chunks carry the k permutation of the accumulator layout), loaded STRAIGHT
+    //      into the accumulator file (a VMEM load may target AGPRs on gfx950): a 128-bit tuple that is born there stays
+    //      there.  The loads are invisible to hipcc's waitcnt pass and are drained by hand below.
+    union Frag { f32x4 f; bf16x8 v; };
+    f32x4 w1[NCH * 4], w2[8];
+#pragma unroll
+    for (int q = 0; q < NCH * 4; ++q) {
+        const f32x4* src_w = wpk + (long long)(q >> 2) * RS_CH_F4 + ((q & 3) * 4 + wave) * 64 + lane;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(w1[q]) : "v"(src_w) : "memory");
+    }
+    f32x4 b1[4], b2c[4];     // biases of units 32 wave + 8g + 4hi + e; b2c = b2 * 2 log2(e): folded into tanh's first fma
+    constexpr float TANH_C = 2.8853900817779268f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        b1[g] = *reinterpret_cast<const f32x4*>(a.q0_b + 32 * wave + 8 * g + 4 * hi);
+        b2c[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (NL) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4* src_w = wpk + (long long)(NCH + (q >> 2)) * RS_CH_F4 + ((q & 3) * 4 + wave) * 64 + lane;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(w2[q]) : "v"(src_w) : "memory");
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b2c[g] = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * wave + 8 * g + 4 * hi) * TANH_C;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the resident weights (and the first tile's pieces) have landed
+    __builtin_amdgcn_sched_barrier(0);
+    const int fr = (l31 & 6) | ((l31 >> 4) & 1);
     const float scale = 0.08838834764831845f;                               // 1/sqrt(128), dsmil.py:56
-    const int C = a.C;
-    issue_w(0);
+    const f32x4* xrd = sX + l31 * 8;                                         // this lane's row in every 32-row group
+    // this lane's (slot ^ row permutation) for the four 16-k steps of a chunk
+    int xsl[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xsl[ks] = (ks * 2 + hi) ^ fr;
+
     for (;;) {
         int in = item + (int)gridDim.x;
         const bool has_next = rs_fetch(a, tiles_per_bag, n_items, in, nxt);
-        RS_STAMP_RESET();
-        RS_STAMP(cur);                                                      // 0: tile start
-
-        // the accumulators start from the bias (unit 32t + 8g + 4hi + e lives in register 4g + e): no bias pass later
+        RS_STAMP();                                                         // 0: tile start
+        // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] X[n][k]; j = this wave's 32 units, n = all 128 rows.
+        // One wave per SIMD: nothing hides an LDS round trip unless the code does, and hipcc left to itself emits
+        // read -> wait -> MFMA.  The B fragments are read TWO 16-k steps ahead into three rotating register sets, the
+        // order pinned by sched_barrier; a chunk's pieces are waited for (own pieces: counted vmcnt — pieces issued after it
+        // may stay in flight, younger stores only make the wait longer — then the barrier) two steps before its first read.
         f32x16 H[4];
+        {
+            Frag xs[3][4];
+            auto rd = [&](int q, Frag (&d)[4]) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+                for (int r = 0; r < 4; ++r) d[r].f = xrd[(q >> 2) * RS_CH_F4 + r * 256 + xsl[q & 3]];
+            };
+            S3_WAIT_VM(4 * (NCH - 1));
+            __builtin_amdgcn_s_barrier();
+            RS_STAMP();                                                     // 1
+            rd(0, xs[0]);
+            rd(1, xs[1]);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(a.q0_b + 32 * t + 8 * g + 4 * hi);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) H[t][4 * g + e] = b[e];
-            }
-        // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] X[n][k], 64 k per step
-        for (int s = 0; s < nk1; ++s) {
-            S3_WAIT_VM(0);
-            RS_STAMP(cur);                                                  // 1 + 2s: at B_s
-            __builtin_amdgcn_s_barrier();                                   // B_s
-            RS_STAMP(cur);                                                  // 2 + 2s: past B_s
-            if (s + 1 < nst) issue_w(s + 1);
-            const f32x4* w = sW + (s & 1) * RS_CH_F4 + lane;
-            const f32x4* x = sX + s * RS_CH_F4 + (wave * 32 + l31) * 8;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                union { f32x4 f; bf16x8 v; } xb, wa;
-                xb.f = x[(ks * 2 + hi) ^ fr];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    wa.f = w[(ks * 4 + t) * 64];
-                    H[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa.v, xb.v, H[t], 0, 0, 0);
+            for (int q = 0; q < NCH * 4; ++q) {
+                constexpr int dummy = 0; (void)dummy;
+                const int q2 = q + 2;
+                if (q2 < NCH * 4) {
+                    if ((q2 & 3) == 0) {
+                        s3_wait_vm_dyn(4 * (NCH - 1 - (q2 >> 2)));          // constant after unrolling
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    rd(q2, xs[q2 % 3]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (q == 0) rs_mfma0(H[r], w1[q], xs[q % 3][r].f);
+                    else rs_mfma(H[r], w1[q], xs[q % 3][r].f);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        RS_NOP();                                                           // last MFMA -> VALU reads of H
+        RS_STAMP();                                                         // 2: GEMM 1 done
         f32x16 Q[4];
         if constexpr (NL) {
+            // ---- bias, round to bf16, ReLU (on the packed pair: a negative bf16 is a negative int16), publish: block
+            //      ((wave, sidx), hi) of row n holds the 8 hidden units that accumulator registers 8 sidx .. 8 sidx + 7 of
+            //      this lane carry — a ready B fragment of GEMM 2
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int r = 0; r < 4; ++r) {
+                const int n = 32 * r + l31;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * t + 8 * g + 4 * hi);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        H[t][4 * g + e] = fmaxf(H[t][4 * g + e], 0.f);   // ReLU
-                        Q[t][4 * g + e] = b[e];
-                    }
-                }
-            // ---- GEMM 2 (transposed): step (tt, sidx) of chunk c2 contracts the 16 hidden units that accumulator
-            //      registers 8 sidx .. 8 sidx + 7 of H[2 c2 + tt] hold (the packed W2 carries the k permutation)
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                const int s = nk1 + c2;
-                S3_WAIT_VM(0);
-                __builtin_amdgcn_s_barrier();                               // B_s
-                RS_STAMP(cur);                                              // 17, 18: past B_8, B_9
-                if (c2 == 0) issue_w(s + 1);
-                const f32x4* w = sW + (s & 1) * RS_CH_F4 + lane;
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int t = 2 * c2 + tt;
-#pragma unroll
-                    for (int sidx = 0; sidx < 2; ++sidx) {
-                        union { unsigned u[4]; bf16x8 v; } hb;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            hb.u[e] = pack_bf16x2_hw(H[t][8 * sidx + 2 * e], H[t][8 * sidx + 2 * e + 1]);
-#pragma unroll
-                        for (int t2 = 0; t2 < 4; ++t2) {
-                            union { f32x4 f; bf16x8 v; } wa;
-                            wa.f = w[((tt * 2 + sidx) * 4 + t2) * 64];
-                            Q[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa.v, hb.v, Q[t2], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) Q[t] = H[t];
-        }
-        // the reads of the last weight chunk are complete once the MFMAs that consume them have issued; make it so
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        RS_STAMP(cur);                                                      // 19: at E0
-        __builtin_amdgcn_s_barrier();                                       // E0: weight ring free
-        RS_STAMP(cur);                                                      // 20
-        if (has_next) issue_w(0);                                           // W(0) is the same for every tile
-        // ---- tanh, scores (dsmil.py:55-56)
-        const float* qm0 = a.qmax + ((long long)cur.bag * C) * QD;
-        const float* qm1 = qm0 + (TWO ? QD : 0);
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 u0 = *reinterpret_cast<const f32x4*>(qm0 + 32 * t + 8 * g + 4 * hi);
-                f32x4 u1 = u0;
-                if constexpr (TWO) u1 = *reinterpret_cast<const f32x4*>(qm1 + 32 * t + 8 * g + 4 * hi);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float q = NL ? rs_tanh(Q[t][4 * g + e]) : Q[t][4 * g + e];
-                    s0 = fmaf(q, u0[e], s0);
-                    if constexpr (TWO) s1 = fmaf(q, u1[e], s1);
-                }
-            }
-        s0 = (s0 + __shfl_xor(s0, 32, 64)) * scale;
-        if constexpr (TWO) s1 = (s1 + __shfl_xor(s1, 32, 64)) * scale;
-        const long long myrow = cur.row0 + wave * 32 + l31;
-        const bool valid = myrow < cur.Nb;
-        if (valid && hi == 0 && !DSMIL_EXPT_ON(a, 64)) {
-            float* o = a.scores + (cur.off0 + myrow) * (long long)C;
-            o[0] = s0;
-            if constexpr (TWO) o[1] = s1;
-        }
-        const float mw0 = wave_max(valid ? s0 : -INFINITY);
-        const float mw1 = TWO ? wave_max(valid ? s1 : -INFINITY) : 0.f;
-        if (lane == 0) { sRed[wave * 2] = mw0; sRed[wave * 2 + 1] = mw1; }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        RS_STAMP(cur);                                                      // 21: at E1 (tanh + scores done)
-        __builtin_amdgcn_s_barrier();                                       // E1
-        const float mb0 = fmaxf(fmaxf(sRed[0], sRed[2]), fmaxf(sRed[4], sRed[6]));
-        const float mb1 = TWO ? fmaxf(fmaxf(sRed[1], sRed[3]), fmaxf(sRed[5], sRed[7])) : 0.f;
-        const float p0 = valid ? expf(s0 - mb0) : 0.f;                      // weights relative to the TILE max
-        const float p1 = (TWO && valid) ? expf(s1 - mb1) : 0.f;
-        if (hi == 0) *reinterpret_cast<float2*>(sP + (wave * 32 + l31) * 2) = make_float2(p0, p1);
-        const float lw0 = wave_sum(hi == 0 ? p0 : 0.f);
-        const float lw1 = TWO ? wave_sum(hi == 0 ? p1 : 0.f) : 0.f;
-        if (lane == 0) { sRed[8 + wave * 2] = lw0; sRed[9 + wave * 2] = lw1; }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                       // E2
-        RS_STAMP(cur);                                                      // 22: past E2
-        if (tid == 0) {
-            float* ml = a.part_ml + cur.slot * C * 2;
-            ml[0] = mb0; ml[1] = (sRed[8] + sRed[10]) + (sRed[12] + sRed[14]);
-            if constexpr (TWO) { ml[2] = mb1; ml[3] = (sRed[9] + sRed[11]) + (sRed[13] + sRed[15]); }
-        }
-        // ---- weighted value sum (dsmil.py:57), split by feature chunk: wave w owns chunks w and 4 + w, all 128 rows.
-        // lane (rr = lane >> 3, g = lane & 7) walks rows 8 i + rr and owns the 8 features of global 16-B slot g.
-        const int rr = lane >> 3, g8 = lane & 7;
-        float2 pw[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) pw[i] = *reinterpret_cast<const float2*>(sP + (8 * i + rr) * 2);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = 4 * j + wave;
-            if (c < nk1) {
-                float a0[8], a1[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
-                const f32x4* xc = sX + c * RS_CH_F4 + rr * 8;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int f = (rr & 6) | ((i & 3) >> 1);
-                    union { f32x4 f4; unsigned u[4]; } v;
-                    v.f4 = xc[i * 64 + (g8 ^ f)];
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const float lo = __uint_as_float(v.u[d] << 16), hi_ = __uint_as_float(v.u[d] & 0xffff0000u);
-                        a0[2 * d] = fmaf(pw[i].x, lo, a0[2 * d]);
-                        a0[2 * d + 1] = fmaf(pw[i].x, hi_, a0[2 * d + 1]);
-                        if constexpr (TWO) {
-                            a1[2 * d] = fmaf(pw[i].y, lo, a1[2 * d]);
-                            a1[2 * d + 1] = fmaf(pw[i].y, hi_, a1[2 * d + 1]);
-                        }
-                    }
-                }
-                // reduce over the 8 row groups (lane bits 3..5), halving the payload at every stage:
-                // bit 5 picks the class, bit 4 the upper / lower 4 features, bit 3 the upper / lower 2 of those
-                float b4[8];
-                {
-                    const bool up = lane & 32;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float send = up ? a0[e] : a1[e], keep = up ? a1[e] : a0[e];
-                        b4[e] = keep + __shfl_xor(send, 32, 64);
-                    }
-                }
-                float b2[4];
-                {
-                    const bool up = lane & 16;
+                for (int sidx = 0; sidx < 2; ++sidx) {
+                    union { unsigned u[4]; f32x4 f; } hb;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float send = up ? b4[e] : b4[4 + e], keep = up ? b4[4 + e] : b4[e];
-                        b2[e] = keep + __shfl_xor(send, 16, 64);
+                        const int i0 = 8 * sidx + 2 * e;
+                        const unsigned pk = pack_bf16x2_hw(H[r][i0] + b1[i0 >> 2][i0 & 3], H[r][i0 + 1] + b1[(i0 + 1) >> 2][(i0 + 1) & 3]);
+                        typedef short s2 __attribute__((ext_vector_type(2)));
+                        const s2 z = {0, 0};
+                        hb.u[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, pk), z));
                     }
-                }
-                float b1[2];
-                {
-                    const bool up = lane & 8;
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const float send = up ? b2[e] : b2[2 + e], keep = up ? b2[2 + e] : b2[e];
-                        b1[e] = keep + __shfl_xor(send, 8, 64);
-                    }
-                }
-                const int cls = (lane >> 5) & 1;
-                if (TWO || cls == 0) {
-                    const int k = c * 64 + g8 * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2;
-                    *reinterpret_cast<float2*>(a.part_B + (cur.slot * C + cls) * (long long)a.Kv + k) = make_float2(b1[0], b1[1]);
+                    sH[n * 16 + ((((wave * 2 + sidx) * 2) + hi) ^ (n & 15))] = hb.f;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            RS_STAMP(cur);                                                  // 23, 25: value-sum step done
-            __builtin_amdgcn_s_barrier();                                   // E3 / E4: this step's chunks are released
-            RS_STAMP(cur);                                                  // 24, 26
+            __builtin_amdgcn_s_barrier();                                   // Bh
+            RS_STAMP();                                                     // 3
+            // ---- GEMM 2 (transposed): Q^T[j2][n] += W2[j2][k] H^T[k][n]; j2 = this wave's 32 units
+            {
+                Frag hs[3][4];
+                auto rdh = [&](int q, Frag (&d)[4]) {   // k-step q = 2 t + sidx: block (q, hi) of every row
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = 32 * r + l31;
+                        d[r].f = sH[n * 16 + (((q * 2) + hi) ^ (n & 15))];
+                    }
+                };
+                rdh(0, hs[0]);
+                rdh(1, hs[1]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (q + 2 < 8) rdh(q + 2, hs[(q + 2) % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // packed chunk c2 = q >> 2, fragment index q & 3 = 2 (t & 1) + sidx  (k_pack_agg_bf16)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (q == 0) rs_mfma0(Q[r], w2[q], hs[q % 3][r].f);
+                        else rs_mfma(Q[r], w2[q], hs[q % 3][r].f);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                RS_NOP();
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) Q[r][i] = H[r][i] + b1[i >> 2][i & 3];
         }
+        __builtin_amdgcn_s_barrier();                                       // E0: sH is free
+        RS_STAMP();                                                         // 4
+        // ---- tanh; partial scores over this wave's 32 query units (dsmil.py:55-56).  Written stage by stage over 16 values
+        //      so that the exp / rcp chains of different values overlap.
+        {
+            const float* qm0 = a.qmax + ((long long)cur.bag * C) * QD + 32 * wave + 4 * hi;
+            f32x4 u0[4], u1[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u0[g] = *reinterpret_cast<const f32x4*>(qm0 + 8 * g);
+                u1[g] = TWO ? *reinterpret_cast<const f32x4*>(qm0 + QD + 8 * g) : u0[g];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float q[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) q[i] = Q[r][i];
+                if constexpr (NL) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) q[i] = __builtin_amdgcn_exp2f(fmaf(q[i], TANH_C, b2c[i >> 2][i & 3]));
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) q[i] = __builtin_amdgcn_rcpf(1.f + q[i]);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) q[i] = fmaf(q[i], -2.f, 1.f);
+                }
+                float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sa[e] = fmaf(q[4 * g + e], u0[g][e], sa[e]);
+                        if constexpr (TWO) sb[e] = fmaf(q[4 * g + e], u1[g][e], sb[e]);
+                    }
+                float s0 = (sa[0] + sa[1]) + (sa[2] + sa[3]), s1 = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+                s0 += __shfl_xor(s0, 32, 64);
+                if constexpr (TWO) s1 += __shfl_xor(s1, 32, 64);
+                if (hi == 0) {
+                    sS[(wave * 2 + 0) * RS_BM + 32 * r + l31] = s0;
+                    if constexpr (TWO) sS[(wave * 2 + 1) * RS_BM + 32 * r + l31] = s1;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                       // E1
+        RS_STAMP();                                                         // 5
+        // ---- scores, tile softmax statistics: thread (cls = tid >> 7, row = tid & 127).  The attention weight is cut into
+        //      three bf16 planes here, once per (row, class), for the value sum's A fragments.
+        {
+            const int cls = tid >> 7, row = tid & 127;
+            const bool act = TWO || cls == 0;
+            const float s = ((sS[(0 * 2 + cls) * RS_BM + row] + sS[(1 * 2 + cls) * RS_BM + row]) +
+                             (sS[(2 * 2 + cls) * RS_BM + row] + sS[(3 * 2 + cls) * RS_BM + row])) * scale;
+            const bool valid = act && cur.row0 + row < cur.Nb;
+            if (valid && !DSMIL_EXPT_ON(a, 64)) a.scores[(cur.off0 + cur.row0 + row) * (long long)C + cls] = s;
+            const float mw = wave_max(valid ? s : -INFINITY);
+            if (lane == 0) sRed[wave] = mw;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                   // E2
+            const float m = fmaxf(sRed[2 * cls], sRed[2 * cls + 1]);        // waves 2 cls, 2 cls + 1 hold class cls
+            const float p = valid ? expf(s - m) : 0.f;                      // weight relative to the TILE max
+            const unsigned h0 = __float_as_uint(p) & 0xFFFF0000u;
+            const float r1 = p - __uint_as_float(h0);
+            const unsigned h1 = __float_as_uint(r1) & 0xFFFF0000u;
+            const unsigned h2 = __float_as_uint(r1 - __uint_as_float(h1));
+            sPl[(0 * 2 + cls) * RS_BM + row] = (unsigned short)(h0 >> 16);
+            sPl[(1 * 2 + cls) * RS_BM + row] = (unsigned short)(h1 >> 16);
+            sPl[(2 * 2 + cls) * RS_BM + row] = (unsigned short)(h2 >> 16);
+            const float lw = wave_sum(p);
+            if (lane == 0) sRed[4 + wave] = lw;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                   // E3
+            if (lane == 0 && (wave & 1) == 0 && act) {
+                float* ml = a.part_ml + (cur.slot * C + cls) * 2;
+                ml[0] = m;
+                ml[1] = sRed[4 + wave] + sRed[5 + wave];
+            }
+        }
+        RS_STAMP();                                                         // 6
+        // ---- value sum on the matrix pipe (dsmil.py:57).  16x16x32: A[i][kk] = plane_{i>>1}(p[row(kk)][class i&1]) for
+        //      i < 6 (three exact bf16 planes of the fp32 weight in different rows), B[kk][j] = x[row(kk)][f0 + j] by
+        //      transposed LDS reads; kk = 8 g + e  <->  row n0 + 16 (e>>2) + 4 g + (e&3)  (a 32-lane half of a transposed read
+        //      then touches 8 consecutive rows: conflict-free).  D rows 0..5 = (hi c0, hi c1, mid c0, mid c1, lo c0, lo c1).
+        {
+            const int ai = lane & 15, ag = lane >> 4;
+            Frag pa[4];
+            {
+                const unsigned short* pl = sPl + (ai < 6 ? ai : 0) * RS_BM + 4 * ag;   // plane ai >> 1, class ai & 1
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(pl + 32 * rg);
+                    const u32x2 up = *reinterpret_cast<const u32x2*>(pl + 32 * rg + 16);
+                    union { unsigned u[4]; f32x4 f; } pk;
+                    pk.u[0] = ai < 6 ? lo.x : 0u; pk.u[1] = ai < 6 ? lo.y : 0u;
+                    pk.u[2] = ai < 6 ? up.x : 0u; pk.u[3] = ai < 6 ? up.y : 0u;
+                    pa[rg].f = pk.f;
+                }
+            }
+            // transposed-read address of this lane inside a (row group, 16-feature block): source lane s = lane & 15 of
+            // 16-lane group g reads 8 B of row 4 g + (s >> 2) (+16 for the second read) at features 4 (s & 3)
+            const int ts = lane & 15;
+            const int trow = 4 * ag + (ts >> 2);                            // 0..15; the second read adds 16
+            const int tq = ts & 3;
+            // byte offsets inside a chunk of the lane's two reads for block b = 0 (rows trow / trow + 16 of row group 0); a
+            // row group adds 4096, block b flips slot bits: slot (2 b + (tq >> 1)) ^ f
+            const int f0 = (trow & 6), f1 = f0 | 1;
+            int toff0[4], toff1[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int sl = 2 * b + (tq >> 1);
+                toff0[b] = trow * 128 + ((sl ^ f0) * 16) + (tq & 1) * 8;
+                toff1[b] = (trow + 16) * 128 + ((sl ^ f1) * 16) + (tq & 1) * 8;
+            }
+            float2 outv[2][4];                                              // [step][block]: (class 0, class 1) of feature f0 + (lane & 15)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = 4 * j + wave;
+                f32x4 acc[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (c < NCH) {
+                    const char* xc = reinterpret_cast<const char*>(sX + c * RS_CH_F4);
+                    rs_v4s t0[3], t1[3];
+                    auto rdt = [&](int u, rs_v4s& d0, rs_v4s& d1) {       // block u = 4 rg + b
+                        d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rs_v4s*)(xc + (u >> 2) * 4096 + toff0[u & 3]));
+                        d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rs_v4s*)(xc + (u >> 2) * 4096 + toff1[u & 3]));
+                    };
+                    rdt(0, t0[0], t1[0]);
+                    rdt(1, t0[1], t1[1]);
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        if (u + 2 < 16) rdt(u + 2, t0[(u + 2) % 3], t1[(u + 2) % 3]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        bf16x8 xb;
+                        xb[0] = t0[u % 3][0]; xb[1] = t0[u % 3][1]; xb[2] = t0[u % 3][2]; xb[3] = t0[u % 3][3];
+                        xb[4] = t1[u % 3][0]; xb[5] = t1[u % 3][1]; xb[6] = t1[u % 3][2]; xb[7] = t1[u % 3][3];
+                        acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[u >> 2].v, xb, acc[u & 3], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                // D row i sits in lane group i >> 2, register i & 3: classes (0, 1) = regs (0, 1) + regs (2, 3) of lanes 0..15
+                // + regs (0, 1) of lanes 16..31
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float l0 = __shfl(acc[b][0], (lane & 15) + 16, 64), l1 = __shfl(acc[b][1], (lane & 15) + 16, 64);
+                    outv[j][b] = make_float2((acc[b][0] + acc[b][2]) + l0, (acc[b][1] + acc[b][3]) + l1);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                RS_STAMP();                                                 // 7, 9
+                __builtin_amdgcn_s_barrier();                               // T0 / T1: this step's chunks are released
+                RS_STAMP();                                                 // 8, 10
+                if (has_next) {
+                    if (j == 0) set_rows(nxt);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+                        if (4 * j + cc < NCH) issue_chunk(4 * j + cc);
+                }
+            }
+            // the stores go out behind the next tile's pieces (nothing younger than a piece that a counted wait names)
+            if (lane < 16) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = 4 * j + wave;
+                    if (c < NCH) {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int k = c * 64 + b * 16 + lane;
+                            a.part_B[(cur.slot * C + 0) * (long long)a.Kv + k] = outv[j][b].x;
+                            if constexpr (TWO) a.part_B[(cur.slot * C + 1) * (long long)a.Kv + k] = outv[j][b].y;
+                        }
+                    }
+                }
+            }
+        }
+        RS_STAMP_FLUSH(cur);
         if (!has_next) break;
         cur = nxt;
         item = in;

@@ -227,9 +227,11 @@ __device__ __forceinline__ void s3_wait_vm_dyn(int n) {  // n is wave-uniform
         case 4: S3_WAIT_VM(4); break;
         case 6: S3_WAIT_VM(6); break;
         case 7: S3_WAIT_VM(7); break;
+        case 8: S3_WAIT_VM(8); break;
         case 10: S3_WAIT_VM(10); break;
         case 12: S3_WAIT_VM(12); break;
         case 16: S3_WAIT_VM(16); break;
+        case 20: S3_WAIT_VM(20); break;
         case 24: S3_WAIT_VM(24); break;
         case 28: S3_WAIT_VM(28); break;
         case 32: S3_WAIT_VM(32); break;

@@ -106,14 +106,17 @@ def _oracle_bags(bags, p, nonlinear=True):
     (512, 2, True, [1, 2, 127, 128, 129, 255, 256, 257, 1000, 31, 4097] * 6 + [70000]),   # ragged, one long bag
     (512, 1, True, [10000] * 8),                                                          # configs[2]'s shape, C = 1
     (256, 2, True, [3000 + 37 * i for i in range(30)]),                                   # 4 feature chunks
-    (64, 2, False, [2500 + 11 * i for i in range(40)]),                                   # 1 chunk, linear query
-    (448, 1, False, [9000] * 9),                                                          # 7 chunks (odd), linear query
+    (256, 1, False, [2500 + 11 * i for i in range(40)]),                                  # linear query
+    (512, 2, False, [9000] * 9),                                                          # linear query, two classes
+    (64, 2, False, [2500 + 11 * i for i in range(40)]),                                   # ring kernel: 1 chunk, linear query
+    (448, 1, False, [9000] * 9),                                                          # ring kernel: 7 chunks
 ])
 def test_bf16_resident_tile_kernel(K, C, nonlinear, lengths):
-    """k_attend_bf16_res (agg_res.h): the persistent kernel with the 128-row tile resident in LDS — taken for
-    >= 512 tiles of 128 rows when K % 64 == 0, K <= 512, C <= 2.  Ragged bags (tiles past a bag's end are skipped by every
-    wave alike, partial last tiles, 1-row bags), 1 / 4 / 7 / 8 feature chunks, linear query; oracle and tolerances as
-    above; five runs bit-identical (hand-counted DMA completion, wave-specialised barrier protocol)."""
+    """k_attend_bf16_res (agg_res.h): the persistent kernel with the 128-row tile resident in LDS and the query weights
+    resident in registers — taken for >= 512 tiles of 128 rows when K is 512 or 256 and C <= 2 (K = 64 / 448 keep the ring
+    kernel).  Ragged bags (tiles past a bag's end are skipped by every wave alike, partial last tiles, 1-row bags), linear
+    query; oracle and tolerances as above; five runs bit-identical (hand-counted DMA completion, value sum on the matrix
+    pipe through transposed LDS reads)."""
     import dsmil_wsi_amd.ops as ops
     rng = np.random.default_rng(K + C)
     p = {"fc_w": rng.standard_normal((C, K), dtype=np.float32) * 0.05, "fc_b": rng.standard_normal(C, dtype=np.float32) * 0.1,

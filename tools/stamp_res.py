@@ -20,18 +20,11 @@ for _ in range(3):
 torch.cuda.synchronize()
 a = A.view(torch.int64).cpu().numpy().reshape(nb, N)       # C = 2: one int64 per row
 ntile = N // 128
-T = np.array([a[b, t * 128:t * 128 + 64] for b in range(nb) for t in range(ntile)])   # [tiles, 64]: 0..31 compute, 32..63 loader
-comp, load = T[:, :27], T[:, 32:32 + 22]
-names_c = ["start"] + [f"{'at' if i % 2 == 0 else 'past'} B{i // 2}" for i in range(16)] + ["past B8", "past B9", "at E0", "past E0", "at E1", "past E2", "vs0 done", "past E3", "vs1 done", "past E4"]
-dc = np.diff(comp, axis=1)
-ok = (np.abs(dc) < 1e6).all(axis=1)
-print("tiles", len(T), "sane", int(ok.sum()))
-print("compute wave 0: median cycles per phase (tile total median %d)" % np.median((comp[ok, -1] - comp[ok, 0])))
-for i in range(dc.shape[1]):
-    print(f"  {names_c[i]:>10s} -> {names_c[i + 1]:<10s} median {int(np.median(dc[ok, i])):6d}  p10 {int(np.percentile(dc[ok, i], 10)):6d}  p90 {int(np.percentile(dc[ok, i], 90)):6d}")
-dl = np.diff(load, axis=1)
-okl = (np.abs(dl) < 1e6).all(axis=1)
-names_l = ["start"] + [f"{'landed' if i % 2 == 0 else 'past B'}{i // 2}" for i in range(16)] + ["past E0", "past E2", "past E3", "issued 0,1", "past E4"]
-print("feature-stream wave: median cycles per phase")
-for i in range(dl.shape[1]):
-    print(f"  {names_l[i]:>10s} -> {names_l[i + 1]:<10s} median {int(np.median(dl[okl, i])):6d}  p10 {int(np.percentile(dl[okl, i], 10)):6d}  p90 {int(np.percentile(dl[okl, i], 90)):6d}")
+T = np.array([a[b, t * 128:t * 128 + 11] for b in range(nb) for t in range(ntile)])   # [tiles, 11] stamps of wave 0
+names = ["start", "chunk0 landed", "GEMM1 done", "Bh (H written)", "E0 (GEMM2 done)", "E1 (tanh+partial scores)", "E3 (softmax stats)",
+         "vs0 done", "past T0", "vs1 done", "past T1"]
+d = np.diff(T, axis=1)
+ok = (np.abs(d) < 1e6).all(axis=1)
+print("tiles", len(T), "sane", int(ok.sum()), "tile total median", int(np.median(T[ok, -1] - T[ok, 0])))
+for i in range(d.shape[1]):
+    print(f"  {names[i]:>26s} -> {names[i + 1]:<26s} median {int(np.median(d[ok, i])):6d}  p10 {int(np.percentile(d[ok, i], 10)):6d}  p90 {int(np.percentile(d[ok, i], 90)):6d}")
