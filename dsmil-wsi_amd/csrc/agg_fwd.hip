@@ -825,14 +825,21 @@ __global__ __launch_bounds__(256) void k_finish(
     const int64_t* __restrict__ offsets, const float* __restrict__ part_ml,
     const float* __restrict__ part_B, const float* __restrict__ fcc_w,
     float* __restrict__ A, float* __restrict__ B, float* __restrict__ pred_part, int Kv, int C, int BM,
-    float* __restrict__ ml_out = nullptr) {
+    float* __restrict__ ml_out = nullptr, int seg_per = 0, int seg_T = 0) {
+    // seg_per > 0 (k_attend_bf16_res): the partials are per (workgroup, bag) — workgroup g owns the BM-row tile items
+    // [g seg_per, (g + 1) seg_per) of the (bag, tile) list with seg_T items per bag, and wrote slot g + bag
     // ml_out != null (instance-sharded bag): leave A and B relative to this shard's max, un-normalised
     // (A = exp(s - m), B = sum exp(s - m) V) and hand (m, l) per class to the caller's cross-shard merge
     const int bag = blockIdx.y, nblk = gridDim.x;
     const long long off0 = offsets[bag];
     const long long Nb = offsets[bag + 1] - off0;
-    const long long slot0 = off0 / BM + bag;
-    const long long ntile = (Nb + BM - 1) / BM;
+    long long slot0 = off0 / BM + bag;
+    long long ntile = (Nb + BM - 1) / BM;
+    if (seg_per > 0) {
+        const long long it0 = (long long)bag * seg_T, g_lo = it0 / seg_per, g_hi = (it0 + ntile - 1) / seg_per;
+        slot0 = g_lo + bag;
+        ntile = g_hi - g_lo + 1;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ float s_red[8];
     __shared__ __attribute__((aligned(16))) float s_acc[16][64];
@@ -970,6 +977,7 @@ WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int K, 
     WsLayout w;
     w.slots0 = total_rows / R0 + n_bags + 1;
     w.slots = total_rows / BM + n_bags + 1;
+    if (w.slots < RS_MAX_WG + n_bags) w.slots = RS_MAX_WG + n_bags;   // k_attend_bf16_res: one slot per (workgroup, bag) pair, slot = workgroup + bag
     w.nchunk_max = finish_blocks(max_rows, Kv);
     size_t o = 0;
     w.part_val = o; o = al(o + (size_t)w.slots0 * C * sizeof(float));
@@ -1067,15 +1075,16 @@ bool bf16_res_ok(const AttendArgs& a) {
     return (a.K == 512 || a.K == 256) && a.Kv == a.K && a.vals == a.feats && a.C <= 2;
 }
 template <int NCH>
-void (*bf16_res_fn(const AttendArgs& a))(AttendArgs, int, int) {
+void (*bf16_res_fn(const AttendArgs& a))(AttendArgs, int, int, int) {
     return a.C == 2 ? (a.nonlinear ? k_attend_bf16_res<NCH, true, true> : k_attend_bf16_res<NCH, true, false>)
                     : (a.nonlinear ? k_attend_bf16_res<NCH, false, true> : k_attend_bf16_res<NCH, false, false>);
 }
-int launch_attend_bf16_res(AttendArgs a, long long max_rows, int n_bags, hipStream_t st) {
+int launch_attend_bf16_res(AttendArgs a, long long max_rows, int n_bags, hipStream_t st, int* seg_per, int* seg_T) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         return DSMIL_E_LAUNCH;
-    typedef void (*res_fn)(AttendArgs, int, int);
+    if (cus > RS_MAX_WG) cus = RS_MAX_WG;
+    typedef void (*res_fn)(AttendArgs, int, int, int);
     const res_fn fn = a.K == 512 ? bf16_res_fn<8>(a) : bf16_res_fn<4>(a);
     if (!dsmil_lds::allow((const void*)fn, RS_LDS_BYTES)) return DSMIL_E_LAUNCH;
     const int K64 = (a.K + 63) / 64 * 64;
@@ -1083,9 +1092,13 @@ int launch_attend_bf16_res(AttendArgs a, long long max_rows, int n_bags, hipStre
     const long long tiles_per_bag = (max_rows + RS_BM - 1) / RS_BM;
     const long long n_items = tiles_per_bag * n_bags;
     if (n_items > 0x7fffffffLL) return DSMIL_E_UNSUPPORTED;
-    const unsigned grid = (unsigned)(n_items < cus ? n_items : cus);
+    // contiguous runs of tile items per workgroup: consecutive tiles belong to the same bag and share one partial
+    const long long per = (n_items + cus - 1) / cus;
+    const unsigned grid = (unsigned)((n_items + per - 1) / per);
+    *seg_per = (int)per;
+    *seg_T = (int)tiles_per_bag;
     const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(RS_THREADS), RS_LDS_BYTES, st, a, (int)tiles_per_bag, (int)n_items);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(RS_THREADS), RS_LDS_BYTES, st, a, (int)tiles_per_bag, (int)n_items, (int)per);
     dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
@@ -1222,6 +1235,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
 #else
     constexpr int logits_old = 0;
 #endif
+    int seg_per = 0, seg_T = 0;   // k_attend_bf16_res: partials per (workgroup, bag), see k_finish
     {
         // Tried and rejected here (round 1, numbers in DESIGN.md §3): (a) chunking the batch and running
         // chunk c+1's HBM-bound logits on a helper stream under chunk c's MFMA-bound attend, and (b) one
@@ -1266,6 +1280,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         // 3. query MLP on MFMA + scores + tile softmax + weighted value sum
         int rc;
+        seg_per = seg_T = 0;
         const int mode = (NW == 8) ? 0 : mlp_mode();
         if (!bf16 && mode && packed_split) {
             a.wpk = (const bf16_t*)packed_split;  // the caller cut the weights once (dsmil_agg_pack_split)
@@ -1284,7 +1299,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
 #ifdef DSMIL_EXPERIMENTS
         if (a.expt & 512) bf16_res = false;
 #endif
-        if (bf16_res) rc = launch_attend_bf16_res(a, max_rows, nb, st);
+        if (bf16_res) rc = launch_attend_bf16_res(a, max_rows, nb, st, &seg_per, &seg_T);
         else if (bf16_dma) rc = launch_attend_bf16_dma(a, max_rows, nb, st);
         else if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, nb, st) : launch_attend_bf16<1>(a, max_rows, nb, st);
         else if (mode == 9 && NW == 4) rc = v4 ? launch_attend_split<4, 4, 9>(a, max_rows, nb, st) : launch_attend_split<4, 1, 9>(a, max_rows, nb, st);
@@ -1306,9 +1321,9 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     if (!DSMIL_EXPT_ON(a, 64)) {
         dim3 grid((unsigned)L.nchunk_max, (unsigned)n_bags);
         if (Kv % 4 == 0)
-            hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM, sh.ml_out);
+            hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, seg_per ? RS_BM : BM, sh.ml_out, seg_per, seg_T);
         else
-            hipLaunchKernelGGL(k_finish<1>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM, sh.ml_out);
+            hipLaunchKernelGGL(k_finish<1>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM, sh.ml_out, 0, 0);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         if (sh.phase == 2) return DSMIL_OK;  // the bag head runs after the cross-shard merge
         const int n = n_bags * C;

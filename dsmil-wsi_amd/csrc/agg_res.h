@@ -1,45 +1,53 @@
-// agg_res.h — k_attend_bf16_res: the bf16-storage query / attend kernel with its 128-row tile RESIDENT in LDS and
-// the query weights RESIDENT in registers (dsmil.py:46-62 behind the instance logits, BASELINE configs[2]).
+// agg_res.h — k_attend_bf16_res: the bf16-storage query / attend kernel (dsmil.py:46-62 behind the instance logits,
+// BASELINE configs[2]) with the feature tile RESIDENT in LDS, the query weights RESIDENT in registers and the bag's
+// partial sums RESIDENT in accumulators.
 //
-// What it replaces: k_query_attend_bf16_dma streamed each 64-k chunk of the tile through a 3-slot LDS ring next to
+// What it replaces: k_query_attend_bf16_dma streamed each 64-k chunk of a 128-row tile through a 3-slot LDS ring next to
 // a ring of weight chunks (as many L2 -> LDS bytes for weights as HBM -> LDS bytes for features, both in one in-order
-// vmcnt queue), then read the whole tile a SECOND time from L2 / HBM for the value sum B = sum_n p[n] x[n,:]
-// (dsmil.py:57) on the VALU.  In-kernel stamps of a first tile-resident form (weights still ringed, one extra wave
-// issuing the features) showed where a tile's 30 k cycles went: every 64-k step waited ~1300 cycles for its 16 KiB
-// of weights to come through L2 -> LDS behind 512 cycles of MFMA, and the VALU value sum took 5 k cycles.  Hence:
-//   * one PERSISTENT 256-thread workgroup per CU (one wave per SIMD, up to 512 VGPRs each) walks (bag, tile) items;
-//   * wave w keeps ITS slice of the weights in VGPRs for the whole launch: W1 rows [32w, 32w+32) x K (<= 128 VGPRs)
-//     and W2 rows [32w, 32w+32) x 128 (32 VGPRs) as ready MFMA A-fragments.  GEMM 1 gives wave w the hidden units
-//     [32w, 32w+32) of ALL 128 rows (B operand = any row of the tile, read from LDS); the ReLU'd bf16 hidden layer is
-//     exchanged through 32 KiB of LDS (one write + one barrier) and GEMM 2 gives wave w the query units [32w, 32w+32)
-//     of all rows.  No weight byte moves after the prologue;
-//   * the tile (128 rows x K <= 512 bf16 = up to 128 KiB) stays in LDS from GEMM 1 until the value sum has consumed
-//     it: ONE read of every feature byte.  Each wave issues the LDS-DMA pieces of its own 32 rows; the only VMEM
-//     traffic between them is a handful of loads / stores that are older or younger than every piece that matters;
+// vmcnt queue), read the whole tile a SECOND time from L2 / HBM for the value sum B = sum_n p[n] x[n,:] (dsmil.py:57) on
+// the VALU, and wrote one (m, l, B) partial per tile (20 MB per 64 bags, read back by k_finish).  Here:
+//   * one PERSISTENT 256-thread workgroup per CU (one wave per SIMD: 256 VGPRs + 256 AGPRs each) owns a CONTIGUOUS run of
+//     64-row tiles (so that consecutive tiles belong to the same bag);
+//   * wave w keeps ITS slice of the weights in AGPRs for the whole launch: W1 rows [32w, 32w+32) x K (<= 128 registers)
+//     and W2 rows [32w, 32w+32) x 128 (32 registers) as ready MFMA A-fragments (hipcc never places an MFMA A operand in the
+//     accumulator file, and 160 resident VGPRs left it ~90 for everything else: it serialised every read -> use chain.
+//     The MFMAs are therefore inline asm with "a" weights and "v" accumulators).  GEMM 1 gives wave w the hidden units
+//     [32w, 32w+32) of all 64 rows (B operand = any row of the tile, read from LDS); the ReLU'd bf16 hidden layer is
+//     exchanged through 16 KiB of LDS and GEMM 2 gives wave w the query units [32w, 32w+32) of all rows.  No weight byte
+//     moves after the prologue;
+//   * the tile (64 rows x K <= 512 bf16 = up to 64 KiB) stays in LDS from GEMM 1 until the value sum has consumed it: ONE
+//     read of every feature byte — and there are TWO tile buffers: the pieces of tile t+1 are issued one at a time
+//     between the MFMA groups of tile t's GEMM 1 (a burst of LDS-DMA instructions blocks the issuing wave for as long as
+//     the CU's address path needs to take them: ~48 cycles per 1 KiB piece, 6 k cycles per 128 KiB) and have a whole
+//     tile's time to land;
 //   * the value sum runs on the matrix pipe: out[c][k] = sum_n p[n][c] x[n][k] with the row-major tile as the B operand
 //     through ds_read_b64_tr_b16 (two transposed reads per 32 rows x 16 features) and the attention weights as the A
 //     operand, cut into three bf16 planes (exact fp32 p) that sit in DIFFERENT ROWS of the same 16-row A fragment —
-//     one v_mfma_f32_16x16x32_bf16 per 32 x 16 block does all three plane products; the planes are added at the end.
-//     Wave w owns the features of chunks w and 4 + w for all 128 rows, so B needs no cross-wave reduction and the
-//     LDS slots are released four chunks at a time for the next tile's stream.
-// LDS map: sX [8 chunks][128 rows][128 B] (16-B slot c of row r holds global slot c ^ f(r), f(r) = (r&6)|((r>>4)&1)
+//     one v_mfma_f32_16x16x32_bf16 per 32 x 16 block does all three plane products.  Wave w owns the features of chunks
+//     w and 4 + w for all rows, so B needs no cross-wave reduction;
+//   * those accumulators run ACROSS the tiles of a bag (online softmax: weights relative to the running max of the
+//     workgroup's part of the bag, accumulators rescaled when it moves) and are written once per (workgroup, bag):
+//     partial slot = blockIdx.x + bag (a workgroup's bags and a bag's workgroups are both contiguous runs, so the
+//     staircase is collision-free).  k_finish merges <= ~3 partials per bag instead of 79.
+// LDS map: sX [2 buffers][8 chunks][64 rows][128 B] (16-B slot c of row r holds global slot c ^ f(r), f(r) = (r&6)|((r>>4)&1)
 // on the row's index inside its 32-row group: conflict-free ds_read_b128 of the MFMA fragments and conflict-free
-// transposed reads), then 32 KiB sH: the hidden layer [128 rows][16 blocks x 16 B] (block b of row n at b ^ (n & 15));
-// after GEMM 2 the same 32 KiB hold the softmax scratch (partial scores, tile max / sum, p[class][row]).
-// Barriers per tile (all four waves): one per feature chunk (its pieces have landed for everybody), Bh (hidden layer
-// written), E0 (GEMM 2 done, sH free), E1 (partial scores), E2 (tile max), E3 (p and sums), T0 (value-sum step 0 done:
-// chunks 0..3 released), T1 (chunks 4..7 released).
+// transposed reads), then 16 KiB sH: the hidden layer [64 rows][16 blocks x 16 B] (block b of row n at b ^ (n & 15));
+// after GEMM 2 the same bytes hold the softmax scratch (partial scores, bf16 planes of p, rescale factors).
+// Barriers per tile (all four waves): S (tile landed for everybody), Bh (hidden layer written), E0 (GEMM 2 done, sH free),
+// E1 (partial scores), E3 (planes + rescale factors), T (value sum done: buffer and scratch released).
 #pragma once
 #include "agg_common.h"
 #include "agg_split.h"
 
 namespace {
 
-constexpr int RS_BM = 128;                  // rows per tile
-constexpr int RS_CH_F4 = 1024;              // float4 (16 B) per 16 KiB feature chunk (128 rows x 128 B)
+constexpr int RS_BM = 64;                   // rows per tile
+constexpr int RS_CH_F4 = 512;               // float4 (16 B) per 8 KiB feature chunk (64 rows x 128 B)
 constexpr int RS_MAXCH = 8;                 // K <= 512 (the kernel is instantiated for K = 512 and K = 256)
+constexpr int RS_BUF_F4 = RS_MAXCH * RS_CH_F4;   // float4 per tile buffer (64 KiB)
 constexpr int RS_THREADS = 256;             // one wave per SIMD
-constexpr int RS_LDS_BYTES = (RS_MAXCH + 2) * RS_CH_F4 * 16;   // 163 840 = all of a CU's LDS
+constexpr int RS_MAX_WG = 1024;             // upper bound of the persistent grid (the workspace holds RS_MAX_WG + n_bags partial slots)
+constexpr int RS_LDS_BYTES = (2 * RS_BUF_F4 + RS_BM * 16) * 16;   // 2 x 64 KiB + 16 KiB = 147 456
 
 typedef short rs_v4s __attribute__((ext_vector_type(4)));
 
@@ -69,36 +77,36 @@ __device__ __forceinline__ void rs_mfma0(f32x16& acc, const f32x4& a_agpr, const
 
 struct RsWork {
     int bag;
-    long long off0, Nb, row0, slot;
+    long long off0, Nb, row0;
 };
 
-// first work item >= item (stepping by the grid) whose tile lies inside its bag; false when the list is exhausted.
-// Evaluated identically by every wave of the workgroup.
-__device__ __forceinline__ bool rs_fetch(const AttendArgs& a, int tiles_per_bag, int n_items, int& item, RsWork& w) {
-    while (item < n_items) {
+// first work item in [item, end) whose tile lies inside its bag; false when the run is exhausted.  Evaluated identically
+// by every wave of the workgroup.
+__device__ __forceinline__ bool rs_fetch(const AttendArgs& a, int tiles_per_bag, int end, int& item, RsWork& w) {
+    while (item < end) {
         const int b = item / tiles_per_bag, tile = item - b * tiles_per_bag;
         const int bag = a.bag0 + b;
         const long long off0 = a.offsets[bag];
         const long long Nb = a.offsets[bag + 1] - off0;
         const long long row0 = (long long)tile * RS_BM;
         if (row0 < Nb) {
-            w.bag = bag; w.off0 = off0; w.Nb = Nb; w.row0 = row0; w.slot = off0 / RS_BM + bag + tile;
+            w.bag = bag; w.off0 = off0; w.Nb = Nb; w.row0 = row0;
             return true;
         }
-        item += (int)gridDim.x;
+        ++item;
     }
     return false;
 }
 
 template <int NCH, bool TWO, bool NL>   // NCH: K / 64; TWO: C == 2 (else C == 1); NL: the two-layer query of dsmil.py:31-32
-__global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a, int tiles_per_bag, int n_items) {
+__global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a, int tiles_per_bag, int n_items, int per_wg) {
     static_assert(NCH >= 1 && NCH <= RS_MAXCH, "feature chunks");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x4* sX = reinterpret_cast<f32x4*>(smem);              // [8][RS_CH_F4]
-    f32x4* sH = sX + RS_MAXCH * RS_CH_F4;                    // [128 rows][16 blocks]: hidden layer, bf16
-    float* sS = reinterpret_cast<float*>(sH);                // scratch after GEMM 2: [4 waves][2 classes][128 rows] partial scores
-    unsigned short* sPl = reinterpret_cast<unsigned short*>(sS + 4 * 2 * RS_BM);   // [3 planes][2 classes][128 rows] bf16 planes of p
-    float* sRed = reinterpret_cast<float*>(sPl + 3 * 2 * RS_BM);                   // [0..3] wave maxima, [4..7] wave sums
+    f32x4* sX = reinterpret_cast<f32x4*>(smem);              // [2][8][RS_CH_F4]
+    f32x4* sH = sX + 2 * RS_BUF_F4;                          // [64 rows][16 blocks]: hidden layer, bf16
+    float* sS = reinterpret_cast<float*>(sH);                // scratch after GEMM 2: [4 waves][2 classes][64 rows] partial scores
+    unsigned short* sPl = reinterpret_cast<unsigned short*>(sS + 4 * 2 * RS_BM);   // [3 planes][2 classes][64 rows] bf16 planes of p
+    float* sF = reinterpret_cast<float*>(sPl + 3 * 2 * RS_BM);                     // [2] rescale factor of the running sums per class
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -106,45 +114,43 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
     const bf16_t* feats = reinterpret_cast<const bf16_t*>(a.feats);
     const f32x4* wpk = reinterpret_cast<const f32x4*>(a.wpk);   // chunk-major fragment image (k_pack_agg_bf16)
 
-    int item = (int)blockIdx.x;
+    int item = (int)blockIdx.x * per_wg;
+    const int item_end = item + per_wg < n_items ? item + per_wg : n_items;
     RsWork cur, nxt;
-    if (!rs_fetch(a, tiles_per_bag, n_items, item, cur)) return;
+    if (!rs_fetch(a, tiles_per_bag, item_end, item, cur)) return;
 #ifdef DSMIL_TRACE
-    // trace builds, DSMIL_EXPT & 64: lane 0 of wave 0 stamps s_memtime at the phase boundaries into the tile's rows of A
-    // (tools/stamp_res.py); k_finish is skipped.  Stamps are LDS-buffered and stored at the end of the tile (a global
-    // store per stamp would sit in the vmcnt queue that the chunk waits count).
-    unsigned long long stamps[20];
+    // trace builds, DSMIL_EXPT & 64: wave 0 keeps s_memtime stamps of the phase boundaries in registers and stores them into
+    // the tile's rows of A at the end of the tile (tools/stamp_res.py); k_finish is skipped.
+    unsigned long long stamps[10];
     int nstamp = 0;
-#define RS_STAMP() do { if (nstamp < 20) stamps[nstamp] = __builtin_readcyclecounter(); ++nstamp; } while (0)
+#define RS_STAMP() do { if (nstamp < 10) stamps[nstamp] = __builtin_readcyclecounter(); ++nstamp; } while (0)
 #define RS_STAMP_FLUSH(w) do { if (DSMIL_EXPT_ON(a, 64) && tid == 0 && (w).row0 + RS_BM <= (w).Nb) { \
         unsigned long long* o_ = reinterpret_cast<unsigned long long*>(a.scores + ((w).off0 + (w).row0) * (long long)C); \
-        _Pragma("unroll") for (int i_ = 0; i_ < 20; ++i_) o_[i_] = stamps[i_]; } nstamp = 0; } while (0)
+        _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) o_[i_] = stamps[i_]; } nstamp = 0; } while (0)
 #else
 #define RS_STAMP()
 #define RS_STAMP_FLUSH(w)
 #endif
 
-    // ---- the feature stream: this wave's 32 rows of every chunk, 4 pieces of 8 rows x 128 B
-    const bf16_t* src[4];
+    // ---- the feature stream: this wave's 16 rows of every chunk, 2 pieces of 8 rows x 128 B
+    const bf16_t* src[2];
     auto set_rows = [&](const RsWork& w) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int r32 = p * 8 + (lane >> 3);
-            long long gr = w.row0 + wave * 32 + r32;
+        for (int p = 0; p < 2; ++p) {
+            const int r = wave * 16 + p * 8 + (lane >> 3), r32 = r & 31;
+            long long gr = w.row0 + r;
             if (gr >= w.Nb) gr = w.Nb - 1;                                  // rows past the bag end get weight 0 later
             const int gslot = (lane & 7) ^ ((r32 & 6) | ((r32 >> 4) & 1));
             src[p] = feats + phys_row(a.rowmap, w.off0 + gr) * (long long)K + gslot * 8;
         }
     };
-    auto issue_chunk = [&](int c) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            __builtin_amdgcn_global_load_lds((const DSMIL_GLOBAL void*)(src[p] + c * 64),
-                                             (__attribute__((address_space(3))) void*)(sX + c * RS_CH_F4 + (wave * 32 + p * 8) * 8), 16, 0, 0);
+    auto issue_piece = [&](int buf, int i) {   // piece i = 2 c + p of this wave
+        __builtin_amdgcn_global_load_lds((const DSMIL_GLOBAL void*)(src[i & 1] + (i >> 1) * 64),
+                                         (__attribute__((address_space(3))) void*)(sX + buf * RS_BUF_F4 + (i >> 1) * RS_CH_F4 + (wave * 16 + (i & 1) * 8) * 8), 16, 0, 0);
     };
     set_rows(cur);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) issue_chunk(c);
+    for (int i = 0; i < 2 * NCH; ++i) issue_piece(0, i);
 
     // ---- resident weights: A fragments of this wave's 32 hidden / query units (fragment image of k_pack_agg_bf16:
     //      chunk s: [ks][t][lane] x 16 B; W2 chunks carry the k permutation of the accumulator layout), loaded STRAIGHT
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
     f32x4 w1[NCH * 4], w2[8];
 #pragma unroll
     for (int q = 0; q < NCH * 4; ++q) {
-        const f32x4* src_w = wpk + (long long)(q >> 2) * RS_CH_F4 + ((q & 3) * 4 + wave) * 64 + lane;
+        const f32x4* src_w = wpk + (long long)(q >> 2) * 1024 + ((q & 3) * 4 + wave) * 64 + lane;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(w1[q]) : "v"(src_w) : "memory");
     }
     f32x4 b1[4], b2c[4];     // biases of units 32 wave + 8g + 4hi + e; b2c = b2 * 2 log2(e): folded into tanh's first fma
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
     if constexpr (NL) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const f32x4* src_w = wpk + (long long)(NCH + (q >> 2)) * RS_CH_F4 + ((q & 3) * 4 + wave) * 64 + lane;
+            const f32x4* src_w = wpk + (long long)(NCH + (q >> 2)) * 1024 + ((q & 3) * 4 + wave) * 64 + lane;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(w2[q]) : "v"(src_w) : "memory");
         }
 #pragma unroll
@@ -177,47 +183,77 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
     __builtin_amdgcn_sched_barrier(0);
     const int fr = (l31 & 6) | ((l31 >> 4) & 1);
     const float scale = 0.08838834764831845f;                               // 1/sqrt(128), dsmil.py:56
-    const f32x4* xrd = sX + l31 * 8;                                         // this lane's row in every 32-row group
-    // this lane's (slot ^ row permutation) for the four 16-k steps of a chunk
-    int xsl[4];
+    int xsl[4];                                                             // (slot ^ row permutation) of the four 16-k steps of a chunk
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) xsl[ks] = (ks * 2 + hi) ^ fr;
+    for (int ks = 0; ks < 4; ++ks) xsl[ks] = l31 * 8 + ((ks * 2 + hi) ^ fr);
 
-    for (;;) {
-        int in = item + (int)gridDim.x;
-        const bool has_next = rs_fetch(a, tiles_per_bag, n_items, in, nxt);
-        RS_STAMP();                                                         // 0: tile start
-        // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] X[n][k]; j = this wave's 32 units, n = all 128 rows.
-        // One wave per SIMD: nothing hides an LDS round trip unless the code does, and hipcc left to itself emits
-        // read -> wait -> MFMA.  The B fragments are read TWO 16-k steps ahead into three rotating register sets, the
-        // order pinned by sched_barrier; a chunk's pieces are waited for (own pieces: counted vmcnt — pieces issued after it
-        // may stay in flight, younger stores only make the wait longer — then the barrier) two steps before its first read.
-        f32x16 H[4];
-        {
-            Frag xs[3][4];
-            auto rd = [&](int q, Frag (&d)[4]) {
+    // ---- value-sum geometry (constant): A-fragment source, transposed-read offsets
+    const int ai = lane & 15, ag = lane >> 4;
+    const int ts = lane & 15, trow = 4 * ag + (ts >> 2), tq = ts & 3;     // source lane ts of 16-lane group ag: row 4 ag + (ts >> 2), features 4 tq
+    int toff0[4], toff1[4];                                                // byte offsets inside a chunk, row group 0: rows trow / trow + 16
 #pragma unroll
-                for (int r = 0; r < 4; ++r) d[r].f = xrd[(q >> 2) * RS_CH_F4 + r * 256 + xsl[q & 3]];
+    for (int b = 0; b < 4; ++b) {
+        const int sl = 2 * b + (tq >> 1), f0 = (trow & 6), f1 = f0 | 1;
+        toff0[b] = trow * 128 + ((sl ^ f0) * 16) + (tq & 1) * 8;
+        toff1[b] = (trow + 16) * 128 + ((sl ^ f1) * 16) + (tq & 1) * 8;
+    }
+    // running sums of the bag in the workgroup's run: raw D layout of the value-sum MFMA (rows = plane x class), 2 chunks x 4 blocks
+    f32x4 acc[2][4];
+    float m_run = -INFINITY, l_run = 0.f;                                   // waves 0 (class 0) and 1 (class 1)
+    auto reset_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[j][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m_run = -INFINITY;
+        l_run = 0.f;
+    };
+    reset_acc();
+    // critical queries of the current bag, this wave's 32 units (reloaded when the bag changes: a vector load issued
+    // while the next tile's pieces are in flight would wait for them in the in-order vmcnt queue)
+    f32x4 u0[4], u1[4];
+    int ubag = -1;
+
+    for (int t = 0;; ++t) {
+        const int buf = t & 1;
+        int in = item + 1;
+        const bool has_next = rs_fetch(a, tiles_per_bag, item_end, in, nxt);
+        if (has_next) set_rows(nxt);
+        if (cur.bag != ubag) {
+            const float* qm0 = a.qmax + ((long long)cur.bag * C) * QD + 32 * wave + 4 * hi;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u0[g] = *reinterpret_cast<const f32x4*>(qm0 + 8 * g);
+                u1[g] = TWO ? *reinterpret_cast<const f32x4*>(qm0 + QD + 8 * g) : u0[g];
+            }
+            ubag = cur.bag;
+        }
+        RS_STAMP();                                                         // 0: tile start
+        // ---- the tile has landed: own pieces (everything this wave ever issued), then everybody's
+        S3_WAIT_VM(0);
+        __builtin_amdgcn_s_barrier();                                       // S
+        RS_STAMP();                                                         // 1
+        // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] X[n][k]; j = this wave's 32 units, n = all 64 rows.
+        // One wave per SIMD: nothing hides an LDS round trip unless the code does.  The B fragments are read TWO 16-k steps
+        // ahead into three rotating register sets, the order pinned by sched_barrier; one piece of the NEXT tile goes out
+        // every other step.
+        f32x16 H[2];
+        {
+            const f32x4* xb_ = sX + buf * RS_BUF_F4;
+            Frag xs[3][2];
+            auto rd = [&](int q, Frag (&d)[2]) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) d[r].f = xb_[(q >> 2) * RS_CH_F4 + r * 256 + xsl[q & 3]];
             };
-            S3_WAIT_VM(4 * (NCH - 1));
-            __builtin_amdgcn_s_barrier();
-            RS_STAMP();                                                     // 1
             rd(0, xs[0]);
             rd(1, xs[1]);
 #pragma unroll
             for (int q = 0; q < NCH * 4; ++q) {
-                constexpr int dummy = 0; (void)dummy;
-                const int q2 = q + 2;
-                if (q2 < NCH * 4) {
-                    if ((q2 & 3) == 0) {
-                        s3_wait_vm_dyn(4 * (NCH - 1 - (q2 >> 2)));          // constant after unrolling
-                        __builtin_amdgcn_s_barrier();
-                    }
-                    rd(q2, xs[q2 % 3]);
-                }
+                if (q + 2 < NCH * 4) rd(q + 2, xs[(q + 2) % 3]);
+                if ((q & 1) == 0 && has_next) issue_piece(buf ^ 1, q >> 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 2; ++r) {
                     if (q == 0) rs_mfma0(H[r], w1[q], xs[q % 3][r].f);
                     else rs_mfma(H[r], w1[q], xs[q % 3][r].f);
                 }
@@ -226,13 +262,13 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
         }
         RS_NOP();                                                           // last MFMA -> VALU reads of H
         RS_STAMP();                                                         // 2: GEMM 1 done
-        f32x16 Q[4];
+        f32x16 Q[2];
         if constexpr (NL) {
             // ---- bias, round to bf16, ReLU (on the packed pair: a negative bf16 is a negative int16), publish: block
             //      ((wave, sidx), hi) of row n holds the 8 hidden units that accumulator registers 8 sidx .. 8 sidx + 7 of
             //      this lane carry — a ready B fragment of GEMM 2
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < 2; ++r) {
                 const int n = 32 * r + l31;
 #pragma unroll
                 for (int sidx = 0; sidx < 2; ++sidx) {
@@ -250,13 +286,12 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                   // Bh
-            RS_STAMP();                                                     // 3
             // ---- GEMM 2 (transposed): Q^T[j2][n] += W2[j2][k] H^T[k][n]; j2 = this wave's 32 units
             {
-                Frag hs[3][4];
-                auto rdh = [&](int q, Frag (&d)[4]) {   // k-step q = 2 t + sidx: block (q, hi) of every row
+                Frag hs[3][2];
+                auto rdh = [&](int q, Frag (&d)[2]) {   // k-step q = 2 t + sidx: block (q, hi) of every row
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < 2; ++r) {
                         const int n = 32 * r + l31;
                         d[r].f = sH[n * 16 + (((q * 2) + hi) ^ (n & 15))];
                     }
@@ -269,7 +304,7 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
                     __builtin_amdgcn_sched_barrier(0);
                     // packed chunk c2 = q >> 2, fragment index q & 3 = 2 (t & 1) + sidx  (k_pack_agg_bf16)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < 2; ++r) {
                         if (q == 0) rs_mfma0(Q[r], w2[q], hs[q % 3][r].f);
                         else rs_mfma(Q[r], w2[q], hs[q % 3][r].f);
                     }
@@ -279,24 +314,17 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) Q[r][i] = H[r][i] + b1[i >> 2][i & 3];
         }
         __builtin_amdgcn_s_barrier();                                       // E0: sH is free
-        RS_STAMP();                                                         // 4
+        RS_STAMP();                                                         // 3
         // ---- tanh; partial scores over this wave's 32 query units (dsmil.py:55-56).  Written stage by stage over 16 values
         //      so that the exp / rcp chains of different values overlap.
         {
-            const float* qm0 = a.qmax + ((long long)cur.bag * C) * QD + 32 * wave + 4 * hi;
-            f32x4 u0[4], u1[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u0[g] = *reinterpret_cast<const f32x4*>(qm0 + 8 * g);
-                u1[g] = TWO ? *reinterpret_cast<const f32x4*>(qm0 + QD + 8 * g) : u0[g];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < 2; ++r) {
                 float q[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) q[i] = Q[r][i];
@@ -327,22 +355,19 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                       // E1
-        RS_STAMP();                                                         // 5
-        // ---- scores, tile softmax statistics: thread (cls = tid >> 7, row = tid & 127).  The attention weight is cut into
-        //      three bf16 planes here, once per (row, class), for the value sum's A fragments.
-        {
-            const int cls = tid >> 7, row = tid & 127;
-            const bool act = TWO || cls == 0;
+        RS_STAMP();                                                         // 4
+        // ---- scores and online softmax: wave cls holds the 64 rows of class cls (lane = row).  The weight is taken
+        //      relative to the running max of this workgroup's part of the bag and cut into three bf16 planes for the value
+        //      sum's A fragments; the factor by which the running sums shrink goes to every wave through sF.
+        if (wave < (TWO ? 2 : 1)) {
+            const int cls = wave, row = lane;
             const float s = ((sS[(0 * 2 + cls) * RS_BM + row] + sS[(1 * 2 + cls) * RS_BM + row]) +
                              (sS[(2 * 2 + cls) * RS_BM + row] + sS[(3 * 2 + cls) * RS_BM + row])) * scale;
-            const bool valid = act && cur.row0 + row < cur.Nb;
+            const bool valid = cur.row0 + row < cur.Nb;
             if (valid && !DSMIL_EXPT_ON(a, 64)) a.scores[(cur.off0 + cur.row0 + row) * (long long)C + cls] = s;
-            const float mw = wave_max(valid ? s : -INFINITY);
-            if (lane == 0) sRed[wave] = mw;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                   // E2
-            const float m = fmaxf(sRed[2 * cls], sRed[2 * cls + 1]);        // waves 2 cls, 2 cls + 1 hold class cls
-            const float p = valid ? expf(s - m) : 0.f;                      // weight relative to the TILE max
+            const float m_new = fmaxf(m_run, wave_max(valid ? s : -INFINITY));   // finite: a tile has a valid row
+            const float f = expf(m_run - m_new);                                 // 0 on the first tile of a run (m_run = -inf)
+            const float p = valid ? expf(s - m_new) : 0.f;
             const unsigned h0 = __float_as_uint(p) & 0xFFFF0000u;
             const float r1 = p - __uint_as_float(h0);
             const unsigned h1 = __float_as_uint(r1) & 0xFFFF0000u;
@@ -350,28 +375,27 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
             sPl[(0 * 2 + cls) * RS_BM + row] = (unsigned short)(h0 >> 16);
             sPl[(1 * 2 + cls) * RS_BM + row] = (unsigned short)(h1 >> 16);
             sPl[(2 * 2 + cls) * RS_BM + row] = (unsigned short)(h2 >> 16);
-            const float lw = wave_sum(p);
-            if (lane == 0) sRed[4 + wave] = lw;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                   // E3
-            if (lane == 0 && (wave & 1) == 0 && act) {
-                float* ml = a.part_ml + (cur.slot * C + cls) * 2;
-                ml[0] = m;
-                ml[1] = sRed[4 + wave] + sRed[5 + wave];
-            }
+            l_run = l_run * f + wave_sum(p);
+            m_run = m_new;
+            if (lane == 0) sF[cls] = f;
+        } else if (!TWO && wave == 1) {
+            // one class: the class-1 rows of the A fragments read zeros
+            sPl[(0 * 2 + 1) * RS_BM + lane] = 0; sPl[(1 * 2 + 1) * RS_BM + lane] = 0; sPl[(2 * 2 + 1) * RS_BM + lane] = 0;
+            if (lane == 0) sF[1] = 1.f;
         }
-        RS_STAMP();                                                         // 6
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                       // E3
+        RS_STAMP();                                                         // 5
         // ---- value sum on the matrix pipe (dsmil.py:57).  16x16x32: A[i][kk] = plane_{i>>1}(p[row(kk)][class i&1]) for
         //      i < 6 (three exact bf16 planes of the fp32 weight in different rows), B[kk][j] = x[row(kk)][f0 + j] by
         //      transposed LDS reads; kk = 8 g + e  <->  row n0 + 16 (e>>2) + 4 g + (e&3)  (a 32-lane half of a transposed read
         //      then touches 8 consecutive rows: conflict-free).  D rows 0..5 = (hi c0, hi c1, mid c0, mid c1, lo c0, lo c1).
         {
-            const int ai = lane & 15, ag = lane >> 4;
-            Frag pa[4];
+            Frag pa[2];
             {
                 const unsigned short* pl = sPl + (ai < 6 ? ai : 0) * RS_BM + 4 * ag;   // plane ai >> 1, class ai & 1
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
+                for (int rg = 0; rg < 2; ++rg) {
                     const u32x2 lo = *reinterpret_cast<const u32x2*>(pl + 32 * rg);
                     const u32x2 up = *reinterpret_cast<const u32x2*>(pl + 32 * rg + 16);
                     union { unsigned u[4]; f32x4 f; } pk;
@@ -380,30 +404,18 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
                     pa[rg].f = pk.f;
                 }
             }
-            // transposed-read address of this lane inside a (row group, 16-feature block): source lane s = lane & 15 of
-            // 16-lane group g reads 8 B of row 4 g + (s >> 2) (+16 for the second read) at features 4 (s & 3)
-            const int ts = lane & 15;
-            const int trow = 4 * ag + (ts >> 2);                            // 0..15; the second read adds 16
-            const int tq = ts & 3;
-            // byte offsets inside a chunk of the lane's two reads for block b = 0 (rows trow / trow + 16 of row group 0); a
-            // row group adds 4096, block b flips slot bits: slot (2 b + (tq >> 1)) ^ f
-            const int f0 = (trow & 6), f1 = f0 | 1;
-            int toff0[4], toff1[4];
+            const float f0 = sF[0], f1 = sF[1];
+            if (f0 != 1.f || f1 != 1.f) {                                   // the running max moved: D rows alternate class 0 / class 1
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int sl = 2 * b + (tq >> 1);
-                toff0[b] = trow * 128 + ((sl ^ f0) * 16) + (tq & 1) * 8;
-                toff1[b] = (trow + 16) * 128 + ((sl ^ f1) * 16) + (tq & 1) * 8;
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { acc[j][b][0] *= f0; acc[j][b][1] *= f1; acc[j][b][2] *= f0; acc[j][b][3] *= f1; }
             }
-            float2 outv[2][4];                                              // [step][block]: (class 0, class 1) of feature f0 + (lane & 15)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int c = 4 * j + wave;
-                f32x4 acc[4];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (c < NCH) {
-                    const char* xc = reinterpret_cast<const char*>(sX + c * RS_CH_F4);
+                    const char* xc = reinterpret_cast<const char*>(sX + buf * RS_BUF_F4 + c * RS_CH_F4);
                     rs_v4s t0[3], t1[3];
                     auto rdt = [&](int u, rs_v4s& d0, rs_v4s& d1) {       // block u = 4 rg + b
                         d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rs_v4s*)(xc + (u >> 2) * 4096 + toff0[u & 3]));
@@ -412,49 +424,47 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
                     rdt(0, t0[0], t1[0]);
                     rdt(1, t0[1], t1[1]);
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        if (u + 2 < 16) rdt(u + 2, t0[(u + 2) % 3], t1[(u + 2) % 3]);
+                    for (int u = 0; u < 8; ++u) {
+                        if (u + 2 < 8) rdt(u + 2, t0[(u + 2) % 3], t1[(u + 2) % 3]);
                         __builtin_amdgcn_sched_barrier(0);
                         bf16x8 xb;
                         xb[0] = t0[u % 3][0]; xb[1] = t0[u % 3][1]; xb[2] = t0[u % 3][2]; xb[3] = t0[u % 3][3];
                         xb[4] = t1[u % 3][0]; xb[5] = t1[u % 3][1]; xb[6] = t1[u % 3][2]; xb[7] = t1[u % 3][3];
-                        acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[u >> 2].v, xb, acc[u & 3], 0, 0, 0);
+                        acc[j][u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[u >> 2].v, xb, acc[j][u & 3], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                // D row i sits in lane group i >> 2, register i & 3: classes (0, 1) = regs (0, 1) + regs (2, 3) of lanes 0..15
-                // + regs (0, 1) of lanes 16..31
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        RS_STAMP();                                                         // 6
+        __builtin_amdgcn_s_barrier();                                       // T: tile buffer and scratch released
+        RS_STAMP();                                                         // 7
+        // ---- end of this workgroup's part of the bag: one (m, l, B) partial, slot = blockIdx.x + bag
+        if (!has_next || nxt.bag != cur.bag) {
+            const long long slot = (long long)blockIdx.x + cur.bag;
+            // D row i sits in lane group i >> 2, register i & 3: classes (0, 1) = regs (0, 1) + regs (2, 3) of lanes 0..15
+            // + regs (0, 1) of lanes 16..31
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = 4 * j + wave;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const float l0 = __shfl(acc[b][0], (lane & 15) + 16, 64), l1 = __shfl(acc[b][1], (lane & 15) + 16, 64);
-                    outv[j][b] = make_float2((acc[b][0] + acc[b][2]) + l0, (acc[b][1] + acc[b][3]) + l1);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                RS_STAMP();                                                 // 7, 9
-                __builtin_amdgcn_s_barrier();                               // T0 / T1: this step's chunks are released
-                RS_STAMP();                                                 // 8, 10
-                if (has_next) {
-                    if (j == 0) set_rows(nxt);
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc)
-                        if (4 * j + cc < NCH) issue_chunk(4 * j + cc);
-                }
-            }
-            // the stores go out behind the next tile's pieces (nothing younger than a piece that a counted wait names)
-            if (lane < 16) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c = 4 * j + wave;
-                    if (c < NCH) {
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const int k = c * 64 + b * 16 + lane;
-                            a.part_B[(cur.slot * C + 0) * (long long)a.Kv + k] = outv[j][b].x;
-                            if constexpr (TWO) a.part_B[(cur.slot * C + 1) * (long long)a.Kv + k] = outv[j][b].y;
-                        }
+                    const float l0 = __shfl(acc[j][b][0], (lane & 15) + 16, 64), l1 = __shfl(acc[j][b][1], (lane & 15) + 16, 64);
+                    const float o0 = (acc[j][b][0] + acc[j][b][2]) + l0, o1 = (acc[j][b][1] + acc[j][b][3]) + l1;
+                    if (lane < 16 && c < NCH) {
+                        const int k = c * 64 + b * 16 + lane;
+                        a.part_B[(slot * C + 0) * (long long)a.Kv + k] = o0;
+                        if constexpr (TWO) a.part_B[(slot * C + 1) * (long long)a.Kv + k] = o1;
                     }
                 }
             }
+            if (lane == 0 && wave < (TWO ? 2 : 1)) {
+                float* ml = a.part_ml + (slot * C + wave) * 2;
+                ml[0] = m_run;
+                ml[1] = l_run;
+            }
+            reset_acc();
         }
         RS_STAMP_FLUSH(cur);
         if (!has_next) break;

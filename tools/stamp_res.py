@@ -19,10 +19,9 @@ for _ in range(3):
     classes, pred, A, B, idx = ops.agg_forward(x, [N] * nb, w)
 torch.cuda.synchronize()
 a = A.view(torch.int64).cpu().numpy().reshape(nb, N)       # C = 2: one int64 per row
-ntile = N // 128
-T = np.array([a[b, t * 128:t * 128 + 11] for b in range(nb) for t in range(ntile)])   # [tiles, 11] stamps of wave 0
-names = ["start", "chunk0 landed", "GEMM1 done", "Bh (H written)", "E0 (GEMM2 done)", "E1 (tanh+partial scores)", "E3 (softmax stats)",
-         "vs0 done", "past T0", "vs1 done", "past T1"]
+ntile = N // 64
+T = np.array([a[b, t * 64:t * 64 + 8] for b in range(nb) for t in range(ntile)])   # [tiles, 8] stamps of wave 0
+names = ["start", "S (tile landed)", "GEMM1 done", "E0 (H exchange + GEMM2)", "E1 (tanh+partial scores)", "E3 (softmax)", "value sum done", "past T"]
 d = np.diff(T, axis=1)
 ok = (np.abs(d) < 1e6).all(axis=1)
 print("tiles", len(T), "sane", int(ok.sum()), "tile total median", int(np.median(T[ok, -1] - T[ok, 0])))
