@@ -1085,7 +1085,11 @@ int launch_attend_bf16_res(AttendArgs a, long long max_rows, int n_bags, hipStre
         return DSMIL_E_LAUNCH;
     if (cus > RS_MAX_WG) cus = RS_MAX_WG;
     typedef void (*res_fn)(AttendArgs, int, int, int);
-    const res_fn fn = a.K == 512 ? bf16_res_fn<8>(a) : bf16_res_fn<4>(a);
+    res_fn fn = a.K == 512 ? bf16_res_fn<8>(a) : bf16_res_fn<4>(a);
+#ifdef DSMIL_EXPERIMENTS
+    if (a.K == 512 && a.C == 2 && a.nonlinear && (a.expt & 1024)) fn = k_attend_bf16_res<8, true, true, 1>;
+    if (a.K == 512 && a.C == 2 && a.nonlinear && (a.expt & 2048)) fn = k_attend_bf16_res<8, true, true, 2>;
+#endif
     if (!dsmil_lds::allow((const void*)fn, RS_LDS_BYTES)) return DSMIL_E_LAUNCH;
     const int K64 = (a.K + 63) / 64 * 64;
     a.wpk = a.wpk + (size_t)QD * K64 + QD * QD;   // the fragment image sits behind the row-major one

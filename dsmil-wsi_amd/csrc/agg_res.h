@@ -73,7 +73,7 @@ __device__ __forceinline__ void rs_mfma(f32x16& acc, const f32x4& a_agpr, const 
 __device__ __forceinline__ void rs_mfma0(f32x16& acc, const f32x4& a_agpr, const f32x4& b_vgpr) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(a_agpr), "v"(b_vgpr));
 }
-#define RS_NOP() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+#define RS_NOP() asm volatile("s_nop 15" ::: "memory")   // 16 states >= the 12 an 8-pass MFMA result needs before a VALU read
 
 struct RsWork {
     int bag;
@@ -98,7 +98,8 @@ __device__ __forceinline__ bool rs_fetch(const AttendArgs& a, int tiles_per_bag,
     return false;
 }
 
-template <int NCH, bool TWO, bool NL>   // NCH: K / 64; TWO: C == 2 (else C == 1); NL: the two-layer query of dsmil.py:31-32
+template <int NCH, bool TWO, bool NL, int PV = 0>   // NCH: K / 64; TWO: C == 2 (else C == 1); NL: the two-layer query of dsmil.py:31-32;
+                                                    // PV: placement of the next tile's pieces (A/B variants of experiment builds)
 __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a, int tiles_per_bag, int n_items, int per_wg) {
     static_assert(NCH >= 1 && NCH <= RS_MAXCH, "feature chunks");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -227,6 +228,11 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
                 u1[g] = TWO ? *reinterpret_cast<const f32x4*>(qm0 + QD + 8 * g) : u0[g];
             }
             ubag = cur.bag;
+            if constexpr (NL) {
+                // the bag's softmax reference (waves 0 / 1 = classes 0 / 1): every wave sums its class's 128 |q_max| alike
+                const float* qa = a.qmax + ((long long)cur.bag * C + (wave < C ? wave : 0)) * QD;
+                m_run = wave_sum(fabsf(qa[lane]) + fabsf(qa[lane + 64])) * scale;
+            }
         }
         RS_STAMP();                                                         // 0: tile start
         // ---- the tile has landed: own pieces (everything this wave ever issued), then everybody's
@@ -235,27 +241,31 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
         RS_STAMP();                                                         // 1
         // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] X[n][k]; j = this wave's 32 units, n = all 64 rows.
         // One wave per SIMD: nothing hides an LDS round trip unless the code does.  The B fragments are read TWO 16-k steps
-        // ahead into three rotating register sets, the order pinned by sched_barrier; one piece of the NEXT tile goes out
-        // every other step.
+        // THREE 16-k steps ahead into four rotating register sets, the order pinned by sched_barrier; one piece of the NEXT tile goes
+        // out every other step (an LDS-DMA issue costs the wave ~45-60 cycles of its own stream here, twice that between the
+        // VALU stages of the tanh phase).
         f32x16 H[2];
         {
             const f32x4* xb_ = sX + buf * RS_BUF_F4;
-            Frag xs[3][2];
+            Frag xs[4][2];
             auto rd = [&](int q, Frag (&d)[2]) {
 #pragma unroll
                 for (int r = 0; r < 2; ++r) d[r].f = xb_[(q >> 2) * RS_CH_F4 + r * 256 + xsl[q & 3]];
             };
             rd(0, xs[0]);
             rd(1, xs[1]);
+            rd(2, xs[2]);
 #pragma unroll
             for (int q = 0; q < NCH * 4; ++q) {
-                if (q + 2 < NCH * 4) rd(q + 2, xs[(q + 2) % 3]);
-                if ((q & 1) == 0 && has_next) issue_piece(buf ^ 1, q >> 1);
+                if (q + 3 < NCH * 4) rd(q + 3, xs[(q + 3) & 3]);
+                if (PV == 1 && (q & 1) == 0 && has_next) issue_piece(buf ^ 1, q >> 1);               // all 2 NCH pieces here
+                if (PV == 0 && (q & 3) == 0 && has_next) issue_piece(buf ^ 1, q >> 2);               // NCH here, NCH behind the tanh stages
+                if (PV == 2 && (q & 3) == 0 && has_next) issue_piece(buf ^ 1, q >> 2);               // NCH here, NCH in the H exchange
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    if (q == 0) rs_mfma0(H[r], w1[q], xs[q % 3][r].f);
-                    else rs_mfma(H[r], w1[q], xs[q % 3][r].f);
+                    if (q == 0) rs_mfma0(H[r], w1[q], xs[q & 3][r].f);
+                    else rs_mfma(H[r], w1[q], xs[q & 3][r].f);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -282,6 +292,10 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
                         hb.u[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, pk), z));
                     }
                     sH[n * 16 + ((((wave * 2 + sidx) * 2) + hi) ^ (n & 15))] = hb.f;
+                    if (PV == 2 && has_next) {
+#pragma unroll
+                        for (int i = 0; i < NCH / 4; ++i) issue_piece(buf ^ 1, NCH + (r * 2 + sidx) * (NCH / 4) + i);
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -331,10 +345,21 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
                 if constexpr (NL) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) q[i] = __builtin_amdgcn_exp2f(fmaf(q[i], TANH_C, b2c[i >> 2][i & 3]));
+                    if (PV == 0 && has_next) {
+#pragma unroll
+                        for (int i = 0; i < NCH / 4; ++i) issue_piece(buf ^ 1, NCH + r * (NCH / 2) + i);
+                    }
 #pragma unroll
                     for (int i = 0; i < 16; ++i) q[i] = __builtin_amdgcn_rcpf(1.f + q[i]);
+                    if (PV == 0 && has_next) {
+#pragma unroll
+                        for (int i = NCH / 4; i < NCH / 2; ++i) issue_piece(buf ^ 1, NCH + r * (NCH / 2) + i);
+                    }
 #pragma unroll
                     for (int i = 0; i < 16; ++i) q[i] = fmaf(q[i], -2.f, 1.f);
+                } else if (PV == 0 && has_next) {
+#pragma unroll
+                    for (int i = 0; i < NCH / 2; ++i) issue_piece(buf ^ 1, NCH + r * (NCH / 2) + i);
                 }
                 float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -365,9 +390,20 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
                              (sS[(2 * 2 + cls) * RS_BM + row] + sS[(3 * 2 + cls) * RS_BM + row])) * scale;
             const bool valid = cur.row0 + row < cur.Nb;
             if (valid && !DSMIL_EXPT_ON(a, 64)) a.scores[(cur.off0 + cur.row0 + row) * (long long)C + cls] = s;
-            const float m_new = fmaxf(m_run, wave_max(valid ? s : -INFINITY));   // finite: a tile has a valid row
-            const float f = expf(m_run - m_new);                                 // 0 on the first tile of a run (m_run = -inf)
-            const float p = valid ? expf(s - m_new) : 0.f;
+            float p;
+            if constexpr (NL) {
+                // tanh bounds the queries: |s| <= scale * sum_j |q_max[j]| = m_run, a constant of the bag — no tile maximum,
+                // no rescaling, and the row weights are summed per lane (one wave reduction per partial, not per tile)
+                p = valid ? expf(s - m_run) : 0.f;
+                l_run += p;
+            } else {
+                const float m_new = fmaxf(m_run, wave_max(valid ? s : -INFINITY));   // finite: a tile has a valid row
+                const float f = expf(m_run - m_new);                                 // 0 on the first tile of a run (m_run = -inf)
+                p = valid ? expf(s - m_new) : 0.f;
+                l_run = l_run * f + wave_sum(p);
+                m_run = m_new;
+                if (lane == 0) sF[cls] = f;
+            }
             const unsigned h0 = __float_as_uint(p) & 0xFFFF0000u;
             const float r1 = p - __uint_as_float(h0);
             const unsigned h1 = __float_as_uint(r1) & 0xFFFF0000u;
@@ -375,13 +411,10 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
             sPl[(0 * 2 + cls) * RS_BM + row] = (unsigned short)(h0 >> 16);
             sPl[(1 * 2 + cls) * RS_BM + row] = (unsigned short)(h1 >> 16);
             sPl[(2 * 2 + cls) * RS_BM + row] = (unsigned short)(h2 >> 16);
-            l_run = l_run * f + wave_sum(p);
-            m_run = m_new;
-            if (lane == 0) sF[cls] = f;
         } else if (!TWO && wave == 1) {
             // one class: the class-1 rows of the A fragments read zeros
             sPl[(0 * 2 + 1) * RS_BM + lane] = 0; sPl[(1 * 2 + 1) * RS_BM + lane] = 0; sPl[(2 * 2 + 1) * RS_BM + lane] = 0;
-            if (lane == 0) sF[1] = 1.f;
+            if (!NL && lane == 0) sF[1] = 1.f;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                       // E3
@@ -404,12 +437,14 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
                     pa[rg].f = pk.f;
                 }
             }
-            const float f0 = sF[0], f1 = sF[1];
-            if (f0 != 1.f || f1 != 1.f) {                                   // the running max moved: D rows alternate class 0 / class 1
+            if constexpr (!NL) {
+                const float f0 = sF[0], f1 = sF[1];
+                if (f0 != 1.f || f1 != 1.f) {                               // the running max moved: D rows alternate class 0 / class 1
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) { acc[j][b][0] *= f0; acc[j][b][1] *= f1; acc[j][b][2] *= f0; acc[j][b][3] *= f1; }
+                        for (int b = 0; b < 4; ++b) { acc[j][b][0] *= f0; acc[j][b][1] *= f1; acc[j][b][2] *= f0; acc[j][b][3] *= f1; }
+                }
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -459,10 +494,13 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
                     }
                 }
             }
-            if (lane == 0 && wave < (TWO ? 2 : 1)) {
-                float* ml = a.part_ml + (slot * C + wave) * 2;
-                ml[0] = m_run;
-                ml[1] = l_run;
+            if (wave < (TWO ? 2 : 1)) {
+                const float lsum = NL ? wave_sum(l_run) : l_run;
+                if (lane == 0) {
+                    float* ml = a.part_ml + (slot * C + wave) * 2;
+                    ml[0] = m_run;
+                    ml[1] = lsum;
+                }
             }
             reset_acc();
         }
