@@ -138,14 +138,20 @@ class Ctx:
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
         self.dist = None
-        if self.world > 1:
+        self.collectives = self.world > 1 or args.force_collective   # do the legs run their RCCL collective?
+        if self.collectives:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:      # --force-collective on a bare `python bench.py`: a one-rank group
+                os.environ.update({"MASTER_PORT": str(_free_port()), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
             dist.init_process_group("nccl", device_id=self.dev)
             assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
             self.dist = dist
         import dsmil  # noqa: F401
         import dsmil_wsi_amd._native as nat
+        if args.force_collective:
+            import dsmil_wsi_amd.dist as dd
+            dd.force_collective(True)
         import dsmil_wsi_amd.ops as ops
         self.L = nat.lib()
         # independent passes are dealt round-robin to --streams HIP streams (ops.StreamPool, one workspace per stream)
@@ -240,22 +246,37 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
         raise SystemExit("--feats must match the weight file (512)")
     w = {k: torch.from_numpy(v).to(dev) for k, v in wnp.items()}
     g = torch.Generator(device=dev).manual_seed(1234 + cx.rank)
-    feats = torch.randn((nb * N, K), generator=g, device=dev, dtype=torch.float32)
     bf16 = dtype == "bf16"
-    if bf16:
-        feats = feats.to(torch.bfloat16)
+    # one DISTINCT batch per stream: passes in flight together are different batches of bags in a real job, so no pass
+    # may ride another's cache fills (3 x 1.31 GB fp32)
+    n_batches = max(1, args.streams)
+    batches = []
+    for _ in range(n_batches):
+        f = torch.randn((nb * N, K), generator=g, device=dev, dtype=torch.float32)
+        batches.append(f.to(torch.bfloat16) if bf16 else f)
+        del f
+    feats = batches[0]
     lengths = [N] * nb
     offsets = ops.offsets_tensor(lengths, dev)
     out = []
+    turn = [0]
 
     def one():
-        return ops.agg_forward(feats, lengths, w, offsets=offsets)
+        turn[0] += 1
+        return ops.agg_forward(batches[turn[0] % n_batches], lengths, w, offsets=offsets)
 
     def step():
         out[:] = cx.run(one)
 
     dt, inner, kern_ms_tot, launches = cx.timed(step, args.steps, args.warmup, args.min_seconds, channel=0)
     kern_alone_ms, _ = cx.kernel_alone(one, 0, passes=300)
+    # the same passes with ONE in flight (no stream pool), beside the pooled headline
+    value_1s = None
+    if cx.pool is not None:
+        def step1():
+            out[:] = one()
+        dt1, inner1, _, _ = cx.timed(step1, max(2, args.steps // 4), 1, args.min_seconds / 4)
+        value_1s = cx.world * nb * inner1 * max(2, args.steps // 4) / dt1
     single_ms = None
     if single_bag:   # one MILNet.forward-sized call per iteration, outside the timed region
         one = feats[:N]
@@ -272,6 +293,7 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
     if not os.environ.get("DSMIL_EXPT"):   # ablation runs of experiment builds compute garbage on purpose
         assert torch.isfinite(out[1]).all() and torch.allclose(s, torch.ones_like(s), atol=1e-4), "attention does not sum to 1"
     del feats, out[:], A, s
+    batches.clear()
     torch.cuda.empty_cache()
 
     world = cx.world
@@ -286,7 +308,8 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
                                    f"HBM-resident", "passes_per_step": inner, "bags_per_pass_per_gpu": nb, "rows": N,
                        "feats": K, "classes": C, "tile_rows": int(cx.L.dsmil_agg_tile_rows(nb, nb * N)),
                        "parallelism": f"bag-sharded x{world}", "timed_region_s": round(dt, 3),
-                       "streams": args.streams,
+                       "streams": args.streams, "distinct_batches": n_batches,
+                       "value_one_stream": round(value_1s, 1) if value_1s else None,
                        "single_bag_forward_ms": round(single_ms, 4) if single_ms is not None else None}}
     if bf16:
         # bf16 storage: the MLP runs on bf16 MFMA (0.7 us/bag at 2.5 PF) and the feature stream (10.5 MB/bag) binds
@@ -294,9 +317,9 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
         kern_region_ms, kern_ms = kern_ms, (kern_alone_ms if cx.pool is not None else kern_ms)
         gbs = by / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
         t_roof = max(flops_per_bag(N, K, C) / (PEAK_BF16_MFMA_TFLOPS * 1e12), bytes_per_bag(N, K, C, s=2) / (PEAK_HBM_GBS * 1e9))
-        line["roofline"] = {"kernel": "k_query_attend_bf16", "bound": "hbm", "achieved": round(gbs, 1) if gbs else None,
+        line["roofline"] = {"kernel": "k_attend_bf16_res", "bound": "hbm", "achieved": round(gbs, 1) if gbs else None,
                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4) if gbs else None,
-                            "traffic": _pmc("pmc_k_query_attend_bf16.json", "hbm_bytes_per_launch") if (nb, N, K) == (64, 10000, 512) else None,
+                            "traffic": _pmc("pmc_k_attend_bf16_res.json", "hbm_bytes_per_launch") if (nb, N, K) == (64, 10000, 512) else None,
                             "kernel_ms": round(kern_ms, 4), "launches": launches, "alg_bytes_per_launch": by,
                             "kernel_ms_in_timed_region": round(kern_region_ms, 4),
                             "kernel_ms_is": "average HIP-event duration of the kernel with ONE pass in flight (300 passes on one stream right after the timed region, same inputs): the kernel's own time. Inside the timed region config.streams passes overlap, so a launch's start-to-end interval (kernel_ms_in_timed_region) also contains the co-running streams' kernels and is not a measure of the kernel",
@@ -403,7 +426,7 @@ def cpu_baseline_aggregator(weights_tag, N, K, budget_s):
 def _build_iclassifier(cx, seed=11, C=2):
     import torch.nn as nn
     import dsmil
-    import resnet_oracle as ro   # weight fixture only (seeded kaiming init)
+    from inputs import make_resnet18_weights   # seeded kaiming init; no oracle/ import in the GPU legs
     from dsmil_wsi_amd.resnet import resnet18
     from conftest import load_weights
     torch = cx.torch
@@ -411,7 +434,7 @@ def _build_iclassifier(cx, seed=11, C=2):
     for p in res.parameters():
         p.requires_grad = False
     res.fc = nn.Identity()
-    res.load_state_dict(ro.make_weights(seed=seed), strict=True)
+    res.load_state_dict(make_resnet18_weights(seed=seed), strict=True)
     wt = load_weights("tcga")
     ic = dsmil.IClassifier(res, 512, output_class=C)
     with torch.no_grad():
@@ -425,13 +448,15 @@ def embedder_leg(cx):
     ic = _build_iclassifier(cx)
     Bp = args.patches
     g = torch.Generator(device=dev).manual_seed(7 + cx.rank)
-    x = torch.rand((Bp, 3, 224, 224), generator=g, device=dev, dtype=torch.float32)
+    xs = [torch.rand((Bp, 3, 224, 224), generator=g, device=dev, dtype=torch.float32) for _ in range(max(1, args.streams))]
     keep = []
+    turn = [0]
 
     def one():
+        turn[0] += 1
         with torch.no_grad():
-            feats, c = ic(x)
-        if world > 1:
+            feats, c = ic(xs[turn[0] % len(xs)])    # a distinct batch per stream
+        if cx.collectives:
             gathered = torch.empty((world * Bp, 512), device=dev)
             dist.all_gather_into_tensor(gathered, feats)
         return feats
@@ -470,7 +495,10 @@ def embedder_leg(cx):
             "config": {"workload": f"IClassifier(ResNet-18 InstanceNorm, fc=Identity)+Linear(512,2), {Bp} synthetic "
                                    f"224x224 patches per GPU per pass, kaiming(seed 11) weights",
                        "passes_per_step": inner, "timed_region_s": round(dt, 3), "streams": args.streams,
-                       "collective": "all_gather_into_tensor([%d,512] f32) per pass" % Bp if world > 1 else "none"},
+                       "distinct_batches": len(xs),
+                       "parity": "unpinned: the reference's backbone is torchvision's resnet18 (absent from the reference tree and "
+                                 "this image) and it ships no embedder vectors; checked against two independent restatements",
+                       "collective": "all_gather_into_tensor([%d,512] f32) per pass, %d rank(s)" % (Bp, world) if cx.collectives else "none"},
             "roofline": {"kernel": "conv kernels of one forward: 13 x k_conv_wino_s3 (Winograd F(2x2,3x3), bf16 MFMA over exact "
                                    "3-plane cuts) + 6 direct convs", "bound": "mfma",
                          # algorithmic (direct-form) rate of the conv kernels; NOT compared with a peak: Winograd does
@@ -545,13 +573,17 @@ def slide_leg(cx, n_patches, n_steps=None):
     del blk
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     res = {}
+    sizes = [dd.shard_range(n_patches, r, world)[1] - dd.shard_range(n_patches, r, world)[0] for r in range(world)]
 
     def step():
         with torch.no_grad():
             ev[0].record()
-            feats, _ = pl.embed_tiles(ic, tiles, args.patches, streams=args.streams)
+            feats, classes = pl.embed_tiles(ic, tiles, args.patches, streams=args.streams)
             ev[1].record()
-            bag = dd.all_gather_rows(feats, n_patches) if world > 1 else feats
+            if cx.collectives:   # ONE collective per slide: feature rows and instance logits as one [N_r, 512 + C] matrix
+                bag, _ = dd.all_gather_packed([feats, classes], sizes)
+            else:
+                bag = feats
             ev[2].record()
             res["out"] = net(bag)
             ev[3].record()
@@ -568,7 +600,12 @@ def slide_leg(cx, n_patches, n_steps=None):
             "config": {"workload": f"one slide = {n_patches} uint8 224x224 tiles (ToTensor fused in the stem), contiguous row "
                                    f"shards over {world} rank(s), batches of {args.patches}, one all-gather of [N_r,512] f32, "
                                    f"MILNet(tcga) on the gathered bag", "slides_timed": steps, "rccl_ranks": world,
-                       "streams": args.streams, "rows_this_rank": hi - lo}}
+                       "streams": args.streams, "rows_this_rank": hi - lo,
+                       "collectives_per_slide": 1 if cx.collectives else 0,
+                       "all_gather_bytes_per_rank": (max(sizes) * (512 + 2) * 4 * world) if cx.collectives else 0,
+                       "multi_gpu": "measured on %d rank(s)%s" % (world, "; RCCL exercised with a one-rank group (--force-collective), "
+                                    "2/4/8-GPU scaling unmeasured on hardware" if world == 1 and cx.collectives else
+                                    ("; unmeasured on hardware beyond one GPU" if world == 1 else ""))}}
 
 
 def e2e_leg(cx, low_grid):
@@ -599,7 +636,8 @@ def e2e_leg(cx, low_grid):
             "config": {"workload": f"synthetic uint8 slide {gy * 896}x{gx * 896}: {n_low} low tiles + {n_high} high tiles (224x224), "
                                    f"two ResNet-18-IN embedders, [high||low] 1024-d, MILNet(FCLayer(1024,2), BClassifier(1024,2)), "
                                    f"32x colour map replicated on the GPU", "slides_timed": steps, "rccl_ranks": world, "streams": args.streams,
-                       "all_gather_s_total": round(tm.get("allgather_s", 0.0), 4)}}
+                       "all_gather_s_total": round(tm.get("allgather_s", 0.0), 4), "all_gather_bytes": tm.get("allgather_bytes", 0),
+                       "collectives_per_slide": 1 if (world > 1 or args.force_collective) else 0}}
 
 
 def main():
@@ -620,6 +658,9 @@ def main():
     ap.add_argument("--e2e-grid", type=int, nargs=2, default=(24, 26), help="low-magnification tile grid of the e2e slide")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the slide / embedder collectives through RCCL even with ONE rank (a one-rank nccl group): "
+                         "exercises the multi-GPU code path on a one-GPU box")
     ap.add_argument("--no-single-bag", action="store_true",
                     help="skip the single-bag latency probe (profiling runs: keeps per-kernel averages clean)")
     args = ap.parse_args()

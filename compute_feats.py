@@ -41,6 +41,10 @@ def build_parser():
     p.add_argument("--weights_low", default=None, type=str)
     p.add_argument("--tree_fusion", default="cat", type=str, help="[cat|fusion]")
     p.add_argument("--dataset", default="TCGA-lung-single", type=str, help="Dataset folder name")
+    p.add_argument("--bg_threshold", default=None, type=float,
+                   help="new, default off: drop background tiles before embedding — keep a tile iff mean(FIND_EDGES band sums) / "
+                        "tile_size^2 > T, the criterion deepzoom_tiler.py:56-61 applies while tiling (its -t, 15); "
+                        "single-magnification bags only")
     p.add_argument("--save_npy", action="store_true",
                    help="(new) also write each bag's features as float32 <bag>.npy next to the '%%.4f' CSV: lossless "
                         "and ~6x smaller/faster to load than the text detour of compute_feats.py:80-82")
@@ -102,6 +106,8 @@ def main(argv=None):
     bags_list = sorted(glob.glob(os.path.join("WSI", args.dataset, sub, "*", "*")))
     feats_path = os.path.join("datasets", args.dataset)
     os.makedirs(feats_path, exist_ok=True)
+    if args.bg_threshold is not None and args.magnification == "tree":
+        raise ValueError("--bg_threshold filters single-magnification bags (a pyramid bag's rows are tied to its tile tree)")
     if args.magnification == "tree":
         pipeline.compute_tree_feats(args, bags_list, ic_l, ic_h, feats_path)
     else:

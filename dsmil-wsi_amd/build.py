@@ -27,7 +27,8 @@ def sources():
 
 
 def _headers():
-    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    return (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "experiments", "*.h")) +
+            glob.glob(os.path.join(ROOT, "include", "*.h")))
 
 
 def build_native(force=False, verbose=True, variant=None, cflags=()):

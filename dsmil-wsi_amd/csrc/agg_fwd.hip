@@ -996,12 +996,7 @@ template <int NW, int VEC>
 int launch_attend(const AttendArgs& a, long long max_rows, int n_bags, hipStream_t st) {
     constexpr int BM = NW * 32;
     const size_t lds = (size_t)(2 * W_TILE + 2 * BM * LDK) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_query_attend<NW, VEC>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    if (!dsmil_lds::allow((const void*)k_query_attend<NW, VEC>, (int)lds)) return DSMIL_E_LAUNCH;
     dim3 grid((unsigned)((max_rows + BM - 1) / BM), (unsigned)n_bags);
     const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
     hipLaunchKernelGGL((k_query_attend<NW, VEC>), grid, dim3(NW * 64), lds, st, a);
@@ -1018,17 +1013,7 @@ int launch_attend_split(const AttendArgs& a, long long max_rows, int n_bags, hip
     static const int lds_pad = expt_env("DSMIL_LDS_PAD");  // force 1 block/CU
     lds += (size_t)lds_pad;
 #endif
-    static bool attr_done = false;
-    if (!attr_done) {
-#ifdef DSMIL_EXPERIMENTS
-        int nb = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_query_attend_split<NW, VEC, NP, XE, TU>, NW * 64, lds);
-        fprintf(stderr, "[dsmil] k_query_attend_split<%d,%d,%d,%d,%d>: lds %zu B, %d blocks/CU\n", NW, VEC, NP, (int)XE, TU, lds, nb);
-#endif
-        (void)hipFuncSetAttribute((const void*)k_query_attend_split<NW, VEC, NP, XE, TU>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    if (!dsmil_lds::allow((const void*)k_query_attend_split<NW, VEC, NP, XE, TU>, (int)lds)) return DSMIL_E_LAUNCH;
     dim3 grid((unsigned)((max_rows + BM - 1) / BM), (unsigned)n_bags);
     const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
     hipLaunchKernelGGL((k_query_attend_split<NW, VEC, NP, XE, TU>), grid, dim3(NW * 64), lds, st, a);
@@ -1039,8 +1024,10 @@ int launch_attend_split(const AttendArgs& a, long long max_rows, int n_bags, hip
 // Which MFMA form the fp32 query MLP uses (see agg_split.h).  Default: 6 plane products — the three left
 // out are together below 2^-20 of |x*w|, i.e. below the fp32 accumulation rounding the reference's own
 // 512-long dot products carry (tests/accuracy_report.py: identical measured error for 0 / 9 / 6).
-// DSMIL_MLP = s9 | f32 selects the bit-exact-product forms; read once per process.
+// Experiment builds (libdsmil_hip_expt.so): DSMIL_MLP = s9 | f32 selects the bit-exact-product forms, read once per
+// process; the product library has the one form.
 int mlp_mode() {
+#ifdef DSMIL_EXPERIMENTS
     static const int mode = [] {
         const char* e = getenv("DSMIL_MLP");
         if (!e) return 6;
@@ -1049,16 +1036,15 @@ int mlp_mode() {
         return 6;
     }();
     return mode;
+#else
+    return 6;
+#endif
 }
 
 int launch_attend_bf16_dma(AttendArgs a, long long max_rows, int n_bags, hipStream_t st) {
     constexpr int NW = 4, BM = NW * 32;
     const size_t lds = (size_t)(2 * BD_WCHUNK_F4 + 3 * BM * 8) * 16;   // 32 KiB weights + 48 KiB features = 80 KiB: 2 per CU
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_query_attend_bf16_dma<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    if (!dsmil_lds::allow((const void*)k_query_attend_bf16_dma<NW>, (int)lds)) return DSMIL_E_LAUNCH;
     const int K64 = (a.K + 63) / 64 * 64;
     a.wpk = a.wpk + (size_t)QD * K64 + QD * QD;   // the fragment image sits behind the row-major one
     dim3 grid((unsigned)((max_rows + BM - 1) / BM), (unsigned)n_bags);
@@ -1111,12 +1097,7 @@ template <int NW>
 int launch_attend_bf16(const AttendArgs& a, long long max_rows, int n_bags, hipStream_t st) {
     constexpr int BM = NW * 32;
     const size_t lds = (size_t)(2 * W_TILE + 2 * BM * LDK) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_query_attend_bf16<NW>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    if (!dsmil_lds::allow((const void*)k_query_attend_bf16<NW>, (int)lds)) return DSMIL_E_LAUNCH;
     dim3 grid((unsigned)((max_rows + BM - 1) / BM), (unsigned)n_bags);
     const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
     hipLaunchKernelGGL((k_query_attend_bf16<NW>), grid, dim3(NW * 64), lds, st, a);

@@ -43,13 +43,45 @@ def shard_bags(n_bags, rank, world):
     return list(range(rank, n_bags, world))
 
 
+# A world of ONE rank needs no exchange, and the functions below return their input untouched in that case — which also
+# means that a single-GPU run never loads RCCL.  `force_collective(True)` (or DSMIL_FORCE_COLLECTIVE=1) makes them take
+# the real collective branch whenever a process group exists, even with one rank: tests/test_dist_gpu.py and
+# `bench.py --force-collective` use it to push tensors through RCCL on a one-GPU box, so that the multi-GPU path has
+# been executed before it first meets 8 GPUs.
+_FORCE = [os.environ.get("DSMIL_FORCE_COLLECTIVE", "0") not in ("", "0")]
+
+
+def force_collective(on=True):
+    prev = _FORCE[0]
+    _FORCE[0] = bool(on)
+    return prev
+
+
+def _skip_collective(world):
+    return world == 1 and not (_FORCE[0] and dist.is_available() and dist.is_initialized())
+
+
+_comm_streams = {}
+
+
+def _comm_stream(device):
+    """One side stream per device for the slide's collective: it is enqueued behind everything the caller's stream has
+    submitted (the last embedder batch) and the caller's stream waits for it, so host-side work that follows the
+    submission (and any kernels of OTHER streams) overlaps the transfer instead of queueing behind it."""
+    key = str(device)
+    st = _comm_streams.get(key)
+    if st is None:
+        st = _comm_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def all_gather_rows(local, n_total, group=None):
     """Reassemble [n_total, D] from per-rank contiguous shards (`shard_range` order) with ONE
     collective.  Shards differ by at most one row, so they are padded to the common maximum and
     sent as one equal-size all-gather (RCCL: a single direct all-gather over the xGMI mesh);
     the pad rows are dropped on arrival."""
     world, rank = world_rank(group)
-    if world == 1:
+    if _skip_collective(world):
         assert local.shape[0] == n_total
         return local
     sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
@@ -60,7 +92,7 @@ def all_gather_rows_sized(local, sizes, group=None):
     """all_gather_rows for arbitrary per-rank row counts (`sizes[r]` rows on rank r, rank order = row order):
     still ONE equal-size collective, shards padded to the largest."""
     world, rank = world_rank(group)
-    if world == 1:
+    if _skip_collective(world):
         return local
     assert len(sizes) == world and local.shape[0] == sizes[rank], (local.shape, sizes, rank)
     D, mx = local.shape[1], max(sizes)
@@ -70,14 +102,44 @@ def all_gather_rows_sized(local, sizes, group=None):
         padded[: local.shape[0]] = local
     padded = padded.contiguous()
     if dist.get_backend(group) == "nccl":
-        out = torch.empty((world * mx, D), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, padded, group=group)
+        cur = torch.cuda.current_stream(local.device)
+        side = _comm_stream(local.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            out = torch.empty((world * mx, D), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(out, padded, group=group)
+        cur.wait_stream(side)
+        padded.record_stream(side)
+        out.record_stream(cur)
         if all(s == mx for s in sizes):
             return out
         return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
     bufs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(bufs, padded, group=group)
     return torch.cat([bufs[r][: sizes[r]] for r in range(world)], dim=0)
+
+
+def all_gather_packed(parts, sizes, group=None):
+    """ONE collective for several per-row tensors of a slide (feature rows and instance logits; tree rows and grid
+    positions): each [n_r, D_i] part is bit-cast to 32-bit lanes (an int64 column travels as two float lanes, exact),
+    the parts are concatenated along the row, all-gathered as one [n_r, sum D_i] matrix and cut apart again.
+    Returns the list of gathered tensors with their original dtypes."""
+    world, _ = world_rank(group)
+    if _skip_collective(world):
+        return list(parts)
+    lanes, cols = [], []
+    for t in parts:
+        assert t.dim() == 2 and t.element_size() in (4, 8), (t.shape, t.dtype)
+        v = t.contiguous().view(torch.float32) if t.dtype != torch.float32 else t
+        lanes.append(v)
+        cols.append(v.shape[1])
+    packed = all_gather_rows_sized(torch.cat(lanes, dim=1), sizes, group)
+    out, c0 = [], 0
+    for t, c in zip(parts, cols):
+        piece = packed[:, c0:c0 + c].contiguous()
+        out.append(piece if t.dtype == torch.float32 else piece.view(t.dtype))
+        c0 += c
+    return out
 
 
 def embed_rows_sharded(embed_fn, n_total, group=None):

@@ -190,7 +190,13 @@ class MILNet(nn.Module):
         (v = Identity) take the fused path; everything else composes the same objective from torch ops."""
         ic, bc = self.i_classifier, self.b_classifier
         if (feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 2 and isinstance(ic, FCLayer)
-                and isinstance(bc, BClassifier) and not bc.passing_v and not feats.requires_grad):
+                and isinstance(bc, BClassifier) and not bc.passing_v and not feats.requires_grad
+                and ic.fc[0].out_features <= 64):   # dsmil_agg_loss_head: one wave of classes; more take the torch expression
+            if row_map is not None and row_map.numel():
+                # an out-of-range index would become an out-of-bounds device read in the row loads: checked once per
+                # bag on the device, surfaced with the step's only host sync (the loss .item() of train_tcga.py:74)
+                torch._assert_async((row_map.min() >= 0) & (row_map.max() < feats.shape[0]),
+                                    "row_map index out of range")
             w = bc._weights()
             lin = ic.fc[0]
             loss, pred, mx = _BagLossFunction.apply(feats, label, row_map, lin.weight, lin.bias, w["q0_w"], w["q0_b"],

@@ -82,12 +82,18 @@ class _Ready:
         self.ev = torch.cuda.Event()
         self.ev.record(torch.cuda.current_stream(dev))
 
-    def wait(self, dev):
+    def wait(self, dev, *buffers):
+        """Make the current stream wait for the producer; `buffers` (the cached device tensors about to be read) are
+        marked as in use on the current stream, so that an entry evicted from the cache while another stream still reads
+        it is not handed back to the producing stream's allocator pool early."""
         if self.ev is None:
             return
         cur = torch.cuda.current_stream(dev)
         if int(cur.cuda_stream) != self.sid:
             cur.wait_event(self.ev)
+            for b in buffers:
+                if b is not None and b.is_cuda:
+                    b.record_stream(cur)
 
 
 class StreamPool:
@@ -183,7 +189,7 @@ def _bf16_params(w, nonlinear, dev):
     key = (str(dev), bool(nonlinear)) + tuple(_tkey(w.get(k)) for k in names)
     ent = _bf16_cache.get(key)
     if ent is not None:
-        ent[3].wait(dev)
+        ent[3].wait(dev, ent[1], *[t for t in ent[0].values() if t is not None])
         return ent[0], ent[1]
     r = {k: (w[k].detach().to(torch.bfloat16).to(torch.float32).contiguous() if w.get(k) is not None else None)
          for k in names}
@@ -208,7 +214,7 @@ def _split_params(q0_w, q2_w, nonlinear, dev):
     key = (str(dev), bool(nonlinear), _tkey(q0_w), _tkey(q2_w) if nonlinear else None)
     ent = _split_cache.get(key)
     if ent is not None:
-        ent[2].wait(dev)
+        ent[2].wait(dev, ent[0])
         return ent[0]
     K = q0_w.shape[1]
     packed = torch.empty(L.dsmil_agg_packed_split_bytes(K, 1 if nonlinear else 0), dtype=torch.uint8, device=dev)
@@ -342,9 +348,11 @@ class GraphedAggForward:
         self._keep.append(_ws_last[0])   # the workspace of the capture stream
 
     def __call__(self, feats):
+        if tuple(feats.shape) != tuple(self.x.shape):   # copy_ would broadcast a wrong-sized bag silently
+            raise ValueError(f"captured for a bag of shape {tuple(self.x.shape)}, got {tuple(feats.shape)}")
         self.x.copy_(feats)
         self.graph.replay()
-        return self.out
+        return self.out   # the STATIC output tensors of the capture: valid until the next call (clone to keep)
 
 
 def _agg_params(w, K, Kv, nonlinear):
@@ -516,7 +524,7 @@ def _packed_resnet_weights(convs, depth=18):
     key = (str(dev), depth) + tuple(_tkey(w) for w in convs)
     ent = _pack_cache.get(key)
     if ent is not None:
-        ent[3].wait(dev)
+        ent[3].wait(dev, ent[0])
         return ent[0]
     L = _native.lib()
     buf = torch.empty(L.dsmil_resnet_packed_bytes(depth) // 4, dtype=torch.float32, device=dev)
@@ -539,7 +547,7 @@ def _folded_bn(norms, dev):
                               for n in norms)
     hit = _bn_cache.get(key)
     if hit is not None:
-        hit[3].wait(dev)
+        hit[3].wait(dev, hit[0], hit[1])
         return hit[0], hit[1]
     ms, rs = [], []
     for n in norms:

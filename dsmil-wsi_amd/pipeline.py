@@ -86,41 +86,73 @@ def glob_patches(bag_dir, magnification="single"):
 
 @torch.no_grad()
 def embed_files(i_classifier, files, batch_size=128, num_workers=4, device=None, want_position=False,
-                sharded=True):
+                sharded=True, bg_threshold=None, return_keep=False):
     """The hot loop of compute_feats.py:70-76 / attention_map.py:69-79.  Returns
     (feats [N,F], classes [N,C]) on `device` (and positions [N,2] if asked).  Sharded over ranks
-    when torch.distributed is initialised."""
+    when torch.distributed is initialised.
+
+    ``bg_threshold`` (new, default off): drop background tiles before they are embedded, by the tilers' own criterion —
+    keep a tile iff mean(FIND_EDGES band sums) / tile_size^2 > bg_threshold (deepzoom_tiler.py:56-61, `-t`, 15 there).
+    The statistics come from dsmil_tile_stats on the decoded uint8 batch (exact integer sums, decisions identical to
+    PIL's); rows, logits and positions of dropped tiles are absent from the result (N = tiles kept), as if the tiler
+    had not written them.  Still ONE collective per slide: the keep flags travel with the rows.
+    ``return_keep``: also return the bool keep mask over `files` (numpy)."""
     device = device or next(i_classifier.parameters()).device
     world, rank = ddist.world_rank() if sharded else (1, 0)
     n_total = len(files)
     lo, hi = ddist.shard_range(n_total, rank, world)
-    feats_l, cls_l, pos_l = [], [], []
+    feats_l, cls_l, keep_l = [], [], []
     # decoded uint8 images go to the GPU as they are when the native ResNet-18-IN stem will take them
     from .modules import resnet_convs_of
     u8 = torch.device(device).type == "cuda" and resnet_convs_of(i_classifier.feature_extractor) is not None
+    filt = bg_threshold is not None
+    F_, C_ = i_classifier.fc.in_features, i_classifier.fc.out_features
     if hi > lo:
-        for batch in patch_loader(files[lo:hi], batch_size, num_workers, want_position, uint8=u8):
+        for batch in patch_loader(files[lo:hi], batch_size, num_workers, False, uint8=u8 or filt):
             patches = batch["input"].to(device, non_blocking=True)
+            if filt:
+                keep = background_keep_mask(patches, edge_threshold=bg_threshold)
+                keep_l.append(keep)
+                patches = patches[keep]
+            if patches.shape[0] == 0:
+                continue
             if not u8:
-                patches = patches.float()
+                patches = patches.permute(0, 3, 1, 2).float().div(255) if filt else patches.float()   # == VF.to_tensor
             feats, classes = i_classifier(patches)
             feats_l.append(feats)
             cls_l.append(classes)
-            if want_position:
-                pos_l.append(batch["position"])
     if feats_l:
         feats, classes = torch.cat(feats_l), torch.cat(cls_l)
     else:
-        F = i_classifier.fc.in_features
-        feats = torch.zeros((0, F), device=device)
-        classes = torch.zeros((0, i_classifier.fc.out_features), device=device)
-    if world > 1:
-        feats = ddist.all_gather_rows(feats, n_total)
-        classes = ddist.all_gather_rows(classes, n_total)
+        feats = torch.zeros((0, F_), device=device)
+        classes = torch.zeros((0, C_), device=device)
+    keep_all = None
+    if filt:   # scatter the kept rows back to the shard's tile positions: shard sizes stay the ones every rank knows
+        keep_loc = torch.cat(keep_l) if keep_l else torch.zeros(0, dtype=torch.bool, device=device)
+        full_f = torch.zeros((hi - lo, F_), device=device)
+        full_c = torch.zeros((hi - lo, C_), device=device)
+        full_f[keep_loc], full_c[keep_loc] = feats, classes
+        feats, classes = full_f, full_c
+        keep_all = keep_loc.to(torch.float32)[:, None]
+    if world > 1 or ddist._FORCE[0]:
+        # ONE collective per slide: feature rows and instance logits (and keep flags) travel as one [n_r, F + C (+1)] matrix
+        sizes = [ddist.shard_range(n_total, r, world)[1] - ddist.shard_range(n_total, r, world)[0] for r in range(world)]
+        parts = ddist.all_gather_packed([feats, classes] + ([keep_all] if filt else []), sizes)
+        feats, classes = parts[0], parts[1]
+        if filt:
+            keep_all = parts[2]
+    keep_np = np.ones(n_total, bool)
+    if filt:
+        kb = keep_all[:, 0] > 0.5
+        feats, classes = feats[kb], classes[kb]
+        keep_np = kb.cpu().numpy()
+    out = (feats, classes)
     if want_position:
         pos = np.vstack([patch_position(f) for f in files]) if n_total else np.zeros((0, 2), int)
-        return feats, classes, pos
-    return feats, classes
+        out = out + (pos[keep_np],)
+    if return_keep:
+        out = out + (keep_np,)
+    return out
 
 
 def save_feats_csv(feats, path, npy=False):
@@ -145,10 +177,11 @@ def compute_feats(args, bags_list, i_classifier, save_path=None, magnification="
     _, rank = ddist.world_rank()
     for i, bag in enumerate(bags_list):
         files = glob_patches(bag, magnification)
-        feats, _ = embed_files(i_classifier, files, args.batch_size, args.num_workers)
+        feats, _ = embed_files(i_classifier, files, args.batch_size, args.num_workers,
+                               bg_threshold=getattr(args, "bg_threshold", None))
         if rank == 0:
-            sys.stdout.write("\r Computed: {}/{} -- {} patches".format(i + 1, len(bags_list), len(files)))
-            if len(files) == 0:
+            sys.stdout.write("\r Computed: {}/{} -- {} patches".format(i + 1, len(bags_list), int(feats.shape[0])))
+            if feats.shape[0] == 0:
                 print("No valid patch extracted from: " + bag)
             else:
                 save_feats_csv(feats, _bag_csv_path(save_path, bag), npy=getattr(args, "save_npy", False))
@@ -512,14 +545,15 @@ def multiscale_bag(wsi, embedder_low, embedder_high, tree_fusion="cat", tile=224
         f_high, _ = embed_tiles(embedder_high, high, batch_size, streams)
     low_of_high = f_low.index_select(0, parent)
     tree = f_high + 0.25 * low_of_high if tree_fusion == "fusion" else torch.cat([f_high, low_of_high], dim=-1)
-    if world > 1:
-        # shards are whole low tiles: rows per rank = f*f x its low-tile count; ONE collective for the tree rows,
-        # a second small one for the (row, col) positions the map needs
+    if world > 1 or ddist._FORCE[0]:
+        # shards are whole low tiles: rows per rank = f*f x its low-tile count; ONE collective carries the tree rows and
+        # the (row, col) grid positions the map needs (int64, bit-cast into float lanes)
         import time
         t0 = time.perf_counter()
         sizes = [(ddist.shard_range(L, r, world)[1] - ddist.shard_range(L, r, world)[0]) * ch for r in range(world)]
-        tree = ddist.all_gather_rows_sized(tree, sizes)
-        pos = ddist.all_gather_rows_sized(pos, sizes)
+        tree, pos = ddist.all_gather_packed([tree, pos], sizes)
+        if timings is not None:
+            timings["allgather_bytes"] = int(sum(sizes)) * (tree.shape[1] * tree.element_size() + pos.shape[1] * pos.element_size())
         if timings is not None:
             if tree.is_cuda:
                 torch.cuda.synchronize()

@@ -126,7 +126,8 @@ int dsmil_agg_shard_attend(const float* feats, const float* vals, int64_t rows,
  *                 below the rounding an fp32 dot product of this length carries anyway
  *   9           — all nine plane products: every fp32 product formed exactly (env DSMIL_MLP=s9)
  *   0           — v_mfma_f32_32x32x2_f32 (env DSMIL_MLP=f32)
- * The choice is read once per process from the environment variable DSMIL_MLP. */
+ * The product library always uses 6; experiment builds (libdsmil_hip_expt.so) read the environment variable DSMIL_MLP
+ * once per process. */
 int dsmil_agg_mlp_form(void);
 
 /* Options of dsmil_agg_forward_ex (all optional; a NULL opts or an all-zero struct = dsmil_agg_forward):
@@ -262,7 +263,8 @@ int32_t dsmil_resnet_feature_dim(int32_t depth);
 int32_t dsmil_resnet_num_convs(int32_t depth);
 /* Which matrix pipe the trunk's convolutions run on (for roofline accounting): bf16 plane products per fp32 MAC
  * of the Winograd convs (3x3 stride 1) and of the direct convs (3x3 stride 2, 1x1) — 9 / 6 = bf16 MFMA over exact
- * three-plane cuts, 0 = v_mfma_f32_32x32x2_f32.  Read once per process from DSMIL_WINO / DSMIL_CONV. */
+ * three-plane cuts, 0 = v_mfma_f32_32x32x2_f32.  The product library has one form (6 / 6); experiment builds read
+ * DSMIL_WINO / DSMIL_CONV once per process. */
 int dsmil_resnet_mfma_forms(int32_t* wino_products, int32_t* direct_products);
 int32_t dsmil_resnet_norm_channels(int32_t depth);
 size_t dsmil_resnet_packed_bytes(int32_t depth);

@@ -98,7 +98,7 @@ def main():
         net = build(512, C)
         net.load_state_dict(sd, strict=True)
         np.savez(os.path.join(HERE, f"weights_{tag}.npz"), **sd_to_np(sd))
-        for N in (1, 2, 37, 128, 500, 2000):
+        for N in (1, 2, 37, 128, 500, 2000, 10000):   # 10000 x 512: the exact shape of BASELINE configs[1] / [2]
             seed = 1000 + N
             x = make_bag(seed, N, 512)
             name = f"{tag}_N{N}"

@@ -29,3 +29,24 @@ def make_patches(seed, B, H=224, W=224):
     (compute_feats.py:35-39, no mean/std normalisation)."""
     rng = np.random.default_rng(int(seed))
     return rng.random((B, 3, H, W), dtype=np.float32)
+
+
+# torchvision ResNet-18 conv tensors in registration order: (name, cout, cin, k)
+RESNET18_CONVS = [("conv1", 64, 3, 7)] + [
+    (f"layer{li}.{b}.{c}", co, (ci if (b == 0 and c != "conv2") else co), (1 if c == "downsample.0" else 3))
+    for li, ci, co in ((1, 64, 64), (2, 64, 128), (3, 128, 256), (4, 256, 512))
+    for b in (0, 1)
+    for c in (("conv1", "conv2") + (("downsample.0",) if (b == 0 and li > 1) else ()))]
+
+
+def make_resnet18_weights(seed=11):
+    """Seeded kaiming-normal(fan_out, relu) conv weights — torchvision's ResNet init — as an ordered dict
+    name -> [Cout,Cin,k,k] (seed 11).  Same stream as oracle/resnet_oracle.make_weights."""
+    import collections
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    w = collections.OrderedDict()
+    for name, cout, cin, k in RESNET18_CONVS:
+        std = (2.0 / (cout * k * k)) ** 0.5
+        w[name + ".weight"] = torch.randn((cout, cin, k, k), generator=g, dtype=torch.float32) * std
+    return w

@@ -14,7 +14,7 @@ from util import VARIANT, build_net
 
 pytestmark = pytest.mark.gpu
 
-FWD_CASES = [(t, n) for t in ("c16", "tcga") for n in (1, 2, 37, 128, 500, 2000)] + \
+FWD_CASES = [(t, n) for t in ("c16", "tcga") for n in (1, 2, 37, 128, 500, 2000, 10000)] + \
             [("musk", 3), ("musk", 40), ("tree", 300), ("linq", 50), ("passv", 50)]
 
 
@@ -62,6 +62,19 @@ def test_full_size_bag_vs_oracle(tag, N):
     x = make_bag(4242 + N, N, 512)
     ref = orc.milnet_forward(x, p, dtype="f64")
     net = build_net(tag, "cuda")
+    with torch.no_grad():
+        out = net(torch.from_numpy(x).cuda())
+    _cmp(out, ref[0], ref[1], ref[2], ref[3], ref[4], np.argmax(out[0].cpu().numpy(), axis=0))
+
+
+@pytest.mark.parametrize("N", [10000, 70000])
+def test_tree_width_full_size_vs_oracle(N):
+    """fp32, K = 1024 (the [high || low] tree features of configs[4], README.md:204) at the sizes the e2e leg runs: the
+    split-plane MFMA kernel over 32 feature chunks, 1-wave tiles at 10 000 rows and 4-wave tiles at 70 000."""
+    p = load_weights("tree")
+    x = make_bag(5151 + N, N, 1024)
+    ref = orc.milnet_forward(x, p, dtype="f64")
+    net = build_net("tree", "cuda")
     with torch.no_grad():
         out = net(torch.from_numpy(x).cuda())
     _cmp(out, ref[0], ref[1], ref[2], ref[3], ref[4], np.argmax(out[0].cpu().numpy(), axis=0))

@@ -12,7 +12,7 @@ import torch
 from inputs import make_bag
 from util import VARIANT, build_net
 
-FWD_CASES = [(t, n) for t in ("c16", "tcga") for n in (1, 2, 37, 128, 500, 2000)] + \
+FWD_CASES = [(t, n) for t in ("c16", "tcga") for n in (1, 2, 37, 128, 500, 2000, 10000)] + \
             [("musk", 3), ("musk", 40), ("tree", 300), ("linq", 50), ("passv", 50)]
 GRAD_CASES = [("c16", 5), ("c16", 200), ("tcga", 5), ("tcga", 200), ("musk", 40), ("tree", 33)]
 

@@ -210,3 +210,43 @@ def test_multiscale_bag_sharded_by_low_tile_equals_unsharded():
         assert p.exitcode == 0
     for rank, same, same_pos, shape in res:
         assert same and same_pos and shape == (48, 1024)
+
+
+def _packed_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dsmil  # noqa: F401
+    from dsmil_wsi_amd import dist as dd
+    sizes = [5, 0, 3][:world]                      # ragged shards, one of them empty
+    g = torch.Generator().manual_seed(3)
+    feats_all = torch.randn(sum(sizes), 16, generator=g)
+    cls_all = torch.randn(sum(sizes), 2, generator=g)
+    pos_all = torch.randint(-2**40, 2**40, (sum(sizes), 2), generator=g, dtype=torch.int64)   # beyond float32 / int32 range
+    lo = sum(sizes[:rank])
+    sl = slice(lo, lo + sizes[rank])
+    f, c, p_ = dd.all_gather_packed([feats_all[sl], cls_all[sl], pos_all[sl]], sizes)
+    ok = torch.equal(f, feats_all) and torch.equal(c, cls_all) and torch.equal(p_, pos_all) and p_.dtype == torch.int64
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_packed_collective_carries_rows_logits_and_int64_positions():
+    """dist.all_gather_packed: feature rows, instance logits and int64 grid positions of a slide in ONE collective (the
+    int64 columns travel bit-cast in float lanes), ragged shards incl. an empty rank, world 3."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_packed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True), (2, True)]

@@ -305,3 +305,151 @@ def test_entry_points_on_gpu_use_native_path(tmp_path, monkeypatch):
     pd.DataFrame(rows, columns=["0", "label"]).to_csv("datasets/toy3/toy3.csv", index=False)
     tt.main(["--dataset", "toy3", "--num_classes", "2", "--num_epochs", "3", "--lr", "0.001"])
     assert glob.glob("weights/*/fold_*_*.pth")   # a fold whose 4 test bags score 0 saves nothing
+
+
+def _oracle_map(feat_fn, files, pos, agg_tag, thres, colors):
+    """Attention colour map the fp64 oracles give for the same decoded tiles: embedder oracle -> aggregator oracle ->
+    pipeline.attention_colormap (the host restatement of attention_map.py:86-113)."""
+    import agg_oracle as orc
+    from conftest import load_weights
+    from dsmil_wsi_amd import pipeline as pl
+    feats = feat_fn(files)
+    r = orc.milnet_forward(feats, load_weights(agg_tag), dtype="f64")
+    prob = 1.0 / (1.0 + np.exp(-np.asarray(r[1], np.float64).ravel()))
+    return pl.attention_colormap(np.asarray(r[2], np.float64), pos, prob, thres, colors, log=lambda *_: None), r
+
+
+@pytest.mark.gpu
+def test_attention_map_scripts_on_gpu(tmp_path, monkeypatch):
+    """attention_map.py itself on the GPU, from files: single scale (attention_map.py:59-118: embed -> aggregate ->
+    threshold -> PNG + score CSV) and --magnification tree.  The PNG must equal the colour map that the fp64 embedder
+    oracle + the fp64 aggregator oracle + attention_colormap give for the same decoded tiles (a byte may differ where
+    rint() sits on .5), the score CSV the oracle's attention."""
+    monkeypatch.chdir(tmp_path)
+    import attention_map as am
+    import pandas as pd
+    from PIL import Image
+    from util import state_dict_from_npz
+    from conftest import load_weights
+    from dsmil_wsi_amd import pipeline as pl
+    from dsmil_wsi_amd.pipeline import PatchFiles
+    assert torch.cuda.is_available()
+    os.makedirs("test/weights", exist_ok=True)
+    ws = {}
+    for name, seed in (("embedder", 51), ("embedder_low", 61), ("embedder_high", 62)):
+        ws[name] = ro.make_weights(seed=seed)
+        emb = collections.OrderedDict(ws[name])
+        for n in ("l1.weight", "l1.bias", "l2.weight", "l2.bias"):
+            emb[n] = torch.zeros(1)
+        torch.save(emb, f"test/weights/{name}.pth")
+    torch.save(state_dict_from_npz(load_weights("tcga")), "test/weights/aggregator.pth")
+    torch.save(state_dict_from_npz(load_weights("tree")), "test/weights/aggregator_tree.pth")
+
+    def feats_of(wname):
+        def f(files):
+            x = torch.stack([PatchFiles(files)[i]["input"] for i in range(len(files))]).double()
+            with torch.no_grad():
+                return ro.resnet18_in_features(x, {k: v.double() for k, v in ws[wname].items()}).numpy()
+        return f
+
+    # ---- single scale
+    for r in range(3):
+        for c in range(4):
+            _jpeg(f"test/patches/slideA/{r}_{c}.jpg", 300 + 10 * r + c, size=224)
+    np.random.seed(7)
+    am.main(["--num_workers", "0", "--thres", "0.0", "0.0", "--export_scores", "1", "--batch_size", "5"])
+    np.random.seed(7)
+    colors = [np.random.choice(range(256), size=3) for _ in range(2)]
+    sc = pd.read_csv("test/score/slideA.csv")
+    files = sorted(glob.glob("test/patches/slideA/*.jpg"), key=lambda f: list(sc["pos"]).index(str(pl.patch_position(f))))
+    pos = np.vstack([pl.patch_position(f) for f in files])
+    cm, r_ = _oracle_map(feats_of("embedder"), files, pos, "tcga", [0.0, 0.0], colors)
+    img = np.asarray(Image.open("test/output/slideA.png"))
+    assert img.shape == cm.shape == (3 * 32, 4 * 32, 3)
+    assert np.abs(img.astype(int) - cm.astype(int)).max() <= 1
+    np.testing.assert_allclose(sc[["0", "1"]].to_numpy(), r_[2], atol=1e-6, rtol=2e-3)
+
+    # ---- two scales: 2 x 2 low tiles, 2 x 2 high children each
+    for lr in range(2):
+        for lc in range(2):
+            _jpeg(f"test/pyr/slideT/{lr}_{lc}.jpg", 400 + 10 * lr + lc, size=224)
+            for hr in range(2):
+                for hc in range(2):
+                    _jpeg(f"test/pyr/slideT/{lr}_{lc}/{2 * lr + hr}_{2 * lc + hc}.jpg", 500 + 100 * lr + 40 * lc + 2 * hr + hc, size=224)
+    np.random.seed(8)
+    am.main(["--magnification", "tree", "--feats_size", "1024", "--embedder_weights_low", "test/weights/embedder_low.pth",
+             "--embedder_weights_high", "test/weights/embedder_high.pth", "--aggregator_weights",
+             "test/weights/aggregator_tree.pth", "--bag_path", "test/pyr", "--num_workers", "0", "--thres", "0.0", "0.0",
+             "--export_scores", "1", "--batch_size", "8"])
+    np.random.seed(8)
+    colors = [np.random.choice(range(256), size=3) for _ in range(2)]
+    sc = pd.read_csv("test/score/slideT.csv")
+    assert sc.shape == (16, 3)
+    highs = glob.glob("test/pyr/slideT/*/*.jpg")
+    highs = sorted(highs, key=lambda f: list(sc["pos"]).index(str(pl.patch_position(f))))
+    pos = np.vstack([pl.patch_position(f) for f in highs])
+
+    def tree_feats(files):
+        lows = [os.path.dirname(f) + ".jpg" for f in files]
+        return np.concatenate([feats_of("embedder_high")(files), feats_of("embedder_low")(lows)], axis=1)
+    cm, r_ = _oracle_map(tree_feats, highs, pos, "tree", [0.0, 0.0], colors)
+    img = np.asarray(Image.open("test/output/slideT.png"))
+    assert img.shape == cm.shape == (4 * 32, 4 * 32, 3)
+    assert np.abs(img.astype(int) - cm.astype(int)).max() <= 1
+    np.testing.assert_allclose(sc[["0", "1"]].to_numpy(), r_[2], atol=1e-6, rtol=2e-3)
+
+
+def _bg_dataset(root, size):
+    """Five tiles per slide: noise (tissue), flat grey (background), a faint ramp (background), noise, flat white."""
+    from PIL import Image
+    rng = np.random.default_rng(77)
+    os.makedirs(root, exist_ok=True)
+    tiles = [rng.integers(0, 256, (size, size, 3), dtype=np.uint8), np.full((size, size, 3), 228, np.uint8),
+             np.repeat((np.arange(size)[None, :, None] * 40 // size + 100).astype(np.uint8), size, axis=0).repeat(3, axis=2),
+             rng.integers(0, 256, (size, size, 3), dtype=np.uint8), np.full((size, size, 3), 255, np.uint8)]
+    for i, t in enumerate(tiles):
+        Image.fromarray(t).save(os.path.join(root, f"{i}_{i}.jpeg"), quality=95)
+
+
+def _pil_keep(files, thr):
+    """deepzoom_tiler.py:56-61 itself, on the decoded files: mean(ImageStat(FIND_EDGES).sum) / tile_size^2 > thr."""
+    from PIL import Image, ImageFilter, ImageStat
+    out = []
+    for f in files:
+        with Image.open(f) as im:
+            im = im.convert("RGB")
+            edge = np.mean(ImageStat.Stat(im.filter(ImageFilter.FIND_EDGES)).sum) / (im.size[0] ** 2)
+        out.append(edge > thr)
+    return np.array(out)
+
+
+def _check_bg_filter(size, atol):
+    import compute_feats as cf
+    import pandas as pd
+    from dsmil_wsi_amd.pipeline import PatchFiles, glob_patches
+    w = _simclr_checkpoint("simclr/runs/r0/checkpoints/model.pth", 31)
+    _bg_dataset("WSI/bg/single/0_x/s1", size)
+    cf.main(["--dataset", "bg", "--weights", "r0", "--batch_size", "2", "--num_workers", "0", "--bg_threshold", "15", "--save_npy"])
+    files = glob_patches("WSI/bg/single/0_x/s1", "single")
+    keep = _pil_keep(files, 15.0)
+    assert len(files) == 5 and 2 <= keep.sum() < 5 and not keep.all()     # the noise tiles stay, the flat tiles go
+    got = np.load("datasets/bg/0_x/s1.npy")
+    assert got.shape == (int(keep.sum()), 512)                       # background rows are absent, order preserved
+    kept = [f for f, k in zip(files, keep) if k]
+    x = torch.stack([PatchFiles(kept)[i]["input"] for i in range(len(kept))])
+    with torch.no_grad():
+        ref = ro.resnet18_in_features(x.double(), {k: v.double() for k, v in w.items()}).numpy()
+    np.testing.assert_allclose(got, ref, atol=atol)
+
+
+def test_compute_feats_background_filter_matches_pil_decisions(workdir):
+    """compute_feats.py --bg_threshold (new, default off): the tilers' FIND_EDGES criterion (deepzoom_tiler.py:56-61)
+    applied to the decoded tiles before embedding; the decisions equal PIL's own, the kept rows equal the oracle's."""
+    _check_bg_filter(64, 1e-4)
+
+
+@pytest.mark.gpu
+def test_compute_feats_background_filter_on_gpu(tmp_path, monkeypatch):
+    """The same on the GPU: dsmil_tile_stats (exact integer band sums) decides, the native trunk embeds the kept tiles."""
+    monkeypatch.chdir(tmp_path)
+    _check_bg_filter(224, 1e-4)

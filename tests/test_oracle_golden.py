@@ -9,7 +9,7 @@ import agg_oracle as orc
 from conftest import load_weights
 from inputs import make_bag
 
-FWD_CASES = [(t, n) for t in ("c16", "tcga") for n in (1, 2, 37, 128, 500, 2000)] + \
+FWD_CASES = [(t, n) for t in ("c16", "tcga") for n in (1, 2, 37, 128, 500, 2000, 10000)] + \
             [("musk", 3), ("musk", 40), ("tree", 300), ("linq", 50), ("passv", 50)]
 KDIM = {"c16": 512, "tcga": 512, "musk": 166, "tree": 1024, "linq": 64, "passv": 64}
 GRAD_CASES = [("c16", 5), ("c16", 200), ("tcga", 5), ("tcga", 200), ("musk", 40), ("tree", 33)]

@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 import dsmil
+import resnet_numpy as rnp
 import resnet_oracle as ro
 from dsmil_wsi_amd.resnet import resnet18
 from inputs import make_patches
@@ -193,9 +194,9 @@ def test_frozen_batchnorm_trunk_vs_torch_fp64(B, H, W, u8):
 
 
 @pytest.mark.parametrize("norm", ["instance", "batch"])
-def test_resnet34_trunk_vs_torch_fp64(norm):
+def test_resnet34_trunk_vs_numpy_oracle(norm):
     """`--backbone resnet34` (compute_feats.py:158-160): the same kernels over blocks [3,4,6,3]
-    (dsmil_resnet_forward, depth 34) against the torch module on the CPU in fp64."""
+    (dsmil_resnet_forward, depth 34) against oracle/resnet_numpy.py in fp64."""
     import copy
     from dsmil_wsi_amd.resnet import resnet34
     from dsmil_wsi_amd.modules import resnet_convs_of
@@ -217,8 +218,9 @@ def test_resnet34_trunk_vs_torch_fp64(norm):
     trunk = resnet_convs_of(ic.feature_extractor)
     assert trunk is not None and len(trunk[0]) == 36
     x = torch.from_numpy(make_patches(77, 2, 224, 224))
-    with torch.no_grad():
-        rf, rc = copy.deepcopy(ic).double()(x.double())
+    # truth: oracle/resnet_numpy.py (plain numpy fp64, no torch operator) on the module's state dict
+    rf = torch.from_numpy(rnp.resnet_features(x.numpy(), {k: v.numpy() for k, v in res.state_dict().items()}, 34, norm))
+    rc = rf @ ic.fc.weight.double().T + ic.fc.bias.double()
     icg = ic.cuda()
     with torch.no_grad():
         f, c = icg(x.cuda())
@@ -227,9 +229,25 @@ def test_resnet34_trunk_vs_torch_fp64(norm):
     np.testing.assert_allclose(c.cpu().numpy(), rc.numpy(), atol=1e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("depth,norm,B,H,W", [(50, "instance", 2, 224, 224), (50, "batch", 3, 224, 224), (50, "instance", 5, 96, 160),
-                                              (101, "instance", 2, 224, 224), (50, "instance", 33, 224, 224)])
-def test_bottleneck_trunks_vs_torch_fp64(depth, norm, B, H, W):
+def test_resnet101_trunk_vs_numpy_oracle_bar_is_1p5x_reference_fp32_error_not_1e_4():
+    """Depth 101 separately, because its bar is NOT the 1e-4 of every other trunk: 104 fp32 conv + norm layers on random
+    weights put the reference's own fp32 evaluation ~3e-4 from fp64, so the bar is 1.5x that error, measured here; the
+    assertion message reports the native error against fp64 and against 1e-4."""
+    _bottleneck_case(101, "instance", 2, 224, 224)
+
+
+@pytest.mark.parametrize("depth,norm,B,H,W", [(50, "instance", 2, 224, 224), (50, "batch", 3, 224, 224), (50, "instance", 33, 224, 224)])
+def test_bottleneck_trunks_vs_numpy_oracle(depth, norm, B, H, W):
+    _bottleneck_case(depth, norm, B, H, W, strict=True)          # the 1e-4 bar, no relaxation
+
+
+def test_resnet50_small_maps_bar_is_1p5x_reference_fp32_error_not_1e_4():
+    """96 x 160 inputs leave layer 4 with 3 x 5 maps: InstanceNorm over 15 values amplifies rounding, and the reference's
+    own fp32 evaluation is ~1.1e-4 from fp64 here — this one case takes the relaxed bar (1.5x that error, measured)."""
+    _bottleneck_case(50, "instance", 5, 96, 160)
+
+
+def _bottleneck_case(depth, norm, B, H, W, strict=False):
     """`--backbone resnet50 | resnet101` (compute_feats.py:161-167: Bottleneck blocks, 2048-d features): the native
     trunk (dsmil_resnet_forward, depth 50 / 101: 1x1 and strided 3x3 convs on the direct MFMA kernel, stride-1 3x3 convs
     on the Winograd kernel, fused InstanceNorm / folded frozen BatchNorm) against the same torch module evaluated on the
@@ -264,7 +282,11 @@ def test_bottleneck_trunks_vs_torch_fp64(depth, norm, B, H, W):
     assert trunk is not None and len(trunk[0]) == (53 if depth == 50 else 104)
     x = torch.from_numpy(make_patches(80 + B, B, H, W))
     with torch.no_grad():
-        rf, rc = copy.deepcopy(ic).double()(x.double())
+        if B <= 5:   # truth: oracle/resnet_numpy.py (plain numpy fp64) on the module's state dict
+            rf = torch.from_numpy(rnp.resnet_features(x.numpy(), {k: v.numpy() for k, v in res.state_dict().items()}, depth, norm))
+            rc = rf @ ic.fc.weight.double().T + ic.fc.bias.double()
+        else:        # 33 x 224 x 224 through ResNet-50 is minutes of numpy: the torch module in fp64, which
+            rf, rc = copy.deepcopy(ic).double()(x.double())   # tests/test_resnet_host.py ties to the numpy oracle
         f32_ref, _ = ic(x)                                     # the reference's arithmetic: torch fp32 on the CPU
     ref_err = float((f32_ref.double() - rf).abs().max())
     icg = ic.cuda()
@@ -274,5 +296,7 @@ def test_bottleneck_trunks_vs_torch_fp64(depth, norm, B, H, W):
     err = float((f.cpu().double() - rf).abs().max())
     tol = max(1e-4, 1.5 * ref_err)
     np.testing.assert_allclose(f.cpu().numpy(), rf.numpy(), atol=tol, rtol=1e-4,
-                               err_msg=f"max abs err {err:.3e}; reference fp32 vs fp64 {ref_err:.3e}")
+                               err_msg=f"max abs err vs fp64 {err:.3e} ({err / 1e-4:.2f} x the 1e-4 bar); reference fp32 vs fp64 {ref_err:.3e}")
+    if strict:
+        assert err <= 1e-4 * (1 + float(rf.abs().max())), f"max abs err vs fp64 {err:.3e} exceeds the 1e-4 bar (reference fp32 {ref_err:.3e})"
     np.testing.assert_allclose(c.cpu().numpy(), rc.numpy(), atol=tol, rtol=1e-4)
