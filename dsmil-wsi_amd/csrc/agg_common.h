@@ -59,6 +59,19 @@ __device__ __forceinline__ unsigned pack_bf16x2_hw(float lo, float hi) {
     return __builtin_bit_cast(unsigned, r);
 }
 
+// tanh x = 1 - 2 / (1 + e^{2x}) on v_exp_f32 / v_rcp_f32: 5 VALU ops where tanhf is ~31 plus branches.  A tile applies
+// it to 64 values per lane — with tanhf that is ~2000 issue slots per wave and tile, a sixth of the fp32 kernel's tile
+// time and more than all MFMAs of the bf16 kernel's.  Abs error ~1e-7 (one ulp of the "1 -"), exact saturation
+// (e -> inf gives 1, e -> 0 gives -1), NaN stays NaN.  Switched by DSMIL_PRECISE_TANH in experiment builds for A/B.
+__device__ __forceinline__ float fast_tanh(float x) {
+#ifdef DSMIL_PRECISE_TANH
+    return tanhf(x);
+#else
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
+#endif
+}
+
 // 4 consecutive elements at p[k..k+3] as floats, zero beyond klim.  VEC=4 needs rows aligned to
 // 4 elements (16 B for fp32, 8 B for bf16).
 template <int VEC, typename T = float>
@@ -468,7 +481,7 @@ __device__ __forceinline__ bool mlp_tile(const AttendArgs& a, int bag, int tile,
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * t + 8 * g + 4 * hi);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = tanhf(Q[t][4 * g + e] + b[e]);
+                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = fast_tanh(Q[t][4 * g + e] + b[e]);
             }
     } else {
 #pragma unroll

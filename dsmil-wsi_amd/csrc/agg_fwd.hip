@@ -605,7 +605,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_query_attend_bf1
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * t + 8 * g + 4 * hi);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = tanhf(Q[t][4 * g + e] + b[e]);
+                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = fast_tanh(Q[t][4 * g + e] + b[e]);
             }
     } else {
 #pragma unroll
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_query_attend_bf16_dma(AttendArgs
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * t + 8 * g + 4 * hi);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = tanhf(Q[t][4 * g + e] + b[e]);
+                for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = fast_tanh(Q[t][4 * g + e] + b[e]);
             }
     } else {
 #pragma unroll

@@ -51,14 +51,6 @@ constexpr int RS_LDS_BYTES = (2 * RS_BUF_F4 + RS_BM * 16) * 16;   // 2 x 64 KiB 
 
 typedef short rs_v4s __attribute__((ext_vector_type(4)));
 
-// tanh x = 1 - 2 / (1 + e^{2x}) on v_exp_f32 / v_rcp_f32 (5 VALU ops against ~31 + branches for tanhf): abs error
-// ~1e-7, exact saturation (e -> inf gives 1, e -> 0 gives -1).  64 of these per lane and tile: with tanhf they cost
-// more issue slots than the tile's MFMAs.
-__device__ __forceinline__ float rs_tanh(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
-}
-
 // v_mfma_f32_32x32x16_bf16 with the A operand AND the accumulator in the accumulator half of the register file.  A wave
 // may hold 512 registers, but only 256 of them are addressable as VGPRs; the resident weight fragments (160 registers)
 // left hipcc ~90 VGPRs for everything else and it serialised every read -> use chain.  "a" operands keep the weights in
@@ -381,6 +373,21 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                       // E1
         RS_STAMP();                                                         // 4
+        // ---- the value sum's B operands do not depend on the attention weights: the transposed reads of this wave's first
+        //      feature chunk (8 blocks x 2 reads) go out NOW, under the softmax, the second chunk's behind the first's MFMAs
+        //      (into the registers they release): no LDS round trip sits between barrier E3 and the sixteen MFMAs
+        rs_v4s tr0[8], tr1[8];
+        auto rd_block = [&](int j, int u) {          // chunk 4 j + wave, block u = 4 rg + b
+            const int c = 4 * j + wave;
+            if (c < NCH) {
+                const char* xc = reinterpret_cast<const char*>(sX + buf * RS_BUF_F4 + c * RS_CH_F4);
+                tr0[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rs_v4s*)(xc + (u >> 2) * 4096 + toff0[u & 3]));
+                tr1[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rs_v4s*)(xc + (u >> 2) * 4096 + toff1[u & 3]));
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rd_block(0, u);  // the second chunk's reads follow each MFMA of the first (same registers)
+        __builtin_amdgcn_sched_barrier(0);
         // ---- scores and online softmax: wave cls holds the 64 rows of class cls (lane = row).  The weight is taken
         //      relative to the running max of this workgroup's part of the bag and cut into three bf16 planes for the value
         //      sum's A fragments; the factor by which the running sums shrink goes to every wave through sF.
@@ -448,25 +455,14 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int c = 4 * j + wave;
-                if (c < NCH) {
-                    const char* xc = reinterpret_cast<const char*>(sX + buf * RS_BUF_F4 + c * RS_CH_F4);
-                    rs_v4s t0[3], t1[3];
-                    auto rdt = [&](int u, rs_v4s& d0, rs_v4s& d1) {       // block u = 4 rg + b
-                        d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rs_v4s*)(xc + (u >> 2) * 4096 + toff0[u & 3]));
-                        d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rs_v4s*)(xc + (u >> 2) * 4096 + toff1[u & 3]));
-                    };
-                    rdt(0, t0[0], t1[0]);
-                    rdt(1, t0[1], t1[1]);
+                if (4 * j + wave < NCH) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        if (u + 2 < 8) rdt(u + 2, t0[(u + 2) % 3], t1[(u + 2) % 3]);
-                        __builtin_amdgcn_sched_barrier(0);
                         bf16x8 xb;
-                        xb[0] = t0[u % 3][0]; xb[1] = t0[u % 3][1]; xb[2] = t0[u % 3][2]; xb[3] = t0[u % 3][3];
-                        xb[4] = t1[u % 3][0]; xb[5] = t1[u % 3][1]; xb[6] = t1[u % 3][2]; xb[7] = t1[u % 3][3];
+                        xb[0] = tr0[u][0]; xb[1] = tr0[u][1]; xb[2] = tr0[u][2]; xb[3] = tr0[u][3];
+                        xb[4] = tr1[u][0]; xb[5] = tr1[u][1]; xb[6] = tr1[u][2]; xb[7] = tr1[u][3];
                         acc[j][u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[u >> 2].v, xb, acc[j][u & 3], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
+                        if (j == 0) rd_block(1, u);
                     }
                 }
             }

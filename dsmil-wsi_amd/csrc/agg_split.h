@@ -202,7 +202,7 @@ __device__ __forceinline__ bool mlp_tile_split(const AttendArgs& a, int bag, int
         for (int g = 0; g < 4; ++g) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * t + 8 * g + 4 * hi);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = tanhf(Q[t][4 * g + e] + b[e]);
+            for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = fast_tanh(Q[t][4 * g + e] + b[e]);
         }
     return true;
 }
@@ -519,7 +519,7 @@ __device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag,
         for (int g = 0; g < 4; ++g) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * t + 8 * g + 4 * hi);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = tanhf(Q[t][4 * g + e] + b[e]);
+            for (int e = 0; e < 4; ++e) Q[t][4 * g + e] = fast_tanh(Q[t][4 * g + e] + b[e]);
         }
     return true;
 }
