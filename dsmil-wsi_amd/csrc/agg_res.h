@@ -32,9 +32,9 @@
 // LDS map: sX [2 buffers][8 chunks][64 rows][128 B] (16-B slot c of row r holds global slot c ^ f(r), f(r) = (r&6)|((r>>4)&1)
 // on the row's index inside its 32-row group: conflict-free ds_read_b128 of the MFMA fragments and conflict-free
 // transposed reads), then 16 KiB sH: the hidden layer [64 rows][16 blocks x 16 B] (block b of row n at b ^ (n & 15));
-// after GEMM 2 the same bytes hold the softmax scratch (partial scores, bf16 planes of p, rescale factors).
-// Barriers per tile (all four waves): S (tile landed for everybody), Bh (hidden layer written), E0 (GEMM 2 done, sH free),
-// E1 (partial scores), E3 (planes + rescale factors), T (value sum done: buffer and scratch released).
+// then 4 KiB of softmax scratch (partial scores, bf16 planes of p, rescale factors).
+// Barriers per tile (all four waves): S (tile landed for everybody; the previous tile's buffer and scratch are released),
+// Bh (hidden layer written), E1 (partial scores), E3 (planes + rescale factors).
 #pragma once
 #include "agg_common.h"
 #include "agg_split.h"
@@ -47,7 +47,8 @@ constexpr int RS_MAXCH = 8;                 // K <= 512 (the kernel is instantia
 constexpr int RS_BUF_F4 = RS_MAXCH * RS_CH_F4;   // float4 per tile buffer (64 KiB)
 constexpr int RS_THREADS = 256;             // one wave per SIMD
 constexpr int RS_MAX_WG = 1024;             // upper bound of the persistent grid (the workspace holds RS_MAX_WG + n_bags partial slots)
-constexpr int RS_LDS_BYTES = (2 * RS_BUF_F4 + RS_BM * 16) * 16;   // 2 x 64 KiB + 16 KiB = 147 456
+constexpr int RS_SCRATCH_BYTES = 4096;      // softmax scratch: partial scores 2 KiB, bf16 planes of p 768 B, rescale factors
+constexpr int RS_LDS_BYTES = (2 * RS_BUF_F4 + RS_BM * 16) * 16 + RS_SCRATCH_BYTES;   // 2 x 64 KiB + 16 KiB + 4 KiB = 151 552
 
 typedef short rs_v4s __attribute__((ext_vector_type(4)));
 
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* sX = reinterpret_cast<f32x4*>(smem);              // [2][8][RS_CH_F4]
     f32x4* sH = sX + 2 * RS_BUF_F4;                          // [64 rows][16 blocks]: hidden layer, bf16
-    float* sS = reinterpret_cast<float*>(sH);                // scratch after GEMM 2: [4 waves][2 classes][64 rows] partial scores
+    float* sS = reinterpret_cast<float*>(sH + RS_BM * 16);   // own scratch (not aliased: no barrier between GEMM 2 and the scores): [4 waves][2 classes][64 rows] partial scores
     unsigned short* sPl = reinterpret_cast<unsigned short*>(sS + 4 * 2 * RS_BM);   // [3 planes][2 classes][64 rows] bf16 planes of p
     float* sF = reinterpret_cast<float*>(sPl + 3 * 2 * RS_BM);                     // [2] rescale factor of the running sums per class
     const int tid = threadIdx.x, lane = tid & 63;
@@ -324,8 +325,7 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
 #pragma unroll
                 for (int i = 0; i < 16; ++i) Q[r][i] = H[r][i] + b1[i >> 2][i & 3];
         }
-        __builtin_amdgcn_s_barrier();                                       // E0: sH is free
-        RS_STAMP();                                                         // 3
+        RS_STAMP();                                                         // 3 (no barrier: the scratch below is not sH)
         // ---- tanh; partial scores over this wave's 32 query units (dsmil.py:55-56).  Written stage by stage over 16 values
         //      so that the exp / rcp chains of different values overlap.
         {
@@ -469,7 +469,8 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         RS_STAMP();                                                         // 6
-        __builtin_amdgcn_s_barrier();                                       // T: tile buffer and scratch released
+        // no barrier here: the next tile's S barrier is the one that releases this tile's buffer (its pieces are issued
+        // behind S) and the scratch (written behind E1)
         RS_STAMP();                                                         // 7
         // ---- end of this workgroup's part of the bag: one (m, l, B) partial, slot = blockIdx.x + bag
         if (!has_next || nxt.bag != cur.bag) {
