@@ -90,6 +90,17 @@ ACT_BYTES_PER_PATCH = (3 * 224 * 224 * 4 + 112 * 112 * 64 * 4          # stem
                              for p, h in ((56, 28), (28, 14), (14, 7))))           # 3 stride-1 convs, 2 residual kernels
 
 
+def _kernel_table(leg):
+    """Per-kernel rows of the committed profile of this leg (profiles/r03_kernel_table.json, tools/kernel_table.py): name,
+    launches per pass, average ms, counter HBM bytes, algorithmic bytes / executed MFMA FLOPs, fraction of the bounding peak —
+    measured under rocprofv3 with --streams 1 on the profiling box, NOT in this run (live numbers: `roofline`)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r03_kernel_table.json")))
+        return {"source": t["source"], "rows": t[leg]} if leg in t else None
+    except Exception:
+        return None
+
+
 def _pmc(name, key):
     """HBM bytes from the committed PMC summary (profiles/): (2*FETCH_SIZE + WRITE_SIZE), or None."""
     try:
@@ -689,6 +700,11 @@ def main():
         line.update({"n_gpus": cx.world, "rccl_ranks": cx.world, "steps": args.steps, "warmup": args.warmup,
                      "higher_is_better": True, "scaling": line.get("scaling", "weak"), "vs_baseline": None, "data": "synthetic"})
         line.update(subs)
+        for leg, obj in (("aggregator", line if "aggregator" in wl else None), ("aggregator_bf16", line.get("aggregator_bf16")),
+                         ("embedder", line.get("embedder"))):
+            kt = _kernel_table(leg)
+            if obj is not None and kt is not None:
+                obj["kernels"] = kt
         if not args.no_cpu_baseline and cx.world == 1:   # CPU baselines: rank 0 at N = 1 only
             if "aggregator" in wl:
                 line["cpu_baseline"] = cpu_baseline_aggregator("c16", args.rows, args.feats, args.cpu_seconds)
