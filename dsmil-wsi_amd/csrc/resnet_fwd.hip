@@ -498,7 +498,9 @@ __global__ __launch_bounds__(256) void k_in_finalize_flat(const float* __restric
     const long long ibeg = (long long)n * HW, iend = ibeg + HW;
     const long long t0 = ibeg >> 5, t1 = (iend - 1) >> 5;
     __shared__ float red[4][64];
-    for (int c = cl; c < C; c += 64) {
+    // grid.y = C / 64: one 64-channel group per workgroup (a deep layer's 8 groups used to be 8 serial rounds of two
+    // block-wide reductions in one workgroup per image — pure latency)
+    for (int c = (int)blockIdx.y * 64 + cl; c < C && c < ((int)blockIdx.y + 1) * 64; c += 64) {
         float s = 0.f;
         for (long long t = t0 + g; t <= t1; t += 4) {
             const long long tb = t << 5;
@@ -1184,7 +1186,7 @@ __global__ __launch_bounds__(256) void k_in_finalize_cnt(const float* __restrict
     const int n = blockIdx.x;
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     __shared__ float red[2][4][64];
-    for (int c = cl; c < C; c += 64) {
+    for (int c = (int)blockIdx.y * 64 + cl; c < C && c < ((int)blockIdx.y + 1) * 64; c += 64) {   // grid.y = C / 64 (see k_in_finalize_flat)
         float s = 0.f, cnt = 0.f;
         for (int t = g; t < nparts; t += 4) {
             const float* o = part + (((long long)n * nparts + t) * C + c) * 3;
@@ -2057,7 +2059,7 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
         dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         if (bn_m) return fill_stats(st, bn_m, bn_r, mean, rstd, B, s.cout);
-        hipLaunchKernelGGL(k_in_finalize_cnt, dim3((unsigned)B), dim3(256), 0, st, part, mean, rstd, wa.PB * 2, s.cout);
+        hipLaunchKernelGGL(k_in_finalize_cnt, dim3((unsigned)B, (unsigned)((s.cout + 63) / 64)), dim3(256), 0, st, part, mean, rstd, wa.PB * 2, s.cout);
         return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
     }
     ConvArgs a;
@@ -2087,7 +2089,7 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
         dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         if (bn_m) return fill_stats(st, bn_m, bn_r, mean, rstd, B, s.cout);
-        hipLaunchKernelGGL(k_in_finalize_flat, dim3((unsigned)B), dim3(256), 0, st, part, mean, rstd,
+        hipLaunchKernelGGL(k_in_finalize_flat, dim3((unsigned)B, (unsigned)((s.cout + 63) / 64)), dim3(256), 0, st, part, mean, rstd,
                            B, HW, s.cout, a.nslots, a.Mtot);
         return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
     }
@@ -2112,7 +2114,7 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
     dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     if (bn_m) return fill_stats(st, bn_m, bn_r, mean, rstd, B, s.cout);
-    hipLaunchKernelGGL(k_in_finalize_flat, dim3((unsigned)B), dim3(256), 0, st, part, mean, rstd,
+    hipLaunchKernelGGL(k_in_finalize_flat, dim3((unsigned)B, (unsigned)((s.cout + 63) / 64)), dim3(256), 0, st, part, mean, rstd,
                        B, HW, s.cout, a.nslots, a.Mtot);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
