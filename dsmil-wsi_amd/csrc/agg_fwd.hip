@@ -190,14 +190,20 @@ struct StreamVec<bf16_t> {
     }
 };
 
+// Register budget of the one-class form: 80 (6 waves per SIMD).  The fp32 attend kernel of ANOTHER batch (another stream)
+// holds 2 x 216 of a SIMD's 512 registers, so a logits wave fits beside it only below 80; measured same-box A/B at three
+// streams: 77.7 k against 76.2 k bags/s (-0.6 % at one stream).  The two-class form does not fit the budget without
+// halving its loads in flight, which costs more (bf16: 195 k against 215 k bags/s) than the co-residency buys: it keeps
+// its ~130 registers.  Either way the streams overlap at kernel tails more than inside kernels.
 template <int CP, typename T>  // classes per pass: 1 or 2; T = float or bf16 feature rows
-__global__ __launch_bounds__(256) void k_logits_stream(
+__global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
     const T* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ fc_w, const float* __restrict__ fc_b, float* __restrict__ classes_out,
     float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C, int bag0,
     const int64_t* __restrict__ rowmap) {
     constexpr int EPL = StreamVec<T>::EPL;   // elements per lane per 128-B segment
     constexpr int SEG = 8 * EPL;             // elements per segment (32 fp32 / 64 bf16)
+    constexpr int U = 8;                     // segments in flight per lane-row
     extern __shared__ __attribute__((aligned(16))) float s_w[];  // [CP][Kpad]: weights, zero past K, plus one zero segment
     __shared__ float s_v[8];
     __shared__ long long s_i[8];
@@ -222,22 +228,24 @@ __global__ __launch_bounds__(256) void k_logits_stream(
         const float b0 = fc_b[c0], b1 = fc_b[c1];
         float bv0 = -INFINITY, bv1 = -INFINITY;
         long long bi0 = 0x7fffffffffffffffLL, bi1 = 0x7fffffffffffffffLL;
+#pragma unroll 1
         for (int g = 0; g < 4; ++g) {
             const long long rbase = row0 + wave * 32 + g * 8;
             if (rbase >= Nb) break;  // wave-uniform
             const long long r = (rbase + rr < Nb) ? rbase + rr : Nb - 1;
             const T* x = feats + phys_row(rowmap, off0 + r) * (long long)K;
             float a0 = 0.f, a1 = 0.f;
-            for (int s0 = 0; s0 < nseg; s0 += 8) {
-                StreamVec<T> v[8];
+#pragma unroll 1
+            for (int s0 = 0; s0 < nseg; s0 += U) {
+                StreamVec<T> v[U];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < U; ++u) {
                     int k = (s0 + u) * SEG + j * EPL;
                     k = k < K ? k : K - EPL;  // clamped re-read; its weight is zero
                     v[u].load(x + k);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < U; ++u) {
                     const int ks = (s0 + u < nseg ? s0 + u : nseg) * SEG + j * EPL;  // segment nseg is all zero
 #pragma unroll
                     for (int q = 0; q < EPL / 4; ++q) {
