@@ -1138,12 +1138,15 @@ __global__ __launch_bounds__(WNN * 128, 2) void k_conv_wino_s3(WinoArgs a) {
     wino_epilogue(a, acc, smem, lane, wn, wp, n0, img0, ty0, tx0, tpi, pb);
 }
 
+#include "wino_w1.h"        // k_conv_wino_w1: the same unit for one wave per SIMD
+
 #ifdef DSMIL_EXPERIMENTS   // measured-and-lost restructurings of the Winograd unit: experiment builds only
 #include "experiments/wino_variants.h"
 #endif  // DSMIL_EXPERIMENTS
 
-// conv weight [O][I][3][3] -> U = G g G^T cut into three bf16 planes: [16 pos][I/16][3][O][16]
-__global__ void k_pack_wino_s3(const float* __restrict__ w, unsigned short* __restrict__ out, int O, int I) {
+// conv weight [O][I][3][3] -> U = G g G^T cut into three bf16 planes: [16 pos][I/16][3][O][16], or (tiled, for
+// k_conv_wino_w1) [O/32][I/16][16 pos][3][32][16]
+__global__ void k_pack_wino_s3(const float* __restrict__ w, unsigned short* __restrict__ out, int O, int I, int tiled) {
     const long long total = (long long)O * I;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -1171,10 +1174,13 @@ __global__ void k_pack_wino_s3(const float* __restrict__ w, unsigned short* __re
                 const float r1 = v - __uint_as_float(hb);
                 const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
                 const unsigned lb = __float_as_uint(r1 - __uint_as_float(mb));
-                const long long base = ((((long long)(xi * 4 + nu) * (I / 16) + ci / 16) * 3) * O + o) * 16 + (ci & 15);
+                const long long base = tiled
+                    ? (((((long long)(o >> 5) * (I / 16) + ci / 16) * 16 + (xi * 4 + nu)) * 3) * 32 + (o & 31)) * 16 + (ci & 15)
+                    : ((((long long)(xi * 4 + nu) * (I / 16) + ci / 16) * 3) * O + o) * 16 + (ci & 15);
+                const long long pstride = tiled ? 32 * 16 : (long long)O * 16;
                 out[base] = (unsigned short)(hb >> 16);
-                out[base + (long long)O * 16] = (unsigned short)(mb >> 16);
-                out[base + 2LL * O * 16] = (unsigned short)(lb >> 16);
+                out[base + pstride] = (unsigned short)(mb >> 16);
+                out[base + 2 * pstride] = (unsigned short)(lb >> 16);
             }
         }
     }
@@ -1822,11 +1828,19 @@ inline bool wino_wide() {   // expt builds: DSMIL_WINO_NARROW=1 keeps the 64-cou
 inline int wino_expt_kernel() {
     static const int k = [] {
         const char* e = getenv("DSMIL_WINO_KERNEL");
-        return (e && !strcmp(e, "pp")) ? 1 : (e && !strcmp(e, "alt")) ? 2 : 0;
+        return (e && !strcmp(e, "pp")) ? 1 : (e && !strcmp(e, "alt")) ? 2 : (e && !strcmp(e, "w1")) ? 3 : 0;
     }();
     return k;
 }
 #endif
+// which Winograd convs run on k_conv_wino_w1 (one wave per SIMD, tiled weights): the packing and the launch must agree
+inline bool use_w1(const ConvSpec& s) {
+#ifdef DSMIL_EXPERIMENTS
+    return wino_expt_kernel() == 3 && wino_s3() && s.cout % 128 == 0;
+#else
+    return false;
+#endif
+}
 #ifdef DSMIL_TRACE
 constexpr size_t WINO_TRACE_WORDS = 4 * 2 * 256 * 8;
 inline unsigned long long* wino_trace_buffer() {
@@ -2018,7 +2032,9 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
                 allow_lds((const void*)kern, lds_pp);
                 hipLaunchKernelGGL(kern, grida, dim3(512), lds_pp, st, wa);
             };
-            const int which = wino_expt_kernel();   // DSMIL_WINO_KERNEL = pp | alt
+            const int which = wino_expt_kernel();   // DSMIL_WINO_KERNEL = pp | alt | w1
+            const int w1_abl = wa.expt;
+            if (which == 3) wa.expt = 0;            // with w1 selected the ablation bits address that kernel only
 #else
             constexpr int which = 0;
 #endif
@@ -2031,6 +2047,24 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
 #ifdef DSMIL_EXPERIMENTS
                 if (in_mean) { if (np9) goa(k_conv_wino_alt<true, 9>); else goa(k_conv_wino_alt<true, 6>); }
                 else { if (np9) goa(k_conv_wino_alt<false, 9>); else goa(k_conv_wino_alt<false, 6>); }
+#endif
+            } else if (use_w1(s)) {
+                // one wave per SIMD: 256 threads, 128 couts, all 16 positions per wave (wino_w1.h)
+                const dim3 gridw(grid.x, (unsigned)(s.cout / 128));
+                const size_t lds_w1 = (size_t)(2 * SV_DW + WRAW_MAX * SRLD + 256 + 1024) * sizeof(float);
+                auto gow1 = [&](auto kern) {
+                    allow_lds((const void*)kern, lds_w1);
+                    hipLaunchKernelGGL(kern, gridw, dim3(256), lds_w1, st, wa);
+                };
+#ifdef DSMIL_EXPERIMENTS
+                switch (w1_abl) {   // DSMIL_WINO_EXPT: compile-time ablations of the w1 kernel (timing only)
+#define W1_ABL(n) case n: if (in_mean) gow1(k_conv_wino_w1<true, 6, n>); else gow1(k_conv_wino_w1<false, 6, n>); break;
+                    W1_ABL(1) W1_ABL(2) W1_ABL(3) W1_ABL(4) W1_ABL(8) W1_ABL(12) W1_ABL(15) W1_ABL(16) W1_ABL(19)
+#undef W1_ABL
+                    default:
+                        if (in_mean) { if (np9) gow1(k_conv_wino_w1<true, 9>); else gow1(k_conv_wino_w1<true, 6>); }
+                        else { if (np9) gow1(k_conv_wino_w1<false, 9>); else gow1(k_conv_wino_w1<false, 6>); }
+                }
 #endif
             } else if (s.cout % 128 == 0 && wino_wide()) {
                 // 128 couts per workgroup (512 threads, one workgroup per CU): half the staging work per MFMA
@@ -2164,7 +2198,7 @@ int dsmil_resnet_pack(int32_t depth, const float* const* conv_w, float* packed, 
             if (blocks > 4096) blocks = 4096;
             if (wino_s3())
                 hipLaunchKernelGGL(k_pack_wino_s3, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
-                                   (unsigned short*)(packed + pack_offset(*A, i)), s.cout, s.cin);
+                                   (unsigned short*)(packed + pack_offset(*A, i)), s.cout, s.cin, use_w1(s) ? 1 : 0);
             else
                 hipLaunchKernelGGL(k_pack_wino, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
                                    packed + pack_offset(*A, i), s.cout, s.cin);

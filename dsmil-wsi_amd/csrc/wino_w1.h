@@ -1,0 +1,439 @@
+// wino_w1.h — k_conv_wino_w1: the Winograd F(2x2,3x3) unit of k_conv_wino_s3 (same packed weights, same V layout, same
+// arithmetic — bit-identical outputs) re-cut for ONE wave per SIMD.  Included by resnet_fwd.hip behind k_conv_wino_s3,
+// whose constants and helpers it uses; not a translation unit of its own.
+//
+// Why.  k_conv_wino_s3 runs two waves per SIMD (256 registers each): eight accumulator tiles take half of them, so weight
+// fragments can be requested only two positions ahead, the staging / transform phases need registers the MFMA phase holds,
+// and the measured phases are ADDITIVE (bare MFMA loop 1.75 of 4.7 ms).  k_attend_bf16_res (agg_res.h) showed
+// what one wave per SIMD buys on gfx950: 512 registers per lane — the sixteen accumulator tiles of ALL sixteen transform
+// positions live in the 256 AGPRs, the 256 VGPRs hold a weight ring that is two position PAIRS deep, next pair's V
+// fragments, the raw pixels of the chunk after next and the transform's temporaries at the same time — and one instruction
+// stream in which the staging and transform work of chunk c+1 is laid into the MFMA shadows of chunk c.
+//
+// Unit: 32 tiles x 128 output channels (wave w owns channels 32w..32w+31 and all 16 positions: 16 x 6 = 96 MFMAs per
+// 16-channel chunk, consecutive MFMAs alternate between the two positions of a pair, so none waits for the one before).
+// LDS: V double-buffered 2 x 56 KB, raw 20 KB (+1 KB pad), producer statistics 4 KB = 137 KB: one workgroup per CU.
+// One chunk iteration = 8 pair-blocks of 12 MFMAs, straight-line code (no branch: the last iterations redo clamped work):
+//   block 0,1 : raw(c+1) registers -> IN + ReLU + padding -> LDS            (loaded during iteration c-1)
+//   block 2   : global loads of raw(c+2) and of its (mean, rstd); barrier A (raw(c+1) is in LDS)
+//   block 3-6 : transform(c+1), one xi row per block: raw window -> B^T d B -> three bf16 planes -> V[(c+1)&1]
+//   block 6   : statistics(c+2) -> LDS; barrier B (V[(c+1)&1] complete, raw free)
+//   block 7   : first V fragments of chunk c+1
+//   every block: weight fragments of the pair two blocks ahead (ring of 4 pair-sets, runs across chunks), V fragments of
+//   the next pair.
+// The inverse transform needs no exchange: a lane holds all sixteen positions of its (tile, channel) in registers.
+// ABL (experiment builds; timing only, wrong results): 1 no transform, 2 no raw staging, 4 weight fragments loaded once,
+// 8 V fragments read once, 16 no MFMAs.
+// plain f32 add / sub / fma the SLP vectoriser cannot fuse into v_pk_*_f32: beside MFMAs a packed op costs ~13 cycles more
+// than the two scalar ops it replaces (MI355X_MICROARCH.md, per-instruction constants)
+__device__ __forceinline__ float w1_add(float x, float y) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float w1_sub(float x, float y) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ f32x4 w1_add4(const f32x4& x, const f32x4& y) { return f32x4{w1_add(x[0], y[0]), w1_add(x[1], y[1]), w1_add(x[2], y[2]), w1_add(x[3], y[3])}; }
+__device__ __forceinline__ f32x4 w1_sub4(const f32x4& x, const f32x4& y) { return f32x4{w1_sub(x[0], y[0]), w1_sub(x[1], y[1]), w1_sub(x[2], y[2]), w1_sub(x[3], y[3])}; }
+
+template <bool NORM, int NP = 6, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
+    constexpr int NT = 256;
+    constexpr int RPT = (WRAW_MAX * 4 + NT - 1) / NT;   // raw float4 per thread per chunk (4)
+    constexpr int R_DW = WRAW_MAX * SRLD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned* sV = reinterpret_cast<unsigned*>(smem);   // [2][SV_DW]
+    float* sR = smem + 2 * SV_DW;                       // [WRAW_MAX][SRLD] + 256 floats that unused staging slots write to
+    float* sS = sR + R_DW + 256;                        // [2 buffers][16 images][2 (mean, rstd)][16 ch]
+    unsigned* sT = reinterpret_cast<unsigned*>(sR + R_DW);   // [32 tile slots][4]: output offset (lo, hi), flags, -
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int n0 = blockIdx.y * 128;
+    const int nchunks = a.C / SK;
+    int bid = blockIdx.x;
+    const int bx = bid % a.nbx; bid /= a.nbx;
+    const int by = bid % a.nby; bid /= a.nby;
+    const int img0 = bid * a.IB;
+    const int ty0 = by * a.TYB, tx0 = bx * a.TXB;
+    const int pb = by * a.nbx + bx;
+    const int RH = 2 * a.TYB + 2, RW = 2 * a.TXB + 2, RP = RH * RW;
+    const int tpi = a.TYB * a.TXB;
+    const int iy_org = 2 * ty0 - 1, ix_org = 2 * tx0 - 1;
+
+    // ---- raw staging role (as k_conv_wino_s3): element e = tid + 256 q -> (pixel, 4-channel group)
+    // (pixel of element q = pixel of element 0 + 64 q < 256: a slot past the unit's region stages zeros into its own,
+    // unused, row of the raw buffer — no branch, no dummy target)
+    int roff[RPT], rsto[RPT];
+    const int rlds0 = ((tid & 7) | ((tid >> 5) << 3)) * SRLD + ((tid >> 3) & 3) * 4;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int e = tid + NT * q, px = (e & 7) | ((e >> 5) << 3), gg = (e >> 3) & 3;
+        roff[q] = -1; rsto[q] = gg * 4;
+        if (px < a.IB * RP) {
+            const int il = px / RP, rem = px - il * RP, ry = rem / RW, rx = rem - ry * RW;
+            const int n = img0 + il, iy = iy_org + ry, ix = ix_org + rx;
+            if (n < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                roff[q] = ((n * a.H + iy) * a.W + ix) * a.C + gg * 4;
+                rsto[q] = il * 32 + gg * 4;
+            }
+        }
+    }
+    // producer statistics of a chunk: thread t fetches 4 channels of (mean | rstd) of local image (t & 127) >> 3 (the upper
+    // half of the workgroup repeats the lower half's work: no branch)
+    f32x4 sreg = {0.f, 0.f, 0.f, 0.f};
+    const int st_il = (tid & 127) >> 3, st_which = (tid >> 2) & 1, st_c4 = tid & 3;
+    const int st_n = img0 + st_il < a.B ? img0 + st_il : a.B - 1;
+    auto stat_load = [&](int cc) {
+        if constexpr (NORM)
+            sreg = *reinterpret_cast<const f32x4*>((st_which ? a.in_rstd : a.in_mean) + (long long)st_n * a.C + cc * SK + st_c4 * 4);
+    };
+    auto stat_write = [&](int cc) {
+        if constexpr (NORM) *reinterpret_cast<f32x4*>(sS + (cc & 1) * 512 + st_il * 32 + st_which * 16 + st_c4 * 4) = sreg;
+    };
+    f32x4 rreg[RPT];
+    auto raw_load = [&](int cc) {
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const unsigned off_b = roff[q] < 0 ? 0u : (unsigned)roff[q] * 4u;
+            rreg[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.x + cc * SK) + off_b);
+        }
+    };
+    auto raw_write_q = [&](int cc, int q) {   // producer's IN + ReLU and the zero padding, once per staged pixel
+        f32x4 x = rreg[q];
+        const bool ok = roff[q] >= 0;
+        if constexpr (NORM) {
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(sS + (cc & 1) * 512 + rsto[q]);
+            const f32x4 rs = *reinterpret_cast<const f32x4*>(sS + (cc & 1) * 512 + rsto[q] + 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = fmaxf((x[e] - mu[e]) * rs[e], 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = ok ? x[e] : 0.f;
+        *reinterpret_cast<f32x4*>(sR + rlds0 + q * (64 * SRLD)) = x;
+    };
+    // ---- transform role (as the 256-thread k_conv_wino_s3): channel group g, tile slot ts, column half h (wave-uniform)
+    const int g = tid & 3, ts = ((lane >> 5) & 1) | (((lane >> 2) & 7) << 1) | ((wave & 1) << 4);
+    const int h = (wave >> 1) & 1;
+    const int sil = ts / tpi, srem = ts - sil * tpi, styl = srem / a.TXB, stxl = srem - styl * a.TXB;
+    const int praw = (ts < a.IB * tpi) ? ((sil * RH + 2 * styl) * RW + 2 * stxl + h) * SRLD + g * 4 : g * 4;
+    // columns of the window are patch columns h..h+2.  With T_c = (B^T d)[xi][column c]:
+    //   h = 0: nu 0 = T0 - T2, nu 1 = T1 + T2;   h = 1: nu 2 = T1 - T0, nu 3 = T0 - T2
+    // i.e. X = T0 - T2 goes to nu (h ? 3 : 0) and Y = T1 + sz * Tz, (sz, z) = h ? (-1, 0) : (+1, 2), to nu (h ? 2 : 1):
+    // the choice is an LDS address and a wave-uniform sign, not a branch (x * +-1 is exact, the fma rounds once like the add).
+    const float sz = h ? -1.f : 1.f;
+    const int zcol = (h ? 0 : 2) * SRLD;
+    const int nuX = h ? 3 : 0, nuY = h ? 2 : 1;
+    const float* rwin = sR + praw;
+    auto tr_xi = [&](int xi, unsigned* vdst) {
+        // (B^T d) row xi = Ra +- Rb:  xi 0: R0 - R2,  1: R1 + R2,  2: R2 - R1,  3: R1 - R3
+        const int ra = xi == 0 ? 0 : xi == 2 ? 2 : 1, rb = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
+        const float* pa = rwin + ra * RW * SRLD;
+        const float* pb_ = rwin + rb * RW * SRLD;
+        f32x4 T[3], Tz;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f32x4 A = *reinterpret_cast<const f32x4*>(pa + c * SRLD);
+            const f32x4 Bv = *reinterpret_cast<const f32x4*>(pb_ + c * SRLD);
+            T[c] = xi == 1 ? A + Bv : A - Bv;
+        }
+        {
+            const f32x4 A = *reinterpret_cast<const f32x4*>(pa + zcol);
+            const f32x4 Bv = *reinterpret_cast<const f32x4*>(pb_ + zcol);
+            Tz = xi == 1 ? A + Bv : A - Bv;
+        }
+        const f32x4 X = T[0] - T[2];
+        f32x4 Y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Y[e] = __builtin_fmaf(sz, Tz[e], T[1][e]);
+        u32x2_t ph, pm, pl;
+        unsigned* dX = vdst + ((xi * 4 + nuX) * WTT + ts) * SVLD + g * 2;
+        cut4(X, ph, pm, pl);
+        *reinterpret_cast<u32x2_t*>(dX) = ph;
+        *reinterpret_cast<u32x2_t*>(dX + 8) = pm;
+        *reinterpret_cast<u32x2_t*>(dX + 16) = pl;
+        unsigned* dY = vdst + ((xi * 4 + nuY) * WTT + ts) * SVLD + g * 2;
+        cut4(Y, ph, pm, pl);
+        *reinterpret_cast<u32x2_t*>(dY) = ph;
+        *reinterpret_cast<u32x2_t*>(dY + 8) = pm;
+        *reinterpret_cast<u32x2_t*>(dY + 16) = pl;
+    };
+    // ---- weights, TILED for this kernel (k_pack_wino_s3, tiled = 1): [Cout/32][C/16][16 pos][3 planes][32 couts][16] bf16 —
+    // the 48 fragments a wave needs for one chunk are 48 consecutive KiB.  Buffer loads: one resource for the tensor, the
+    // lane's 16 bytes as the only address VGPR, a wave-uniform soffset per 4 fragments and the 12-bit immediate for the
+    // fragment among them: no per-load address arithmetic on the VALU (the per-lane L2 loads of k_conv_wino_s3 cost one
+    // 64-bit add each — an issue slot this kernel does not have).
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.u), 0, (int)((long long)a.C * a.Cout * 96), 0x00020000);
+    const int ulane_b = l31 * 32 + hi * 16;             // the lane's 16 B inside a 1 KiB fragment
+    const int utile_b = (((n0 >> 5) + wave) * nchunks) * (48 * 1024);   // wave-uniform
+    union Frag { u32x4_t u; bf16x8_t v; };
+    Frag uw[4][2][3];                                   // ring of 4 pair-sets; two pairs in flight beside the one in use
+    auto uload_pair = [&](int P, int cc, Frag (&w)[2][3]) {
+        const int c2 = cc < nchunks ? cc : nchunks - 1;
+        const int sbase = utile_b + c2 * (48 * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const int f = (2 * P + j) * 3 + pl;
+                w[j][pl].u = __builtin_amdgcn_raw_buffer_load_b128(urs, ulane_b + (f & 3) * 1024, sbase + (f >> 2) * 4096, 0);
+            }
+    };
+    Frag vq[2][2][3];                                   // V fragments: the pair in use and the next one
+    const int vfo = l31 * SVLD + 4 * hi;                // dwords
+    auto vread_pair = [&](int P, int buf, Frag (&v)[2][3]) {
+        const unsigned* b = sV + buf * SV_DW + vfo + (2 * P) * WTT * SVLD;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) v[j][pl].u = *reinterpret_cast<const u32x4_t*>(b + j * WTT * SVLD + pl * 8);
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    // ---- prologue: raw(0) -> LDS -> V[0]; raw(1) in registers, its statistics in LDS; weight pairs 0, 1; V pair 0
+    raw_load(0);
+    stat_load(0);
+    uload_pair(0, 0, uw[0]);
+    uload_pair(1, 0, uw[1]);
+    if (tid < 32) {
+        // where the epilogue stores tile slot `tid` (the divisions once per slot here, not once per accumulator row there):
+        // element offset of pixel (2 ty, 2 tx) of its image, flags 1 = slot holds a tile, 2 = column 2 tx + 1 exists,
+        // 4 = row 2 ty + 1 exists, local image number from bit 8
+        const int slot = tid;
+        const int il = slot / tpi, rem = slot - il * tpi, tyl = rem / a.TXB, txl = rem - tyl * a.TXB;
+        const int n = img0 + il, ty = ty0 + tyl, tx = tx0 + txl;
+        const bool ok = slot < a.IB * tpi && n < a.B && ty < a.TY && tx < a.TX;
+        const long long off = ok ? ((long long)(n * a.H + 2 * ty) * a.W + 2 * tx) * a.Cout : 0;
+        const unsigned fl = ok ? (1u | (2 * tx + 1 < a.W ? 2u : 0u) | (2 * ty + 1 < a.H ? 4u : 0u) | ((unsigned)il << 8)) : 0u;
+        sT[slot * 4 + 0] = (unsigned)off;
+        sT[slot * 4 + 1] = (unsigned)(off >> 32);
+        sT[slot * 4 + 2] = fl;
+    }
+    stat_write(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) raw_write_q(0, q);
+    raw_load(1 < nchunks ? 1 : 0);
+    stat_load(1 < nchunks ? 1 : 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) tr_xi(xi, sV);
+    stat_write(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    vread_pair(0, 0, vq[0]);
+
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const int c1 = cc + 1 < nchunks ? cc + 1 : nchunks - 1;   // clamped: the last iterations redo work nobody reads
+        const int c2 = cc + 2 < nchunks ? cc + 2 : nchunks - 1;
+        const int buf = cc & 1;
+        unsigned* vnext = sV + (buf ^ 1) * SV_DW;
+        // One pair-block = 2 NP MFMAs; behind each MFMA one PIECE of the other work, pinned there by sched_barrier (left to
+        // itself — or to sched_group_barrier patterns — hipcc issues the MFMAs back to back and the VALU work in 60-100
+        // instruction clumps: the pipe idles for the length of every clump).  A piece is at most ~8 VALU ops, the length of
+        // one MFMA's shadow.
+#ifdef DSMIL_TRACE
+        unsigned long long stamp[8];
+#endif
+        auto block = [&](auto Pc) {
+            constexpr int P = decltype(Pc)::value;
+#ifdef DSMIL_TRACE
+            stamp[P] = __builtin_amdgcn_s_memtime();   // kept in SGPRs, written out behind block 7
+#endif
+            Frag (&va)[2][3] = vq[P & 1];
+            Frag (&wb)[2][3] = uw[P & 3];
+            constexpr int PV9[9] = {2, 1, 2, 2, 0, 1, 1, 0, 0}, PW9[9] = {2, 2, 1, 0, 2, 1, 0, 1, 0};
+            constexpr bool TR = P >= 3 && P <= 6;           // transform block: xi = P - 3
+            constexpr int xi = TR ? P - 3 : 0;
+            constexpr int ra = xi == 0 ? 0 : xi == 2 ? 2 : 1, rb = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
+            f32x4 wA[4], wB[4], T[4], X, Y;                 // window rows (columns 0, 1, 2, z), (B^T d) row, the two outputs
+            u32x2_t ph, pm, pl;
+            f32x4 q0, q1;                                   // raw pixels on their way to LDS
+            f32x4 mu0, rs0, mu1, rs1;
+            auto cut2 = [&](float x0, float x1, int i) {    // two elements -> one packed dword per plane
+                const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+                const float r10 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r11 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
+                const unsigned v0 = __float_as_uint(r10), v1 = __float_as_uint(r11);
+                const unsigned w0 = __float_as_uint(r10 - __uint_as_float(v0 & 0xFFFF0000u));
+                const unsigned w1 = __float_as_uint(r11 - __uint_as_float(v1 & 0xFFFF0000u));
+                ph[i] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+                pm[i] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+                pl[i] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+            };
+            auto put = [&](int nu) {
+                unsigned* d = vnext + ((xi * 4 + nu) * WTT + ts) * SVLD + g * 2;
+                *reinterpret_cast<u32x2_t*>(d) = ph;
+                *reinterpret_cast<u32x2_t*>(d + 8) = pm;
+                *reinterpret_cast<u32x2_t*>(d + 16) = pl;
+            };
+            auto norm = [&](f32x4& x, const f32x4& mu, const f32x4& rs) {
+                if constexpr (NORM) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = fmaxf((x[e] - mu[e]) * rs[e], 0.f);
+                }
+            };
+            auto mask_put = [&](f32x4 x, int q) {
+                const bool ok = roff[q] >= 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = ok ? x[e] : 0.f;
+                *reinterpret_cast<f32x4*>(sR + rlds0 + q * (64 * SRLD)) = x;
+            };
+            auto step = [&](auto Ic) {
+                constexpr int I = decltype(Ic)::value;
+                constexpr int k = 9 - NP + I / 2, j = I & 1;
+                if constexpr (!(ABL & 16))
+                    acc[2 * P + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[j][PV9[k]].v, wb[j][PW9[k]].v, acc[2 * P + j], 0, 0, 0);
+                else asm volatile("" ::"v"(va[j][PV9[k]].u), "v"(wb[j][PW9[k]].u));
+                // every block: weight fragments of the pair two blocks ahead, V fragments of the next pair (block 7: pair 0
+                // of the next chunk, behind barrier B)
+                if constexpr (I == 0 && !(ABL & 4)) uload_pair((P + 2) & 7, cc + ((P + 2) >> 3), uw[(P + 2) & 3]);
+                if constexpr (I == 2 * NP - 5 && !(ABL & 8)) {
+                    if constexpr (P < 7) vread_pair(P + 1, buf, vq[(P + 1) & 1]);
+                    else vread_pair(0, buf ^ 1, vq[(P + 1) & 1]);
+                }
+                if constexpr (P <= 1 && !(ABL & 2)) {       // raw(c1): registers -> IN + ReLU + padding -> LDS, two per block
+                    constexpr int qa = 2 * P, qb = 2 * P + 1;
+                    if constexpr (I == 2 && NORM) {
+                        mu0 = *reinterpret_cast<const f32x4*>(sS + (c1 & 1) * 512 + rsto[qa]);
+                        rs0 = *reinterpret_cast<const f32x4*>(sS + (c1 & 1) * 512 + rsto[qa] + 16);
+                        mu1 = *reinterpret_cast<const f32x4*>(sS + (c1 & 1) * 512 + rsto[qb]);
+                        rs1 = *reinterpret_cast<const f32x4*>(sS + (c1 & 1) * 512 + rsto[qb] + 16);
+                    }
+                    if constexpr (I == 4) { q0 = rreg[qa]; norm(q0, mu0, rs0); }
+                    if constexpr (I == 6) mask_put(q0, qa);
+                    if constexpr (I == 7) { q1 = rreg[qb]; norm(q1, mu1, rs1); }
+                    if constexpr (I == 9) mask_put(q1, qb);
+                }
+                if constexpr (P == 2 && !(ABL & 2)) {
+                    if constexpr (I == 2) raw_load(c2);
+                    if constexpr (I == 3) stat_load(c2);
+                }
+                if constexpr (TR && !(ABL & 1)) {           // transform(c1), row xi: window -> B^T d B -> planes -> V[next]
+                    if constexpr (I == 2) {
+                        const float* pa = rwin + ra * RW * SRLD;
+                        const float* pb_ = rwin + rb * RW * SRLD;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            wA[c] = *reinterpret_cast<const f32x4*>(pa + c * SRLD);
+                            wB[c] = *reinterpret_cast<const f32x4*>(pb_ + c * SRLD);
+                        }
+                        wA[3] = *reinterpret_cast<const f32x4*>(pa + zcol);
+                        wB[3] = *reinterpret_cast<const f32x4*>(pb_ + zcol);
+                    }
+                    if constexpr (I == 4) { T[0] = xi == 1 ? w1_add4(wA[0], wB[0]) : w1_sub4(wA[0], wB[0]); T[1] = xi == 1 ? w1_add4(wA[1], wB[1]) : w1_sub4(wA[1], wB[1]); }
+                    if constexpr (I == 5) { T[2] = xi == 1 ? w1_add4(wA[2], wB[2]) : w1_sub4(wA[2], wB[2]); T[3] = xi == 1 ? w1_add4(wA[3], wB[3]) : w1_sub4(wA[3], wB[3]); }
+                    if constexpr (I == 6) {
+                        X = w1_sub4(T[0], T[2]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Y[e] = __builtin_fmaf(sz, T[3][e], T[1][e]);
+                    }
+                    if constexpr (I == 7) cut2(X[0], X[1], 0);
+                    if constexpr (I == 8) { cut2(X[2], X[3], 1); put(nuX); }
+                    if constexpr (I == 9) cut2(Y[0], Y[1], 0);
+                    if constexpr (I == 10) { cut2(Y[2], Y[3], 1); put(nuY); }
+                }
+                if constexpr (P == 6 && I == 11) stat_write(cc + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+            step(std::integral_constant<int, 8>{}); step(std::integral_constant<int, 9>{});
+            step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+            if constexpr (NP == 9) {
+                step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{});
+                step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
+                step(std::integral_constant<int, 16>{}); step(std::integral_constant<int, 17>{});
+            }
+            if constexpr (P == 2 || P == 6) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        };
+        block(std::integral_constant<int, 0>{});
+        block(std::integral_constant<int, 1>{});
+        block(std::integral_constant<int, 2>{});
+        block(std::integral_constant<int, 3>{});
+        block(std::integral_constant<int, 4>{});
+        block(std::integral_constant<int, 5>{});
+        block(std::integral_constant<int, 6>{});
+        block(std::integral_constant<int, 7>{});
+#ifdef DSMIL_TRACE
+        if (a.trace && blockIdx.x < 4 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 3) && cc < 256) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a.trace[(((long long)blockIdx.x * 2 + (wave != 0)) * 256 + cc) * 8 + i] = stamp[i];
+        }
+#endif
+    }
+
+    // ---- epilogue: inverse transform in registers (the arithmetic order of wino_epilogue, so the outputs are bit-identical
+    // to k_conv_wino_s3), raw NHWC store, (cnt, mean, M2) statistics partials per output-row parity
+    const int co = n0 + wave * 32 + l31;
+    u32x4_t tsl[16];              // the table entries of this lane's 16 accumulator rows
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tsl[r] = *reinterpret_cast<const u32x4_t*>(sT + drow(r, hi) * 4);
+    float ya[2][16], yb[2][16];   // [output row parity][accumulator row]: pixels (oy + parity, ox) and (oy + parity, ox + 1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float ra[4], rb[4];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            ra[xi] = acc[4 * xi][r] + acc[4 * xi + 1][r] + acc[4 * xi + 2][r];
+            rb[xi] = acc[4 * xi + 1][r] - acc[4 * xi + 2][r] - acc[4 * xi + 3][r];
+        }
+        ya[0][r] = (ra[0] + ra[1]) + ra[2];
+        yb[0][r] = (rb[0] + rb[1]) + rb[2];
+        ya[1][r] = (-ra[2] - ra[3]) + ra[1];
+        yb[1][r] = (-rb[2] - rb[3]) + rb[1];
+    }
+    const long long rowstep = (long long)a.W * a.Cout;
+#pragma unroll
+    for (int wp = 0; wp < 2; ++wp) {
+        unsigned vmask[16];
+        int rimg[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned fl = tsl[r][2];
+            unsigned vm = 0;
+            rimg[r] = -1;
+            if ((fl & 1u) && (wp == 0 || (fl & 4u))) {
+                const long long off = (long long)(((unsigned long long)tsl[r][1] << 32) | tsl[r][0]);
+                float* o = a.y + off + wp * rowstep + co;
+                o[0] = ya[wp][r]; vm = 1u;
+                if (fl & 2u) { o[a.Cout] = yb[wp][r]; vm |= 2u; }
+                rimg[r] = (int)(fl >> 8);
+            }
+            vmask[r] = vm;
+        }
+        for (int il = 0; il < a.IB; ++il) {
+            const int n = img0 + il;
+            if (n >= a.B) break;
+            float sum = 0.f, cnt = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned vm = (rimg[r] == il) ? vmask[r] : 0u;
+                sum += ((vm & 1u) ? ya[wp][r] : 0.f) + ((vm & 2u) ? yb[wp][r] : 0.f);
+                cnt += (float)__popc(vm);
+            }
+            sum += __shfl_xor(sum, 32, 64);
+            cnt += __shfl_xor(cnt, 32, 64);
+            const float mean = cnt > 0.f ? sum / cnt : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned vm = (rimg[r] == il) ? vmask[r] : 0u;
+                const float d0 = ya[wp][r] - mean, d1 = yb[wp][r] - mean;
+                q += ((vm & 1u) ? d0 * d0 : 0.f) + ((vm & 2u) ? d1 * d1 : 0.f);
+            }
+            q += __shfl_xor(q, 32, 64);
+            if (hi == 0) {
+                float* o = a.part + ((((long long)n * a.PB + pb) * 2 + wp) * a.Cout + co) * 3;
+                o[0] = cnt; o[1] = mean; o[2] = q;
+            }
+        }
+    }
+}

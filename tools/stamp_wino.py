@@ -6,7 +6,8 @@ k = which Winograd launch of the process records (1 = first conv of the first fo
 k_conv_wino_s3 (unit kernel; wave 0 = role 0, last wave = role 1; a step = one chunk): 0 top, 1 after the MFMAs, 2 after
 raw_write + raw_load, 3 after barrier 1, 4 after the transform, 5 after barrier 2.
 k_conv_wino_pp: multiply wave (role 0) slots: 0 step top, 1 after position 3, 2 after position 7, 3 after the barrier, 4 after the epilogue.
-Staging wave (role 1) slots: 0 top, 1 after the transform, 2 after raw_write, 3 after raw_load + statistics, 4 after the barrier."""
+Staging wave (role 1) slots: 0 top, 1 after the transform, 2 after raw_write, 3 after raw_load + statistics, 4 after the barrier.
+k_conv_wino_w1 (DSMIL_WINO_KERNEL=w1; waves 0 and 3): slot P = start of pair-block P of the chunk (8 blocks of 12 MFMAs)."""
 import _path  # noqa: F401  (repo root on sys.path)
 import ctypes
 import os
@@ -44,7 +45,7 @@ for wg in range(2):
         t = t[:n]
         step = np.diff(t[:, 0])
         print(f"wg {wg} {name}: steps {n}, step period median {np.median(step):.0f} mean {step.mean():.0f} ticks")
-        ns = 6 if (t[:, 5] > 0).any() else 5
+        ns = 8 if (t[:, 7] > 0).any() else 6 if (t[:, 5] > 0).any() else 5
         segs = np.diff(t[:, :ns], axis=1)
         print("   segment medians (slot k -> k+1):", np.median(segs, axis=0).astype(int).tolist())
         print("   first 24 step periods:", step[:24].tolist())
