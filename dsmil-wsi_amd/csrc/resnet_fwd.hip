@@ -1824,11 +1824,12 @@ inline bool wino_wide() {   // expt builds: DSMIL_WINO_NARROW=1 keeps the 64-cou
 #endif
 }
 #ifdef DSMIL_EXPERIMENTS
-// experiment builds: DSMIL_WINO_KERNEL = pp (persistent role-split k_conv_wino_pp) | alt (k_conv_wino_alt, 128-cout layers)
+// experiment builds: DSMIL_WINO_KERNEL = unit (k_conv_wino_s3 everywhere) | w1 (default: k_conv_wino_w1 on the 128-cout layers) |
+// pp (persistent role-split k_conv_wino_pp) | alt (k_conv_wino_alt, 128-cout layers)
 inline int wino_expt_kernel() {
     static const int k = [] {
         const char* e = getenv("DSMIL_WINO_KERNEL");
-        return (e && !strcmp(e, "pp")) ? 1 : (e && !strcmp(e, "alt")) ? 2 : (e && !strcmp(e, "w1")) ? 3 : 0;
+        return (e && !strcmp(e, "pp")) ? 1 : (e && !strcmp(e, "alt")) ? 2 : (e && !strcmp(e, "w1")) ? 3 : (e && !strcmp(e, "unit")) ? 4 : 0;
     }();
     return k;
 }
@@ -1836,10 +1837,9 @@ inline int wino_expt_kernel() {
 // which Winograd convs run on k_conv_wino_w1 (one wave per SIMD, tiled weights): the packing and the launch must agree
 inline bool use_w1(const ConvSpec& s) {
 #ifdef DSMIL_EXPERIMENTS
-    return wino_expt_kernel() == 3 && wino_s3() && s.cout % 128 == 0;
-#else
-    return false;
+    if (wino_expt_kernel() != 0 && wino_expt_kernel() != 3) return false;   // DSMIL_WINO_KERNEL = unit | pp | alt: the older kernels
 #endif
+    return wino_s3() && s.cout % 128 == 0;
 }
 #ifdef DSMIL_TRACE
 constexpr size_t WINO_TRACE_WORDS = 4 * 2 * 256 * 8;
@@ -2034,7 +2034,7 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
             };
             const int which = wino_expt_kernel();   // DSMIL_WINO_KERNEL = pp | alt | w1
             const int w1_abl = wa.expt;
-            if (which == 3) wa.expt = 0;            // with w1 selected the ablation bits address that kernel only
+            if (which == 3) wa.expt = 0;            // with w1 named explicitly the ablation bits address that kernel only
 #else
             constexpr int which = 0;
 #endif
@@ -2050,8 +2050,8 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
 #endif
             } else if (use_w1(s)) {
                 // one wave per SIMD: 256 threads, 128 couts, all 16 positions per wave (wino_w1.h)
-                const dim3 gridw(grid.x, (unsigned)(s.cout / 128));
-                const size_t lds_w1 = (size_t)(2 * SV_DW + WRAW_MAX * SRLD + 256 + 1024) * sizeof(float);
+                const dim3 gridw(grid.x * (unsigned)(s.cout / 128));   // 1-D: the kernel maps it to (unit, cout block) per XCD
+                const size_t lds_w1 = (size_t)(2 * SV_DW + 2 * WRAW_MAX * SRLD + 256 + 1024) * sizeof(float);
                 auto gow1 = [&](auto kern) {
                     allow_lds((const void*)kern, lds_w1);
                     hipLaunchKernelGGL(kern, gridw, dim3(256), lds_w1, st, wa);
@@ -2065,6 +2065,8 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
                         if (in_mean) { if (np9) gow1(k_conv_wino_w1<true, 9>); else gow1(k_conv_wino_w1<true, 6>); }
                         else { if (np9) gow1(k_conv_wino_w1<false, 9>); else gow1(k_conv_wino_w1<false, 6>); }
                 }
+#else
+                if (in_mean) gow1(k_conv_wino_w1<true, 6>); else gow1(k_conv_wino_w1<false, 6>);
 #endif
             } else if (s.cout % 128 == 0 && wino_wide()) {
                 // 128 couts per workgroup (512 threads, one workgroup per CU): half the staging work per MFMA

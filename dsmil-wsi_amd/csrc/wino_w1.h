@@ -12,15 +12,19 @@
 //
 // Unit: 32 tiles x 128 output channels (wave w owns channels 32w..32w+31 and all 16 positions: 16 x 6 = 96 MFMAs per
 // 16-channel chunk, consecutive MFMAs alternate between the two positions of a pair, so none waits for the one before).
-// LDS: V double-buffered 2 x 56 KB, raw 20 KB (+1 KB pad), producer statistics 4 KB = 137 KB: one workgroup per CU.
-// One chunk iteration = 8 pair-blocks of 12 MFMAs, straight-line code (no branch: the last iterations redo clamped work):
-//   block 0,1 : raw(c+1) registers -> IN + ReLU + padding -> LDS            (loaded during iteration c-1)
-//   block 2   : global loads of raw(c+2) and of its (mean, rstd); barrier A (raw(c+1) is in LDS)
-//   block 3-6 : transform(c+1), one xi row per block: raw window -> B^T d B -> three bf16 planes -> V[(c+1)&1]
-//   block 6   : statistics(c+2) -> LDS; barrier B (V[(c+1)&1] complete, raw free)
-//   block 7   : first V fragments of chunk c+1
-//   every block: weight fragments of the pair two blocks ahead (ring of 4 pair-sets, runs across chunks), V fragments of
-//   the next pair.
+// LDS: V double-buffered 2 x 56 KB, raw double-buffered 2 x 20 KB, producer statistics 4 KB, tile table 1 KB = 157 KB:
+// one workgroup per CU.
+// One wave per SIMD hides about FIVE other instructions behind each MFMA (MI355X_MICROARCH.md) — 480 per chunk, and the
+// chunk needs ~540 (48 weight loads, 48 V reads, the transform's 32 window reads, ~250 VALU ops of B^T d B and plane cuts,
+// 24 plane writes, the raw staging).  So the work of the chunks ahead is spread EVENLY over the chunk's 8 pair-blocks of 12
+// MFMAs, one piece behind each MFMA, straight-line code (no branch: the last iterations redo clamped work):
+//   block P       : half a transform row of chunk c+1 (xi = P/2, output X or Y): raw[(c+1)&1] -> planes -> V[(c+1)&1]
+//   blocks 4-7    : raw(c+2) registers -> IN + ReLU + padding -> raw[c&1], one float4 per block
+//                   (loaded in iteration c-1) and the load of the same float4 of raw(c+3) into the freed register
+//   block 0 / 6   : statistics(c+3) global -> register / register -> LDS
+//   block 7       : ONE barrier (V[(c+1)&1], raw[c&1], statistics complete); first V fragments of c+1
+//   every block   : weight fragments of the pair two blocks ahead (ring of 4 pair-sets, runs across chunks), V fragments of
+//                   the next pair.
 // The inverse transform needs no exchange: a lane holds all sixteen positions of its (tile, channel) in registers.
 // ABL (experiment builds; timing only, wrong results): 1 no transform, 2 no raw staging, 4 weight fragments loaded once,
 // 8 V fragments read once, 16 no MFMAs.
@@ -38,15 +42,26 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
     constexpr int R_DW = WRAW_MAX * SRLD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned* sV = reinterpret_cast<unsigned*>(smem);   // [2][SV_DW]
-    float* sR = smem + 2 * SV_DW;                       // [WRAW_MAX][SRLD] + 256 floats that unused staging slots write to
-    float* sS = sR + R_DW + 256;                        // [2 buffers][16 images][2 (mean, rstd)][16 ch]
-    unsigned* sT = reinterpret_cast<unsigned*>(sR + R_DW);   // [32 tile slots][4]: output offset (lo, hi), flags, -
+    float* sR = smem + 2 * SV_DW;                       // [2][WRAW_MAX][SRLD]
+    float* sS = sR + 2 * R_DW + 256;                    // [2 buffers][16 images][2 (mean, rstd)][16 ch]
+    unsigned* sT = reinterpret_cast<unsigned*>(sR + 2 * R_DW);   // [32 tile slots][4]: output offset (lo, hi), flags, -
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int n0 = blockIdx.y * 128;
+    // 1-D grid over (unit, 128-cout block).  Workgroup L runs on XCD L % 8 (dispatch order; used for speed only): all the
+    // workgroups of an XCD take the SAME cout block(s), so its 4 MiB L2 holds one block's weights (the 3.1-6.3 MB slices of
+    // layers 3-4), not all of them.  CB cout blocks, G = 8 / CB XCDs per block.
+    const int CB = a.Cout >> 7;
+    int bid, cbk;
+    {
+        const int L = blockIdx.x, total = gridDim.x;
+        if ((CB == 2 || CB == 4) && (total & 7) == 0) { cbk = (L & 7) % CB; bid = (L >> 3) * (8 / CB) + (L & 7) / CB; }
+        else { cbk = L % CB; bid = L / CB; }
+    }
+    const int n0 = cbk * 128;
     const int nchunks = a.C / SK;
-    int bid = blockIdx.x;
+    const int bid_u = bid;   // unit number (trace builds)
+    (void)bid_u;
     const int bx = bid % a.nbx; bid /= a.nbx;
     const int by = bid % a.nby; bid /= a.nby;
     const int img0 = bid * a.IB;
@@ -94,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
             rreg[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.x + cc * SK) + off_b);
         }
     };
-    auto raw_write_q = [&](int cc, int q) {   // producer's IN + ReLU and the zero padding, once per staged pixel
+    auto raw_write_q = [&](int cc, int q) {   // producer's IN + ReLU and the zero padding, once per staged pixel -> raw[cc & 1]
         f32x4 x = rreg[q];
         const bool ok = roff[q] >= 0;
         if constexpr (NORM) {
@@ -105,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[e] = ok ? x[e] : 0.f;
-        *reinterpret_cast<f32x4*>(sR + rlds0 + q * (64 * SRLD)) = x;
+        *reinterpret_cast<f32x4*>(sR + (cc & 1) * R_DW + rlds0 + q * (64 * SRLD)) = x;
     };
     // ---- transform role (as the 256-thread k_conv_wino_s3): channel group g, tile slot ts, column half h (wave-uniform)
     const int g = tid & 3, ts = ((lane >> 5) & 1) | (((lane >> 2) & 7) << 1) | ((wave & 1) << 4);
@@ -119,8 +134,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
     const float sz = h ? -1.f : 1.f;
     const int zcol = (h ? 0 : 2) * SRLD;
     const int nuX = h ? 3 : 0, nuY = h ? 2 : 1;
-    const float* rwin = sR + praw;
-    auto tr_xi = [&](int xi, unsigned* vdst) {
+    auto tr_xi = [&](int xi, const float* rwin, unsigned* vdst) {   // prologue form: one whole row, unpipelined
         // (B^T d) row xi = Ra +- Rb:  xi 0: R0 - R2,  1: R1 + R2,  2: R2 - R1,  3: R1 - R3
         const int ra = xi == 0 ? 0 : xi == 2 ? 2 : 1, rb = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
         const float* pa = rwin + ra * RW * SRLD;
@@ -191,9 +205,26 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    // ---- prologue: raw(0) -> LDS -> V[0]; raw(1) in registers, its statistics in LDS; weight pairs 0, 1; V pair 0
+    // ---- prologue: raw(0) -> raw[0] -> V[0]; raw(1) -> raw[1]; raw(2) in registers; statistics(2) in LDS; weight pairs 0, 1;
+    //      the epilogue's tile table; V pair 0.  Every global load of the three chunks goes out FIRST (one memory round
+    //      trip, not three: nothing hides the prologue of the only workgroup on a CU).
+    const int cl1 = 1 < nchunks ? 1 : nchunks - 1, cl2 = 2 < nchunks ? 2 : nchunks - 1;
+    f32x4 rr1[RPT], rr2[RPT], sr1 = {0.f, 0.f, 0.f, 0.f}, sr2 = {0.f, 0.f, 0.f, 0.f};
     raw_load(0);
     stat_load(0);
+    {
+        const f32x4 s0 = sreg;
+        f32x4 keep[RPT];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) keep[q] = rreg[q];
+        raw_load(cl1); stat_load(cl1); sr1 = sreg;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) rr1[q] = rreg[q];
+        raw_load(cl2); stat_load(cl2); sr2 = sreg;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) { rr2[q] = rreg[q]; rreg[q] = keep[q]; }
+        sreg = s0;
+    }
     uload_pair(0, 0, uw[0]);
     uload_pair(1, 0, uw[1]);
     if (tid < 32) {
@@ -210,34 +241,42 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
         sT[slot * 4 + 1] = (unsigned)(off >> 32);
         sT[slot * 4 + 2] = fl;
     }
-    stat_write(0);
+    stat_write(0);                                       // statistics(0) -> sS[0]
+    sreg = sr1;
+    stat_write(1);                                       // statistics(1) -> sS[1]
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int q = 0; q < RPT; ++q) raw_write_q(0, q);
-    raw_load(1 < nchunks ? 1 : 0);
-    stat_load(1 < nchunks ? 1 : 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int xi = 0; xi < 4; ++xi) tr_xi(xi, sV);
-    stat_write(1);
+    for (int q = 0; q < RPT; ++q) rreg[q] = rr1[q];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) raw_write_q(1, q);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) rreg[q] = rr2[q];      // raw(2): staged by blocks 4-7 of iteration 0
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // raw[0], raw[1] complete; every read of sS[0] is done
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) tr_xi(xi, sR + praw, sV);
+    sreg = sr2;
+    stat_write(2);                                       // statistics(2) -> sS[0]
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     vread_pair(0, 0, vq[0]);
 
     for (int cc = 0; cc < nchunks; ++cc) {
-        const int c1 = cc + 1 < nchunks ? cc + 1 : nchunks - 1;   // clamped: the last iterations redo work nobody reads
-        const int c2 = cc + 2 < nchunks ? cc + 2 : nchunks - 1;
+        const int c3 = cc + 3 < nchunks ? cc + 3 : nchunks - 1;   // clamped: the last iterations redo work nobody reads
         const int buf = cc & 1;
         unsigned* vnext = sV + (buf ^ 1) * SV_DW;
-        // One pair-block = 2 NP MFMAs; behind each MFMA one PIECE of the other work, pinned there by sched_barrier (left to
-        // itself — or to sched_group_barrier patterns — hipcc issues the MFMAs back to back and the VALU work in 60-100
-        // instruction clumps: the pipe idles for the length of every clump).  A piece is at most ~8 VALU ops, the length of
-        // one MFMA's shadow.
+        const float* rwin = sR + (buf ^ 1) * R_DW + praw;        // raw[(cc+1) & 1]
 #ifdef DSMIL_TRACE
         unsigned long long stamp[8];
 #endif
+        // One pair-block = 2 NP MFMAs; behind each MFMA one PIECE of the other work, pinned there by sched_barrier (left to
+        // itself — or to sched_group_barrier patterns — hipcc issues the MFMAs back to back and the VALU work in 60-100
+        // instruction clumps: the pipe idles for the length of every clump).  Pieces are ~4 VALU ops; the plane cut runs
+        // stage by stage over the four elements of an output (and x4, sub x4, ...: as one chain per element every op
+        // waits for the one before).
         auto block = [&](auto Pc) {
             constexpr int P = decltype(Pc)::value;
 #ifdef DSMIL_TRACE
@@ -246,96 +285,100 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
             Frag (&va)[2][3] = vq[P & 1];
             Frag (&wb)[2][3] = uw[P & 3];
             constexpr int PV9[9] = {2, 1, 2, 2, 0, 1, 1, 0, 0}, PW9[9] = {2, 2, 1, 0, 2, 1, 0, 1, 0};
-            constexpr bool TR = P >= 3 && P <= 6;           // transform block: xi = P - 3
-            constexpr int xi = TR ? P - 3 : 0;
+            // half a transform row: xi = P / 2; outputs X = T0 - T2 (even blocks) or Y = T1 + sz Tz (odd blocks),
+            // T_c = (B^T d)[xi][c] = Ra[c] +- Rb[c]:  xi 0: R0 - R2,  1: R1 + R2,  2: R2 - R1,  3: R1 - R3
+            constexpr int xi = P >> 1;
+            constexpr bool isY = P & 1;
             constexpr int ra = xi == 0 ? 0 : xi == 2 ? 2 : 1, rb = xi == 0 ? 2 : xi == 1 ? 2 : xi == 2 ? 1 : 3;
-            f32x4 wA[4], wB[4], T[4], X, Y;                 // window rows (columns 0, 1, 2, z), (B^T d) row, the two outputs
-            u32x2_t ph, pm, pl;
-            f32x4 q0, q1;                                   // raw pixels on their way to LDS
-            f32x4 mu0, rs0, mu1, rs1;
-            auto cut2 = [&](float x0, float x1, int i) {    // two elements -> one packed dword per plane
-                const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-                const float r10 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r11 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
-                const unsigned v0 = __float_as_uint(r10), v1 = __float_as_uint(r11);
-                const unsigned w0 = __float_as_uint(r10 - __uint_as_float(v0 & 0xFFFF0000u));
-                const unsigned w1 = __float_as_uint(r11 - __uint_as_float(v1 & 0xFFFF0000u));
-                ph[i] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-                pm[i] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-                pl[i] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
-            };
-            auto put = [&](int nu) {
-                unsigned* d = vnext + ((xi * 4 + nu) * WTT + ts) * SVLD + g * 2;
-                *reinterpret_cast<u32x2_t*>(d) = ph;
-                *reinterpret_cast<u32x2_t*>(d + 8) = pm;
-                *reinterpret_cast<u32x2_t*>(d + 16) = pl;
-            };
-            auto norm = [&](f32x4& x, const f32x4& mu, const f32x4& rs) {
-                if constexpr (NORM) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = fmaxf((x[e] - mu[e]) * rs[e], 0.f);
-                }
-            };
-            auto mask_put = [&](f32x4 x, int q) {
-                const bool ok = roff[q] >= 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = ok ? x[e] : 0.f;
-                *reinterpret_cast<f32x4*>(sR + rlds0 + q * (64 * SRLD)) = x;
-            };
+            f32x4 wA0, wB0, wA1, wB1, Ta, Tb, O;           // window rows of the two columns, their row transforms, the output
+            unsigned u_[4], r1_[4], r2_[4];                // plane cut, stage by stage
+            f32x4 qx, mu, rs;                              // a raw float4 on its way to LDS
             auto step = [&](auto Ic) {
                 constexpr int I = decltype(Ic)::value;
                 constexpr int k = 9 - NP + I / 2, j = I & 1;
                 if constexpr (!(ABL & 16))
                     acc[2 * P + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[j][PV9[k]].v, wb[j][PW9[k]].v, acc[2 * P + j], 0, 0, 0);
                 else asm volatile("" ::"v"(va[j][PV9[k]].u), "v"(wb[j][PW9[k]].u));
-                // every block: weight fragments of the pair two blocks ahead, V fragments of the next pair (block 7: pair 0
-                // of the next chunk, behind barrier B)
+                // every block: weight fragments of the pair two blocks ahead; V fragments of the next pair in two halves
                 if constexpr (I == 0 && !(ABL & 4)) uload_pair((P + 2) & 7, cc + ((P + 2) >> 3), uw[(P + 2) & 3]);
-                if constexpr (I == 2 * NP - 5 && !(ABL & 8)) {
-                    if constexpr (P < 7) vread_pair(P + 1, buf, vq[(P + 1) & 1]);
-                    else vread_pair(0, buf ^ 1, vq[(P + 1) & 1]);
+                if constexpr ((I == 8 || I == 9) && !(ABL & 8) && P < 7) {
+                    const unsigned* b = sV + buf * SV_DW + vfo + (2 * (P + 1) + (I - 8)) * WTT * SVLD;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) vq[(P + 1) & 1][I - 8][pl].u = *reinterpret_cast<const u32x4_t*>(b + pl * 8);
                 }
-                if constexpr (P <= 1 && !(ABL & 2)) {       // raw(c1): registers -> IN + ReLU + padding -> LDS, two per block
-                    constexpr int qa = 2 * P, qb = 2 * P + 1;
-                    if constexpr (I == 2 && NORM) {
-                        mu0 = *reinterpret_cast<const f32x4*>(sS + (c1 & 1) * 512 + rsto[qa]);
-                        rs0 = *reinterpret_cast<const f32x4*>(sS + (c1 & 1) * 512 + rsto[qa] + 16);
-                        mu1 = *reinterpret_cast<const f32x4*>(sS + (c1 & 1) * 512 + rsto[qb]);
-                        rs1 = *reinterpret_cast<const f32x4*>(sS + (c1 & 1) * 512 + rsto[qb] + 16);
-                    }
-                    if constexpr (I == 4) { q0 = rreg[qa]; norm(q0, mu0, rs0); }
-                    if constexpr (I == 6) mask_put(q0, qa);
-                    if constexpr (I == 7) { q1 = rreg[qb]; norm(q1, mu1, rs1); }
-                    if constexpr (I == 9) mask_put(q1, qb);
-                }
-                if constexpr (P == 2 && !(ABL & 2)) {
-                    if constexpr (I == 2) raw_load(c2);
-                    if constexpr (I == 3) stat_load(c2);
-                }
-                if constexpr (TR && !(ABL & 1)) {           // transform(c1), row xi: window -> B^T d B -> planes -> V[next]
-                    if constexpr (I == 2) {
+                if constexpr (!(ABL & 1)) {                 // transform(c+1), half row
+                    if constexpr (I == 1) {
                         const float* pa = rwin + ra * RW * SRLD;
                         const float* pb_ = rwin + rb * RW * SRLD;
+                        const int c0 = isY ? SRLD : 0, c1 = isY ? zcol : 2 * SRLD;   // Y: columns 1 and z; X: columns 0 and 2
+                        wA0 = *reinterpret_cast<const f32x4*>(pa + c0);
+                        wB0 = *reinterpret_cast<const f32x4*>(pb_ + c0);
+                        wA1 = *reinterpret_cast<const f32x4*>(pa + c1);
+                        wB1 = *reinterpret_cast<const f32x4*>(pb_ + c1);
+                    }
+                    if constexpr (I == 3) Ta = xi == 1 ? w1_add4(wA0, wB0) : w1_sub4(wA0, wB0);
+                    if constexpr (I == 4) Tb = xi == 1 ? w1_add4(wA1, wB1) : w1_sub4(wA1, wB1);
+                    if constexpr (I == 5) {
+                        if constexpr (!isY) O = w1_sub4(Ta, Tb);
+                        else {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            wA[c] = *reinterpret_cast<const f32x4*>(pa + c * SRLD);
-                            wB[c] = *reinterpret_cast<const f32x4*>(pb_ + c * SRLD);
+                            for (int e = 0; e < 4; ++e) O[e] = __builtin_fmaf(sz, Tb[e], Ta[e]);
                         }
-                        wA[3] = *reinterpret_cast<const f32x4*>(pa + zcol);
-                        wB[3] = *reinterpret_cast<const f32x4*>(pb_ + zcol);
                     }
-                    if constexpr (I == 4) { T[0] = xi == 1 ? w1_add4(wA[0], wB[0]) : w1_sub4(wA[0], wB[0]); T[1] = xi == 1 ? w1_add4(wA[1], wB[1]) : w1_sub4(wA[1], wB[1]); }
-                    if constexpr (I == 5) { T[2] = xi == 1 ? w1_add4(wA[2], wB[2]) : w1_sub4(wA[2], wB[2]); T[3] = xi == 1 ? w1_add4(wA[3], wB[3]) : w1_sub4(wA[3], wB[3]); }
                     if constexpr (I == 6) {
-                        X = w1_sub4(T[0], T[2]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) Y[e] = __builtin_fmaf(sz, T[3][e], T[1][e]);
+                        for (int e = 0; e < 4; ++e) { u_[e] = __float_as_uint(O[e]); r1_[e] = __float_as_uint(O[e] - __uint_as_float(u_[e] & 0xFFFF0000u)); }
                     }
-                    if constexpr (I == 7) cut2(X[0], X[1], 0);
-                    if constexpr (I == 8) { cut2(X[2], X[3], 1); put(nuX); }
-                    if constexpr (I == 9) cut2(Y[0], Y[1], 0);
-                    if constexpr (I == 10) { cut2(Y[2], Y[3], 1); put(nuY); }
+                    if constexpr (I == 7) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r2_[e] = __float_as_uint(__uint_as_float(r1_[e]) - __uint_as_float(r1_[e] & 0xFFFF0000u));
+                    }
+                    if constexpr (I == 10) {
+                        u32x2_t ph, pm, pl;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            ph[i] = __builtin_amdgcn_perm(u_[2 * i + 1], u_[2 * i], 0x07060302u);
+                            pm[i] = __builtin_amdgcn_perm(r1_[2 * i + 1], r1_[2 * i], 0x07060302u);
+                            pl[i] = __builtin_amdgcn_perm(r2_[2 * i + 1], r2_[2 * i], 0x07060302u);
+                        }
+                        unsigned* d = vnext + ((xi * 4 + (isY ? nuY : nuX)) * WTT + ts) * SVLD + g * 2;
+                        *reinterpret_cast<u32x2_t*>(d) = ph;
+                        *reinterpret_cast<u32x2_t*>(d + 8) = pm;
+                        *reinterpret_cast<u32x2_t*>(d + 16) = pl;
+                    }
                 }
-                if constexpr (P == 6 && I == 11) stat_write(cc + 2);
+                if constexpr (P >= 4 && !(ABL & 2)) {       // raw(c+2): float4 q = P - 4 -> IN + ReLU + padding -> raw[c & 1]
+                    constexpr int q = P - 4;
+                    if constexpr (I == 2 && NORM) {
+                        mu = *reinterpret_cast<const f32x4*>(sS + buf * 512 + rsto[q]);
+                        rs = *reinterpret_cast<const f32x4*>(sS + buf * 512 + rsto[q] + 16);
+                    }
+                    if constexpr (I == 8) {
+                        qx = rreg[q];
+                        if constexpr (NORM) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) qx[e] = (qx[e] - mu[e]) * rs[e];
+                        }
+                    }
+                    if constexpr (I == 9) {
+                        const bool ok = roff[q] >= 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) qx[e] = ok ? (NORM ? fmaxf(qx[e], 0.f) : qx[e]) : 0.f;
+                        *reinterpret_cast<f32x4*>(sR + buf * R_DW + rlds0 + q * (64 * SRLD)) = qx;
+                    }
+                    if constexpr (I == 11) {                // the register is free: the same float4 of raw(c+3), used 8 blocks on
+                        const unsigned off_b = roff[q] < 0 ? 0u : (unsigned)roff[q] * 4u;
+                        rreg[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.x + c3 * SK) + off_b);
+                    }
+                }
+                if constexpr (P == 0 && I == 2 && !(ABL & 2)) stat_load(c3);         // six blocks before it is written to LDS
+                if constexpr (P == 6 && I == 11 && !(ABL & 2)) stat_write(cc + 3);
+                if constexpr (P == 7 && I == 10) {          // everything the next chunk reads is in LDS (or about to be waited for)
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    vread_pair(0, buf ^ 1, vq[(P + 1) & 1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             };
             step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
@@ -349,10 +392,6 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
                 step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
                 step(std::integral_constant<int, 16>{}); step(std::integral_constant<int, 17>{});
             }
-            if constexpr (P == 2 || P == 6) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
         };
         block(std::integral_constant<int, 0>{});
         block(std::integral_constant<int, 1>{});
@@ -363,9 +402,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
         block(std::integral_constant<int, 6>{});
         block(std::integral_constant<int, 7>{});
 #ifdef DSMIL_TRACE
-        if (a.trace && blockIdx.x < 4 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 3) && cc < 256) {
+        if (a.trace && bid_u < 4 && n0 == 0 && lane == 0 && (wave == 0 || wave == 3) && cc < 256) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) a.trace[(((long long)blockIdx.x * 2 + (wave != 0)) * 256 + cc) * 8 + i] = stamp[i];
+            for (int i = 0; i < 8; ++i) a.trace[(((long long)bid_u * 2 + (wave != 0)) * 256 + cc) * 8 + i] = stamp[i];
         }
 #endif
     }

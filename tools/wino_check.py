@@ -2,7 +2,9 @@
 """Same-box check of a Winograd kernel variant of the experiment library against the product kernel: the features of a few
 seeded batches are computed in two subprocesses (the knobs are read once per process) and compared bit for bit, then the
 embedder leg of bench.py is timed both ways.
-Usage (GPU box): DSMIL_NATIVE_LIB=libdsmil_hip_expt.so python tools/wino_check.py [K=V ...]   (default DSMIL_WINO_KERNEL=w1)"""
+Usage (GPU box): DSMIL_NATIVE_LIB=libdsmil_hip_expt.so python tools/wino_check.py [K=V ...]
+base = DSMIL_WINO_KERNEL=unit (k_conv_wino_s3 everywhere); variant = the library's default (k_conv_wino_w1 on the 128-cout
+layers) plus the given knobs."""
 import os
 import subprocess
 import sys
@@ -37,10 +39,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "run":
         run(sys.argv[2])
         sys.exit(0)
-    knobs = dict(a.split("=", 1) for a in sys.argv[1:]) or {"DSMIL_WINO_KERNEL": "w1"}
+    knobs = dict(a.split("=", 1) for a in sys.argv[1:])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     outs = []
-    for tag, env in (("base", {}), ("var", knobs)):
+    for tag, env in (("base", {"DSMIL_WINO_KERNEL": "unit"}), ("var", knobs)):
         e = dict(os.environ)
         e.update(env)
         o = os.path.join(ROOT, "gpurun_out", f"wino_check_{tag}.npy")
@@ -53,4 +55,4 @@ if __name__ == "__main__":
     print("features:", a.shape, "finite", bool(np.isfinite(b).all()), "bit-identical", bool(np.array_equal(a, b)),
           "max abs diff %.3e" % float(np.abs(a - b).max()), "max |base| %.3f" % float(np.abs(a).max()), flush=True)
     spec = ",".join(f"{k}={v}" for k, v in knobs.items())
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variants.py"), "embedder", "base:", "var:" + spec])
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variants.py"), "embedder", "base:DSMIL_WINO_KERNEL=unit", "var:" + spec])
