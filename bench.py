@@ -510,8 +510,8 @@ def embedder_leg(cx):
                        "parity": "unpinned: the reference's backbone is torchvision's resnet18 (absent from the reference tree and "
                                  "this image) and it ships no embedder vectors; checked against two independent restatements",
                        "collective": "all_gather_into_tensor([%d,512] f32) per pass, %d rank(s)" % (Bp, world) if cx.collectives else "none"},
-            "roofline": {"kernel": "conv kernels of one forward: 13 x k_conv_wino_s3 (Winograd F(2x2,3x3), bf16 MFMA over exact "
-                                   "3-plane cuts) + 6 direct convs", "bound": "mfma",
+            "roofline": {"kernel": "conv kernels of one forward: 9 x k_conv_wino_w1 + 4 x k_conv_wino_s3 (Winograd F(2x2,3x3), bf16 "
+                                   "MFMA over exact 3-plane cuts) + 6 direct convs", "bound": "mfma",
                          # algorithmic (direct-form) rate of the conv kernels; NOT compared with a peak: Winograd does
                          # 2.25x fewer multiplies than the direct form, so this rate may exceed the f32 MFMA peak
                          "achieved": round(ach, 2) if ach else None, "unit": "TFLOP/s",

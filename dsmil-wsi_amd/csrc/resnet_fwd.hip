@@ -2059,7 +2059,7 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
 #ifdef DSMIL_EXPERIMENTS
                 switch (w1_abl) {   // DSMIL_WINO_EXPT: compile-time ablations of the w1 kernel (timing only)
 #define W1_ABL(n) case n: if (in_mean) gow1(k_conv_wino_w1<true, 6, n>); else gow1(k_conv_wino_w1<false, 6, n>); break;
-                    W1_ABL(1) W1_ABL(2) W1_ABL(3) W1_ABL(4) W1_ABL(8) W1_ABL(12) W1_ABL(15) W1_ABL(16) W1_ABL(19)
+                    W1_ABL(3) W1_ABL(4) W1_ABL(15) W1_ABL(16) W1_ABL(32) W1_ABL(64) W1_ABL(96) W1_ABL(128) W1_ABL(143)
 #undef W1_ABL
                     default:
                         if (in_mean) { if (np9) gow1(k_conv_wino_w1<true, 9>); else gow1(k_conv_wino_w1<true, 6>); }
