@@ -199,6 +199,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
             for (int pl = 0; pl < 3; ++pl) v[j][pl].u = *reinterpret_cast<const u32x4_t*>(b + j * WTT * SVLD + pl * 8);
     };
 
+#ifdef DSMIL_TRACE
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
     f32x16 acc[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p)
@@ -264,6 +267,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
     __builtin_amdgcn_s_barrier();
     vread_pair(0, 0, vq[0]);
 
+#ifdef DSMIL_TRACE
+    const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
     for (int cc = 0; cc < nchunks; ++cc) {
         const int c3 = cc + 3 < nchunks ? cc + 3 : nchunks - 1;   // clamped: the last iterations redo work nobody reads
         const int buf = cc & 1;
@@ -418,6 +424,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
         if (keep == 123.456f) a.y[0] = keep;
         return;
     }
+#ifdef DSMIL_TRACE
+    const unsigned long long t_epi = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue: inverse transform in registers (the arithmetic order of wino_epilogue, so the outputs are bit-identical
     // to k_conv_wino_s3), raw NHWC store, (cnt, mean, M2) statistics partials per output-row parity
     const int co = n0 + wave * 32 + l31;
@@ -485,4 +494,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
             }
         }
     }
+#ifdef DSMIL_TRACE
+    // slot 255 of the trace: kernel start, loop start, epilogue start, end (per workgroup 0-3, waves 0 and 3)
+    if (a.trace && bid_u < 4 && n0 == 0 && lane == 0 && (wave == 0 || wave == 3)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* t = a.trace + (((long long)bid_u * 2 + (wave != 0)) * 256 + 255) * 8;
+        t[0] = t_start; t[1] = t_loop; t[2] = t_epi; t[3] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 }

@@ -29,3 +29,26 @@ def test_alternative_mfma_forms(env, form):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("FORM-OK")]
     assert line and int(line[0].split()[1]) == form
+
+
+def test_one_wave_winograd_unit_is_bit_identical_to_the_two_wave_unit(tmp_path):
+    """k_conv_wino_w1 (one wave per SIMD, tiled weights, layers with Cout % 128 == 0; the product default) computes exactly
+    what k_conv_wino_s3 computes — same plane cuts, product order and inverse-transform order — so the features of the
+    same inputs must agree BIT FOR BIT between the default and DSMIL_WINO_KERNEL=unit (experiment build), incl. odd sizes
+    and batch sizes that leave partial units."""
+    import numpy as np
+    lib = os.path.join(os.path.dirname(HERE), "dsmil-wsi_amd", "libdsmil_hip_expt.so")
+    assert os.path.exists(lib), "python dsmil-wsi_amd/build.py --variant expt -DDSMIL_EXPERIMENTS (done by __graft_entry__.build())"
+    tool = os.path.join(os.path.dirname(HERE), "tools", "wino_check.py")
+    outs = []
+    for tag, env in (("unit", {"DSMIL_WINO_KERNEL": "unit"}), ("w1", {})):
+        e = dict(os.environ)
+        e.pop("DSMIL_WINO_KERNEL", None)
+        e.update(env)
+        e["DSMIL_NATIVE_LIB"] = "libdsmil_hip_expt.so"
+        o = str(tmp_path / f"{tag}.npy")
+        r = subprocess.run([sys.executable, tool, "run", o], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        outs.append(np.load(o))
+    assert np.isfinite(outs[1]).all()
+    assert np.array_equal(outs[0], outs[1]), float(np.abs(outs[0] - outs[1]).max())
