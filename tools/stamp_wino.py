@@ -36,6 +36,13 @@ f.restype = ctypes.c_int
 rc = f(buf, W)
 assert rc == 0, rc
 T = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(4, 2, 256, 8)
+if (T[:, :, 255, 3] > 0).any():   # k_conv_wino_w1: slot 255 = kernel start, loop start, epilogue start, end
+    for wg in range(4):
+        for role in range(2):
+            t = T[wg, role, 255]
+            if t[3] > 0:
+                print(f"wg {wg} wave {'0' if role == 0 else 'last'}: prologue {t[1] - t[0]}, chunk loop {t[2] - t[1]}, epilogue {t[3] - t[2]} ticks")
+    T[:, :, 255, :] = 0
 for wg in range(2):
     for role, name in ((0, "multiply"), (1, "staging")):
         t = T[wg, role]
