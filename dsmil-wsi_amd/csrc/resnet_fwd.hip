@@ -1402,6 +1402,7 @@ __global__ __launch_bounds__(256) void k_stem(const void* __restrict__ xin, cons
     }
 }
 
+
 // ---------------------------------------------------------------------------------------------
 // k_stem_s6: the same 7x7 stride-2 conv on bf16 MFMA over exact three-plane cuts (6 plane products, see agg_split.h).
 // K is laid out (c, kh, kw padded to 8): 21 rows of 8 = 168, padded to 176 = 11 steps of 16, so the 8 k of a lane are
@@ -1443,17 +1444,28 @@ __host__ __device__ constexpr int stem6_off(int row) {      // window element of
     return row >= 21 ? 0 : (row / 7) * SS_PLANE + (row % 7) * SS_LW;
 }
 
-template <bool U8>
+// POOL: the 3x3 stride-2 max-pool is taken HERE, on the raw conv values while they are in registers (max commutes with the
+// increasing map IN + ReLU, as in k_norm_relu_maxpool): the kernel writes the pooled raw map [B,Hp,Wp,64] (4x smaller than
+// the 822 MB raw stem output it replaces) plus the last conv row of every tile row (`halo`, [B][tiles_y][Wo][64]) — the one
+// row a tile's first pool row needs from the tile above; k_pool_fix_norm folds it in and normalises.  A wave holds two conv
+// rows of the tile = pool row `wave`'s centre and lower row; its upper row is the second row of the wave above (through
+// LDS, 32 KB); columns: a lane holds 8 of the 16 (two groups of 4), the 3-wide stride-2 windows need one value from the
+// other half-wave (two shuffles) and, at the left edge, the last column of the previous tile of the walk (a carried register).
+constexpr size_t SS_POOL_LDS = (size_t)8 * 16 * 64 * 4;
+template <bool U8, bool POOL = false>
 __global__ __launch_bounds__(512, 2) void k_stem_s6(const void* __restrict__ xin, const unsigned short* __restrict__ wimg,
                                                     float* __restrict__ y, float* __restrict__ part, int B, int H, int W,
-                                                    int Ho, int Wo, int tiles_x, int tiles_y) {
+                                                    int Ho, int Wo, int tiles_x, int tiles_y,
+                                                    float* __restrict__ halo = nullptr, int Hp = 0, int Wp = 0) {
     const float* x = reinterpret_cast<const float*>(xin);
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(xin);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short* sIn = reinterpret_cast<unsigned short*>(smem);         // [2][3 planes][SS_WIN]
     unsigned short* sW = sIn + 2 * 3 * SS_WIN;                              // [3][64][SS_LDW]
+    float* sE = reinterpret_cast<float*>(sW + SS_WIMG);                     // POOL: [8 waves][16 cols][64 ch] second conv rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int ty = blockIdx.x, n = blockIdx.y;
+    float carry[2] = {-INFINITY, -INFINITY};                                // POOL: column-max of the previous tile's last column
     const int oy0 = ty * SS_TR;
     const int iy00 = oy0 * 2 - 3;
     // per-thread window pairs (two adjacent columns of one row): row base offset in x (or -1) and the first column
@@ -1553,9 +1565,11 @@ __global__ __launch_bounds__(512, 2) void k_stem_s6(const void* __restrict__ xin
             const int oy = oy0 + 2 * wave + (q >> 4), ox = ox0 + (q & 15);
             okr[r] = (oy < Ho) && (ox < Wo);
             if (okr[r]) {
-                float* o = y + (((long long)n * Ho + oy) * Wo + ox) * 64;
-                o[l31] = acc[0][r];
-                o[32 + l31] = acc[1][r];
+                if constexpr (!POOL) {
+                    float* o = y + (((long long)n * Ho + oy) * Wo + ox) * 64;
+                    o[l31] = acc[0][r];
+                    o[32 + l31] = acc[1][r];
+                }
                 s0 += acc[0][r];
                 s1 += acc[1][r];
                 ++cnt;
@@ -1581,7 +1595,89 @@ __global__ __launch_bounds__(512, 2) void k_stem_s6(const void* __restrict__ xin
             o[l31 * 3 + 0] = fc; o[l31 * 3 + 1] = m0; o[l31 * 3 + 2] = q0;
             o[(32 + l31) * 3 + 0] = fc; o[(32 + l31) * 3 + 1] = m1; o[(32 + l31) * 3 + 2] = q1;
         }
+        if constexpr (POOL) {
+            // register k (0..7) of a lane = column 4 hi + k (k < 4) or 8 + 4 hi + (k - 4); registers k and k + 8 are the two rows
+            float v[2][8], low[2][8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float r0 = okr[k] ? acc[t][k] : -INFINITY;
+                    low[t][k] = okr[k + 8] ? acc[t][k + 8] : -INFINITY;
+                    v[t][k] = fmaxf(r0, low[t][k]);
+                    const int col = (k < 4 ? 4 * hi + k : 8 + 4 * hi + (k - 4));
+                    sE[(wave * 16 + col) * 64 + t * 32 + l31] = low[t][k];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (wave > 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int col = (k < 4 ? 4 * hi + k : 8 + 4 * hi + (k - 4));
+                        v[t][k] = fmaxf(v[t][k], sE[((wave - 1) * 16 + col) * 64 + t * 32 + l31]);
+                    }
+                }
+                // pool columns: hi = 0 lanes form 0, 1, 4, 5; hi = 1 lanes 2, 3, 6, 7 (windows 2i-1 .. 2i+1)
+                const float t3 = __shfl_xor(v[t][3], 32, 64), t7 = __shfl_xor(v[t][7], 32, 64);
+                const float X = hi ? t3 : carry[t], Y = hi ? t7 : t3;
+                float o4[4];
+                o4[0] = fmaxf(fmaxf(X, v[t][0]), v[t][1]);
+                o4[1] = fmaxf(fmaxf(v[t][1], v[t][2]), v[t][3]);
+                o4[2] = fmaxf(fmaxf(Y, v[t][4]), v[t][5]);
+                o4[3] = fmaxf(fmaxf(v[t][5], v[t][6]), v[t][7]);
+                carry[t] = t7;                                            // (hi = 0 lanes: column 15 of this tile)
+                const int py = (oy0 >> 1) + wave;
+                if (py < Hp) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int px = (ox0 >> 1) + 2 * hi + (j & 1) + 4 * (j >> 1);
+                        if (px < Wp) y[(((long long)n * Hp + py) * Wp + px) * 64 + t * 32 + l31] = o4[j];
+                    }
+                }
+                if (wave == 7 && ty + 1 < tiles_y) {                      // the row the tile below needs above its first pool row
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int ox = ox0 + (k < 4 ? 4 * hi + k : 8 + 4 * hi + (k - 4));
+                        if (ox < Wo) halo[(((long long)n * tiles_y + ty) * Wo + ox) * 64 + t * 32 + l31] = low[t][k];
+                    }
+                }
+            }
+        }
         __syncthreads();
+    }
+}
+
+// POOL path, second half: fold the row from the tile above into the first pool row of every tile row, then IN + ReLU
+// (in place on the pooled raw map; the same arithmetic as k_norm_relu_maxpool for r > 0, so the result is bit-identical)
+__global__ __launch_bounds__(256) void k_pool_fix_norm(float* __restrict__ p, const float* __restrict__ halo,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       int B, int Hp, int Wp, int Wo, int tiles_y) {
+    const int c4 = threadIdx.x & 15;
+    const unsigned np = (unsigned)B * Hp * Wp;
+    for (unsigned pp = blockIdx.x * 16 + threadIdx.x / 16; pp < np; pp += gridDim.x * 16) {
+        unsigned q = pp;
+        const int px = (int)(q % (unsigned)Wp); q /= (unsigned)Wp;
+        const int py = (int)(q % (unsigned)Hp);
+        const int n = (int)(q / (unsigned)Hp);
+        float* o = p + (size_t)pp * 64 + c4 * 4;
+        f32x4 m = *reinterpret_cast<const f32x4*>(o);
+        if ((py & 7) == 0 && py > 0) {
+            const float* hrow = halo + ((size_t)n * tiles_y + (py >> 3) - 1) * Wo * 64 + c4 * 4;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ox = 2 * px + dx;
+                if (ox < 0 || ox >= Wo) continue;
+                const f32x4 h = *reinterpret_cast<const f32x4*>(hrow + (size_t)ox * 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], h[e]);
+            }
+        }
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (long long)n * 64 + c4 * 4);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + (long long)n * 64 + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf((m[e] - mu[e]) * rs[e], 0.f);
+        *reinterpret_cast<f32x4*>(o) = m;
     }
 }
 
@@ -1786,6 +1882,14 @@ inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // hipFuncAttributeMaxDynamicSharedMemorySize once per (device, kernel), not once per launch (lds_attr.h: the attribute
 // applies to the current device only, so a process that drives several GPUs must set it on each)
 inline void allow_lds(const void* kern, size_t bytes) { (void)dsmil_lds::allow(kern, (int)bytes); }
+inline bool stem_fuse() {   // expt builds: DSMIL_STEM_FUSE=0 keeps the stem + k_norm_relu_maxpool pair (A/B, bit-identity test)
+#ifdef DSMIL_EXPERIMENTS
+    static const int off = [] { const char* e = getenv("DSMIL_STEM_FUSE"); return (e && !strcmp(e, "0")) ? 1 : 0; }();
+    return !off;
+#else
+    return true;
+#endif
+}
 inline bool use_wino(const ConvSpec& s) {  // 3x3 stride-1 convs run as Winograd F(2x2,3x3)
 #ifdef DSMIL_EXPERIMENTS
     static const int off = expt_env("DSMIL_NO_WINO");
@@ -2269,7 +2373,20 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
     {
         const bool s6 = conv_s6();   // DSMIL_CONV: the stem follows the direct convs' MFMA form
         const int tx = (d.W1 + 15) / 16, ty = s6 ? (d.H1 + SS_TR - 1) / SS_TR : (d.H1 + 7) / 8;
-        if (s6) {
+        // InstanceNorm trunks: the max-pool is fused into the stem (a frozen BatchNorm may have a negative scale, for which
+        // the pool needs the window MINIMUM too: that path keeps the raw map + k_norm_relu_maxpool)
+        const bool fuse = s6 && !bn_m && stem_fuse();
+        if (fuse) {
+            const unsigned short* wimg = (const unsigned short*)(packed + pack_offset(A, A.nconv));
+            const size_t ldsp = SS_LDS + SS_POOL_LDS;
+            allow_lds((const void*)k_stem_s6<true, true>, ldsp);
+            allow_lds((const void*)k_stem_s6<false, true>, ldsp);
+            // the pooled raw map goes straight to the max-pool's destination; the raw-map region holds the halo rows
+            if (u8) hipLaunchKernelGGL((k_stem_s6<true, true>), dim3((unsigned)ty, (unsigned)B), dim3(512), ldsp, st, x_nchw, wimg,
+                                       buf[0], part, B, H, W, d.H1, d.W1, tx, ty, y0, d.Hp, d.Wp);
+            else hipLaunchKernelGGL((k_stem_s6<false, true>), dim3((unsigned)ty, (unsigned)B), dim3(512), ldsp, st, x_nchw, wimg,
+                                    buf[0], part, B, H, W, d.H1, d.W1, tx, ty, y0, d.Hp, d.Wp);
+        } else if (s6) {
             const unsigned short* wimg = (const unsigned short*)(packed + pack_offset(A, A.nconv));
             allow_lds((const void*)k_stem_s6<true>, SS_LDS);
             allow_lds((const void*)k_stem_s6<false>, SS_LDS);
@@ -2289,8 +2406,10 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
         const long long total = (long long)B * d.Hp * d.Wp * 16;
         long long blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(k_norm_relu_maxpool, dim3((unsigned)blocks), dim3(256), 0, st, y0, mean[0], rstd[0],
-                           buf[0], B, d.H1, d.W1, d.Hp, d.Wp, 64);
+        if (fuse) hipLaunchKernelGGL(k_pool_fix_norm, dim3((unsigned)blocks), dim3(256), 0, st, buf[0], y0, mean[0], rstd[0],
+                                     B, d.Hp, d.Wp, d.W1, ty);
+        else hipLaunchKernelGGL(k_norm_relu_maxpool, dim3((unsigned)blocks), dim3(256), 0, st, y0, mean[0], rstd[0],
+                                buf[0], B, d.H1, d.W1, d.Hp, d.Wp, 64);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
     // ---- layers 1..4, nblk[l] BasicBlocks each.  cur = block input (materialised, normalised)

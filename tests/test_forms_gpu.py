@@ -52,3 +52,26 @@ def test_one_wave_winograd_unit_is_bit_identical_to_the_two_wave_unit(tmp_path):
         outs.append(np.load(o))
     assert np.isfinite(outs[1]).all()
     assert np.array_equal(outs[0], outs[1]), float(np.abs(outs[0] - outs[1]).max())
+
+
+def test_fused_stem_maxpool_is_bit_identical_to_the_two_kernel_path(tmp_path):
+    """The InstanceNorm trunks take the 3x3 stride-2 max-pool inside the stem kernel (pooled raw map + halo rows, then
+    k_pool_fix_norm); DSMIL_STEM_FUSE=0 (experiment build) keeps the raw stem output + k_norm_relu_maxpool.  max is exact
+    and the normalisation is the same expression, so the features must agree BIT FOR BIT, incl. sizes whose tiles are
+    partly outside the image."""
+    import numpy as np
+    lib = os.path.join(os.path.dirname(HERE), "dsmil-wsi_amd", "libdsmil_hip_expt.so")
+    assert os.path.exists(lib), "python dsmil-wsi_amd/build.py --variant expt -DDSMIL_EXPERIMENTS (done by __graft_entry__.build())"
+    tool = os.path.join(os.path.dirname(HERE), "tools", "wino_check.py")
+    outs = []
+    for tag, env in (("two", {"DSMIL_STEM_FUSE": "0"}), ("fused", {})):
+        e = dict(os.environ)
+        e.pop("DSMIL_STEM_FUSE", None)
+        e.update(env)
+        e["DSMIL_NATIVE_LIB"] = "libdsmil_hip_expt.so"
+        o = str(tmp_path / f"{tag}.npy")
+        r = subprocess.run([sys.executable, tool, "run", o], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        outs.append(np.load(o))
+    assert np.isfinite(outs[1]).all()
+    assert np.array_equal(outs[0], outs[1]), float(np.abs(outs[0] - outs[1]).max())

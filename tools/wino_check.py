@@ -3,8 +3,8 @@
 seeded batches are computed in two subprocesses (the knobs are read once per process) and compared bit for bit, then the
 embedder leg of bench.py is timed both ways.
 Usage (GPU box): DSMIL_NATIVE_LIB=libdsmil_hip_expt.so python tools/wino_check.py [K=V ...]
-base = DSMIL_WINO_KERNEL=unit (k_conv_wino_s3 everywhere); variant = the library's default (k_conv_wino_w1 on the 128-cout
-layers) plus the given knobs."""
+base = DSMIL_WINO_KERNEL=unit (k_conv_wino_s3 everywhere) unless the first argument is base:K=V,...; variant = the library's
+default (k_conv_wino_w1 on the 128-cout layers, max-pool fused into the stem) plus the given knobs."""
 import os
 import subprocess
 import sys
@@ -13,7 +13,7 @@ import _path  # noqa: F401
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHAPES = [(5, 96, 96), (3, 224, 224), (33, 64, 160), (64, 224, 224)]
+SHAPES = [(5, 96, 96), (3, 224, 224), (33, 64, 160), (2, 225, 231), (4, 250, 250), (64, 224, 224)]
 
 
 def run(out):
@@ -39,10 +39,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "run":
         run(sys.argv[2])
         sys.exit(0)
-    knobs = dict(a.split("=", 1) for a in sys.argv[1:])
+    base = {"DSMIL_WINO_KERNEL": "unit"}
+    args = sys.argv[1:]
+    if args and args[0].startswith("base:"):   # another baseline: base:K=V,K=V (e.g. base:DSMIL_STEM_FUSE=0)
+        base = dict(x.split("=", 1) for x in args[0][5:].split(",") if x)
+        args = args[1:]
+    knobs = dict(a.split("=", 1) for a in args)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     outs = []
-    for tag, env in (("base", {"DSMIL_WINO_KERNEL": "unit"}), ("var", knobs)):
+    for tag, env in (("base", base), ("var", knobs)):
         e = dict(os.environ)
         e.update(env)
         o = os.path.join(ROOT, "gpurun_out", f"wino_check_{tag}.npy")
@@ -55,4 +60,4 @@ if __name__ == "__main__":
     print("features:", a.shape, "finite", bool(np.isfinite(b).all()), "bit-identical", bool(np.array_equal(a, b)),
           "max abs diff %.3e" % float(np.abs(a - b).max()), "max |base| %.3f" % float(np.abs(a).max()), flush=True)
     spec = ",".join(f"{k}={v}" for k, v in knobs.items())
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variants.py"), "embedder", "base:DSMIL_WINO_KERNEL=unit", "var:" + spec])
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variants.py"), "embedder", "base:" + ",".join(f"{k}={v}" for k, v in base.items()), "var:" + spec])
