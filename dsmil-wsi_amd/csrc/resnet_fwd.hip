@@ -1020,17 +1020,21 @@ __global__ __launch_bounds__(WNN * 128, 2) void k_conv_wino_s3(WinoArgs a) {
             *reinterpret_cast<u32x2_t*>(d1 + 16) = pl;
         }
     };
-    // weights: uniform base per (wave), lane offset inside the [Cout][16] bf16 slab of a (pos, chunk, plane)
-    const unsigned short* ub16 = reinterpret_cast<const unsigned short*>(a.u);
-    const long long uplane = (long long)a.Cout * SK;                 // bf16 between planes
-    const long long uchunk = 3 * uplane;                             // between channel chunks
-    const long long upos = (long long)nchunks * uchunk;              // between transform positions
-    const unsigned short* ubase = ub16 + (long long)(8 * wp) * upos + (long long)(n0 + wn * 32) * SK;
-    const int ulane = l31 * SK + 8 * hi;
+    // weights, TILED (k_pack_wino_s3, tiled = 1: [Cout/32][C/16][16 pos][3 planes][32 couts][16] bf16 — the 24 fragments a wave
+    // needs for one chunk lie inside one 48 KiB slab) and fetched by buffer loads: one resource for the tensor, the lane's 16
+    // bytes as the only address VGPR, a wave-uniform soffset and the 12-bit immediate — no per-load 64-bit address arithmetic
+    // on the VALU (see wino_w1.h, which introduced the layout)
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.u), 0, (int)((long long)a.C * a.Cout * 96), 0x00020000);
+    const int ulane_b = l31 * 32 + hi * 16;
+    const int utile_b = (((n0 >> 5) + wn) * nchunks) * (48 * 1024) + (8 * wp) * 3072;   // wave-uniform: cout tile, position half
     auto uload = [&](int p, int cc, u32x4_t (&w)[3]) {
-        const unsigned short* q = ubase + p * upos + cc * uchunk + ulane;
+        const int sb = utile_b + cc * (48 * 1024);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const u32x4_t*>(q + pl * uplane);
+        for (int pl = 0; pl < 3; ++pl) {
+            const int f = p * 3 + pl;                        // fragment inside the wave's 24 KiB of the slab
+            w[pl] = __builtin_amdgcn_raw_buffer_load_b128(urs, ulane_b + (f & 3) * 1024, sb + (f >> 2) * 4096, 0);
+        }
     };
 
     f32x16 acc[8];
@@ -1938,6 +1942,15 @@ inline int wino_expt_kernel() {
     return k;
 }
 #endif
+// the packed Winograd weights are tiled ([Cout/32][C/16][16][3][32][16]) for k_conv_wino_w1 and k_conv_wino_s3; the two
+// experiment kernels (wino_variants.h) keep the position-major layout
+inline bool wino_tiled() {
+#ifdef DSMIL_EXPERIMENTS
+    return wino_expt_kernel() != 1 && wino_expt_kernel() != 2;
+#else
+    return true;
+#endif
+}
 // which Winograd convs run on k_conv_wino_w1 (one wave per SIMD, tiled weights): the packing and the launch must agree
 inline bool use_w1(const ConvSpec& s) {
 #ifdef DSMIL_EXPERIMENTS
@@ -2304,7 +2317,7 @@ int dsmil_resnet_pack(int32_t depth, const float* const* conv_w, float* packed, 
             if (blocks > 4096) blocks = 4096;
             if (wino_s3())
                 hipLaunchKernelGGL(k_pack_wino_s3, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
-                                   (unsigned short*)(packed + pack_offset(*A, i)), s.cout, s.cin, use_w1(s) ? 1 : 0);
+                                   (unsigned short*)(packed + pack_offset(*A, i)), s.cout, s.cin, wino_tiled() ? 1 : 0);
             else
                 hipLaunchKernelGGL(k_pack_wino, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
                                    packed + pack_offset(*A, i), s.cout, s.cin);

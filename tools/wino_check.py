@@ -36,6 +36,14 @@ def run(out):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "against":   # against <ref.npy>: the first, third-from-last ... = the 4 shapes of an older reference file
+        SHAPES[:] = [(5, 96, 96), (3, 224, 224), (33, 64, 160), (64, 224, 224)]
+        o = os.path.join(ROOT, "gpurun_out", "wino_check_now.npy")
+        os.makedirs(os.path.dirname(o), exist_ok=True)
+        run(o)
+        a, b = np.load(sys.argv[2]), np.load(o)
+        print("against", sys.argv[2], "bit-identical", bool(np.array_equal(a, b)), "max abs diff %.3e" % float(np.abs(a - b).max()))
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "run":
         run(sys.argv[2])
         sys.exit(0)
