@@ -2227,17 +2227,33 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
     const int slot = dsmil_prof::begin(dsmil_prof::CH_CONV, st);
     const long long blocks128 = ((a.Mtot + 127) / 128) * (s.cout / 128 > 0 ? s.cout / 128 : 1);
     if (conv_s6()) {
-        // 128-pixel tiles; 128 output channels per workgroup while that still yields two workgroups per CU, else 64
-        auto go = [&](auto kern, int TN, size_t lds) {
+        // tile = BM pixels x TN output channels per 256-thread workgroup: 128 x 128, 128 x 64, 64 x 256 or 64 x 128
+        auto go = [&](auto kern, int BM, int TN) {
+            const size_t lds = (size_t)2 * (BM + TN) * S6LD * 4;
             allow_lds((const void*)kern, lds);
-            dim3 grid((unsigned)((a.Mtot + 127) / 128), (unsigned)(s.cout / TN));
+            dim3 grid((unsigned)((a.Mtot + BM - 1) / BM), (unsigned)(s.cout / TN));
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
         };
-        const size_t l128 = (size_t)2 * (128 + 128) * S6LD * 4, l64 = (size_t)2 * (128 + 64) * S6LD * 4;
-        if (s.cout % 128 == 0 && blocks128 >= 512) {
-            if (norm) go(k_conv_s6<4, 4, true>, 128, l128); else go(k_conv_s6<4, 4, false>, 128, l128);
-        } else {
-            if (norm) go(k_conv_s6<4, 2, true>, 64, l64); else go(k_conv_s6<4, 2, false>, 64, l64);
+        // Measured per layer (tools/s6_shapes.sh, bs 256): the activation rows are the expensive operand to stage (im2col
+        // gather, producer's IN + ReLU, plane cut; the weights are a plain copy), so the tile is as short in pixels and as wide
+        // in channels as the layer allows — 64 x 256, else 64 x 128 — which also quantises better (l4.0.conv1: 392 workgroups
+        // in ONE round instead of 784 on 768 slots; 195 us against 288).  Six direct convs of ResNet-18: 850 -> 726 us.
+        (void)blocks128;
+        int shape = s.cout % 256 == 0 ? 24 : s.cout % 128 == 0 ? 22 : 42;
+#ifdef DSMIL_EXPERIMENTS
+        {   // DSMIL_S6_TILE = 44 | 42 | 24 | 22 forces a tile shape wherever the channel count allows it (A/B)
+            static const int force = expt_env("DSMIL_S6_TILE");
+            if (force == 44 && s.cout % 128 == 0) shape = 44;
+            if (force == 42) shape = 42;
+            if (force == 24 && s.cout % 256 == 0) shape = 24;
+            if (force == 22 && s.cout % 128 == 0) shape = 22;
+        }
+#endif
+        switch (shape) {
+            case 44: if (norm) go(k_conv_s6<4, 4, true>, 128, 128); else go(k_conv_s6<4, 4, false>, 128, 128); break;
+            case 24: if (norm) go(k_conv_s6<2, 4, true>, 64, 256); else go(k_conv_s6<2, 4, false>, 64, 256); break;
+            case 22: if (norm) go(k_conv_s6<2, 2, true>, 64, 128); else go(k_conv_s6<2, 2, false>, 64, 128); break;
+            default: if (norm) go(k_conv_s6<4, 2, true>, 128, 64); else go(k_conv_s6<4, 2, false>, 128, 64); break;
         }
         dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
