@@ -1295,9 +1295,9 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         if (bf16_res) rc = launch_attend_bf16_res(a, max_rows, nb, st, &seg_per, &seg_T);
         else if (bf16_dma) rc = launch_attend_bf16_dma(a, max_rows, nb, st);
         else if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, nb, st) : launch_attend_bf16<1>(a, max_rows, nb, st);
+#ifdef DSMIL_EXPERIMENTS   // DSMIL_MLP=s9 and the ablation variants: not instantiated in the product library
         else if (mode == 9 && NW == 4) rc = v4 ? launch_attend_split<4, 4, 9>(a, max_rows, nb, st) : launch_attend_split<4, 1, 9>(a, max_rows, nb, st);
         else if (mode == 9) rc = v4 ? launch_attend_split<1, 4, 9>(a, max_rows, nb, st) : launch_attend_split<1, 1, 9>(a, max_rows, nb, st);
-#ifdef DSMIL_EXPERIMENTS
         else if (mode == 6 && NW == 4 && v4 && (a.expt & 16)) rc = launch_attend_split<4, 4, 6, false, 16>(a, max_rows, nb, st);
         else if (mode == 6 && NW == 4 && v4 && (a.expt & 32)) rc = launch_attend_split<4, 4, 6, false, 32>(a, max_rows, nb, st);
         else if (mode == 6 && NW == 4 && v4 && (a.expt & 8)) rc = launch_attend_split<4, 4, 6, true>(a, max_rows, nb, st);

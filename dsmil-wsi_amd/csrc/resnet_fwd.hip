@@ -2126,7 +2126,12 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
             // product configuration: weights two positions ahead (UD = 2), producer statistics staged through LDS (LS,
             // +4 KiB: 80 KiB per workgroup, still two per CU), NP = 6 | 9 by DSMIL_WINO
             const size_t lds_ls = lds + 4096;
+#ifdef DSMIL_EXPERIMENTS
             const bool np9 = wino_form() == 9;
+#define DSMIL_IF_NP9 if (np9)
+#else
+#define DSMIL_IF_NP9 if constexpr (false)   // the product library has the six-product form only: the nine-product kernels are not instantiated
+#endif
             auto go = [&](auto kern, size_t l) {
                 allow_lds((const void*)kern, l);
                 hipLaunchKernelGGL(kern, grid, dim3(256), l, st, wa);
@@ -2185,8 +2190,9 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
 #else
                 if (in_mean) gow1(k_conv_wino_w1<true, 6>); else gow1(k_conv_wino_w1<false, 6>);
 #endif
+#ifdef DSMIL_EXPERIMENTS
             } else if (s.cout % 128 == 0 && wino_wide()) {
-                // 128 couts per workgroup (512 threads, one workgroup per CU): half the staging work per MFMA
+                // (DSMIL_WINO_KERNEL=unit) 128 couts per workgroup (512 threads, one workgroup per CU): round 2's form of layers 2-4
                 const dim3 gridw(grid.x, (unsigned)(s.cout / 128));
                 auto gow = [&](auto kern, size_t l) {
                     allow_lds((const void*)kern, l);
@@ -2199,16 +2205,19 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
                     if (np9) gow(k_conv_wino_s3<false, WIDE_UD, false, 9, 4, WIDE_UC>, lds);
                     else gow(k_conv_wino_s3<false, WIDE_UD, false, 6, 4, WIDE_UC>, lds);
                 }
+#endif
             } else if (in_mean) {
-                if (np9) go(k_conv_wino_s3<true, 2, true, 9>, lds_ls);
+                DSMIL_IF_NP9 go(k_conv_wino_s3<true, 2, true, 9>, lds_ls);
                 else go(k_conv_wino_s3<true, 2, true, 6>, lds_ls);
             } else {
-                if (np9) go(k_conv_wino_s3<false, 2, false, 9>, lds);
+                DSMIL_IF_NP9 go(k_conv_wino_s3<false, 2, false, 9>, lds);
                 else go(k_conv_wino_s3<false, 2, false, 6>, lds);
             }
         }
+#ifdef DSMIL_EXPERIMENTS   // DSMIL_WINO=f32: the f32-MFMA Winograd unit
         else if (in_mean) hipLaunchKernelGGL((k_conv_wino<true>), grid, dim3(256), lds, st, wa);
         else hipLaunchKernelGGL((k_conv_wino<false>), grid, dim3(256), lds, st, wa);
+#endif
         dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         if (bn_m) return fill_stats(st, bn_m, bn_r, mean, rstd, B, s.cout);
@@ -2250,7 +2259,9 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
         }
 #endif
         switch (shape) {
+#ifdef DSMIL_EXPERIMENTS
             case 44: if (norm) go(k_conv_s6<4, 4, true>, 128, 128); else go(k_conv_s6<4, 4, false>, 128, 128); break;
+#endif
             case 24: if (norm) go(k_conv_s6<2, 4, true>, 64, 256); else go(k_conv_s6<2, 4, false>, 64, 256); break;
             case 22: if (norm) go(k_conv_s6<2, 2, true>, 64, 128); else go(k_conv_s6<2, 2, false>, 64, 128); break;
             default: if (norm) go(k_conv_s6<4, 2, true>, 128, 64); else go(k_conv_s6<4, 2, false>, 128, 64); break;
@@ -2262,7 +2273,11 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
                            B, HW, s.cout, a.nslots, a.Mtot);
         return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
     }
-    // tile choice (f32 form): 128x64 for Cout = 64; 128x128 while that yields >= 4 workgroups per CU;
+#ifndef DSMIL_EXPERIMENTS
+    (void)blocks128;
+    return DSMIL_E_UNSUPPORTED;   // (unreachable: the product library has the bf16-MFMA form only)
+#else
+    // DSMIL_CONV=f32.  Tile choice: 128x64 for Cout = 64; 128x128 while that yields >= 4 workgroups per CU;
     // 64x64 (finer units, less tail quantisation) for the small late-layer maps
     if (s.cout == 64) {
         const size_t lds = (size_t)(2 * 128 * LDK + 2 * 64 * LDK) * 4;
@@ -2286,9 +2301,11 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
     hipLaunchKernelGGL(k_in_finalize_flat, dim3((unsigned)B, (unsigned)((s.cout + 63) / 64)), dim3(256), 0, st, part, mean, rstd,
                        B, HW, s.cout, a.nslots, a.Mtot);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+#endif
 }
 
-void set_conv_attrs() {   // per (device, kernel): lds_attr.h
+void set_conv_attrs() {   // per (device, kernel): lds_attr.h.  Only the f32 forms of experiment builds: the others set theirs at launch
+#ifdef DSMIL_EXPERIMENTS
     const int l4 = (2 * 128 * LDK + 2 * 128 * LDK) * 4, l2 = (2 * 128 * LDK + 2 * 64 * LDK) * 4;
     allow_lds((const void*)k_conv<4, 4, true>, l4);
     allow_lds((const void*)k_conv<4, 4, false>, l4);
@@ -2296,6 +2313,7 @@ void set_conv_attrs() {   // per (device, kernel): lds_attr.h
     allow_lds((const void*)k_conv<4, 2, false>, l2);
     allow_lds((const void*)k_conv_wino<true>, (2 * WTILE + 2 * WRAW_MAX * WLD) * 4);
     allow_lds((const void*)k_conv_wino<false>, (2 * WTILE + 2 * WRAW_MAX * WLD) * 4);
+#endif
 }
 
 }  // namespace
@@ -2334,9 +2352,11 @@ int dsmil_resnet_pack(int32_t depth, const float* const* conv_w, float* packed, 
             if (wino_s3())
                 hipLaunchKernelGGL(k_pack_wino_s3, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
                                    (unsigned short*)(packed + pack_offset(*A, i)), s.cout, s.cin, wino_tiled() ? 1 : 0);
+#ifdef DSMIL_EXPERIMENTS
             else
                 hipLaunchKernelGGL(k_pack_wino, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
                                    packed + pack_offset(*A, i), s.cout, s.cin);
+#endif
         } else {
             const long long total = (long long)s.cout * s.cin * s.ks * s.ks;
             long long blocks = (total + 255) / 256;
@@ -2344,9 +2364,11 @@ int dsmil_resnet_pack(int32_t depth, const float* const* conv_w, float* packed, 
             if (conv_s6())
                 hipLaunchKernelGGL(k_pack_conv_s6, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
                                    (unsigned short*)(packed + pack_offset(*A, i)), s.cout, s.cin, s.ks * s.ks);
+#ifdef DSMIL_EXPERIMENTS
             else
                 hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
                                    packed + pack_offset(*A, i), s.cout, s.cin, s.ks * s.ks);
+#endif
         }
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
@@ -2424,10 +2446,12 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
             else hipLaunchKernelGGL(k_stem_s6<false>, dim3((unsigned)ty, (unsigned)B), dim3(512), SS_LDS, st, x_nchw, wimg, y0,
                                     part, B, H, W, d.H1, d.W1, tx, ty);
         }
+#ifdef DSMIL_EXPERIMENTS   // DSMIL_CONV=f32
         else if (u8) hipLaunchKernelGGL(k_stem<true>, dim3((unsigned)ty, (unsigned)B), dim3(256), 0, st, x_nchw, conv1_w, y0,
                                         part, B, H, W, d.H1, d.W1, tx, ty);
         else hipLaunchKernelGGL(k_stem<false>, dim3((unsigned)ty, (unsigned)B), dim3(256), 0, st, x_nchw, conv1_w, y0,
                                 part, B, H, W, d.H1, d.W1, tx, ty);
+#endif
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         if (bn_m) { const int rcf = fill_stats(st, bm(0), br(0), mean[0], rstd[0], B, 64); if (rcf) return rcf; }
         else hipLaunchKernelGGL(k_in_finalize_stem, dim3((unsigned)B), dim3(64 * FS_G), 0, st, part,
