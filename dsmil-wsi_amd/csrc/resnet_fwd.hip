@@ -2017,7 +2017,17 @@ Dims dims_for(int H, int W) {
 
 // Winograd unit shape: IB images x TYB x TXB tiles with IB*TYB*TXB <= 32 and a raw input region of
 // at most WRAW_MAX pixels, maximising the fraction of the 32 MFMA rows that carry real tiles.
-void wino_shape(int B, int TY, int TX, int& IB, int& TYB, int& TXB) {
+// cb > 0: the conv runs on k_conv_wino_w1 with cb 128-cout blocks and `nchunks` 16-channel chunks — ONE workgroup per CU, so
+// what counts is the number of ROUNDS of workgroups and the per-workgroup overhead, which grows with the images per unit
+// (the statistics partials are formed per image: stamps 13.4 / 15.4 / 23 k cycles of epilogue at 1 / 2 / 4 images, 8 k of
+// prologue, 6.1 k per chunk).  E.g. 14 x 14 maps at bs 256: 4 images x 1 x 7 tiles (448 units, 87 % of the slots) and
+// 1 image x 4 x 7 (512 units, 77 %) both take 4 rounds of two cout blocks; the second has the 10 k shorter epilogue.
+void wino_shape(int B, int TY, int TX, int& IB, int& TYB, int& TXB, int cb = 0, int nchunks = 0) {
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n > 0 ? n : 256;
+    }();
     double best = -1.0;
     IB = 1; TYB = 1; TXB = TX < WTT ? TX : WTT;
     for (int txb = 1; txb <= TX && txb <= WTT; ++txb) {
@@ -2027,9 +2037,17 @@ void wino_shape(int B, int TY, int TX, int& IB, int& TYB, int& TXB) {
                 if (ib > 1 && (tyb != TY && txb != TX) ) continue;  // several images per unit only for whole rows
                 if ((long long)ib * (2 * tyb + 2) * (2 * txb + 2) > WRAW_MAX) continue;
                 const double units = (double)((B + ib - 1) / ib) * ((TY + tyb - 1) / tyb) * ((TX + txb - 1) / txb);
-                const double util = (double)B * TY * TX / (units * (double)WTT);
-                // prefer higher utilisation, then fewer raw pixels per tile (less halo)
-                const double score = util - 1e-4 * (double)(2 * tyb + 2) * (2 * txb + 2) / (tyb * txb);
+                const double halo = 1e-4 * (double)(2 * tyb + 2) * (2 * txb + 2) / (tyb * txb);
+                double score;
+                if (cb > 0) {
+                    const double rounds = ceil(units * cb / ncu);
+                    const double wg = 6.1 * nchunks + 8.0 + 13.4 + 3.2 * (ib - 1);   // k cycles per workgroup
+                    score = 1e6 / (rounds * wg) - halo;
+                } else {
+                    const double util = (double)B * TY * TX / (units * (double)WTT);
+                    // prefer higher utilisation, then fewer raw pixels per tile (less halo)
+                    score = util - halo;
+                }
                 if (score > best) { best = score; IB = ib; TYB = tyb; TXB = txb; }
             }
     }
@@ -2068,12 +2086,14 @@ RWs rws_layout(int B, int H, int W, int depth = 18) {
             const long long e = ((M + 31) / 32) * nslots * C * 2;
             if (e > mx) mx = e;
         }
-        int ib, tyb, txb;
         const int TYl = (d.h[l] + 1) / 2, TXl = (d.w[l] + 1) / 2;
-        wino_shape(B, TYl, TXl, ib, tyb, txb);
-        const long long PBl = (long long)((TYl + tyb - 1) / tyb) * ((TXl + txb - 1) / txb);
-        const long long ew = (long long)B * PBl * 2 * Cw * 3;  // Winograd (cnt, mean, M2) partials
-        if (ew > mx) mx = ew;
+        for (int v = 0; v < 2; ++v) {   // the unit shape of both Winograd kernels (wino_shape: utilisation / rounds of workgroups)
+            int ib, tyb, txb;
+            wino_shape(B, TYl, TXl, ib, tyb, txb, v ? (Cw >= 128 ? Cw / 128 : 1) : 0, v ? Cw / 16 : 0);
+            const long long PBl = (long long)((TYl + tyb - 1) / tyb) * ((TXl + txb - 1) / txb);
+            const long long ew = (long long)B * PBl * 2 * Cw * 3;  // Winograd (cnt, mean, M2) partials
+            if (ew > mx) mx = ew;
+        }
     }
     r.part_elems = mx;
     r.part = o; o = al256(o + (size_t)mx * 4);
@@ -2103,7 +2123,8 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
         wa.x = x; wa.u = wpk; wa.in_mean = in_mean; wa.in_rstd = in_rstd; wa.y = y; wa.part = part;
         wa.B = B; wa.H = H; wa.W = W; wa.C = s.cin; wa.Cout = s.cout;
         wa.TY = (H + 1) / 2; wa.TX = (W + 1) / 2;
-        wino_shape(B, wa.TY, wa.TX, wa.IB, wa.TYB, wa.TXB);
+        if (use_w1(s)) wino_shape(B, wa.TY, wa.TX, wa.IB, wa.TYB, wa.TXB, s.cout / 128, s.cin / 16);
+        else wino_shape(B, wa.TY, wa.TX, wa.IB, wa.TYB, wa.TXB);
 #ifdef DSMIL_EXPERIMENTS
         static const int wexpt = expt_env("DSMIL_WINO_EXPT");
         wa.expt = wexpt;
