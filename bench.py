@@ -18,6 +18,10 @@ Sub-objects of the same JSON line (each measured the same way):
   aggregator_bf16  BASELINE configs[2]: TCGA weights (C=2), bf16 feature storage, f32 accumulate
   embedder         configs[3]: IClassifier(ResNet-18-IN) over --patches synthetic 224x224 patches per rank per step;
                    with N ranks ONE RCCL all-gather of the [--patches,512] rows follows inside the step (weak)
+  train_c1/_c2     SURVEY §8 a9: one train_tcga.py:60-75 step (forward, two BCEs, backward, Adam, loss.item()) per 10 000 x 512
+                   bag, C = 1 (c16 weights) and C = 2 (tcga weights): bags/s and the GPU time of forward+loss / backward / Adam
+  slide_h2d        the `slide` leg below starting from PINNED HOST tiles (compute_feats.py:69-75: H2D per batch, overlapped
+                   with the other streams' convs; D2H of rows + logits once per slide)
   slide            configs[3] per-slide strong scaling: a slide of --slide-patches uint8 tiles
                    cut contiguously over the ranks, embedded in batches, ONE all-gather of feature rows, aggregated
   slide_100k       the same with 100 000 tiles (2 slides timed)
@@ -33,7 +37,9 @@ MFMA-bound attend kernel of another, and the few-round kernels of one embedder f
 launch stream inside the library.  With several streams a launch's start-to-end interval inside the timed region also
 contains the kernels co-running with it, so the kernel's OWN duration is measured in a second region right after the
 timed one (same inputs, one pass in flight, 300 passes); the in-region interval is reported beside it.
-`cpu_baseline` is the same forward on this box's host cores.  Prints ONE JSON line (rank 0).
+`cpu_baseline` is the same forward on this box's host cores.  Prints ONE JSON line (rank 0).  The line is compact by default
+(--verbose adds the explanatory strings and the committed per-kernel tables); `config.legs` and the trailing `summary` key
+repeat every leg's value and roofline fraction so that a truncated stdout tail still carries them.
 """
 import argparse
 import ctypes
@@ -46,9 +52,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:     # the `dsmil` shim; inputs and example weights come from the package (dsmil-wsi_amd/synthetic.py),
+    sys.path.insert(0, ROOT)  # nothing under tests/ is imported; oracle/ only inside cpu_baseline_embedder
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA (no sparsity)
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: exact-f32 MFMA (no xf32 on gfx950)
@@ -90,12 +95,15 @@ ACT_BYTES_PER_PATCH = (3 * 224 * 224 * 4 + 112 * 112 * 64 * 4          # stem
                              for p, h in ((56, 28), (28, 14), (14, 7))))           # 3 stride-1 convs, 2 residual kernels
 
 
+KERNEL_TABLE = "r03_kernel_table.json"   # the latest committed per-kernel table (tools/kernel_table.py)
+
+
 def _kernel_table(leg):
     """Per-kernel rows of the committed profile of this leg (profiles/r03_kernel_table.json, tools/kernel_table.py): name,
     launches per pass, average ms, counter HBM bytes, algorithmic bytes / executed MFMA FLOPs, fraction of the bounding peak —
     measured under rocprofv3 with --streams 1 on the profiling box, NOT in this run (live numbers: `roofline`)."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r03_kernel_table.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", KERNEL_TABLE)))
         return {"source": t["source"], "rows": t[leg]} if leg in t else None
     except Exception:
         return None
@@ -249,7 +257,7 @@ class Ctx:
 def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
     torch, args, dev = cx.torch, cx.args, cx.dev
     import dsmil_wsi_amd.ops as ops
-    from conftest import load_weights
+    from dsmil_wsi_amd.synthetic import load_weights
     wnp = load_weights(weights_tag)
     N, K, nb = args.rows, args.feats, args.bags
     C = wnp["fc_w"].shape[0]
@@ -408,8 +416,7 @@ def cpu_baseline_aggregator(weights_tag, N, K, budget_s):
     `_forward_cpu` + FCLayer), op for op the torch sequence of dsmil.py:6-12,46-62 (and checked against vectors the
     reference produced, tests/test_cpu_module_golden.py), all cores."""
     import torch
-    from inputs import make_bag
-    from util import build_net
+    from dsmil_wsi_amd.synthetic import build_net, make_bag
     net = build_net(weights_tag, "cpu")
     bags = [torch.from_numpy(make_bag(50 + i, N, K)) for i in range(4)]
     with torch.no_grad():
@@ -437,9 +444,8 @@ def cpu_baseline_aggregator(weights_tag, N, K, budget_s):
 def _build_iclassifier(cx, seed=11, C=2):
     import torch.nn as nn
     import dsmil
-    from inputs import make_resnet18_weights   # seeded kaiming init; no oracle/ import in the GPU legs
+    from dsmil_wsi_amd.synthetic import load_weights, make_resnet18_weights   # seeded kaiming init
     from dsmil_wsi_amd.resnet import resnet18
-    from conftest import load_weights
     torch = cx.torch
     res = resnet18(pretrained=False, norm_layer=nn.InstanceNorm2d)
     for p in res.parameters():
@@ -507,8 +513,7 @@ def embedder_leg(cx):
                                    f"224x224 patches per GPU per pass, kaiming(seed 11) weights",
                        "passes_per_step": inner, "timed_region_s": round(dt, 3), "streams": args.streams,
                        "distinct_batches": len(xs),
-                       "parity": "unpinned: the reference's backbone is torchvision's resnet18 (absent from the reference tree and "
-                                 "this image) and it ships no embedder vectors; checked against two independent restatements",
+                       "parity": "unpinned (torchvision absent, the reference ships no embedder vectors); two independent restatements",
                        "collective": "all_gather_into_tensor([%d,512] f32) per pass, %d rank(s)" % (Bp, world) if cx.collectives else "none"},
             "roofline": {"kernel": "conv kernels of one forward: 9 x k_conv_wino_w1 + 4 x k_conv_wino_s3 (Winograd F(2x2,3x3), bf16 "
                                    "MFMA over exact 3-plane cuts) + 6 direct convs", "bound": "mfma",
@@ -542,8 +547,10 @@ def embedder_leg(cx):
 def cpu_baseline_embedder(budget_s):
     """oracle/resnet_oracle.py (the torch-CPU restatement of the torchvision backbone, fp32) on the host cores, bounded."""
     import torch
+    if os.path.join(ROOT, "oracle") not in sys.path:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import resnet_oracle as ro
-    from inputs import make_patches
+    from dsmil_wsi_amd.synthetic import make_patches
     w = ro.make_weights(seed=11)
     x = torch.from_numpy(make_patches(7, 16))
     with torch.no_grad():
@@ -561,14 +568,17 @@ def cpu_baseline_embedder(budget_s):
                       f"at the thread count that ran fastest in a short trial"}
 
 
-def slide_leg(cx, n_patches, n_steps=None):
+def slide_leg(cx, n_patches, n_steps=None, host=False):
     """ONE slide of n_patches ordered tiles (uint8 NHWC, resident), cut contiguously over the
     ranks, embedded in batches of --patches, ONE all-gather of the [N_r,512] rows, then the aggregator on the bag.
-    Strong scaling: the slide is fixed, per-rank work shrinks with N."""
+    Strong scaling: the slide is fixed, per-rank work shrinks with N.
+    host=True (`slide_h2d`): the tiles start in PINNED HOST memory, as compute_feats.py:69-75 has them after decode; every
+    batch is copied H2D on the stream that embeds it, so the copy engines run under the other streams' convs, and the bag's
+    rows + logits go back D2H at the end (the reference's per-batch `.cpu()`, once)."""
     torch, args, dev, world, dist = cx.torch, cx.args, cx.dev, cx.world, cx.dist
     from dsmil_wsi_amd import dist as dd
     from dsmil_wsi_amd import pipeline as pl
-    from util import build_net
+    from dsmil_wsi_amd.synthetic import build_net
     ic = _build_iclassifier(cx)
     net = build_net("tcga", dev)
     lo, hi = dd.shard_range(n_patches, cx.rank, world)
@@ -582,6 +592,11 @@ def slide_leg(cx, n_patches, n_steps=None):
         if b > a:
             tiles[a - lo:b - lo] = blk[a - s:b - s]
     del blk
+    if host:
+        tiles_dev, tiles = tiles, torch.empty(tiles.shape, dtype=torch.uint8, pin_memory=True)
+        tiles.copy_(tiles_dev)
+        del tiles_dev
+        torch.cuda.empty_cache()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     res = {}
     sizes = [dd.shard_range(n_patches, r, world)[1] - dd.shard_range(n_patches, r, world)[0] for r in range(world)]
@@ -589,7 +604,7 @@ def slide_leg(cx, n_patches, n_steps=None):
     def step():
         with torch.no_grad():
             ev[0].record()
-            feats, classes = pl.embed_tiles(ic, tiles, args.patches, streams=args.streams)
+            feats, classes = pl.embed_tiles(ic, tiles, args.patches, streams=args.streams, device=dev)
             ev[1].record()
             if cx.collectives:   # ONE collective per slide: feature rows and instance logits as one [N_r, 512 + C] matrix
                 bag, _ = dd.all_gather_packed([feats, classes], sizes)
@@ -597,6 +612,8 @@ def slide_leg(cx, n_patches, n_steps=None):
                 bag = feats
             ev[2].record()
             res["out"] = net(bag)
+            if host:   # features and instance logits back to the host, once per slide (compute_feats.py:74 does it per batch)
+                res["host"] = (bag.to("cpu", non_blocking=True), res["out"][0].to("cpu", non_blocking=True))
             ev[3].record()
 
     steps = n_steps if n_steps else max(2, min(args.steps, 5))
@@ -604,11 +621,14 @@ def slide_leg(cx, n_patches, n_steps=None):
     torch.cuda.synchronize()
     out = res["out"]
     assert out[2].shape[0] == n_patches and torch.isfinite(out[1]).all()
-    return {"metric": "patches/sec, one slide embedded + gathered + aggregated", "value": round(n_patches * steps / dt, 1),
+    return {"metric": "patches/sec, one slide %sembedded + gathered + aggregated" % ("copied H2D + " if host else ""),
+            "value": round(n_patches * steps / dt, 1),
             "unit": "patches/s", "scaling": "strong", "ms_per_slide": round(dt / steps * 1e3, 3),
             "last_slide_ms": {"embed": round(ev[0].elapsed_time(ev[1]), 3), "all_gather": round(ev[1].elapsed_time(ev[2]), 3),
                               "aggregate": round(ev[2].elapsed_time(ev[3]), 3)},
-            "config": {"workload": f"one slide = {n_patches} uint8 224x224 tiles (ToTensor fused in the stem), contiguous row "
+            "config": {"tiles_start_in": "pinned host memory (H2D per batch on its embed stream, D2H of rows + logits per slide)" if host else "HBM",
+                       "h2d_bytes_per_slide": int(tiles.numel()) if host else 0,
+                       "workload": f"one slide = {n_patches} uint8 224x224 tiles (ToTensor fused in the stem), contiguous row "
                                    f"shards over {world} rank(s), batches of {args.patches}, one all-gather of [N_r,512] f32, "
                                    f"MILNet(tcga) on the gathered bag", "slides_timed": steps, "rccl_ranks": world,
                        "streams": args.streams, "rows_this_rank": hi - lo,
@@ -624,7 +644,7 @@ def e2e_leg(cx, low_grid):
     torch, args, dev, world = cx.torch, cx.args, cx.dev, cx.world
     import numpy as np
     from dsmil_wsi_amd import pipeline as pl
-    from util import build_net
+    from dsmil_wsi_amd.synthetic import build_net
     gy, gx = low_grid
     e_lo, e_hi = _build_iclassifier(cx, seed=11), _build_iclassifier(cx, seed=12)
     net = build_net("tree", dev)
@@ -651,6 +671,115 @@ def e2e_leg(cx, low_grid):
                        "collectives_per_slide": 1 if (world > 1 or args.force_collective) else 0}}
 
 
+def train_leg(cx, weights_tag):
+    """SURVEY §8 a9 / N1 — one `train_tcga.py:60-75` step per bag: zero_grad, forward, 0.5 BCE(bag) + 0.5 BCE(max instance),
+    backward, Adam(lr 1e-4, betas (0.5, 0.9), weight_decay 1e-3: train_tcga.py:203,207,241), and the loss `.item()` of the
+    progress line (:74) — the step's one host sync.  Bags are 10 000 x 512 fp32, HBM-resident (training.BagCache), a
+    different bag every step.  Training is replicas-only across GPUs (bag-level data parallelism would change the per-bag
+    SGD semantics): with N ranks the value is N independent replicas."""
+    torch, args, dev = cx.torch, cx.args, cx.dev
+    from dsmil_wsi_amd import training
+    from dsmil_wsi_amd.synthetic import build_net
+    N, K = args.rows, args.feats
+    net = build_net(weights_tag, dev).train()
+    C = net.i_classifier.fc[0].out_features
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.5, 0.9), weight_decay=1e-3)
+    crit = torch.nn.BCEWithLogitsLoss()
+    g = torch.Generator(device=dev).manual_seed(4321 + cx.rank)
+    nbags = 16
+    bags = [torch.randn((N, K), generator=g, device=dev) for _ in range(nbags)]
+    labels = [torch.zeros((1, C), device=dev) for _ in range(nbags)]
+    for i, y in enumerate(labels):
+        y[0, i % C] = float((i // C) % 2) if C == 1 else 1.0
+    turn = [0]
+    last = {}
+
+    def step(sync=True):
+        i = turn[0] = (turn[0] + 1) % nbags
+        opt.zero_grad()
+        loss, _, _ = training.bag_loss(net, crit, bags[i], labels[i])
+        loss.backward()
+        opt.step()
+        last["loss"] = loss.item() if sync else loss
+
+    dt, inner, _, _ = cx.timed(step, args.steps, args.warmup, args.min_seconds / 2)
+    value = cx.world * inner * args.steps / dt
+    dt2, inner2, _, _ = cx.timed(lambda: step(False), max(2, args.steps // 4), 1, args.min_seconds / 4)
+    value_nosync = cx.world * inner2 * max(2, args.steps // 4) / dt2
+    # the parts, from HIP events on the launch stream over 100 steps (each part enqueued back to back, one sync at the end)
+    n_ev = 100
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(n_ev)]
+    for k in range(n_ev):
+        i = k % nbags
+        e = evs[k]
+        e[0].record()
+        opt.zero_grad()
+        loss, _, _ = training.bag_loss(net, crit, bags[i], labels[i])
+        e[1].record()
+        loss.backward()
+        e[2].record()
+        opt.step()
+        e[3].record()
+    torch.cuda.synchronize()
+    part = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in evs[10:]) / (n_ev - 10)
+    assert math.isfinite(float(last["loss"])), "training loss is not finite"
+    fl = 3 * flops_per_bag(N, K, C)                      # forward + two backward contractions per forward contraction
+    form = int(cx.L.dsmil_agg_mlp_form())
+    peak_exec = PEAK_BF16_MFMA_TFLOPS / form if form else PEAK_F32_MFMA_TFLOPS
+    t_roof = fl / (peak_exec * 1e12)
+    return {"metric": "bags/sec trained (one Adam step per 10kx512 bag)", "value": round(value, 1), "unit": "bags/s",
+            "ms_per_step_bag": round(1e3 / (value / cx.world), 4), "dtype": "f32", "scaling": "replicas",
+            "value_without_per_step_sync": round(value_nosync, 1),
+            "gpu_ms": {"forward_and_loss_head": round(part(0, 1), 4), "backward": round(part(1, 2), 4), "adam": round(part(2, 3), 4)},
+            "config": {"workload": f"train_tcga.py:60-75 step on MILNet(FCLayer({K},{C}), BClassifier({K},{C})), {weights_tag} weights, "
+                                   f"one {N} x {K} fp32 bag per step ({nbags} distinct, HBM-resident), Adam, loss.item() per step",
+                       "steps_timed": inner * args.steps, "timed_region_s": round(dt, 3), "classes": C},
+            "roofline": {"bound": "mfma", "kernel": "whole step (forward kernels + dsmil_agg_backward)", "unit": "TFLOP/s",
+                         "achieved": round(fl * value / cx.world / 1e12, 2), "peak": round(peak_exec, 1),
+                         "frac": round(t_roof * value / cx.world, 4),
+                         "alg_flops_per_step": fl, "peak_is": "3 x forward FLOPs on the pipe the forward's MLP executes on (bf16 MFMA / plane products)"}}
+
+
+def _strip_prose(obj):
+    """Drop the explanatory strings (`*_is`, notes) from the printed line: DESIGN.md §5 documents every field."""
+    if isinstance(obj, dict):
+        for k in [k for k in obj if k.endswith("_is") or k in ("frac_is", "peak_is")]:
+            del obj[k]
+        for v in obj.values():
+            _strip_prose(v)
+    elif isinstance(obj, list):
+        for v in obj:
+            _strip_prose(v)
+
+
+def _summary(line):
+    """Compact per-leg summary (value + the roofline fraction that bounds the leg): stored in config.legs — the driver keeps
+    `config` whole — and repeated as the LAST key of the line, so a tail-truncated stdout still carries every leg's number."""
+    out = {}
+
+    def put(name, obj):
+        if not obj:
+            return
+        r = obj.get("roofline") or {}
+        e = {"value": obj.get("value"), "unit": obj.get("unit")}
+        for k in ("frac", "whole_path_frac_of_roofline", "kernel_ms", "conv_ms_per_forward"):
+            if r.get(k) is not None:
+                e[k] = r[k]
+        if "ms_per_slide" in obj:
+            e["ms_per_slide"] = obj["ms_per_slide"]
+        if "gpu_ms" in obj:
+            e["gpu_ms"] = obj["gpu_ms"]
+        if obj.get("config", {}).get("single_bag_forward_ms") is not None:
+            e["single_bag_forward_ms"] = obj["config"]["single_bag_forward_ms"]
+        if obj.get("config", {}).get("value_one_stream") is not None:
+            e["value_one_stream"] = obj["config"]["value_one_stream"]
+        out[name] = e
+    put("aggregator_f32", line if line.get("unit") == "bags/s" else None)
+    for k in ("aggregator_bf16", "embedder", "train_c1", "train_c2", "slide", "slide_h2d", "slide_100k", "e2e"):
+        put(k, line.get(k))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -661,7 +790,7 @@ def main():
     ap.add_argument("--feats", type=int, default=512)
     ap.add_argument("--patches", type=int, default=256, help="patches per rank per embedder pass (batch size)")
     ap.add_argument("--workload", default="all",
-                    help="comma list of aggregator, aggregator_bf16, embedder, slide, slide100k, e2e; or all / both (= aggregator,embedder)")
+                    help="comma list of aggregator, aggregator_bf16, embedder, train, slide, slide_h2d, slide100k, e2e; or all / both (= aggregator,embedder)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on each timed region")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams independent passes are dealt to (ops.StreamPool); 1 = one pass in flight")
@@ -672,11 +801,14 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="run the slide / embedder collectives through RCCL even with ONE rank (a one-rank nccl group): "
                          "exercises the multi-GPU code path on a one-GPU box")
+    ap.add_argument("--verbose", action="store_true",
+                    help="keep the long explanatory strings (*_is) and attach the committed per-kernel tables (profiles/) to the line; "
+                         "the default line is compact so that a truncated stdout tail still holds every leg")
     ap.add_argument("--no-single-bag", action="store_true",
                     help="skip the single-bag latency probe (profiling runs: keeps per-kernel averages clean)")
     args = ap.parse_args()
     maybe_self_launch(args)
-    wl = {"all": "aggregator,aggregator_bf16,embedder,slide,slide100k,e2e", "both": "aggregator,embedder"}.get(args.workload, args.workload)
+    wl = {"all": "aggregator,aggregator_bf16,embedder,train,slide,slide_h2d,slide100k,e2e", "both": "aggregator,embedder"}.get(args.workload, args.workload)
     wl = [w for w in wl.split(",") if w]
     cx = Ctx(args)
     line = {}
@@ -687,8 +819,13 @@ def main():
         subs["aggregator_bf16"] = aggregator_leg(cx, "tcga", "bf16", single_bag=False)
     if "embedder" in wl:
         subs["embedder"] = embedder_leg(cx)
+    if "train" in wl:
+        subs["train_c1"] = train_leg(cx, "c16")
+        subs["train_c2"] = train_leg(cx, "tcga")
     if "slide" in wl:
         subs["slide"] = slide_leg(cx, args.slide_patches)
+    if "slide_h2d" in wl:
+        subs["slide_h2d"] = slide_leg(cx, args.slide_patches, host=True)
     if "slide100k" in wl:   # the large slide of SURVEY §8(d) config 4 (15 GB of uint8 tiles over the ranks)
         subs["slide_100k"] = slide_leg(cx, 100000, n_steps=2)
     if "e2e" in wl:
@@ -700,11 +837,12 @@ def main():
         line.update({"n_gpus": cx.world, "rccl_ranks": cx.world, "steps": args.steps, "warmup": args.warmup,
                      "higher_is_better": True, "scaling": line.get("scaling", "weak"), "vs_baseline": None, "data": "synthetic"})
         line.update(subs)
-        for leg, obj in (("aggregator", line if "aggregator" in wl else None), ("aggregator_bf16", line.get("aggregator_bf16")),
-                         ("embedder", line.get("embedder"))):
-            kt = _kernel_table(leg)
-            if obj is not None and kt is not None:
-                obj["kernels"] = kt
+        if args.verbose:
+            for leg, obj in (("aggregator", line if "aggregator" in wl else None), ("aggregator_bf16", line.get("aggregator_bf16")),
+                             ("embedder", line.get("embedder"))):
+                kt = _kernel_table(leg)
+                if obj is not None and kt is not None:
+                    obj["kernels"] = kt
         if not args.no_cpu_baseline and cx.world == 1:   # CPU baselines: rank 0 at N = 1 only
             if "aggregator" in wl:
                 line["cpu_baseline"] = cpu_baseline_aggregator("c16", args.rows, args.feats, args.cpu_seconds)
@@ -713,6 +851,11 @@ def main():
         order = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
         line = {**{k: line[k] for k in order if k in line}, **{k: v for k, v in line.items() if k not in order}}
+        if not args.verbose:
+            _strip_prose(line)
+        summ = _summary(line)
+        line.setdefault("config", {})["legs"] = summ     # the driver's parsed record keeps `config` whole
+        line["summary"] = summ                           # ... and the tail of stdout keeps the last key
         print(json.dumps(line), flush=True)
     if cx.dist is not None:
         cx.dist.barrier()

@@ -843,7 +843,8 @@ __global__ __launch_bounds__(256) void k_finish(
     const long long Nb = offsets[bag + 1] - off0;
     long long slot0 = off0 / BM + bag;
     long long ntile = (Nb + BM - 1) / BM;
-    if (seg_per > 0) {
+    if (seg_per > 0 && ntile > 0) {   // (an EMPTY bag keeps ntile = 0: no workgroup wrote a partial for it — merging a slot
+                                      // would read stale workspace; the bag then gets the same NaN / 0 outputs as on the tile path)
         const long long it0 = (long long)bag * seg_T, g_lo = it0 / seg_per, g_hi = (it0 + ntile - 1) / seg_per;
         slot0 = g_lo + bag;
         ntile = g_hi - g_lo + 1;

@@ -107,20 +107,50 @@ def embed_files(i_classifier, files, batch_size=128, num_workers=4, device=None,
     u8 = torch.device(device).type == "cuda" and resnet_convs_of(i_classifier.feature_extractor) is not None
     filt = bg_threshold is not None
     F_, C_ = i_classifier.fc.in_features, i_classifier.fc.out_features
+    on_gpu = torch.device(device).type == "cuda"
+
+    def embed(patches, keep_idx):
+        if keep_idx is not None:
+            if keep_idx.numel() == 0:
+                return
+            patches = patches.index_select(0, keep_idx)
+        if patches.shape[0] == 0:
+            return
+        if not u8:
+            patches = patches.permute(0, 3, 1, 2).float().div(255) if filt else patches.float()   # == VF.to_tensor
+        feats, classes = i_classifier(patches)
+        feats_l.append(feats)
+        cls_l.append(classes)
+
+    def finish(p):   # p = (patches, keep [device], keep [host copy in flight], its event)
+        patches, keep, keep_h, ev = p
+        if ev is not None:
+            ev.synchronize()          # recorded one batch ago: the next batch's decode and H2D ran meanwhile
+        embed(patches, torch.nonzero(keep_h)[:, 0].to(device, non_blocking=True))
+
     if hi > lo:
+        pending = None
         for batch in patch_loader(files[lo:hi], batch_size, num_workers, False, uint8=u8 or filt):
             patches = batch["input"].to(device, non_blocking=True)
-            if filt:
-                keep = background_keep_mask(patches, edge_threshold=bg_threshold)
-                keep_l.append(keep)
-                patches = patches[keep]
-            if patches.shape[0] == 0:
+            if not filt:
+                embed(patches, None)
                 continue
-            if not u8:
-                patches = patches.permute(0, 3, 1, 2).float().div(255) if filt else patches.float()   # == VF.to_tensor
-            feats, classes = i_classifier(patches)
-            feats_l.append(feats)
-            cls_l.append(classes)
+            # the keep mask is computed on the device and read by the host ONE BATCH LATER, so the loader, the H2D copy and
+            # the embedder of the previous batch do not wait for it
+            keep = background_keep_mask(patches, edge_threshold=bg_threshold)
+            keep_l.append(keep)
+            if on_gpu:
+                keep_h = torch.empty(keep.shape, dtype=torch.bool, pin_memory=True)
+                keep_h.copy_(keep, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            else:
+                keep_h, ev = keep, None
+            if pending is not None:
+                finish(pending)
+            pending = (patches, keep, keep_h, ev)
+        if pending is not None:
+            finish(pending)
     if feats_l:
         feats, classes = torch.cat(feats_l), torch.cat(cls_l)
     else:
@@ -134,7 +164,7 @@ def embed_files(i_classifier, files, batch_size=128, num_workers=4, device=None,
         full_f[keep_loc], full_c[keep_loc] = feats, classes
         feats, classes = full_f, full_c
         keep_all = keep_loc.to(torch.float32)[:, None]
-    if world > 1 or ddist._FORCE[0]:
+    if sharded and (world > 1 or ddist._FORCE[0]):
         # ONE collective per slide: feature rows and instance logits (and keep flags) travel as one [n_r, F + C (+1)] matrix
         sizes = [ddist.shard_range(n_total, r, world)[1] - ddist.shard_range(n_total, r, world)[0] for r in range(world)]
         parts = ddist.all_gather_packed([feats, classes] + ([keep_all] if filt else []), sizes)
@@ -433,12 +463,19 @@ def background_keep_mask(tiles, edge_threshold=15, sat_threshold=None):
     tile_size^2 > edge_threshold, default 15 = `-t`) and / or test_crop_single.py:17-24 (mean ubyte saturation >=
     sat_threshold, 30 at its call site).  Device tiles run dsmil_tile_stats; the decisions are made in float64 from
     the exact integer sums, as numpy does.  Returns a bool tensor [B] on the tiles' device."""
-    if torch.is_tensor(tiles) and tiles.is_cuda:
-        from . import ops
-        st = ops.tile_stats(tiles).cpu().numpy()
-    else:
-        st = tile_stats_reference(tiles)
     B, H, W = tiles.shape[0], tiles.shape[1], tiles.shape[2]
+    if torch.is_tensor(tiles) and tiles.is_cuda:
+        # decided ON the device, no host round trip (the embed loop reads the mask one batch later): the sums are exact
+        # integers < 2^53, so float64 sum / 3 / H^2 rounds exactly as numpy's mean(...) / tile_size**2 does (torch.mean would
+        # multiply by 1/3 instead of dividing)
+        st = ops.tile_stats(tiles).to(torch.float64)
+        keep = torch.ones(B, dtype=torch.bool, device=tiles.device)
+        if edge_threshold is not None:
+            keep &= (st[:, 0] + st[:, 1] + st[:, 2]) / 3.0 / float(H ** 2) > edge_threshold
+        if sat_threshold is not None:
+            keep &= st[:, 3] / float(H * W) >= sat_threshold
+        return keep
+    st = tile_stats_reference(tiles)
     keep = np.ones(B, bool)
     if edge_threshold is not None:
         edge = st[:, :3].astype(np.float64).mean(axis=1) / float(H ** 2)   # np.mean(edge) / tile_size**2
@@ -461,28 +498,38 @@ def stream_pool(device, streams):
 
 
 @torch.no_grad()
-def embed_tiles(i_classifier, tiles, batch_size=256, streams=3):
-    """IClassifier over resident uint8 NHWC tiles in batches (compute_feats.py:70-76 without the loader: the
-    tiles are already decoded and on the device).  Returns (feats [N,F], classes [N,C]).
-    Batches are independent (InstanceNorm is per image), so on the GPU they are dealt round-robin to `streams` HIP
-    streams (ops.StreamPool): the kernels of one forward have few workgroup rounds each and latency-bound phases that
-    a second batch fills (41.8 k -> 46.4 k patches/s with two streams, 47.0 k with three, bs 256)."""
+def embed_tiles(i_classifier, tiles, batch_size=256, streams=3, device=None):
+    """IClassifier over uint8 NHWC tiles in batches (compute_feats.py:70-76 without the JPEG decode).  Returns
+    (feats [N,F], classes [N,C]) on the device.
+    `tiles` resident on the GPU: batches are independent (InstanceNorm is per image), so they are dealt round-robin to
+    `streams` HIP streams (ops.StreamPool): the kernels of one forward have few workgroup rounds each and latency-bound
+    phases that a second batch fills (41.8 k -> 46.4 k patches/s with two streams, 47.0 k with three, bs 256).
+    `tiles` in HOST memory (decoded tiles as the loader hands them over, compute_feats.py:71 `patches.cuda()`): each
+    batch's H2D copy is issued non-blocking on the pool stream that will run its forward, in front of it — with pinned
+    memory the copy engines move batch i+1 .. i+streams-1 while the convs of batch i run, so PCIe time (38.5 MB per 256
+    tiles) hides under compute; `device` names the GPU (default: the classifier's)."""
     fl, cl = [], []
-    pool = stream_pool(tiles.device, streams) if (tiles.is_cuda and streams > 1 and tiles.shape[0] > batch_size) else None
+    on_host = not tiles.is_cuda
+    dev = (torch.device(device) if device is not None else next(i_classifier.parameters()).device) if on_host else tiles.device
+    use_gpu = dev.type == "cuda"
+    pool = stream_pool(dev, streams) if (use_gpu and streams > 1 and tiles.shape[0] > batch_size) else None
+
+    def one(lo):
+        x = tiles[lo:lo + batch_size]
+        if on_host and use_gpu:
+            x = x.to(dev, non_blocking=True)    # allocated and filled on the stream that consumes it
+        return i_classifier(x)
+
     for lo in range(0, tiles.shape[0], batch_size):
-        if pool is not None:
-            f, c = pool.run(i_classifier, tiles[lo:lo + batch_size])
-        else:
-            f, c = i_classifier(tiles[lo:lo + batch_size])
+        f, c = pool.run(one, lo) if pool is not None else one(lo)
         fl.append(f)
         cl.append(c)
     if pool is not None:
         pool.join()
-        cur = torch.cuda.current_stream(tiles.device)
+        cur = torch.cuda.current_stream(dev)
         for t in fl + cl:                               # produced on a pool stream, consumed (and freed) on this one
             t.record_stream(cur)
     if not fl:
-        dev = tiles.device
         return (torch.zeros((0, i_classifier.fc.in_features), device=dev),
                 torch.zeros((0, i_classifier.fc.out_features), device=dev))
     return torch.cat(fl), torch.cat(cl)

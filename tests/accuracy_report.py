@@ -20,7 +20,7 @@ from dsmil_wsi_amd import ops  # noqa: E402
 
 mode = os.environ.get("DSMIL_MLP", "default")
 for tag, N in (("c16", 10000), ("tcga", 10000), ("tcga", 100000), ("tree", 3000), ("musk", 500)):
-    p = dict(np.load(os.path.join(HERE, "golden", f"weights_{tag}.npz")))
+    p = dict(np.load(os.path.join(os.path.dirname(HERE), "dsmil-wsi_amd", "data", f"weights_{tag}.npz")))
     K = p["q0_w"].shape[1]
     x = make_bag(4242 + N, N, K)
     ref = orc.milnet_forward(x, p, dtype="f64")

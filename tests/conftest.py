@@ -30,6 +30,5 @@ def golden():
 
 
 def load_weights(tag):
-    import numpy as np
-    z = np.load(os.path.join(ROOT, "tests", "golden", f"weights_{tag}.npz"))
-    return {k: z[k] for k in z.files}
+    from dsmil_wsi_amd.synthetic import load_weights as lw
+    return lw(tag)

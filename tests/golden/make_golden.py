@@ -11,7 +11,7 @@ testing_tcga.py:129), feeds seeded synthetic bags and stores
   * the weights re-packed as plain .npz (so that tests and bench can run without the reference),
   * the reference outputs (classes, pred, A, B, critical index),
   * reference autograd gradients of the train_tcga.py:67-71 objective for small bags.
-Inputs are not stored: they are regenerated from ``tests/inputs.py`` and guarded by a sha256.
+Inputs are not stored: they are regenerated from ``dsmil-wsi_amd/synthetic.py`` and guarded by a sha256.
 """
 import hashlib
 import os
@@ -21,10 +21,17 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(os.path.dirname(os.path.dirname(HERE)), "dsmil-wsi_amd", "data")   # the re-packed weight sets ship with the package
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, "/root/reference")
 import dsmil as ref  # noqa: E402  (the reference module)
-from inputs import make_bag, make_label  # noqa: E402
+import importlib.util  # noqa: E402
+# the seeded input generators live in the package (dsmil-wsi_amd/synthetic.py); loaded by path because `import dsmil` is the
+# REFERENCE module in this script
+_spec = importlib.util.spec_from_file_location("_synthetic", os.path.join(os.path.dirname(DATA), "synthetic.py"))
+_syn = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_syn)
+make_bag, make_label = _syn.make_bag, _syn.make_label
 
 torch.set_num_threads(1)
 torch.manual_seed(0)
@@ -97,7 +104,7 @@ def main():
                         map_location="cpu")
         net = build(512, C)
         net.load_state_dict(sd, strict=True)
-        np.savez(os.path.join(HERE, f"weights_{tag}.npz"), **sd_to_np(sd))
+        np.savez(os.path.join(DATA, f"weights_{tag}.npz"), **sd_to_np(sd))
         for N in (1, 2, 37, 128, 500, 2000, 10000):   # 10000 x 512: the exact shape of BASELINE configs[1] / [2]
             seed = 1000 + N
             x = make_bag(seed, N, 512)
@@ -126,7 +133,7 @@ def main():
     for tag, K, C, nonlinear, passing_v, Ns in variants:
         net = build(K, C, nonlinear, passing_v)
         ortho_init(net, seed={"musk": 11, "tree": 12, "linq": 13, "passv": 14}[tag])
-        np.savez(os.path.join(HERE, f"weights_{tag}.npz"), **sd_to_np(net.state_dict()))
+        np.savez(os.path.join(DATA, f"weights_{tag}.npz"), **sd_to_np(net.state_dict()))
         for N in Ns:
             seed = 3000 + N + K
             x = make_bag(seed, N, K)

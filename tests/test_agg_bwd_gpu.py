@@ -240,4 +240,4 @@ def test_train_loop_uses_fused_objective_and_learns():
     losses = [T.train(args, bags, net, crit, opt, log=False) for _ in range(8)]
     assert losses[-1] < 0.8 * losses[0], losses
     tl, score, aucs, th = T.test(args, bags, net, crit, log=False)
-    assert aucs[0] > 0.8   # 16 bags: one swapped pair is 1/64 of AUC; unseeded, the bag order moved this between 0.86 and 1.0
+    assert aucs[0] > 0.9, aucs   # seeded run (torch + numpy generators above): deterministic; 16 bags, one swapped pair is 1/64 of AUC

@@ -8,7 +8,7 @@ import torch.nn as nn
 import dsmil
 from dsmil_wsi_amd import pipeline as pl
 import sys
-from util import build_net
+from dsmil_wsi_amd.synthetic import build_net  # noqa: E402
 from dsmil_wsi_amd.resnet import resnet18
 
 dev = torch.device("cuda:0")

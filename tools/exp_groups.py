@@ -15,7 +15,7 @@ import time
 import torch
 import dsmil  # noqa: F401
 from dsmil_wsi_amd import ops, _native
-from conftest import load_weights
+from dsmil_wsi_amd.synthetic import load_weights  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 20

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 import dsmil  # noqa: F401
 from dsmil_wsi_amd import ops
-from conftest import load_weights
+from dsmil_wsi_amd.synthetic import load_weights  # noqa: E402
 
 assert int(os.environ.get("DSMIL_EXPT", "0")) & 64
 nb, N, K = 64, 10000, 512

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 import dsmil
 from dsmil_wsi_amd import ops
-from conftest import load_weights  # noqa: E402
+from dsmil_wsi_amd.synthetic import load_weights  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "agg"
 dev = torch.device("cuda:0")

@@ -21,7 +21,7 @@ def run(out):
     import torch.nn as nn
     import dsmil
     from dsmil_wsi_amd.resnet import resnet18
-    from inputs import make_patches, make_resnet18_weights
+    from dsmil_wsi_amd.synthetic import make_patches, make_resnet18_weights
     res = resnet18(norm_layer=nn.InstanceNorm2d)
     res.fc = nn.Identity()
     res.load_state_dict(make_resnet18_weights(11), strict=True)
