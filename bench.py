@@ -693,35 +693,42 @@ def train_leg(cx, weights_tag):
         y[0, i % C] = float((i // C) % 2) if C == 1 else 1.0
     turn = [0]
     last = {}
+    fused = training.FusedTrainStep.create(net, crit, opt)   # what training.train (train_tcga.py's loop here) uses
+    assert fused is not None, "the reference's model / criterion / optimiser must take the fused step"
 
     def step(sync=True):
+        i = turn[0] = (turn[0] + 1) % nbags
+        loss = fused(bags[i], labels[i])
+        last["loss"] = loss.item() if sync else loss
+
+    def step_generic(sync=True):   # the autograd path (any criterion / optimiser): bag_loss -> backward -> optimizer.step
         i = turn[0] = (turn[0] + 1) % nbags
         opt.zero_grad()
         loss, _, _ = training.bag_loss(net, crit, bags[i], labels[i])
         loss.backward()
         opt.step()
-        last["loss"] = loss.item() if sync else loss
+        last["loss"] = loss.item() if sync else loss.detach()
 
     dt, inner, _, _ = cx.timed(step, args.steps, args.warmup, args.min_seconds / 2)
     value = cx.world * inner * args.steps / dt
     dt2, inner2, _, _ = cx.timed(lambda: step(False), max(2, args.steps // 4), 1, args.min_seconds / 4)
     value_nosync = cx.world * inner2 * max(2, args.steps // 4) / dt2
-    # the parts, from HIP events on the launch stream over 100 steps (each part enqueued back to back, one sync at the end)
+    fused.sync()
+    dt3, inner3, _, _ = cx.timed(step_generic, max(2, args.steps // 4), 1, args.min_seconds / 4)
+    value_generic = cx.world * inner3 * max(2, args.steps // 4) / dt3
+    # GPU time of a step: HIP events around 100 fused steps enqueued back to back (no host sync in between)
     n_ev = 100
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(n_ev)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fused2 = training.FusedTrainStep.create(net, crit, opt)
+    for k in range(10):
+        fused2(bags[k % nbags], labels[k % nbags])
+    e0.record()
     for k in range(n_ev):
-        i = k % nbags
-        e = evs[k]
-        e[0].record()
-        opt.zero_grad()
-        loss, _, _ = training.bag_loss(net, crit, bags[i], labels[i])
-        e[1].record()
-        loss.backward()
-        e[2].record()
-        opt.step()
-        e[3].record()
+        fused2(bags[k % nbags], labels[k % nbags])
+    e1.record()
     torch.cuda.synchronize()
-    part = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in evs[10:]) / (n_ev - 10)
+    fused2.sync()
+    gpu_ms_step = e0.elapsed_time(e1) / n_ev
     assert math.isfinite(float(last["loss"])), "training loss is not finite"
     fl = 3 * flops_per_bag(N, K, C)                      # forward + two backward contractions per forward contraction
     form = int(cx.L.dsmil_agg_mlp_form())
@@ -730,11 +737,13 @@ def train_leg(cx, weights_tag):
     return {"metric": "bags/sec trained (one Adam step per 10kx512 bag)", "value": round(value, 1), "unit": "bags/s",
             "ms_per_step_bag": round(1e3 / (value / cx.world), 4), "dtype": "f32", "scaling": "replicas",
             "value_without_per_step_sync": round(value_nosync, 1),
-            "gpu_ms": {"forward_and_loss_head": round(part(0, 1), 4), "backward": round(part(1, 2), 4), "adam": round(part(2, 3), 4)},
+            "value_generic_autograd_path": round(value_generic, 1),
+            "gpu_ms": {"step_enqueued_back_to_back": round(gpu_ms_step, 4)},
             "config": {"workload": f"train_tcga.py:60-75 step on MILNet(FCLayer({K},{C}), BClassifier({K},{C})), {weights_tag} weights, "
-                                   f"one {N} x {K} fp32 bag per step ({nbags} distinct, HBM-resident), Adam, loss.item() per step",
+                                   f"one {N} x {K} fp32 bag per step ({nbags} distinct, HBM-resident), Adam, loss.item() per step; "
+                                   f"training.FusedTrainStep = one dsmil_agg_train_step call per step",
                        "steps_timed": inner * args.steps, "timed_region_s": round(dt, 3), "classes": C},
-            "roofline": {"bound": "mfma", "kernel": "whole step (forward kernels + dsmil_agg_backward)", "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "whole step (dsmil_agg_train_step: forward, loss head, backward, Adam)", "unit": "TFLOP/s",
                          "achieved": round(fl * value / cx.world / 1e12, 2), "peak": round(peak_exec, 1),
                          "frac": round(t_roof * value / cx.world, 4),
                          "alg_flops_per_step": fl, "peak_is": "3 x forward FLOPs on the pipe the forward's MLP executes on (bf16 MFMA / plane products)"}}

@@ -40,6 +40,13 @@ class AggGrads(ctypes.Structure):
                 ("fc_w", "fc_b", "q0_w", "q0_b", "q2_w", "q2_b", "fcc_w", "fcc_b")]
 
 
+class AdamState(ctypes.Structure):
+    """struct dsmil_adam_state (include/dsmil_hip.h)."""
+    _fields_ = [("exp_avg", ctypes.POINTER(ctypes.c_void_p)), ("exp_avg_sq", ctypes.POINTER(ctypes.c_void_p)),
+                ("step", ctypes.c_int64), ("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double),
+                ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double)]
+
+
 # symbol -> (restype, argtypes); must list every function include/dsmil_hip.h declares
 SIGNATURES = {
     "dsmil_abi_version": (ctypes.c_int, []),
@@ -108,6 +115,14 @@ SIGNATURES = {
                                           c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p,
                                           ctypes.POINTER(AggGrads), c_f32p, ctypes.c_void_p, ctypes.c_size_t,
                                           ctypes.c_void_p]),
+    "dsmil_agg_train_step_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "dsmil_agg_train_step": (ctypes.c_int, [c_f32p, ctypes.c_int64, c_i64p, c_f32p, ctypes.POINTER(AggParams),
+                                            ctypes.POINTER(AdamState), c_f32p, ctypes.c_void_p, ctypes.c_size_t,
+                                            ctypes.c_void_p]),
+    "dsmil_adam_step": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                       ctypes.POINTER(ctypes.c_int64), ctypes.c_int64, ctypes.c_double, ctypes.c_double,
+                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]),
     "dsmil_agg_forward": (ctypes.c_int, [c_f32p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int64,
                                          ctypes.c_int64, ctypes.POINTER(AggParams), c_f32p, c_f32p,
                                          c_f32p, c_f32p, c_f32p, c_i64p, ctypes.c_void_p,

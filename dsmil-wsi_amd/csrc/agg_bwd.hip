@@ -1,4 +1,4 @@
-// DSMIL dual-stream aggregator, backward — hand-written HIP for gfx950 (MI355X, CDNA4).
+// DSMIL dual-stream aggregator, backward + the fused training step — hand-written HIP for gfx950 (MI355X, CDNA4).
 //
 // Gradient of dsmil.py:46-62 (+ the fused FCLayer, dsmil.py:6-12) for ONE bag, as autograd would
 // produce it for train_tcga.py:67-72 (the arg-max indices are constants; nonlinear or linear query;
@@ -11,27 +11,39 @@
 //   gQ  = gs q  (+ at row idx_c:  sum_n gs[n,c] Q[n])        gz2 = gQ (1 - Q^2)
 //   g_W2 = gz2^T H, g_b2 = colsum gz2, gH = (gz2 W2) [H > 0], g_W1 = gH^T x, g_b1 = colsum gH
 //   g_Wf = g_c^T x, g_bf = colsum g_c
-// Launch sequence (one stream, no host sync):
-//   k_bwd_prep      gB, D, g_fcc_*, W2^T                       (1 workgroup)
-//   dsmil_fc_forward  gA = V gB^T                              (HBM stream, reuses the forward kernel)
-//   k_bwd_qrow      q_c = q(x[idx_c])                          (1 workgroup per class)
-//   k_bwd_rows      recompute H, Q per 32-row wave tile on f32 MFMA (mlp_tile of the forward),
-//                   gs, gz2 -> workspace (row-major gz2, H, Q, gs)
-//   k_tn_small      g_q = gs^T Q        then k_bwd_critical adds it into gz2 at the critical rows
-//   k_bwd_gh        gH = (gz2 W2) [H>0]  — the forward GEMM-1 pipeline with X := gz2, W := W2^T
-//   k_tn_gemm       g_W2 = gz2^T H, g_W1 = gH^T x  (contraction over instances on f32 MFMA,
-//                   split over row ranges, deterministic two-stage reduction) + column sums
-//   k_tn_small      g_Wf = g_c^T x, g_bf
+// Every matrix product runs on bf16 MFMA over EXACT three-plane cuts of both fp32 operands, six plane products
+// (agg_split.h — the form the forward uses; round 3 had the backward on v_mfma_f32_32x32x2_f32, 1/16 of the rate).
+// Launch sequence (one stream, no host sync; 9 launches, round 3: 17):
+//   k_pack_agg_split x2  plane-cut W1 | W2 (skipped when the forward's packed image is handed in) and W2^T
+//   k_bwd_prep           gB, D, g_fcc_*                                  (block 0: head; the others: g_fcc_w)
+//   k_fc                 gA = V gB^T                                     (HBM stream, the forward's FCLayer kernel)
+//   k_bwd_qrow           q_c = q(x[idx_c])                               (skipped when the forward's q_max is handed in)
+//   k_bwd_rows           recompute H, Q per 32-row wave tile (the forward's MLP tile, H stored from the accumulators),
+//                        gs, gz2 -> workspace; per-tile partials of g_q = gs^T Q (register butterfly over the rows)
+//   k_bwd_critical       g_q = sum of the partials; gz2[idx_c] += g_q[c] (1 - Q[idx_c]^2)
+//   k_bwd_gh             gH = (gz2 W2) [H>0]  — the forward GEMM-1 pipeline with X := gz2, W := W2^T
+//   k_tn_split           g_W1 = gH^T x and g_W2 = gz2^T H in ONE launch: contraction over instances, 64-column slabs x
+//                        row ranges, both operands cut into planes as they are staged (k = instance rows along the
+//                        registers: the planes are written TRANSPOSED, one ds_write_b128 per 8 rows), column sums of
+//                        gH / gz2 (bias gradients) from the staged values
+//   k_bwd_reduce         fixed-order sums of the row-range partials -> g_W1, g_b1, g_W2, g_b2; the sparse max-stream
+//                        gradient of the FCLayer (g_max) in the same launch
+// dsmil_agg_train_step chains forward -> loss head -> this backward -> one Adam kernel over all eight tensors:
+// one C call per train_tcga.py:60-75 step.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
 #include "agg_common.h"
+#include "agg_split.h"
+#include "lds_attr.h"
 
 namespace {
 
-// instance rows per workgroup of the contraction-over-N kernels: >= 128, multiple of 32, and at most
-// 256 row ranges per bag (bounds the partial buffers; ~1000 workgroups on the 4-slab weight GEMM)
+constexpr int NP_BWD = 6;   // plane products per fp32 MAC (the forward's default form)
+
+// instance rows per workgroup of k_tn_small (dense instance-logit gradient only): >= 128, multiple of 32, and at most
+// 256 row ranges per bag
 inline int tn_rows(long long N) {
     long long r = (N + 255) / 256;
     r = (r + 31) / 32 * 32;
@@ -47,14 +59,26 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 // ---- k_bwd_prep ----------------------------------------------------------------------------
+// block 0: gB, D, g_fcc_b, the zero bias of the gH pipeline; blocks 1..: g_fcc_w = g_pred (x) B, 1024 elements each
 __global__ __launch_bounds__(256) void k_bwd_prep(
     const float* __restrict__ fcc_w, const float* __restrict__ Bm, const float* __restrict__ g_pred,
     const float* __restrict__ g_B, const float* __restrict__ A, const float* __restrict__ g_A,
-    const float* __restrict__ q2_w, float* __restrict__ gB, float* __restrict__ Dv,
-    float* __restrict__ g_fcc_w, float* __restrict__ g_fcc_b, float* __restrict__ W2T,
-    float* __restrict__ zero128, long long N, int Kv, int C, int nonlinear) {
+    float* __restrict__ gB, float* __restrict__ Dv, float* __restrict__ g_fcc_w, float* __restrict__ g_fcc_b,
+    float* __restrict__ zero128, long long N, int Kv, int C) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
+    if (blockIdx.x > 0) {
+        const long long n = (long long)C * C * Kv, i0 = (long long)(blockIdx.x - 1) * 1024;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long i = i0 + tid + 256 * u;
+            if (i < n) {
+                const int o = (int)(i / ((long long)C * Kv));
+                g_fcc_w[i] = g_pred[o] * Bm[i - (long long)o * C * Kv];
+            }
+        }
+        return;
+    }
     for (int c = 0; c < C; ++c) {
         float dpart = 0.f;
         for (int k = tid; k < Kv; k += 256) {
@@ -68,15 +92,8 @@ __global__ __launch_bounds__(256) void k_bwd_prep(
         const float d = block_sum_256(dpart, red);
         if (tid == 0) Dv[c] = d;
     }
-    for (long long i = tid; i < (long long)C * C * Kv; i += 256) {
-        const int o = (int)(i / ((long long)C * Kv));
-        const long long ck = i - (long long)o * C * Kv;
-        g_fcc_w[i] = g_pred[o] * Bm[ck];
-    }
     if (tid < C) g_fcc_b[tid] = g_pred[tid];
     if (tid < QD) zero128[tid] = 0.f;
-    if (nonlinear)
-        for (int i = tid; i < QD * QD; i += 256) W2T[i] = q2_w[(i & (QD - 1)) * QD + (i >> 7)];  // W2T[j][j2] = W2[j2][j]
 }
 
 // ---- k_bwd_qrow: q_c = q(x[idx_c]) (dsmil.py:53-54), one workgroup per class ------------------
@@ -125,7 +142,7 @@ __global__ __launch_bounds__(256) void k_bwd_qrow(
 
 // ---- k_bwd_rows ----------------------------------------------------------------------------
 struct BwdRowsArgs {
-    AttendArgs at;        // feats, offsets (2 entries: 0, N), q-weights, qmax; bag 0
+    AttendArgs at;        // feats, offsets (2 entries: 0, N), q-weights (+ packed planes), qmax; bag 0
     const float* A;       // [N,C]
     const float* gA;      // [N,C]  = V gB^T
     const float* g_A;     // [N,C] or null
@@ -134,18 +151,90 @@ struct BwdRowsArgs {
     float* gz2;           // [N,128]
     float* Hbuf;          // [N,128]
     float* Qbuf;          // [N,128]
+    float* gqp;           // [ceil(N/32), C, 128]: per 32-row wave tile, sum_n gs[n,c] Q[n,:]
 };
+
+// stores the hidden layer from the accumulator registers: register 4g+e of H[t] = unit 32t + 8g + 4hi + e of row l31
+struct StoreH {
+    float* Hbuf;
+    long long row;
+    bool valid;
+    int hi;
+    __device__ __forceinline__ void operator()(const f32x16 (&H)[4]) const {
+        if (!valid) return;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = H[t][4 * g + e];
+                *reinterpret_cast<f32x4*>(Hbuf + row * QD + 32 * t + 8 * g + 4 * hi) = hv;
+            }
+    }
+};
+
+// Sum 64 per-lane values over the 32 lanes of a half-wave by recursive halving: after the exchange with mask 16 a lane
+// keeps 32 of its 64 registers (each now a sum over 2 lanes), after mask 8 it keeps 16 ... after mask 1 it keeps 2,
+// each the sum over all 32 lanes: 62 exchanges instead of 320.  Lane l31 ends with the sums of indices 2 l31, 2 l31 + 1.
+__device__ __forceinline__ void halfwave_colsum64(const float (&v)[64], int l31, float& s0, float& s1) {
+    float a32[32], a16[16], a8[8], a4[4];
+    {
+        const bool b = (l31 >> 4) & 1;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const float send = b ? v[i] : v[i + 32], keep = b ? v[i + 32] : v[i];
+            a32[i] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    {
+        const bool b = (l31 >> 3) & 1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float send = b ? a32[i] : a32[i + 16], keep = b ? a32[i + 16] : a32[i];
+            a16[i] = keep + __shfl_xor(send, 8, 64);
+        }
+    }
+    {
+        const bool b = (l31 >> 2) & 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float send = b ? a16[i] : a16[i + 8], keep = b ? a16[i + 8] : a16[i];
+            a8[i] = keep + __shfl_xor(send, 4, 64);
+        }
+    }
+    {
+        const bool b = (l31 >> 1) & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float send = b ? a8[i] : a8[i + 4], keep = b ? a8[i + 4] : a8[i];
+            a4[i] = keep + __shfl_xor(send, 2, 64);
+        }
+    }
+    {
+        const bool b = l31 & 1;
+        const float send0 = b ? a4[0] : a4[2], keep0 = b ? a4[2] : a4[0];
+        const float send1 = b ? a4[1] : a4[3], keep1 = b ? a4[3] : a4[1];
+        s0 = keep0 + __shfl_xor(send0, 1, 64);
+        s1 = keep1 + __shfl_xor(send1, 1, 64);
+    }
+}
 
 template <int NW, int VEC>
 __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_bwd_rows(BwdRowsArgs b) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const AttendArgs& a = b.at;
-    f32x16 H[4], Q[4];
-    if (!mlp_tile<NW, VEC>(a, 0, (int)blockIdx.x, smem, H, Q)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const long long Nb = a.offsets[1] - a.offsets[0];
     const long long row = (long long)blockIdx.x * (NW * 32) + wave * 32 + l31;
     const bool valid = row < Nb;
+    f32x16 Q[4];
+    const StoreH hook{a.nonlinear ? b.Hbuf : nullptr, row, valid && a.nonlinear, hi};
+    if constexpr (VEC == 4) {
+        if (!mlp_tile_split_dma<NW, NP_BWD, false>(a, 0, (int)blockIdx.x, smem, Q, hook)) return;
+    } else {
+        if (!mlp_tile_split<NW, VEC, NP_BWD>(a, 0, (int)blockIdx.x, smem, Q, hook)) return;
+    }
     const long long rc = valid ? row : Nb - 1;
     const int C = a.C;
     const float scale = 0.08838834764831845f;  // 1/sqrt(128)
@@ -154,6 +243,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_bwd_rows(BwdRows
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) G[t][r] = 0.f;
+    const long long wtile = (long long)blockIdx.x * NW + wave;         // this wave's 32-row tile
+    const bool wave_live = wtile * 32 < Nb;                            // (uniform per wave)
     for (int c = 0; c < C; ++c) {
         float ga = b.gA[rc * C + c];
         if (b.g_A) ga += b.g_A[rc * C + c];
@@ -168,6 +259,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_bwd_rows(BwdRows
 #pragma unroll
                 for (int e = 0; e < 4; ++e) G[t][4 * g + e] = fmaf(gsc, u[e], G[t][4 * g + e]);
             }
+        // this tile's share of g_q[c] = sum_n gs[n,c] Q[n,:] (the gradient of the critical query)
+        float v[64];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[16 * t + r] = gsc * Q[t][r];
+        float s0, s1;
+        halfwave_colsum64(v, l31, s0, s1);
+        if (wave_live) {
+            const int i = 2 * l31, t = i >> 4, r = i & 15;              // indices i, i+1 = registers r, r+1 of tile t
+            float* o = b.gqp + (wtile * C + c) * QD + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            o[0] = s0;
+            o[1] = s1;
+        }
     }
     if (!valid) return;
     // gz2 = gQ (1 - Q^2) for the tanh query; rows go to the workspace row-major (4 units per store)
@@ -175,43 +280,53 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_bwd_rows(BwdRows
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 gz, hv, qv;
+            f32x4 gz, qv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float q = Q[t][4 * g + e];
                 gz[e] = a.nonlinear ? G[t][4 * g + e] * (1.f - q * q) : G[t][4 * g + e];
-                hv[e] = H[t][4 * g + e];
                 qv[e] = q;
             }
             const long long o = row * QD + 32 * t + 8 * g + 4 * hi;
             *reinterpret_cast<f32x4*>(b.gz2 + o) = gz;
-            *reinterpret_cast<f32x4*>(b.Hbuf + o) = hv;
             *reinterpret_cast<f32x4*>(b.Qbuf + o) = qv;
         }
 }
 
-// gz2[idx_c] += g_q[c] (1 - Q[idx_c]^2): q_c IS row idx_c of Q, so its gradient joins that row
-__global__ void k_bwd_critical(const int64_t* __restrict__ idx, const float* __restrict__ gq,
-                               const float* __restrict__ Qbuf, float* __restrict__ gz2, int C, int nonlinear) {
-    const int j = threadIdx.x;  // 128 threads
+// g_q[c] = sum over the 32-row tiles of their partials (fixed order); gz2[idx_c] += g_q[c] (1 - Q[idx_c]^2): q_c IS row
+// idx_c of Q, so its gradient joins that row.  One workgroup of 1024 threads = 128 units x 8 strided tile groups.
+__global__ __launch_bounds__(1024) void k_bwd_critical(const int64_t* __restrict__ idx, const float* __restrict__ gqp,
+                                                       const float* __restrict__ Qbuf, float* __restrict__ gz2,
+                                                       float* __restrict__ gq, long long ntile, int C, int nonlinear) {
+    __shared__ float red[8][QD];
+    const int j = threadIdx.x & (QD - 1), grp = threadIdx.x >> 7;
     for (int c = 0; c < C; ++c) {
-        const long long o = idx[c] * QD + j;
-        const float q = Qbuf[o];
-        gz2[o] += gq[c * QD + j] * (nonlinear ? (1.f - q * q) : 1.f);
+        float s = 0.f;
+        for (long long t = grp; t < ntile; t += 8) s += gqp[(t * C + c) * QD + j];
+        __syncthreads();
+        red[grp][j] = s;
+        __syncthreads();
+        if (grp == 0) {
+            const float g = ((red[0][j] + red[1][j]) + (red[2][j] + red[3][j])) + ((red[4][j] + red[5][j]) + (red[6][j] + red[7][j]));
+            gq[c * QD + j] = g;
+            const long long o = idx[c] * QD + j;
+            const float q = Qbuf[o];
+            gz2[o] += g * (nonlinear ? (1.f - q * q) : 1.f);   // classes run in order: two classes may share a row
+        }
     }
 }
 
 // ---- k_bwd_gh: gH = (gz2 W2) [H > 0] — forward GEMM-1 pipeline with X := gz2, W := W2^T ------------
 struct GhArgs {
-    AttendArgs at;  // feats = gz2 (K = 128), q0_w = W2T, q0_b = zeros, nonlinear = 0
+    AttendArgs at;  // feats = gz2 (K = 128), wpk = packed W2^T, q0_b = zeros, nonlinear = 0
     const float* Hbuf;
     float* gH;
 };
 template <int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_bwd_gh(GhArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x16 H[4], Q[4];
-    if (!mlp_tile<NW, 4>(g.at, 0, (int)blockIdx.x, smem, H, Q)) return;
+    f32x16 H[4];
+    if (!mlp_tile_split_dma<NW, NP_BWD, false>(g.at, 0, (int)blockIdx.x, smem, H)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
     const long long Nb = g.at.offsets[1] - g.at.offsets[0];
     const long long row = (long long)blockIdx.x * (NW * 32) + wave * 32 + l31;
@@ -229,74 +344,190 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_bwd_gh(GhArgs g)
         }
 }
 
-// ---- k_tn_gemm: part[s][128][Kc] = Am[rows of split s][128]^T  Bm[rows][Kc]  on f32 MFMA -------------
-// grid = (ceil(Kc/128), splits).  Per 32-row step both operands sit row-major in LDS; MFMA step k
-// contracts instance rows 2k, 2k+1: A lane (m = l31, hi) reads Am[2k+hi][32 mt + l31], B lane reads
-// Bm[2k+hi][32 w + l31] — consecutive lanes, consecutive words: conflict-free ds_read_b32.
-// Wave w owns output columns 32w..32w+31 of the slab, all 4 row tiles (units).  Slab 0 also sums
-// the columns of Am (bias gradient).
-template <int VEC>
-__global__ __launch_bounds__(256, 2) void k_tn_gemm(const float* __restrict__ Am, const float* __restrict__ Bm,
-                                                    float* __restrict__ part, float* __restrict__ part_b,
-                                                    long long N, int Kc, int TNR, const int64_t* __restrict__ bmap) {
-    __shared__ __attribute__((aligned(16))) float sA[32 * QD];
-    __shared__ __attribute__((aligned(16))) float sB[32 * QD];
+// ---- k_tn_split: contractions over the instance rows on bf16 MFMA (exact three-plane cuts, six products) -------
+//   part0[s][128][K]   = A0[rows of split s]^T x[rows]        (A0 = gH; gz2 for the linear query)
+//   part1[s][128][128] = A1[rows]^T Hbuf[rows]                (A1 = gz2; nonlinear query only)
+// grid = (slabs of 64 output columns: ceil(K/64) of x, then 2 of H; row ranges).  The contraction index (instance rows)
+// runs along the MFMA k axis, i.e. along a lane's registers, while memory holds rows along the slow axis: the staging
+// threads therefore own one COLUMN each and 8 consecutive rows (8 coalesced dword loads: a wave covers 256 B of a row
+// per instruction), cut the 8 values into three bf16 planes (split3: each element cut once) and write each plane's
+// 16 bytes to sX[plane][column][8 rows] with one ds_write_b128; a fragment read is one ds_read_b128.  Row stride 80 B:
+// both are conflict-free (16 consecutive columns hit 16 distinct 4-bank groups).  Global loads of step s+1 are issued
+// before the MFMAs of step s.  Wave w = (column tile w & 1, unit-tile pair w >> 1): 2 accumulator tiles, 24 MFMAs per
+// 32 rows.  Column sums of A0 / A1 (bias gradients) come from the staged values of the first slab of each kind.
+constexpr int TN_LDW = 20;      // 32-bit words per (plane, column) row: 16 row pairs + 4 pad
+constexpr int TN_WGS = 512;     // target workgroups per launch (two per CU): sets the number of row ranges
+struct TnArgs {
+    const float* A0;
+    const float* A1;
+    const float* X;
+    const float* Hb;
+    const int64_t* rowmap;
+    float* part0;
+    float* part1;
+    float* pb0;   // [S][128]
+    float* pb1;   // [S][128]
+    long long N;
+    int K, R, nx;
+};
+
+__global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned sA[3 * QD * TN_LDW];
+    __shared__ __attribute__((aligned(16))) unsigned sB[3 * 64 * TN_LDW];
+    __shared__ float s_cs[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int slab = blockIdx.x, split = blockIdx.y;
-    const int k0 = slab * QD;
-    const long long rbeg = (long long)split * TNR, rend = (rbeg + TNR < N) ? rbeg + TNR : N;
-    f32x16 acc[4];
+    const bool is_h = slab >= a.nx;
+    const float* Am = is_h ? a.A1 : a.A0;
+    const float* Bm = is_h ? a.Hb : a.X;
+    const int ldb = is_h ? QD : a.K;
+    const int col0 = (is_h ? slab - a.nx : slab) * 64;
+    const int64_t* bmap = is_h ? nullptr : a.rowmap;
+    const long long rbeg = (long long)split * a.R, rend = (rbeg + a.R < a.N) ? rbeg + a.R : a.N;
+    const bool want_cs = (slab == 0) || (slab == a.nx);
+    // staging roles: A: column u, 8-row groups ja, ja + 2; B: column cb, 8-row group jb
+    const int u = tid & 127, ja = tid >> 7;
+    const int cb = tid & 63, jb = tid >> 6;
+    const bool bcol_ok = col0 + cb < ldb;
+    float ra[2][8], rb[8];
+    auto prefetch = [&](long long r0) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const long long r = r0 + 8 * (ja + 2 * i) + e;
+                ra[i][e] = r < rend ? Am[r * QD + u] : 0.f;
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const long long r = r0 + 8 * jb + e;
+            rb[e] = (r < rend && bcol_ok) ? Bm[phys_row(bmap, r) * (long long)ldb + col0 + cb] : 0.f;
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float colsum = 0.f;
+    const int ct = wave & 1, up = wave >> 1;
+    constexpr int P0 = 9 - NP_BWD;
+    prefetch(rbeg);
     for (long long r0 = rbeg; r0 < rend; r0 += 32) {
-        // stage 32 rows x 128 of both operands (zero beyond the bag / beyond Kc)
+        // cut the staged values into planes, transposed into LDS
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 256 * i, r = f >> 5, c4 = f & 31;
-            const long long row = r0 + r;
-            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-            if (row < rend) {
-                va = *reinterpret_cast<const f32x4*>(Am + row * QD + c4 * 4);
-                vb = load4<VEC, float>(Bm + phys_row(bmap, row) * (long long)Kc, k0 + c4 * 4, Kc);
+        for (int i = 0; i < 2; ++i) {
+            S3Frag f[3];
+            split3(ra[i], f);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<f32x4*>(&sA[(p * QD + u) * TN_LDW + 4 * (ja + 2 * i)]) = f[p].f;
+            if (want_cs) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) colsum += ra[i][e];
             }
-            *reinterpret_cast<f32x4*>(sA + r * QD + c4 * 4) = va;
-            *reinterpret_cast<f32x4*>(sB + r * QD + c4 * 4) = vb;
+        }
+        {
+            S3Frag f[3];
+            split3(rb, f);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<f32x4*>(&sB[(p * 64 + cb) * TN_LDW + 4 * jb]) = f[p].f;
         }
         __syncthreads();
-        if (slab == 0 && tid < QD) {
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) colsum += sA[r * QD + tid];
-        }
-#pragma unroll 4
-        for (int ks = 0; ks < 16; ++ks) {
-            const float bv = sB[(2 * ks + hi) * QD + wave * 32 + l31];
+        if (r0 + 32 < rend) prefetch(r0 + 32);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float av = sA[(2 * ks + hi) * QD + t * 32 + l31];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) {
+            const int j = 2 * ks + hi;    // this lane's 8-row group: MFMA k = 8 hi + i  <->  row 16 ks + 8 hi + i
+            S3Frag fb[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[p].f = *reinterpret_cast<const f32x4*>(&sB[(p * 64 + 32 * ct + l31) * TN_LDW + 4 * j]);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                S3Frag fa[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    fa[p].f = *reinterpret_cast<const f32x4*>(&sA[(p * QD + 32 * (2 * up + tt) + l31) * TN_LDW + 4 * j]);
+#pragma unroll
+                for (int q = P0; q < 9; ++q)
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S3_PA(q)].v, fb[S3_PB(q)].v, acc[tt], 0, 0, 0);
             }
         }
         __syncthreads();
     }
-    // D[row = unit m][col = slab column]: lane holds column 32w + l31, units drow(r,hi) + 32t
-    const int col = k0 + wave * 32 + l31;
-    if (col < Kc) {
-        float* o = part + (long long)split * QD * Kc;
+    // D[m = unit][n = column]: lane holds column 32 ct + l31, units 32 (2 up + tt) + (r & 3) + 8 (r >> 2) + 4 hi
+    const int col = col0 + 32 * ct + l31;
+    if (col < ldb) {
+        float* o = is_h ? a.part1 + (long long)split * QD * QD : a.part0 + (long long)split * QD * a.K;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                o[(long long)m * Kc + col] = acc[t][r];
+                const int m = 32 * (2 * up + tt) + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                o[(long long)m * ldb + col] = acc[tt][r];
             }
     }
-    if (slab == 0 && tid < QD) part_b[split * QD + tid] = colsum;
+    if (want_cs) {
+        s_cs[tid] = colsum;
+        __syncthreads();
+        if (tid < QD) (is_h ? a.pb1 : a.pb0)[split * QD + tid] = s_cs[tid] + s_cs[tid + QD];
+    }
 }
 
-// out[i] = sum_s part[s][i]  (fixed order: deterministic)
+// ---- k_bwd_reduce: fixed-order sums over the row ranges (deterministic), every output of the query stream in one
+//      launch, plus the sparse max-stream gradient of the FCLayer (train_tcga.py:68,70: only the critical rows carry
+//      gradient: g_fc_w[c] (+)= g_max[c] x[idx_c], g_fc_b[c] (+)= g_max[c]) -------------------------------------
+struct ReduceArgs {
+    const float* part0; const float* part1; const float* pb0; const float* pb1;
+    float* g_w0; float* g_b0;    // outputs of (part0, pb0): g_q0_w [128,K], g_q0_b
+    float* g_w1; float* g_b1;    // outputs of (part1, pb1): g_q2_w [128,128], g_q2_b (nonlinear only)
+    int S, K, nonlinear;
+    // sparse FCLayer gradient (g_max != null)
+    const float* feats; const int64_t* idx; const float* g_max; const int64_t* rowmap;
+    float* g_fc_w; float* g_fc_b; int C, accumulate;
+};
+__global__ __launch_bounds__(256) void k_bwd_reduce(ReduceArgs a) {
+    const long long n0 = (long long)QD * a.K, n1 = a.nonlinear ? (long long)QD * QD : 0;
+    const long long nb = QD * (a.nonlinear ? 2 : 1), nf = a.g_max ? (long long)a.C * a.K + a.C : 0;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n0) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < a.S; ++k) s += a.part0[(long long)k * n0 + i];
+        a.g_w0[i] = s;
+        return;
+    }
+    i -= n0;
+    if (i < n1) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < a.S; ++k) s += a.part1[(long long)k * n1 + i];
+        a.g_w1[i] = s;
+        return;
+    }
+    i -= n1;
+    if (i < nb) {
+        const float* pb = i < QD ? a.pb0 : a.pb1;
+        const int j = (int)(i & (QD - 1));
+        float s = 0.f;
+        for (int k = 0; k < a.S; ++k) s += pb[k * QD + j];
+        (i < QD ? a.g_b0 : a.g_b1)[j] = s;
+        return;
+    }
+    i -= nb;
+    if (i < nf) {
+        if (i < (long long)a.C * a.K) {
+            const int c = (int)(i / a.K), k = (int)(i - (long long)c * a.K);
+            const float v = a.g_max[c] * a.feats[phys_row(a.rowmap, a.idx[c]) * (long long)a.K + k];
+            a.g_fc_w[i] = a.accumulate ? a.g_fc_w[i] + v : v;
+        } else {
+            const int c = (int)(i - (long long)a.C * a.K);
+            a.g_fc_b[c] = a.accumulate ? a.g_fc_b[c] + a.g_max[c] : a.g_max[c];
+        }
+    }
+}
+
+// out[i] = sum_s part[s][i]  (fixed order: deterministic) — the dense instance-logit gradient only
 __global__ void k_reduce_parts(const float* __restrict__ part, float* __restrict__ out, int S, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float s = 0.f;
@@ -307,7 +538,8 @@ __global__ void k_reduce_parts(const float* __restrict__ part, float* __restrict
 
 // ---- k_tn_small: part[s][M][Kc] = a[rows][M]^T b[rows][Kc] for a handful of columns M (classes);
 //      also part_a[s][M] = column sums of a.  grid = (row ranges, 256-wide k-segments); the 4 waves
-//      stride the rows (b row read once for up to 4 classes), then merge through LDS. -------------
+//      stride the rows (b row read once for up to 4 classes), then merge through LDS.  Only the DENSE instance-logit
+//      gradient (g_classes: never requested by the reference's training loop) takes it. -------------
 template <int VEC>
 __global__ __launch_bounds__(256) void k_tn_small(const float* __restrict__ a, const float* __restrict__ bm,
                                                   float* __restrict__ part, float* __restrict__ part_a,
@@ -375,37 +607,65 @@ __global__ void k_bwd_gvals(const float* __restrict__ A, const float* __restrict
     }
 }
 
-// Sparse instance-stream gradient of the training objective (train_tcga.py:68,70: max over instances): only the
-// critical rows carry gradient, g_fc_w[c] (+)= g_max[c] x[idx_c], g_fc_b[c] (+)= g_max[c].  grid = C.
-__global__ void k_bwd_fc_sparse(const float* __restrict__ feats, const int64_t* __restrict__ idx,
-                                const float* __restrict__ g_max, float* __restrict__ g_fc_w, float* __restrict__ g_fc_b,
-                                int K, int accumulate, const int64_t* __restrict__ rowmap) {
-    const int c = blockIdx.x;
-    const float g = g_max[c];
-    const float* x = feats + phys_row(rowmap, idx[c]) * (long long)K;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        const float v = g * x[k];
-        g_fc_w[(long long)c * K + k] = accumulate ? g_fc_w[(long long)c * K + k] + v : v;
-    }
-    if (threadIdx.x == 0) g_fc_b[c] = accumulate ? g_fc_b[c] + g : g;
+// ---- Adam over all parameter tensors of the step in one launch (torch.optim.Adam, amsgrad = False, maximize = False:
+//      g += wd p; m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps),
+//      the operation order of torch's single-tensor / foreach implementation) --------------------------------------
+struct AdamTensors {
+    float* p[DSMIL_ADAM_MAX_TENSORS];
+    float* m[DSMIL_ADAM_MAX_TENSORS];
+    float* v[DSMIL_ADAM_MAX_TENSORS];
+    const float* g[DSMIL_ADAM_MAX_TENSORS];
+    long long end[DSMIL_ADAM_MAX_TENSORS];   // running element counts
+    int n;
+};
+__global__ __launch_bounds__(256) void k_adam(AdamTensors t, float step_size, float w1, float beta2, float w2, float eps,
+                                              float wd, float bc2_sqrt) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= t.end[t.n - 1]) return;
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < DSMIL_ADAM_MAX_TENSORS - 1; ++j)
+        if (j < t.n - 1 && i >= t.end[j]) k = j + 1;
+    const long long o = i - (k ? t.end[k - 1] : 0);
+    float* p = t.p[k];
+    float g = t.g[k][o];
+    const float pv = p[o];
+    if (wd != 0.f) g = fmaf(wd, pv, g);                       // grad.add(param, alpha = weight_decay)
+    const float m0 = t.m[k][o];                               // exp_avg.lerp_(grad, 1 - beta1): torch's two-sided formula
+    const float m = w1 < 0.5f ? m0 + w1 * (g - m0) : g - (g - m0) * (1.f - w1);
+    const float v = t.v[k][o] * beta2 + w2 * (g * g);         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    t.m[k][o] = m;
+    t.v[k][o] = v;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    p[o] = pv - step_size * (m / denom);                      // param.addcdiv_(exp_avg, denom, value = -step_size)
 }
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 struct BwdWs {
-    size_t gB, Dv, zero, W2T, qmax, gq, gA, gs, gz2, Hb, Qb, gH, part, part_b, off, total;
-    int splits, rows;
+    size_t gB, Dv, zero, qmax, gq, gA, gs, gz2, Hb, Qb, gH, gqp, wsplit, w2t, part0, part1, pb0, pb1, part, part_b, off, total;
+    int splits, rows;   // k_tn_small (dense instance-logit gradient)
+    int S, R, nx;       // k_tn_split
+    long long T32;
 };
-BwdWs bwd_layout(long long N, int K, int Kv, int C) {
+BwdWs bwd_layout(long long N, int K, int Kv, int C, int nonlinear) {
     BwdWs w;
     w.rows = tn_rows(N);
     w.splits = (int)((N + w.rows - 1) / w.rows);
-    const int Kmax = K > QD ? K : QD;
+    w.nx = (K + 63) / 64;
+    const int nslab = w.nx + (nonlinear ? 2 : 0);
+    long long st = TN_WGS / nslab;
+    if (st < 1) st = 1;
+    if (st > 256) st = 256;
+    long long R = ((N + st - 1) / st + 31) / 32 * 32;
+    if (R < 32) R = 32;
+    w.R = (int)R;
+    w.S = (int)((N + R - 1) / R);
+    w.T32 = (N + 31) / 32;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t p = o; o = al(o + bytes); return p; };
     w.gB = take((size_t)C * Kv * 4);
     w.Dv = take((size_t)C * 4);
     w.zero = take(QD * 4);
-    w.W2T = take((size_t)QD * QD * 4);
     w.qmax = take((size_t)C * QD * 4);
     w.gq = take((size_t)C * QD * 4);
     w.gA = take((size_t)N * C * 4);
@@ -414,7 +674,14 @@ BwdWs bwd_layout(long long N, int K, int Kv, int C) {
     w.Hb = take((size_t)N * QD * 4);
     w.Qb = take((size_t)N * QD * 4);
     w.gH = take((size_t)N * QD * 4);
-    w.part = take((size_t)w.splits * QD * Kmax * 4);
+    w.gqp = take((size_t)w.T32 * C * QD * 4);
+    w.wsplit = take((size_t)(2 * ((K + 31) / 32) + 8) * S3_CHUNK_F4 * 16);
+    w.w2t = take((size_t)8 * S3_CHUNK_F4 * 16);
+    w.part0 = take((size_t)w.S * QD * K * 4);
+    w.part1 = take((size_t)w.S * QD * QD * 4);
+    w.pb0 = take((size_t)w.S * QD * 4);
+    w.pb1 = take((size_t)w.S * QD * 4);
+    w.part = take((size_t)w.splits * (C > 4 ? C : 4) * (K > QD ? K : QD) * 4);   // k_tn_small: [splits][C][K]
     w.part_b = take((size_t)w.splits * QD * 4);
     w.off = take(2 * sizeof(int64_t));
     w.total = o;
@@ -424,23 +691,12 @@ BwdWs bwd_layout(long long N, int K, int Kv, int C) {
 __global__ void k_set_offsets(int64_t* off, long long N) { off[0] = 0; off[1] = N; }
 
 template <typename KernelT, typename ArgT>
-int launch_tile_kernel(KernelT kern, const ArgT& arg, int nw, long long N, hipStream_t st) {
+int launch_tile_kernel(KernelT kern, const ArgT& arg, int nw, bool dma, long long N, hipStream_t st) {
     const int BM = nw * 32;
-    const size_t lds = (size_t)(2 * W_TILE + 2 * BM * LDK) * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = dma ? (size_t)(3 * S3_CHUNK_F4 * 4 + 2 * BM * 32) * sizeof(float)
+                           : (size_t)(2 * S3_CHUNK_F4 * 4 + 2 * BM * LDK) * sizeof(float);
+    if (!dsmil_lds::allow((const void*)kern, (int)lds)) return DSMIL_E_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)((N + BM - 1) / BM)), dim3(nw * 64), lds, st, arg);
-    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
-}
-
-int tn_gemm(const float* Am, const float* Bm, long long N, int Kc, float* part, float* part_b, float* out,
-            float* out_b, int splits, bool v4, hipStream_t st, const int64_t* bmap = nullptr) {
-    dim3 grid((unsigned)((Kc + QD - 1) / QD), (unsigned)splits);
-    if (v4) hipLaunchKernelGGL(k_tn_gemm<4>, grid, dim3(256), 0, st, Am, Bm, part, part_b, N, Kc, tn_rows(N), bmap);
-    else hipLaunchKernelGGL(k_tn_gemm<1>, grid, dim3(256), 0, st, Am, Bm, part, part_b, N, Kc, tn_rows(N), bmap);
-    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
-    const long long n = (long long)QD * Kc;
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, out, splits, n);
-    if (out_b) hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(128), 0, st, part_b, out_b, splits, (long long)QD);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
@@ -456,28 +712,13 @@ int tn_small(const float* a, const float* bm, long long N, int M, int Kc, float*
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
-}  // namespace
-
-extern "C" {
-
-size_t dsmil_agg_backward_workspace_bytes(int64_t N, int32_t K, int32_t Kv, int32_t C) {
-    if (N <= 0 || K <= 0 || Kv <= 0 || C <= 0) return 0;
-    return bwd_layout(N, K, Kv, C).total;
-}
-
-int dsmil_agg_backward(const float* feats, const float* vals, int64_t N, const dsmil_agg_params* p,
-                       const float* A, const float* Bm, const int64_t* idx, const float* g_classes,
-                       const float* g_pred, const float* g_A, const float* g_B, const dsmil_agg_grads* g,
-                       float* g_vals, void* ws, size_t ws_bytes, void* stream) {
-    return dsmil_agg_backward_ex(feats, vals, N, p, A, Bm, idx, g_classes, nullptr, g_pred, g_A, g_B, g, g_vals, nullptr,
-                                 ws, ws_bytes, stream);
-}
-
-int dsmil_agg_backward_ex(const float* feats, const float* vals, int64_t N, const dsmil_agg_params* p,
-                          const float* A, const float* Bm, const int64_t* idx, const float* g_classes,
-                          const float* g_max, const float* g_pred, const float* g_A, const float* g_B,
-                          const dsmil_agg_grads* g, float* g_vals, const int64_t* rowmap, void* ws, size_t ws_bytes,
-                          void* stream) {
+// packed_split: the forward's plane-cut W1 | W2 image (dsmil_agg_pack_split layout) or null; qmax_in: the forward's
+// q_max [C,128] or null — both are recomputed here when absent
+int agg_backward_impl(const float* feats, const float* vals, int64_t N, const dsmil_agg_params* p,
+                      const float* A, const float* Bm, const int64_t* idx, const float* g_classes,
+                      const float* g_max, const float* g_pred, const float* g_A, const float* g_B,
+                      const dsmil_agg_grads* g, float* g_vals, const int64_t* rowmap, void* ws, size_t ws_bytes,
+                      void* stream, const void* packed_split, const float* qmax_in) {
     if (!feats || !p || !A || !Bm || !idx || !g_pred || !g || !ws) return DSMIL_E_INVALID;
     if (g_max && (!g->fc_w || !g->fc_b)) return DSMIL_E_INVALID;
     if (N <= 0 || p->K <= 0 || p->Kv <= 0 || p->C <= 0) return DSMIL_E_INVALID;
@@ -486,75 +727,96 @@ int dsmil_agg_backward_ex(const float* feats, const float* vals, int64_t N, cons
     if (g_classes && (!g->fc_w || !g->fc_b)) return DSMIL_E_INVALID;
     if (!vals) vals = feats;
     if (vals == feats && p->Kv != p->K) return DSMIL_E_INVALID;
-    if ((uintptr_t)ws % 256) return DSMIL_E_ALIGN;
+    if (((uintptr_t)ws % 256) || ((uintptr_t)p->q0_b % 16) || (p->nonlinear && ((uintptr_t)p->q2_b % 16))) return DSMIL_E_ALIGN;
+    if (packed_split && ((uintptr_t)packed_split % 16)) return DSMIL_E_ALIGN;
     const int K = p->K, Kv = p->Kv, C = p->C;
-    const BwdWs L = bwd_layout(N, K, Kv, C);
+    const BwdWs L = bwd_layout(N, K, Kv, C, p->nonlinear);
     if (ws_bytes < L.total) return DSMIL_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* w8 = (char*)ws;
     float* gB = (float*)(w8 + L.gB); float* Dv = (float*)(w8 + L.Dv); float* zero = (float*)(w8 + L.zero);
-    float* W2T = (float*)(w8 + L.W2T); float* qmax = (float*)(w8 + L.qmax); float* gq = (float*)(w8 + L.gq);
+    float* qmax = (float*)(w8 + L.qmax); float* gq = (float*)(w8 + L.gq);
     float* gA = (float*)(w8 + L.gA); float* gs = (float*)(w8 + L.gs); float* gz2 = (float*)(w8 + L.gz2);
     float* Hb = (float*)(w8 + L.Hb); float* Qb = (float*)(w8 + L.Qb); float* gH = (float*)(w8 + L.gH);
+    float* gqp = (float*)(w8 + L.gqp);
+    bf16_t* wsplit = (bf16_t*)(w8 + L.wsplit); bf16_t* w2t = (bf16_t*)(w8 + L.w2t);
+    float* part0 = (float*)(w8 + L.part0); float* part1 = (float*)(w8 + L.part1);
+    float* pb0 = (float*)(w8 + L.pb0); float* pb1 = (float*)(w8 + L.pb1);
     float* part = (float*)(w8 + L.part); float* part_b = (float*)(w8 + L.part_b);
     int64_t* off = (int64_t*)(w8 + L.off);
-    const bool v4 = (K % 4 == 0) && (((uintptr_t)feats | (uintptr_t)p->q0_w | (uintptr_t)p->q0_b |
-                                      (uintptr_t)(p->nonlinear ? p->q2_w : p->q0_w)) % 16 == 0);
+    // the DMA tile needs 16-B aligned rows; K % 4 != 0 (MUSK: 166) takes the register-staged tile
+    const bool v4 = (K % 4 == 0) && (((uintptr_t)feats) % 16 == 0);
+    const bool w4 = (K % 4 == 0) && (((uintptr_t)feats | (uintptr_t)p->q0_w) % 16 == 0);
     const bool v4v = (Kv % 4 == 0) && ((uintptr_t)vals % 16 == 0);
     int rc;
-    // 1. head: gB, D, g_fcc_*, W2^T
+    // 0. plane-cut weights: W1 | W2 unless the forward's image was handed in; W2^T for the gH pipeline
+    const int nks = 2 * ((K + 31) / 32);
     hipLaunchKernelGGL(k_set_offsets, dim3(1), dim3(1), 0, st, off, (long long)N);
-    hipLaunchKernelGGL(k_bwd_prep, dim3(1), dim3(256), 0, st, p->fcc_w, Bm, g_pred, g_B, A, g_A, p->q2_w, gB, Dv,
-                       g->fcc_w, g->fcc_b, W2T, zero, (long long)N, Kv, C, p->nonlinear);
+    if (!packed_split) {
+        hipLaunchKernelGGL(k_pack_agg_split, dim3(240), dim3(256), 0, st, p->q0_w, p->nonlinear ? p->q2_w : nullptr, wsplit, K, nks, 0);
+        packed_split = wsplit;
+    }
+    if (p->nonlinear)
+        hipLaunchKernelGGL(k_pack_agg_split, dim3(48), dim3(256), 0, st, p->q2_w, (const float*)nullptr, w2t, QD, 8, 1);
+    // 1. head: gB, D, g_fcc_*
+    const long long nfcc = (long long)C * C * Kv;
+    hipLaunchKernelGGL(k_bwd_prep, dim3((unsigned)(1 + (nfcc + 1023) / 1024)), dim3(256), 0, st, p->fcc_w, Bm, g_pred, g_B, A, g_A,
+                       gB, Dv, g->fcc_w, g->fcc_b, zero, (long long)N, Kv, C);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     // 2. gA = V gB^T  (the forward's FCLayer kernel with W := gB, b := 0)
     rc = dsmil_fc_forward_rows(vals, N, Kv, C, gB, zero, gA, rowmap, stream);
     if (rc) return rc;
     // 3. critical queries
-    if (v4) hipLaunchKernelGGL(k_bwd_qrow<4>, dim3((unsigned)C), dim3(256), 0, st, feats, idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, K, p->nonlinear, rowmap);
-    else hipLaunchKernelGGL(k_bwd_qrow<1>, dim3((unsigned)C), dim3(256), 0, st, feats, idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, K, p->nonlinear, rowmap);
-    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    if (qmax_in) qmax = const_cast<float*>(qmax_in);
+    else {
+        if (w4) hipLaunchKernelGGL(k_bwd_qrow<4>, dim3((unsigned)C), dim3(256), 0, st, feats, idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, K, p->nonlinear, rowmap);
+        else hipLaunchKernelGGL(k_bwd_qrow<1>, dim3((unsigned)C), dim3(256), 0, st, feats, idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, K, p->nonlinear, rowmap);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    }
     // 4. per-row part on MFMA
     const int nw = (N / 128 >= 512) ? 4 : 1;
     BwdRowsArgs br{};
-    br.at = AttendArgs{feats, feats, nullptr, off, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, nullptr, nullptr, nullptr,
+    br.at = AttendArgs{feats, feats, (const bf16_t*)packed_split, off, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, nullptr, nullptr, nullptr,
                        K, K, C, p->nonlinear, 0, 0, rowmap};
-    br.A = A; br.gA = gA; br.g_A = g_A; br.Dv = Dv; br.gs = gs; br.gz2 = gz2; br.Hbuf = Hb; br.Qbuf = Qb;
-    if (nw == 4) rc = v4 ? launch_tile_kernel(k_bwd_rows<4, 4>, br, 4, N, st) : launch_tile_kernel(k_bwd_rows<4, 1>, br, 4, N, st);
-    else rc = v4 ? launch_tile_kernel(k_bwd_rows<1, 4>, br, 1, N, st) : launch_tile_kernel(k_bwd_rows<1, 1>, br, 1, N, st);
+    br.A = A; br.gA = gA; br.g_A = g_A; br.Dv = Dv; br.gs = gs; br.gz2 = gz2; br.Hbuf = Hb; br.Qbuf = Qb; br.gqp = gqp;
+    if (nw == 4) rc = v4 ? launch_tile_kernel(k_bwd_rows<4, 4>, br, 4, true, N, st) : launch_tile_kernel(k_bwd_rows<4, 1>, br, 4, false, N, st);
+    else rc = v4 ? launch_tile_kernel(k_bwd_rows<1, 4>, br, 1, true, N, st) : launch_tile_kernel(k_bwd_rows<1, 1>, br, 1, false, N, st);
     if (rc) return rc;
     // 5. gradient of the critical queries joins their rows
-    rc = tn_small(gs, Qb, N, C, QD, part, nullptr, gq, nullptr, L.splits, true, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_bwd_critical, dim3(1), dim3(QD), 0, st, idx, gq, Qb, gz2, C, p->nonlinear);
+    hipLaunchKernelGGL(k_bwd_critical, dim3(1), dim3(1024), 0, st, idx, gqp, Qb, gz2, gq, L.T32, C, p->nonlinear);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    TnArgs tn{};
+    tn.X = feats; tn.rowmap = rowmap; tn.N = N; tn.K = K; tn.R = L.R; tn.nx = L.nx;
+    tn.part0 = part0; tn.part1 = part1; tn.pb0 = pb0; tn.pb1 = pb1;
     if (p->nonlinear) {
         // 6. gH = (gz2 W2) [H > 0]
         GhArgs gh{};
-        gh.at = AttendArgs{gz2, gz2, nullptr, off, W2T, zero, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+        gh.at = AttendArgs{gz2, gz2, w2t, off, nullptr, zero, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                            QD, QD, C, 0, 0, 0, nullptr};
         gh.Hbuf = Hb; gh.gH = gH;
-        rc = (nw == 4) ? launch_tile_kernel(k_bwd_gh<4>, gh, 4, N, st) : launch_tile_kernel(k_bwd_gh<1>, gh, 1, N, st);
+        rc = (nw == 4) ? launch_tile_kernel(k_bwd_gh<4>, gh, 4, true, N, st) : launch_tile_kernel(k_bwd_gh<1>, gh, 1, true, N, st);
         if (rc) return rc;
-        // 7. weight gradients: contractions over instances
-        rc = tn_gemm(gz2, Hb, N, QD, part, part_b, g->q2_w, g->q2_b, L.splits, true, st);
-        if (rc) return rc;
-        rc = tn_gemm(gH, feats, N, K, part, part_b, g->q0_w, g->q0_b, L.splits, v4, st, rowmap);
-        if (rc) return rc;
+        tn.A0 = gH; tn.A1 = gz2; tn.Hb = Hb;
     } else {
-        rc = tn_gemm(gz2, feats, N, K, part, part_b, g->q0_w, g->q0_b, L.splits, v4, st, rowmap);
-        if (rc) return rc;
+        tn.A0 = gz2; tn.A1 = nullptr; tn.Hb = nullptr;
     }
-    // 8. instance stream (FCLayer)
+    // 7. weight gradients: contractions over instances, then the fixed-order reduction (+ the sparse FCLayer gradient)
+    hipLaunchKernelGGL(k_tn_split, dim3((unsigned)(L.nx + (p->nonlinear ? 2 : 0)), (unsigned)L.S), dim3(256), 0, st, tn);
+    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    // 8. dense instance stream (FCLayer): only when the caller has a dense upstream gradient on the instance logits
     if (g_classes) {
-        rc = tn_small(g_classes, feats, N, C, K, part, part_b, g->fc_w, g->fc_b, L.splits, v4, st, rowmap);
+        rc = tn_small(g_classes, feats, N, C, K, part, part_b, g->fc_w, g->fc_b, L.splits, w4, st, rowmap);
         if (rc) return rc;
     }
-    if (g_max) {   // the max-over-instances stream of the training objective: one row per class
-        hipLaunchKernelGGL(k_bwd_fc_sparse, dim3((unsigned)C), dim3(256), 0, st, feats, idx, g_max, g->fc_w, g->fc_b, K,
-                           g_classes ? 1 : 0, rowmap);
-        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
-    }
+    ReduceArgs ra{};
+    ra.part0 = part0; ra.part1 = part1; ra.pb0 = pb0; ra.pb1 = pb1;
+    ra.g_w0 = g->q0_w; ra.g_b0 = g->q0_b; ra.g_w1 = g->q2_w; ra.g_b1 = g->q2_b;
+    ra.S = L.S; ra.K = K; ra.nonlinear = p->nonlinear;
+    ra.feats = feats; ra.idx = idx; ra.g_max = g_max; ra.rowmap = rowmap; ra.g_fc_w = g->fc_w; ra.g_fc_b = g->fc_b;
+    ra.C = C; ra.accumulate = g_classes ? 1 : 0;
+    const long long nred = (long long)QD * K + (p->nonlinear ? QD * QD + 2 * QD : QD) + (g_max ? (long long)C * K + C : 0);
+    hipLaunchKernelGGL(k_bwd_reduce, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, st, ra);
+    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     // 9. gradient of the value rows (only when v is a trainable layer of the caller)
     if (g_vals) {
         const long long n4 = (long long)N * ((Kv + 3) / 4);
@@ -565,6 +827,152 @@ int dsmil_agg_backward_ex(const float* feats, const float* vals, int64_t N, cons
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
     return DSMIL_OK;
+}
+
+// workspace of dsmil_agg_train_step: the forward's, the backward's, and the step's own tensors
+struct StepWs {
+    size_t fwd, bwd, classes, A, B, pred, idx, mx, gpred, gmax, off, grads, total;
+    size_t fwd_bytes, bwd_bytes;
+    long long gelems;
+};
+StepWs step_layout(long long N, int K, int C, int nonlinear) {
+    StepWs s;
+    s.fwd_bytes = dsmil_agg_workspace_bytes(1, N, K, K, C);
+    s.bwd_bytes = bwd_layout(N, K, K, C, nonlinear).total;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t p = o; o = al(o + bytes); return p; };
+    s.fwd = take(s.fwd_bytes);
+    s.bwd = take(s.bwd_bytes);
+    s.classes = take((size_t)N * C * 4);
+    s.A = take((size_t)N * C * 4);
+    s.B = take((size_t)C * K * 4);
+    s.pred = take((size_t)C * 4);
+    s.idx = take((size_t)C * 8);
+    s.mx = take((size_t)C * 4);
+    s.gpred = take((size_t)C * 4);
+    s.gmax = take((size_t)C * 4);
+    s.off = take(2 * sizeof(int64_t));
+    // gradients in parameter order: fc_w, fc_b, q0_w, q0_b, q2_w, q2_b, fcc_w, fcc_b (each 256-B aligned)
+    s.grads = o;
+    const long long sizes[8] = {(long long)C * K, C, (long long)QD * K, QD, nonlinear ? QD * QD : 0, nonlinear ? QD : 0,
+                                (long long)C * C * K, C};
+    s.gelems = 0;
+    for (int i = 0; i < 8; ++i) { take((size_t)sizes[i] * 4); s.gelems += sizes[i]; }
+    s.total = o;
+    return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dsmil_agg_backward_workspace_bytes(int64_t N, int32_t K, int32_t Kv, int32_t C) {
+    if (N <= 0 || K <= 0 || Kv <= 0 || C <= 0) return 0;
+    return bwd_layout(N, K, Kv, C, 1).total;   // the nonlinear layout is the larger one
+}
+
+int dsmil_agg_backward(const float* feats, const float* vals, int64_t N, const dsmil_agg_params* p,
+                       const float* A, const float* Bm, const int64_t* idx, const float* g_classes,
+                       const float* g_pred, const float* g_A, const float* g_B, const dsmil_agg_grads* g,
+                       float* g_vals, void* ws, size_t ws_bytes, void* stream) {
+    return agg_backward_impl(feats, vals, N, p, A, Bm, idx, g_classes, nullptr, g_pred, g_A, g_B, g, g_vals, nullptr,
+                             ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+int dsmil_agg_backward_ex(const float* feats, const float* vals, int64_t N, const dsmil_agg_params* p,
+                          const float* A, const float* Bm, const int64_t* idx, const float* g_classes,
+                          const float* g_max, const float* g_pred, const float* g_A, const float* g_B,
+                          const dsmil_agg_grads* g, float* g_vals, const int64_t* rowmap, void* ws, size_t ws_bytes,
+                          void* stream) {
+    return agg_backward_impl(feats, vals, N, p, A, Bm, idx, g_classes, g_max, g_pred, g_A, g_B, g, g_vals, rowmap,
+                             ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+int dsmil_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const int64_t* numel, int64_t step, double lr, double beta1, double beta2,
+                    double eps, double weight_decay, void* stream) {
+    if (n_tensors <= 0 || n_tensors > DSMIL_ADAM_MAX_TENSORS || !params || !grads || !exp_avg || !exp_avg_sq || !numel || step <= 0)
+        return DSMIL_E_INVALID;
+    AdamTensors t{};
+    long long tot = 0;
+    int n = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (numel[i] < 0) return DSMIL_E_INVALID;
+        if (numel[i] == 0) continue;
+        if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]) return DSMIL_E_INVALID;
+        tot += numel[i];
+        t.p[n] = params[i]; t.g[n] = grads[i]; t.m[n] = exp_avg[i]; t.v[n] = exp_avg_sq[i]; t.end[n] = tot;
+        ++n;
+    }
+    if (n == 0) return DSMIL_OK;
+    t.n = n;
+    for (int i = n; i < DSMIL_ADAM_MAX_TENSORS; ++i) t.end[i] = tot;
+    // scalars formed in double, as torch forms them from Python floats, then handed to the kernel as fp32
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, (float)(lr / bc1),
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)sqrt(bc2));
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
+size_t dsmil_agg_train_step_workspace_bytes(int64_t N, int32_t K, int32_t C, int32_t nonlinear) {
+    if (N <= 0 || K <= 0 || C <= 0) return 0;
+    return step_layout(N, K, C, nonlinear).total;
+}
+
+int dsmil_agg_train_step(const float* feats, int64_t N, const int64_t* row_map, const float* label,
+                         const dsmil_agg_params* p, const dsmil_adam_state* opt, float* loss, void* ws,
+                         size_t ws_bytes, void* stream) {
+    if (!feats || !label || !p || !opt || !loss || !ws || N <= 0) return DSMIL_E_INVALID;
+    if (p->K <= 0 || p->C <= 0 || p->Kv != p->K) return DSMIL_E_INVALID;
+    if (p->C > 64) return DSMIL_E_UNSUPPORTED;
+    if (!p->fc_w || !p->fc_b || !p->q0_w || !p->q0_b || !p->fcc_w || !p->fcc_b || (p->nonlinear && (!p->q2_w || !p->q2_b)))
+        return DSMIL_E_INVALID;
+    if ((uintptr_t)ws % 256) return DSMIL_E_ALIGN;
+    const int K = p->K, C = p->C;
+    const StepWs L = step_layout(N, K, C, p->nonlinear);
+    if (ws_bytes < L.total) return DSMIL_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* w8 = (char*)ws;
+    float* classes = (float*)(w8 + L.classes); float* A = (float*)(w8 + L.A); float* Bm = (float*)(w8 + L.B);
+    float* pred = (float*)(w8 + L.pred); int64_t* idx = (int64_t*)(w8 + L.idx); float* mx = (float*)(w8 + L.mx);
+    float* gpred = (float*)(w8 + L.gpred); float* gmax = (float*)(w8 + L.gmax); int64_t* off = (int64_t*)(w8 + L.off);
+    // gradient tensors in parameter order
+    const long long sizes[8] = {(long long)C * K, C, (long long)QD * K, QD, p->nonlinear ? QD * QD : 0, p->nonlinear ? QD : 0,
+                                (long long)C * C * K, C};
+    float* gr[8];
+    {
+        size_t o = L.grads;
+        for (int i = 0; i < 8; ++i) { gr[i] = (float*)(w8 + o); o = al(o + (size_t)sizes[i] * 4); }
+    }
+    hipLaunchKernelGGL(k_set_offsets, dim3(1), dim3(1), 0, st, off, (long long)N);
+    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    // forward (train_tcga.py:67) — its plane-cut weights and q_max stay in its workspace for the backward
+    dsmil_agg_opts fo{};
+    fo.row_map = row_map;
+    int rc = dsmil_agg_forward_ex(feats, nullptr, off, 1, N, N, p, &fo, nullptr, classes, A, Bm, pred, idx, w8 + L.fwd,
+                                  L.fwd_bytes, stream);
+    if (rc) return rc;
+    // loss = 0.5 BCE(bag) + 0.5 BCE(max instance) and both upstream gradients (train_tcga.py:68-71)
+    rc = dsmil_agg_loss_head(classes, pred, idx, label, C, loss, mx, gpred, gmax, stream);
+    if (rc) return rc;
+    // backward (train_tcga.py:72)
+    dsmil_agg_grads g{};
+    g.fc_w = gr[0]; g.fc_b = gr[1]; g.q0_w = gr[2]; g.q0_b = gr[3]; g.q2_w = p->nonlinear ? gr[4] : nullptr;
+    g.q2_b = p->nonlinear ? gr[5] : nullptr; g.fcc_w = gr[6]; g.fcc_b = gr[7];
+    const void* packed = nullptr;
+    const float* qmax = nullptr;
+    dsmil_agg_forward_leftovers(w8 + L.fwd, 1, N, K, K, C, &packed, &qmax);
+    rc = agg_backward_impl(feats, nullptr, N, p, A, Bm, idx, nullptr, gmax, gpred, nullptr, nullptr, &g, nullptr, row_map,
+                           w8 + L.bwd, L.bwd_bytes, stream, dsmil_agg_mlp_form() == NP_BWD ? packed : nullptr, qmax);
+    if (rc) return rc;
+    // optimizer.step() (train_tcga.py:73): Adam over the eight tensors in one launch
+    float* params[8] = {const_cast<float*>(p->fc_w), const_cast<float*>(p->fc_b), const_cast<float*>(p->q0_w),
+                        const_cast<float*>(p->q0_b), const_cast<float*>(p->q2_w), const_cast<float*>(p->q2_b),
+                        const_cast<float*>(p->fcc_w), const_cast<float*>(p->fcc_b)};
+    int64_t numel[8];
+    for (int i = 0; i < 8; ++i) numel[i] = sizes[i];
+    return dsmil_adam_step(8, params, (const float* const*)gr, opt->exp_avg, opt->exp_avg_sq, numel, opt->step, opt->lr,
+                           opt->beta1, opt->beta2, opt->eps, opt->weight_decay, stream);
 }
 
 }  // extern "C"

@@ -10,6 +10,12 @@
 int dsmil_fc_forward_rows(const float* feats, int64_t total_rows, int32_t K, int32_t C, const float* fc_w,
                           const float* fc_b, float* classes, const int64_t* rowmap, void* stream);
 
+// library-internal (defined in agg_fwd.hip): what a finished fp32 dsmil_agg_forward(_ex) call leaves in its workspace for
+// the backward of the same bag — the plane-cut query weights (null if the forward did not cut them: caller-supplied
+// packed_split, or an MFMA form without planes) and q_max [n_bags, C, 128]
+void dsmil_agg_forward_leftovers(void* ws, int32_t n_bags, int64_t total_rows, int32_t K, int32_t Kv, int32_t C,
+                                 const void** packed_split, const float** qmax);
+
 namespace {
 
 

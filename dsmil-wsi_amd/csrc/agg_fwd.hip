@@ -1129,6 +1129,13 @@ int dsmil_fc_forward_rows(const float* feats, int64_t total_rows, int32_t K, int
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
+void dsmil_agg_forward_leftovers(void* ws, int32_t n_bags, int64_t total_rows, int32_t K, int32_t Kv, int32_t C,
+                                 const void** packed_split, const float** qmax) {
+    const WsLayout L = ws_layout(n_bags, total_rows, total_rows, K, Kv, C, pick_nw(n_bags, total_rows) * 32);
+    if (packed_split) *packed_split = (pick_nw(n_bags, total_rows) != 8 && mlp_mode()) ? (const void*)((char*)ws + L.wsplit) : nullptr;
+    if (qmax) *qmax = (const float*)((char*)ws + L.qmax);
+}
+
 extern "C" {
 
 int dsmil_abi_version(void) { return DSMIL_ABI_VERSION; }

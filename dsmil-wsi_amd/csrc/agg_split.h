@@ -55,8 +55,14 @@ __device__ __forceinline__ void split3(const float (&x)[8], S3Frag (&o)[3]) {
 
 // Same contract as mlp_tile (agg_common.h) except that only Q is returned and the query weights
 // come from the packed planes in a.wpk: [nks + 8 (nonlinear)] chunks of S3_CHUNK_F4 float4.
-template <int NW, int VEC, int NP>
-__device__ __forceinline__ bool mlp_tile_split(const AttendArgs& a, int bag, int tile, float* smem, f32x16 (&Q)[4]) {
+// `on_h(H)` is called with the hidden layer (after bias + ReLU) while it is still in the accumulator registers — the
+// backward stores it there (agg_bwd.hip); the default does nothing.
+struct S3NoHook {
+    __device__ __forceinline__ void operator()(const f32x16 (&)[4]) const {}
+};
+template <int NW, int VEC, int NP, typename OnH = S3NoHook>
+__device__ __forceinline__ bool mlp_tile_split(const AttendArgs& a, int bag, int tile, float* smem, f32x16 (&Q)[4],
+                                               OnH on_h = OnH()) {
     static_assert(NP == 6 || NP == 9, "plane products");
     constexpr int T = NW * 64;
     constexpr int BM = NW * 32;
@@ -162,6 +168,7 @@ __device__ __forceinline__ bool mlp_tile_split(const AttendArgs& a, int bag, int
                 H[t][4 * g + e] = a.nonlinear ? fmaxf(v, 0.f) : v;
             }
         }
+    on_h(H);
     if (!a.nonlinear) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) Q[t] = H[t];
@@ -243,8 +250,9 @@ __device__ __forceinline__ void s3_wait_vm_dyn(int n) {  // n is wave-uniform
 // XE ("x early"): feature chunk c+2 is issued at the ODD step 2c+1 (its buffer, chunk c's, was last read in the
 // middle of step 2c by this very wave) instead of chunk c+1 at the even step 2c: the HBM-sourced pieces get a full
 // extra step (~1000+ cycles) of flight before their first read.
-template <int NW, int NP, bool XE = false>
-__device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag, int tile, float* smem, f32x16 (&Q)[4]) {
+template <int NW, int NP, bool XE = false, typename OnH = S3NoHook>
+__device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag, int tile, float* smem, f32x16 (&Q)[4],
+                                                   OnH on_h = OnH()) {
     static_assert(NP == 6 || NP == 9, "plane products");
     constexpr int BM = NW * 32;
     constexpr int X_TILE = BM * 32;       // floats per feature buffer (128 B per row, no padding)
@@ -480,6 +488,7 @@ __device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag,
                 H[t][4 * g + e] = a.nonlinear ? fmaxf(v, 0.f) : v;
             }
         }
+    on_h(H);
     if (!a.nonlinear) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) Q[t] = H[t];
@@ -527,8 +536,10 @@ __device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag,
 // fp32 query weights -> three truncated bf16 planes in MFMA-fragment order.
 //   chunk s < nks (GEMM 1):  [t][p][lane (l31,hi)][e] = plane_p(W1[32t + l31][16s + 8hi + e])   (0 past K)
 //   chunk nks + 2t + sx:     [t2][p][lane][e] = plane_p(W2[32t2 + l31][32t + 16sx + (e&3) + 8(e>>2) + 4hi])
+// tr != 0: the first matrix is read TRANSPOSED — element (row j, column k) = q0_w[k * QD + j] (K = 128): the backward's
+// gH = gz2 W2 runs the GEMM-1 pipeline with W := W2^T without materialising the transpose.
 __global__ void k_pack_agg_split(const float* __restrict__ q0_w, const float* __restrict__ q2_w,
-                                 bf16_t* __restrict__ out, int K, int nks) {
+                                 bf16_t* __restrict__ out, int K, int nks, int tr = 0) {
     const long long per = (long long)S3_CHUNK_F4 * 8;  // bf16 per chunk
     const long long total = (long long)(nks + (q2_w ? 8 : 0)) * per;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -541,7 +552,7 @@ __global__ void k_pack_agg_split(const float* __restrict__ q0_w, const float* __
         float v;
         if (s < nks) {
             const int k = 16 * s + 8 * hi + e;
-            v = k < K ? q0_w[(long long)(32 * t + l31) * K + k] : 0.f;
+            v = k < K ? (tr ? q0_w[(long long)k * QD + (32 * t + l31)] : q0_w[(long long)(32 * t + l31) * K + k]) : 0.f;
         } else {
             const int st = s - nks, tt = st >> 1, sx = st & 1;
             v = q2_w[(32 * t + l31) * QD + 32 * tt + 16 * sx + (e & 3) + 8 * (e >> 2) + 4 * hi];

@@ -474,6 +474,51 @@ def agg_backward(feats, w, A, B, idx, g_pred, g_classes=None, g_A=None, g_B=None
     return out
 
 
+def agg_train_step(feats, label, params, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay, nonlinear=True,
+                   row_map=None, loss_out=None):
+    """dsmil_agg_train_step: one train_tcga.py:60-75 step (forward, 0.5 BCE(bag) + 0.5 BCE(max instance), backward,
+    Adam) as ONE native call.  ``params`` / ``exp_avg`` / ``exp_avg_sq``: the eight tensors in the order fc_w, fc_b, q0_w,
+    q0_b, q2_w, q2_b, fcc_w, fcc_b (None for q2_* of a linear query) — parameters and moments are updated IN PLACE.
+    ``step`` = 1-based index of this update.  Returns the loss as a 1-element device tensor (no host sync)."""
+    feats = _f32c(feats, "feats")
+    dev = feats.device
+    rows, K = feats.shape
+    row_map = _i64c(row_map, "row_map")
+    N = int(row_map.numel()) if row_map is not None else rows
+    label = _f32c(label.reshape(-1).to(torch.float32), "label")
+    C = int(label.numel())
+    for t in list(params) + list(exp_avg) + list(exp_avg_sq):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("agg_train_step: parameters and Adam moments must be contiguous fp32 CUDA tensors")
+    ptr = lambda t: (t.data_ptr() if t is not None else 0)
+    p = _native.AggParams(*[ptr(t) for t in params], K, K, C, 1 if nonlinear else 0)
+    arr = ctypes.c_void_p * 8
+    m_arr, v_arr = arr(*[ptr(t) for t in exp_avg]), arr(*[ptr(t) for t in exp_avg_sq])
+    st = _native.AdamState(ctypes.cast(m_arr, ctypes.POINTER(ctypes.c_void_p)), ctypes.cast(v_arr, ctypes.POINTER(ctypes.c_void_p)),
+                           int(step), float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay))
+    loss = loss_out if loss_out is not None else torch.empty((1,), dtype=torch.float32, device=dev)
+    L = _native.lib()
+    ws = _workspace(dev, L.dsmil_agg_train_step_workspace_bytes(N, K, C, 1 if nonlinear else 0))
+    with torch.cuda.device(dev):
+        rc = L.dsmil_agg_train_step(_ptr(feats), N, _ptr(row_map), _ptr(label), ctypes.byref(p), ctypes.byref(st), _ptr(loss),
+                                    _ptr(ws), ws.numel(), _stream(dev))
+    _native.check(rc, "dsmil_agg_train_step")
+    return loss
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay):
+    """dsmil_adam_step: torch.optim.Adam's update (amsgrad = maximize = False) of up to 8 tensors in one launch, in place."""
+    n = len(params)
+    arr = ctypes.c_void_p * n
+    cast = lambda ts: ctypes.cast(arr(*[t.data_ptr() for t in ts]), ctypes.POINTER(ctypes.c_void_p))
+    numel = (ctypes.c_int64 * n)(*[int(t.numel()) for t in params])
+    dev = params[0].device
+    with torch.cuda.device(dev):
+        rc = _native.lib().dsmil_adam_step(n, cast(params), cast(grads), cast(exp_avg), cast(exp_avg_sq), numel, int(step),
+                                           float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), _stream(dev))
+    _native.check(rc, "dsmil_adam_step")
+
+
 # ---------------------------------------------------------------------------------------------
 # patch embedder (ResNet-18 + InstanceNorm) — compute_feats.py:146-170,211 / dsmil.py:21-25
 # ---------------------------------------------------------------------------------------------

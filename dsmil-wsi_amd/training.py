@@ -112,6 +112,90 @@ def bag_loss(milnet, criterion, bag_feats, bag_label, row_map=None):
     return loss, bag_prediction, max_prediction
 
 
+class FusedTrainStep:
+    """train_tcga.py:60-75 as ONE native call per bag (dsmil_agg_train_step): forward, the two-BCE objective, backward and
+    the Adam update of all parameter tensors are enqueued by a single C call — the Python side of a step is that call plus
+    the loss read-back of the progress line.  Numerically it is the step the generic path takes (same kernels, same Adam
+    arithmetic as torch.optim.Adam's; tests/test_agg_bwd_gpu.py compares the two trajectories).
+
+    Eligible (``FusedTrainStep.create`` returns None otherwise, and ``train`` keeps the generic autograd path):
+    MILNet(FCLayer, BClassifier) with v = Identity on a GPU, every parameter trainable fp32, the stock
+    BCEWithLogitsLoss, and a plain torch.optim.Adam (one parameter group holding exactly the model's parameters; amsgrad,
+    maximize, capturable, differentiable off).  The optimiser's own state tensors (exp_avg, exp_avg_sq) are updated in
+    place, ``step`` is written back by ``sync()`` — so optimizer.state_dict(), LR schedulers and a later generic step see a
+    consistent optimiser.  ``.grad`` is not populated (as after zero_grad(set_to_none=True))."""
+
+    def __init__(self, milnet, optimizer, params):
+        self.net, self.opt, self.params = milnet, optimizer, params
+        self.group = optimizer.param_groups[0]
+        self.m, self.v, steps = [], [], []
+        for p in params:
+            if p is None:
+                self.m.append(None); self.v.append(None)
+                continue
+            st = optimizer.state[p]
+            if len(st) == 0:   # what torch.optim.Adam._init_group creates on a parameter's first step
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            self.m.append(st["exp_avg"]); self.v.append(st["exp_avg_sq"])
+            steps.append(int(float(st["step"])))
+        if len(set(steps)) != 1:
+            raise RuntimeError("Adam state with different step counts per parameter")
+        self.step = steps[0]
+        self.nonlinear = milnet.b_classifier.nonlinear
+        self._live = [p for p in params if p is not None] + [t for t in self.m + self.v if t is not None]
+
+    @staticmethod
+    def create(milnet, criterion, optimizer):
+        from .modules import BClassifier, FCLayer
+        try:
+            ic, bc = milnet.i_classifier, milnet.b_classifier
+            if not (isinstance(ic, FCLayer) and isinstance(bc, BClassifier)) or bc.passing_v or not _is_plain_bce(criterion):
+                return None
+            if type(optimizer) is not torch.optim.Adam or len(optimizer.param_groups) != 1:
+                return None
+            g = optimizer.param_groups[0]
+            if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
+                return None
+            w = bc._weights()
+            lin = ic.fc[0]
+            params = [lin.weight, lin.bias, w["q0_w"], w["q0_b"], w["q2_w"], w["q2_b"], w["fcc_w"], w["fcc_b"]]
+            live = [p for p in params if p is not None]
+            if {id(p) for p in live} != {id(p) for p in g["params"]} or len(live) != len(list(milnet.parameters())):
+                return None
+            if not all(p.is_cuda and p.dtype == torch.float32 and p.requires_grad and p.is_contiguous() for p in live):
+                return None
+            if lin.out_features > 64:
+                return None
+            return FusedTrainStep(milnet, optimizer, params)
+        except (AttributeError, KeyError):
+            return None
+
+    def accepts(self, bag_feats):
+        return bag_feats.is_cuda and bag_feats.dtype == torch.float32 and bag_feats.dim() == 2 and bag_feats.is_contiguous()
+
+    def __call__(self, bag_feats, bag_label, row_map=None):
+        """One optimiser step on one bag; returns the loss (0-dim device tensor, detached)."""
+        from . import ops
+        g = self.group
+        self.step += 1
+        with torch.no_grad():
+            loss = ops.agg_train_step(bag_feats, bag_label, [p.data if p is not None else None for p in self.params], self.m,
+                                      self.v, self.step, g["lr"], g["betas"], g["eps"], g["weight_decay"],
+                                      nonlinear=self.nonlinear, row_map=row_map)
+        # the kernels wrote the parameters through raw pointers: tell torch (version counters key the packed-weight caches
+        # of the inference path, and autograd's saved-tensor checks)
+        torch.autograd.graph.increment_version(self._live)
+        return loss.reshape(())
+
+    def sync(self):
+        """Write the step count back into the optimiser's state (torch keeps it as a CPU float tensor per parameter)."""
+        for p in self.params:
+            if p is not None:
+                self.opt.state[p]["step"] = torch.tensor(float(self.step), dtype=torch.float32)
+
+
 def train(args, train_df, milnet, criterion, optimizer, cache=None, log=True):
     """train_tcga.py:55-76: one optimiser step per bag, bags in random order."""
     from sklearn.utils import shuffle
@@ -121,16 +205,23 @@ def train(args, train_df, milnet, criterion, optimizer, cache=None, log=True):
     total_loss = 0.0
     dirs = shuffle(list(train_df))
     losses = []
+    # the whole step as one native call when the model / criterion / optimiser are the reference's (FusedTrainStep)
+    fused = FusedTrainStep.create(milnet, criterion, optimizer) if getattr(args, "fused_step", True) else None
     for i, item in enumerate(dirs):
-        optimizer.zero_grad()
         bag_feats, bag_label = cache.get(item, args.feats_size)
         rows = dropout_rows(bag_feats.size(0), 1 - args.dropout_patch, bag_feats.device)
-        loss, _, _ = bag_loss(milnet, criterion, bag_feats, bag_label, rows)
-        loss.backward()
-        optimizer.step()
+        if fused is not None and fused.accepts(bag_feats):
+            loss = fused(bag_feats, bag_label, rows)
+        else:
+            optimizer.zero_grad()
+            loss, _, _ = bag_loss(milnet, criterion, bag_feats, bag_label, rows)
+            loss.backward()
+            optimizer.step()
         losses.append(loss.detach())
         if log:   # the progress line is the only host sync of a step (train_tcga.py:74-75 syncs twice per step)
             sys.stdout.write("\r Training bag [%d/%d] bag loss: %.4f" % (i, len(dirs), loss.item()))
+    if fused is not None:
+        fused.sync()
     if losses:
         total_loss = float(torch.stack(losses).sum().item())
     return total_loss / max(1, len(dirs))

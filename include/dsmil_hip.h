@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSMIL_ABI_VERSION 2
+#define DSMIL_ABI_VERSION 3
 #define DSMIL_Q_DIM 128 /* query width hard-coded at dsmil.py:31,33 */
 
 enum {
@@ -203,6 +203,42 @@ int dsmil_agg_backward(const float* feats, const float* vals, int64_t N, const d
                        const float* g_pred, const float* g_A, const float* g_B,
                        const dsmil_agg_grads* g, float* g_vals, void* ws, size_t ws_bytes,
                        void* stream);
+
+/* ---- one training step per C call (ABI 3) --------------------------------------------------------
+ * Replaces the body of the reference's training loop for one bag, train_tcga.py:60-75 (train_mil.py:44-56 likewise):
+ *     optimizer.zero_grad()
+ *     ins_prediction, bag_prediction, _, _ = milnet(bag_feats)                     (:67)
+ *     max_prediction, _ = torch.max(ins_prediction, 0)                             (:68)
+ *     loss = 0.5 * BCEWithLogitsLoss(bag_prediction, y) + 0.5 * BCEWithLogitsLoss(max_prediction, y)   (:69-71)
+ *     loss.backward(); optimizer.step()                                            (:72-73)
+ * with optimizer = torch.optim.Adam(milnet.parameters(), lr, betas, weight_decay) (:241; amsgrad = maximize = False).
+ * The forward, the loss head, the backward and ONE Adam kernel over the eight parameter tensors are enqueued on
+ * `stream`; nothing synchronises.  The parameters in *p are UPDATED IN PLACE (they are the optimiser's tensors), as
+ * are the moment tensors in *opt; `loss` (device, 1 float) receives the step's loss (the caller reads it for the
+ * progress line of :74 — the step's only host sync).
+ *   feats    device [rows, K] fp32, the bag;  row_map int64 [N] or NULL (dropout_patches, :78-83, as an index list)
+ *   N        instances that enter the bag (= rows when row_map is NULL)
+ *   label    device [C] fp32, the bag label (0/1)
+ *   p        MILNet(FCLayer, BClassifier) parameters, v = Identity (Kv == K), C <= 64
+ *   opt      Adam state: exp_avg / exp_avg_sq = 8 device pointers each in the order fc_w, fc_b, q0_w, q0_b, q2_w, q2_b,
+ *            fcc_w, fcc_b (the q2 entries are ignored when !nonlinear); step = the 1-based index of THIS update
+ *            (torch's state['step'] after its increment); hyper-parameters as Python floats (double)
+ *   ws       dsmil_agg_train_step_workspace_bytes(N, K, C, nonlinear) bytes, 256-B aligned
+ * dsmil_adam_step is the optimiser kernel alone (n_tensors <= DSMIL_ADAM_MAX_TENSORS; numel[i] == 0 skips entry i). */
+#define DSMIL_ADAM_MAX_TENSORS 8
+typedef struct dsmil_adam_state {
+    float* const* exp_avg;
+    float* const* exp_avg_sq;
+    int64_t step;
+    double lr, beta1, beta2, eps, weight_decay;
+} dsmil_adam_state;
+size_t dsmil_agg_train_step_workspace_bytes(int64_t N, int32_t K, int32_t C, int32_t nonlinear);
+int dsmil_agg_train_step(const float* feats, int64_t N, const int64_t* row_map, const float* label,
+                         const dsmil_agg_params* p, const dsmil_adam_state* opt, float* loss, void* ws,
+                         size_t ws_bytes, void* stream);
+int dsmil_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const int64_t* numel, int64_t step, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, void* stream);
 
 /* ---- patch embedder: ResNet-18 with InstanceNorm2d, fc = Identity --------------------------
  * Replaces the torchvision backbone that compute_feats.py:157,170 builds and dsmil.IClassifier

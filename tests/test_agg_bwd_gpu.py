@@ -241,3 +241,81 @@ def test_train_loop_uses_fused_objective_and_learns():
     assert losses[-1] < 0.8 * losses[0], losses
     tl, score, aucs, th = T.test(args, bags, net, crit, log=False)
     assert aucs[0] > 0.9, aucs   # seeded run (torch + numpy generators above): deterministic; 16 bags, one swapped pair is 1/64 of AUC
+
+
+def test_adam_kernel_matches_torch_adam():
+    """dsmil_adam_step against torch.optim.Adam (the optimiser of train_tcga.py:241) over several steps with weight decay:
+    same update to within a few fp32 roundings (the scalar factors are formed in double on both sides; torch runs the
+    update as a chain of foreach kernels, this is one fused expression per element)."""
+    from dsmil_wsi_amd import ops
+    g = torch.Generator().manual_seed(5)
+    shapes = [(2, 512), (2,), (128, 512), (128,), (128, 128), (128,), (2, 2, 512), (2,)]
+    ref = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+    ours = [p.detach().clone() for p in ref]
+    m = [torch.zeros_like(p) for p in ours]
+    v = [torch.zeros_like(p) for p in ours]
+    hp = dict(lr=2e-4, betas=(0.5, 0.9), eps=1e-8, weight_decay=1e-3)
+    opt = torch.optim.Adam(ref, **hp)
+    for step in range(1, 8):
+        grads = [(torch.randn(s, generator=g) * (10.0 ** (step % 3 - 1))).cuda() for s in shapes]
+        for p, gr in zip(ref, grads):
+            p.grad = gr.clone()
+        opt.step()
+        ops.adam_step(ours, grads, m, v, step, hp["lr"], hp["betas"], hp["eps"], hp["weight_decay"])
+        for a, b in zip(ours, ref):
+            np.testing.assert_allclose(a.cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-5, atol=2e-6)
+    for a, p in zip(m, ref):
+        np.testing.assert_allclose(a.cpu().numpy(), opt.state[p]["exp_avg"].cpu().numpy(), rtol=1e-5, atol=1e-7)
+    for a, p in zip(v, ref):
+        np.testing.assert_allclose(a.cpu().numpy(), opt.state[p]["exp_avg_sq"].cpu().numpy(), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag,N,drop", [("tcga", 3000, 0.0), ("c16", 10000, 0.0), ("tcga", 777, 0.4), ("musk", 150, 0.0),
+                                        ("linq", 400, 0.25), ("tree", 500, 0.0)])
+def test_fused_train_step_follows_the_generic_path(tag, N, drop):
+    """training.FusedTrainStep (ONE native call per train_tcga.py:60-75 step: forward + loss + backward + Adam) against the
+    generic path — MILNet.bag_loss under autograd, loss.backward(), torch.optim.Adam.step() — from the same start, on the
+    same bags and row maps: per-step losses to 1e-5, parameters after 6 steps to 1e-4 of their scale, and the optimiser
+    state (step count, moments) left consistent for a following generic step."""
+    from dsmil_wsi_amd import training as T
+    from util import build_net
+    K, C, nonlinear, _ = VARIANT[tag]
+    nets = [build_net(tag, "cuda").train() for _ in range(2)]
+    hp = dict(lr=1e-3, betas=(0.5, 0.9), weight_decay=1e-3)   # a larger lr than the default makes 6 steps move the weights
+    opts = [torch.optim.Adam(n.parameters(), **hp) for n in nets]
+    crit = torch.nn.BCEWithLogitsLoss()
+    fused = T.FusedTrainStep.create(nets[1], crit, opts[1])
+    assert fused is not None
+    gen = torch.Generator().manual_seed(11)
+    for step in range(6):
+        x = torch.from_numpy(make_bag(900 + step, N, K)).cuda()
+        y = torch.zeros(1, C).cuda()
+        y[0, step % C] = float(step % 2) if C == 1 else 1.0
+        keep = int(N * (1 - drop))
+        rows = torch.randperm(N, generator=gen)[:keep].cuda() if keep < N else None
+        opts[0].zero_grad()
+        l0, _, _ = T.bag_loss(nets[0], crit, x, y, rows)
+        l0.backward()
+        opts[0].step()
+        l1 = fused(x, y, rows)
+        assert abs(l0.item() - l1.item()) < 1e-5 * max(1.0, abs(l0.item())), (step, l0.item(), l1.item())
+    fused.sync()
+    for (n0, p0), (n1, p1) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        a, b = p0.detach().cpu().numpy(), p1.detach().cpu().numpy()
+        np.testing.assert_allclose(b, a, atol=1e-4 * max(1e-3, float(np.abs(a).max())), rtol=0, err_msg=n0)
+        s0, s1 = opts[0].state[p0], opts[1].state[p1]
+        assert float(s0["step"]) == float(s1["step"]) == 6.0
+        np.testing.assert_allclose(s1["exp_avg"].cpu().numpy(), s0["exp_avg"].cpu().numpy(),
+                                   atol=2e-4 * max(1e-6, float(s0["exp_avg"].abs().max())), rtol=0, err_msg=n0)
+    # the inference path sees the updated weights (the packed-weight caches are keyed on the version counters)
+    x = torch.from_numpy(make_bag(1, 300, K)).cuda()
+    with torch.no_grad():
+        o0, o1 = nets[0].eval()(x), nets[1].eval()(x)
+    np.testing.assert_allclose(o1[1].cpu().numpy(), o0[1].cpu().numpy(), atol=1e-4)
+    # and a generic step after the fused ones continues from the same optimiser state
+    nets[1].train()
+    opts[1].zero_grad()
+    l, _, _ = T.bag_loss(nets[1], crit, x, torch.ones(1, C).cuda())
+    l.backward()
+    opts[1].step()
+    assert float(opts[1].state[next(nets[1].parameters())]["step"]) == 7.0

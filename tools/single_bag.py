@@ -6,7 +6,7 @@ import time
 import torch
 import dsmil  # noqa: F401
 from dsmil_wsi_amd import ops
-from dsmil_wsi_amd.synthetic import load_weights  # noqa: E402
+from dsmil_wsi_amd.synthetic import load_weights
 tag = sys.argv[1] if len(sys.argv) > 1 else "c16"
 dt = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.float32
 w = {k: torch.from_numpy(v).cuda() for k, v in load_weights(tag).items()}
