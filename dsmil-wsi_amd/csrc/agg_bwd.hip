@@ -36,6 +36,7 @@
 #include <math.h>
 #include "agg_common.h"
 #include "agg_split.h"
+#include "agg_hs.h"
 #include "lds_attr.h"
 
 namespace {
@@ -59,14 +60,50 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 // ---- k_bwd_prep ----------------------------------------------------------------------------
-// block 0: gB, D, g_fcc_b, the zero bias of the gH pipeline; blocks 1..: g_fcc_w = g_pred (x) B, 1024 elements each
+// block 0: gB, D, g_fcc_b, the zero bias of the gH pipeline; blocks 1..: g_fcc_w = g_pred (x) B, 1024 elements each.
+// With `lh.label` set (dsmil_agg_train_step) the kernel FIRST forms the training objective of the bag and its two logit
+// gradients — what dsmil_agg_loss_head does (train_tcga.py:67-71) — so the step needs no separate loss-head launch: every
+// block derives g_pred for itself (C values), block 0 publishes loss / max_pred / g_pred / g_max.
+struct LossHeadArgs {
+    const float* label;     // [C] or null: g_pred comes from the caller
+    const float* classes;   // [N,C]
+    const float* pred;      // [C]
+    const int64_t* idx;     // [C]
+    float* loss; float* max_pred; float* g_pred_out; float* g_max_out;
+};
 __global__ __launch_bounds__(256) void k_bwd_prep(
-    const float* __restrict__ fcc_w, const float* __restrict__ Bm, const float* __restrict__ g_pred,
+    const float* __restrict__ fcc_w, const float* __restrict__ Bm, const float* __restrict__ g_pred_in,
     const float* __restrict__ g_B, const float* __restrict__ A, const float* __restrict__ g_A,
     float* __restrict__ gB, float* __restrict__ Dv, float* __restrict__ g_fcc_w, float* __restrict__ g_fcc_b,
-    float* __restrict__ zero128, long long N, int Kv, int C) {
+    float* __restrict__ zero128, long long N, int Kv, int C, LossHeadArgs lh) {
     __shared__ float red[4];
+    __shared__ float s_gp[64];
     const int tid = threadIdx.x;
+    const float* g_pred = g_pred_in;
+    if (lh.label) {   // C <= 64: one wave (the arithmetic of k_loss_head, agg_fwd.hip)
+        if (tid < 64) {
+            float l = 0.f;
+            if (tid < C) {
+                const float y = lh.label[tid];
+                const float zb = lh.pred[tid], zm = lh.classes[lh.idx[tid] * (long long)C + tid];
+                const float lb = fmaxf(zb, 0.f) - zb * y + log1pf(expf(-fabsf(zb)));
+                const float lm = fmaxf(zm, 0.f) - zm * y + log1pf(expf(-fabsf(zm)));
+                l = 0.5f * (lb + lm) / (float)C;
+                const float sb = 1.f / (1.f + expf(-zb)), sm = 1.f / (1.f + expf(-zm));
+                const float gp = 0.5f * (sb - y) / (float)C;
+                s_gp[tid] = gp;
+                if (blockIdx.x == 0) {
+                    if (lh.max_pred) lh.max_pred[tid] = zm;
+                    lh.g_pred_out[tid] = gp;
+                    lh.g_max_out[tid] = 0.5f * (sm - y) / (float)C;
+                }
+            }
+            l = wave_sum(l);
+            if (blockIdx.x == 0 && tid == 0) *lh.loss = l;
+        }
+        __syncthreads();
+        g_pred = s_gp;
+    }
     if (blockIdx.x > 0) {
         const long long n = (long long)C * C * Kv, i0 = (long long)(blockIdx.x - 1) * 1024;
 #pragma unroll
@@ -94,6 +131,17 @@ __global__ __launch_bounds__(256) void k_bwd_prep(
     }
     if (tid < C) g_fcc_b[tid] = g_pred[tid];
     if (tid < QD) zero128[tid] = 0.f;
+}
+
+// ---- k_train_prologue: everything a training step needs before its first kernel, in one launch: the plane-cut query
+//      weights W1 | W2 (forward + backward), W2^T (backward) and the {0, N} offsets of the lone bag --------------------
+__global__ void k_train_prologue(const float* __restrict__ q0_w, const float* __restrict__ q2_w, bf16_t* __restrict__ wsplit,
+                                 bf16_t* __restrict__ w2t, int K, int nks, int64_t* __restrict__ off_a,
+                                 int64_t* __restrict__ off_b, long long N) {
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    pack_agg_split_range(q0_w, q2_w, wsplit, K, nks, 0, i0, stride);
+    if (q2_w) pack_agg_split_range(q2_w, nullptr, w2t, QD, 8, 1, i0, stride);
+    if (i0 == 0) { off_a[0] = 0; off_a[1] = N; off_b[0] = 0; off_b[1] = N; }
 }
 
 // ---- k_bwd_qrow: q_c = q(x[idx_c]) (dsmil.py:53-54), one workgroup per class ------------------
@@ -293,6 +341,97 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_bwd_rows(BwdRows
         }
 }
 
+// ---- the same two kernels on the hidden-split tile (agg_hs.h): few rows — a training step on one bag ----------------
+// 16 per-lane values summed over the 32 lanes of a half-wave (recursive halving, 15 exchanges); every lane ends with the
+// sum of index l31 >> 1
+__device__ __forceinline__ float halfwave_colsum16(const float (&v)[16], int l31) {
+    float a8[8], a4[4], a2[2];
+    {
+        const bool b = (l31 >> 4) & 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float send = b ? v[i] : v[i + 8], keep = b ? v[i + 8] : v[i];
+            a8[i] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    {
+        const bool b = (l31 >> 3) & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float send = b ? a8[i] : a8[i + 4], keep = b ? a8[i + 4] : a8[i];
+            a4[i] = keep + __shfl_xor(send, 8, 64);
+        }
+    }
+    {
+        const bool b = (l31 >> 2) & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float send = b ? a4[i] : a4[i + 2], keep = b ? a4[i + 2] : a4[i];
+            a2[i] = keep + __shfl_xor(send, 4, 64);
+        }
+    }
+    const bool b = (l31 >> 1) & 1;
+    const float send = b ? a2[0] : a2[1], keep = b ? a2[1] : a2[0];
+    const float a1 = keep + __shfl_xor(send, 2, 64);
+    return a1 + __shfl_xor(a1, 1, 64);
+}
+
+__global__ __launch_bounds__(256, 2) void k_bwd_rows_hs(BwdRowsArgs b) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AttendArgs& a = b.at;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const long long Nb = a.offsets[1] - a.offsets[0];
+    const long long row = (long long)blockIdx.x * 32 + l31;
+    const bool valid = row < Nb;
+    f32x16 Hw, Qw;
+    if (!mlp_tile_hs<NP_BWD>(a, 0, (int)blockIdx.x, smem, Hw, Qw)) return;
+    const long long rc = valid ? row : Nb - 1;
+    const int C = a.C, u0 = 32 * wave + 4 * hi;     // reg 4g+e <-> unit u0 + 8g + e
+    const float scale = 0.08838834764831845f;       // 1/sqrt(128)
+    float G[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) G[r] = 0.f;
+    for (int c = 0; c < C; ++c) {
+        float ga = b.gA[rc * C + c];
+        if (b.g_A) ga += b.g_A[rc * C + c];
+        const float gsc = valid ? b.A[rc * C + c] * (ga - b.Dv[c]) * scale : 0.f;
+        if (valid && hi == 0 && wave == 0) b.gs[row * C + c] = gsc;
+        const float* qm = a.qmax + (long long)c * QD + u0;
+        float v[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(qm + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                G[4 * g + e] = fmaf(gsc, u[e], G[4 * g + e]);
+                v[4 * g + e] = gsc * Qw[4 * g + e];
+            }
+        }
+        // this tile's share of g_q[c] = sum_n gs[n,c] Q[n,:] for the wave's 32 units
+        const float sum = halfwave_colsum16(v, l31);
+        if (!(l31 & 1)) {
+            const int i = l31 >> 1;   // register index 4g+e
+            b.gqp[((long long)blockIdx.x * C + c) * QD + u0 + 8 * (i >> 2) + (i & 3)] = sum;
+        }
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 gz, qv, hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float q = Qw[4 * g + e];
+            gz[e] = a.nonlinear ? G[4 * g + e] * (1.f - q * q) : G[4 * g + e];
+            qv[e] = q;
+            hv[e] = Hw[4 * g + e];
+        }
+        const long long o = row * QD + u0 + 8 * g;
+        *reinterpret_cast<f32x4*>(b.gz2 + o) = gz;
+        *reinterpret_cast<f32x4*>(b.Qbuf + o) = qv;
+        if (a.nonlinear) *reinterpret_cast<f32x4*>(b.Hbuf + o) = hv;
+    }
+}
+
 // g_q[c] = sum over the 32-row tiles of their partials (fixed order); gz2[idx_c] += g_q[c] (1 - Q[idx_c]^2): q_c IS row
 // idx_c of Q, so its gradient joins that row.  One workgroup of 1024 threads = 128 units x 8 strided tile groups.
 __global__ __launch_bounds__(1024) void k_bwd_critical(const int64_t* __restrict__ idx, const float* __restrict__ gqp,
@@ -344,6 +483,25 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_bwd_gh(GhArgs g)
         }
 }
 
+__global__ __launch_bounds__(256, 2) void k_bwd_gh_hs(GhArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x16 Hw, Qw;
+    if (!mlp_tile_hs<NP_BWD>(g.at, 0, (int)blockIdx.x, smem, Hw, Qw)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+    const long long Nb = g.at.offsets[1] - g.at.offsets[0];
+    const long long row = (long long)blockIdx.x * 32 + l31;
+    if (row >= Nb) return;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+        const long long o = row * QD + 32 * wave + 8 * gg + 4 * hi;
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(g.Hbuf + o);
+        f32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = hv[e] > 0.f ? Hw[4 * gg + e] : 0.f;
+        *reinterpret_cast<f32x4*>(g.gH + o) = out;
+    }
+}
+
 // ---- k_tn_split: contractions over the instance rows on bf16 MFMA (exact three-plane cuts, six products) -------
 //   part0[s][128][K]   = A0[rows of split s]^T x[rows]        (A0 = gH; gz2 for the linear query)
 //   part1[s][128][128] = A1[rows]^T Hbuf[rows]                (A1 = gz2; nonlinear query only)
@@ -368,15 +526,21 @@ struct TnArgs {
     float* pb0;   // [S][128]
     float* pb1;   // [S][128]
     long long N;
-    int K, R, nx;
+    int K, R, nx, nslab, S;
 };
 
+// 1-D grid of nslab x (S rounded up to 8) workgroups.  Workgroup L runs on XCD L % 8 (round-robin dispatch); the slabs of
+// ONE row range all read the same A rows, so they are given to consecutive workgroups of the SAME XCD — its L2 then serves
+// the A tile to nine of the ten slabs (with (slab, split) = (L % nslab, L / nslab) the slabs of a range sat on eight
+// different L2s: 75 MB of fabric reads per launch for 35 MB of operands).
 __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned sA[3 * QD * TN_LDW];
     __shared__ __attribute__((aligned(16))) unsigned sB[3 * 64 * TN_LDW];
     __shared__ float s_cs[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int slab = blockIdx.x, split = blockIdx.y;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int slab = q % a.nslab, split = xcd + 8 * (q / a.nslab);
+    if (split >= a.S) return;
     const bool is_h = slab >= a.nx;
     const float* Am = is_h ? a.A1 : a.A0;
     const float* Bm = is_h ? a.Hb : a.X;
@@ -389,19 +553,22 @@ __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
     const int u = tid & 127, ja = tid >> 7;
     const int cb = tid & 63, jb = tid >> 6;
     const bool bcol_ok = col0 + cb < ldb;
-    float ra[2][8], rb[8];
-    auto prefetch = [&](long long r0) {
+    // two register sets: the loads of steps s+1 AND s+2 are in flight while step s runs (one set ahead left every step
+    // waiting a full memory latency for its operands: 7 steps x ~4.5 us)
+    float ra[2][2][8], rb[2][8];
+    auto prefetch = [&](auto setc, long long r0) {
+        constexpr int SET = decltype(setc)::value;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const long long r = r0 + 8 * (ja + 2 * i) + e;
-                ra[i][e] = r < rend ? Am[r * QD + u] : 0.f;
+                ra[SET][i][e] = r < rend ? Am[r * QD + u] : 0.f;
             }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const long long r = r0 + 8 * jb + e;
-            rb[e] = (r < rend && bcol_ok) ? Bm[phys_row(bmap, r) * (long long)ldb + col0 + cb] : 0.f;
+            rb[SET][e] = (r < rend && bcol_ok) ? Bm[phys_row(bmap, r) * (long long)ldb + col0 + cb] : 0.f;
         }
     };
     f32x16 acc[2];
@@ -412,30 +579,30 @@ __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
     float colsum = 0.f;
     const int ct = wave & 1, up = wave >> 1;
     constexpr int P0 = 9 - NP_BWD;
-    prefetch(rbeg);
-    for (long long r0 = rbeg; r0 < rend; r0 += 32) {
+    auto step = [&](auto setc, long long r0) {
+        constexpr int SET = decltype(setc)::value;
         // cut the staged values into planes, transposed into LDS
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             S3Frag f[3];
-            split3(ra[i], f);
+            split3(ra[SET][i], f);
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 *reinterpret_cast<f32x4*>(&sA[(p * QD + u) * TN_LDW + 4 * (ja + 2 * i)]) = f[p].f;
             if (want_cs) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) colsum += ra[i][e];
+                for (int e = 0; e < 8; ++e) colsum += ra[SET][i][e];
             }
         }
         {
             S3Frag f[3];
-            split3(rb, f);
+            split3(rb[SET], f);
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 *reinterpret_cast<f32x4*>(&sB[(p * 64 + cb) * TN_LDW + 4 * jb]) = f[p].f;
         }
         __syncthreads();
-        if (r0 + 32 < rend) prefetch(r0 + 32);
+        prefetch(setc, r0 + 64);   // (rows past the range load nothing)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int j = 2 * ks + hi;    // this lane's 8-row group: MFMA k = 8 hi + i  <->  row 16 ks + 8 hi + i
@@ -454,6 +621,12 @@ __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
             }
         }
         __syncthreads();
+    };
+    prefetch(std::integral_constant<int, 0>{}, rbeg);
+    prefetch(std::integral_constant<int, 1>{}, rbeg + 32);
+    for (long long r0 = rbeg; r0 < rend; r0 += 64) {
+        step(std::integral_constant<int, 0>{}, r0);
+        if (r0 + 32 < rend) step(std::integral_constant<int, 1>{}, r0 + 32);
     }
     // D[m = unit][n = column]: lane holds column 32 ct + l31, units 32 (2 up + tt) + (r & 3) + 8 (r >> 2) + 4 hi
     const int col = col0 + 32 * ct + l31;
@@ -718,8 +891,9 @@ int agg_backward_impl(const float* feats, const float* vals, int64_t N, const ds
                       const float* A, const float* Bm, const int64_t* idx, const float* g_classes,
                       const float* g_max, const float* g_pred, const float* g_A, const float* g_B,
                       const dsmil_agg_grads* g, float* g_vals, const int64_t* rowmap, void* ws, size_t ws_bytes,
-                      void* stream, const void* packed_split, const float* qmax_in) {
-    if (!feats || !p || !A || !Bm || !idx || !g_pred || !g || !ws) return DSMIL_E_INVALID;
+                      void* stream, const void* packed_split, const float* qmax_in, bool prepared = false,
+                      const LossHeadArgs* lhp = nullptr) {
+    if (!feats || !p || !A || !Bm || !idx || (!g_pred && !lhp) || !g || !ws) return DSMIL_E_INVALID;
     if (g_max && (!g->fc_w || !g->fc_b)) return DSMIL_E_INVALID;
     if (N <= 0 || p->K <= 0 || p->Kv <= 0 || p->C <= 0) return DSMIL_E_INVALID;
     if (!p->q0_w || !p->q0_b || !p->fcc_w || (p->nonlinear && (!p->q2_w || !p->q2_b))) return DSMIL_E_INVALID;
@@ -750,18 +924,22 @@ int agg_backward_impl(const float* feats, const float* vals, int64_t N, const ds
     const bool v4v = (Kv % 4 == 0) && ((uintptr_t)vals % 16 == 0);
     int rc;
     // 0. plane-cut weights: W1 | W2 unless the forward's image was handed in; W2^T for the gH pipeline
+    // (`prepared`: dsmil_agg_train_step's prologue already filled wsplit, w2t and off of THIS workspace)
     const int nks = 2 * ((K + 31) / 32);
-    hipLaunchKernelGGL(k_set_offsets, dim3(1), dim3(1), 0, st, off, (long long)N);
-    if (!packed_split) {
-        hipLaunchKernelGGL(k_pack_agg_split, dim3(240), dim3(256), 0, st, p->q0_w, p->nonlinear ? p->q2_w : nullptr, wsplit, K, nks, 0);
+    if (prepared) packed_split = wsplit;
+    else if (packed_split && p->nonlinear) {
+        hipLaunchKernelGGL(k_train_prologue, dim3(48), dim3(256), 0, st, (const float*)nullptr, p->q2_w, wsplit, w2t, 0, 0, off, off, (long long)N);
+    } else if (!packed_split || p->nonlinear) {
+        hipLaunchKernelGGL(k_train_prologue, dim3(240), dim3(256), 0, st, p->q0_w, p->nonlinear ? p->q2_w : nullptr, wsplit, w2t, K, nks,
+                           off, off, (long long)N);
         packed_split = wsplit;
+    } else {
+        hipLaunchKernelGGL(k_set_offsets, dim3(1), dim3(1), 0, st, off, (long long)N);
     }
-    if (p->nonlinear)
-        hipLaunchKernelGGL(k_pack_agg_split, dim3(48), dim3(256), 0, st, p->q2_w, (const float*)nullptr, w2t, QD, 8, 1);
     // 1. head: gB, D, g_fcc_*
     const long long nfcc = (long long)C * C * Kv;
     hipLaunchKernelGGL(k_bwd_prep, dim3((unsigned)(1 + (nfcc + 1023) / 1024)), dim3(256), 0, st, p->fcc_w, Bm, g_pred, g_B, A, g_A,
-                       gB, Dv, g->fcc_w, g->fcc_b, zero, (long long)N, Kv, C);
+                       gB, Dv, g->fcc_w, g->fcc_b, zero, (long long)N, Kv, C, lhp ? *lhp : LossHeadArgs{});
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     // 2. gA = V gB^T  (the forward's FCLayer kernel with W := gB, b := 0)
     rc = dsmil_fc_forward_rows(vals, N, Kv, C, gB, zero, gA, rowmap, stream);
@@ -779,14 +957,21 @@ int agg_backward_impl(const float* feats, const float* vals, int64_t N, const ds
     br.at = AttendArgs{feats, feats, (const bf16_t*)packed_split, off, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, nullptr, nullptr, nullptr,
                        K, K, C, p->nonlinear, 0, 0, rowmap};
     br.A = A; br.gA = gA; br.g_A = g_A; br.Dv = Dv; br.gs = gs; br.gz2 = gz2; br.Hbuf = Hb; br.Qbuf = Qb; br.gqp = gqp;
+    auto launch_hs = [&](auto kern, const auto& arg) {   // hidden-split tile: 256 threads per 32 rows
+        if (!dsmil_lds::allow((const void*)kern, HS_LDS_BYTES)) return (int)DSMIL_E_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((N + 31) / 32)), dim3(256), HS_LDS_BYTES, st, arg);
+        return hipGetLastError() == hipSuccess ? (int)DSMIL_OK : (int)DSMIL_E_LAUNCH;
+    };
     if (nw == 4) rc = v4 ? launch_tile_kernel(k_bwd_rows<4, 4>, br, 4, true, N, st) : launch_tile_kernel(k_bwd_rows<4, 1>, br, 4, false, N, st);
-    else rc = v4 ? launch_tile_kernel(k_bwd_rows<1, 4>, br, 1, true, N, st) : launch_tile_kernel(k_bwd_rows<1, 1>, br, 1, false, N, st);
+    else if (v4) rc = launch_hs(k_bwd_rows_hs, br);
+    else rc = launch_tile_kernel(k_bwd_rows<1, 1>, br, 1, false, N, st);
     if (rc) return rc;
     // 5. gradient of the critical queries joins their rows
     hipLaunchKernelGGL(k_bwd_critical, dim3(1), dim3(1024), 0, st, idx, gqp, Qb, gz2, gq, L.T32, C, p->nonlinear);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     TnArgs tn{};
     tn.X = feats; tn.rowmap = rowmap; tn.N = N; tn.K = K; tn.R = L.R; tn.nx = L.nx;
+    tn.nslab = L.nx + (p->nonlinear ? 2 : 0); tn.S = L.S;
     tn.part0 = part0; tn.part1 = part1; tn.pb0 = pb0; tn.pb1 = pb1;
     if (p->nonlinear) {
         // 6. gH = (gz2 W2) [H > 0]
@@ -794,14 +979,14 @@ int agg_backward_impl(const float* feats, const float* vals, int64_t N, const ds
         gh.at = AttendArgs{gz2, gz2, w2t, off, nullptr, zero, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                            QD, QD, C, 0, 0, 0, nullptr};
         gh.Hbuf = Hb; gh.gH = gH;
-        rc = (nw == 4) ? launch_tile_kernel(k_bwd_gh<4>, gh, 4, true, N, st) : launch_tile_kernel(k_bwd_gh<1>, gh, 1, true, N, st);
+        rc = (nw == 4) ? launch_tile_kernel(k_bwd_gh<4>, gh, 4, true, N, st) : launch_hs(k_bwd_gh_hs, gh);
         if (rc) return rc;
         tn.A0 = gH; tn.A1 = gz2; tn.Hb = Hb;
     } else {
         tn.A0 = gz2; tn.A1 = nullptr; tn.Hb = nullptr;
     }
     // 7. weight gradients: contractions over instances, then the fixed-order reduction (+ the sparse FCLayer gradient)
-    hipLaunchKernelGGL(k_tn_split, dim3((unsigned)(L.nx + (p->nonlinear ? 2 : 0)), (unsigned)L.S), dim3(256), 0, st, tn);
+    hipLaunchKernelGGL(k_tn_split, dim3((unsigned)(tn.nslab * ((L.S + 7) / 8 * 8))), dim3(256), 0, st, tn);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     // 8. dense instance stream (FCLayer): only when the caller has a dense upstream gradient on the instance logits
     if (g_classes) {
@@ -944,26 +1129,31 @@ int dsmil_agg_train_step(const float* feats, int64_t N, const int64_t* row_map, 
         size_t o = L.grads;
         for (int i = 0; i < 8; ++i) { gr[i] = (float*)(w8 + o); o = al(o + (size_t)sizes[i] * 4); }
     }
-    hipLaunchKernelGGL(k_set_offsets, dim3(1), dim3(1), 0, st, off, (long long)N);
+    // prologue: plane-cut W1 | W2 and W2^T + the bag's offsets for the forward and the backward, one launch
+    const BwdWs LB = bwd_layout(N, K, K, C, p->nonlinear);
+    char* bw8 = w8 + L.bwd;
+    const bool planes = dsmil_agg_mlp_form() == NP_BWD;   // (experiment builds may run the forward in another MFMA form)
+    hipLaunchKernelGGL(k_train_prologue, dim3(240), dim3(256), 0, st, p->q0_w, p->nonlinear ? p->q2_w : nullptr,
+                       (bf16_t*)(bw8 + LB.wsplit), (bf16_t*)(bw8 + LB.w2t), K, 2 * ((K + 31) / 32), off, (int64_t*)(bw8 + LB.off),
+                       (long long)N);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
-    // forward (train_tcga.py:67) — its plane-cut weights and q_max stay in its workspace for the backward
+    // forward (train_tcga.py:67) — q_max stays in its workspace for the backward
     dsmil_agg_opts fo{};
     fo.row_map = row_map;
+    fo.packed_split = planes ? (const void*)(bw8 + LB.wsplit) : nullptr;
     int rc = dsmil_agg_forward_ex(feats, nullptr, off, 1, N, N, p, &fo, nullptr, classes, A, Bm, pred, idx, w8 + L.fwd,
                                   L.fwd_bytes, stream);
     if (rc) return rc;
-    // loss = 0.5 BCE(bag) + 0.5 BCE(max instance) and both upstream gradients (train_tcga.py:68-71)
-    rc = dsmil_agg_loss_head(classes, pred, idx, label, C, loss, mx, gpred, gmax, stream);
-    if (rc) return rc;
-    // backward (train_tcga.py:72)
+    // backward (train_tcga.py:72); its first kernel also forms loss = 0.5 BCE(bag) + 0.5 BCE(max instance) and both
+    // upstream gradients (train_tcga.py:68-71)
     dsmil_agg_grads g{};
     g.fc_w = gr[0]; g.fc_b = gr[1]; g.q0_w = gr[2]; g.q0_b = gr[3]; g.q2_w = p->nonlinear ? gr[4] : nullptr;
     g.q2_b = p->nonlinear ? gr[5] : nullptr; g.fcc_w = gr[6]; g.fcc_b = gr[7];
-    const void* packed = nullptr;
     const float* qmax = nullptr;
-    dsmil_agg_forward_leftovers(w8 + L.fwd, 1, N, K, K, C, &packed, &qmax);
+    dsmil_agg_forward_leftovers(w8 + L.fwd, 1, N, K, K, C, nullptr, &qmax);
+    const LossHeadArgs lh{label, classes, pred, idx, loss, mx, gpred, gmax};
     rc = agg_backward_impl(feats, nullptr, N, p, A, Bm, idx, nullptr, gmax, gpred, nullptr, nullptr, &g, nullptr, row_map,
-                           w8 + L.bwd, L.bwd_bytes, stream, dsmil_agg_mlp_form() == NP_BWD ? packed : nullptr, qmax);
+                           bw8, L.bwd_bytes, stream, nullptr, qmax, true, &lh);
     if (rc) return rc;
     // optimizer.step() (train_tcga.py:73): Adam over the eight tensors in one launch
     float* params[8] = {const_cast<float*>(p->fc_w), const_cast<float*>(p->fc_b), const_cast<float*>(p->q0_w),

@@ -40,6 +40,7 @@
 
 #include "agg_common.h"
 #include "agg_split.h"
+#include "agg_hs.h"
 #include "agg_res.h"
 #include "lds_attr.h"
 
@@ -814,6 +815,19 @@ __global__ void k_pack_agg_bf16(const float* __restrict__ q0_w, const float* __r
     }
 }
 
+// few rows (a lone bag, a training step): the hidden units of a 32-row tile split over the four SIMDs of a CU (agg_hs.h)
+template <int NP>
+__global__ __launch_bounds__(256, 2) void k_attend_hs(AttendArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bag = a.bag0 + (int)blockIdx.y, tile = (int)blockIdx.x;
+    f32x16 Hw, Qw;
+    if (!mlp_tile_hs<NP>(a, bag, tile, smem, Hw, Qw)) return;
+    const long long off0 = a.offsets[bag];
+    const long long Nb = a.offsets[bag + 1] - off0;
+    attend_tail_hs<float>(a, Qw, smem + HS_W_FLOATS + HS_X_FLOATS, smem + HS_W_FLOATS, bag, off0, Nb, (long long)tile * 32,
+                          off0 / 32 + bag + tile);
+}
+
 // --------------------------------------------------------------------------------------------
 // k_finish: per bag, combine tile partials (online-softmax merge), normalise A in place,
 // produce B (dsmil.py:57-59) and pred = Conv1d(C,C,Kv)(B) (dsmil.py:60-61).
@@ -1030,6 +1044,20 @@ int launch_attend_split(const AttendArgs& a, long long max_rows, int n_bags, hip
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
+int launch_attend_hs(const AttendArgs& a, long long max_rows, int n_bags, hipStream_t st) {
+    size_t lds = HS_LDS_BYTES;
+#ifdef DSMIL_EXPERIMENTS
+    static const int lds_pad = expt_env("DSMIL_LDS_PAD");  // force 1 block/CU
+    lds += (size_t)lds_pad;
+#endif
+    if (!dsmil_lds::allow((const void*)k_attend_hs<6>, (int)lds)) return DSMIL_E_LAUNCH;
+    dim3 grid((unsigned)((max_rows + 31) / 32), (unsigned)n_bags);
+    const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
+    hipLaunchKernelGGL(k_attend_hs<6>, grid, dim3(256), lds, st, a);
+    dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
 // Which MFMA form the fp32 query MLP uses (see agg_split.h).  Default: 6 plane products — the three left
 // out are together below 2^-20 of |x*w|, i.e. below the fp32 accumulation rounding the reference's own
 // 512-long dot products carry (tests/accuracy_report.py: identical measured error for 0 / 9 / 6).
@@ -1231,10 +1259,10 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     AttendArgs a{feats, vals, (const bf16_t*)packed_bf16, offsets, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, A,
                  part_ml, part_B, K, Kv, C, p->nonlinear, 0, 0, rowmap};
 #ifdef DSMIL_EXPERIMENTS
-    static const int expt = expt_env("DSMIL_EXPT"), logits_old = expt_env("DSMIL_LOGITS_OLD");
+    static const int expt = expt_env("DSMIL_EXPT"), logits_old = expt_env("DSMIL_LOGITS_OLD"), no_hs = expt_env("DSMIL_NO_HS");
     a.expt = expt;
 #else
-    constexpr int logits_old = 0;
+    constexpr int logits_old = 0, no_hs = 0;
 #endif
     int seg_per = 0, seg_T = 0;   // k_attend_bf16_res: partials per (workgroup, bag), see k_finish
     {
@@ -1312,6 +1340,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         else if (mode == 6 && NW == 1 && v4 && (a.expt & 8)) rc = launch_attend_split<1, 4, 6, true>(a, max_rows, nb, st);
 #endif
         else if (mode == 6 && NW == 4) rc = v4 ? launch_attend_split<4, 4, 6>(a, max_rows, nb, st) : launch_attend_split<4, 1, 6>(a, max_rows, nb, st);
+        else if (mode == 6 && v4 && !no_hs) rc = launch_attend_hs(a, max_rows, nb, st);   // few rows: hidden units split over the SIMDs
         else if (mode == 6) rc = v4 ? launch_attend_split<1, 4, 6>(a, max_rows, nb, st) : launch_attend_split<1, 1, 6>(a, max_rows, nb, st);
         else if (NW == 8) rc = launch_attend<8, 4>(a, max_rows, nb, st);
         else if (NW == 4) rc = v4 ? launch_attend<4, 4>(a, max_rows, nb, st) : launch_attend<4, 1>(a, max_rows, nb, st);

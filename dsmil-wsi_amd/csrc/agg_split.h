@@ -538,11 +538,12 @@ __device__ __forceinline__ bool mlp_tile_split_dma(const AttendArgs& a, int bag,
 //   chunk nks + 2t + sx:     [t2][p][lane][e] = plane_p(W2[32t2 + l31][32t + 16sx + (e&3) + 8(e>>2) + 4hi])
 // tr != 0: the first matrix is read TRANSPOSED — element (row j, column k) = q0_w[k * QD + j] (K = 128): the backward's
 // gH = gz2 W2 runs the GEMM-1 pipeline with W := W2^T without materialising the transpose.
-__global__ void k_pack_agg_split(const float* __restrict__ q0_w, const float* __restrict__ q2_w,
-                                 bf16_t* __restrict__ out, int K, int nks, int tr = 0) {
+__device__ __forceinline__ void pack_agg_split_range(const float* __restrict__ q0_w, const float* __restrict__ q2_w,
+                                                     bf16_t* __restrict__ out, int K, int nks, int tr, long long i0,
+                                                     long long stride) {
     const long long per = (long long)S3_CHUNK_F4 * 8;  // bf16 per chunk
     const long long total = (long long)(nks + (q2_w ? 8 : 0)) * per;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = i0; i < total; i += stride) {
         const int s = (int)(i / per);
         int r = (int)(i - s * per);
         const int e = r & 7; r >>= 3;
@@ -564,6 +565,11 @@ __global__ void k_pack_agg_split(const float* __restrict__ q0_w, const float* __
         const unsigned bits = p == 0 ? h : (p == 1 ? m : __float_as_uint(r2));
         out[i] = (bf16_t)(bits >> 16);
     }
+}
+__global__ void k_pack_agg_split(const float* __restrict__ q0_w, const float* __restrict__ q2_w,
+                                 bf16_t* __restrict__ out, int K, int nks, int tr = 0) {
+    pack_agg_split_range(q0_w, q2_w, out, K, nks, tr, (long long)blockIdx.x * blockDim.x + threadIdx.x,
+                         (long long)gridDim.x * blockDim.x);
 }
 
 }  // namespace
