@@ -376,59 +376,64 @@ __device__ __forceinline__ float halfwave_colsum16(const float (&v)[16], int l31
     return a1 + __shfl_xor(a1, 1, 64);
 }
 
-__global__ __launch_bounds__(256, 2) void k_bwd_rows_hs(BwdRowsArgs b) {
+__global__ __launch_bounds__(HS_THREADS, 2) void k_bwd_rows_hs(BwdRowsArgs b) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const AttendArgs& a = b.at;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const long long Nb = a.offsets[1] - a.offsets[0];
-    const long long row = (long long)blockIdx.x * 32 + l31;
-    const bool valid = row < Nb;
-    f32x16 Hw, Qw;
+    f32x16 Hw[HS_RG], Qw[HS_RG];
     if (!mlp_tile_hs<NP_BWD>(a, 0, (int)blockIdx.x, smem, Hw, Qw)) return;
-    const long long rc = valid ? row : Nb - 1;
-    const int C = a.C, u0 = 32 * wave + 4 * hi;     // reg 4g+e <-> unit u0 + 8g + e
+    const int C = a.C, u0 = 32 * wave + 4 * hi;     // reg 4q+e <-> unit u0 + 8q + e
     const float scale = 0.08838834764831845f;       // 1/sqrt(128)
-    float G[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) G[r] = 0.f;
-    for (int c = 0; c < C; ++c) {
-        float ga = b.gA[rc * C + c];
-        if (b.g_A) ga += b.g_A[rc * C + c];
-        const float gsc = valid ? b.A[rc * C + c] * (ga - b.Dv[c]) * scale : 0.f;
-        if (valid && hi == 0 && wave == 0) b.gs[row * C + c] = gsc;
-        const float* qm = a.qmax + (long long)c * QD + u0;
-        float v[16];
+    for (int g = 0; g < HS_RG; ++g) {
+        const long long row = (long long)blockIdx.x * HS_BM + 32 * g + l31;
+        const long long t32 = (long long)blockIdx.x * HS_RG + g;     // this group's 32-row tile
+        if (t32 * 32 >= Nb) break;                                   // (block-uniform)
+        const bool valid = row < Nb;
+        const long long rc = valid ? row : Nb - 1;
+        float G[16];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 u = *reinterpret_cast<const f32x4*>(qm + 8 * g);
+        for (int r = 0; r < 16; ++r) G[r] = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float ga = b.gA[rc * C + c];
+            if (b.g_A) ga += b.g_A[rc * C + c];
+            const float gsc = valid ? b.A[rc * C + c] * (ga - b.Dv[c]) * scale : 0.f;
+            if (valid && hi == 0 && wave == 0) b.gs[row * C + c] = gsc;
+            const float* qm = a.qmax + (long long)c * QD + u0;
+            float v[16];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                G[4 * g + e] = fmaf(gsc, u[e], G[4 * g + e]);
-                v[4 * g + e] = gsc * Qw[4 * g + e];
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(qm + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    G[4 * q + e] = fmaf(gsc, u[e], G[4 * q + e]);
+                    v[4 * q + e] = gsc * Qw[g][4 * q + e];
+                }
+            }
+            // this 32-row tile's share of g_q[c] = sum_n gs[n,c] Q[n,:] for the wave's 32 units
+            const float sum = halfwave_colsum16(v, l31);
+            if (!(l31 & 1)) {
+                const int i = l31 >> 1;   // register index 4q+e
+                b.gqp[(t32 * C + c) * QD + u0 + 8 * (i >> 2) + (i & 3)] = sum;
             }
         }
-        // this tile's share of g_q[c] = sum_n gs[n,c] Q[n,:] for the wave's 32 units
-        const float sum = halfwave_colsum16(v, l31);
-        if (!(l31 & 1)) {
-            const int i = l31 >> 1;   // register index 4g+e
-            b.gqp[((long long)blockIdx.x * C + c) * QD + u0 + 8 * (i >> 2) + (i & 3)] = sum;
-        }
-    }
-    if (!valid) return;
+        if (!valid) continue;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 gz, qv, hv;
+        for (int q = 0; q < 4; ++q) {
+            f32x4 gz, qv, hv;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float q = Qw[4 * g + e];
-            gz[e] = a.nonlinear ? G[4 * g + e] * (1.f - q * q) : G[4 * g + e];
-            qv[e] = q;
-            hv[e] = Hw[4 * g + e];
+            for (int e = 0; e < 4; ++e) {
+                const float qq = Qw[g][4 * q + e];
+                gz[e] = a.nonlinear ? G[4 * q + e] * (1.f - qq * qq) : G[4 * q + e];
+                qv[e] = qq;
+                hv[e] = Hw[g][4 * q + e];
+            }
+            const long long o = row * QD + u0 + 8 * q;
+            *reinterpret_cast<f32x4*>(b.gz2 + o) = gz;
+            *reinterpret_cast<f32x4*>(b.Qbuf + o) = qv;
+            if (a.nonlinear) *reinterpret_cast<f32x4*>(b.Hbuf + o) = hv;
         }
-        const long long o = row * QD + u0 + 8 * g;
-        *reinterpret_cast<f32x4*>(b.gz2 + o) = gz;
-        *reinterpret_cast<f32x4*>(b.Qbuf + o) = qv;
-        if (a.nonlinear) *reinterpret_cast<f32x4*>(b.Hbuf + o) = hv;
     }
 }
 
@@ -483,22 +488,25 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_bwd_gh(GhArgs g)
         }
 }
 
-__global__ __launch_bounds__(256, 2) void k_bwd_gh_hs(GhArgs g) {
+__global__ __launch_bounds__(HS_THREADS, 2) void k_bwd_gh_hs(GhArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x16 Hw, Qw;
+    f32x16 Hw[HS_RG], Qw[HS_RG];
     if (!mlp_tile_hs<NP_BWD>(g.at, 0, (int)blockIdx.x, smem, Hw, Qw)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
     const long long Nb = g.at.offsets[1] - g.at.offsets[0];
-    const long long row = (long long)blockIdx.x * 32 + l31;
-    if (row >= Nb) return;
 #pragma unroll
-    for (int gg = 0; gg < 4; ++gg) {
-        const long long o = row * QD + 32 * wave + 8 * gg + 4 * hi;
-        const f32x4 hv = *reinterpret_cast<const f32x4*>(g.Hbuf + o);
-        f32x4 out;
+    for (int rg = 0; rg < HS_RG; ++rg) {
+        const long long row = (long long)blockIdx.x * HS_BM + 32 * rg + l31;
+        if (row >= Nb) continue;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = hv[e] > 0.f ? Hw[4 * gg + e] : 0.f;
-        *reinterpret_cast<f32x4*>(g.gH + o) = out;
+        for (int q = 0; q < 4; ++q) {
+            const long long o = row * QD + 32 * wave + 8 * q + 4 * hi;
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(g.Hbuf + o);
+            f32x4 out;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[e] = hv[e] > 0.f ? Hw[rg][4 * q + e] : 0.f;
+            *reinterpret_cast<f32x4*>(g.gH + o) = out;
+        }
     }
 }
 
@@ -957,9 +965,9 @@ int agg_backward_impl(const float* feats, const float* vals, int64_t N, const ds
     br.at = AttendArgs{feats, feats, (const bf16_t*)packed_split, off, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, nullptr, nullptr, nullptr,
                        K, K, C, p->nonlinear, 0, 0, rowmap};
     br.A = A; br.gA = gA; br.g_A = g_A; br.Dv = Dv; br.gs = gs; br.gz2 = gz2; br.Hbuf = Hb; br.Qbuf = Qb; br.gqp = gqp;
-    auto launch_hs = [&](auto kern, const auto& arg) {   // hidden-split tile: 256 threads per 32 rows
+    auto launch_hs = [&](auto kern, const auto& arg) {   // hidden-split tile: 256 threads per 64 rows
         if (!dsmil_lds::allow((const void*)kern, HS_LDS_BYTES)) return (int)DSMIL_E_LAUNCH;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((N + 31) / 32)), dim3(256), HS_LDS_BYTES, st, arg);
+        hipLaunchKernelGGL(kern, dim3((unsigned)((N + HS_BM - 1) / HS_BM)), dim3(HS_THREADS), HS_LDS_BYTES, st, arg);
         return hipGetLastError() == hipSuccess ? (int)DSMIL_OK : (int)DSMIL_E_LAUNCH;
     };
     if (nw == 4) rc = v4 ? launch_tile_kernel(k_bwd_rows<4, 4>, br, 4, true, N, st) : launch_tile_kernel(k_bwd_rows<4, 1>, br, 4, false, N, st);

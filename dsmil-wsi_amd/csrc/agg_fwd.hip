@@ -201,7 +201,9 @@ __global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
     const T* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ fc_w, const float* __restrict__ fc_b, float* __restrict__ classes_out,
     float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C, int bag0,
-    const int64_t* __restrict__ rowmap) {
+    const int64_t* __restrict__ rowmap, int r0 = R0) {
+    // r0 = rows per workgroup: R0 (128: a wave walks four 8-row groups) for batches, 32 (one group per wave) when there are
+    // few rows — a lone 10 000-row bag is 79 workgroups at 128 rows, a third of the chip's CUs for an HBM-bound stream
     constexpr int EPL = StreamVec<T>::EPL;   // elements per lane per 128-B segment
     constexpr int SEG = 8 * EPL;             // elements per segment (32 fp32 / 64 bf16)
     constexpr int U = 8;                     // segments in flight per lane-row
@@ -211,12 +213,13 @@ __global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
     const int bag = bag0 + (int)blockIdx.y, tile = (int)blockIdx.x;
     const long long off0 = offsets[bag];
     const long long Nb = offsets[bag + 1] - off0;
-    const long long row0 = (long long)tile * R0;
+    const long long row0 = (long long)tile * r0;
     if (row0 >= Nb) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 7, rr = lane >> 3;
-    const long long slot = off0 / R0 + bag + tile;
+    const long long slot = off0 / r0 + bag + tile;
     const int nseg = (K + SEG - 1) / SEG, Kpad = (nseg + 1) * SEG;
+    const int ngrp = r0 >> 5, rpw = r0 >> 2;   // 8-row groups per wave, rows per wave
 
     for (int c0 = 0; c0 < C; c0 += CP) {
         const int c1 = (CP == 2 && c0 + 1 < C) ? c0 + 1 : c0;
@@ -230,8 +233,8 @@ __global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
         float bv0 = -INFINITY, bv1 = -INFINITY;
         long long bi0 = 0x7fffffffffffffffLL, bi1 = 0x7fffffffffffffffLL;
 #pragma unroll 1
-        for (int g = 0; g < 4; ++g) {
-            const long long rbase = row0 + wave * 32 + g * 8;
+        for (int g = 0; g < ngrp; ++g) {
+            const long long rbase = row0 + wave * rpw + g * 8;
             if (rbase >= Nb) break;  // wave-uniform
             const long long r = (rbase + rr < Nb) ? rbase + rr : Nb - 1;
             const T* x = feats + phys_row(rowmap, off0 + r) * (long long)K;
@@ -320,7 +323,7 @@ __device__ __forceinline__ void qmax_block(
     const float* __restrict__ q2_w, const float* __restrict__ q2_b,
     float* __restrict__ qmax, int64_t* __restrict__ idx_out, int K, int C, int nonlinear,
     int bag, int c, float* s_v, long long* s_i, float* s_h, int mode = 0, float* __restrict__ best_val_out = nullptr,
-    const int64_t* __restrict__ rowmap = nullptr) {
+    const int64_t* __restrict__ rowmap = nullptr, int r0 = R0) {
     // mode 0: arg-max + query of the critical row.  Instance-sharded bags (dsmil_agg_shard_*):
     // mode 1 = arg-max only (index and value out), mode 2 = query of a GIVEN row (feats = [C,K] rows)
     const long long off0 = mode == 2 ? 0 : offsets[bag];
@@ -328,8 +331,8 @@ __device__ __forceinline__ void qmax_block(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwv = (int)blockDim.x >> 6;          // 16 waves: every wave owns 8 hidden units -> one load round per layer
     const int upw = QD / nwv;                      // hidden units per wave (multiple of 8)
-    const long long slot0 = off0 / R0 + bag;
-    const long long ntile = mode == 2 ? 0 : (Nb + R0 - 1) / R0;
+    const long long slot0 = off0 / r0 + bag;
+    const long long ntile = mode == 2 ? 0 : (Nb + r0 - 1) / r0;   // r0 = rows per workgroup of the logits kernel that ran
     float bv = -INFINITY;
     long long bi = 0x7fffffffffffffffLL;
     for (long long t = threadIdx.x; t < ntile; t += blockDim.x) {
@@ -407,12 +410,12 @@ __global__ __launch_bounds__(QMAX_T) void k_qmax(
     const float* __restrict__ q0_w, const float* __restrict__ q0_b,
     const float* __restrict__ q2_w, const float* __restrict__ q2_b,
     float* __restrict__ qmax, int64_t* __restrict__ idx_out, int K, int C, int nonlinear, int bag0,
-    int mode = 0, float* __restrict__ best_val_out = nullptr, const int64_t* __restrict__ rowmap = nullptr) {
+    int mode = 0, float* __restrict__ best_val_out = nullptr, const int64_t* __restrict__ rowmap = nullptr, int r0 = R0) {
     __shared__ float s_v[QMAX_T / 64];
     __shared__ long long s_i[QMAX_T / 64];
     __shared__ float s_h[QD];
     qmax_block<VEC, T>(feats, offsets, part_val, part_idx, q0_w, q0_b, q2_w, q2_b, qmax, idx_out, K, C, nonlinear,
-                       bag0 + (int)blockIdx.x, (int)blockIdx.y, s_v, s_i, s_h, mode, best_val_out, rowmap);
+                       bag0 + (int)blockIdx.x, (int)blockIdx.y, s_v, s_i, s_h, mode, best_val_out, rowmap, r0);
 }
 
 template <int NW, int VEC>
@@ -817,15 +820,14 @@ __global__ void k_pack_agg_bf16(const float* __restrict__ q0_w, const float* __r
 
 // few rows (a lone bag, a training step): the hidden units of a 32-row tile split over the four SIMDs of a CU (agg_hs.h)
 template <int NP>
-__global__ __launch_bounds__(256, 2) void k_attend_hs(AttendArgs a) {
+__global__ __launch_bounds__(HS_THREADS, 2) void k_attend_hs(AttendArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bag = a.bag0 + (int)blockIdx.y, tile = (int)blockIdx.x;
-    f32x16 Hw, Qw;
+    f32x16 Hw[HS_RG], Qw[HS_RG];
     if (!mlp_tile_hs<NP>(a, bag, tile, smem, Hw, Qw)) return;
     const long long off0 = a.offsets[bag];
     const long long Nb = a.offsets[bag + 1] - off0;
-    attend_tail_hs<float>(a, Qw, smem + HS_W_FLOATS + HS_X_FLOATS, smem + HS_W_FLOATS, bag, off0, Nb, (long long)tile * 32,
-                          off0 / 32 + bag + tile);
+    attend_tail_hs<float>(a, Qw, smem + HS_STAGE + HS_PLANES, smem, bag, off0, Nb, (long long)tile * HS_BM, off0 / HS_BM + bag + tile);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -998,7 +1000,7 @@ int pick_nw(int n_bags, long long total_rows) {
 
 WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int K, int Kv, int C, int BM) {
     WsLayout w;
-    w.slots0 = total_rows / R0 + n_bags + 1;
+    w.slots0 = total_rows / 32 + n_bags + 1;   // (32 = the smallest rows-per-workgroup of the logits kernels)
     w.slots = total_rows / BM + n_bags + 1;
     if (w.slots < RS_MAX_WG + n_bags) w.slots = RS_MAX_WG + n_bags;   // k_attend_bf16_res: one slot per (workgroup, bag) pair, slot = workgroup + bag
     w.nchunk_max = finish_blocks(max_rows, Kv);
@@ -1051,9 +1053,9 @@ int launch_attend_hs(const AttendArgs& a, long long max_rows, int n_bags, hipStr
     lds += (size_t)lds_pad;
 #endif
     if (!dsmil_lds::allow((const void*)k_attend_hs<6>, (int)lds)) return DSMIL_E_LAUNCH;
-    dim3 grid((unsigned)((max_rows + 31) / 32), (unsigned)n_bags);
+    dim3 grid((unsigned)((max_rows + HS_BM - 1) / HS_BM), (unsigned)n_bags);
     const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
-    hipLaunchKernelGGL(k_attend_hs<6>, grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k_attend_hs<6>, grid, dim3(HS_THREADS), lds, st, a);
     dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
@@ -1265,6 +1267,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     constexpr int logits_old = 0, no_hs = 0;
 #endif
     int seg_per = 0, seg_T = 0;   // k_attend_bf16_res: partials per (workgroup, bag), see k_finish
+    int hs_bm = 0;                // k_attend_hs: rows per tile (the partial slots follow it)
     {
         // Tried and rejected here (round 1, numbers in DESIGN.md §3): (a) chunking the batch and running
         // chunk c+1's HBM-bound logits on a helper stream under chunk c's MFMA-bound attend, and (b) one
@@ -1272,20 +1275,24 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         // release/acquire hand-offs.  Both were slower than these plain back-to-back launches.
         const int b0 = 0, nb = n_bags;
         // 1. instance logits + arg-max partials
-        dim3 grid((unsigned)((max_rows + R0 - 1) / R0), (unsigned)nb);
+        // rows per workgroup of the logits pass: 32 instead of R0 when there are few rows (the 32-row-tile regime of pick_nw)
+        // and the streaming kernel runs
+        const bool stream_ok = !classes_in && !logits_old && ((bf16 && (K % 8 == 0)) || (!bf16 && v4));
+        const int r0 = (NW == 1 && stream_ok && sh.phase != 2) ? 32 : R0;
+        dim3 grid((unsigned)((max_rows + r0 - 1) / r0), (unsigned)nb);
         if (sh.phase == 2) {}  // the caller already knows the bag-wide critical rows
         else if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else if (bf16 && (K % 8 == 0) && !logits_old) {
             const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 63) / 64 + 1) * 64) * sizeof(float);
-            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, bf16_t>), grid, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap);
-            else hipLaunchKernelGGL((k_logits_stream<1, bf16_t>), grid, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap);
+            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, bf16_t>), grid, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0);
+            else hipLaunchKernelGGL((k_logits_stream<1, bf16_t>), grid, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0);
         }
         else if (bf16 && w4) hipLaunchKernelGGL((k_logits_argmax<4, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else if (bf16) hipLaunchKernelGGL((k_logits_argmax<1, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else if (v4 && !logits_old) {
             const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 31) / 32 + 1) * 32) * sizeof(float);
-            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap);
-            else hipLaunchKernelGGL((k_logits_stream<1, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap);
+            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0);
+            else hipLaunchKernelGGL((k_logits_stream<1, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0);
         }
         else if (v4) hipLaunchKernelGGL((k_logits_argmax<4, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else hipLaunchKernelGGL((k_logits_argmax<1, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
@@ -1293,8 +1300,8 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         // 2. critical instance + its query
         dim3 gq((unsigned)nb, (unsigned)C);
         if (sh.phase == 1) {
-            if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap);
-            else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap);
+            if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap, r0);
+            else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap, r0);
             return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
         }
         if (sh.phase == 2) {
@@ -1302,10 +1309,10 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
             if (r4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
             else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
         }
-        else if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), gq, dim3(QMAX_T), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
-        else if (bf16) hipLaunchKernelGGL((k_qmax<1, bf16_t>), gq, dim3(QMAX_T), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
-        else if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
-        else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap);
+        else if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), gq, dim3(QMAX_T), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0);
+        else if (bf16) hipLaunchKernelGGL((k_qmax<1, bf16_t>), gq, dim3(QMAX_T), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0);
+        else if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0);
+        else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         // 3. query MLP on MFMA + scores + tile softmax + weighted value sum
         int rc;
@@ -1340,7 +1347,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         else if (mode == 6 && NW == 1 && v4 && (a.expt & 8)) rc = launch_attend_split<1, 4, 6, true>(a, max_rows, nb, st);
 #endif
         else if (mode == 6 && NW == 4) rc = v4 ? launch_attend_split<4, 4, 6>(a, max_rows, nb, st) : launch_attend_split<4, 1, 6>(a, max_rows, nb, st);
-        else if (mode == 6 && v4 && !no_hs) rc = launch_attend_hs(a, max_rows, nb, st);   // few rows: hidden units split over the SIMDs
+        else if (mode == 6 && v4 && !no_hs) { rc = launch_attend_hs(a, max_rows, nb, st); hs_bm = HS_BM; }   // few rows: hidden units split over the SIMDs
         else if (mode == 6) rc = v4 ? launch_attend_split<1, 4, 6>(a, max_rows, nb, st) : launch_attend_split<1, 1, 6>(a, max_rows, nb, st);
         else if (NW == 8) rc = launch_attend<8, 4>(a, max_rows, nb, st);
         else if (NW == 4) rc = v4 ? launch_attend<4, 4>(a, max_rows, nb, st) : launch_attend<4, 1>(a, max_rows, nb, st);
@@ -1351,7 +1358,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     if (!DSMIL_EXPT_ON(a, 64)) {
         dim3 grid((unsigned)L.nchunk_max, (unsigned)n_bags);
         if (Kv % 4 == 0)
-            hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, seg_per ? RS_BM : BM, sh.ml_out, seg_per, seg_T);
+            hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, seg_per ? RS_BM : (hs_bm ? hs_bm : BM), sh.ml_out, seg_per, seg_T);
         else
             hipLaunchKernelGGL(k_finish<1>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM, sh.ml_out, 0, 0);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;

@@ -1,50 +1,64 @@
-// agg_hs.h — the query MLP tile for FEW rows (a lone bag, a training step): the HIDDEN units of a 32-row tile are split
-// over the four SIMDs of a CU.
+// agg_hs.h — the query MLP tile for FEW rows (a lone bag, a training step): the HIDDEN units of a 64-row tile are split
+// over the four SIMDs of a CU, and four more waves prepare the operands.
 //
 // The batched kernels (agg_split.h) give a wave 32 rows and all 128 hidden units: a 10 000-row bag is 313 waves on the
 // chip's 1024 SIMDs, each walking 40 k-steps x 24 dependent MFMAs — 35 us for 1.6 GFLOP (dsmil.py:49 on one bag, the call
-// train_tcga.py:67 and attention_map.py:85 make).  Here a 256-thread workgroup owns the 32 rows and wave w owns hidden
-// units 32w..32w+31 (GEMM 1: H^T tile w) and query units 32w..32w+31 (GEMM 2: Q^T tile w): a quarter of the MFMA chain per
-// wave, four times the waves.  Same arithmetic as the batched kernels — three exact bf16 planes per fp32 operand, the same
-// six plane products in the same order, k ascending — so H and Q are bit-identical to theirs.
-//   weights   the packed image of k_pack_agg_split: chunk s = [tile t][plane p][lane] x 16 B.  Wave w needs exactly pieces
-//             3w..3w+2 of every chunk, so its weight stream is PRIVATE: LDS-DMA into its own slice of a 4-deep ring, its
-//             own vmcnt wait, no barrier.
-//   features  the 32 rows x 32 k chunk is shared by the four waves (each reads all of it as the MFMA B operand and cuts
-//             its fragment itself); wave w issues rows 8w..8w+7; a 6-deep ring keeps five chunks (~4000 cycles of work)
-//             in flight; one barrier per chunk = "chunk c landed for everybody, chunk c-1 released".
-//   hidden    after GEMM 1 the four H tiles are exchanged through LDS (the feature ring is dead by then; rows padded to
-//             132 floats: conflict-free 16-B accesses) and every wave reads the 8 hidden units of a GEMM-2 step for its
-//             row as two 16-B loads.
-// 48 KiB weights + 24 KiB features (+ 4 KiB scratch for the tail) = 76 KiB: two workgroups per CU.
+// train_tcga.py:67 and attention_map.py:85 make).  Here a 512-thread workgroup owns 64 rows:
+//   compute waves 0-3  wave w owns hidden units 32w..32w+31 (GEMM 1: H^T tile w) and query units 32w..32w+31 (GEMM 2: Q^T
+//             tile w) for both 32-row groups: a quarter of the MFMA chain per wave, two independent accumulators, and
+//             NOTHING but MFMAs, 16-B LDS fragment reads and its weight loads in the loop.
+//   cutter waves 4-7   wave 4+j streams rows 16j..16j+15 of every 32-k feature chunk through LDS-DMA into a private ring
+//             (five chunks ahead), cuts each fp32 value ONCE into its three exact bf16 planes and writes them in
+//             MFMA-fragment order into a two-slot plane ring; they leave the kernel after the last chunk.
+// Same arithmetic as the batched kernels — the same exact planes, the same six plane products in the same order, k
+// ascending — so H and Q are bit-identical to theirs.
+//   weights   the packed image of k_pack_agg_split: chunk s = [tile t][plane p][lane] x 16 B.  Compute wave w needs exactly
+//             pieces 3w..3w+2 of every chunk — a PRIVATE stream already in A-operand order: global -> VGPR, three 16-B loads
+//             per step, three steps ahead in a register ring; it never touches LDS.
+//   hidden    after GEMM 1 every compute wave cuts its own H tile straight from the accumulators (registers 8sx..8sx+7 of
+//             a row ARE the 8 hidden units of GEMM-2 step (w, sx)) and writes the plane fragments; after one barrier every
+//             wave reads the fragments of all eight steps.
+// How it got here (same box class, 10 000 x 512 bag, kernel time): one wave per 32-row tile 35 us -> hidden split, weights
+// and features through LDS-DMA issued by the compute waves 31 us (the CU's LDS-DMA path takes ~48 cycles per KiB: 25 us
+// of weight traffic alone) -> weights through VGPRs, 64-row tiles 36 us (vector memory returns in order per wave: every
+// wait for a step's weights also waited for each feature piece issued before them, so the features' ten-step lead shrank
+// to the weights' three) -> a fifth wave issuing the features 27 us (the wave's own VALU work — 90 ops of cutting per
+// step — and its MFMAs ran back to back) -> the cut pipelined by hand behind the MFMAs 54 us (41 spilled registers: a
+// scratch reload is a vector-memory operation and waits for the whole weight ring) -> this form.
 #pragma once
 #include "agg_split.h"
 
 namespace {
 
-constexpr int HS_WR = 4;                 // weight ring depth, in 16-k steps
-constexpr int HS_XR = 6;                 // feature ring depth, in 32-k chunks
-constexpr int HS_XT = 32 * 32;           // floats per feature chunk (32 rows x 128 B, slots permuted as in agg_split.h)
-constexpr int HS_HLD = 132;              // row stride of the hidden-layer exchange buffer (floats)
-constexpr int HS_W_FLOATS = HS_WR * S3_CHUNK_F4 * 4;
-constexpr int HS_X_FLOATS = HS_XR * HS_XT;
-constexpr int HS_SCRATCH = 1024;         // floats behind the rings, for the caller's tail
-constexpr int HS_LDS_BYTES = (HS_W_FLOATS + HS_X_FLOATS + HS_SCRATCH) * 4;
-static_assert(32 * HS_HLD <= HS_X_FLOATS, "the hidden-layer exchange buffer aliases the feature ring");
+constexpr int HS_RG = 2;                 // 32-row groups per tile
+constexpr int HS_BM = 32 * HS_RG;        // rows per tile
+constexpr int HS_WRD = 3;                // weight register ring depth, in 16-k steps (two steps ahead)
+constexpr int HS_XR = 6;                 // depth of a cutter's staging ring, in 32-k chunks
+constexpr int HS_THREADS = 512;          // four compute waves + four cutter waves
+constexpr int HS_STAGE = 4 * HS_XR * 512;        // floats: [cutter][ring slot][16 rows x 32 k]
+constexpr int HS_PL_SLOT = 3 * 2 * 2 * HS_BM;    // 16-B units per plane-ring slot: [plane][k-step][hi][row]
+constexpr int HS_PLANES = 2 * HS_PL_SLOT * 4;    // floats: two slots
+constexpr int HS_SCRATCH = 1536;         // floats behind the rings, for the caller's tail
+constexpr int HS_LDS_BYTES = (HS_STAGE + HS_PLANES + HS_SCRATCH) * 4;
+static_assert(3 * 8 * 2 * HS_BM * 4 <= HS_STAGE, "the hidden-layer plane fragments alias the staging rings");
+static_assert(4 * 1024 <= HS_STAGE, "the value-sum merge buffer aliases the staging rings");
 
-// On return wave w holds, in the MFMA D layout (lane (l31, hi), reg 4g+e <-> row l31, unit 32w + 8g + 4hi + e):
-//   Hw = relu(x W1^T + b1) tile w (the plain linear query when !nonlinear), Qw = tanh(H W2^T + b2) tile w (= Hw when
-// !nonlinear); every wave is past the last barrier and no DMA is in flight (the LDS is free).
-// Returns false when the tile lies past the end of the bag (block-uniform).  Rows 16-B aligned, K % 4 == 0.
+// On return compute wave w holds, per 32-row group g, in the MFMA D layout (lane (l31, hi), reg 4q+e <-> row 32g + l31, unit
+// 32w + 8q + 4hi + e):  Hw[g] = relu(x W1^T + b1) tile w (the plain linear query when !nonlinear), Qw[g] = tanh(H W2^T + b2)
+// tile w (= Hw when !nonlinear); every remaining wave is past the last barrier and no DMA is in flight (the LDS is free).
+// Returns false for the cutter waves (they are done) and when the tile lies past the end of the bag (block-uniform): the
+// caller returns.  Rows 16-B aligned, K % 4 == 0.
 template <int NP>
-__device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int tile, float* smem, f32x16& Hw, f32x16& Qw) {
-    static_assert(NP == 6 || NP == 9, "plane products");
+__device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int tile, float* smem, f32x16 (&Hw)[HS_RG],
+                                            f32x16 (&Qw)[HS_RG]) {
+    static_assert(NP == 6 && HS_RG == 2, "12 MFMAs per step");
     constexpr int P0 = 9 - NP;
-    f32x4* sW = reinterpret_cast<f32x4*>(smem);   // [HS_WR][S3_CHUNK_F4]
-    float* sX = smem + HS_W_FLOATS;               // [HS_XR][HS_XT], later sH [32][HS_HLD]
+    float* sStage = smem;
+    f32x4* sPl = reinterpret_cast<f32x4*>(smem + HS_STAGE);     // [2][plane][k-step][hi][row]
+    f32x4* sHp = reinterpret_cast<f32x4*>(smem);                // later: [plane][GEMM-2 step][hi][row]
     const long long off0 = a.offsets[bag];
     const long long Nb = a.offsets[bag + 1] - off0;
-    const long long row0 = (long long)tile * 32;
+    const long long row0 = (long long)tile * HS_BM;
     if (row0 >= Nb) return false;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -52,205 +66,306 @@ __device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int ti
     const int nk1 = (K + 31) / 32;
     const int nks = 2 * nk1;
     const int nst = nks + (a.nonlinear ? 8 : 0);
-    const float* feats = reinterpret_cast<const float*>(a.feats);
-    const f32x4* wpk = reinterpret_cast<const f32x4*>(a.wpk);
 
-    // this lane's share of the wave's feature piece (rows 8 wave .. 8 wave + 7), and its permuted 16-B slot
-    const int xr = wave * 8 + (lane >> 3);
-    long long gr = row0 + xr;
-    if (gr >= Nb) gr = Nb - 1;   // rows past the bag end are masked by the caller
-    const float* xsrc = feats + phys_row(a.rowmap, off0 + gr) * (long long)K;
-    const int xslot = ((lane & 7) ^ ((xr & 6) | ((xr >> 4) & 1))) * 4;
-    auto issue_w = [&](int s) {   // past the end the last chunk is re-read into a dead ring slot: uniform counts
-        const int sc = s < nst ? s : nst - 1;
+    if (wave >= 4) {
+        // ---- a CUTTER wave: rows 16j .. 16j+15 of the tile.  Its DMA pieces, their vmcnt and the staging ring are private:
+        // no barrier between "landed" and "cut"; the one barrier per chunk publishes the planes.  (vmcnt is per wave and
+        // vector memory returns in order: the compute waves' weight stream must not queue behind the HBM-sourced features.)
+        const int j = wave - 4;
+        const float* feats = reinterpret_cast<const float*>(a.feats);
+        const float* xsrc[2];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const int q = 3 * wave + p;
-            __builtin_amdgcn_global_load_lds((const DSMIL_GLOBAL void*)(wpk + (long long)sc * S3_CHUNK_F4 + q * 64 + lane),
-                                             (__attribute__((address_space(3))) void*)(sW + (s % HS_WR) * S3_CHUNK_F4 + q * 64), 16, 0, 0);
+        for (int i = 0; i < 2; ++i) {             // piece i = rows 16j + 8i .. + 7, lane -> (row lane >> 3, 16-B slot lane & 7)
+            long long gr = row0 + 16 * j + 8 * i + (lane >> 3);
+            if (gr >= Nb) gr = Nb - 1;            // rows past the bag end are masked by the caller
+            xsrc[i] = feats + phys_row(a.rowmap, off0 + gr) * (long long)K;
         }
-    };
-    auto issue_x = [&](int c) {   // c < nk1
-        int k = c * 32 + xslot;
-        k = k < K ? k : K - 4;    // past K the packed weights are zero: any finite data will do
-        __builtin_amdgcn_global_load_lds((const DSMIL_GLOBAL void*)(xsrc + k),
-                                         (__attribute__((address_space(3))) void*)(sX + (c % HS_XR) * HS_XT + (wave * 8) * 32), 16, 0, 0);
-    };
-    // feature pieces that are YOUNGER than the weight pieces of step s when step s begins: those issued at the even steps
-    // among s-3, s-2, s-1 (step e issues chunk (e >> 1) + HS_XR - 1 after its own weights)
-    auto x_younger = [&](int s) {
-        int n = 0;
+        float* stage = sStage + j * (HS_XR * 512);
+        auto issue_chunk = [&](int c) {
 #pragma unroll
-        for (int d = 1; d <= 3; ++d) {
-            const int e = s - d;
-            if (e >= 0 && !(e & 1) && (e >> 1) + HS_XR - 1 < nk1) ++n;
+            for (int i = 0; i < 2; ++i) {
+                int k = c * 32 + (lane & 7) * 4;
+                k = k < K ? k : K - 4;            // past K the packed weights are zero: any finite data will do
+                __builtin_amdgcn_global_load_lds((const DSMIL_GLOBAL void*)(xsrc[i] + k),
+                                                 (__attribute__((address_space(3))) void*)(stage + (c % HS_XR) * 512 + i * 256), 16, 0, 0);
+            }
+        };
+        for (int c = 0; c < HS_XR - 1 && c < nk1; ++c) issue_chunk(c);
+        const int rr = lane >> 2, o = lane & 3;   // this lane cuts row 16j + rr, k-octet o = (k-step o >> 1, half o & 1)
+        for (int c = 0; c < nk1; ++c) {
+            const int ahead = (c + HS_XR - 2 < nk1 - 1 ? c + HS_XR - 2 : nk1 - 1) - c;   // chunks issued behind chunk c
+            s3_wait_vm_dyn(2 * ahead);             // chunk c has landed (this wave's own pieces: all it reads)
+            const float* x = stage + (c % HS_XR) * 512 + rr * 32 + o * 8;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(x);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(x + 4);
+            const float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            S3Frag f[3];
+            split3(xv, f);
+            // (slot c & 1 is free: the compute waves read chunk c - 2 before the barrier of chunk c - 1, which this wave passed)
+            f32x4* dst = sPl + (c & 1) * HS_PL_SLOT + o * HS_BM + 16 * j + rr;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) dst[p * 4 * HS_BM] = f[p].f;
+            if (c + HS_XR - 1 < nk1) issue_chunk(c + HS_XR - 1);   // into the staging slot of chunk c - 1 (cut an iteration ago)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the plane writes are in LDS (NOT vmcnt: the ring stays in flight)
+            __builtin_amdgcn_s_barrier();          // planes of chunk c are visible to the compute waves
         }
-        return n;
-    };
-    const int fr = (l31 & 6) | ((l31 >> 4) & 1);   // this lane's row permutation as a reader
-    auto read_cut = [&](int s, S3Frag (&xb)[3]) {
-        const float* x = sX + ((s >> 1) % HS_XR) * HS_XT + l31 * 32;
-        const int j0 = ((s & 1) * 4 + hi * 2) ^ fr;
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + j0 * 4);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(x + (j0 ^ 1) * 4);
-        const float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        split3(xv, xb);
-    };
-
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Hw[r] = 0.f;
-    // prologue: weights of steps 0..2, the first HS_XR - 1 feature chunks
-    issue_w(0);
-    issue_w(1);
-    issue_w(2);
-    for (int c = 0; c < HS_XR - 1 && c < nk1; ++c) issue_x(c);
-    // ---- GEMM 1 (transposed): H^T[32 wave + j][n] += W1[32 wave + j][k] X[n][k], 16 k per step
-    for (int s = 0; s < nks; ++s) {
-        if (s == 0) S3_WAIT_VM(0);
-        else s3_wait_vm_dyn(6 + x_younger(s));          // weights of step s (and everything older) have landed
-        if (!(s & 1)) {
-            __builtin_amdgcn_s_barrier();                // chunk s/2 landed for every wave; chunk s/2 - 1 is released
-            if ((s >> 1) + HS_XR - 1 < nk1) { issue_w(s + HS_WR - 1); issue_x((s >> 1) + HS_XR - 1); }
-            else issue_w(s + HS_WR - 1);
-        } else {
-            issue_w(s + HS_WR - 1);
-        }
-        S3Frag xb[3], wa[3];
-        read_cut(s, xb);
-        const f32x4* w = sW + (s % HS_WR) * S3_CHUNK_F4 + (3 * wave) * 64 + lane;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) wa[p].f = w[p * 64];
-#pragma unroll
-        for (int q = P0; q < 9; ++q)
-            Hw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[S3_PA(q)].v, xb[S3_PB(q)].v, Hw, 0, 0, 0);
+        return false;                              // (a finished wave no longer counts at barriers)
     }
-    // ---- bias (+ReLU): reg 4g+e <-> unit 32 wave + 8g + 4hi + e
+    const f32x4* wpk = reinterpret_cast<const f32x4*>(a.wpk) + (3 * wave) * 64 + lane;   // this lane's slot of piece 3w
+    // weight fragments of step s: three 16-B loads straight into the A-operand registers (past the end: the last chunk again)
+    S3Frag wr[HS_WRD][3];
+    auto load_w = [&](auto slot, int s) {
+        constexpr int R = decltype(slot)::value;
+        const int sc = s < nst ? s : nst - 1;
+        const f32x4* src = wpk + (long long)sc * S3_CHUNK_F4;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(a.q0_b + 32 * wave + 8 * g + 4 * hi);
+        for (int p = 0; p < 3; ++p) wr[R][p].f = *(const DSMIL_GLOBAL f32x4*)(src + p * 64);
+    };
+    // the B-operand plane fragments of step s for both row groups
+    auto read_frags = [&](auto g2, int s, S3Frag (&fb)[HS_RG][3]) {
+        const f32x4* src;
+        int pstride;
+        if constexpr (!decltype(g2)::value) { src = sPl + ((s >> 1) & 1) * HS_PL_SLOT + ((s & 1) * 2 + hi) * HS_BM + l31; pstride = 4 * HS_BM; }
+        else { src = sHp + ((s - nks) * 2 + hi) * HS_BM + l31; pstride = 16 * HS_BM; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float v = Hw[4 * g + e] + b[e];
-            Hw[4 * g + e] = a.nonlinear ? fmaxf(v, 0.f) : v;
+        for (int g = 0; g < HS_RG; ++g)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[g][p].f = src[p * pstride + 32 * g];
+    };
+
+#pragma unroll
+    for (int g = 0; g < HS_RG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Hw[g][r] = 0.f;
+    // prologue: the weights of the first HS_WRD - 1 steps; chunk 0; the operand fragments of step 0
+    load_w(std::integral_constant<int, 0>{}, 0);
+    load_w(std::integral_constant<int, 1>{}, 1);
+    static_assert(HS_WRD == 3, "prologue and step grouping below");
+    __builtin_amdgcn_s_barrier();                    // the cutters' first: planes of chunk 0
+    asm volatile("" ::: "memory");
+    S3Frag xb[HS_RG][3];
+    read_frags(std::false_type{}, 0, xb);
+    // One 16-k step: the fragments of step s+1 are requested first, then 12 MFMAs alternate between the two row groups
+    // (independent accumulators: back-to-back issue).  RI = the step's slot of the weight ring, G2 = second GEMM, PRE = there
+    // is a next step whose fragments are in LDS already (literals: registers are addressed statically).
+    auto step = [&](auto ri, auto g2, auto pre_, int s) {
+        constexpr int RI = decltype(ri)::value;
+        constexpr bool G2 = decltype(g2)::value;
+        constexpr bool PRE = decltype(pre_)::value;
+        // the cutters' barrier for the chunk step s+1 reads (odd s): its planes are complete
+        if (!G2 && (s & 1) && s + 1 < nks) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
+        load_w(std::integral_constant<int, (RI + HS_WRD - 1) % HS_WRD>{}, s + HS_WRD - 1);
+        S3Frag xn[HS_RG][3];
+        if constexpr (PRE) read_frags(g2, s + 1, xn);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int g = k & 1, q = P0 + (k >> 1);
+            if constexpr (G2) Qw[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[RI][S3_PA(q)].v, xb[g][S3_PB(q)].v, Qw[g], 0, 0, 0);
+            else Hw[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[RI][S3_PA(q)].v, xb[g][S3_PB(q)].v, Hw[g], 0, 0, 0);
+        }
+        if constexpr (PRE) {
+#pragma unroll
+            for (int g = 0; g < HS_RG; ++g)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) xb[g][p] = xn[g][p];
+        }
+        if (!G2 && s == nks - 1) {
+            // ---- bias (+ReLU): reg 4q+e <-> unit 32 wave + 8q + 4hi + e
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(a.q0_b + 32 * wave + 8 * q + 4 * hi);
+#pragma unroll
+                for (int g = 0; g < HS_RG; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = Hw[g][4 * q + e] + b[e];
+                        Hw[g][4 * q + e] = a.nonlinear ? fmaxf(v, 0.f) : v;
+                    }
+            }
+            if (a.nonlinear) {
+                // ---- the hidden layer as GEMM-2 operands: registers 8sx..8sx+7 of this wave's H tile are, for row l31, the 8
+                //      hidden units of step (t = wave, sx) (the k permutation the packed W2 carries): cut and publish them
+#pragma unroll
+                for (int g = 0; g < HS_RG; ++g)
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx) {
+                        float hv[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) hv[i] = Hw[g][8 * sx + i];
+                        S3Frag f[3];
+                        split3(hv, f);
+                        f32x4* dst = sHp + ((2 * wave + sx) * 2 + hi) * HS_BM + 32 * g + l31;
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) dst[p * 16 * HS_BM] = f[p].f;
+                    }
+                __syncthreads();
+#pragma unroll
+                for (int g = 0; g < HS_RG; ++g)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Qw[g][r] = 0.f;
+                read_frags(std::true_type{}, nks, xb);
+            }
+        }
+    };
+    using F_ = std::false_type;
+    using T_ = std::true_type;
+    // No run-time choice of a step variant inside the steady loop (every variant is its own copy of the 12-MFMA block: with
+    // a selection per step hipcc kept several copies of the accumulators alive and spilled): GEMM-1 steps 0 .. nks-2 in
+    // groups of HS_WRD (ring slot = position in the group), then — per residue of nks — the last GEMM-1 step (no
+    // read-ahead: the hidden layer is not in LDS yet) and the eight GEMM-2 steps with literal ring slots.
+    auto finish = [&](auto r0, int s) {
+        constexpr int R0 = decltype(r0)::value;
+        step(std::integral_constant<int, R0>{}, F_{}, F_{}, s);                        // s == nks - 1
+        if (a.nonlinear) {
+            step(std::integral_constant<int, (R0 + 1) % HS_WRD>{}, T_{}, T_{}, s + 1);
+            step(std::integral_constant<int, (R0 + 2) % HS_WRD>{}, T_{}, T_{}, s + 2);
+            step(std::integral_constant<int, (R0 + 3) % HS_WRD>{}, T_{}, T_{}, s + 3);
+            step(std::integral_constant<int, (R0 + 4) % HS_WRD>{}, T_{}, T_{}, s + 4);
+            step(std::integral_constant<int, (R0 + 5) % HS_WRD>{}, T_{}, T_{}, s + 5);
+            step(std::integral_constant<int, (R0 + 6) % HS_WRD>{}, T_{}, T_{}, s + 6);
+            step(std::integral_constant<int, (R0 + 7) % HS_WRD>{}, T_{}, T_{}, s + 7);
+            step(std::integral_constant<int, (R0 + 8) % HS_WRD>{}, T_{}, F_{}, s + 8);
+        }
+    };
+    int s = 0;
+    for (; s + HS_WRD <= nks - 1; s += HS_WRD) {
+        step(std::integral_constant<int, 0>{}, F_{}, T_{}, s);
+        step(std::integral_constant<int, 1>{}, F_{}, T_{}, s + 1);
+        step(std::integral_constant<int, 2>{}, F_{}, T_{}, s + 2);
+    }
+    switch (nks - 1 - s) {
+        case 0: finish(std::integral_constant<int, 0>{}, s); break;
+        case 1:
+            step(std::integral_constant<int, 0>{}, F_{}, T_{}, s);
+            finish(std::integral_constant<int, 1>{}, s + 1);
+            break;
+        default:
+            step(std::integral_constant<int, 0>{}, F_{}, T_{}, s);
+            step(std::integral_constant<int, 1>{}, F_{}, T_{}, s + 1);
+            finish(std::integral_constant<int, 2>{}, s + 2);
+            break;
     }
     if (!a.nonlinear) {
-        Qw = Hw;
-        S3_WAIT_VM(0);
-        __builtin_amdgcn_s_barrier();
-        return true;
+#pragma unroll
+        for (int g = 0; g < HS_RG; ++g) Qw[g] = Hw[g];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * wave + 8 * q + 4 * hi);
+#pragma unroll
+            for (int g = 0; g < HS_RG; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Qw[g][4 * q + e] = fast_tanh(Qw[g][4 * q + e] + b[e]);
+        }
     }
-    // ---- exchange the hidden layer: sH[row][unit], rows padded to HS_HLD floats
-    __syncthreads();                                     // every wave is done reading the feature ring
-    float* sH = sX;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 hv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hv[e] = Hw[4 * g + e];
-        *reinterpret_cast<f32x4*>(sH + l31 * HS_HLD + 32 * wave + 8 * g + 4 * hi) = hv;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Qw[r] = 0.f;
-    // ---- GEMM 2 (transposed): Q^T[32 wave + j][n] += W2[32 wave + j][k] H^T[k][n]; step (t, sx) contracts hidden units
-    //      32t + 16sx + {0..3, 8..11} + 4hi (the k permutation the packed W2 carries)
-#pragma unroll
-    for (int st = 0; st < 8; ++st) {
-        const int t = st >> 1, sx = st & 1, s = nks + st;
-        s3_wait_vm_dyn(6 + x_younger(s));
-        issue_w(s + HS_WR - 1);
-        const float* h = sH + l31 * HS_HLD + 32 * t + 16 * sx + 4 * hi;
-        const f32x4 h0 = *reinterpret_cast<const f32x4*>(h);
-        const f32x4 h1 = *reinterpret_cast<const f32x4*>(h + 8);
-        const float hv[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-        S3Frag hb[3], wa[3];
-        split3(hv, hb);
-        const f32x4* w = sW + (s % HS_WR) * S3_CHUNK_F4 + (3 * wave) * 64 + lane;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) wa[p].f = w[p * 64];
-#pragma unroll
-        for (int q = P0; q < 9; ++q)
-            Qw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[S3_PA(q)].v, hb[S3_PB(q)].v, Qw, 0, 0, 0);
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * wave + 8 * g + 4 * hi);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Qw[4 * g + e] = fast_tanh(Qw[4 * g + e] + b[e]);
-    }
-    S3_WAIT_VM(0);                                       // the clamped weight re-reads of the last steps
     __syncthreads();
     return true;
 }
 
 // Everything behind the query MLP for the hidden-split tile: scores (dsmil.py:55-56) from the four waves' partial dot
-// products, the tile's softmax statistics, the weighted value sum (dsmil.py:57) with the ROWS split over the waves (8 each,
+// products, the tile's softmax statistics, the weighted value sum (dsmil.py:57) with the ROWS split over the waves (16 each,
 // all features: the loop of attend_tail, row index wave-uniform) and a four-way merge through LDS.  `scr` = HS_SCRATCH
 // floats of LDS, `merge` = 4096 floats (the dead feature ring).  Partials go to slot `slot` as attend_tail writes them.
+// (A first form kept the rows' addresses and weights in LDS tables and gave every lane 16 rows x 4 features, eight loads
+// in flight: with two workgroups per CU it returned run-to-run different sums — one component of one wave's share, about
+// once per launch — while the same loop one row at a time, or one workgroup per CU, was exact.  Not understood; this form
+// is the one the batched kernels have run since round 1.)
 template <typename T>
-__device__ __forceinline__ void attend_tail_hs(const AttendArgs& a, const f32x16& Qw, float* scr, float* merge, int bag,
-                                               long long off0, long long Nb, long long row0, long long slot) {
+__device__ __forceinline__ void attend_tail_hs(const AttendArgs& a, const f32x16 (&Qw)[HS_RG], float* scr, float* merge,
+                                               int bag, long long off0, long long Nb, long long row0, long long slot) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const long long myrow = row0 + l31;
-    const bool valid = myrow < Nb;
     const float scale = 0.08838834764831845f;            // 1/sqrt(128), dsmil.py:56
     const int Kv = a.Kv;
     const T* vbase = reinterpret_cast<const T*>(a.vals);
-    float* sS = scr;                                      // [4 waves][2 classes][32 rows]
-    // physical value row of this lane's instance (rows past the bag end: the last row, weight 0)
-    const long long myphys = phys_row(a.rowmap, off0 + (valid ? myrow : Nb - 1));
+    float* sS = scr;                                      // [4 waves][2 classes][HS_BM rows]
+    bool valid[HS_RG];
+    long long myphys[HS_RG];                              // physical value rows (past the bag end: the last row, weight 0)
+#pragma unroll
+    for (int g = 0; g < HS_RG; ++g) {
+        const long long myrow = row0 + 32 * g + l31;
+        valid[g] = myrow < Nb;
+        myphys[g] = phys_row(a.rowmap, off0 + (valid[g] ? myrow : Nb - 1));
+    }
     for (int c0 = 0; c0 < a.C; c0 += 2) {
         const int c1 = (c0 + 1 < a.C) ? c0 + 1 : c0;
         const float* qm0 = a.qmax + ((long long)bag * a.C + c0) * QD + 32 * wave;
         const float* qm1 = a.qmax + ((long long)bag * a.C + c1) * QD + 32 * wave;
-        float s0 = 0.f, s1 = 0.f;
+        float s0[HS_RG], s1[HS_RG];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 u0 = *reinterpret_cast<const f32x4*>(qm0 + 8 * g + 4 * hi);
-            const f32x4 u1 = *reinterpret_cast<const f32x4*>(qm1 + 8 * g + 4 * hi);
+        for (int g = 0; g < HS_RG; ++g) { s0[g] = 0.f; s1[g] = 0.f; }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s0 = fmaf(Qw[4 * g + e], u0[e], s0);
-                s1 = fmaf(Qw[4 * g + e], u1[e], s1);
-            }
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(qm0 + 8 * q + 4 * hi);
+            const f32x4 u1 = *reinterpret_cast<const f32x4*>(qm1 + 8 * q + 4 * hi);
+#pragma unroll
+            for (int g = 0; g < HS_RG; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s0[g] = fmaf(Qw[g][4 * q + e], u0[e], s0[g]);
+                    s1[g] = fmaf(Qw[g][4 * q + e], u1[e], s1[g]);
+                }
         }
-        s0 += __shfl_xor(s0, 32, 64);
-        s1 += __shfl_xor(s1, 32, 64);
-        if (hi == 0) { sS[(wave * 2 + 0) * 32 + l31] = s0; sS[(wave * 2 + 1) * 32 + l31] = s1; }
+#pragma unroll
+        for (int g = 0; g < HS_RG; ++g) {
+            s0[g] += __shfl_xor(s0[g], 32, 64);
+            s1[g] += __shfl_xor(s1[g], 32, 64);
+            if (hi == 0) { sS[(wave * 2 + 0) * HS_BM + 32 * g + l31] = s0[g]; sS[(wave * 2 + 1) * HS_BM + 32 * g + l31] = s1[g]; }
+        }
         __syncthreads();
         // every wave forms the same scores in the same (fixed) order
-        s0 = ((sS[0 * 32 + l31] + sS[2 * 32 + l31]) + (sS[4 * 32 + l31] + sS[6 * 32 + l31])) * scale;
-        s1 = ((sS[1 * 32 + l31] + sS[3 * 32 + l31]) + (sS[5 * 32 + l31] + sS[7 * 32 + l31])) * scale;
-        const float m0 = wave_max(valid ? s0 : -INFINITY), m1 = wave_max(valid ? s1 : -INFINITY);
-        const float p0 = valid ? expf(s0 - m0) : 0.f, p1 = valid ? expf(s1 - m1) : 0.f;
-        const float l0 = wave_sum(hi == 0 ? p0 : 0.f), l1 = wave_sum(hi == 0 ? p1 : 0.f);
+        float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < HS_RG; ++g) {
+            const int r = 32 * g + l31;
+            s0[g] = ((sS[0 * HS_BM + r] + sS[2 * HS_BM + r]) + (sS[4 * HS_BM + r] + sS[6 * HS_BM + r])) * scale;
+            s1[g] = ((sS[1 * HS_BM + r] + sS[3 * HS_BM + r]) + (sS[5 * HS_BM + r] + sS[7 * HS_BM + r])) * scale;
+            if (valid[g]) { m0 = fmaxf(m0, s0[g]); m1 = fmaxf(m1, s1[g]); }
+        }
+        m0 = wave_max(m0);
+        m1 = wave_max(m1);
+        float p0[HS_RG], p1[HS_RG], l0 = 0.f, l1 = 0.f;
+#pragma unroll
+        for (int g = 0; g < HS_RG; ++g) {
+            p0[g] = valid[g] ? expf(s0[g] - m0) : 0.f;
+            p1[g] = valid[g] ? expf(s1[g] - m1) : 0.f;
+            if (hi == 0) { l0 += p0[g]; l1 += p1[g]; }
+        }
+        l0 = wave_sum(l0);
+        l1 = wave_sum(l1);
         if (wave == 0) {
-            if (valid && hi == 0) {
-                float* o = a.scores + (off0 + myrow) * (long long)a.C;
-                o[c0] = s0;
-                if (c1 != c0) o[c1] = s1;
-            }
+#pragma unroll
+            for (int g = 0; g < HS_RG; ++g)
+                if (valid[g] && hi == 0) {
+                    float* o = a.scores + (off0 + row0 + 32 * g + l31) * (long long)a.C;
+                    o[c0] = s0[g];
+                    if (c1 != c0) o[c1] = s1[g];
+                }
             if (lane == 0) {
                 float* ml = a.part_ml + (slot * a.C + c0) * 2;
                 ml[0] = m0; ml[1] = l0;
                 if (c1 != c0) { ml[2] = m1; ml[3] = l1; }
             }
         }
-        // ---- weighted value sum: Bpart[c][k] = sum_n p[n][c] V[n][k], 512 k per sweep; wave w sums rows 8w..8w+7
+        // ---- weighted value sum: Bpart[c][k] = sum_n p[n][c] V[n][k], 512 k per sweep; wave w sums rows 16w..16w+15
+        //      (they all belong to row group w >> 1: the shuffles below read this wave's own copies of p and the rows)
         float* pb0 = a.part_B + (slot * a.C + c0) * (long long)Kv;
         float* pb1 = a.part_B + (slot * a.C + c1) * (long long)Kv;
+        const long long rsrc = (wave >> 1) ? myphys[HS_RG - 1] : myphys[0];
+        const float w0src = (wave >> 1) ? p0[HS_RG - 1] : p0[0], w1src = (wave >> 1) ? p1[HS_RG - 1] : p1[0];
         for (int k0 = 0; k0 < Kv; k0 += 512) {
             f32x4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
             const int ka = k0 + lane * 4, kb = ka + 256;
             // unconditional loads from a clamped column (a lane past Kv accumulates junk it never stores)
             const int kac = ka < Kv ? ka : Kv - 4, kbc = kb < Kv ? kb : Kv - 4;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int n = 8 * wave + j;
-                const long long r = __shfl(myphys, n, 64);   // rows past the bag end were clamped (weight 0)
-                const float w0 = __shfl(p0, n, 64), w1 = __shfl(p1, n, 64);
+#pragma unroll 8
+            for (int j = 0; j < 16; ++j) {
+                const int n = 16 * (wave & 1) + j;
+                const long long r = __shfl(rsrc, n, 64);     // rows past the bag end were clamped (weight 0)
+                const float w0 = __shfl(w0src, n, 64), w1 = __shfl(w1src, n, 64);
                 const T* vr = vbase + r * (long long)Kv;
                 const f32x4 va = load4_nocheck<T>(vr, kac), vb = load4_nocheck<T>(vr, kbc);
                 acc00 += w0 * va; acc01 += w0 * vb;

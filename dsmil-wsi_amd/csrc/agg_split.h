@@ -230,6 +230,7 @@ __device__ __forceinline__ bool mlp_tile_split(const AttendArgs& a, int bag, int
 __device__ __forceinline__ void s3_wait_vm_dyn(int n) {  // n is wave-uniform
     switch (n) {
         case 0: S3_WAIT_VM(0); break;
+        case 2: S3_WAIT_VM(2); break;
         case 3: S3_WAIT_VM(3); break;
         case 4: S3_WAIT_VM(4); break;
         case 6: S3_WAIT_VM(6); break;
