@@ -446,6 +446,7 @@ __global__ __launch_bounds__(1024) void k_bwd_critical(const int64_t* __restrict
     const int j = threadIdx.x & (QD - 1), grp = threadIdx.x >> 7;
     for (int c = 0; c < C; ++c) {
         float s = 0.f;
+#pragma unroll 8
         for (long long t = grp; t < ntile; t += 8) s += gqp[(t * C + c) * QD + j];
         __syncthreads();
         red[grp][j] = s;
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(HS_THREADS, 2) void k_bwd_gh_hs(GhArgs g) {
 // before the MFMAs of step s.  Wave w = (column tile w & 1, unit-tile pair w >> 1): 2 accumulator tiles, 24 MFMAs per
 // 32 rows.  Column sums of A0 / A1 (bias gradients) come from the staged values of the first slab of each kind.
 constexpr int TN_LDW = 20;      // 32-bit words per (plane, column) row: 16 row pairs + 4 pad
-constexpr int TN_WGS = 512;     // target workgroups per launch (two per CU): sets the number of row ranges
+constexpr int TN_WGS = 384;     // target workgroups per launch: sets the number of row ranges (fewer = fewer partials to reduce)
 struct TnArgs {
     const float* A0;
     const float* A1;
@@ -564,20 +565,32 @@ __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
     // two register sets: the loads of steps s+1 AND s+2 are in flight while step s runs (one set ahead left every step
     // waiting a full memory latency for its operands: 7 steps x ~4.5 us)
     float ra[2][2][8], rb[2][8];
+    const int bcol = bcol_ok ? col0 + cb : ldb - 1;    // (a clamped column's products are never stored)
+    // Branch-free: rows past the range read its last row (the A values are zeroed when they are cut), so the 24 loads of a
+    // step issue back to back — behind a per-row bounds branch hipcc had waited for each one (and for the row-map entry
+    // in front of it) before issuing the next: 33 us for 75 MB.
     auto prefetch = [&](auto setc, long long r0) {
         constexpr int SET = decltype(setc)::value;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const long long r = r0 + 8 * (ja + 2 * i) + e;
-                ra[SET][i][e] = r < rend ? Am[r * QD + u] : 0.f;
+                long long r = r0 + 8 * (ja + 2 * i) + e;
+                r = r < rend ? r : rend - 1;
+                ra[SET][i][e] = Am[r * QD + u];
             }
+        long long pr[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const long long r = r0 + 8 * jb + e;
-            rb[SET][e] = (r < rend && bcol_ok) ? Bm[phys_row(bmap, r) * (long long)ldb + col0 + cb] : 0.f;
+            pr[e] = r < rend ? r : rend - 1;
         }
+        if (bmap) {   // (one uniform branch; the eight row-map entries load back to back)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pr[e] = (long long)bmap[pr[e]];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rb[SET][e] = Bm[pr[e] * (long long)ldb + bcol];
     };
     f32x16 acc[2];
 #pragma unroll
@@ -592,6 +605,9 @@ __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
         // cut the staged values into planes, transposed into LDS
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (r0 + 8 * (ja + 2 * i) + e >= rend) ra[SET][i][e] = 0.f;   // rows past the range (wave-uniform)
             S3Frag f[3];
             split3(ra[SET][i], f);
 #pragma unroll
