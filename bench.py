@@ -709,7 +709,7 @@ def train_leg(cx, weights_tag):
         opt.step()
         last["loss"] = loss.item() if sync else loss.detach()
 
-    dt, inner, _, _ = cx.timed(step, args.steps, args.warmup, args.min_seconds / 2)
+    dt, inner, _, _ = cx.timed(step, args.steps, max(50, args.warmup), args.min_seconds / 2)   # (50 steps: allocator + clocks settled)
     value = cx.world * inner * args.steps / dt
     dt2, inner2, _, _ = cx.timed(lambda: step(False), max(2, args.steps // 4), 1, args.min_seconds / 4)
     value_nosync = cx.world * inner2 * max(2, args.steps // 4) / dt2

@@ -410,9 +410,7 @@ __global__ __launch_bounds__(QMAX_T) void k_qmax(
     const float* __restrict__ q0_w, const float* __restrict__ q0_b,
     const float* __restrict__ q2_w, const float* __restrict__ q2_b,
     float* __restrict__ qmax, int64_t* __restrict__ idx_out, int K, int C, int nonlinear, int bag0,
-    int mode = 0, float* __restrict__ best_val_out = nullptr, const int64_t* __restrict__ rowmap = nullptr, int r0 = R0,
-    unsigned* __restrict__ done_cnt = nullptr) {
-    if (done_cnt && blockIdx.y == 0 && threadIdx.x == 0) done_cnt[bag0 + blockIdx.x] = 0u;   // k_finish's last-block ticket
+    int mode = 0, float* __restrict__ best_val_out = nullptr, const int64_t* __restrict__ rowmap = nullptr, int r0 = R0) {
     __shared__ float s_v[QMAX_T / 64];
     __shared__ long long s_i[QMAX_T / 64];
     __shared__ float s_h[QD];
@@ -851,11 +849,7 @@ __global__ __launch_bounds__(256) void k_finish(
     const int64_t* __restrict__ offsets, const float* __restrict__ part_ml,
     const float* __restrict__ part_B, const float* __restrict__ fcc_w,
     float* __restrict__ A, float* __restrict__ B, float* __restrict__ pred_part, int Kv, int C, int BM,
-    float* __restrict__ ml_out = nullptr, int seg_per = 0, int seg_T = 0, const float* __restrict__ fcc_b = nullptr,
-    float* __restrict__ pred = nullptr, unsigned* __restrict__ done_cnt = nullptr) {
-    // pred != null: the LAST block of a bag to finish adds up the bag head (what k_pred did in a launch of its own):
-    // pred[bag][o] = fcc_b[o] + sum_{block, c} pred_part, blocks and classes in fixed order (deterministic).  done_cnt[bag]
-    // was zeroed by k_qmax of this forward and is left at zero.
+    float* __restrict__ ml_out = nullptr, int seg_per = 0, int seg_T = 0) {
     // seg_per > 0 (k_attend_bf16_res): the partials are per (workgroup, bag) — workgroup g owns the BM-row tile items
     // [g seg_per, (g + 1) seg_per) of the (bag, tile) list with seg_T items per bag, and wrote slot g + bag
     // ml_out != null (instance-sharded bag): leave A and B relative to this shard's max, un-normalised
@@ -936,23 +930,18 @@ __global__ __launch_bounds__(256) void k_finish(
         }
         __syncthreads();
     }
-    if (pred) {
-        __shared__ int s_last;
-        __threadfence();                                   // this block's pred_part is visible device-wide ...
-        if (tid == 0) s_last = (atomicAdd(&done_cnt[bag], 1u) == (unsigned)nblk - 1u);
-        __syncthreads();
-        if (s_last) {
-            __threadfence();                               // ... and the last block sees everybody's
-            if (tid < C) {
-                float sum = fcc_b[tid];
-                const volatile float* pp = pred_part + (long long)bag * nblk * C * C;
-                for (int j = 0; j < nblk; ++j)
-                    for (int c = 0; c < C; ++c) sum += pp[((long long)j * C + tid) * C + c];
-                pred[(long long)bag * C + tid] = sum;
-            }
-            if (tid == 0) done_cnt[bag] = 0u;
-        }
-    }
+}
+
+// pred[bag][o] = fcc_b[o] + sum_{block,c} pred_part  (fixed order => deterministic)
+__global__ void k_pred(const float* __restrict__ pred_part, const float* __restrict__ fcc_b,
+                       float* __restrict__ pred, int C, int nblk, int n_bags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bags * C) return;
+    const int bag = i / C, o = i % C;
+    float s = fcc_b[o];
+    for (int j = 0; j < nblk; ++j)
+        for (int c = 0; c < C; ++c) s += pred_part[(((long long)bag * nblk + j) * C + o) * C + c];
+    pred[i] = s;
 }
 
 // FCLayer alone
@@ -984,7 +973,7 @@ __global__ __launch_bounds__(256) void k_fc(const float* __restrict__ feats,
 
 // ---- host side ------------------------------------------------------------------------------
 struct WsLayout {
-    size_t part_val, part_idx, qmax, part_ml, part_B, pred_part, wsplit, off2, cnt, total;
+    size_t part_val, part_idx, qmax, part_ml, part_B, pred_part, wsplit, off2, total;
     long long slots0, slots, nchunk_max;
 };
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1024,7 +1013,6 @@ WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int K, 
     w.pred_part = o; o = al(o + (size_t)n_bags * w.nchunk_max * C * C * sizeof(float));
     w.wsplit = o; o = al(o + (size_t)(2 * ((K + 31) / 32) + 8) * S3_CHUNK_F4 * 16);  // cut query weights
     w.off2 = o; o = al(o + 2 * sizeof(int64_t));  // {0, N} of a lone shard (dsmil_agg_shard_*)
-    w.cnt = o; o = al(o + (size_t)n_bags * sizeof(unsigned));   // k_finish: blocks of a bag that have finished
     w.total = o;
     return w;
 }
@@ -1263,7 +1251,6 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     float* part_ml = (float*)(w8 + L.part_ml);
     float* part_B = (float*)(w8 + L.part_B);
     float* pred_part = (float*)(w8 + L.pred_part);
-    unsigned* done_cnt = (sh.phase == 0) ? (unsigned*)(w8 + L.cnt) : nullptr;
     const float* f32 = (const float*)feats;
     const bf16_t* b16 = (const bf16_t*)feats;
 
@@ -1313,8 +1300,8 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         // 2. critical instance + its query
         dim3 gq((unsigned)nb, (unsigned)C);
         if (sh.phase == 1) {
-            if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap, r0, done_cnt);
-            else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap, r0, done_cnt);
+            if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap, r0);
+            else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap, r0);
             return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
         }
         if (sh.phase == 2) {
@@ -1322,10 +1309,10 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
             if (r4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
             else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
         }
-        else if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), gq, dim3(QMAX_T), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0, done_cnt);
-        else if (bf16) hipLaunchKernelGGL((k_qmax<1, bf16_t>), gq, dim3(QMAX_T), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0, done_cnt);
-        else if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0, done_cnt);
-        else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0, done_cnt);
+        else if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), gq, dim3(QMAX_T), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0);
+        else if (bf16) hipLaunchKernelGGL((k_qmax<1, bf16_t>), gq, dim3(QMAX_T), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0);
+        else if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0);
+        else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
         // 3. query MLP on MFMA + scores + tile softmax + weighted value sum
         int rc;
@@ -1371,11 +1358,17 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     if (!DSMIL_EXPT_ON(a, 64)) {
         dim3 grid((unsigned)L.nchunk_max, (unsigned)n_bags);
         if (Kv % 4 == 0)
-            hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, seg_per ? RS_BM : (hs_bm ? hs_bm : BM), sh.ml_out, seg_per, seg_T, p->fcc_b, done_cnt ? pred : nullptr, done_cnt);
+            hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, seg_per ? RS_BM : (hs_bm ? hs_bm : BM), sh.ml_out, seg_per, seg_T);
         else
-            hipLaunchKernelGGL(k_finish<1>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM, sh.ml_out, 0, 0, p->fcc_b, done_cnt ? pred : nullptr, done_cnt);
+            hipLaunchKernelGGL(k_finish<1>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM, sh.ml_out, 0, 0);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
-        // (sh.phase == 2: the bag head runs after the cross-shard merge; otherwise k_finish's last block per bag formed pred)
+        if (sh.phase == 2) return DSMIL_OK;  // the bag head runs after the cross-shard merge
+        // (folding this sum into k_finish's last block per bag — a device-scope fence + ticket in every block — was tried:
+        // 11 -> 52 us for 64 bags, the fences wait for the 5 MB of attention the blocks have just written)
+        const int n = n_bags * C;
+        hipLaunchKernelGGL(k_pred, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pred_part,
+                           p->fcc_b, pred, C, (int)L.nchunk_max, n_bags);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
     return DSMIL_OK;
 }
