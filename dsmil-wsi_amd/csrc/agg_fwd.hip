@@ -828,6 +828,10 @@ __global__ __launch_bounds__(HS_THREADS, 2) void k_attend_hs(AttendArgs a) {
     const long long off0 = a.offsets[bag];
     const long long Nb = a.offsets[bag + 1] - off0;
     attend_tail_hs<float>(a, Qw, smem + HS_STAGE + HS_PLANES, smem, bag, off0, Nb, (long long)tile * HS_BM, off0 / HS_BM + bag + tile);
+#ifdef DSMIL_TRACE
+    if (DSMIL_EXPT_ON(a, 64) && threadIdx.x == 0 && a.C == 1)
+        reinterpret_cast<unsigned long long*>(a.scores + (off0 + (long long)tile * HS_BM) * (long long)a.C)[4] = __builtin_readcyclecounter();
+#endif
 }
 
 // --------------------------------------------------------------------------------------------

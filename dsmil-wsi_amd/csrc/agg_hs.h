@@ -8,7 +8,7 @@
 //             tile w) for both 32-row groups: a quarter of the MFMA chain per wave, two independent accumulators, and
 //             NOTHING but MFMAs, 16-B LDS fragment reads and its weight loads in the loop.
 //   cutter waves 4-7   wave 4+j streams rows 16j..16j+15 of every 32-k feature chunk through LDS-DMA into a private ring
-//             (five chunks ahead), cuts each fp32 value ONCE into its three exact bf16 planes and writes them in
+//             (eleven chunks ahead), cuts each fp32 value ONCE into its three exact bf16 planes and writes them in
 //             MFMA-fragment order into a two-slot plane ring; they leave the kernel after the last chunk.
 // Same arithmetic as the batched kernels — the same exact planes, the same six plane products in the same order, k
 // ascending — so H and Q are bit-identical to theirs.
@@ -32,15 +32,17 @@ namespace {
 
 constexpr int HS_RG = 2;                 // 32-row groups per tile
 constexpr int HS_BM = 32 * HS_RG;        // rows per tile
-constexpr int HS_WRD = 3;                // weight register ring depth, in 16-k steps (two steps ahead)
-constexpr int HS_XR = 6;                 // depth of a cutter's staging ring, in 32-k chunks
+constexpr int HS_WRD = 4;                // weight register ring depth, in 16-k steps (three steps ahead)
+constexpr int HS_XR = 12;                // depth of a cutter's staging ring, in 32-k chunks: 11 chunks = 88 KiB of the tile in
+                                         // flight per CU (HBM's bandwidth-delay product is ~48 KiB per CU; with 6 a tile's 128 KiB
+                                         // took three latency periods)
 constexpr int HS_THREADS = 512;          // four compute waves + four cutter waves
 constexpr int HS_STAGE = 4 * HS_XR * 512;        // floats: [cutter][ring slot][16 rows x 32 k]
 constexpr int HS_PL_SLOT = 3 * 2 * 2 * HS_BM;    // 16-B units per plane-ring slot: [plane][k-step][hi][row]
 constexpr int HS_PLANES = 2 * HS_PL_SLOT * 4;    // floats: two slots
 constexpr int HS_SCRATCH = 1536;         // floats behind the rings, for the caller's tail
 constexpr int HS_LDS_BYTES = (HS_STAGE + HS_PLANES + HS_SCRATCH) * 4;
-static_assert(3 * 8 * 2 * HS_BM * 4 <= HS_STAGE, "the hidden-layer plane fragments alias the staging rings");
+static_assert((3 * 8 + 1) * 2 * HS_BM * 4 <= HS_STAGE, "the hidden-layer plane fragments (+ one read-ahead) alias the staging rings");
 static_assert(4 * 1024 <= HS_STAGE, "the value-sum merge buffer aliases the staging rings");
 
 // On return compute wave w holds, per 32-row group g, in the MFMA D layout (lane (l31, hi), reg 4q+e <-> row 32g + l31, unit
@@ -66,6 +68,13 @@ __device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int ti
     const int nk1 = (K + 31) / 32;
     const int nks = 2 * nk1;
     const int nst = nks + (a.nonlinear ? 8 : 0);
+#ifdef DSMIL_TRACE   // trace builds + DSMIL_EXPT=64: s_memtime stamps into this tile's rows of A (tools/stamp_hs.py)
+    unsigned long long* hs_tr = reinterpret_cast<unsigned long long*>(a.scores + (off0 + row0) * (long long)a.C);
+    auto STAMP = [&](int i) { if (DSMIL_EXPT_ON(a, 64) && lane == 0 && (wave == 0 || wave == 4) && a.C == 1) hs_tr[i] = __builtin_readcyclecounter(); };
+#else
+    auto STAMP = [](int) {};
+#endif
+    STAMP(wave == 4 ? 16 : 0);
 
     if (wave >= 4) {
         // ---- a CUTTER wave: rows 16j .. 16j+15 of the tile.  Its DMA pieces, their vmcnt and the staging ring are private:
@@ -91,10 +100,14 @@ __device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int ti
             }
         };
         for (int c = 0; c < HS_XR - 1 && c < nk1; ++c) issue_chunk(c);
+        STAMP(17);
         const int rr = lane >> 2, o = lane & 3;   // this lane cuts row 16j + rr, k-octet o = (k-step o >> 1, half o & 1)
         for (int c = 0; c < nk1; ++c) {
             const int ahead = (c + HS_XR - 2 < nk1 - 1 ? c + HS_XR - 2 : nk1 - 1) - c;   // chunks issued behind chunk c
             s3_wait_vm_dyn(2 * ahead);             // chunk c has landed (this wave's own pieces: all it reads)
+            if (c == 0) STAMP(18);
+            if (c == 1) STAMP(20);
+            if (c == 8) STAMP(21);
             const float* x = stage + (c % HS_XR) * 512 + rr * 32 + o * 8;
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(x);
             const f32x4 x1 = *reinterpret_cast<const f32x4*>(x + 4);
@@ -109,6 +122,7 @@ __device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int ti
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the plane writes are in LDS (NOT vmcnt: the ring stays in flight)
             __builtin_amdgcn_s_barrier();          // planes of chunk c are visible to the compute waves
         }
+        STAMP(19);
         return false;                              // (a finished wave no longer counts at barriers)
     }
     const f32x4* wpk = reinterpret_cast<const f32x4*>(a.wpk) + (3 * wave) * 64 + lane;   // this lane's slot of piece 3w
@@ -140,11 +154,13 @@ __device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int ti
     // prologue: the weights of the first HS_WRD - 1 steps; chunk 0; the operand fragments of step 0
     load_w(std::integral_constant<int, 0>{}, 0);
     load_w(std::integral_constant<int, 1>{}, 1);
-    static_assert(HS_WRD == 3, "prologue and step grouping below");
+    load_w(std::integral_constant<int, 2>{}, 2);
+    static_assert(HS_WRD == 4, "prologue and step grouping below");
     __builtin_amdgcn_s_barrier();                    // the cutters' first: planes of chunk 0
     asm volatile("" ::: "memory");
     S3Frag xb[HS_RG][3];
     read_frags(std::false_type{}, 0, xb);
+    STAMP(1);
     // One 16-k step: the fragments of step s+1 are requested first, then 12 MFMAs alternate between the two row groups
     // (independent accumulators: back-to-back issue).  RI = the step's slot of the weight ring, G2 = second GEMM, PRE = there
     // is a next step whose fragments are in LDS already (literals: registers are addressed statically).
@@ -157,9 +173,18 @@ __device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int ti
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-        load_w(std::integral_constant<int, (RI + HS_WRD - 1) % HS_WRD>{}, s + HS_WRD - 1);
+        if (!DSMIL_EXPT_ON(a, 0x8000)) load_w(std::integral_constant<int, (RI + HS_WRD - 1) % HS_WRD>{}, s + HS_WRD - 1);
         S3Frag xn[HS_RG][3];
-        if constexpr (PRE) read_frags(g2, s + 1, xn);
+        if constexpr (PRE) {
+            if (!DSMIL_EXPT_ON(a, 0x10000)) read_frags(g2, s + 1, xn);
+            else {
+#pragma unroll
+                for (int g = 0; g < HS_RG; ++g)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) xn[g][p] = xb[g][p];
+            }
+        }
+        if (!DSMIL_EXPT_ON(a, 0x4000))
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
             const int g = k & 1, q = P0 + (k >> 1);
@@ -218,34 +243,50 @@ __device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int ti
     // read-ahead: the hidden layer is not in LDS yet) and the eight GEMM-2 steps with literal ring slots.
     auto finish = [&](auto r0, int s) {
         constexpr int R0 = decltype(r0)::value;
+        STAMP(12);
         step(std::integral_constant<int, R0>{}, F_{}, F_{}, s);                        // s == nks - 1
+        STAMP(5);
         if (a.nonlinear) {
-            step(std::integral_constant<int, (R0 + 1) % HS_WRD>{}, T_{}, T_{}, s + 1);
-            step(std::integral_constant<int, (R0 + 2) % HS_WRD>{}, T_{}, T_{}, s + 2);
-            step(std::integral_constant<int, (R0 + 3) % HS_WRD>{}, T_{}, T_{}, s + 3);
-            step(std::integral_constant<int, (R0 + 4) % HS_WRD>{}, T_{}, T_{}, s + 4);
-            step(std::integral_constant<int, (R0 + 5) % HS_WRD>{}, T_{}, T_{}, s + 5);
-            step(std::integral_constant<int, (R0 + 6) % HS_WRD>{}, T_{}, T_{}, s + 6);
-            step(std::integral_constant<int, (R0 + 7) % HS_WRD>{}, T_{}, T_{}, s + 7);
-            step(std::integral_constant<int, (R0 + 8) % HS_WRD>{}, T_{}, F_{}, s + 8);
+            // the eight GEMM-2 steps as TWO passes over one four-step body (every ring slot once per pass).  Unrolled, the
+            // first steps ran at 5.6 k ticks against 1 k for a GEMM-1 step (stamps): straight-line code is fetched cold on
+            // every tile, the loop body is not.  (The last step reads ahead like the others: one unused fragment.)
+#pragma unroll 1
+            for (int it = 0; it < 2; ++it) {
+                const int sb = s + 1 + 4 * it;
+                step(std::integral_constant<int, (R0 + 1) % HS_WRD>{}, T_{}, T_{}, sb);
+                step(std::integral_constant<int, (R0 + 2) % HS_WRD>{}, T_{}, T_{}, sb + 1);
+                if (it == 0) STAMP(6);
+                step(std::integral_constant<int, (R0 + 3) % HS_WRD>{}, T_{}, T_{}, sb + 2);
+                step(std::integral_constant<int, (R0 + 4) % HS_WRD>{}, T_{}, T_{}, sb + 3);
+            }
+            STAMP(7);
         }
     };
     int s = 0;
     for (; s + HS_WRD <= nks - 1; s += HS_WRD) {
+        if ((s & 7) == 0) STAMP(8 + (s >> 3));
         step(std::integral_constant<int, 0>{}, F_{}, T_{}, s);
         step(std::integral_constant<int, 1>{}, F_{}, T_{}, s + 1);
         step(std::integral_constant<int, 2>{}, F_{}, T_{}, s + 2);
+        step(std::integral_constant<int, 3>{}, F_{}, T_{}, s + 3);
     }
+    STAMP(2);
     switch (nks - 1 - s) {
         case 0: finish(std::integral_constant<int, 0>{}, s); break;
         case 1:
             step(std::integral_constant<int, 0>{}, F_{}, T_{}, s);
             finish(std::integral_constant<int, 1>{}, s + 1);
             break;
-        default:
+        case 2:
             step(std::integral_constant<int, 0>{}, F_{}, T_{}, s);
             step(std::integral_constant<int, 1>{}, F_{}, T_{}, s + 1);
             finish(std::integral_constant<int, 2>{}, s + 2);
+            break;
+        default:
+            step(std::integral_constant<int, 0>{}, F_{}, T_{}, s);
+            step(std::integral_constant<int, 1>{}, F_{}, T_{}, s + 1);
+            step(std::integral_constant<int, 2>{}, F_{}, T_{}, s + 2);
+            finish(std::integral_constant<int, 3>{}, s + 3);
             break;
     }
     if (!a.nonlinear) {
@@ -261,6 +302,7 @@ __device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int ti
                 for (int e = 0; e < 4; ++e) Qw[g][4 * q + e] = fast_tanh(Qw[g][4 * q + e] + b[e]);
         }
     }
+    STAMP(3);
     __syncthreads();
     return true;
 }
@@ -339,7 +381,7 @@ __device__ __forceinline__ void attend_tail_hs(const AttendArgs& a, const f32x16
         if (wave == 0) {
 #pragma unroll
             for (int g = 0; g < HS_RG; ++g)
-                if (valid[g] && hi == 0) {
+                if (valid[g] && hi == 0 && !DSMIL_EXPT_ON(a, 64)) {
                     float* o = a.scores + (off0 + row0 + 32 * g + l31) * (long long)a.C;
                     o[c0] = s0[g];
                     if (c1 != c0) o[c1] = s1[g];

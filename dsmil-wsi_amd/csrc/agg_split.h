@@ -227,23 +227,12 @@ __device__ __forceinline__ bool mlp_tile_split(const AttendArgs& a, int bag, int
 // the DMA queue at every step.
 #define S3_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-__device__ __forceinline__ void s3_wait_vm_dyn(int n) {  // n is wave-uniform
+__device__ __forceinline__ void s3_wait_vm_dyn(int n) {  // n is wave-uniform; a count without a case waits for everything
     switch (n) {
-        case 0: S3_WAIT_VM(0); break;
-        case 2: S3_WAIT_VM(2); break;
-        case 3: S3_WAIT_VM(3); break;
-        case 4: S3_WAIT_VM(4); break;
-        case 6: S3_WAIT_VM(6); break;
-        case 7: S3_WAIT_VM(7); break;
-        case 8: S3_WAIT_VM(8); break;
-        case 10: S3_WAIT_VM(10); break;
-        case 12: S3_WAIT_VM(12); break;
-        case 16: S3_WAIT_VM(16); break;
-        case 20: S3_WAIT_VM(20); break;
-        case 24: S3_WAIT_VM(24); break;
-        case 28: S3_WAIT_VM(28); break;
-        case 32: S3_WAIT_VM(32); break;
-        case 48: S3_WAIT_VM(48); break;
+#define S3_CASE(k) case k: S3_WAIT_VM(k); break;
+        S3_CASE(0) S3_CASE(2) S3_CASE(3) S3_CASE(4) S3_CASE(6) S3_CASE(7) S3_CASE(8) S3_CASE(10) S3_CASE(12) S3_CASE(14)
+        S3_CASE(16) S3_CASE(18) S3_CASE(20) S3_CASE(22) S3_CASE(24) S3_CASE(26) S3_CASE(28) S3_CASE(30) S3_CASE(32) S3_CASE(48)
+#undef S3_CASE
         default: S3_WAIT_VM(0); break;
     }
 }
