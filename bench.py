@@ -824,13 +824,13 @@ def main():
     if "aggregator" in wl:
         line = aggregator_leg(cx, "c16", "f32", single_bag=not args.no_single_bag)
     subs = {}
+    if "train" in wl:   # (the latency-bound legs run before the long throughput legs)
+        subs["train_c1"] = train_leg(cx, "c16")
+        subs["train_c2"] = train_leg(cx, "tcga")
     if "aggregator_bf16" in wl:
         subs["aggregator_bf16"] = aggregator_leg(cx, "tcga", "bf16", single_bag=False)
     if "embedder" in wl:
         subs["embedder"] = embedder_leg(cx)
-    if "train" in wl:
-        subs["train_c1"] = train_leg(cx, "c16")
-        subs["train_c2"] = train_leg(cx, "tcga")
     if "slide" in wl:
         subs["slide"] = slide_leg(cx, args.slide_patches)
     if "slide_h2d" in wl:

@@ -82,18 +82,25 @@ __device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int ti
         // vector memory returns in order: the compute waves' weight stream must not queue behind the HBM-sourced features.)
         const int j = wave - 4;
         const float* feats = reinterpret_cast<const float*>(a.feats);
+        // LDS-DMA writes lane-linear (lane -> row lane >> 3 of the piece, 16-B slot lane & 7): the slot is permuted on the
+        // SOURCE side (slot c of row rr holds global slot c ^ (rr >> 1)) so that the cutting lanes — lane -> (row lane & 15,
+        // k-octet lane >> 4): 16 consecutive lanes = 16 rows, which makes the plane WRITES one contiguous 256-B run per
+        // octet — read their two 16-B slots without bank conflicts (PMC before: 38 % of the LDS cycles were conflicts).
         const float* xsrc[2];
+        int xslot[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {             // piece i = rows 16j + 8i .. + 7, lane -> (row lane >> 3, 16-B slot lane & 7)
-            long long gr = row0 + 16 * j + 8 * i + (lane >> 3);
+        for (int i = 0; i < 2; ++i) {             // piece i = rows 16j + 8i .. + 7
+            const int rrp = 8 * i + (lane >> 3);  // row inside the cutter's 16
+            long long gr = row0 + 16 * j + rrp;
             if (gr >= Nb) gr = Nb - 1;            // rows past the bag end are masked by the caller
             xsrc[i] = feats + phys_row(a.rowmap, off0 + gr) * (long long)K;
+            xslot[i] = ((lane & 7) ^ (rrp >> 1)) * 4;
         }
         float* stage = sStage + j * (HS_XR * 512);
         auto issue_chunk = [&](int c) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                int k = c * 32 + (lane & 7) * 4;
+                int k = c * 32 + xslot[i];
                 k = k < K ? k : K - 4;            // past K the packed weights are zero: any finite data will do
                 __builtin_amdgcn_global_load_lds((const DSMIL_GLOBAL void*)(xsrc[i] + k),
                                                  (__attribute__((address_space(3))) void*)(stage + (c % HS_XR) * 512 + i * 256), 16, 0, 0);
@@ -101,16 +108,17 @@ __device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int ti
         };
         for (int c = 0; c < HS_XR - 1 && c < nk1; ++c) issue_chunk(c);
         STAMP(17);
-        const int rr = lane >> 2, o = lane & 3;   // this lane cuts row 16j + rr, k-octet o = (k-step o >> 1, half o & 1)
+        const int rr = lane & 15, o = lane >> 4;  // this lane cuts row 16j + rr, k-octet o = (k-step o >> 1, half o & 1)
+        const int s0 = ((2 * o) ^ (rr >> 1)) * 4, s1 = ((2 * o + 1) ^ (rr >> 1)) * 4;
         for (int c = 0; c < nk1; ++c) {
             const int ahead = (c + HS_XR - 2 < nk1 - 1 ? c + HS_XR - 2 : nk1 - 1) - c;   // chunks issued behind chunk c
             s3_wait_vm_dyn(2 * ahead);             // chunk c has landed (this wave's own pieces: all it reads)
             if (c == 0) STAMP(18);
             if (c == 1) STAMP(20);
             if (c == 8) STAMP(21);
-            const float* x = stage + (c % HS_XR) * 512 + rr * 32 + o * 8;
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(x);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(x + 4);
+            const float* x = stage + (c % HS_XR) * 512 + rr * 32;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + s0);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(x + s1);
             const float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
             S3Frag f[3];
             split3(xv, f);
