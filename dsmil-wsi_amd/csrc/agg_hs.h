@@ -8,7 +8,7 @@
 //             tile w) for both 32-row groups: a quarter of the MFMA chain per wave, two independent accumulators, and
 //             NOTHING but MFMAs, 16-B LDS fragment reads and its weight loads in the loop.
 //   cutter waves 4-7   wave 4+j streams rows 16j..16j+15 of every 32-k feature chunk through LDS-DMA into a private ring
-//             (eleven chunks ahead), cuts each fp32 value ONCE into its three exact bf16 planes and writes them in
+//             (five chunks ahead), cuts each fp32 value ONCE into its three exact bf16 planes and writes them in
 //             MFMA-fragment order into a two-slot plane ring; they leave the kernel after the last chunk.
 // Same arithmetic as the batched kernels — the same exact planes, the same six plane products in the same order, k
 // ascending — so H and Q are bit-identical to theirs.
@@ -24,18 +24,26 @@
 // wait for a step's weights also waited for each feature piece issued before them, so the features' ten-step lead shrank
 // to the weights' three) -> a fifth wave issuing the features 27 us (the wave's own VALU work — 90 ops of cutting per
 // step — and its MFMAs ran back to back) -> the cut pipelined by hand behind the MFMAs 54 us (41 spilled registers: a
-// scratch reload is a vector-memory operation and waits for the whole weight ring) -> this form.
+// scratch reload is a vector-memory operation and waits for the whole weight ring) -> four cutter waves 23.6 us -> the weight
+// loads pinned in front of each step's MFMAs (hipcc had sunk them and waited with vmcnt(0)) 20.5 us = this form.  Stamps
+// (tools/stamp_hs.py): prologue 11 %, GEMM 1 45 % (680 ticks per step against 384 of MFMA), exchange + GEMM 2 18 %, tail 26 %.
 #pragma once
 #include "agg_split.h"
+
+// timing-only ablations of the step (no weight loads / no fragment reads / no MFMAs): their run-time branches change the
+// code around them, so they exist only with -DDSMIL_HS_ABLATE, not in the experiment or trace builds
+#ifdef DSMIL_HS_ABLATE
+#define HS_ABL(a, bit) DSMIL_EXPT_ON(a, bit)
+#else
+#define HS_ABL(a, bit) false
+#endif
 
 namespace {
 
 constexpr int HS_RG = 2;                 // 32-row groups per tile
 constexpr int HS_BM = 32 * HS_RG;        // rows per tile
 constexpr int HS_WRD = 4;                // weight register ring depth, in 16-k steps (three steps ahead)
-constexpr int HS_XR = 12;                // depth of a cutter's staging ring, in 32-k chunks: 11 chunks = 88 KiB of the tile in
-                                         // flight per CU (HBM's bandwidth-delay product is ~48 KiB per CU; with 6 a tile's 128 KiB
-                                         // took three latency periods)
+constexpr int HS_XR = 6;                 // depth of a cutter's staging ring, in 32-k chunks (12 measured the same)
 constexpr int HS_THREADS = 512;          // four compute waves + four cutter waves
 constexpr int HS_STAGE = 4 * HS_XR * 512;        // floats: [cutter][ring slot][16 rows x 32 k]
 constexpr int HS_PL_SLOT = 3 * 2 * 2 * HS_BM;    // 16-B units per plane-ring slot: [plane][k-step][hi][row]
@@ -181,10 +189,14 @@ __device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int ti
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-        if (!DSMIL_EXPT_ON(a, 0x8000)) load_w(std::integral_constant<int, (RI + HS_WRD - 1) % HS_WRD>{}, s + HS_WRD - 1);
+        // (sched_barrier: hipcc otherwise sinks these three loads behind the MFMAs of later steps and then waits for them
+        // with vmcnt(0) — the stamps showed whole steps waiting an L2 round trip)
+        __builtin_amdgcn_sched_barrier(0);
+        if (!HS_ABL(a, 0x8000)) load_w(std::integral_constant<int, (RI + HS_WRD - 1) % HS_WRD>{}, s + HS_WRD - 1);
+        __builtin_amdgcn_sched_barrier(0);
         S3Frag xn[HS_RG][3];
         if constexpr (PRE) {
-            if (!DSMIL_EXPT_ON(a, 0x10000)) read_frags(g2, s + 1, xn);
+            if (!HS_ABL(a, 0x10000)) read_frags(g2, s + 1, xn);
             else {
 #pragma unroll
                 for (int g = 0; g < HS_RG; ++g)
@@ -192,7 +204,7 @@ __device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int ti
                     for (int p = 0; p < 3; ++p) xn[g][p] = xb[g][p];
             }
         }
-        if (!DSMIL_EXPT_ON(a, 0x4000))
+        if (!HS_ABL(a, 0x4000))
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
             const int g = k & 1, q = P0 + (k >> 1);
@@ -205,6 +217,7 @@ __device__ __forceinline__ bool mlp_tile_hs(const AttendArgs& a, int bag, int ti
 #pragma unroll
                 for (int p = 0; p < 3; ++p) xb[g][p] = xn[g][p];
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (!G2 && s == nks - 1) {
             // ---- bias (+ReLU): reg 4q+e <-> unit 32 wave + 8q + 4hi + e
 #pragma unroll
