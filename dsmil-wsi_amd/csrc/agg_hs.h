@@ -50,7 +50,8 @@ constexpr int HS_PL_SLOT = 3 * 2 * 2 * HS_BM;    // 16-B units per plane-ring sl
 constexpr int HS_PLANES = 2 * HS_PL_SLOT * 4;    // floats: two slots
 constexpr int HS_SCRATCH = 1536;         // floats behind the rings, for the caller's tail
 constexpr int HS_LDS_BYTES = (HS_STAGE + HS_PLANES + HS_SCRATCH) * 4;
-static_assert((3 * 8 + 1) * 2 * HS_BM * 4 <= HS_STAGE, "the hidden-layer plane fragments (+ one read-ahead) alias the staging rings");
+static_assert(3 * 8 * 2 * HS_BM * 4 <= HS_STAGE, "the hidden-layer plane fragments alias the staging rings");
+static_assert((3 * 8 + 1) * 2 * HS_BM * 4 <= HS_STAGE + HS_PLANES, "(the last GEMM-2 step reads one unused fragment ahead: it falls into the plane ring)");
 static_assert(4 * 1024 <= HS_STAGE, "the value-sum merge buffer aliases the staging rings");
 
 // On return compute wave w holds, per 32-row group g, in the MFMA D layout (lane (l31, hi), reg 4q+e <-> row 32g + l31, unit
