@@ -542,10 +542,14 @@ struct TnArgs {
 // ONE row range all read the same A rows, so they are given to consecutive workgroups of the SAME XCD — its L2 then serves
 // the A tile to nine of the ten slabs (with (slab, split) = (L % nslab, L / nslab) the slabs of a range sat on eight
 // different L2s: 75 MB of fabric reads per launch for 35 MB of operands).
+// WIDE (rows 16-B aligned, K % 4 == 0): a staging thread loads 16 B — 4 columns x 8 rows = 8 loads instead of 32 — and the
+// LDS holds the columns permuted (column 4g + c at position 32c + g, 16c + g for B) so that consecutive lanes still write
+// consecutive positions; the epilogue undoes the permutation.  26.4 -> 23.5 us for the 10 000-row bag (staging-, not MFMA-bound: 3.3 us of MFMA time).
+template <bool WIDE>
 __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned sA[3 * QD * TN_LDW];
     __shared__ __attribute__((aligned(16))) unsigned sB[3 * 64 * TN_LDW];
-    __shared__ float s_cs[256];
+    __shared__ float s_cs[512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int slab = q % a.nslab, split = xcd + 8 * (q / a.nslab);
@@ -558,75 +562,15 @@ __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
     const int64_t* bmap = is_h ? nullptr : a.rowmap;
     const long long rbeg = (long long)split * a.R, rend = (rbeg + a.R < a.N) ? rbeg + a.R : a.N;
     const bool want_cs = (slab == 0) || (slab == a.nx);
-    // staging roles: A: column u, 8-row groups ja, ja + 2; B: column cb, 8-row group jb
-    const int u = tid & 127, ja = tid >> 7;
-    const int cb = tid & 63, jb = tid >> 6;
-    const bool bcol_ok = col0 + cb < ldb;
-    // two register sets: the loads of steps s+1 AND s+2 are in flight while step s runs (one set ahead left every step
-    // waiting a full memory latency for its operands: 7 steps x ~4.5 us)
-    float ra[2][2][8], rb[2][8];
-    const int bcol = bcol_ok ? col0 + cb : ldb - 1;    // (a clamped column's products are never stored)
-    // Branch-free: rows past the range read its last row (the A values are zeroed when they are cut), so the 24 loads of a
-    // step issue back to back — behind a per-row bounds branch hipcc had waited for each one (and for the row-map entry
-    // in front of it) before issuing the next: 33 us for 75 MB.
-    auto prefetch = [&](auto setc, long long r0) {
-        constexpr int SET = decltype(setc)::value;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                long long r = r0 + 8 * (ja + 2 * i) + e;
-                r = r < rend ? r : rend - 1;
-                ra[SET][i][e] = Am[r * QD + u];
-            }
-        long long pr[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const long long r = r0 + 8 * jb + e;
-            pr[e] = r < rend ? r : rend - 1;
-        }
-        if (bmap) {   // (one uniform branch; the eight row-map entries load back to back)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pr[e] = (long long)bmap[pr[e]];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rb[SET][e] = Bm[pr[e] * (long long)ldb + bcol];
-    };
     f32x16 acc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float colsum = 0.f;
     const int ct = wave & 1, up = wave >> 1;
     constexpr int P0 = 9 - NP_BWD;
-    auto step = [&](auto setc, long long r0) {
-        constexpr int SET = decltype(setc)::value;
-        // cut the staged values into planes, transposed into LDS
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (r0 + 8 * (ja + 2 * i) + e >= rend) ra[SET][i][e] = 0.f;   // rows past the range (wave-uniform)
-            S3Frag f[3];
-            split3(ra[SET][i], f);
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                *reinterpret_cast<f32x4*>(&sA[(p * QD + u) * TN_LDW + 4 * (ja + 2 * i)]) = f[p].f;
-            if (want_cs) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) colsum += ra[SET][i][e];
-            }
-        }
-        {
-            S3Frag f[3];
-            split3(rb[SET], f);
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                *reinterpret_cast<f32x4*>(&sB[(p * 64 + cb) * TN_LDW + 4 * jb]) = f[p].f;
-        }
-        __syncthreads();
-        prefetch(setc, r0 + 64);   // (rows past the range load nothing)
+    // the MFMA phase of a 32-row step: the same for both staging forms (positions, not columns, index the LDS rows)
+    auto mfma_phase = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int j = 2 * ks + hi;    // this lane's 8-row group: MFMA k = 8 hi + i  <->  row 16 ks + 8 hi + i
@@ -640,34 +584,179 @@ __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
                 for (int p = 0; p < 3; ++p)
                     fa[p].f = *reinterpret_cast<const f32x4*>(&sA[(p * QD + 32 * (2 * up + tt) + l31) * TN_LDW + 4 * j]);
 #pragma unroll
-                for (int q = P0; q < 9; ++q)
-                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S3_PA(q)].v, fb[S3_PB(q)].v, acc[tt], 0, 0, 0);
+                for (int qq = P0; qq < 9; ++qq)
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S3_PA(qq)].v, fb[S3_PB(qq)].v, acc[tt], 0, 0, 0);
             }
         }
-        __syncthreads();
     };
-    prefetch(std::integral_constant<int, 0>{}, rbeg);
-    prefetch(std::integral_constant<int, 1>{}, rbeg + 32);
-    for (long long r0 = rbeg; r0 < rend; r0 += 64) {
-        step(std::integral_constant<int, 0>{}, r0);
-        if (r0 + 32 < rend) step(std::integral_constant<int, 1>{}, r0 + 32);
-    }
-    // D[m = unit][n = column]: lane holds column 32 ct + l31, units 32 (2 up + tt) + (r & 3) + 8 (r >> 2) + 4 hi
-    const int col = col0 + 32 * ct + l31;
-    if (col < ldb) {
-        float* o = is_h ? a.part1 + (long long)split * QD * QD : a.part0 + (long long)split * QD * a.K;
+    if constexpr (WIDE) {
+        // staging roles: threads 0..127: A, columns 4g..4g+3 (g = tid & 31), 8-row group tid >> 5; threads 128..191: B, columns
+        // col0 + 4g.. (g = tid & 15), 8-row group (tid >> 4) & 3; the fourth wave only multiplies
+        const bool roleA = tid < 128, roleB = tid >= 128 && tid < 192;
+        const int g = roleA ? (tid & 31) : (tid & 15), jg = roleA ? (tid >> 5) : ((tid >> 4) & 3);
+        int bc = col0 + 4 * g;
+        bc = bc < ldb ? bc : ldb - 4;                      // (a clamped column's products are never stored)
+        const float* base = roleA ? Am + 4 * g : Bm + bc;
+        const int ld = roleA ? QD : ldb;
+        const int64_t* map = roleA ? nullptr : bmap;
+        f32x4 v[2][8];
+        auto prefetch = [&](auto setc, long long r0) {     // branch-free: rows past the range re-read its last row
+            constexpr int SET = decltype(setc)::value;
+            if (!(roleA || roleB)) return;
+            long long pr[8];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = 32 * (2 * up + tt) + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                o[(long long)m * ldb + col] = acc[tt][r];
+            for (int e = 0; e < 8; ++e) {
+                const long long r = r0 + 8 * jg + e;
+                pr[e] = r < rend ? r : rend - 1;
             }
-    }
-    if (want_cs) {
-        s_cs[tid] = colsum;
-        __syncthreads();
-        if (tid < QD) (is_h ? a.pb1 : a.pb0)[split * QD + tid] = s_cs[tid] + s_cs[tid + QD];
+            if (map) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pr[e] = (long long)map[pr[e]];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[SET][e] = *(const DSMIL_GLOBAL f32x4*)(base + pr[e] * (long long)ld);
+        };
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+        auto step = [&](auto setc, long long r0) {
+            constexpr int SET = decltype(setc)::value;
+            if (roleA || roleB) {
+                unsigned* dstb = roleA ? sA : sB;
+                const int npos = roleA ? QD : 64, cstride = roleA ? 32 : 16;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float xv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[e] = (roleA && r0 + 8 * jg + e >= rend) ? 0.f : v[SET][e][c];   // A rows past the range
+                    if (want_cs && roleA) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) cs[c] += xv[e];
+                    }
+                    S3Frag f[3];
+                    split3(xv, f);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        *reinterpret_cast<f32x4*>(&dstb[(p * npos + c * cstride + g) * TN_LDW + 4 * jg]) = f[p].f;
+                }
+            }
+            __syncthreads();
+            prefetch(setc, r0 + 64);
+            mfma_phase();
+            __syncthreads();
+        };
+        prefetch(std::integral_constant<int, 0>{}, rbeg);
+        prefetch(std::integral_constant<int, 1>{}, rbeg + 32);
+        for (long long r0 = rbeg; r0 < rend; r0 += 64) {
+            step(std::integral_constant<int, 0>{}, r0);
+            if (r0 + 32 < rend) step(std::integral_constant<int, 1>{}, r0 + 32);
+        }
+        // D[m position][n position]: position -> unit 4 (m & 31) + (m >> 5), column col0 + 4 (n & 15) + (n >> 4)
+        const int npos_ = 32 * ct + l31, col = col0 + 4 * (npos_ & 15) + (npos_ >> 4);
+        if (col < ldb) {
+            float* o = is_h ? a.part1 + (long long)split * QD * QD : a.part0 + (long long)split * QD * a.K;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mp = 32 * (2 * up + tt) + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    o[(long long)(4 * (mp & 31) + (mp >> 5)) * ldb + col] = acc[tt][r];
+                }
+        }
+        if (want_cs) {
+            if (roleA) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s_cs[jg * QD + 4 * g + c] = cs[c];
+            }
+            __syncthreads();
+            if (tid < QD) (is_h ? a.pb1 : a.pb0)[split * QD + tid] = (s_cs[tid] + s_cs[QD + tid]) + (s_cs[2 * QD + tid] + s_cs[3 * QD + tid]);
+        }
+    } else {
+        // staging roles: A: column u, 8-row groups ja, ja + 2; B: column cb, 8-row group jb
+        const int u = tid & 127, ja = tid >> 7;
+        const int cb = tid & 63, jb = tid >> 6;
+        const bool bcol_ok = col0 + cb < ldb;
+        // two register sets: the loads of steps s+1 AND s+2 are in flight while step s runs
+        float ra[2][2][8], rb[2][8];
+        const int bcol = bcol_ok ? col0 + cb : ldb - 1;    // (a clamped column's products are never stored)
+        // Branch-free: rows past the range read its last row (the A values are zeroed when they are cut), so the 24 loads of a
+        // step issue back to back — behind a per-row bounds branch hipcc had waited for each one (and for the row-map entry
+        // in front of it) before issuing the next: 33 us for 75 MB.
+        auto prefetch = [&](auto setc, long long r0) {
+            constexpr int SET = decltype(setc)::value;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    long long r = r0 + 8 * (ja + 2 * i) + e;
+                    r = r < rend ? r : rend - 1;
+                    ra[SET][i][e] = Am[r * QD + u];
+                }
+            long long pr[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const long long r = r0 + 8 * jb + e;
+                pr[e] = r < rend ? r : rend - 1;
+            }
+            if (bmap) {   // (one uniform branch; the eight row-map entries load back to back)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pr[e] = (long long)bmap[pr[e]];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rb[SET][e] = Bm[pr[e] * (long long)ldb + bcol];
+        };
+        float colsum = 0.f;
+        auto step = [&](auto setc, long long r0) {
+            constexpr int SET = decltype(setc)::value;
+            // cut the staged values into planes, transposed into LDS
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (r0 + 8 * (ja + 2 * i) + e >= rend) ra[SET][i][e] = 0.f;   // rows past the range (wave-uniform)
+                S3Frag f[3];
+                split3(ra[SET][i], f);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<f32x4*>(&sA[(p * QD + u) * TN_LDW + 4 * (ja + 2 * i)]) = f[p].f;
+                if (want_cs) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) colsum += ra[SET][i][e];
+                }
+            }
+            {
+                S3Frag f[3];
+                split3(rb[SET], f);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<f32x4*>(&sB[(p * 64 + cb) * TN_LDW + 4 * jb]) = f[p].f;
+            }
+            __syncthreads();
+            prefetch(setc, r0 + 64);   // (rows past the range re-read its last row)
+            mfma_phase();
+            __syncthreads();
+        };
+        prefetch(std::integral_constant<int, 0>{}, rbeg);
+        prefetch(std::integral_constant<int, 1>{}, rbeg + 32);
+        for (long long r0 = rbeg; r0 < rend; r0 += 64) {
+            step(std::integral_constant<int, 0>{}, r0);
+            if (r0 + 32 < rend) step(std::integral_constant<int, 1>{}, r0 + 32);
+        }
+        // D[m = unit][n = column]: lane holds column 32 ct + l31, units 32 (2 up + tt) + (r & 3) + 8 (r >> 2) + 4 hi
+        const int col = col0 + 32 * ct + l31;
+        if (col < ldb) {
+            float* o = is_h ? a.part1 + (long long)split * QD * QD : a.part0 + (long long)split * QD * a.K;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = 32 * (2 * up + tt) + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    o[(long long)m * ldb + col] = acc[tt][r];
+                }
+        }
+        if (want_cs) {
+            s_cs[tid] = colsum;
+            __syncthreads();
+            if (tid < QD) (is_h ? a.pb1 : a.pb0)[split * QD + tid] = s_cs[tid] + s_cs[tid + QD];
+        }
     }
 }
 
@@ -1010,7 +1099,8 @@ int agg_backward_impl(const float* feats, const float* vals, int64_t N, const ds
         tn.A0 = gz2; tn.A1 = nullptr; tn.Hb = nullptr;
     }
     // 7. weight gradients: contractions over instances, then the fixed-order reduction (+ the sparse FCLayer gradient)
-    hipLaunchKernelGGL(k_tn_split, dim3((unsigned)(tn.nslab * ((L.S + 7) / 8 * 8))), dim3(256), 0, st, tn);
+    if (v4) hipLaunchKernelGGL(k_tn_split<true>, dim3((unsigned)(tn.nslab * ((L.S + 7) / 8 * 8))), dim3(256), 0, st, tn);
+    else hipLaunchKernelGGL(k_tn_split<false>, dim3((unsigned)(tn.nslab * ((L.S + 7) / 8 * 8))), dim3(256), 0, st, tn);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     // 8. dense instance stream (FCLayer): only when the caller has a dense upstream gradient on the instance logits
     if (g_classes) {
