@@ -160,6 +160,14 @@ struct AttendArgs {
     // Row indirection (train_tcga.py:78-83 dropout_patches as an index list instead of a gathered copy): logical row i
     // of the batch lives at physical row rowmap[i] of feats / vals; nullptr = identity.  Outputs stay logical.
     const int64_t* rowmap;
+    // k_attend_hs only (qm_flag != nullptr): the critical row's query (k_qmax) runs INSIDE the attend launch — workgroups
+    // [0, C) of a bag's grid row produce qmax / the arg-max index while the tiles run their MLP, and publish through
+    // qm_flag[bag * C + c] (cleared by the logits launch before); the tiles read qmax behind the flag with agent-scope loads.
+    int* qm_flag;
+    const float* qm_part_val;
+    const long long* qm_part_idx;
+    int64_t* qm_idx;
+    int qm_r0;
 };
 
 __device__ __forceinline__ long long phys_row(const int64_t* __restrict__ rowmap, long long logical) {

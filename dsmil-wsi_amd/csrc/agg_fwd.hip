@@ -201,7 +201,9 @@ __global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
     const T* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ fc_w, const float* __restrict__ fc_b, float* __restrict__ classes_out,
     float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C, int bag0,
-    const int64_t* __restrict__ rowmap, int r0 = R0) {
+    const int64_t* __restrict__ rowmap, int r0 = R0, int* __restrict__ qm_flag = nullptr) {
+    // qm_flag: the hand-off flags of the attend launch that follows (AttendArgs::qm_flag), cleared here
+    if (qm_flag && blockIdx.x == 0 && (int)threadIdx.x < C) qm_flag[(long long)(bag0 + (int)blockIdx.y) * C + threadIdx.x] = 0;
     // r0 = rows per workgroup: R0 (128: a wave walks four 8-row groups) for batches, 32 (one group per wave) when there are
     // few rows — a lone 10 000-row bag is 79 workgroups at 128 rows, a third of the chip's CUs for an HBM-bound stream
     constexpr int EPL = StreamVec<T>::EPL;   // elements per lane per 128-B segment
@@ -822,7 +824,22 @@ __global__ void k_pack_agg_bf16(const float* __restrict__ q0_w, const float* __r
 template <int NP>
 __global__ __launch_bounds__(HS_THREADS, 2) void k_attend_hs(AttendArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int bag = a.bag0 + (int)blockIdx.y, tile = (int)blockIdx.x;
+    const int bag = a.bag0 + (int)blockIdx.y;
+    int tile = (int)blockIdx.x;
+    if (a.qm_flag) {   // the first C workgroups of the grid row: the critical row's query, beside the tiles' MLP
+        if (tile < a.C) {
+            long long* s_i = reinterpret_cast<long long*>(smem);
+            float* s_v = smem + 2 * (HS_THREADS / 64), *s_h = s_v + HS_THREADS / 64;
+            qmax_block<4, float>(reinterpret_cast<const float*>(a.feats), a.offsets, a.qm_part_val, a.qm_part_idx, a.q0_w, a.q0_b,
+                                 a.q2_w, a.q2_b, const_cast<float*>(a.qmax), a.qm_idx, a.K, a.C, a.nonlinear, bag, tile, s_v, s_i,
+                                 s_h, 0, nullptr, a.rowmap, a.qm_r0);
+            __syncthreads();   // every wave's stores are out (vmcnt 0) before the release below writes the L2 back
+            if (threadIdx.x == 0)
+                __hip_atomic_store(a.qm_flag + (long long)bag * a.C + tile, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        tile -= a.C;
+    }
     f32x16 Hw[HS_RG], Qw[HS_RG];
     if (!mlp_tile_hs<NP>(a, bag, tile, smem, Hw, Qw)) return;
     const long long off0 = a.offsets[bag];
@@ -977,7 +994,7 @@ __global__ __launch_bounds__(256) void k_fc(const float* __restrict__ feats,
 
 // ---- host side ------------------------------------------------------------------------------
 struct WsLayout {
-    size_t part_val, part_idx, qmax, part_ml, part_B, pred_part, wsplit, off2, total;
+    size_t part_val, part_idx, qmax, qflag, part_ml, part_B, pred_part, wsplit, off2, total;
     long long slots0, slots, nchunk_max;
 };
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1012,6 +1029,7 @@ WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int K, 
     w.part_val = o; o = al(o + (size_t)w.slots0 * C * sizeof(float));
     w.part_idx = o; o = al(o + (size_t)w.slots0 * C * sizeof(long long));
     w.qmax = o; o = al(o + (size_t)n_bags * C * QD * sizeof(float));
+    w.qflag = o; o = al(o + (size_t)n_bags * C * sizeof(int));   // k_attend_hs: hand-off flags of the in-launch critical query
     w.part_ml = o; o = al(o + (size_t)w.slots * C * 2 * sizeof(float));
     w.part_B = o; o = al(o + (size_t)w.slots * C * Kv * sizeof(float));
     w.pred_part = o; o = al(o + (size_t)n_bags * w.nchunk_max * C * C * sizeof(float));
@@ -1057,7 +1075,7 @@ int launch_attend_hs(const AttendArgs& a, long long max_rows, int n_bags, hipStr
     lds += (size_t)lds_pad;
 #endif
     if (!dsmil_lds::allow((const void*)k_attend_hs<6>, (int)lds)) return DSMIL_E_LAUNCH;
-    dim3 grid((unsigned)((max_rows + HS_BM - 1) / HS_BM), (unsigned)n_bags);
+    dim3 grid((unsigned)((max_rows + HS_BM - 1) / HS_BM + (a.qm_flag ? a.C : 0)), (unsigned)n_bags);
     const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
     hipLaunchKernelGGL(k_attend_hs<6>, grid, dim3(HS_THREADS), lds, st, a);
     dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
@@ -1265,10 +1283,11 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     AttendArgs a{feats, vals, (const bf16_t*)packed_bf16, offsets, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, A,
                  part_ml, part_B, K, Kv, C, p->nonlinear, 0, 0, rowmap};
 #ifdef DSMIL_EXPERIMENTS
-    static const int expt = expt_env("DSMIL_EXPT"), logits_old = expt_env("DSMIL_LOGITS_OLD"), no_hs = expt_env("DSMIL_NO_HS");
+    static const int expt = expt_env("DSMIL_EXPT"), logits_old = expt_env("DSMIL_LOGITS_OLD"), no_hs = expt_env("DSMIL_NO_HS"),
+                     no_qmi = expt_env("DSMIL_NO_QMI");
     a.expt = expt;
 #else
-    constexpr int logits_old = 0, no_hs = 0;
+    constexpr int logits_old = 0, no_hs = 0, no_qmi = 0;
 #endif
     int seg_per = 0, seg_T = 0;   // k_attend_bf16_res: partials per (workgroup, bag), see k_finish
     int hs_bm = 0;                // k_attend_hs: rows per tile (the partial slots follow it)
@@ -1283,6 +1302,14 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         // and the streaming kernel runs
         const bool stream_ok = !classes_in && !logits_old && ((bf16 && (K % 8 == 0)) || (!bf16 && v4));
         const int r0 = (NW == 1 && stream_ok && sh.phase != 2) ? 32 : R0;
+        // few rows, fp32: k_attend_hs (below); with the streaming logits kernel before it, the critical row's query runs
+        // inside the attend launch (AttendArgs::qm_flag) instead of as k_qmax between the two
+        bool use_hs = !bf16 && NW == 1 && v4 && !no_hs && mlp_mode() == 6;
+#ifdef DSMIL_EXPERIMENTS
+        if (a.expt & 8) use_hs = false;
+#endif
+        const bool qm_inline = use_hs && stream_ok && sh.phase == 0 && !no_qmi;
+        int* qflag = qm_inline ? (int*)(w8 + L.qflag) : nullptr;
         dim3 grid((unsigned)((max_rows + r0 - 1) / r0), (unsigned)nb);
         if (sh.phase == 2) {}  // the caller already knows the bag-wide critical rows
         else if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
@@ -1295,8 +1322,8 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         else if (bf16) hipLaunchKernelGGL((k_logits_argmax<1, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else if (v4 && !logits_old) {
             const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 31) / 32 + 1) * 32) * sizeof(float);
-            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0);
-            else hipLaunchKernelGGL((k_logits_stream<1, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0);
+            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, qflag);
+            else hipLaunchKernelGGL((k_logits_stream<1, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, qflag);
         }
         else if (v4) hipLaunchKernelGGL((k_logits_argmax<4, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else hipLaunchKernelGGL((k_logits_argmax<1, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
@@ -1308,7 +1335,10 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
             else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 1, sh.best_val, rowmap, r0);
             return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
         }
-        if (sh.phase == 2) {
+        if (qm_inline) {   // produced by the first C workgroups of every grid row of k_attend_hs
+            a.qm_flag = qflag; a.qm_part_val = part_val; a.qm_part_idx = part_idx; a.qm_idx = idx; a.qm_r0 = r0;
+        }
+        else if (sh.phase == 2) {
             const bool r4 = (K % 4 == 0) && ((uintptr_t)sh.crit_rows % 16 == 0) && (((uintptr_t)p->q0_w) % 16 == 0);
             if (r4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
             else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
@@ -1351,7 +1381,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         else if (mode == 6 && NW == 1 && v4 && (a.expt & 8)) rc = launch_attend_split<1, 4, 6, true>(a, max_rows, nb, st);
 #endif
         else if (mode == 6 && NW == 4) rc = v4 ? launch_attend_split<4, 4, 6>(a, max_rows, nb, st) : launch_attend_split<4, 1, 6>(a, max_rows, nb, st);
-        else if (mode == 6 && v4 && !no_hs) { rc = launch_attend_hs(a, max_rows, nb, st); hs_bm = HS_BM; }   // few rows: hidden units split over the SIMDs
+        else if (use_hs) { rc = launch_attend_hs(a, max_rows, nb, st); hs_bm = HS_BM; }   // few rows: hidden units split over the SIMDs
         else if (mode == 6) rc = v4 ? launch_attend_split<1, 4, 6>(a, max_rows, nb, st) : launch_attend_split<1, 1, 6>(a, max_rows, nb, st);
         else if (NW == 8) rc = launch_attend<8, 4>(a, max_rows, nb, st);
         else if (NW == 4) rc = v4 ? launch_attend<4, 4>(a, max_rows, nb, st) : launch_attend<4, 1>(a, max_rows, nb, st);

@@ -361,10 +361,35 @@ __device__ __forceinline__ void attend_tail_hs(const AttendArgs& a, const f32x16
         float s0[HS_RG], s1[HS_RG];
 #pragma unroll
         for (int g = 0; g < HS_RG; ++g) { s0[g] = 0.f; s1[g] = 0.f; }
+        f32x4 u0q[4], u1q[4];
+        if (a.qm_flag) {
+            // the critical row's query comes from workgroups [0, C) of this launch: wait for their flags, then read it with
+            // agent-scope loads (another XCD's L2 may hold the previous launch's lines).  The producers were dispatched
+            // before any tile of this grid row and wait for nothing; the spin is bounded all the same.
+            const int* f0 = a.qm_flag + (long long)bag * a.C + c0;
+            const int* f1 = a.qm_flag + (long long)bag * a.C + c1;
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                if (__hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
+                    __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u0q[q][e] = __hip_atomic_load(qm0 + 8 * q + 4 * hi + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    u1q[q][e] = __hip_atomic_load(qm1 + 8 * q + 4 * hi + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u0q[q] = *reinterpret_cast<const f32x4*>(qm0 + 8 * q + 4 * hi);
+                u1q[q] = *reinterpret_cast<const f32x4*>(qm1 + 8 * q + 4 * hi);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 u0 = *reinterpret_cast<const f32x4*>(qm0 + 8 * q + 4 * hi);
-            const f32x4 u1 = *reinterpret_cast<const f32x4*>(qm1 + 8 * q + 4 * hi);
+            const f32x4 u0 = u0q[q], u1 = u1q[q];
 #pragma unroll
             for (int g = 0; g < HS_RG; ++g)
 #pragma unroll

@@ -43,7 +43,7 @@ def row(r, pmc, per_pass, **extra):
 
 
 table = {"source": f"profiles/{tag}_agg, profiles/{tag}_emb: rocprofv3 --kernel-trace --stats and separate --pmc passes of "
-                   f"`bench.py --streams 1` (tools/r3.sh prof_* / pmc_*), condensed by tools/prof_summary.py + tools/kernel_table.py",
+                   f"`bench.py --streams 1` (tools/r3.sh or tools/r4.sh prof_* / pmc_*), condensed by tools/prof_summary.py + tools/kernel_table.py",
          "peaks": {"bf16_mfma_tflops": 2500, "hbm_gbs": 8000}}
 rows, pmc = load("agg")
 feat32, feat16 = NB * N * K * 4, NB * N * K * 2
@@ -86,9 +86,19 @@ try:
     table["embedder_forward_ms"] = round(sum(e["ms_per_pass"] for e in emb), 3)
 except FileNotFoundError:
     pass
+for which, key in (("train", "train_step"), ("single", "single_bag")):
+    # one launch of every kernel per fused train step / per single-bag forward (tools/r4.sh prof_fused / prof_single)
+    try:
+        rows, pmc = load(which)
+    except FileNotFoundError:
+        continue
+    top = max(int(r["Calls"]) for r in rows)
+    sec = [row(r, pmc, round(int(r["Calls"]) / top, 2)) for r in rows if int(r["Calls"]) >= top // 2]
+    table[key] = sec
+    table[key + "_gpu_ms"] = round(sum(e["ms_per_pass"] for e in sec), 4)
 out = os.path.join(P, f"{tag}_kernel_table.json")
 json.dump(table, open(out, "w"), indent=1)
 print("wrote", out)
-for leg in ("aggregator", "aggregator_bf16", "embedder"):
+for leg in ("aggregator", "aggregator_bf16", "embedder", "train_step", "single_bag"):
     for e in table.get(leg, []):
         print(leg, e["kernel"][:50], e["ms_per_pass"], e.get("frac_of_bf16_mfma_peak"), e.get("frac_of_hbm_peak"), e.get("counter_over_alg_bytes"))
