@@ -317,7 +317,10 @@ __global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
 // --------------------------------------------------------------------------------------------
 // One (bag, class) by a 256-thread workgroup; s_v[4], s_i[4], s_h[128]: LDS scratch.  Ends with
 // every thread past its last LDS read (callers may reuse the scratch after a __syncthreads()).
-template <int VEC, typename T = float>
+// PRE (the in-launch producer of k_attend_hs: 8 waves, a 256-register budget): with K = 512 and the two-layer query, the
+// wave's whole share of both weight matrices (128 + 32 registers a lane) is requested BEFORE the arg-max, so the chain
+// arg-max -> row -> layer 1 -> layer 2 has one dependent load (the row) instead of five.  Same fmaf order either way.
+template <int VEC, typename T = float, bool PRE = false>
 __device__ __forceinline__ void qmax_block(
     const T* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ part_val, const long long* __restrict__ part_idx,
@@ -335,9 +338,40 @@ __device__ __forceinline__ void qmax_block(
     const int upw = QD / nwv;                      // hidden units per wave (multiple of 8)
     const long long slot0 = off0 / r0 + bag;
     const long long ntile = mode == 2 ? 0 : (Nb + r0 - 1) / r0;   // r0 = rows per workgroup of the logits kernel that ran
+    f32x4 w1r[PRE ? 32 : 1];   // [jb 2][k0 2][u 8]
+    float w2r[PRE ? 32 : 1];   // [jb 2][u 8][half 2]
+    bool pre = false;
     float bv = -INFINITY;
     long long bi = 0x7fffffffffffffffLL;
-    for (long long t = threadIdx.x; t < ntile; t += blockDim.x) {
+    long long t_next = threadIdx.x;
+    if constexpr (PRE) {
+        pre = K == 512 && nwv == 8 && nonlinear && VEC == 4;
+        if (pre) {
+            if (t_next < ntile) {   // the first round of tile partials goes out ahead of the weights (loads return in order)
+                bv = part_val[(slot0 + t_next) * C + c];
+                bi = part_idx[(slot0 + t_next) * C + c];
+                t_next += blockDim.x;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        w1r[(jb * 2 + kk) * 8 + u] = *reinterpret_cast<const f32x4*>(q0_w + (long long)(wave * 16 + jb * 8 + u) * 512 + kk * 256 + lane * 4);
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float* wr = q2_w + (long long)(wave * 16 + jb * 8 + u) * QD;
+                    w2r[(jb * 8 + u) * 2] = wr[lane];
+                    w2r[(jb * 8 + u) * 2 + 1] = wr[lane + 64];
+                }
+            __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the arg-max
+        }
+    }
+    for (long long t = t_next; t < ntile; t += blockDim.x) {
         const float v = part_val[(slot0 + t) * C + c];
         const long long i = part_idx[(slot0 + t) * C + c];
         if (better(v, i, bv, bi)) { bv = v; bi = i; }
@@ -361,6 +395,43 @@ __device__ __forceinline__ void qmax_block(
     }
     if (mode == 1) return;
     const T* x = feats + (mode == 2 ? best : phys_row(rowmap, off0 + best)) * (long long)K;
+    if (PRE && pre) {
+        const f32x4 xv0 = load4<VEC, T>(x, lane * 4, K), xv1 = load4<VEC, T>(x, 256 + lane * 4, K);
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const f32x4 xv = kk ? xv1 : xv0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const f32x4 wv = w1r[(jb * 2 + kk) * 8 + u];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[u] = fmaf(xv[e], wv[e], acc[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float a = fmaxf(wave_sum(acc[u]) + q0_b[wave * 16 + jb * 8 + u], 0.f);
+                if (lane == 0) s_h[wave * 16 + jb * 8 + u] = a;
+            }
+        }
+        __syncthreads();
+        float* out = qmax + ((long long)bag * C + c) * QD;
+        const float h0 = s_h[lane], h1 = s_h[lane + 64];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            float acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = fmaf(h0, w2r[(jb * 8 + u) * 2], h1 * w2r[(jb * 8 + u) * 2 + 1]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float a = wave_sum(acc[u]) + q2_b[wave * 16 + jb * 8 + u];
+                if (lane == 0) out[wave * 16 + jb * 8 + u] = tanhf(a);
+            }
+        }
+        return;
+    }
     // layer 1: wave w computes hidden units upw*w .. upw*w + upw - 1, 8 at a time; lanes stride k by 4
     for (int jb = 0; jb < upw; jb += 8) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -830,7 +901,7 @@ __global__ __launch_bounds__(HS_THREADS, 2) void k_attend_hs(AttendArgs a) {
         if (tile < a.C) {
             long long* s_i = reinterpret_cast<long long*>(smem);
             float* s_v = smem + 2 * (HS_THREADS / 64), *s_h = s_v + HS_THREADS / 64;
-            qmax_block<4, float>(reinterpret_cast<const float*>(a.feats), a.offsets, a.qm_part_val, a.qm_part_idx, a.q0_w, a.q0_b,
+            qmax_block<4, float, true>(reinterpret_cast<const float*>(a.feats), a.offsets, a.qm_part_val, a.qm_part_idx, a.q0_w, a.q0_b,
                                  a.q2_w, a.q2_b, const_cast<float*>(a.qmax), a.qm_idx, a.K, a.C, a.nonlinear, bag, tile, s_v, s_i,
                                  s_h, 0, nullptr, a.rowmap, a.qm_r0);
             __syncthreads();   // every wave's stores are out (vmcnt 0) before the release below writes the L2 back
