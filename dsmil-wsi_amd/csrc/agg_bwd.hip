@@ -64,20 +64,26 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // With `lh.label` set (dsmil_agg_train_step) the kernel FIRST forms the training objective of the bag and its two logit
 // gradients — what dsmil_agg_loss_head does (train_tcga.py:67-71) — so the step needs no separate loss-head launch: every
 // block derives g_pred for itself (C values), block 0 publishes loss / max_pred / g_pred / g_max.
+// The last `fr.blocks` workgroups (dsmil_agg_train_step; 0 otherwise) are step 2 of the backward, gA = V gB^T, in the same
+// launch: each forms gB for itself in LDS (block 0's arithmetic) and then runs agg_fwd.hip k_fc<4> over its rows (W := gB, b := 0).
+constexpr int FC_ROLE_MAX = 2048;   // C * Kv floats of LDS
+struct FcRole { const float* vals; const int64_t* rowmap; float* gA; int blocks; int first; };
 struct LossHeadArgs {
     const float* label;     // [C] or null: g_pred comes from the caller
     const float* classes;   // [N,C]
-    const float* pred;      // [C]
+    const float* pred;      // [C], or null: summed here from the forward's partials (k_pred's sum, same order)
     const int64_t* idx;     // [C]
     float* loss; float* max_pred; float* g_pred_out; float* g_max_out;
+    const float* pred_part; const float* fcc_b; float* pred_out; int pred_blocks;   // pred == null: [blocks][C][C], [C], [C]
 };
 __global__ __launch_bounds__(256) void k_bwd_prep(
     const float* __restrict__ fcc_w, const float* __restrict__ Bm, const float* __restrict__ g_pred_in,
     const float* __restrict__ g_B, const float* __restrict__ A, const float* __restrict__ g_A,
     float* __restrict__ gB, float* __restrict__ Dv, float* __restrict__ g_fcc_w, float* __restrict__ g_fcc_b,
-    float* __restrict__ zero128, long long N, int Kv, int C, LossHeadArgs lh) {
+    float* __restrict__ zero128, long long N, int Kv, int C, LossHeadArgs lh, FcRole fr) {
     __shared__ float red[4];
     __shared__ float s_gp[64];
+    __shared__ __attribute__((aligned(16))) float s_gB[FC_ROLE_MAX];
     const int tid = threadIdx.x;
     const float* g_pred = g_pred_in;
     if (lh.label) {   // C <= 64: one wave (the arithmetic of k_loss_head, agg_fwd.hip)
@@ -85,7 +91,15 @@ __global__ __launch_bounds__(256) void k_bwd_prep(
             float l = 0.f;
             if (tid < C) {
                 const float y = lh.label[tid];
-                const float zb = lh.pred[tid], zm = lh.classes[lh.idx[tid] * (long long)C + tid];
+                float zb;
+                if (lh.pred) zb = lh.pred[tid];
+                else {   // agg_fwd.hip k_pred
+                    zb = lh.fcc_b[tid];
+                    for (int j = 0; j < lh.pred_blocks; ++j)
+                        for (int c = 0; c < C; ++c) zb += lh.pred_part[((long long)j * C + tid) * C + c];
+                    if (blockIdx.x == 0) lh.pred_out[tid] = zb;
+                }
+                const float zm = lh.classes[lh.idx[tid] * (long long)C + tid];
                 const float lb = fmaxf(zb, 0.f) - zb * y + log1pf(expf(-fabsf(zb)));
                 const float lm = fmaxf(zm, 0.f) - zm * y + log1pf(expf(-fabsf(zm)));
                 l = 0.5f * (lb + lm) / (float)C;
@@ -103,6 +117,34 @@ __global__ __launch_bounds__(256) void k_bwd_prep(
         }
         __syncthreads();
         g_pred = s_gp;
+    }
+    if (fr.blocks && (int)blockIdx.x >= fr.first) {
+        for (int i = tid; i < C * Kv; i += 256) {
+            const int c = i / Kv, k = i - c * Kv;
+            float g = g_B ? g_B[c * Kv + k] : 0.f;
+            for (int o = 0; o < C; ++o) g = fmaf(g_pred[o], fcc_w[((long long)o * C + c) * Kv + k], g);
+            s_gB[i] = g;
+        }
+        __syncthreads();
+        const int lane = tid & 63;
+        const long long nw = (long long)fr.blocks * 4;
+        for (long long r = (long long)((int)blockIdx.x - fr.first) * 4 + (tid >> 6); r < N; r += nw) {
+            const float* x = fr.vals + phys_row(fr.rowmap, r) * Kv;
+            for (int c = 0; c < C; ++c) {
+                float acc = 0.f;
+                for (int k0 = 0; k0 < Kv; k0 += 256) {
+                    const int k = k0 + lane * 4;
+                    const f32x4 xv = load4<4>(x, k, Kv);
+                    f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+                    if (k < Kv) wv = *reinterpret_cast<const f32x4*>(&s_gB[c * Kv + k]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = fmaf(xv[e], wv[e], acc);
+                }
+                acc = wave_sum(acc) + 0.f;
+                if (lane == 0) fr.gA[r * C + c] = acc;
+            }
+        }
+        return;
     }
     if (blockIdx.x > 0) {
         const long long n = (long long)C * C * Kv, i0 = (long long)(blockIdx.x - 1) * 1024;
@@ -763,6 +805,32 @@ __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
 // ---- k_bwd_reduce: fixed-order sums over the row ranges (deterministic), every output of the query stream in one
 //      launch, plus the sparse max-stream gradient of the FCLayer (train_tcga.py:68,70: only the critical rows carry
 //      gradient: g_fc_w[c] (+)= g_max[c] x[idx_c], g_fc_b[c] (+)= g_max[c]) -------------------------------------
+// One element of torch.optim.Adam (amsgrad = False, maximize = False), the operation order of torch's single-tensor /
+// foreach implementation: g += wd p; m = lerp(m, g, 1 - b1); v = b2 v + (1 - b2) g^2; p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)
+struct AdamScalars { float step_size, w1, beta2, w2, eps, wd, bc2_sqrt; };
+__device__ __forceinline__ void adam_elem(float* __restrict__ p, float* __restrict__ mp, float* __restrict__ vp, float g,
+                                          const AdamScalars& h) {
+    // every fused multiply-add is spelled out: left to the compiler's contraction, the choice (e.g. which of the two products
+    // of the second moment is rounded first) changes with the code around the call, and the update with it by an ulp
+    const float pv = *p;
+    if (h.wd != 0.f) g = fmaf(h.wd, pv, g);                   // grad.add(param, alpha = weight_decay)
+    const float m0 = *mp;                                     // exp_avg.lerp_(grad, 1 - beta1): torch's two-sided formula
+    const float m = h.w1 < 0.5f ? fmaf(h.w1, g - m0, m0) : fmaf(-(1.f - h.w1), g - m0, g);
+    const float v = fmaf(h.w2, g * g, *vp * h.beta2);         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    *mp = m;
+    *vp = v;
+    const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
+    *p = fmaf(-h.step_size, m / denom, pv);                   // param.addcdiv_(exp_avg, denom, value = -step_size)
+}
+// dsmil_agg_train_step: optimizer.step() inside k_bwd_reduce — the thread that has just formed a gradient element applies
+// it (every tensor's last reader is an earlier launch); tensors in parameter order fc_w, fc_b, q0_w, q0_b, q2_w, q2_b,
+// fcc_w, fcc_b; the two fcc gradients (k_bwd_prep's) ride along as extra elements
+struct AdamFuse {
+    int on;
+    float* p[8]; float* m[8]; float* v[8];
+    AdamScalars h;
+    const float* g_fcc_w; const float* g_fcc_b; long long n_fcc_w; int n_fcc_b;
+};
 struct ReduceArgs {
     const float* part0; const float* part1; const float* pb0; const float* pb1;
     float* g_w0; float* g_b0;    // outputs of (part0, pb0): g_q0_w [128,K], g_q0_b
@@ -771,6 +839,7 @@ struct ReduceArgs {
     // sparse FCLayer gradient (g_max != null)
     const float* feats; const int64_t* idx; const float* g_max; const int64_t* rowmap;
     float* g_fc_w; float* g_fc_b; int C, accumulate;
+    AdamFuse af;
 };
 __global__ __launch_bounds__(256) void k_bwd_reduce(ReduceArgs a) {
     const long long n0 = (long long)QD * a.K, n1 = a.nonlinear ? (long long)QD * QD : 0;
@@ -781,6 +850,7 @@ __global__ __launch_bounds__(256) void k_bwd_reduce(ReduceArgs a) {
 #pragma unroll 8
         for (int k = 0; k < a.S; ++k) s += a.part0[(long long)k * n0 + i];
         a.g_w0[i] = s;
+        if (a.af.on) adam_elem(a.af.p[2] + i, a.af.m[2] + i, a.af.v[2] + i, s, a.af.h);
         return;
     }
     i -= n0;
@@ -789,6 +859,7 @@ __global__ __launch_bounds__(256) void k_bwd_reduce(ReduceArgs a) {
 #pragma unroll 8
         for (int k = 0; k < a.S; ++k) s += a.part1[(long long)k * n1 + i];
         a.g_w1[i] = s;
+        if (a.af.on) adam_elem(a.af.p[4] + i, a.af.m[4] + i, a.af.v[4] + i, s, a.af.h);
         return;
     }
     i -= n1;
@@ -798,6 +869,10 @@ __global__ __launch_bounds__(256) void k_bwd_reduce(ReduceArgs a) {
         float s = 0.f;
         for (int k = 0; k < a.S; ++k) s += pb[k * QD + j];
         (i < QD ? a.g_b0 : a.g_b1)[j] = s;
+        if (a.af.on) {
+            const int t = i < QD ? 3 : 5;
+            adam_elem(a.af.p[t] + j, a.af.m[t] + j, a.af.v[t] + j, s, a.af.h);
+        }
         return;
     }
     i -= nb;
@@ -805,10 +880,23 @@ __global__ __launch_bounds__(256) void k_bwd_reduce(ReduceArgs a) {
         if (i < (long long)a.C * a.K) {
             const int c = (int)(i / a.K), k = (int)(i - (long long)c * a.K);
             const float v = a.g_max[c] * a.feats[phys_row(a.rowmap, a.idx[c]) * (long long)a.K + k];
-            a.g_fc_w[i] = a.accumulate ? a.g_fc_w[i] + v : v;
+            const float g = a.accumulate ? a.g_fc_w[i] + v : v;
+            a.g_fc_w[i] = g;
+            if (a.af.on) adam_elem(a.af.p[0] + i, a.af.m[0] + i, a.af.v[0] + i, g, a.af.h);
         } else {
             const int c = (int)(i - (long long)a.C * a.K);
-            a.g_fc_b[c] = a.accumulate ? a.g_fc_b[c] + a.g_max[c] : a.g_max[c];
+            const float g = a.accumulate ? a.g_fc_b[c] + a.g_max[c] : a.g_max[c];
+            a.g_fc_b[c] = g;
+            if (a.af.on) adam_elem(a.af.p[1] + c, a.af.m[1] + c, a.af.v[1] + c, g, a.af.h);
+        }
+        return;
+    }
+    i -= nf;
+    if (a.af.on) {   // the bag stream's Conv1d: gradients formed by k_bwd_prep
+        if (i < a.af.n_fcc_w) adam_elem(a.af.p[6] + i, a.af.m[6] + i, a.af.v[6] + i, a.af.g_fcc_w[i], a.af.h);
+        else if (i - a.af.n_fcc_w < a.af.n_fcc_b) {
+            const long long j = i - a.af.n_fcc_w;
+            adam_elem(a.af.p[7] + j, a.af.m[7] + j, a.af.v[7] + j, a.af.g_fcc_b[j], a.af.h);
         }
     }
 }
@@ -913,17 +1001,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamTensors t, float step_size, fl
     for (int j = 0; j < DSMIL_ADAM_MAX_TENSORS - 1; ++j)
         if (j < t.n - 1 && i >= t.end[j]) k = j + 1;
     const long long o = i - (k ? t.end[k - 1] : 0);
-    float* p = t.p[k];
-    float g = t.g[k][o];
-    const float pv = p[o];
-    if (wd != 0.f) g = fmaf(wd, pv, g);                       // grad.add(param, alpha = weight_decay)
-    const float m0 = t.m[k][o];                               // exp_avg.lerp_(grad, 1 - beta1): torch's two-sided formula
-    const float m = w1 < 0.5f ? m0 + w1 * (g - m0) : g - (g - m0) * (1.f - w1);
-    const float v = t.v[k][o] * beta2 + w2 * (g * g);         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
-    t.m[k][o] = m;
-    t.v[k][o] = v;
-    const float denom = sqrtf(v) / bc2_sqrt + eps;
-    p[o] = pv - step_size * (m / denom);                      // param.addcdiv_(exp_avg, denom, value = -step_size)
+    adam_elem(t.p[k] + o, t.m[k] + o, t.v[k] + o, t.g[k][o], AdamScalars{step_size, w1, beta2, w2, eps, wd, bc2_sqrt});
 }
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1005,7 +1083,8 @@ int agg_backward_impl(const float* feats, const float* vals, int64_t N, const ds
                       const float* g_max, const float* g_pred, const float* g_A, const float* g_B,
                       const dsmil_agg_grads* g, float* g_vals, const int64_t* rowmap, void* ws, size_t ws_bytes,
                       void* stream, const void* packed_split, const float* qmax_in, bool prepared = false,
-                      const LossHeadArgs* lhp = nullptr) {
+                      const LossHeadArgs* lhp = nullptr, const AdamFuse* adam = nullptr, bool own_fc_launch = false) {
+    if (adam && (!g_max || g_classes)) return DSMIL_E_INVALID;   // the fused optimizer step is the training loop's
     if (!feats || !p || !A || !Bm || !idx || (!g_pred && !lhp) || !g || !ws) return DSMIL_E_INVALID;
     if (g_max && (!g->fc_w || !g->fc_b)) return DSMIL_E_INVALID;
     if (N <= 0 || p->K <= 0 || p->Kv <= 0 || p->C <= 0) return DSMIL_E_INVALID;
@@ -1051,12 +1130,20 @@ int agg_backward_impl(const float* feats, const float* vals, int64_t N, const ds
     }
     // 1. head: gB, D, g_fcc_*
     const long long nfcc = (long long)C * C * Kv;
-    hipLaunchKernelGGL(k_bwd_prep, dim3((unsigned)(1 + (nfcc + 1023) / 1024)), dim3(256), 0, st, p->fcc_w, Bm, g_pred, g_B, A, g_A,
-                       gB, Dv, g->fcc_w, g->fcc_b, zero, (long long)N, Kv, C, lhp ? *lhp : LossHeadArgs{});
+    const int prep_blocks = (int)(1 + (nfcc + 1023) / 1024);
+    FcRole fr{vals, rowmap, gA, 0, prep_blocks};
+    if (lhp && !own_fc_launch && (Kv % 4 == 0) && ((uintptr_t)vals % 16 == 0) && (long long)C * Kv <= FC_ROLE_MAX) {   // the training step: one launch less
+        long long fb = ((long long)N + 3) / 4;
+        fr.blocks = (int)(fb > 4096 ? 4096 : fb);
+    }
+    hipLaunchKernelGGL(k_bwd_prep, dim3((unsigned)(prep_blocks + fr.blocks)), dim3(256), 0, st, p->fcc_w, Bm, g_pred, g_B, A, g_A,
+                       gB, Dv, g->fcc_w, g->fcc_b, zero, (long long)N, Kv, C, lhp ? *lhp : LossHeadArgs{}, fr);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     // 2. gA = V gB^T  (the forward's FCLayer kernel with W := gB, b := 0)
-    rc = dsmil_fc_forward_rows(vals, N, Kv, C, gB, zero, gA, rowmap, stream);
-    if (rc) return rc;
+    if (!fr.blocks) {
+        rc = dsmil_fc_forward_rows(vals, N, Kv, C, gB, zero, gA, rowmap, stream);
+        if (rc) return rc;
+    }
     // 3. critical queries
     if (qmax_in) qmax = const_cast<float*>(qmax_in);
     else {
@@ -1113,7 +1200,12 @@ int agg_backward_impl(const float* feats, const float* vals, int64_t N, const ds
     ra.S = L.S; ra.K = K; ra.nonlinear = p->nonlinear;
     ra.feats = feats; ra.idx = idx; ra.g_max = g_max; ra.rowmap = rowmap; ra.g_fc_w = g->fc_w; ra.g_fc_b = g->fc_b;
     ra.C = C; ra.accumulate = g_classes ? 1 : 0;
-    const long long nred = (long long)QD * K + (p->nonlinear ? QD * QD + 2 * QD : QD) + (g_max ? (long long)C * K + C : 0);
+    if (adam) {
+        ra.af = *adam;
+        ra.af.g_fcc_w = g->fcc_w; ra.af.g_fcc_b = g->fcc_b; ra.af.n_fcc_w = (long long)C * C * Kv; ra.af.n_fcc_b = C;
+    }
+    const long long nred = (long long)QD * K + (p->nonlinear ? QD * QD + 2 * QD : QD) + (g_max ? (long long)C * K + C : 0) +
+                           (adam ? (long long)C * C * Kv + C : 0);
     hipLaunchKernelGGL(k_bwd_reduce, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, st, ra);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     // 9. gradient of the value rows (only when v is a trainable layer of the caller)
@@ -1255,8 +1347,14 @@ int dsmil_agg_train_step(const float* feats, int64_t N, const int64_t* row_map, 
     dsmil_agg_opts fo{};
     fo.row_map = row_map;
     fo.packed_split = planes ? (const void*)(bw8 + LB.wsplit) : nullptr;
-    int rc = dsmil_agg_forward_ex(feats, nullptr, off, 1, N, N, p, &fo, nullptr, classes, A, Bm, pred, idx, w8 + L.fwd,
-                                  L.fwd_bytes, stream);
+#ifdef DSMIL_EXPERIMENTS   // DSMIL_TRAIN_UNFUSE: 1 = Adam as its own launch, 2 = gA as its own launch, 4 = k_pred as its own launch
+    static const int unfuse = getenv("DSMIL_TRAIN_UNFUSE") ? atoi(getenv("DSMIL_TRAIN_UNFUSE")) : 0;
+#else
+    constexpr int unfuse = 0;
+#endif
+    int rc = (unfuse & 4) ? dsmil_agg_forward_ex(feats, nullptr, off, 1, N, N, p, &fo, nullptr, classes, A, Bm, pred, idx, w8 + L.fwd,
+                                                 L.fwd_bytes, stream)
+                          : dsmil_agg_forward_nopred(feats, off, N, p, &fo, classes, A, Bm, idx, w8 + L.fwd, L.fwd_bytes, stream);
     if (rc) return rc;
     // backward (train_tcga.py:72); its first kernel also forms loss = 0.5 BCE(bag) + 0.5 BCE(max instance) and both
     // upstream gradients (train_tcga.py:68-71)
@@ -1264,19 +1362,36 @@ int dsmil_agg_train_step(const float* feats, int64_t N, const int64_t* row_map, 
     g.fc_w = gr[0]; g.fc_b = gr[1]; g.q0_w = gr[2]; g.q0_b = gr[3]; g.q2_w = p->nonlinear ? gr[4] : nullptr;
     g.q2_b = p->nonlinear ? gr[5] : nullptr; g.fcc_w = gr[6]; g.fcc_b = gr[7];
     const float* qmax = nullptr;
-    dsmil_agg_forward_leftovers(w8 + L.fwd, 1, N, K, K, C, nullptr, &qmax);
-    const LossHeadArgs lh{label, classes, pred, idx, loss, mx, gpred, gmax};
-    rc = agg_backward_impl(feats, nullptr, N, p, A, Bm, idx, nullptr, gmax, gpred, nullptr, nullptr, &g, nullptr, row_map,
-                           bw8, L.bwd_bytes, stream, nullptr, qmax, true, &lh);
-    if (rc) return rc;
-    // optimizer.step() (train_tcga.py:73): Adam over the eight tensors in one launch
+    const float* pred_part = nullptr;
+    int pred_blocks = 0;
+    dsmil_agg_forward_leftovers(w8 + L.fwd, 1, N, K, K, C, nullptr, &qmax, &pred_part, &pred_blocks);
+    const LossHeadArgs lh{label, classes, (unfuse & 4) ? pred : nullptr, idx, loss, mx, gpred, gmax, pred_part, p->fcc_b, pred, pred_blocks};
+    // optimizer.step() (train_tcga.py:73): Adam over the eight tensors, applied by the backward's last launch (k_bwd_reduce)
+    // to the gradient elements it has just formed; scalars formed in double as in dsmil_adam_step
     float* params[8] = {const_cast<float*>(p->fc_w), const_cast<float*>(p->fc_b), const_cast<float*>(p->q0_w),
                         const_cast<float*>(p->q0_b), const_cast<float*>(p->q2_w), const_cast<float*>(p->q2_b),
                         const_cast<float*>(p->fcc_w), const_cast<float*>(p->fcc_b)};
-    int64_t numel[8];
-    for (int i = 0; i < 8; ++i) numel[i] = sizes[i];
-    return dsmil_adam_step(8, params, (const float* const*)gr, opt->exp_avg, opt->exp_avg_sq, numel, opt->step, opt->lr,
-                           opt->beta1, opt->beta2, opt->eps, opt->weight_decay, stream);
+    if (opt->step <= 0) return DSMIL_E_INVALID;
+    AdamFuse af{};
+    af.on = 1;
+    for (int i = 0; i < 8; ++i) {
+        if (sizes[i] && (!opt->exp_avg[i] || !opt->exp_avg_sq[i])) return DSMIL_E_INVALID;
+        af.p[i] = params[i]; af.m[i] = opt->exp_avg[i]; af.v[i] = opt->exp_avg_sq[i];
+    }
+    const double bc1 = 1.0 - pow(opt->beta1, (double)opt->step), bc2 = 1.0 - pow(opt->beta2, (double)opt->step);
+    af.h = AdamScalars{(float)(opt->lr / bc1), (float)(1.0 - opt->beta1), (float)opt->beta2, (float)(1.0 - opt->beta2),
+                       (float)opt->eps, (float)opt->weight_decay, (float)sqrt(bc2)};
+    if (unfuse & 1) {
+        rc = agg_backward_impl(feats, nullptr, N, p, A, Bm, idx, nullptr, gmax, gpred, nullptr, nullptr, &g, nullptr, row_map,
+                               bw8, L.bwd_bytes, stream, nullptr, qmax, true, &lh, nullptr, (unfuse & 2) != 0);
+        if (rc) return rc;
+        int64_t numel[8];
+        for (int i = 0; i < 8; ++i) numel[i] = sizes[i];
+        return dsmil_adam_step(8, params, (const float* const*)gr, opt->exp_avg, opt->exp_avg_sq, numel, opt->step, opt->lr,
+                               opt->beta1, opt->beta2, opt->eps, opt->weight_decay, stream);
+    }
+    return agg_backward_impl(feats, nullptr, N, p, A, Bm, idx, nullptr, gmax, gpred, nullptr, nullptr, &g, nullptr, row_map,
+                             bw8, L.bwd_bytes, stream, nullptr, qmax, true, &lh, &af, (unfuse & 2) != 0);
 }
 
 }  // extern "C"

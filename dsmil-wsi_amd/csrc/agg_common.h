@@ -14,7 +14,13 @@ int dsmil_fc_forward_rows(const float* feats, int64_t total_rows, int32_t K, int
 // the backward of the same bag — the plane-cut query weights (null if the forward did not cut them: caller-supplied
 // packed_split, or an MFMA form without planes) and q_max [n_bags, C, 128]
 void dsmil_agg_forward_leftovers(void* ws, int32_t n_bags, int64_t total_rows, int32_t K, int32_t Kv, int32_t C,
-                                 const void** packed_split, const float** qmax);
+                                 const void** packed_split, const float** qmax, const float** pred_part = nullptr,
+                                 int* pred_blocks = nullptr);
+// library-internal: dsmil_agg_forward_ex WITHOUT its last launch (k_pred): pred[o] = fcc_b[o] + the sum of
+// pred_part[block][o][c] in (block, c) order is left to the caller (dsmil_agg_train_step: the loss head of k_bwd_prep)
+int dsmil_agg_forward_nopred(const float* feats, const int64_t* offsets, int64_t total_rows, const dsmil_agg_params* p,
+                             const dsmil_agg_opts* opts, float* classes_out, float* A, float* B, int64_t* idx, void* ws,
+                             size_t ws_bytes, void* stream);
 
 namespace {
 

@@ -1253,8 +1253,10 @@ int dsmil_fc_forward_rows(const float* feats, int64_t total_rows, int32_t K, int
 }
 
 void dsmil_agg_forward_leftovers(void* ws, int32_t n_bags, int64_t total_rows, int32_t K, int32_t Kv, int32_t C,
-                                 const void** packed_split, const float** qmax) {
+                                 const void** packed_split, const float** qmax, const float** pred_part, int* pred_blocks) {
     const WsLayout L = ws_layout(n_bags, total_rows, total_rows, K, Kv, C, pick_nw(n_bags, total_rows) * 32);
+    if (pred_part) *pred_part = (const float*)((char*)ws + L.pred_part);
+    if (pred_blocks) *pred_blocks = (int)L.nchunk_max;
     if (packed_split) *packed_split = (pick_nw(n_bags, total_rows) != 8 && mlp_mode()) ? (const void*)((char*)ws + L.wsplit) : nullptr;
     if (qmax) *qmax = (const float*)((char*)ws + L.qmax);
 }
@@ -1299,6 +1301,7 @@ struct ShardCtl {
     const float* crit_rows = nullptr; // phase 2: [C,K] feature rows of the bag-wide critical instances
     float* best_val = nullptr;        // phase 1 out: [C]
     float* ml_out = nullptr;          // phase 2 out: [C,2] (max, sum) of this shard
+    bool skip_pred = false;           // phase 0: leave the last sum (k_pred) to the caller (dsmil_agg_forward_nopred)
 };
 
 static int agg_forward_impl(const void* feats, const void* vals, const int64_t* offsets,
@@ -1308,7 +1311,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
                             void* stream, const ShardCtl& sh = ShardCtl(), const void* packed_split = nullptr,
                             const int64_t* rowmap = nullptr) {
     if (!feats || !p || !ws) return DSMIL_E_INVALID;
-    if (sh.phase == 0 && (!offsets || !A || !B || !pred || !idx)) return DSMIL_E_INVALID;
+    if (sh.phase == 0 && (!offsets || !A || !B || (!pred && !sh.skip_pred) || !idx)) return DSMIL_E_INVALID;
     if (sh.phase == 1 && (!classes_out || !idx || !sh.best_val)) return DSMIL_E_INVALID;
     if (sh.phase == 2 && (!A || !B || !sh.crit_rows || !sh.ml_out)) return DSMIL_E_INVALID;
     if (n_bags <= 0 || total_rows <= 0 || max_rows <= 0 || max_rows > total_rows) return DSMIL_E_INVALID;
@@ -1467,7 +1470,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         else
             hipLaunchKernelGGL(k_finish<1>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM, sh.ml_out, 0, 0);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
-        if (sh.phase == 2) return DSMIL_OK;  // the bag head runs after the cross-shard merge
+        if (sh.phase == 2 || sh.skip_pred) return DSMIL_OK;  // the bag head runs after the cross-shard merge / in the caller's next launch
         // (folding this sum into k_finish's last block per bag — a device-scope fence + ticket in every block — was tried:
         // 11 -> 52 us for 64 bags, the fences wait for the 5 MB of attention the blocks have just written)
         const int n = n_bags * C;
@@ -1511,6 +1514,18 @@ int dsmil_agg_forward_ex(const float* feats, const float* vals, const int64_t* o
     return agg_forward_impl(feats, vals, offsets, n_bags, total_rows, max_rows, p, nullptr, false, classes_in,
                             classes_out, A, B, pred, idx, ws, ws_bytes, stream, ShardCtl(), packed_split, row_map);
 }
+
+}  // extern "C"
+int dsmil_agg_forward_nopred(const float* feats, const int64_t* offsets, int64_t total_rows, const dsmil_agg_params* p,
+                             const dsmil_agg_opts* opts, float* classes_out, float* A, float* B, int64_t* idx, void* ws,
+                             size_t ws_bytes, void* stream) {
+    ShardCtl sh;
+    sh.skip_pred = true;
+    return agg_forward_impl(feats, nullptr, offsets, 1, total_rows, total_rows, p, nullptr, false, nullptr, classes_out, A, B,
+                            nullptr, idx, ws, ws_bytes, stream, sh, opts ? opts->packed_split : nullptr,
+                            opts ? opts->row_map : nullptr);
+}
+extern "C" {
 
 // ---- fused training objective of one bag (train_tcga.py:67-71) -----------------------------------------
 // loss = 0.5 BCEWithLogits(pred, y) + 0.5 BCEWithLogits(max_n classes[n,:], y)   (mean over the C classes each),
