@@ -168,8 +168,9 @@ def _build_bn(seed, C=2):
                                       (256, 224, 224, False), (33, 224, 224, True), (3, 250, 250, False),
                                       (2, 225, 231, True)])
 def test_frozen_batchnorm_trunk_vs_torch_fp64(B, H, W, u8):
-    """dsmil_resnet18bn_forward (eval-mode BatchNorm folded into the InstanceNorm kernels' (x-m)*r step)
-    against the same torch module evaluated on the CPU in fp64.  Tolerance 1e-4 abs + 1e-4 rel."""
+    """dsmil_resnet18bn_forward (eval-mode BatchNorm folded into the InstanceNorm kernels' (x-m)*r step).  Truth for the
+    small batches (B <= 5): oracle/resnet_numpy.py (kind="batch": plain numpy fp64, no torch operator); for the large ones
+    (minutes of numpy) the same torch module evaluated on the CPU in fp64.  Tolerance 1e-4 abs + 1e-4 rel."""
     import copy
     ic = _build_bn(seed=17)
     g = torch.Generator().manual_seed(5 + B)
@@ -179,9 +180,14 @@ def test_frozen_batchnorm_trunk_vs_torch_fp64(B, H, W, u8):
     else:
         x = torch.from_numpy(make_patches(9 + B, B, H, W))
         img = None
-    ref = copy.deepcopy(ic).double()
-    with torch.no_grad():
-        rf, rc = ref(x.double())
+    if B <= 5:
+        sd = {k: v.numpy() for k, v in ic.feature_extractor.state_dict().items()}
+        rf = torch.from_numpy(rnp.resnet_features(x.numpy(), sd, 18, "batch"))
+        rc = rf @ ic.fc.weight.double().T + ic.fc.bias.double()
+    else:
+        ref = copy.deepcopy(ic).double()
+        with torch.no_grad():
+            rf, rc = ref(x.double())
     icg = ic.cuda()
     with torch.no_grad():
         f, c = icg(img.cuda() if u8 else x.cuda())
