@@ -183,7 +183,7 @@ def test_frozen_batchnorm_trunk_vs_torch_fp64(B, H, W, u8):
     if B <= 5:
         sd = {k: v.numpy() for k, v in ic.feature_extractor.state_dict().items()}
         rf = torch.from_numpy(rnp.resnet_features(x.numpy(), sd, 18, "batch"))
-        rc = rf @ ic.fc.weight.double().T + ic.fc.bias.double()
+        rc = rf @ ic.fc.weight.detach().double().T + ic.fc.bias.detach().double()
     else:
         ref = copy.deepcopy(ic).double()
         with torch.no_grad():
