@@ -734,11 +734,23 @@ def train_leg(cx, weights_tag):
     form = int(cx.L.dsmil_agg_mlp_form())
     peak_exec = PEAK_BF16_MFMA_TFLOPS / form if form else PEAK_F32_MFMA_TFLOPS
     t_roof = fl / (peak_exec * 1e12)
+    # where the GPU time of a step goes, from the committed rocprofv3 profile of tools/train_fused.py (C = 1; not this run)
+    split = None
+    tab = _kernel_table("train_step")
+    if tab and C == 1:
+        ms = {r["kernel"].split("<")[0]: r["ms_per_pass"] for r in tab["rows"]}
+        fwd = ("k_logits_stream", "k_attend_hs", "k_finish")
+        bwd = ("k_bwd_prep", "k_bwd_rows_hs", "k_bwd_critical", "k_bwd_gh_hs", "k_tn_split", "k_bwd_reduce")
+        split = {"source": "profiles/" + KERNEL_TABLE + " (train_step)", "launches": len(tab["rows"]),
+                 "weight_planes_and_offsets": round(ms.get("k_train_prologue", 0.0), 4),
+                 "forward": round(sum(ms.get(k, 0.0) for k in fwd), 4),
+                 "loss_head_backward_adam": round(sum(ms.get(k, 0.0) for k in bwd), 4),
+                 "merged_is": "the loss head (and the bag head's last sum) run inside k_bwd_prep, Adam inside k_bwd_reduce"}
     return {"metric": "bags/sec trained (one Adam step per 10kx512 bag)", "value": round(value, 1), "unit": "bags/s",
             "ms_per_step_bag": round(1e3 / (value / cx.world), 4), "dtype": "f32", "scaling": "replicas",
             "value_without_per_step_sync": round(value_nosync, 1),
             "value_generic_autograd_path": round(value_generic, 1),
-            "gpu_ms": {"step_enqueued_back_to_back": round(gpu_ms_step, 4)},
+            "gpu_ms": {"step_enqueued_back_to_back": round(gpu_ms_step, 4), "split_profiled": split},
             "config": {"workload": f"train_tcga.py:60-75 step on MILNet(FCLayer({K},{C}), BClassifier({K},{C})), {weights_tag} weights, "
                                    f"one {N} x {K} fp32 bag per step ({nbags} distinct, HBM-resident), Adam, loss.item() per step; "
                                    f"training.FusedTrainStep = one dsmil_agg_train_step call per step",

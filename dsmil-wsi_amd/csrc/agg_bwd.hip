@@ -1335,26 +1335,32 @@ int dsmil_agg_train_step(const float* feats, int64_t N, const int64_t* row_map, 
         size_t o = L.grads;
         for (int i = 0; i < 8; ++i) { gr[i] = (float*)(w8 + o); o = al(o + (size_t)sizes[i] * 4); }
     }
-    // prologue: plane-cut W1 | W2 and W2^T + the bag's offsets for the forward and the backward, one launch
-    const BwdWs LB = bwd_layout(N, K, K, C, p->nonlinear);
-    char* bw8 = w8 + L.bwd;
-    const bool planes = dsmil_agg_mlp_form() == NP_BWD;   // (experiment builds may run the forward in another MFMA form)
-    hipLaunchKernelGGL(k_train_prologue, dim3(240), dim3(256), 0, st, p->q0_w, p->nonlinear ? p->q2_w : nullptr,
-                       (bf16_t*)(bw8 + LB.wsplit), (bf16_t*)(bw8 + LB.w2t), K, 2 * ((K + 31) / 32), off, (int64_t*)(bw8 + LB.off),
-                       (long long)N);
-    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
-    // forward (train_tcga.py:67) — q_max stays in its workspace for the backward
-    dsmil_agg_opts fo{};
-    fo.row_map = row_map;
-    fo.packed_split = planes ? (const void*)(bw8 + LB.wsplit) : nullptr;
-#ifdef DSMIL_EXPERIMENTS   // DSMIL_TRAIN_UNFUSE: 1 = Adam as its own launch, 2 = gA as its own launch, 4 = k_pred as its own launch
+#ifdef DSMIL_EXPERIMENTS   // DSMIL_TRAIN_UNFUSE: 1 = Adam as its own launch, 2 = gA as its own launch, 4 = k_pred and the prologue as their own launches
     static const int unfuse = getenv("DSMIL_TRAIN_UNFUSE") ? atoi(getenv("DSMIL_TRAIN_UNFUSE")) : 0;
 #else
     constexpr int unfuse = 0;
 #endif
+    // prologue: plane-cut W1 | W2 and W2^T + the bag's offsets for the forward and the backward, one launch
+    const BwdWs LB = bwd_layout(N, K, K, C, p->nonlinear);
+    char* bw8 = w8 + L.bwd;
+    const bool planes = dsmil_agg_mlp_form() == NP_BWD;   // (experiment builds may run the forward in another MFMA form)
+    // (as 240 extra workgroups of the forward's first launch when that is k_logits_stream, else as its own launch)
+    TrainPrologueJob job{p->q0_w, p->nonlinear ? p->q2_w : nullptr, (bf16_t*)(bw8 + LB.wsplit), (bf16_t*)(bw8 + LB.w2t), K,
+                         2 * ((K + 31) / 32), off, (int64_t*)(bw8 + LB.off), (long long)N, 240};
+    const bool carried = !(unfuse & 4) && dsmil_agg_forward_carries_prologue(feats, N, p);
+    if (!carried) {
+        hipLaunchKernelGGL(k_train_prologue, dim3(240), dim3(256), 0, st, job.q0_w, job.q2_w, job.wsplit, job.w2t, K, job.nks,
+                           job.off_a, job.off_b, (long long)N);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    }
+    // forward (train_tcga.py:67) — q_max stays in its workspace for the backward
+    dsmil_agg_opts fo{};
+    fo.row_map = row_map;
+    fo.packed_split = planes ? (const void*)(bw8 + LB.wsplit) : nullptr;
     int rc = (unfuse & 4) ? dsmil_agg_forward_ex(feats, nullptr, off, 1, N, N, p, &fo, nullptr, classes, A, Bm, pred, idx, w8 + L.fwd,
                                                  L.fwd_bytes, stream)
-                          : dsmil_agg_forward_nopred(feats, off, N, p, &fo, classes, A, Bm, idx, w8 + L.fwd, L.fwd_bytes, stream);
+                          : dsmil_agg_forward_nopred(feats, off, N, p, &fo, classes, A, Bm, idx, w8 + L.fwd, L.fwd_bytes, stream,
+                                                     carried ? &job : nullptr);
     if (rc) return rc;
     // backward (train_tcga.py:72); its first kernel also forms loss = 0.5 BCE(bag) + 0.5 BCE(max instance) and both
     // upstream gradients (train_tcga.py:68-71)

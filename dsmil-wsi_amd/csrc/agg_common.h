@@ -18,9 +18,18 @@ void dsmil_agg_forward_leftovers(void* ws, int32_t n_bags, int64_t total_rows, i
                                  int* pred_blocks = nullptr);
 // library-internal: dsmil_agg_forward_ex WITHOUT its last launch (k_pred): pred[o] = fcc_b[o] + the sum of
 // pred_part[block][o][c] in (block, c) order is left to the caller (dsmil_agg_train_step: the loss head of k_bwd_prep)
+// `job` (dsmil_agg_train_step): what k_train_prologue does — plane-cut W1 | W2 (-> wsplit), W2^T (-> w2t) and the lone bag's
+// {0, N} offsets (-> off_a, off_b) — done by extra workgroups of the forward's FIRST launch (k_logits_stream, which then takes
+// the bag's extent from job->N instead of the offsets in memory).  *job_taken tells whether the forward's launch path could
+// carry it (dsmil_agg_forward_carries_prologue); if not, the caller runs the prologue as its own launch BEFORE this call.
+struct TrainPrologueJob {
+    const float* q0_w; const float* q2_w; unsigned short* wsplit; unsigned short* w2t; int K, nks;
+    int64_t* off_a; int64_t* off_b; long long N; int blocks;
+};
+bool dsmil_agg_forward_carries_prologue(const float* feats, int64_t total_rows, const dsmil_agg_params* p);
 int dsmil_agg_forward_nopred(const float* feats, const int64_t* offsets, int64_t total_rows, const dsmil_agg_params* p,
                              const dsmil_agg_opts* opts, float* classes_out, float* A, float* B, int64_t* idx, void* ws,
-                             size_t ws_bytes, void* stream);
+                             size_t ws_bytes, void* stream, const TrainPrologueJob* job = nullptr);
 
 namespace {
 

@@ -201,9 +201,20 @@ __global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
     const T* __restrict__ feats, const int64_t* __restrict__ offsets,
     const float* __restrict__ fc_w, const float* __restrict__ fc_b, float* __restrict__ classes_out,
     float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C, int bag0,
-    const int64_t* __restrict__ rowmap, int r0 = R0, int* __restrict__ qm_flag = nullptr) {
+    const int64_t* __restrict__ rowmap, int r0 = R0, int* __restrict__ qm_flag = nullptr,
+    TrainPrologueJob job = TrainPrologueJob{}) {
     // qm_flag: the hand-off flags of the attend launch that follows (AttendArgs::qm_flag), cleared here
     if (qm_flag && blockIdx.x == 0 && (int)threadIdx.x < C) qm_flag[(long long)(bag0 + (int)blockIdx.y) * C + threadIdx.x] = 0;
+    if (job.blocks) {   // a training step: the last job.blocks workgroups cut the weight planes and write the offsets
+        const int first = (int)gridDim.x - job.blocks;
+        if ((int)blockIdx.x >= first) {
+            const long long i0 = (long long)((int)blockIdx.x - first) * 256 + threadIdx.x, stride = (long long)job.blocks * 256;
+            pack_agg_split_range(job.q0_w, job.q2_w, job.wsplit, job.K, job.nks, 0, i0, stride);
+            if (job.q2_w) pack_agg_split_range(job.q2_w, nullptr, job.w2t, QD, 8, 1, i0, stride);
+            if (i0 == 0) { job.off_a[0] = 0; job.off_a[1] = job.N; job.off_b[0] = 0; job.off_b[1] = job.N; }
+            return;
+        }
+    }
     // r0 = rows per workgroup: R0 (128: a wave walks four 8-row groups) for batches, 32 (one group per wave) when there are
     // few rows — a lone 10 000-row bag is 79 workgroups at 128 rows, a third of the chip's CUs for an HBM-bound stream
     constexpr int EPL = StreamVec<T>::EPL;   // elements per lane per 128-B segment
@@ -213,8 +224,8 @@ __global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
     __shared__ float s_v[8];
     __shared__ long long s_i[8];
     const int bag = bag0 + (int)blockIdx.y, tile = (int)blockIdx.x;
-    const long long off0 = offsets[bag];
-    const long long Nb = offsets[bag + 1] - off0;
+    const long long off0 = job.blocks ? 0 : offsets[bag];       // (the job's offsets are being written by this very launch)
+    const long long Nb = job.blocks ? job.N : offsets[bag + 1] - off0;
     const long long row0 = (long long)tile * r0;
     if (row0 >= Nb) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1296,12 +1307,20 @@ int dsmil_fc_forward(const float* feats, int64_t total_rows, int32_t K, int32_t 
 
 __global__ void k_set_offsets2(int64_t* off, long long N) { off[0] = 0; off[1] = N; }
 
+// 16-B vector loads on every fp32 operand of the forward
+static bool fwd_v4(const void* feats, const void* vals, const dsmil_agg_params* p) {
+    return (p->K % 4 == 0) && (p->Kv % 4 == 0) &&
+           (((uintptr_t)feats | (uintptr_t)vals | (uintptr_t)p->q0_w | (uintptr_t)p->fc_w |
+             (uintptr_t)(p->nonlinear ? p->q2_w : p->q0_w)) % 16 == 0);
+}
+
 struct ShardCtl {
     int phase = 0;                    // 0 whole forward; 1 logits + arg-max only; 2 attend against given rows
     const float* crit_rows = nullptr; // phase 2: [C,K] feature rows of the bag-wide critical instances
     float* best_val = nullptr;        // phase 1 out: [C]
     float* ml_out = nullptr;          // phase 2 out: [C,2] (max, sum) of this shard
     bool skip_pred = false;           // phase 0: leave the last sum (k_pred) to the caller (dsmil_agg_forward_nopred)
+    const TrainPrologueJob* job = nullptr;   // carried by the logits launch (dsmil_agg_forward_nopred)
 };
 
 static int agg_forward_impl(const void* feats, const void* vals, const int64_t* offsets,
@@ -1350,9 +1369,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     const float* f32 = (const float*)feats;
     const bf16_t* b16 = (const bf16_t*)feats;
 
-    const bool v4 = bf16 || ((K % 4 == 0) && (Kv % 4 == 0) &&
-                             (((uintptr_t)feats | (uintptr_t)vals | (uintptr_t)p->q0_w | (uintptr_t)p->fc_w |
-                               (uintptr_t)(p->nonlinear ? p->q2_w : p->q0_w)) % 16 == 0));
+    const bool v4 = bf16 || fwd_v4(feats, vals, p);
     const bool w4 = (K % 4 == 0) && (((uintptr_t)p->q0_w | (uintptr_t)p->fc_w) % 16 == 0);
     AttendArgs a{feats, vals, (const bf16_t*)packed_bf16, offsets, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, A,
                  part_ml, part_B, K, Kv, C, p->nonlinear, 0, 0, rowmap};
@@ -1396,8 +1413,10 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         else if (bf16) hipLaunchKernelGGL((k_logits_argmax<1, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else if (v4 && !logits_old) {
             const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 31) / 32 + 1) * 32) * sizeof(float);
-            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, qflag);
-            else hipLaunchKernelGGL((k_logits_stream<1, float>), grid, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, qflag);
+            const TrainPrologueJob job = sh.job ? *sh.job : TrainPrologueJob{};
+            dim3 gridj(grid.x + (unsigned)job.blocks, grid.y);
+            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, float>), gridj, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, qflag, job);
+            else hipLaunchKernelGGL((k_logits_stream<1, float>), gridj, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, qflag, job);
         }
         else if (v4) hipLaunchKernelGGL((k_logits_argmax<4, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else hipLaunchKernelGGL((k_logits_argmax<1, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
@@ -1516,11 +1535,21 @@ int dsmil_agg_forward_ex(const float* feats, const float* vals, const int64_t* o
 }
 
 }  // extern "C"
+bool dsmil_agg_forward_carries_prologue(const float* feats, int64_t total_rows, const dsmil_agg_params* p) {
+#ifdef DSMIL_EXPERIMENTS
+    static const int off = expt_env("DSMIL_LOGITS_OLD") | expt_env("DSMIL_NO_PROLOGUE_ROLE");
+    if (off) return false;
+#endif
+    (void)total_rows;
+    return feats && p && p->fc_w && fwd_v4(feats, feats, p);   // = the fp32 k_logits_stream launch of agg_forward_impl
+}
 int dsmil_agg_forward_nopred(const float* feats, const int64_t* offsets, int64_t total_rows, const dsmil_agg_params* p,
                              const dsmil_agg_opts* opts, float* classes_out, float* A, float* B, int64_t* idx, void* ws,
-                             size_t ws_bytes, void* stream) {
+                             size_t ws_bytes, void* stream, const TrainPrologueJob* job) {
     ShardCtl sh;
     sh.skip_pred = true;
+    if (job && !dsmil_agg_forward_carries_prologue(feats, total_rows, p)) return DSMIL_E_INVALID;
+    sh.job = job;
     return agg_forward_impl(feats, nullptr, offsets, 1, total_rows, total_rows, p, nullptr, false, nullptr, classes_out, A, B,
                             nullptr, idx, ws, ws_bytes, stream, sh, opts ? opts->packed_split : nullptr,
                             opts ? opts->row_map : nullptr);
