@@ -432,3 +432,10 @@ def test_stream_pool_results_equal_single_stream():
     f3, c3 = pl.embed_tiles(ic, tiles, batch_size=32, streams=3)
     torch.cuda.synchronize()
     assert torch.equal(f1, f3) and torch.equal(c1, c3)
+    # the same tiles handed over in HOST memory (compute_feats.py:71 `patches.cuda()`): pinned or pageable, each batch's copy
+    # is issued on the pool stream in front of its forward — same features
+    host = tiles.cpu()
+    for src in (host.pin_memory(), host):
+        fh, ch = pl.embed_tiles(ic, src, batch_size=32, streams=3)
+        torch.cuda.synchronize()
+        assert fh.is_cuda and torch.equal(fh, f1) and torch.equal(ch, c1)
