@@ -383,6 +383,25 @@ __global__ __launch_bounds__(NW * 64, (NW == 1 ? 1 : 2)) void k_bwd_rows(BwdRows
         }
 }
 
+// sum_k p[k * stride], k = 0 .. S-1 in order (deterministic), sixteen loads in flight at a time: the additions are a chain, the
+// loads are not.  The last round is padded with clamped re-reads that are not added, so that no round degenerates into the
+// one-load-at-a-time remainder loop an unrolled run-time trip count leaves (k_bwd_reduce, S = 38: 4 rounds of 8 + SIX dependent
+// round trips before: 11.8 -> 5.7 us).
+__device__ __forceinline__ float sum_parts16(const float* __restrict__ p, long long stride, int S) {
+    float s = 0.f;
+    for (int k0 = 0; k0 < S; k0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = k0 + j < S ? k0 + j : S - 1;
+            v[j] = p[(long long)k * stride];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s = k0 + j < S ? s + v[j] : s;
+    }
+    return s;
+}
+
 // ---- the same two kernels on the hidden-split tile (agg_hs.h): few rows — a training step on one bag ----------------
 // 16 per-lane values summed over the 32 lanes of a half-wave (recursive halving, 15 exchanges); every lane ends with the
 // sum of index l31 >> 1
@@ -487,9 +506,8 @@ __global__ __launch_bounds__(1024) void k_bwd_critical(const int64_t* __restrict
     __shared__ float red[8][QD];
     const int j = threadIdx.x & (QD - 1), grp = threadIdx.x >> 7;
     for (int c = 0; c < C; ++c) {
-        float s = 0.f;
-#pragma unroll 8
-        for (long long t = grp; t < ntile; t += 8) s += gqp[(t * C + c) * QD + j];
+        const int cnt = ntile > grp ? (int)((ntile - grp + 7) / 8) : 0;   // tiles grp, grp + 8, ...
+        const float s = sum_parts16(gqp + ((long long)grp * C + c) * QD + j, 8LL * C * QD, cnt);
         __syncthreads();
         red[grp][j] = s;
         __syncthreads();
@@ -578,6 +596,7 @@ struct TnArgs {
     float* pb1;   // [S][128]
     long long N;
     int K, R, nx, nslab, S;
+    unsigned long long* trace;   // trace builds (tools/stamp_tn.py): [workgroup][16] s_memtime stamps of wave 0; else null
 };
 
 // 1-D grid of nslab x (S rounded up to 8) workgroups.  Workgroup L runs on XCD L % 8 (round-robin dispatch); the slabs of
@@ -587,7 +606,11 @@ struct TnArgs {
 // WIDE (rows 16-B aligned, K % 4 == 0): a staging thread loads 16 B — 4 columns x 8 rows = 8 loads instead of 32 — and the
 // LDS holds the columns permuted (column 4g + c at position 32c + g, 16c + g for B) so that consecutive lanes still write
 // consecutive positions; the epilogue undoes the permutation.  26.4 -> 23.5 us for the 10 000-row bag (staging-, not MFMA-bound: 3.3 us of MFMA time).
-template <bool WIDE>
+// MAP (a row map on X: dropout_patches): the physical rows of a prefetch are themselves loaded ONE prefetch ahead and IN FRONT of
+// that call's data loads.  Vector memory returns in order: waiting for map entries requested after the previous step's data
+// (as the first form did — and, the wait being emitted behind the `if (map)`, also when there was no map) drained the whole
+// queue at every prefetch, so only one step's loads were ever in flight.
+template <bool WIDE, bool MAP>
 __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned sA[3 * QD * TN_LDW];
     __shared__ __attribute__((aligned(16))) unsigned sB[3 * 64 * TN_LDW];
@@ -642,18 +665,38 @@ __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
         const int ld = roleA ? QD : ldb;
         const int64_t* map = roleA ? nullptr : bmap;
         f32x4 v[2][8];
+        long long nmap[8];                                 // MAP, B role: physical rows of the NEXT prefetch
+        auto map_load = [&](long long r0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const long long r = r0 + 8 * jg + e;
+                nmap[e] = (long long)map[r < rend ? r : rend - 1];
+            }
+        };
+        // The code below is shaped for hipcc's wait-count pass, which is exact only on straight-line code:
+        // * the staging waves (0-2) and the multiply-only wave (3) take SEPARATE loops — with the staging behind an
+        //   `if (role)` inside one loop, the pass assumed at the join that the refilled set's previous loads might still be in
+        //   flight and waited vmcnt(7..0) before forming the new addresses: every prefetch drained the queue;
+        // * steps always come in PAIRS (set 0, set 1; R is a multiple of 64, a range's tail is padded with a step whose A rows
+        //   are zero) — behind `if (r0 + 32 < rend) step<1>` the wait for set 0 had to assume that no younger loads exist
+        //   (vmcnt(0)) and drained set 1 as well;
+        // * four pairs are unrolled straight-line: at a loop HEADER the pass merges the entry state with the back edge's and
+        //   again waits vmcnt(0) for the older set (once per 256 rows now: once per workgroup for the 10 000-row bag).
+        // Together: one step's loads in flight instead of two (24 us for the 10 000-row bag before).
         auto prefetch = [&](auto setc, long long r0) {     // branch-free: rows past the range re-read its last row
             constexpr int SET = decltype(setc)::value;
-            if (!(roleA || roleB)) return;
             long long pr[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const long long r = r0 + 8 * jg + e;
                 pr[e] = r < rend ? r : rend - 1;
             }
-            if (map) {
+            if constexpr (MAP) {
+                if (roleB && map) {                        // (the H slabs have no map)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pr[e] = (long long)map[pr[e]];
+                    for (int e = 0; e < 8; ++e) pr[e] = nmap[e];
+                    map_load(r0 + 32);                     // in front of this call's data loads
+                }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[SET][e] = *(const DSMIL_GLOBAL f32x4*)(base + pr[e] * (long long)ld);
@@ -661,35 +704,61 @@ __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
         float cs[4] = {0.f, 0.f, 0.f, 0.f};
         auto step = [&](auto setc, long long r0) {
             constexpr int SET = decltype(setc)::value;
-            if (roleA || roleB) {
-                unsigned* dstb = roleA ? sA : sB;
-                const int npos = roleA ? QD : 64, cstride = roleA ? 32 : 16;
+            unsigned* dstb = roleA ? sA : sB;
+            const int npos = roleA ? QD : 64, cstride = roleA ? 32 : 16;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float xv[8];
+            for (int c = 0; c < 4; ++c) {
+                float xv[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) xv[e] = (roleA && r0 + 8 * jg + e >= rend) ? 0.f : v[SET][e][c];   // A rows past the range
-                    if (want_cs && roleA) {
+                for (int e = 0; e < 8; ++e) xv[e] = (roleA && r0 + 8 * jg + e >= rend) ? 0.f : v[SET][e][c];   // A rows past the range
+                if (want_cs && roleA) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) cs[c] += xv[e];
-                    }
-                    S3Frag f[3];
-                    split3(xv, f);
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        *reinterpret_cast<f32x4*>(&dstb[(p * npos + c * cstride + g) * TN_LDW + 4 * jg]) = f[p].f;
+                    for (int e = 0; e < 8; ++e) cs[c] += xv[e];
                 }
+                S3Frag f[3];
+                split3(xv, f);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<f32x4*>(&dstb[(p * npos + c * cstride + g) * TN_LDW + 4 * jg]) = f[p].f;
             }
             __syncthreads();
             prefetch(setc, r0 + 64);
             mfma_phase();
             __syncthreads();
         };
-        prefetch(std::integral_constant<int, 0>{}, rbeg);
-        prefetch(std::integral_constant<int, 1>{}, rbeg + 32);
-        for (long long r0 = rbeg; r0 < rend; r0 += 64) {
-            step(std::integral_constant<int, 0>{}, r0);
-            if (r0 + 32 < rend) step(std::integral_constant<int, 1>{}, r0 + 32);
+#ifdef DSMIL_TRACE
+        int tn_i = 0;
+        auto TSTAMP = [&]() { if (a.trace && tid == 0 && tn_i < 16) a.trace[(long long)blockIdx.x * 16 + tn_i++] = __builtin_amdgcn_s_memtime(); };
+#else
+        auto TSTAMP = []() {};
+#endif
+        if (wave < 3) {
+            TSTAMP();                                     // 0: entry
+            if constexpr (MAP) {
+                if (roleB && map) map_load(rbeg);
+            }
+            prefetch(std::integral_constant<int, 0>{}, rbeg);
+            prefetch(std::integral_constant<int, 1>{}, rbeg + 32);
+            TSTAMP();                                     // 1: first loads issued
+            for (long long r0 = rbeg; r0 < rend; r0 += 256) {   // four pairs straight-line, forward exits only (see above)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    if (r0 + 64 * h >= rend) break;
+                    step(std::integral_constant<int, 0>{}, r0 + 64 * h);
+                    TSTAMP();                             // 2, 4, ...: even steps done
+                    step(std::integral_constant<int, 1>{}, r0 + 64 * h + 32);
+                    TSTAMP();                             // 3, 5, ...: odd steps done
+                }
+            }
+        } else {
+            for (long long r0 = rbeg; r0 < rend; r0 += 64) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    __syncthreads();
+                    mfma_phase();
+                    __syncthreads();
+                }
+            }
         }
         // D[m position][n position]: position -> unit 4 (m & 31) + (m >> 5), column col0 + 4 (n & 15) + (n >> 4)
         const int npos_ = 32 * ct + l31, col = col0 + 4 * (npos_ & 15) + (npos_ >> 4);
@@ -711,6 +780,9 @@ __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
             __syncthreads();
             if (tid < QD) (is_h ? a.pb1 : a.pb0)[split * QD + tid] = (s_cs[tid] + s_cs[QD + tid]) + (s_cs[2 * QD + tid] + s_cs[3 * QD + tid]);
         }
+#ifdef DSMIL_TRACE
+        if (a.trace && tid == 0) a.trace[(long long)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();   // 15: epilogue stores issued
+#endif
     } else {
         // staging roles: A: column u, 8-row groups ja, ja + 2; B: column cb, 8-row group jb
         const int u = tid & 127, ja = tid >> 7;
@@ -738,9 +810,11 @@ __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
                 const long long r = r0 + 8 * jb + e;
                 pr[e] = r < rend ? r : rend - 1;
             }
-            if (bmap) {   // (one uniform branch; the eight row-map entries load back to back)
+            if constexpr (MAP) {   // (the eight row-map entries load back to back; this form waits for them at once)
+                if (bmap) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pr[e] = (long long)bmap[pr[e]];
+                    for (int e = 0; e < 8; ++e) pr[e] = (long long)bmap[pr[e]];
+                }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) rb[SET][e] = Bm[pr[e] * (long long)ldb + bcol];
@@ -846,18 +920,14 @@ __global__ __launch_bounds__(256) void k_bwd_reduce(ReduceArgs a) {
     const long long nb = QD * (a.nonlinear ? 2 : 1), nf = a.g_max ? (long long)a.C * a.K + a.C : 0;
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n0) {
-        float s = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < a.S; ++k) s += a.part0[(long long)k * n0 + i];
+        const float s = sum_parts16(a.part0 + i, n0, a.S);
         a.g_w0[i] = s;
         if (a.af.on) adam_elem(a.af.p[2] + i, a.af.m[2] + i, a.af.v[2] + i, s, a.af.h);
         return;
     }
     i -= n0;
     if (i < n1) {
-        float s = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < a.S; ++k) s += a.part1[(long long)k * n1 + i];
+        const float s = sum_parts16(a.part1 + i, n1, a.S);
         a.g_w1[i] = s;
         if (a.af.on) adam_elem(a.af.p[4] + i, a.af.m[4] + i, a.af.v[4] + i, s, a.af.h);
         return;
@@ -866,8 +936,7 @@ __global__ __launch_bounds__(256) void k_bwd_reduce(ReduceArgs a) {
     if (i < nb) {
         const float* pb = i < QD ? a.pb0 : a.pb1;
         const int j = (int)(i & (QD - 1));
-        float s = 0.f;
-        for (int k = 0; k < a.S; ++k) s += pb[k * QD + j];
+        const float s = sum_parts16(pb + j, QD, a.S);
         (i < QD ? a.g_b0 : a.g_b1)[j] = s;
         if (a.af.on) {
             const int t = i < QD ? 3 : 5;
@@ -1004,6 +1073,18 @@ __global__ __launch_bounds__(256) void k_adam(AdamTensors t, float step_size, fl
     adam_elem(t.p[k] + o, t.m[k] + o, t.v[k] + o, t.g[k][o], AdamScalars{step_size, w1, beta2, w2, eps, wd, bc2_sqrt});
 }
 
+#ifdef DSMIL_TRACE
+constexpr size_t TN_TRACE_WORDS = 1024 * 16;
+inline unsigned long long* tn_trace_buffer() {
+    static unsigned long long* buf = [] {
+        unsigned long long* p = nullptr;
+        (void)hipMalloc(&p, TN_TRACE_WORDS * 8);
+        (void)hipMemset(p, 0, TN_TRACE_WORDS * 8);
+        return p;
+    }();
+    return buf;
+}
+#endif
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 struct BwdWs {
     size_t gB, Dv, zero, qmax, gq, gA, gs, gz2, Hb, Qb, gH, gqp, wsplit, w2t, part0, part1, pb0, pb1, part, part_b, off, total;
@@ -1020,8 +1101,8 @@ BwdWs bwd_layout(long long N, int K, int Kv, int C, int nonlinear) {
     long long st = TN_WGS / nslab;
     if (st < 1) st = 1;
     if (st > 256) st = 256;
-    long long R = ((N + st - 1) / st + 31) / 32 * 32;
-    if (R < 32) R = 32;
+    long long R = ((N + st - 1) / st + 32) / 64 * 64;   // nearest multiple of 64: k_tn_split takes its 32-row steps in pairs
+    if (R < 64) R = 64;
     w.R = (int)R;
     w.S = (int)((N + R - 1) / R);
     w.T32 = (N + 31) / 32;
@@ -1186,8 +1267,16 @@ int agg_backward_impl(const float* feats, const float* vals, int64_t N, const ds
         tn.A0 = gz2; tn.A1 = nullptr; tn.Hb = nullptr;
     }
     // 7. weight gradients: contractions over instances, then the fixed-order reduction (+ the sparse FCLayer gradient)
-    if (v4) hipLaunchKernelGGL(k_tn_split<true>, dim3((unsigned)(tn.nslab * ((L.S + 7) / 8 * 8))), dim3(256), 0, st, tn);
-    else hipLaunchKernelGGL(k_tn_split<false>, dim3((unsigned)(tn.nslab * ((L.S + 7) / 8 * 8))), dim3(256), 0, st, tn);
+#ifdef DSMIL_TRACE
+    tn.trace = tn_trace_buffer();
+#endif
+    {
+        const dim3 gtn((unsigned)(tn.nslab * ((L.S + 7) / 8 * 8)));
+        if (v4 && rowmap) hipLaunchKernelGGL((k_tn_split<true, true>), gtn, dim3(256), 0, st, tn);
+        else if (v4) hipLaunchKernelGGL((k_tn_split<true, false>), gtn, dim3(256), 0, st, tn);
+        else if (rowmap) hipLaunchKernelGGL((k_tn_split<false, true>), gtn, dim3(256), 0, st, tn);
+        else hipLaunchKernelGGL((k_tn_split<false, false>), gtn, dim3(256), 0, st, tn);
+    }
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     // 8. dense instance stream (FCLayer): only when the caller has a dense upstream gradient on the instance logits
     if (g_classes) {
@@ -1399,5 +1488,13 @@ int dsmil_agg_train_step(const float* feats, int64_t N, const int64_t* row_map, 
     return agg_backward_impl(feats, nullptr, N, p, A, Bm, idx, nullptr, gmax, gpred, nullptr, nullptr, &g, nullptr, row_map,
                              bw8, L.bwd_bytes, stream, nullptr, qmax, true, &lh, &af, (unfuse & 2) != 0);
 }
+
+#ifdef DSMIL_TRACE
+int dsmil_debug_tn_trace(unsigned long long* out, int words) {
+    if (!out || words < (int)TN_TRACE_WORDS) return DSMIL_E_INVALID;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out, tn_trace_buffer(), TN_TRACE_WORDS * 8, hipMemcpyDeviceToHost) == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+#endif
 
 }  // extern "C"

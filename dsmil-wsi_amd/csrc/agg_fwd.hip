@@ -998,9 +998,20 @@ __global__ __launch_bounds__(256) void k_finish(
         const float il = ml_out ? 1.f : 1.f / l;
         if (ml_out && blockIdx.x == 0 && tid == 0) { ml_out[((long long)bag * C + c) * 2] = m; ml_out[((long long)bag * C + c) * 2 + 1] = l; }
         // A = exp(s - m) / l for this block's rows
-        for (long long r = rbeg + tid; r < rend; r += 256) {
-            float* p = A + (off0 + r) * (long long)C + c;
-            *p = expf(*p - m) * il;
+        // (eight rows per thread in flight: as `*p = f(*p)` in a loop every load waits for the store before it — a block's
+        // share is at most FR = 2048 rows, i.e. ONE round of loads instead of up to eight dependent round trips)
+        for (long long r0 = rbeg + tid; r0 < rend; r0 += 256 * 8) {
+            float sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long r = r0 + 256 * u;
+                sv[u] = A[(off0 + (r < rend ? r : rend - 1)) * (long long)C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long r = r0 + 256 * u;
+                if (r < rend) A[(off0 + r) * (long long)C + c] = expf(sv[u] - m) * il;
+            }
         }
         float* pp = pred_part + (((long long)bag * nblk + blockIdx.x) * C) * C + c;  // [o] stride C
         if (!has_k) {
@@ -1011,10 +1022,26 @@ __global__ __launch_bounds__(256) void k_finish(
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* pb = part_B + (slot0 * C + c) * (long long)Kv;
         const float* pm = part_ml + (slot0 * C + c) * 2;
-#pragma unroll 4
-        for (long long t = tg; t < ntile; t += 16) {
-            const float w = expf(pm[t * C * 2] - m);
-            acc += w * load4<VEC>(pb + t * C * (long long)Kv, kb + kq * 4, Kv);
+        // rounds of eight tiles, the last one padded with clamped re-reads that are not added (an unrolled run-time trip
+        // count leaves a one-load-at-a-time remainder loop: 157 tiles / 16 groups = 2 rounds of 4 + 2 dependent round trips)
+        for (long long t0 = tg; t0 < ntile; t0 += 16 * 8) {
+            float wv[8];
+            f32x4 bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                long long t = t0 + 16 * u;
+                t = t < ntile ? t : ntile - 1;
+                wv[u] = pm[t * C * 2];
+                bv[u] = load4<VEC>(pb + t * C * (long long)Kv, kb + kq * 4, Kv);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (t0 + 16 * u < ntile) {
+                    const float w = expf(wv[u] - m);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(w, bv[u][e], acc[e]);
+                }
+            }
         }
         *reinterpret_cast<f32x4*>(&s_acc[tg][kq * 4]) = acc;
         __syncthreads();
