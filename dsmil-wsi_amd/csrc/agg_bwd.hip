@@ -91,15 +91,36 @@ __global__ __launch_bounds__(256) void k_bwd_prep(
             float l = 0.f;
             if (tid < C) {
                 const float y = lh.label[tid];
+                const long long ci = lh.idx[tid];          // (requested ahead of the partials: its row is the second hop)
                 float zb;
                 if (lh.pred) zb = lh.pred[tid];
-                else {   // agg_fwd.hip k_pred
+                else {   // agg_fwd.hip k_pred: fcc_b + the partials in (block, class) order — for C <= 2 eight blocks at a time (every
+                         // workgroup of this launch starts with this sum: one load at a time it was 8 dependent round trips)
                     zb = lh.fcc_b[tid];
-                    for (int j = 0; j < lh.pred_blocks; ++j)
-                        for (int c = 0; c < C; ++c) zb += lh.pred_part[((long long)j * C + tid) * C + c];
+                    if (C <= 2) {   // eight blocks' partials in flight
+                        for (int j0 = 0; j0 < lh.pred_blocks; j0 += 8) {
+                            float pv[8][2];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int j = j0 + u < lh.pred_blocks ? j0 + u : lh.pred_blocks - 1;
+                                const float* q = lh.pred_part + ((long long)j * C + tid) * C;
+                                pv[u][0] = q[0];
+                                pv[u][1] = q[C - 1];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (j0 + u < lh.pred_blocks) {
+                                    zb += pv[u][0];
+                                    if (C == 2) zb += pv[u][1];
+                                }
+                        }
+                    } else {
+                        for (int j = 0; j < lh.pred_blocks; ++j)
+                            for (int c = 0; c < C; ++c) zb += lh.pred_part[((long long)j * C + tid) * C + c];
+                    }
                     if (blockIdx.x == 0) lh.pred_out[tid] = zb;
                 }
-                const float zm = lh.classes[lh.idx[tid] * (long long)C + tid];
+                const float zm = lh.classes[ci * (long long)C + tid];
                 const float lb = fmaxf(zb, 0.f) - zb * y + log1pf(expf(-fabsf(zb)));
                 const float lm = fmaxf(zm, 0.f) - zm * y + log1pf(expf(-fabsf(zm)));
                 l = 0.5f * (lb + lm) / (float)C;
