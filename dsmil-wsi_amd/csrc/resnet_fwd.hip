@@ -486,6 +486,7 @@ __global__ void k_pack_conv_s6(const float* __restrict__ w, unsigned short* __re
     }
 }
 
+constexpr int FIN_U = 8;   // partial loads in flight per thread in the k_in_finalize_stem / _cnt walks
 // partials of flattened 32-pixel tiles -> mean / rstd per (image, channel).  One workgroup per
 // image; thread (c mod 64, g) sums the tiles t = g mod 4 of its channel: first the weighted means,
 // then M2 about the image mean (M2 = sum M2_t + cnt_t (mean_t - mean)^2) — two flat reductions,
@@ -1198,10 +1199,17 @@ __global__ __launch_bounds__(256) void k_in_finalize_cnt(const float* __restrict
     __shared__ float red[2][4][64];
     for (int c = (int)blockIdx.y * 64 + cl; c < C && c < ((int)blockIdx.y + 1) * 64; c += 64) {   // grid.y = C / 64 (see k_in_finalize_flat)
         float s = 0.f, cnt = 0.f;
-        for (int t = g; t < nparts; t += 4) {
-            const float* o = part + (((long long)n * nparts + t) * C + c) * 3;
-            s += o[0] * o[1];
-            cnt += o[0];
+        for (int t0 = g; t0 < nparts; t0 += 4 * FIN_U) {   // rounds of FIN_U loads (see k_in_finalize_stem)
+            float o0[FIN_U], o1[FIN_U];
+#pragma unroll
+            for (int u = 0; u < FIN_U; ++u) {
+                const int t = t0 + 4 * u < nparts ? t0 + 4 * u : nparts - 1;
+                const float* o = part + (((long long)n * nparts + t) * C + c) * 3;
+                o0[u] = o[0]; o1[u] = o[1];
+            }
+#pragma unroll
+            for (int u = 0; u < FIN_U; ++u)
+                if (t0 + 4 * u < nparts) { s += o0[u] * o1[u]; cnt += o0[u]; }
         }
         __syncthreads();
         red[0][g][cl] = s;
@@ -1210,10 +1218,20 @@ __global__ __launch_bounds__(256) void k_in_finalize_cnt(const float* __restrict
         const float tot = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
         const float mu = ((red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl])) / tot;
         float q = 0.f;
-        for (int t = g; t < nparts; t += 4) {
-            const float* o = part + (((long long)n * nparts + t) * C + c) * 3;
-            const float dlt = o[1] - mu;
-            q += o[2] + o[0] * dlt * dlt;
+        for (int t0 = g; t0 < nparts; t0 += 4 * FIN_U) {
+            float o0[FIN_U], o1[FIN_U], o2[FIN_U];
+#pragma unroll
+            for (int u = 0; u < FIN_U; ++u) {
+                const int t = t0 + 4 * u < nparts ? t0 + 4 * u : nparts - 1;
+                const float* o = part + (((long long)n * nparts + t) * C + c) * 3;
+                o0[u] = o[0]; o1[u] = o[1]; o2[u] = o[2];
+            }
+#pragma unroll
+            for (int u = 0; u < FIN_U; ++u)
+                if (t0 + 4 * u < nparts) {
+                    const float dlt = o1[u] - mu;
+                    q += o2[u] + o0[u] * dlt * dlt;
+                }
         }
         __syncthreads();
         red[0][g][cl] = q;
@@ -1692,11 +1710,22 @@ __global__ __launch_bounds__(64 * FS_G) void k_in_finalize_stem(const float* __r
                                                               float* __restrict__ rstd, int B, int nparts) {
     const int n = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
     __shared__ float red[2][FS_G][64];
+    // The partial walks run in rounds of FIN_U loads, the last round padded with clamped re-reads that are not added: as
+    // plain loops hipcc issued ONE load, waited for it (vmcnt(0)) and added.  Same order of additions.  (Measured: 25.7 ->
+    // 22.9 us here — the walk is 2 x 77 MB of partials per 256 images, i.e. bandwidth — and 5.8 -> 4.4 us for
+    // k_in_finalize_cnt; the same form of k_in_finalize_flat, whose tiles need a division each, was slower and is not kept.)
     float s = 0.f, cnt = 0.f;
-    for (int t = g; t < nparts; t += FS_G) {
-        const float* o = part + (((long long)n * nparts + t) * 64 + c) * 3;
-        s += o[0] * o[1];
-        cnt += o[0];
+    for (int t0 = g; t0 < nparts; t0 += FS_G * FIN_U) {
+        float o0[FIN_U], o1[FIN_U];
+#pragma unroll
+        for (int u = 0; u < FIN_U; ++u) {
+            const int t = t0 + FS_G * u < nparts ? t0 + FS_G * u : nparts - 1;
+            const float* o = part + (((long long)n * nparts + t) * 64 + c) * 3;
+            o0[u] = o[0]; o1[u] = o[1];
+        }
+#pragma unroll
+        for (int u = 0; u < FIN_U; ++u)
+            if (t0 + FS_G * u < nparts) { s += o0[u] * o1[u]; cnt += o0[u]; }
     }
     red[0][g][c] = s;
     red[1][g][c] = cnt;
@@ -1706,10 +1735,20 @@ __global__ __launch_bounds__(64 * FS_G) void k_in_finalize_stem(const float* __r
     for (int k = 0; k < FS_G; ++k) { tot += red[1][k][c]; sm += red[0][k][c]; }
     const float mu = sm / tot;
     float q = 0.f;
-    for (int t = g; t < nparts; t += FS_G) {
-        const float* o = part + (((long long)n * nparts + t) * 64 + c) * 3;
-        const float d = o[1] - mu;
-        q += o[2] + o[0] * d * d;
+    for (int t0 = g; t0 < nparts; t0 += FS_G * FIN_U) {
+        float o0[FIN_U], o1[FIN_U], o2[FIN_U];
+#pragma unroll
+        for (int u = 0; u < FIN_U; ++u) {
+            const int t = t0 + FS_G * u < nparts ? t0 + FS_G * u : nparts - 1;
+            const float* o = part + (((long long)n * nparts + t) * 64 + c) * 3;
+            o0[u] = o[0]; o1[u] = o[1]; o2[u] = o[2];
+        }
+#pragma unroll
+        for (int u = 0; u < FIN_U; ++u)
+            if (t0 + FS_G * u < nparts) {
+                const float d = o1[u] - mu;
+                q += o2[u] + o0[u] * d * d;
+            }
     }
     __syncthreads();
     red[0][g][c] = q;
