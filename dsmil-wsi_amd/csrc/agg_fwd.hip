@@ -910,6 +910,13 @@ __global__ __launch_bounds__(HS_THREADS, 2) void k_attend_hs(AttendArgs a) {
     int tile = (int)blockIdx.x;
     if (a.qm_flag) {   // the first C workgroups of the grid row: the critical row's query, beside the tiles' MLP
         if (tile < a.C) {
+            if (a.offsets[bag + 1] <= a.offsets[bag]) {   // an empty bag has no tiles waiting and no row to read
+                if (threadIdx.x == 0) {
+                    a.qm_idx[(long long)bag * a.C + tile] = 0;
+                    __hip_atomic_store(a.qm_flag + (long long)bag * a.C + tile, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
             long long* s_i = reinterpret_cast<long long*>(smem);
             float* s_v = smem + 2 * (HS_THREADS / 64), *s_h = s_v + HS_THREADS / 64;
             qmax_block<4, float, true>(reinterpret_cast<const float*>(a.feats), a.offsets, a.qm_part_val, a.qm_part_idx, a.q0_w, a.q0_b,

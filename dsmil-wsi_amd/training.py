@@ -196,6 +196,45 @@ class FusedTrainStep:
                 self.opt.state[p]["step"] = torch.tensor(float(self.step), dtype=torch.float32)
 
 
+class LossReadback:
+    """The per-step `loss.item()` of train_tcga.py:75 without the per-step stall: every step's loss is still copied to the host
+    and reported, but through a pinned two-slot ring — `push(loss)` enqueues this step's device-to-host copy and hands back the
+    PREVIOUS step's value (its copy finished while this step was being enqueued), `flush()` the last one.  The host stays at
+    most one step ahead of the GPU, every value arrives, in order; only the moment of the read moves by one step."""
+
+    def __init__(self, device):
+        self.cuda = torch.device(device).type == "cuda"
+        self.buf = torch.zeros(2, dtype=torch.float32, pin_memory=True) if self.cuda else None
+        self.ev = [torch.cuda.Event(), torch.cuda.Event()] if self.cuda else None
+        self.n = 0
+        self.pending = None
+
+    def push(self, loss):
+        """loss: 0-dim tensor of this step.  Returns the previous step's loss as a float (None on the first call)."""
+        if not self.cuda:
+            prev, self.pending = self.pending, float(loss.detach())
+            return prev
+        k = self.n & 1
+        self.buf[k:k + 1].copy_(loss.detach().reshape(1), non_blocking=True)
+        self.ev[k].record()
+        prev = None
+        if self.n > 0:
+            self.ev[k ^ 1].synchronize()
+            prev = float(self.buf[k ^ 1])
+        self.n += 1
+        return prev
+
+    def flush(self):
+        if not self.cuda:
+            prev, self.pending = self.pending, None
+            return prev
+        if self.n == 0:
+            return None
+        k = (self.n - 1) & 1
+        self.ev[k].synchronize()
+        return float(self.buf[k])
+
+
 def train(args, train_df, milnet, criterion, optimizer, cache=None, log=True):
     """train_tcga.py:55-76: one optimiser step per bag, bags in random order."""
     from sklearn.utils import shuffle
@@ -207,6 +246,7 @@ def train(args, train_df, milnet, criterion, optimizer, cache=None, log=True):
     losses = []
     # the whole step as one native call when the model / criterion / optimiser are the reference's (FusedTrainStep)
     fused = FusedTrainStep.create(milnet, criterion, optimizer) if getattr(args, "fused_step", True) else None
+    readback = LossReadback(device)
     for i, item in enumerate(dirs):
         bag_feats, bag_label = cache.get(item, args.feats_size)
         rows = dropout_rows(bag_feats.size(0), 1 - args.dropout_patch, bag_feats.device)
@@ -218,8 +258,12 @@ def train(args, train_df, milnet, criterion, optimizer, cache=None, log=True):
             loss.backward()
             optimizer.step()
         losses.append(loss.detach())
-        if log:   # the progress line is the only host sync of a step (train_tcga.py:74-75 syncs twice per step)
-            sys.stdout.write("\r Training bag [%d/%d] bag loss: %.4f" % (i, len(dirs), loss.item()))
+        if log:   # the progress line of train_tcga.py:74-75, every bag's loss, written one step late (LossReadback): no stall
+            prev = readback.push(loss)
+            if prev is not None:
+                sys.stdout.write("\r Training bag [%d/%d] bag loss: %.4f" % (i - 1, len(dirs), prev))
+    if log and dirs:
+        sys.stdout.write("\r Training bag [%d/%d] bag loss: %.4f" % (len(dirs) - 1, len(dirs), readback.flush()))
     if fused is not None:
         fused.sync()
     if losses:

@@ -453,3 +453,30 @@ def test_compute_feats_background_filter_on_gpu(tmp_path, monkeypatch):
     """The same on the GPU: dsmil_tile_stats (exact integer band sums) decides, the native trunk embeds the kept tiles."""
     monkeypatch.chdir(tmp_path)
     _check_bg_filter(224, 1e-4)
+
+
+def test_train_progress_line_reports_every_bag_in_order(capsys):
+    """training.train writes train_tcga.py:75's progress line for EVERY bag, in order, with that bag's loss — through
+    training.LossReadback (each loss is read one step late, so a step never stalls on the host read; CPU: same code path with
+    plain floats) — and returns the mean of exactly those losses."""
+    import argparse
+    import re
+    import numpy as np
+    import torch
+    import dsmil as mil
+    from dsmil_wsi_amd import training as T
+    rng = np.random.default_rng(3)
+    bags = [torch.from_numpy(np.concatenate([rng.standard_normal((20 + b, 16)).astype(np.float32),
+                                             np.full((20 + b, 1), b % 2, np.float32)], 1)) for b in range(5)]
+    args = argparse.Namespace(feats_size=16, num_classes=1, dropout_patch=0.0, dropout_node=0.0, non_linearity=1,
+                              lr=1e-3, weight_decay=1e-4, num_epochs=1, average=False)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net, crit, opt, sched = T.init_model(args, mil, torch.device("cpu"))
+    mean_loss = T.train(args, bags, net, crit, opt, log=True)
+    out = capsys.readouterr().out
+    lines = re.findall(r"Training bag \[(\d+)/5\] bag loss: ([0-9.]+)", out)
+    assert [int(i) for i, _ in lines] == [0, 1, 2, 3, 4], out
+    assert abs(sum(float(v) for _, v in lines) / 5 - mean_loss) < 1e-3
+    rb = T.LossReadback("cpu")
+    assert rb.push(torch.tensor(1.5)) is None and rb.push(torch.tensor(2.5)) == 1.5 and rb.flush() == 2.5
