@@ -307,21 +307,32 @@ def test(args, test_df, milnet, criterion, thresholds=None, return_predictions=F
     milnet.eval()
     device = next(milnet.parameters()).device
     cache = cache or BagCache(device)
-    total_loss, labels, preds = 0.0, [], []
+    # The reference reads the loss (twice), the label and the prediction on the host after every bag: four stalls per forward.
+    # Here everything stays on the device until the loop ends (one transfer each), the progress line reads each loss one step
+    # late (LossReadback): same numbers, same line for every bag.
+    total_loss, losses, labels, preds = 0.0, [], [], []
+    readback = LossReadback(device)
     for i, item in enumerate(test_df):
         bag_feats, bag_label = cache.get(item, args.feats_size)
         rows = dropout_rows(bag_feats.size(0), 1 - args.dropout_patch, bag_feats.device)   # train_tcga.py:96
         loss, bag_prediction, max_prediction = bag_loss(milnet, criterion, bag_feats, bag_label, rows)
-        total_loss += loss.item()
+        losses.append(loss.detach().reshape(()))
         if log:
-            sys.stdout.write("\r Testing bag [%d/%d] bag loss: %.4f" % (i, len(test_df), loss.item()))
-        labels.append(bag_label.squeeze().cpu().numpy().astype(int))
+            prev = readback.push(loss)
+            if prev is not None:
+                sys.stdout.write("\r Testing bag [%d/%d] bag loss: %.4f" % (i - 1, len(test_df), prev))
+        labels.append(bag_label.reshape(-1))
         if args.average:
-            preds.append((torch.sigmoid(max_prediction) + torch.sigmoid(bag_prediction)).squeeze().cpu().numpy())
+            preds.append((torch.sigmoid(max_prediction) + torch.sigmoid(bag_prediction)).reshape(-1))
         else:
-            preds.append(torch.sigmoid(bag_prediction).squeeze().cpu().numpy())
-    test_labels = np.array(labels)
-    test_predictions = np.array(preds)
+            preds.append(torch.sigmoid(bag_prediction).reshape(-1))
+    if log and len(losses):
+        sys.stdout.write("\r Testing bag [%d/%d] bag loss: %.4f" % (len(losses) - 1, len(test_df), readback.flush()))
+    if losses:
+        total_loss = float(torch.stack(losses).double().sum().item())
+    sq = (lambda a: a.squeeze(-1)) if args.num_classes == 1 else (lambda a: a)   # (the reference's per-bag .squeeze())
+    test_labels = sq(torch.stack(labels).cpu().numpy().astype(int)) if labels else np.array([])
+    test_predictions = sq(torch.stack(preds).cpu().numpy()) if preds else np.array([])
     auc_value, _, thresholds_optimal = multi_label_roc(test_labels, test_predictions, args.num_classes, log=log)
     if thresholds:
         thresholds_optimal = thresholds

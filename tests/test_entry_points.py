@@ -480,3 +480,45 @@ def test_train_progress_line_reports_every_bag_in_order(capsys):
     assert abs(sum(float(v) for _, v in lines) / 5 - mean_loss) < 1e-3
     rb = T.LossReadback("cpu")
     assert rb.push(torch.tensor(1.5)) is None and rb.push(torch.tensor(2.5)) == 1.5 and rb.flush() == 2.5
+
+
+@pytest.mark.parametrize("C", [1, 2])
+def test_test_loop_matches_a_per_bag_host_loop(C, capsys):
+    """training.test keeps losses / labels / predictions on the device until the loop ends; result and progress lines equal
+    the reference's per-bag host reads (train_tcga.py:85-132 written out plainly here)."""
+    import argparse
+    import re
+    import numpy as np
+    import torch
+    import dsmil as mil
+    from dsmil_wsi_amd import training as T
+    rng = np.random.default_rng(7)
+    bags = []
+    for b in range(6):
+        X = rng.standard_normal((15 + 3 * b, 16)).astype(np.float32)
+        lab = np.zeros((X.shape[0], C), np.float32)
+        lab[:, b % C] = 1.0 if C > 1 else float(b % 2)
+        bags.append(torch.from_numpy(np.concatenate([X, lab], 1)))
+    args = argparse.Namespace(feats_size=16, num_classes=C, dropout_patch=0.0, dropout_node=0.0, non_linearity=1,
+                              lr=1e-3, weight_decay=1e-4, num_epochs=1, average=True)
+    torch.manual_seed(1)
+    net, crit, opt, sched = T.init_model(args, mil, torch.device("cpu"))
+    loss, score, aucs, th = T.test(args, bags, net, crit, log=True)
+    out = capsys.readouterr().out
+    lines = re.findall(r"Testing bag \[(\d+)/6\] bag loss: ([0-9.]+)", out)
+    assert [int(i) for i, _ in lines] == list(range(6))
+    # the same loop with the reference's host reads
+    net.eval()
+    cache = T.BagCache(torch.device("cpu"))
+    tot, labels, preds = 0.0, [], []
+    with torch.no_grad():
+        for item in bags:
+            x, y = cache.get(item, 16)
+            l, bp, mp = T.bag_loss(net, crit, x, y, None)
+            tot += l.item()
+            labels.append(y.squeeze().numpy().astype(int))
+            preds.append((torch.sigmoid(mp) + torch.sigmoid(bp)).squeeze().numpy())
+    assert abs(tot / 6 - loss) < 1e-6
+    assert abs(sum(float(v) for _, v in lines) / 6 - loss) < 1e-3
+    ref_auc, _, ref_th = T.multi_label_roc(np.array(labels), np.array(preds), C, log=False)
+    assert np.allclose(aucs, ref_auc) and np.allclose(th, ref_th)
