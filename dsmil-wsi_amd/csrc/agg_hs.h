@@ -368,18 +368,22 @@ __device__ __forceinline__ void attend_tail_hs(const AttendArgs& a, const f32x16
             // before any tile of this grid row and wait for nothing; the spin is bounded all the same.
             const int* f0 = a.qm_flag + (long long)bag * a.C + c0;
             const int* f1 = a.qm_flag + (long long)bag * a.C + c1;
+            // The flags and the query go out TOGETHER: loads are served in order, so a query read behind a flag read that
+            // returned 1 is the published one (the producer's release orders its stores before the flag) — one round trip
+            // instead of two; while a flag is still 0 the round is simply repeated.
             for (int spin = 0; spin < (1 << 22); ++spin) {
-                if (__hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
-                    __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                const int g0 = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int g1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        u0q[q][e] = __hip_atomic_load(qm0 + 8 * q + 4 * hi + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        u1q[q][e] = __hip_atomic_load(qm1 + 8 * q + 4 * hi + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                if (g0 && g1) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    u0q[q][e] = __hip_atomic_load(qm0 + 8 * q + 4 * hi + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    u1q[q][e] = __hip_atomic_load(qm1 + 8 * q + 4 * hi + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
