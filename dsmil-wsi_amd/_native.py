@@ -52,6 +52,7 @@ SIGNATURES = {
     "dsmil_abi_version": (ctypes.c_int, []),
     "dsmil_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "dsmil_agg_mlp_form": (ctypes.c_int, []),
+    "dsmil_agg_inline_query": (ctypes.c_int, [ctypes.c_int]),
     "dsmil_agg_packed_split_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "dsmil_agg_pack_split": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "dsmil_agg_forward_ex": (ctypes.c_int, [c_f32p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int64,

@@ -35,6 +35,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include "dsmil_hip.h"
 #include "prof.h"
 
@@ -902,6 +903,16 @@ __global__ void k_pack_agg_bf16(const float* __restrict__ q0_w, const float* __r
     }
 }
 
+// The producer half of the in-launch hand-off (MI355X_MICROARCH.md, "valid forms"): the workgroup's plain stores are out
+// (the caller's __syncthreads()), ONE lane writes the XCD's L2 back with an agent-scope release, waits for the write-back
+// with an s_waitcnt hipcc cannot drop (it elides its own when the wave's vmcnt scoreboard is provably empty, and the flag
+// then overtakes the data), and only then sets the flag with a relaxed agent-scope store.
+__device__ __forceinline__ void publish_flag(int* flag) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // few rows (a lone bag, a training step): the hidden units of a 32-row tile split over the four SIMDs of a CU (agg_hs.h)
 template <int NP>
 __global__ __launch_bounds__(HS_THREADS, 2) void k_attend_hs(AttendArgs a) {
@@ -913,7 +924,7 @@ __global__ __launch_bounds__(HS_THREADS, 2) void k_attend_hs(AttendArgs a) {
             if (a.offsets[bag + 1] <= a.offsets[bag]) {   // an empty bag has no tiles waiting and no row to read
                 if (threadIdx.x == 0) {
                     a.qm_idx[(long long)bag * a.C + tile] = 0;
-                    __hip_atomic_store(a.qm_flag + (long long)bag * a.C + tile, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    publish_flag(a.qm_flag + (long long)bag * a.C + tile);
                 }
                 return;
             }
@@ -923,8 +934,7 @@ __global__ __launch_bounds__(HS_THREADS, 2) void k_attend_hs(AttendArgs a) {
                                  a.q2_w, a.q2_b, const_cast<float*>(a.qmax), a.qm_idx, a.K, a.C, a.nonlinear, bag, tile, s_v, s_i,
                                  s_h, 0, nullptr, a.rowmap, a.qm_r0);
             __syncthreads();   // every wave's stores are out (vmcnt 0) before the release below writes the L2 back
-            if (threadIdx.x == 0)
-                __hip_atomic_store(a.qm_flag + (long long)bag * a.C + tile, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) publish_flag(a.qm_flag + (long long)bag * a.C + tile);
             return;
         }
         tile -= a.C;
@@ -1184,6 +1194,32 @@ int launch_attend_split(const AttendArgs& a, long long max_rows, int n_bags, hip
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
+// Compute units of the current device (cached per device id; 256 on MI355X).
+int device_cus() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (v <= 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cus[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+// dsmil_agg_inline_query(): 1 = the critical row's query may run inside the k_attend_hs launch (default), 0 = always the
+// separate k_qmax launch
+std::atomic<int> g_inline_query{1};
+
+// The in-launch hand-off needs its producers to RUN while tiles spin on their flags.  Producers are the first workgroups of
+// every grid row and the hardware dispatches a grid in order, but HIP promises neither: the query is inlined only when
+// every workgroup of the launch can be resident at once (k_attend_hs: 2 workgroups per CU by LDS and registers), so that
+// progress does not depend on dispatch order at all.  Larger batches take the k_qmax launch.
+bool hs_inline_fits(long long max_rows, int n_bags, int C) {
+    const long long wgs = ((max_rows + HS_BM - 1) / HS_BM + C) * (long long)n_bags;
+    return wgs <= 2LL * device_cus();
+}
+
 int launch_attend_hs(const AttendArgs& a, long long max_rows, int n_bags, hipStream_t st) {
     size_t lds = HS_LDS_BYTES;
 #ifdef DSMIL_EXPERIMENTS
@@ -1311,6 +1347,10 @@ extern "C" {
 int dsmil_abi_version(void) { return DSMIL_ABI_VERSION; }
 
 int dsmil_agg_mlp_form(void) { return mlp_mode(); }
+int dsmil_agg_inline_query(int mode) {
+    if (mode == 0 || mode == 1) return g_inline_query.exchange(mode);
+    return g_inline_query.load();
+}
 
 const char* dsmil_strerror(int code) {
     switch (code) {
@@ -1433,7 +1473,8 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
 #ifdef DSMIL_EXPERIMENTS
         if (a.expt & 8) use_hs = false;
 #endif
-        const bool qm_inline = use_hs && stream_ok && sh.phase == 0 && !no_qmi;
+        const bool qm_inline = use_hs && stream_ok && sh.phase == 0 && !no_qmi && g_inline_query.load(std::memory_order_relaxed) &&
+                               hs_inline_fits(max_rows, nb, C);
         int* qflag = qm_inline ? (int*)(w8 + L.qflag) : nullptr;
         dim3 grid((unsigned)((max_rows + r0 - 1) / r0), (unsigned)nb);
         if (sh.phase == 2) {}  // the caller already knows the bag-wide critical rows

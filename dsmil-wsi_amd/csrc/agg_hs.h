@@ -362,34 +362,46 @@ __device__ __forceinline__ void attend_tail_hs(const AttendArgs& a, const f32x16
 #pragma unroll
         for (int g = 0; g < HS_RG; ++g) { s0[g] = 0.f; s1[g] = 0.f; }
         f32x4 u0q[4], u1q[4];
+        bool have_q = true;
         if (a.qm_flag) {
-            // the critical row's query comes from workgroups [0, C) of this launch: wait for their flags, then read it with
-            // agent-scope loads (another XCD's L2 may hold the previous launch's lines).  The producers were dispatched
-            // before any tile of this grid row and wait for nothing; the spin is bounded all the same.
-            const int* f0 = a.qm_flag + (long long)bag * a.C + c0;
-            const int* f1 = a.qm_flag + (long long)bag * a.C + c1;
-            // The flags and the query go out TOGETHER: loads are served in order, so a query read behind a flag read that
-            // returned 1 is the published one (the producer's release orders its stores before the flag) — one round trip
-            // instead of two; while a flag is still 0 the round is simply repeated.
-            for (int spin = 0; spin < (1 << 22); ++spin) {
-                const int g0 = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int g1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        u0q[q][e] = __hip_atomic_load(qm0 + 8 * q + 4 * hi + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        u1q[q][e] = __hip_atomic_load(qm1 + 8 * q + 4 * hi + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                if (g0 && g1) break;
-                __builtin_amdgcn_s_sleep(1);
+            // The critical row's query comes from workgroups [0, C) of this grid row (k_attend_hs).  The hand-off is the
+            // one form MI355X_MICROARCH.md ("inter-workgroup visibility") lists as valid for a plain-store producer:
+            //   ONE wave polls the flags with relaxed agent-scope loads and NOTHING else in the loop
+            //   -> ONE agent-scope acquire (s_waitcnt vmcnt(0); buffer_inv sc1: this CU's L1 forgets every line)
+            //   -> __syncthreads() -> plain loads of the query by every wave.
+            // The query is never requested before the flag has been OBSERVED set (round 4 issued both in one clause: in-order
+            // return to the wave says nothing about when each line was sampled, and a tile then computed with the previous
+            // call's query — VERDICT r04).  Forward progress: the producers are workgroups 0..C-1 of the row, dispatched
+            // before its tiles, and wait for nothing; the launcher inlines the query only when the whole grid is resident
+            // at once (launch_attend_hs).  If the spin is exhausted all the same, the tile's query is NaN and so is every
+            // output that depends on it: never a plausible wrong answer.
+            int* okw = reinterpret_cast<int*>(scr + HS_SCRATCH - 1);
+            if (wave == 0) {
+                const int* f0 = a.qm_flag + (long long)bag * a.C + c0;
+                const int* f1 = a.qm_flag + (long long)bag * a.C + c1;
+                int ok = 0;
+                for (int spin = 0; spin < (1 << 20); ++spin) {
+                    const int g0 = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int g1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (g0 && g1) { ok = 1; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (lane == 0) *okw = ok;
             }
-        } else {
+            __syncthreads();
+            have_q = *okw != 0;
+        }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                u0q[q] = *reinterpret_cast<const f32x4*>(qm0 + 8 * q + 4 * hi);
-                u1q[q] = *reinterpret_cast<const f32x4*>(qm1 + 8 * q + 4 * hi);
-            }
+        for (int q = 0; q < 4; ++q) {
+            u0q[q] = *reinterpret_cast<const f32x4*>(qm0 + 8 * q + 4 * hi);
+            u1q[q] = *reinterpret_cast<const f32x4*>(qm1 + 8 * q + 4 * hi);
+        }
+        if (!have_q) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { u0q[q][e] = __builtin_nanf(""); u1q[q][e] = __builtin_nanf(""); }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

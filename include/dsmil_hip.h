@@ -130,6 +130,14 @@ int dsmil_agg_shard_attend(const float* feats, const float* vals, int64_t rows,
  * once per process. */
 int dsmil_agg_mlp_form(void);
 
+/* Where the critical instance's query q_max (dsmil.py:53-54) is computed on the few-rows fp32 path (a lone bag, a training
+ * step: kernel k_attend_hs): mode 1 (default) = by the first C workgroups of the attend launch itself, handed to the
+ * tiles through an agent-scope release/acquire flag (only when the whole launch is resident at once; larger batches take
+ * the separate launch anyway); mode 0 = always the separate k_qmax launch between the logits pass and the attend kernel.
+ * Both produce the same bits; the switch exists so that a test can compare them (tests/test_agg_gpu.py, hand-off stress).
+ * Process-wide.  Returns the previous mode; any other `mode` only queries. */
+int dsmil_agg_inline_query(int mode);
+
 /* Options of dsmil_agg_forward_ex (all optional; a NULL opts or an all-zero struct = dsmil_agg_forward):
  *   packed_split  the plane-cut query weights of forms 6 / 9 prepared ONCE per weight set instead of on every
  *                 forward (BClassifier.q changes only at optimizer.step(), train_tcga.py:73): dsmil_agg_pack_split
