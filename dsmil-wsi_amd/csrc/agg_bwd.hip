@@ -1221,9 +1221,7 @@ int agg_backward_impl(const float* feats, const float* vals, int64_t N, const ds
     // (`prepared`: dsmil_agg_train_step's prologue already filled wsplit, w2t and off of THIS workspace)
     const int nks = 2 * ((K + 31) / 32);
     if (prepared) packed_split = wsplit;
-    else if (packed_split && p->nonlinear) {
-        hipLaunchKernelGGL(k_train_prologue, dim3(48), dim3(256), 0, st, (const float*)nullptr, p->q2_w, wsplit, w2t, 0, 0, off, off, (long long)N);
-    } else if (!packed_split || p->nonlinear) {
+    else if (!packed_split || p->nonlinear) {   // (a nonlinear query needs W2^T from here anyway: the caller's image is then not used)
         hipLaunchKernelGGL(k_train_prologue, dim3(240), dim3(256), 0, st, p->q0_w, p->nonlinear ? p->q2_w : nullptr, wsplit, w2t, K, nks,
                            off, off, (long long)N);
         packed_split = wsplit;

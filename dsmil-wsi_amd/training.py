@@ -189,6 +189,13 @@ class FusedTrainStep:
         torch.autograd.graph.increment_version(self._live)
         return loss.reshape(())
 
+    def resync(self):
+        """Re-read the step count from the optimiser's state (after a generic optimizer.step() between fused steps)."""
+        steps = {int(float(self.opt.state[p]["step"])) for p in self.params if p is not None}
+        if len(steps) != 1:
+            raise RuntimeError("Adam state with different step counts per parameter")
+        self.step = steps.pop()
+
     def sync(self):
         """Write the step count back into the optimiser's state (torch keeps it as a CPU float tensor per parameter)."""
         for p in self.params:
@@ -247,25 +254,35 @@ def train(args, train_df, milnet, criterion, optimizer, cache=None, log=True):
     # the whole step as one native call when the model / criterion / optimiser are the reference's (FusedTrainStep)
     fused = FusedTrainStep.create(milnet, criterion, optimizer) if getattr(args, "fused_step", True) else None
     readback = LossReadback(device)
-    for i, item in enumerate(dirs):
-        bag_feats, bag_label = cache.get(item, args.feats_size)
-        rows = dropout_rows(bag_feats.size(0), 1 - args.dropout_patch, bag_feats.device)
-        if fused is not None and fused.accepts(bag_feats):
-            loss = fused(bag_feats, bag_label, rows)
-        else:
-            optimizer.zero_grad()
-            loss, _, _ = bag_loss(milnet, criterion, bag_feats, bag_label, rows)
-            loss.backward()
-            optimizer.step()
-        losses.append(loss.detach())
-        if log:   # the progress line of train_tcga.py:74-75, every bag's loss, written one step late (LossReadback): no stall
-            prev = readback.push(loss)
-            if prev is not None:
-                sys.stdout.write("\r Training bag [%d/%d] bag loss: %.4f" % (i - 1, len(dirs), prev))
-    if log and dirs:
-        sys.stdout.write("\r Training bag [%d/%d] bag loss: %.4f" % (len(dirs) - 1, len(dirs), readback.flush()))
-    if fused is not None:
-        fused.sync()
+    try:
+        for i, item in enumerate(dirs):
+            bag_feats, bag_label = cache.get(item, args.feats_size)
+            rows = dropout_rows(bag_feats.size(0), 1 - args.dropout_patch, bag_feats.device)
+            if fused is not None and fused.accepts(bag_feats):
+                loss = fused(bag_feats, bag_label, rows)
+            else:
+                if fused is not None:
+                    fused.sync()          # the optimiser's own step count = every update so far, fused ones included
+                optimizer.zero_grad()
+                loss, _, _ = bag_loss(milnet, criterion, bag_feats, bag_label, rows)
+                loss.backward()
+                optimizer.step()
+                if fused is not None:
+                    fused.resync()        # ... and the fused counter follows the generic update
+            losses.append(loss.detach())
+            if log:   # the progress line of train_tcga.py:74-75, every bag's loss, written one step late (LossReadback): no stall
+                prev = readback.push(loss)
+                if prev is not None:
+                    sys.stdout.write("\r Training bag [%d/%d] bag loss: %.4f" % (i - 1, len(dirs), prev))
+    finally:
+        # also when a step raised: the loss of the last COMPLETED step is still reported and the optimiser's step count is
+        # written back (a checkpoint saved by the caller's handler is then consistent)
+        if log and dirs:
+            last = readback.flush()
+            if last is not None:
+                sys.stdout.write("\r Training bag [%d/%d] bag loss: %.4f" % (len(losses) - 1, len(dirs), last))
+        if fused is not None:
+            fused.sync()
     if losses:
         total_loss = float(torch.stack(losses).sum().item())
     return total_loss / max(1, len(dirs))
