@@ -31,7 +31,7 @@ class AggParams(ctypes.Structure):
 
 class AggOpts(ctypes.Structure):
     """struct dsmil_agg_opts (include/dsmil_hip.h)."""
-    _fields_ = [("packed_split", ctypes.c_void_p), ("row_map", ctypes.c_void_p)]
+    _fields_ = [("packed_split", ctypes.c_void_p), ("row_map", ctypes.c_void_p), ("packed_f2", ctypes.c_void_p)]
 
 
 class AggGrads(ctypes.Structure):
@@ -53,6 +53,9 @@ SIGNATURES = {
     "dsmil_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "dsmil_agg_mlp_form": (ctypes.c_int, []),
     "dsmil_agg_inline_query": (ctypes.c_int, [ctypes.c_int]),
+    "dsmil_agg_batch_form": (ctypes.c_int, [ctypes.c_int]),
+    "dsmil_agg_packed_f2_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
+    "dsmil_agg_pack_f2": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "dsmil_agg_packed_split_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "dsmil_agg_pack_split": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "dsmil_agg_forward_ex": (ctypes.c_int, [c_f32p, c_f32p, c_i64p, ctypes.c_int32, ctypes.c_int64,

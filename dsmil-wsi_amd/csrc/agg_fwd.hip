@@ -42,6 +42,7 @@
 #include "agg_common.h"
 #include "agg_split.h"
 #include "agg_hs.h"
+#include "agg_f2.h"
 #include "agg_res.h"
 #include "lds_attr.h"
 
@@ -203,7 +204,9 @@ __global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
     const float* __restrict__ fc_w, const float* __restrict__ fc_b, float* __restrict__ classes_out,
     float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C, int bag0,
     const int64_t* __restrict__ rowmap, int r0 = R0, int* __restrict__ qm_flag = nullptr,
-    TrainPrologueJob job = TrainPrologueJob{}) {
+    TrainPrologueJob job = TrainPrologueJob{}, float* __restrict__ rowmax = nullptr) {
+    // rowmax (fp32 rows, k_attend_f2 follows): max_k |x[row][k]| of every LOGICAL row, a by-product of this pass over the
+    // bag — the attend kernel derives the row's power-of-two scale for its fp16 plane cut from it (agg_f2.h)
     // qm_flag: the hand-off flags of the attend launch that follows (AttendArgs::qm_flag), cleared here
     if (qm_flag && blockIdx.x == 0 && (int)threadIdx.x < C) qm_flag[(long long)(bag0 + (int)blockIdx.y) * C + threadIdx.x] = 0;
     if (job.blocks) {   // a training step: the last job.blocks workgroups cut the weight planes and write the offsets
@@ -252,7 +255,8 @@ __global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
             if (rbase >= Nb) break;  // wave-uniform
             const long long r = (rbase + rr < Nb) ? rbase + rr : Nb - 1;
             const T* x = feats + phys_row(rowmap, off0 + r) * (long long)K;
-            float a0 = 0.f, a1 = 0.f;
+            float a0 = 0.f, a1 = 0.f, xm = 0.f;
+            const bool want_max = std::is_same<T, float>::value && rowmax && c0 == 0;   // block-uniform
 #pragma unroll 1
             for (int s0 = 0; s0 < nseg; s0 += U) {
                 StreamVec<T> v[U];
@@ -261,6 +265,12 @@ __global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
                     int k = (s0 + u) * SEG + j * EPL;
                     k = k < K ? k : K - EPL;  // clamped re-read; its weight is zero
                     v[u].load(x + k);
+                }
+                if (want_max) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) xm = fmaxf(xm, fabsf(v[u].at(e)));   // (a clamped re-read repeats row data)
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -285,6 +295,11 @@ __global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
             }
             a0 += b0;
             a1 += b1;
+            if (want_max) {
+#pragma unroll
+                for (int m = 1; m < 8; m <<= 1) xm = fmaxf(xm, __shfl_xor(xm, m, 64));
+                if (j == 0 && rbase + rr < Nb) rowmax[off0 + r] = xm;
+            }
             if (j == 0 && rbase + rr < Nb) {
                 float* o = classes_out + (off0 + r) * (long long)C;
                 o[c0] = a0;
@@ -1120,7 +1135,7 @@ __global__ __launch_bounds__(256) void k_fc(const float* __restrict__ feats,
 
 // ---- host side ------------------------------------------------------------------------------
 struct WsLayout {
-    size_t part_val, part_idx, qmax, qflag, part_ml, part_B, pred_part, wsplit, off2, total;
+    size_t part_val, part_idx, qmax, qflag, part_ml, part_B, pred_part, wsplit, wf2, rowmax, off2, total;
     long long slots0, slots, nchunk_max;
 };
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1145,10 +1160,13 @@ int pick_nw(int n_bags, long long total_rows) {
     return tiles128 >= 512 ? 4 : 1;
 }
 
+inline size_t f2_image_bytes(int K) { return (size_t)(2 * ((K + 31) / 32) + 8) * F2_CHUNK_F4 * 16 + F2_TRAILER_BYTES; }
+
 WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int K, int Kv, int C, int BM) {
     WsLayout w;
     w.slots0 = total_rows / 32 + n_bags + 1;   // (32 = the smallest rows-per-workgroup of the logits kernels)
-    w.slots = total_rows / BM + n_bags + 1;
+    const int bms = BM > F2_BM ? F2_BM : BM;   // (k_attend_f2 runs 64-row tiles in the 128-row regime)
+    w.slots = total_rows / bms + n_bags + 1;
     if (w.slots < RS_MAX_WG + n_bags) w.slots = RS_MAX_WG + n_bags;   // k_attend_bf16_res: one slot per (workgroup, bag) pair, slot = workgroup + bag
     w.nchunk_max = finish_blocks(max_rows, Kv);
     size_t o = 0;
@@ -1160,6 +1178,8 @@ WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int K, 
     w.part_B = o; o = al(o + (size_t)w.slots * C * Kv * sizeof(float));
     w.pred_part = o; o = al(o + (size_t)n_bags * w.nchunk_max * C * C * sizeof(float));
     w.wsplit = o; o = al(o + (size_t)(2 * ((K + 31) / 32) + 8) * S3_CHUNK_F4 * 16);  // cut query weights
+    w.wf2 = o; o = al(o + f2_image_bytes(K));     // k_attend_f2: fp16 two-plane query weights (when the caller brought none)
+    w.rowmax = o; o = al(o + (size_t)total_rows * sizeof(float));   // k_attend_f2: max |x| per row (k_logits_stream)
     w.off2 = o; o = al(o + 2 * sizeof(int64_t));  // {0, N} of a lone shard (dsmil_agg_shard_*)
     w.total = o;
     return w;
@@ -1210,6 +1230,8 @@ int device_cus() {
 // dsmil_agg_inline_query(): 1 = the critical row's query may run inside the k_attend_hs launch (default), 0 = always the
 // separate k_qmax launch
 std::atomic<int> g_inline_query{1};
+// dsmil_agg_batch_form(): 1 = batches of fp32 bags take k_attend_f2 (default), 0 = k_query_attend_split (rounds 2-4)
+std::atomic<int> g_use_f2{1};
 
 // The in-launch hand-off needs its producers to RUN while tiles spin on their flags.  Producers are the first workgroups of
 // every grid row and the hardware dispatches a grid in order, but HIP promises neither: the query is inlined only when
@@ -1239,6 +1261,51 @@ int launch_attend_hs(const AttendArgs& a, long long max_rows, int n_bags, hipStr
 // 512-long dot products carry (tests/accuracy_report.py: identical measured error for 0 / 9 / 6).
 // Experiment builds (libdsmil_hip_expt.so): DSMIL_MLP = s9 | f32 selects the bit-exact-product forms, read once per
 // process; the product library has the one form.
+// batches of fp32 bags: resident 64-row tiles, fp16 two-plane MFMA (agg_f2.h)
+int launch_attend_f2(const AttendArgs& a, const float* rowmax, long long max_rows, int n_bags, hipStream_t st) {
+    void (*fn)(AttendArgs, const float*, int, int) = nullptr;
+    switch (a.K / 32) {
+        case 4: fn = k_attend_f2<4>; break;
+        case 8: fn = k_attend_f2<8>; break;
+        case 12: fn = k_attend_f2<12>; break;
+        case 16: fn = k_attend_f2<16>; break;
+        default: return DSMIL_E_UNSUPPORTED;
+    }
+#ifdef DSMIL_EXPERIMENTS   // timing-only ablations of the K = 512 form (tools/f2_ablate.py)
+    static const int abl = expt_env("DSMIL_F2_ABL");
+    switch (a.K == 512 ? abl : 0) {
+        case 1: fn = k_attend_f2<16, 1>; break;
+        case 2: fn = k_attend_f2<16, 2>; break;
+        case 3: fn = k_attend_f2<16, 3>; break;
+        case 4: fn = k_attend_f2<16, 4>; break;
+        case 7: fn = k_attend_f2<16, 7>; break;
+        case 8: fn = k_attend_f2<16, 8>; break;
+        case 16: fn = k_attend_f2<16, 16>; break;
+        case 31: fn = k_attend_f2<16, 31>; break;
+        case 32: fn = k_attend_f2<16, 32>; break;
+        case 64: fn = k_attend_f2<16, 64>; break;
+        case 128: fn = k_attend_f2<16, 128>; break;
+        case 192: fn = k_attend_f2<16, 192>; break;
+        default: break;
+    }
+#endif
+    if (!dsmil_lds::allow((const void*)fn, F2_LDS_BYTES)) return DSMIL_E_LAUNCH;
+    const int tiles_per_bag = (int)((max_rows + F2_BM - 1) / F2_BM);
+    const long long n_items = (long long)tiles_per_bag * n_bags;
+    if (n_items > 0x7fffffffLL) return DSMIL_E_UNSUPPORTED;
+    int cus = device_cus();
+    if (cus <= 0) cus = 256;
+#ifdef DSMIL_EXPERIMENTS
+    static const int f2_grid = expt_env("DSMIL_F2_GRID");
+    if (f2_grid > 0) cus = f2_grid;
+#endif
+    const long long grid = n_items < cus ? n_items : cus;   // persistent: one workgroup per CU (148 KiB of LDS each)
+    const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(F2_THREADS), F2_LDS_BYTES, st, a, rowmax, tiles_per_bag, (int)n_items);
+    dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
 int mlp_mode() {
 #ifdef DSMIL_EXPERIMENTS
     static const int mode = [] {
@@ -1347,6 +1414,10 @@ extern "C" {
 int dsmil_abi_version(void) { return DSMIL_ABI_VERSION; }
 
 int dsmil_agg_mlp_form(void) { return mlp_mode(); }
+int dsmil_agg_batch_form(int mode) {
+    if (mode == 0 || mode == 1) return g_use_f2.exchange(mode);
+    return g_use_f2.load();
+}
 int dsmil_agg_inline_query(int mode) {
     if (mode == 0 || mode == 1) return g_inline_query.exchange(mode);
     return g_inline_query.load();
@@ -1395,6 +1466,7 @@ struct ShardCtl {
     float* ml_out = nullptr;          // phase 2 out: [C,2] (max, sum) of this shard
     bool skip_pred = false;           // phase 0: leave the last sum (k_pred) to the caller (dsmil_agg_forward_nopred)
     const TrainPrologueJob* job = nullptr;   // carried by the logits launch (dsmil_agg_forward_nopred)
+    const void* packed_f2 = nullptr;         // dsmil_agg_opts::packed_f2 (k_attend_f2's weight image, prepared by the caller)
 };
 
 static int agg_forward_impl(const void* feats, const void* vals, const int64_t* offsets,
@@ -1449,10 +1521,10 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
                  part_ml, part_B, K, Kv, C, p->nonlinear, 0, 0, rowmap};
 #ifdef DSMIL_EXPERIMENTS
     static const int expt = expt_env("DSMIL_EXPT"), logits_old = expt_env("DSMIL_LOGITS_OLD"), no_hs = expt_env("DSMIL_NO_HS"),
-                     no_qmi = expt_env("DSMIL_NO_QMI");
+                     no_qmi = expt_env("DSMIL_NO_QMI"), no_f2 = expt_env("DSMIL_NO_F2");
     a.expt = expt;
 #else
-    constexpr int logits_old = 0, no_hs = 0, no_qmi = 0;
+    constexpr int logits_old = 0, no_hs = 0, no_qmi = 0, no_f2 = 0;
 #endif
     int seg_per = 0, seg_T = 0;   // k_attend_bf16_res: partials per (workgroup, bag), see k_finish
     int hs_bm = 0;                // k_attend_hs: rows per tile (the partial slots follow it)
@@ -1473,6 +1545,11 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
 #ifdef DSMIL_EXPERIMENTS
         if (a.expt & 8) use_hs = false;
 #endif
+        // batches (128-row regime), fp32, v = Identity, K a multiple of 128 up to 512: resident 64-row tiles on the fp16 two-plane
+        // form (agg_f2.h); it needs the row maxima the streaming logits kernel leaves behind
+        const bool use_f2 = !bf16 && NW == 4 && v4 && !no_f2 && mlp_mode() == 6 && stream_ok && sh.phase == 0 && vals == feats &&
+                            (K % 128 == 0) && K <= 16 * F2_MAXSTEPS && g_use_f2.load(std::memory_order_relaxed);
+        float* rowmax = use_f2 ? (float*)(w8 + L.rowmax) : nullptr;
         const bool qm_inline = use_hs && stream_ok && sh.phase == 0 && !no_qmi && g_inline_query.load(std::memory_order_relaxed) &&
                                hs_inline_fits(max_rows, nb, C);
         int* qflag = qm_inline ? (int*)(w8 + L.qflag) : nullptr;
@@ -1490,8 +1567,8 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
             const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 31) / 32 + 1) * 32) * sizeof(float);
             const TrainPrologueJob job = sh.job ? *sh.job : TrainPrologueJob{};
             dim3 gridj(grid.x + (unsigned)job.blocks, grid.y);
-            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, float>), gridj, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, qflag, job);
-            else hipLaunchKernelGGL((k_logits_stream<1, float>), gridj, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, qflag, job);
+            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, float>), gridj, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, qflag, job, rowmax);
+            else hipLaunchKernelGGL((k_logits_stream<1, float>), gridj, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, qflag, job, rowmax);
         }
         else if (v4) hipLaunchKernelGGL((k_logits_argmax<4, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else hipLaunchKernelGGL((k_logits_argmax<1, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
@@ -1520,7 +1597,14 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         int rc;
         seg_per = seg_T = 0;
         const int mode = (NW == 8) ? 0 : mlp_mode();
-        if (!bf16 && mode && packed_split) {
+        if (use_f2 && sh.packed_f2) {
+            a.wpk = (const bf16_t*)sh.packed_f2;  // the caller cut the weights once (dsmil_agg_pack_f2)
+        } else if (use_f2) {
+            _Float16* wf2 = (_Float16*)(w8 + L.wf2);
+            hipLaunchKernelGGL(k_pack_agg_f2, dim3(64), dim3(256), 0, st, p->q0_w, p->nonlinear ? p->q2_w : nullptr, wf2, K, 2 * ((K + 31) / 32));
+            if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+            a.wpk = (const bf16_t*)wf2;
+        } else if (!bf16 && mode && packed_split) {
             a.wpk = (const bf16_t*)packed_split;  // the caller cut the weights once (dsmil_agg_pack_split)
         } else if (!bf16 && mode) {
             const int nks = 2 * ((K + 31) / 32);
@@ -1537,7 +1621,8 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
 #ifdef DSMIL_EXPERIMENTS
         if (a.expt & 512) bf16_res = false;
 #endif
-        if (bf16_res) rc = launch_attend_bf16_res(a, max_rows, nb, st, &seg_per, &seg_T);
+        if (use_f2) { rc = launch_attend_f2(a, rowmax, max_rows, nb, st); hs_bm = F2_BM; }
+        else if (bf16_res) rc = launch_attend_bf16_res(a, max_rows, nb, st, &seg_per, &seg_T);
         else if (bf16_dma) rc = launch_attend_bf16_dma(a, max_rows, nb, st);
         else if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, nb, st) : launch_attend_bf16<1>(a, max_rows, nb, st);
 #ifdef DSMIL_EXPERIMENTS   // DSMIL_MLP=s9 and the ablation variants: not instantiated in the product library
@@ -1597,6 +1682,16 @@ int dsmil_agg_pack_split(const float* q0_w, const float* q2_w, int32_t K, void* 
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
+size_t dsmil_agg_packed_f2_bytes(int32_t K) { return K <= 0 ? 0 : f2_image_bytes(K); }
+
+int dsmil_agg_pack_f2(const float* q0_w, const float* q2_w, int32_t K, void* packed, void* stream) {
+    if (!q0_w || !packed || K <= 0) return DSMIL_E_INVALID;
+    if ((uintptr_t)packed % 16) return DSMIL_E_ALIGN;
+    hipLaunchKernelGGL(k_pack_agg_f2, dim3(64), dim3(256), 0, (hipStream_t)stream, q0_w, q2_w, (_Float16*)packed, K,
+                       2 * ((K + 31) / 32));
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
 int dsmil_agg_forward_ex(const float* feats, const float* vals, const int64_t* offsets,
                          int32_t n_bags, int64_t total_rows, int64_t max_rows,
                          const dsmil_agg_params* p, const dsmil_agg_opts* opts, const float* classes_in,
@@ -1605,8 +1700,11 @@ int dsmil_agg_forward_ex(const float* feats, const float* vals, const int64_t* o
     const void* packed_split = opts ? opts->packed_split : nullptr;
     const int64_t* row_map = opts ? opts->row_map : nullptr;
     if (packed_split && ((uintptr_t)packed_split % 16)) return DSMIL_E_ALIGN;
+    ShardCtl sh;
+    sh.packed_f2 = opts ? opts->packed_f2 : nullptr;
+    if (sh.packed_f2 && ((uintptr_t)sh.packed_f2 % 16)) return DSMIL_E_ALIGN;
     return agg_forward_impl(feats, vals, offsets, n_bags, total_rows, max_rows, p, nullptr, false, classes_in,
-                            classes_out, A, B, pred, idx, ws, ws_bytes, stream, ShardCtl(), packed_split, row_map);
+                            classes_out, A, B, pred, idx, ws, ws_bytes, stream, sh, packed_split, row_map);
 }
 
 }  // extern "C"

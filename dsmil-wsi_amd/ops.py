@@ -225,6 +225,24 @@ def _split_params(q0_w, q2_w, nonlinear, dev):
     return packed
 
 
+def _f2_params(q0_w, q2_w, nonlinear, dev):
+    """fp32 path, batches of bags (k_attend_f2, csrc/agg_f2.h): the query weights as two fp16 planes of their power-of-two
+    scaled values in MFMA-fragment order (dsmil_agg_pack_f2), prepared once per weight set."""
+    L = _native.lib()
+    key = ("f2", str(dev), bool(nonlinear), _tkey(q0_w), _tkey(q2_w) if nonlinear else None)
+    ent = _split_cache.get(key)
+    if ent is not None:
+        ent[2].wait(dev, ent[0])
+        return ent[0]
+    K = q0_w.shape[1]
+    packed = torch.empty(L.dsmil_agg_packed_f2_bytes(K), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.dsmil_agg_pack_f2(_ptr(q0_w), _ptr(q2_w if nonlinear else None), K, _ptr(packed), _stream(dev))
+    _native.check(rc, "dsmil_agg_pack_f2")
+    _split_cache.put(key, (packed, [q0_w, q2_w], _Ready(dev)))
+    return packed
+
+
 def _i64c(t, name):
     if t is None:
         return None
@@ -304,8 +322,14 @@ def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, o
                                           _stream(dev))
         else:
             split = _split_params(keep[2], keep[4], nonlinear, dev)
+            # batches in the 128-row-tile regime take k_attend_f2 (K a multiple of 64 up to 512, v = Identity): its weight image
+            f2 = None
+            if (split is not None and L.dsmil_agg_tile_rows(n_bags, total) == 128 and K % 128 == 0 and K <= 512 and vals is feats
+                    and classes_in is None):
+                f2 = _f2_params(keep[2], keep[4], nonlinear, dev)
             opts = _native.AggOpts(split.data_ptr() if split is not None else 0,
-                                   row_map.data_ptr() if row_map is not None else 0)
+                                   row_map.data_ptr() if row_map is not None else 0,
+                                   f2.data_ptr() if f2 is not None else 0)
             rc = L.dsmil_agg_forward_ex(_ptr(feats), _ptr(vals), _ptr(off), n_bags, total, max(lengths),
                                         ctypes.byref(p), ctypes.byref(opts), _ptr(classes_in),
                                         _ptr(classes if classes_in is None else None),

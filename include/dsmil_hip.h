@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSMIL_ABI_VERSION 3
+#define DSMIL_ABI_VERSION 4
 #define DSMIL_Q_DIM 128 /* query width hard-coded at dsmil.py:31,33 */
 
 enum {
@@ -138,6 +138,14 @@ int dsmil_agg_mlp_form(void);
  * Process-wide.  Returns the previous mode; any other `mode` only queries. */
 int dsmil_agg_inline_query(int mode);
 
+/* Which kernel a BATCH of fp32 bags (>= 512 tiles of 128 rows; v = Identity; K a multiple of 128 up to 512) takes for
+ * dsmil.py:49-57: mode 1 (default) = k_attend_f2 — 64-row tiles resident in LDS from the query MLP to the value sum (every
+ * feature byte read once), the MLP on fp16 MFMA over two-plane cuts of the row-scaled operands, three plane products
+ * (fp32-class accuracy: csrc/agg_f2.h, tools/form_error_study.py); mode 0 = k_query_attend_split of rounds 2-4 (bf16 MFMA,
+ * exact three-plane cuts, six products, the tile read twice).  Process-wide; returns the previous mode; any other `mode`
+ * only queries.  tests/test_agg_gpu.py compares the two. */
+int dsmil_agg_batch_form(int mode);
+
 /* Options of dsmil_agg_forward_ex (all optional; a NULL opts or an all-zero struct = dsmil_agg_forward):
  *   packed_split  the plane-cut query weights of forms 6 / 9 prepared ONCE per weight set instead of on every
  *                 forward (BClassifier.q changes only at optimizer.step(), train_tcga.py:73): dsmil_agg_pack_split
@@ -147,13 +155,19 @@ int dsmil_agg_inline_query(int mode);
  *                 row row_map[i] of feats / vals.  This is train_tcga.py:78-83 `dropout_patches` (a random subset /
  *                 permutation of a bag's rows, `feats[random_indices]`) as an index list folded into the kernels' row
  *                 loads instead of a gathered 20 MB copy.  classes_out / A / idx stay in LOGICAL order (= the order of
- *                 the reference's gathered tensor). */
+ *                 the reference's gathered tensor).
+ *   packed_f2     (ABI 4) the same query weights in the form BATCHES of fp32 bags use since round 5 (kernel k_attend_f2:
+ *                 two fp16 planes of the power-of-two scaled weights, csrc/agg_f2.h), prepared once per weight set by
+ *                 dsmil_agg_pack_f2 into dsmil_agg_packed_f2_bytes(K) bytes, 16-B aligned; NULL = cut inside the forward. */
 typedef struct dsmil_agg_opts {
     const void* packed_split;
     const int64_t* row_map;
+    const void* packed_f2;
 } dsmil_agg_opts;
 size_t dsmil_agg_packed_split_bytes(int32_t K, int32_t nonlinear);
 int dsmil_agg_pack_split(const float* q0_w, const float* q2_w, int32_t K, void* packed, void* stream);
+size_t dsmil_agg_packed_f2_bytes(int32_t K);
+int dsmil_agg_pack_f2(const float* q0_w, const float* q2_w, int32_t K, void* packed, void* stream);
 int dsmil_agg_forward_ex(const float* feats, const float* vals, const int64_t* offsets,
                          int32_t n_bags, int64_t total_rows, int64_t max_rows,
                          const dsmil_agg_params* p, const dsmil_agg_opts* opts, const float* classes_in,

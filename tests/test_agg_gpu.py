@@ -205,6 +205,80 @@ def test_varlen_batch_equals_per_bag(golden):
             np.testing.assert_allclose(u.cpu().numpy(), v.detach().cpu().numpy(), atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("tag", ["c16", "tcga", "linq"])
+def test_batch_form_f2_vs_oracle_and_six_product_form(tag):
+    """k_attend_f2 (round 5: resident 64-row tiles, fp16 two-plane cuts of the row-scaled operands, three plane products) on
+    a ragged batch in the 128-row regime whose bags live on very different scales (rows x 1e-3, x 1, x 300; one bag with a
+    1e4 dynamic range between its rows): every output within the parity bar of the fp64 oracle, and within 2e-5 of the
+    six-product bf16 form of rounds 2-4 (dsmil_agg_batch_form(0)) — the two forms are the same fp32-class arithmetic."""
+    from dsmil_wsi_amd import ops, _native
+    L = _native.lib()
+    K, nonlinear = VARIANT[tag][0], VARIANT[tag][2]
+    w = load_weights(tag)
+    p = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in w.items()}
+    lengths = [4097, 3000, 1, 6400, 63, 65, 9000, 5000, 12000, 7000, 8000, 6000, 3001, 2999]
+    scales = [1.0, 1e-3, 1.0, 300.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]
+    if not nonlinear:   # (a linear query has unbounded scores: scaled features change the conditioning of the softmax itself)
+        scales = [1.0] * len(lengths)
+    assert L.dsmil_agg_tile_rows(len(lengths), sum(lengths)) == 128
+    bags = []
+    for i, (n, sc) in enumerate(zip(lengths, scales)):
+        x = make_bag(4000 + i, n, K) * np.float32(sc)
+        if i == 6 and nonlinear:   # rows of one bag spread over four decades
+            x *= (10.0 ** np.random.default_rng(5).uniform(-2, 2, size=(n, 1))).astype(np.float32)
+        bags.append(x)
+    x = torch.from_numpy(np.concatenate(bags)).cuda()
+    prev = L.dsmil_agg_batch_form(1)
+    try:
+        got = [t.clone() for t in ops.agg_forward(x, lengths, p, nonlinear=nonlinear)]
+        L.dsmil_agg_batch_form(0)
+        old = [t.clone() for t in ops.agg_forward(x, lengths, p, nonlinear=nonlinear)]
+    finally:
+        L.dsmil_agg_batch_form(prev if prev in (0, 1) else 1)
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    for b, n in enumerate(lengths):
+        sl = slice(int(off[b]), int(off[b + 1]))
+        r = orc.milnet_forward(bags[b], w, nonlinear=nonlinear, dtype="f64")
+        sc = max(1.0, float(np.abs(r[3]).max()))   # B and pred scale with the features
+        cls, pred, A, B = [o.cpu().numpy() for o in (got[0][sl], got[1][b:b + 1], got[2][sl], got[3][b:b + 1])]
+        np.testing.assert_allclose(cls, r[0], atol=1e-4 * max(1.0, float(np.abs(r[0]).max())), rtol=1e-5)
+        np.testing.assert_allclose(A, r[2], atol=1e-6, rtol=1e-3)
+        np.testing.assert_allclose(B, r[3], atol=1e-4 * sc, rtol=1e-5)
+        np.testing.assert_allclose(pred, r[1], atol=1e-4 * sc, rtol=1e-5)
+        assert np.array_equal(got[4][b].cpu().numpy(), r[4])
+        np.testing.assert_allclose(A, old[2][sl].cpu().numpy(), atol=2e-7, rtol=2e-4)
+        np.testing.assert_allclose(B, old[3][b:b + 1].cpu().numpy(), atol=2e-5 * sc, rtol=1e-5)
+        np.testing.assert_allclose(pred, old[1][b:b + 1].cpu().numpy(), atol=2e-5 * sc, rtol=1e-5)
+
+
+def test_batch_form_f2_narrow_features_row_map_and_repeatability():
+    """k_attend_f2 at K = 256 (units past K store nothing), through a row map (dropout_patches as an index list), ten runs
+    bit-identical, vs the fp64 oracle on the gathered rows."""
+    from dsmil_wsi_amd import ops, _native
+    L = _native.lib()
+    rng = np.random.default_rng(12)
+    K, C = 256, 2
+    w = {"fc_w": rng.normal(0, 0.05, (C, K)), "fc_b": rng.normal(0, 0.05, (C,)), "q0_w": rng.normal(0, 0.05, (128, K)),
+         "q0_b": rng.normal(0, 0.05, (128,)), "q2_w": rng.normal(0, 0.08, (128, 128)), "q2_b": rng.normal(0, 0.05, (128,)),
+         "fcc_w": rng.normal(0, 0.05, (C, C, K)), "fcc_b": rng.normal(0, 0.05, (C,))}
+    w = {k: v.astype(np.float32) for k, v in w.items()}
+    p = {k: torch.from_numpy(v).cuda() for k, v in w.items()}
+    lengths = [9000] * 8
+    phys = make_bag(31, 80000, K)
+    rmap = rng.permutation(80000)[:sum(lengths)].astype(np.int64)
+    assert L.dsmil_agg_tile_rows(len(lengths), sum(lengths)) == 128
+    x = torch.from_numpy(phys).cuda()
+    rm = torch.from_numpy(rmap).cuda()
+    ref = [t.clone() for t in ops.agg_forward(x, lengths, p, row_map=rm)]
+    for _ in range(9):
+        for a, b in zip(ops.agg_forward(x, lengths, p, row_map=rm), ref):
+            assert torch.equal(a, b)
+    for b in (0, 3, 7):
+        sl = slice(9000 * b, 9000 * (b + 1))
+        r = orc.milnet_forward(phys[rmap[sl]], w, dtype="f64")
+        _cmp((ref[0][sl], ref[1][b:b + 1], ref[2][sl], ref[3][b:b + 1]), r[0], r[1], r[2], r[3], r[4], ref[4][b].cpu().numpy())
+
+
 def test_large_batch_uses_wide_tiles_and_matches():
     """>= 512 tiles of 128 rows switches the launcher to 4-wave workgroups."""
     import dsmil_wsi_amd._native as nat
