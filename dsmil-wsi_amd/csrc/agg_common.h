@@ -43,15 +43,34 @@ constexpr int LDK = BK + 4;      // LDS row stride in floats (144 B): conflict-f
 constexpr int W_TILE = QD * LDK; // floats per staged weight chunk
 constexpr int R0 = 128;          // rows per workgroup of k_logits_argmax
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave-wide sum / max, every lane gets the result.  On DPP: row_ror 8, 4, 2, 1 inside the four 16-lane rows (every lane of a
+// row then holds the row's value), then the four rows through v_readlane and three scalar-operand VALU ops — ~11 instructions,
+// no LDS.  (Rounds 1-4 wrote these as six __shfl_xor stages, which hipcc lowers to ds_bpermute_b32: six dependent LDS round
+// trips of ~100 cycles each; k_qmax is a chain of 32 such sums, the tile softmax of k_attend_hs of four.)  Fixed order:
+// ((r0 + r1) + (r2 + r3)) over the rows, rotation order inside a row — deterministic, NOT the xor tree's rounding.
+__device__ __forceinline__ float dpp_row_sum(float v) {
+#define DSMIL_ROR(n) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xf, 0xf, false))
+    DSMIL_ROR(8); DSMIL_ROR(4); DSMIL_ROR(2); DSMIL_ROR(1);
+#undef DSMIL_ROR
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float dpp_row_max(float v) {
+#define DSMIL_ROR(n) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x120 + (n), 0xf, 0xf, false)))
+    DSMIL_ROR(8); DSMIL_ROR(4); DSMIL_ROR(2); DSMIL_ROR(1);
+#undef DSMIL_ROR
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_row_sum(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = dpp_row_max(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // Every feature / weight / workspace pointer handed to this library is device GLOBAL memory.  Inside

@@ -96,31 +96,10 @@ __device__ __forceinline__ void split2h_scaled(const f32x4& x0, const f32x4& x1,
     }
 }
 
-// wave-wide max / sum on DPP (row_ror inside the 16-lane rows, then the four rows through v_readlane): every lane gets the
-// result.  (__shfl_xor lowers to ds_bpermute — an LDS round trip per stage; the tile's softmax statistics were a chain of 24.)
-__device__ __forceinline__ float f2_wave_max(float v) {
-#define F2_RORM(n) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xf, 0xf, false)))
-    F2_RORM(8); F2_RORM(4); F2_RORM(2); F2_RORM(1);
-#undef F2_RORM
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-}
-__device__ __forceinline__ float f2_row_sum(float v);
-__device__ __forceinline__ float f2_wave_sum(float v) {
-    v = f2_row_sum(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return (r0 + r1) + (r2 + r3);
-}
-
-// sum over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1): every lane ends with the row's sum
-__device__ __forceinline__ float f2_row_sum(float v) {
-#define F2_ROR(n) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xf, 0xf, false))
-    F2_ROR(8); F2_ROR(4); F2_ROR(2); F2_ROR(1);
-#undef F2_ROR
-    return v;
-}
+// (wave_sum / wave_max / dpp_row_sum: agg_common.h)
+__device__ __forceinline__ float f2_wave_max(float v) { return wave_max(v); }
+__device__ __forceinline__ float f2_wave_sum(float v) { return wave_sum(v); }
+__device__ __forceinline__ float f2_row_sum(float v) { return dpp_row_sum(v); }
 
 // chunk c >= 1 opens a group of the cutters' barrier schedule (a barrier follows every chunk of the first half of the tile
 // and every c % 4 == 3 behind it)
