@@ -15,7 +15,7 @@ from dsmil_wsi_amd import ops  # noqa: E402
 from dsmil_wsi_amd.synthetic import load_weights  # noqa: E402
 
 p = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in load_weights("c16").items()}
-n_bags, rows = 64, 10000
+n_bags, rows = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (64, 10000)
 x = torch.randn(n_bags * rows, 512, device="cuda")
 for _ in range(3):
     out = ops.agg_forward(x, [rows] * n_bags, p)
