@@ -407,7 +407,8 @@ __global__ __launch_bounds__(F2_THREADS, 1) void k_attend_f2(AttendArgs a, const
                 // chunk with a refill behind every cut — the rate at which the chip drains 8 KB per CU from HBM — against ~450
                 // without), so the requests are spread over the tile.
                 if constexpr ((ABL & 2) == 0) {           // (ablation: no feature loads behind the first ring fill)
-                    if (c < NK1 / 2) refill(c);
+                    if constexpr ((ABL & 256) != 0) { if (c % 2 == 1) refill(c / 2); }   // (variant: one refill per two cuts, all through GEMM 1)
+                    else if (c < NK1 / 2) refill(c);
                 }
                 // planes up to chunk c are visible to the compute waves: one barrier per chunk through the first half of the tile
                 // (the cut is only a chunk ahead of the MFMAs there), then one per four chunks (a barrier costs ~300 cycles of eight

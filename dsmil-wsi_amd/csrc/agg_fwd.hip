@@ -1286,6 +1286,7 @@ int launch_attend_f2(const AttendArgs& a, const float* rowmax, long long max_row
         case 64: fn = k_attend_f2<16, 64>; break;
         case 128: fn = k_attend_f2<16, 128>; break;
         case 192: fn = k_attend_f2<16, 192>; break;
+        case 256: fn = k_attend_f2<16, 256>; break;
         default: break;
     }
 #endif

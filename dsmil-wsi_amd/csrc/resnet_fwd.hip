@@ -63,8 +63,61 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 
-// cut 4 fp32 values into three bf16 planes (truncation: exact), 2 packed dwords per plane
+// ---- operand forms of the conv kernels (template parameter NP = plane products per fp32 MAC) -------------------------------
+//   9 / 6  bf16 x 3 planes by truncation (exact cut), nine / the six largest products (rounds 2-4; experiment builds:
+//          DSMIL_WINO / DSMIL_CONV = s9 | s6)
+//   3      fp16 x 2 planes by round-to-nearest, products h0 w0 + h0 w1 + h1 w0 (round 5, the product form).  Two RNE fp16
+//          planes carry a value to 2^-24 relative while the second plane is normal (absolute 2^-25 below: gfx950's f16 MFMA
+//          keeps subnormals), the dropped h1 w1 is <= 2^-24 |x w|: the accuracy class of the six-product bf16 form
+//          (tools/form_error_study.py: 5.7e-7 against 3.6e-7 max feature error through the 20 convs) for HALF the MFMAs and
+//          2/3 of the plane bytes.  fp16 has five exponent bits: WEIGHTS are multiplied by 2^EMB_WSHIFT at pack time (a conv
+//          weight of ~0.03 would otherwise keep ~8 bits in its second plane) and the accumulators by 2^-EMB_WSHIFT before
+//          anything reads them; ACTIVATIONS are what an InstanceNorm / frozen BatchNorm + ReLU (or the [0,1] image) produces:
+//          far inside +-65504, also after the Winograd input transform (sums of four).
+constexpr int NPD = 3;                        // the product library's form
+constexpr int EMB_WSHIFT = 8;
+constexpr float EMB_WSCALE = 256.f, EMB_OSCALE = 1.f / 256.f;
+template <int NP> __host__ __device__ constexpr int emb_planes() { return NP == 3 ? 2 : 3; }
+// (operand plane of the activations, of the weights) per product, smallest terms first
+template <int NP> struct PlaneProducts;
+template <> struct PlaneProducts<9> { static constexpr int N = 9; static constexpr int X[9] = {2, 1, 2, 2, 0, 1, 1, 0, 0}, W[9] = {2, 2, 1, 0, 2, 1, 0, 1, 0}; };
+template <> struct PlaneProducts<6> { static constexpr int N = 6; static constexpr int X[6] = {2, 0, 1, 1, 0, 0}, W[6] = {0, 2, 1, 0, 1, 0}; };
+template <> struct PlaneProducts<3> { static constexpr int N = 3; static constexpr int X[3] = {1, 0, 0}, W[3] = {0, 1, 0}; };
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+// one 32x32x16 plane product on the matrix pipe: fp16 operands for NP = 3, bf16 otherwise (same rate, same layout)
+template <int NP>
+__device__ __forceinline__ f32x16 plane_mfma(const u32x4_t& a, const u32x4_t& b, const f32x16& c) {
+    if constexpr (NP == 3) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// two fp32 values -> their packed fp16 planes: h = (rne16(a), rne16(b)), l = (rne16(a - h.lo), rne16(b - h.hi)); v_fma_mix
+// forms each half in one instruction (hipcc's own sequence: a v_cvt_pk, two conversions back and two subtractions per pair)
+__device__ __forceinline__ void cut2h(float a, float b, unsigned& h, unsigned& l) {
+    const float one = 1.f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "v"(one));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "v"(one));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(one), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "v"(one), "v"(h));
+}
+// host/pack side of the same cut (one value): plane 0 / plane 1 of v (already scaled), as fp16 bits
+__device__ __forceinline__ unsigned short pack_h0(float v) { const _Float16 h = (_Float16)v; return __builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ unsigned short pack_h1(float v) { const _Float16 h = (_Float16)v; const _Float16 l = (_Float16)(v - (float)h); return __builtin_bit_cast(unsigned short, l); }
+
+// cut 4 fp32 values into operand planes, 2 packed dwords per plane: NP = 3 -> (h0, h1, -) fp16; else three bf16 planes
+// (truncation: exact)
+template <int NP = 6>
 __device__ __forceinline__ void cut4(const f32x4& x, u32x2_t& ph, u32x2_t& pm, u32x2_t& pl) {
+    if constexpr (NP == 3) {
+        unsigned h0, l0, h1, l1;
+        cut2h(x[0], x[1], h0, l0);
+        cut2h(x[2], x[3], h1, l1);
+        ph = u32x2_t{h0, h1};
+        pm = u32x2_t{l0, l1};
+        pl = u32x2_t{0u, 0u};
+        return;
+    }
     unsigned xu[4], r1u[4], r2u[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -306,13 +359,14 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
 constexpr int S6K = 16;
 constexpr int S6LD = 28;   // dwords per LDS row (112 B)
 
-template <int MW, int NT, bool NORM>
+template <int MW, int NT, bool NORM, int NP = NPD>
 __global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
+    constexpr int PLN = emb_planes<NP>();
     constexpr int NWN = 4 / MW;
     constexpr int BM = MW * 32;
     constexpr int TN = NWN * NT * 32;
     constexpr int XPT = BM / 64;                    // float4 (4 k) per thread per activation step
-    constexpr int WIT = 6 * TN;                     // 16-B weight items per step: 3 planes x TN rows x 2 halves
+    constexpr int WIT = 2 * PLN * TN;               // 16-B weight items per step: planes x TN rows x 2 halves
     constexpr int WPT = (WIT + 255) / 256;
     constexpr int X_TILE = BM * S6LD, W_TILE = TN * S6LD;   // dwords
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -407,11 +461,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
                 v[e] = ok ? v[e] : 0.f;
             }
             u32x2_t ph, pm, pl;
-            cut4(v, ph, pm, pl);
+            cut4<NP>(v, ph, pm, pl);
             unsigned* d = x + (xrow + 64 * i) * S6LD + c4 * 2;
             *reinterpret_cast<u32x2_t*>(d) = ph;
             *reinterpret_cast<u32x2_t*>(d + 8) = pm;
-            *reinterpret_cast<u32x2_t*>(d + 16) = pl;
+            if constexpr (PLN == 3) *reinterpret_cast<u32x2_t*>(d + 16) = pl;
         }
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
@@ -428,23 +482,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
     auto mfmas = [&](int st) {
         const unsigned* x = sX + (st & 1) * X_TILE + wm * 32 * S6LD + frag;
         const unsigned* w = sW + (st & 1) * W_TILE + wn * NT * 32 * S6LD + frag;
-        Frag16 xa[3];
+        Frag16 xa[PLN];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) xa[p].u = *reinterpret_cast<const u32x4_t*>(x + p * 8);
-        Frag16 wb[NT][3];
+        for (int p = 0; p < PLN; ++p) xa[p].u = *reinterpret_cast<const u32x4_t*>(x + p * 8);
+        Frag16 wb[NT][PLN];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) wb[t][p].u = *reinterpret_cast<const u32x4_t*>(w + t * 32 * S6LD + p * 8);
-        // smallest products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h).  The N-tiles ALTERNATE inside each product, so
-        // no MFMA accumulates into the tile the previous one is still writing (a dependent 32x32x16 chain issues every
-        // ~48 cycles instead of 32: MI355X_MICROARCH.md, measured constants)
-        constexpr int PX[6] = {2, 0, 1, 1, 0, 0}, PW[6] = {0, 2, 1, 0, 1, 0};
+            for (int p = 0; p < PLN; ++p) wb[t][p].u = *reinterpret_cast<const u32x4_t*>(w + t * 32 * S6LD + p * 8);
+        // smallest products first (PlaneProducts).  The N-tiles ALTERNATE inside each product, so no MFMA accumulates into
+        // the tile the previous one is still writing (a dependent 32x32x16 chain issues every ~48 cycles instead of 32:
+        // MI355X_MICROARCH.md, measured constants)
+        using PP = PlaneProducts<NP>;
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
+        for (int k = 0; k < PP::N; ++k)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PX[k]].v, wb[t][PW[k]].v, acc[t], 0, 0, 0);
+                acc[t] = plane_mfma<NP>(xa[PP::X[k]].u, wb[t][PP::W[k]].u, acc[t]);
     };
     // step st: [issue loads of st+2 -> the set st's data just left] [MFMAs on LDS buffer st&1] [set of st+1 -> buffer (st+1)&1]
     stage_load(0, ra);
@@ -463,11 +517,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
             __syncthreads();
         }
     }
+    if constexpr (NP == 3) {                        // the weights carry 2^EMB_WSHIFT
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] *= EMB_OSCALE;
+    }
     conv_epilogue<NT>(a, acc, m0 + wm * 32, n0 + wn * NT * 32, HW, l31, hi);
 }
 
-// conv weight [O][I][k][k] -> three truncated bf16 planes [tap][I/16][3][O][16]
-__global__ void k_pack_conv_s6(const float* __restrict__ w, unsigned short* __restrict__ out, int O, int I, int taps) {
+// conv weight [O][I][k][k] -> operand planes [tap][I/16][3][O][16] (the third plane slot stays in the layout for every form):
+// np = 3: two fp16 planes of 2^EMB_WSHIFT w; else three truncated bf16 planes
+__global__ void k_pack_conv_s6(const float* __restrict__ w, unsigned short* __restrict__ out, int O, int I, int taps, int np) {
     const long long total = (long long)O * I * taps;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -475,11 +536,17 @@ __global__ void k_pack_conv_s6(const float* __restrict__ w, unsigned short* __re
         const long long r = i / taps;
         const int ci = (int)(r % I), o = (int)(r / I);
         const float v = w[i];                                   // OIHW: ((o*I + ci)*taps + t)
+        const long long base = ((((long long)t * (I / 16) + ci / 16) * 3) * O + o) * 16 + (ci & 15);
+        if (np == 3) {
+            out[base] = pack_h0(v * EMB_WSCALE);
+            out[base + (long long)O * 16] = pack_h1(v * EMB_WSCALE);
+            out[base + 2LL * O * 16] = 0;
+            continue;
+        }
         const unsigned hb = __float_as_uint(v) & 0xFFFF0000u;
         const float r1 = v - __uint_as_float(hb);
         const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
         const unsigned lb = __float_as_uint(r1 - __uint_as_float(mb));
-        const long long base = ((((long long)t * (I / 16) + ci / 16) * 3) * O + o) * 16 + (ci & 15);
         out[base] = (unsigned short)(hb >> 16);
         out[base + (long long)O * 16] = (unsigned short)(mb >> 16);
         out[base + 2LL * O * 16] = (unsigned short)(lb >> 16);
@@ -590,7 +657,8 @@ struct WinoArgs {
 // the partner wave's output row through LDS (smem must be free: call behind a barrier), raw NHWC
 // store and the (cnt, mean, M2) statistics partials.  acc[p][r] = M[position 8wp+p][slot drow(r,hi)][cout].
 __device__ __forceinline__ void wino_epilogue(const WinoArgs& a, const f32x16 (&acc)[8], float* smem, int lane,
-                                              int wn, int wp, int n0, int img0, int ty0, int tx0, int tpi, int pb) {
+                                              int wn, int wp, int n0, int img0, int ty0, int tx0, int tpi, int pb,
+                                              float oscale = 1.f) {   // oscale: 2^-EMB_WSHIFT for the fp16 form (exact)
     const int l31 = lane & 31, hi = lane >> 5;
     // ---- inverse transform: partial outputs of this wave's two xi rows
     //   ra[xi] = m[xi][0]+m[xi][1]+m[xi][2], rb[xi] = m[xi][1]-m[xi][2]-m[xi][3]
@@ -616,8 +684,8 @@ __device__ __forceinline__ void wino_epilogue(const WinoArgs& a, const f32x16 (&
     float ya[16], yb[16];  // this wave's output row: pixels (oy+wp, ox) and (oy+wp, ox+1)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        ya[r] = (wp == 0 ? y00[r] : y10[r]) + xpr[r];
-        yb[r] = (wp == 0 ? y01[r] : y11[r]) + xpr[16 + r];
+        ya[r] = ((wp == 0 ? y00[r] : y10[r]) + xpr[r]) * oscale;
+        yb[r] = ((wp == 0 ? y01[r] : y11[r]) + xpr[16 + r]) * oscale;
     }
     // ---- raw store + statistics partials
     const int co = n0 + wn * 32 + l31;
@@ -1010,15 +1078,15 @@ __global__ __launch_bounds__(WNN * 128, 2) void k_conv_wino_s3(WinoArgs a) {
             const int pos = xi * 4 + 2 * h;
             u32x2_t ph, pm, pl;
             unsigned* d0 = sV + (pos * WTT + ts) * SVLD + g * 2;
-            cut4(o0, ph, pm, pl);
+            cut4<NP>(o0, ph, pm, pl);
             *reinterpret_cast<u32x2_t*>(d0) = ph;
             *reinterpret_cast<u32x2_t*>(d0 + 8) = pm;
-            *reinterpret_cast<u32x2_t*>(d0 + 16) = pl;
+            if constexpr (emb_planes<NP>() == 3) *reinterpret_cast<u32x2_t*>(d0 + 16) = pl;
             unsigned* d1 = d0 + WTT * SVLD;
-            cut4(o1, ph, pm, pl);
+            cut4<NP>(o1, ph, pm, pl);
             *reinterpret_cast<u32x2_t*>(d1) = ph;
             *reinterpret_cast<u32x2_t*>(d1 + 8) = pm;
-            *reinterpret_cast<u32x2_t*>(d1 + 16) = pl;
+            if constexpr (emb_planes<NP>() == 3) *reinterpret_cast<u32x2_t*>(d1 + 16) = pl;
         }
     };
     // weights, TILED (k_pack_wino_s3, tiled = 1: [Cout/32][C/16][16 pos][3 planes][32 couts][16] bf16 — the 24 fragments a wave
@@ -1029,10 +1097,11 @@ __global__ __launch_bounds__(WNN * 128, 2) void k_conv_wino_s3(WinoArgs a) {
         const_cast<float*>(a.u), 0, (int)((long long)a.C * a.Cout * 96), 0x00020000);
     const int ulane_b = l31 * 32 + hi * 16;
     const int utile_b = (((n0 >> 5) + wn) * nchunks) * (48 * 1024) + (8 * wp) * 3072;   // wave-uniform: cout tile, position half
+    constexpr int PLN = emb_planes<NP>();
     auto uload = [&](int p, int cc, u32x4_t (&w)[3]) {
         const int sb = utile_b + cc * (48 * 1024);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < PLN; ++pl) {
             const int f = p * 3 + pl;                        // fragment inside the wave's 24 KiB of the slab
             w[pl] = __builtin_amdgcn_raw_buffer_load_b128(urs, ulane_b + (f & 3) * 1024, sb + (f >> 2) * 4096, 0);
         }
@@ -1077,7 +1146,7 @@ __global__ __launch_bounds__(WNN * 128, 2) void k_conv_wino_s3(WinoArgs a) {
         Frag vq[2][3];
         if constexpr (VA2) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) vq[0][pl].u = *reinterpret_cast<const u32x4_t*>(sV + vfo + pl * 8);
+            for (int pl = 0; pl < PLN; ++pl) vq[0][pl].u = *reinterpret_cast<const u32x4_t*>(sV + vfo + pl * 8);
         }
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -1085,7 +1154,7 @@ __global__ __launch_bounds__(WNN * 128, 2) void k_conv_wino_s3(WinoArgs a) {
             else if (UC) uload(p + UD - 8, more ? cc + 1 : cc, w[(p + UD) % (UD + 1)]);   // next chunk's first positions
             Frag va[3], wb[3];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < PLN; ++pl) {
                 if constexpr (VA2) {
                     if (p < 7) vq[(p + 1) & 1][pl].u = *reinterpret_cast<const u32x4_t*>(sV + vfo + (p + 1) * WTT * SVLD + pl * 8);
                     va[pl] = vq[p & 1][pl];
@@ -1098,21 +1167,15 @@ __global__ __launch_bounds__(WNN * 128, 2) void k_conv_wino_s3(WinoArgs a) {
             // weight load to just before its use (an s_waitcnt vmcnt(0) in front of each MFMA group: 413 us against 257)
             __builtin_amdgcn_sched_barrier(0);
             if (DSMIL_WEXPT_ON(a, 16)) {   // ablation: no MFMAs (operands kept live)
-                asm volatile("" ::"v"(va[0].u), "v"(va[1].u), "v"(va[2].u), "v"(wb[0].u), "v"(wb[1].u), "v"(wb[2].u));
+                asm volatile("" ::"v"(va[0].u), "v"(va[1].u), "v"(wb[0].u), "v"(wb[1].u));
                 continue;
             }
-            // smallest products first: (l,l) (m,l) (l,m) | (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-            if constexpr (NP == 9) {
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[2].v, acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[2].v, acc[p], 0, 0, 0);
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[1].v, acc[p], 0, 0, 0);
+            // smallest products first (PlaneProducts<NP>)
+            {
+                using PP = PlaneProducts<NP>;
+#pragma unroll
+                for (int k = 0; k < PP::N; ++k) acc[p] = plane_mfma<NP>(va[PP::X[k]].u, wb[PP::W[k]].u, acc[p]);
             }
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2].v, wb[0].v, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[2].v, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[1].v, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1].v, wb[0].v, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[1].v, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0].v, wb[0].v, acc[p], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- raw(cc+1): registers -> LDS (the raw buffer was consumed before the last barrier), then the
@@ -1140,7 +1203,7 @@ __global__ __launch_bounds__(WNN * 128, 2) void k_conv_wino_s3(WinoArgs a) {
         if (keep == 123.456f) a.y[0] = keep;
         return;
     }
-    wino_epilogue(a, acc, smem, lane, wn, wp, n0, img0, ty0, tx0, tpi, pb);
+    wino_epilogue(a, acc, smem, lane, wn, wp, n0, img0, ty0, tx0, tpi, pb, NP == 3 ? EMB_OSCALE : 1.f);
 }
 
 #include "wino_w1.h"        // k_conv_wino_w1: the same unit for one wave per SIMD
@@ -1151,7 +1214,7 @@ __global__ __launch_bounds__(WNN * 128, 2) void k_conv_wino_s3(WinoArgs a) {
 
 // conv weight [O][I][3][3] -> U = G g G^T cut into three bf16 planes: [16 pos][I/16][3][O][16], or (tiled, for
 // k_conv_wino_w1) [O/32][I/16][16 pos][3][32][16]
-__global__ void k_pack_wino_s3(const float* __restrict__ w, unsigned short* __restrict__ out, int O, int I, int tiled) {
+__global__ void k_pack_wino_s3(const float* __restrict__ w, unsigned short* __restrict__ out, int O, int I, int tiled, int np) {
     const long long total = (long long)O * I;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -1175,14 +1238,20 @@ __global__ void k_pack_wino_s3(const float* __restrict__ w, unsigned short* __re
             u4[3] = tmp[xi][2];
             for (int nu = 0; nu < 4; ++nu) {
                 const float v = u4[nu];
-                const unsigned hb = __float_as_uint(v) & 0xFFFF0000u;
-                const float r1 = v - __uint_as_float(hb);
-                const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
-                const unsigned lb = __float_as_uint(r1 - __uint_as_float(mb));
                 const long long base = tiled
                     ? (((((long long)(o >> 5) * (I / 16) + ci / 16) * 16 + (xi * 4 + nu)) * 3) * 32 + (o & 31)) * 16 + (ci & 15)
                     : ((((long long)(xi * 4 + nu) * (I / 16) + ci / 16) * 3) * O + o) * 16 + (ci & 15);
                 const long long pstride = tiled ? 32 * 16 : (long long)O * 16;
+                if (np == 3) {   // two fp16 planes of 2^EMB_WSHIFT U (see PlaneProducts)
+                    out[base] = pack_h0(v * EMB_WSCALE);
+                    out[base + pstride] = pack_h1(v * EMB_WSCALE);
+                    out[base + 2 * pstride] = 0;
+                    continue;
+                }
+                const unsigned hb = __float_as_uint(v) & 0xFFFF0000u;
+                const float r1 = v - __uint_as_float(hb);
+                const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
+                const unsigned lb = __float_as_uint(r1 - __uint_as_float(mb));
                 out[base] = (unsigned short)(hb >> 16);
                 out[base + pstride] = (unsigned short)(mb >> 16);
                 out[base + 2 * pstride] = (unsigned short)(lb >> 16);
@@ -1446,12 +1515,18 @@ constexpr int SS_PPT = (SS_WIN / 2 + 511) / 512;            // window element PA
 constexpr size_t SS_LDS = (size_t)(2 * 3 * SS_WIN + SS_WIMG) * 2;
 
 // conv1 weight [64][3][7][7] -> three truncated bf16 planes [3][64][184], k' = (c*7 + kh)*8 + kw
-__global__ void k_pack_stem_s6(const float* __restrict__ w, unsigned short* __restrict__ out) {
+__global__ void k_pack_stem_s6(const float* __restrict__ w, unsigned short* __restrict__ out, int np) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * SS_LDW; i += gridDim.x * blockDim.x) {
         const int co = i / SS_LDW, k = i - co * SS_LDW;
         const int row = k >> 3, kw = k & 7;
         float v = 0.f;
         if (row < 21 && kw < 7) v = w[co * 147 + (row / 7) * 49 + (row % 7) * 7 + kw];
+        if (np == 3) {   // two fp16 planes of 2^EMB_WSHIFT w (see PlaneProducts)
+            out[i] = pack_h0(v * EMB_WSCALE);
+            out[64 * SS_LDW + i] = pack_h1(v * EMB_WSCALE);
+            out[2 * 64 * SS_LDW + i] = 0;
+            continue;
+        }
         const unsigned hb = __float_as_uint(v) & 0xFFFF0000u;
         const float r1 = v - __uint_as_float(hb);
         const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
@@ -1474,7 +1549,7 @@ __host__ __device__ constexpr int stem6_off(int row) {      // window element of
 // LDS, 32 KB); columns: a lane holds 8 of the 16 (two groups of 4), the 3-wide stride-2 windows need one value from the
 // other half-wave (two shuffles) and, at the left edge, the last column of the previous tile of the walk (a carried register).
 constexpr size_t SS_POOL_LDS = (size_t)8 * 16 * 64 * 4;
-template <bool U8, bool POOL = false>
+template <bool U8, bool POOL = false, int NP = NPD>
 __global__ __launch_bounds__(512, 2) void k_stem_s6(const void* __restrict__ xin, const unsigned short* __restrict__ wimg,
                                                     float* __restrict__ y, float* __restrict__ part, int B, int H, int W,
                                                     int Ho, int Wo, int tiles_x, int tiles_y,
@@ -1524,6 +1599,13 @@ __global__ __launch_bounds__(512, 2) void k_stem_s6(const void* __restrict__ xin
         for (int q = 0; q < SS_PPT; ++q) {
             const int e2 = tid + 512 * q;                   // pair index
             if (2 * e2 < SS_WIN) {
+                if constexpr (NP == 3) {
+                    unsigned h, l;
+                    cut2h(wreg[q][0], wreg[q][1], h, l);
+                    dst[e2] = h;
+                    dst[SS_WIN / 2 + e2] = l;
+                    continue;
+                }
                 unsigned xu[2], r1u[2], r2u[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -1559,22 +1641,26 @@ __global__ __launch_bounds__(512, 2) void k_stem_s6(const void* __restrict__ xin
 #pragma unroll
         for (int st = 0; st < SS_KP / 16; ++st) {
             const int off = hi ? stem6_off(2 * st + 1) : stem6_off(2 * st);
-            Frag16 xa[3], wb[2][3];
+            constexpr int PLN = emb_planes<NP>();
+            Frag16 xa[PLN], wb[2][PLN];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < PLN; ++pl) {
                 const unsigned* a4 = reinterpret_cast<const unsigned*>(win + pl * SS_WIN + off);
                 xa[pl].u = u32x4_t{a4[0], a4[1], a4[2], a4[3]};
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
                     wb[t][pl].u = *reinterpret_cast<const u32x4_t*>(sW + (pl * 64 + t * 32) * SS_LDW + wfrag + st * 16);
             }
-            // smallest products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-            constexpr int PX[6] = {2, 0, 1, 1, 0, 0}, PW[6] = {0, 2, 1, 0, 1, 0};
+            using PP = PlaneProducts<NP>;   // smallest products first
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
+            for (int k = 0; k < PP::N; ++k)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PX[k]].v, wb[t][PW[k]].v, acc[t], 0, 0, 0);
+                    acc[t] = plane_mfma<NP>(xa[PP::X[k]].u, wb[t][PP::W[k]].u, acc[t]);
+        }
+        if constexpr (NP == 3) {                            // the weights carry 2^EMB_WSHIFT
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[0][r] *= EMB_OSCALE; acc[1][r] *= EMB_OSCALE; }
         }
         if (tx + 1 < tiles_x) win_write((tx + 1) & 1);
         // store raw NHWC + statistics partial (cnt, mean, M2) per (image, tile, wave, channel)
@@ -1941,20 +2027,21 @@ inline bool use_wino(const ConvSpec& s) {  // 3x3 stride-1 convs run as Winograd
 #endif
     return !off && s.ks == 3 && s.stride == 1 && s.pad == 1 && s.cin % WK == 0 && s.cout % 64 == 0;
 }
-// Experiment builds: DSMIL_WINO = s6 (default) | s9 | f32: which MFMA form the Winograd convs use (read once per process; the packed
-// weights and the kernels must agree): s6 / s9 = bf16 MFMA over exact three-plane cuts with the 6 largest / all 9
-// plane products, f32 = v_mfma_f32_32x32x2_f32
+// Experiment builds: DSMIL_WINO = h3 (default) | s6 | s9 | f32: which MFMA form the Winograd convs use (read once per process;
+// the packed weights and the kernels must agree): h3 = fp16 MFMA over two-plane cuts, three products (PlaneProducts, round 5);
+// s6 / s9 = bf16 MFMA over exact three-plane cuts with the 6 largest / all 9 plane products; f32 = v_mfma_f32_32x32x2_f32
 inline int wino_form() {
 #ifdef DSMIL_EXPERIMENTS
     static const int form = [] {
         const char* e = getenv("DSMIL_WINO");
         if (e && !strcmp(e, "f32")) return 0;
-        if (e && (!strcmp(e, "s9") || !strcmp(e, "s3"))) return 9;
-        return 6;
+        if (e && !strcmp(e, "s9")) return 9;
+        if (e && !strcmp(e, "s6")) return 6;
+        return NPD;
     }();
     return form;
 #else
-    return 6;   // the product library has one form; the alternatives are selectable in experiment builds only
+    return NPD;   // the product library has one form; the alternatives are selectable in experiment builds only
 #endif
 }
 inline bool wino_s3() { return wino_form() != 0; }
@@ -2009,20 +2096,24 @@ inline unsigned long long* wino_trace_buffer() {
     return buf;
 }
 #endif
-// Experiment builds: DSMIL_CONV = s6 (default) | f32: MFMA form of the DIRECT convs (strided 3x3, 1x1): s6 = bf16 MFMA over exact
-// three-plane cuts, 6 plane products (k_conv_s6; weights cut at pack time), f32 = v_mfma_f32_32x32x2_f32 (k_conv).
-// Read once per process; the packed weights and the kernels must agree.
-inline bool conv_s6() {
+// Experiment builds: DSMIL_CONV = h3 (default) | s6 | f32: MFMA form of the DIRECT convs (strided 3x3, 1x1) and the stem: h3 =
+// fp16 MFMA over two-plane cuts, three products; s6 = bf16 MFMA over exact three-plane cuts, 6 plane products (both k_conv_s6 /
+// k_stem_s6; weights cut at pack time); f32 = v_mfma_f32_32x32x2_f32 (k_conv / k_stem).  Read once per process; the packed
+// weights and the kernels must agree.
+inline int conv_np() {   // plane products of the direct convs (0 = the f32 form)
 #ifdef DSMIL_EXPERIMENTS
-    static const bool on = [] {
+    static const int np = [] {
         const char* e = getenv("DSMIL_CONV");
-        return !(e && !strcmp(e, "f32"));
+        if (e && !strcmp(e, "f32")) return 0;
+        if (e && !strcmp(e, "s6")) return 6;
+        return NPD;
     }();
-    return on;
+    return np;
 #else
-    return true;
+    return NPD;
 #endif
 }
+inline bool conv_s6() { return conv_np() != 0; }
 // floats of conv i in the packed buffer: 16 transform positions for Winograd convs (x 3 bf16 planes = 1.5
 // floats per weight in the s3 form), ks*ks taps otherwise
 inline long long wsize(const Arch& A, int i) {
@@ -2189,10 +2280,12 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
             // +4 KiB: 80 KiB per workgroup, still two per CU), NP = 6 | 9 by DSMIL_WINO
             const size_t lds_ls = lds + 4096;
 #ifdef DSMIL_EXPERIMENTS
-            const bool np9 = wino_form() == 9;
+            const bool np9 = wino_form() == 9, np6 = wino_form() == 6;
 #define DSMIL_IF_NP9 if (np9)
+#define DSMIL_IF_NP6 if (np6)
 #else
-#define DSMIL_IF_NP9 if constexpr (false)   // the product library has the six-product form only: the nine-product kernels are not instantiated
+#define DSMIL_IF_NP9 if constexpr (false)   // the product library has the fp16 three-product form only: the bf16 forms are
+#define DSMIL_IF_NP6 if constexpr (false)   // not instantiated
 #endif
             auto go = [&](auto kern, size_t l) {
                 allow_lds((const void*)kern, l);
@@ -2216,7 +2309,8 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
                 allow_lds((const void*)kern, lds_pp);
                 hipLaunchKernelGGL(kern, grida, dim3(512), lds_pp, st, wa);
             };
-            const int which = wino_expt_kernel();   // DSMIL_WINO_KERNEL = pp | alt | w1
+            int which = wino_expt_kernel();         // DSMIL_WINO_KERNEL = pp | alt | w1
+            if ((which == 1 || which == 2) && !(np9 || np6)) which = 0;   // the two rejected restructurings exist in the bf16 forms only
             const int w1_abl = wa.expt;
             if (which == 3) wa.expt = 0;            // with w1 named explicitly the ablation bits address that kernel only
 #else
@@ -2242,15 +2336,15 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
                 };
 #ifdef DSMIL_EXPERIMENTS
                 switch (w1_abl) {   // DSMIL_WINO_EXPT: compile-time ablations of the w1 kernel (timing only)
-#define W1_ABL(n) case n: if (in_mean) gow1(k_conv_wino_w1<true, 6, n>); else gow1(k_conv_wino_w1<false, 6, n>); break;
+#define W1_ABL(n) case n: if (in_mean) gow1(k_conv_wino_w1<true, NPD, n>); else gow1(k_conv_wino_w1<false, NPD, n>); break;
                     W1_ABL(3) W1_ABL(4) W1_ABL(15) W1_ABL(16) W1_ABL(32) W1_ABL(64) W1_ABL(96) W1_ABL(128) W1_ABL(143)
 #undef W1_ABL
                     default:
-                        if (in_mean) { if (np9) gow1(k_conv_wino_w1<true, 9>); else gow1(k_conv_wino_w1<true, 6>); }
-                        else { if (np9) gow1(k_conv_wino_w1<false, 9>); else gow1(k_conv_wino_w1<false, 6>); }
+                        if (in_mean) { if (np9) gow1(k_conv_wino_w1<true, 9>); else if (np6) gow1(k_conv_wino_w1<true, 6>); else gow1(k_conv_wino_w1<true, NPD>); }
+                        else { if (np9) gow1(k_conv_wino_w1<false, 9>); else if (np6) gow1(k_conv_wino_w1<false, 6>); else gow1(k_conv_wino_w1<false, NPD>); }
                 }
 #else
-                if (in_mean) gow1(k_conv_wino_w1<true, 6>); else gow1(k_conv_wino_w1<false, 6>);
+                if (in_mean) gow1(k_conv_wino_w1<true, NPD>); else gow1(k_conv_wino_w1<false, NPD>);
 #endif
 #ifdef DSMIL_EXPERIMENTS
             } else if (s.cout % 128 == 0 && wino_wide()) {
@@ -2262,18 +2356,22 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
                 };
                 if (in_mean) {
                     if (np9) gow(k_conv_wino_s3<true, WIDE_UD, true, 9, 4, WIDE_UC>, lds_ls);
-                    else gow(k_conv_wino_s3<true, WIDE_UD, true, 6, 4, WIDE_UC>, lds_ls);
+                    else if (np6) gow(k_conv_wino_s3<true, WIDE_UD, true, 6, 4, WIDE_UC>, lds_ls);
+                    else gow(k_conv_wino_s3<true, WIDE_UD, true, NPD, 4, WIDE_UC>, lds_ls);
                 } else {
                     if (np9) gow(k_conv_wino_s3<false, WIDE_UD, false, 9, 4, WIDE_UC>, lds);
-                    else gow(k_conv_wino_s3<false, WIDE_UD, false, 6, 4, WIDE_UC>, lds);
+                    else if (np6) gow(k_conv_wino_s3<false, WIDE_UD, false, 6, 4, WIDE_UC>, lds);
+                    else gow(k_conv_wino_s3<false, WIDE_UD, false, NPD, 4, WIDE_UC>, lds);
                 }
 #endif
             } else if (in_mean) {
                 DSMIL_IF_NP9 go(k_conv_wino_s3<true, 2, true, 9>, lds_ls);
-                else go(k_conv_wino_s3<true, 2, true, 6>, lds_ls);
+                else DSMIL_IF_NP6 go(k_conv_wino_s3<true, 2, true, 6>, lds_ls);
+                else go(k_conv_wino_s3<true, 2, true, NPD>, lds_ls);
             } else {
                 DSMIL_IF_NP9 go(k_conv_wino_s3<false, 2, false, 9>, lds);
-                else go(k_conv_wino_s3<false, 2, false, 6>, lds);
+                else DSMIL_IF_NP6 go(k_conv_wino_s3<false, 2, false, 6>, lds);
+                else go(k_conv_wino_s3<false, 2, false, NPD>, lds);
             }
         }
 #ifdef DSMIL_EXPERIMENTS   // DSMIL_WINO=f32: the f32-MFMA Winograd unit
@@ -2320,13 +2418,23 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
             if (force == 22 && s.cout % 128 == 0) shape = 22;
         }
 #endif
+#ifdef DSMIL_EXPERIMENTS
+        if (conv_np() == 6) {   // DSMIL_CONV=s6: the bf16 three-plane form
+            switch (shape) {
+                case 44: if (norm) go(k_conv_s6<4, 4, true, 6>, 128, 128); else go(k_conv_s6<4, 4, false, 6>, 128, 128); break;
+                case 24: if (norm) go(k_conv_s6<2, 4, true, 6>, 64, 256); else go(k_conv_s6<2, 4, false, 6>, 64, 256); break;
+                case 22: if (norm) go(k_conv_s6<2, 2, true, 6>, 64, 128); else go(k_conv_s6<2, 2, false, 6>, 64, 128); break;
+                default: if (norm) go(k_conv_s6<4, 2, true, 6>, 128, 64); else go(k_conv_s6<4, 2, false, 6>, 128, 64); break;
+            }
+        } else
+#endif
         switch (shape) {
 #ifdef DSMIL_EXPERIMENTS
-            case 44: if (norm) go(k_conv_s6<4, 4, true>, 128, 128); else go(k_conv_s6<4, 4, false>, 128, 128); break;
+            case 44: if (norm) go(k_conv_s6<4, 4, true, NPD>, 128, 128); else go(k_conv_s6<4, 4, false, NPD>, 128, 128); break;
 #endif
-            case 24: if (norm) go(k_conv_s6<2, 4, true>, 64, 256); else go(k_conv_s6<2, 4, false>, 64, 256); break;
-            case 22: if (norm) go(k_conv_s6<2, 2, true>, 64, 128); else go(k_conv_s6<2, 2, false>, 64, 128); break;
-            default: if (norm) go(k_conv_s6<4, 2, true>, 128, 64); else go(k_conv_s6<4, 2, false>, 128, 64); break;
+            case 24: if (norm) go(k_conv_s6<2, 4, true, NPD>, 64, 256); else go(k_conv_s6<2, 4, false, NPD>, 64, 256); break;
+            case 22: if (norm) go(k_conv_s6<2, 2, true, NPD>, 64, 128); else go(k_conv_s6<2, 2, false, NPD>, 64, 128); break;
+            default: if (norm) go(k_conv_s6<4, 2, true, NPD>, 128, 64); else go(k_conv_s6<4, 2, false, NPD>, 128, 64); break;
         }
         dsmil_prof::end(dsmil_prof::CH_CONV, slot, st);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
@@ -2384,7 +2492,7 @@ extern "C" {
 
 int dsmil_resnet_mfma_forms(int32_t* wino_products, int32_t* direct_products) {
     if (wino_products) *wino_products = wino_form();
-    if (direct_products) *direct_products = conv_s6() ? 6 : 0;
+    if (direct_products) *direct_products = conv_np();
     return DSMIL_OK;
 }
 
@@ -2403,7 +2511,7 @@ int dsmil_resnet_pack(int32_t depth, const float* const* conv_w, float* packed, 
     hipStream_t st = (hipStream_t)stream;
     if (!conv_w[0]) return DSMIL_E_INVALID;
     hipLaunchKernelGGL(k_pack_stem_s6, dim3(46), dim3(256), 0, st, conv_w[0],
-                       (unsigned short*)(packed + pack_offset(*A, A->nconv)));
+                       (unsigned short*)(packed + pack_offset(*A, A->nconv)), conv_np());
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     for (int i = 1; i < A->nconv; ++i) {
         if (!conv_w[i]) return DSMIL_E_INVALID;
@@ -2413,7 +2521,7 @@ int dsmil_resnet_pack(int32_t depth, const float* const* conv_w, float* packed, 
             if (blocks > 4096) blocks = 4096;
             if (wino_s3())
                 hipLaunchKernelGGL(k_pack_wino_s3, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
-                                   (unsigned short*)(packed + pack_offset(*A, i)), s.cout, s.cin, wino_tiled() ? 1 : 0);
+                                   (unsigned short*)(packed + pack_offset(*A, i)), s.cout, s.cin, wino_tiled() ? 1 : 0, wino_form());
 #ifdef DSMIL_EXPERIMENTS
             else
                 hipLaunchKernelGGL(k_pack_wino, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
@@ -2425,7 +2533,7 @@ int dsmil_resnet_pack(int32_t depth, const float* const* conv_w, float* packed, 
             if (blocks > 4096) blocks = 4096;
             if (conv_s6())
                 hipLaunchKernelGGL(k_pack_conv_s6, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
-                                   (unsigned short*)(packed + pack_offset(*A, i)), s.cout, s.cin, s.ks * s.ks);
+                                   (unsigned short*)(packed + pack_offset(*A, i)), s.cout, s.cin, s.ks * s.ks, conv_np());
 #ifdef DSMIL_EXPERIMENTS
             else
                 hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)blocks), dim3(256), 0, st, conv_w[i],
@@ -2489,24 +2597,32 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
         // InstanceNorm trunks: the max-pool is fused into the stem (a frozen BatchNorm may have a negative scale, for which
         // the pool needs the window MINIMUM too: that path keeps the raw map + k_norm_relu_maxpool)
         const bool fuse = s6 && !bn_m && stem_fuse();
+        auto stem_go = [&](auto kern, size_t lds_, float* out, float* halo, int Hp_, int Wp_) {
+            allow_lds((const void*)kern, lds_);
+            hipLaunchKernelGGL(kern, dim3((unsigned)ty, (unsigned)B), dim3(512), lds_, st, x_nchw,
+                               (const unsigned short*)(packed + pack_offset(A, A.nconv)), out, part, B, H, W, d.H1, d.W1, tx, ty, halo, Hp_, Wp_);
+        };
+#ifdef DSMIL_EXPERIMENTS
+        const bool stem6 = conv_np() == 6;   // DSMIL_CONV=s6: the bf16 three-plane form
+#else
+        constexpr bool stem6 = false;
+#endif
         if (fuse) {
-            const unsigned short* wimg = (const unsigned short*)(packed + pack_offset(A, A.nconv));
-            const size_t ldsp = SS_LDS + SS_POOL_LDS;
-            allow_lds((const void*)k_stem_s6<true, true>, ldsp);
-            allow_lds((const void*)k_stem_s6<false, true>, ldsp);
             // the pooled raw map goes straight to the max-pool's destination; the raw-map region holds the halo rows
-            if (u8) hipLaunchKernelGGL((k_stem_s6<true, true>), dim3((unsigned)ty, (unsigned)B), dim3(512), ldsp, st, x_nchw, wimg,
-                                       buf[0], part, B, H, W, d.H1, d.W1, tx, ty, y0, d.Hp, d.Wp);
-            else hipLaunchKernelGGL((k_stem_s6<false, true>), dim3((unsigned)ty, (unsigned)B), dim3(512), ldsp, st, x_nchw, wimg,
-                                    buf[0], part, B, H, W, d.H1, d.W1, tx, ty, y0, d.Hp, d.Wp);
+            const size_t ldsp = SS_LDS + SS_POOL_LDS;
+            if (stem6) {
+#ifdef DSMIL_EXPERIMENTS
+                if (u8) stem_go(k_stem_s6<true, true, 6>, ldsp, buf[0], y0, d.Hp, d.Wp); else stem_go(k_stem_s6<false, true, 6>, ldsp, buf[0], y0, d.Hp, d.Wp);
+#endif
+            } else if (u8) stem_go(k_stem_s6<true, true, NPD>, ldsp, buf[0], y0, d.Hp, d.Wp);
+            else stem_go(k_stem_s6<false, true, NPD>, ldsp, buf[0], y0, d.Hp, d.Wp);
         } else if (s6) {
-            const unsigned short* wimg = (const unsigned short*)(packed + pack_offset(A, A.nconv));
-            allow_lds((const void*)k_stem_s6<true>, SS_LDS);
-            allow_lds((const void*)k_stem_s6<false>, SS_LDS);
-            if (u8) hipLaunchKernelGGL(k_stem_s6<true>, dim3((unsigned)ty, (unsigned)B), dim3(512), SS_LDS, st, x_nchw, wimg, y0,
-                                       part, B, H, W, d.H1, d.W1, tx, ty);
-            else hipLaunchKernelGGL(k_stem_s6<false>, dim3((unsigned)ty, (unsigned)B), dim3(512), SS_LDS, st, x_nchw, wimg, y0,
-                                    part, B, H, W, d.H1, d.W1, tx, ty);
+            if (stem6) {
+#ifdef DSMIL_EXPERIMENTS
+                if (u8) stem_go(k_stem_s6<true, false, 6>, SS_LDS, y0, nullptr, 0, 0); else stem_go(k_stem_s6<false, false, 6>, SS_LDS, y0, nullptr, 0, 0);
+#endif
+            } else if (u8) stem_go(k_stem_s6<true, false, NPD>, SS_LDS, y0, nullptr, 0, 0);
+            else stem_go(k_stem_s6<false, false, NPD>, SS_LDS, y0, nullptr, 0, 0);
         }
 #ifdef DSMIL_EXPERIMENTS   // DSMIL_CONV=f32
         else if (u8) hipLaunchKernelGGL(k_stem<true>, dim3((unsigned)ty, (unsigned)B), dim3(256), 0, st, x_nchw, conv1_w, y0,

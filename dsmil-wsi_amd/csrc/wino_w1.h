@@ -38,6 +38,7 @@ __device__ __forceinline__ f32x4 w1_sub4(const f32x4& x, const f32x4& y) { retur
 template <bool NORM, int NP = 6, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
     constexpr int NT = 256;
+    constexpr int PLN = emb_planes<NP>();               // operand planes: 2 (fp16 form, NP = 3) or 3 (bf16 forms)
     constexpr int RPT = (WRAW_MAX * 4 + NT - 1) / NT;   // raw float4 per thread per chunk (4)
     constexpr int R_DW = WRAW_MAX * SRLD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -157,15 +158,15 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
         for (int e = 0; e < 4; ++e) Y[e] = __builtin_fmaf(sz, Tz[e], T[1][e]);
         u32x2_t ph, pm, pl;
         unsigned* dX = vdst + ((xi * 4 + nuX) * WTT + ts) * SVLD + g * 2;
-        cut4(X, ph, pm, pl);
+        cut4<NP>(X, ph, pm, pl);
         *reinterpret_cast<u32x2_t*>(dX) = ph;
         *reinterpret_cast<u32x2_t*>(dX + 8) = pm;
-        *reinterpret_cast<u32x2_t*>(dX + 16) = pl;
+        if constexpr (PLN == 3) *reinterpret_cast<u32x2_t*>(dX + 16) = pl;
         unsigned* dY = vdst + ((xi * 4 + nuY) * WTT + ts) * SVLD + g * 2;
-        cut4(Y, ph, pm, pl);
+        cut4<NP>(Y, ph, pm, pl);
         *reinterpret_cast<u32x2_t*>(dY) = ph;
         *reinterpret_cast<u32x2_t*>(dY + 8) = pm;
-        *reinterpret_cast<u32x2_t*>(dY + 16) = pl;
+        if constexpr (PLN == 3) *reinterpret_cast<u32x2_t*>(dY + 16) = pl;
     };
     // ---- weights, TILED for this kernel (k_pack_wino_s3, tiled = 1): [Cout/32][C/16][16 pos][3 planes][32 couts][16] bf16 —
     // the 48 fragments a wave needs for one chunk are 48 consecutive KiB.  Buffer loads: one resource for the tensor, the
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < PLN; ++pl) {
                 const int f = (2 * P + j) * 3 + pl;
                 w[j][pl].u = __builtin_amdgcn_raw_buffer_load_b128(urs, ulane_b + (f & 3) * 1024, sbase + (f >> 2) * 4096, 0);
             }
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) v[j][pl].u = *reinterpret_cast<const u32x4_t*>(b + j * WTT * SVLD + pl * 8);
+            for (int pl = 0; pl < PLN; ++pl) v[j][pl].u = *reinterpret_cast<const u32x4_t*>(b + j * WTT * SVLD + pl * 8);
     };
 
 #ifdef DSMIL_TRACE
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
 #endif
             Frag (&va)[2][3] = vq[P & 1];
             Frag (&wb)[2][3] = uw[P & 3];
-            constexpr int PV9[9] = {2, 1, 2, 2, 0, 1, 1, 0, 0}, PW9[9] = {2, 2, 1, 0, 2, 1, 0, 1, 0};
+            using PP = PlaneProducts<NP>;
             // half a transform row: xi = P / 2; outputs X = T0 - T2 (even blocks) or Y = T1 + sz Tz (odd blocks),
             // T_c = (B^T d)[xi][c] = Ra[c] +- Rb[c]:  xi 0: R0 - R2,  1: R1 + R2,  2: R2 - R1,  3: R1 - R3
             constexpr int xi = P >> 1;
@@ -301,16 +302,22 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
             f32x4 qx, mu, rs;                              // a raw float4 on its way to LDS
             auto step = [&](auto Ic) {
                 constexpr int I = decltype(Ic)::value;
-                constexpr int k = 9 - NP + I / 2, j = I & 1;
-                if constexpr (!(ABL & 16))
-                    acc[2 * P + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[j][PV9[k]].v, wb[j][PW9[k]].v, acc[2 * P + j], 0, 0, 0);
-                else asm volatile("" ::"v"(va[j][PV9[k]].u), "v"(wb[j][PW9[k]].u));
+                // MFMA slots: 2 NP per pair-block, the two positions alternating (no MFMA waits for the one before).  NP = 6 / 9:
+                // one per step (12 / 18 steps).  NP = 3 (fp16 form): six MFMAs in the block's twelve steps — steps 0 1, 4 5, 8 9 —
+                // so that the pieces of the other work still sit between MFMAs
+                constexpr bool has_mfma = NP == 3 ? (I % 4) < 2 : true;
+                constexpr int k = NP == 3 ? I / 4 : I / 2, j = I & 1;
+                if constexpr (has_mfma) {
+                    if constexpr (!(ABL & 16))
+                        acc[2 * P + j] = plane_mfma<NP>(va[j][PP::X[k]].u, wb[j][PP::W[k]].u, acc[2 * P + j]);
+                    else asm volatile("" ::"v"(va[j][PP::X[k]].u), "v"(wb[j][PP::W[k]].u));
+                }
                 // every block: weight fragments of the pair two blocks ahead; V fragments of the next pair in two halves
                 if constexpr (I == 0 && !(ABL & 4)) uload_pair((P + 2) & 7, cc + ((P + 2) >> 3), uw[(P + 2) & 3]);
                 if constexpr ((I == 8 || I == 9) && !(ABL & 8) && P < 7) {
                     const unsigned* b = sV + buf * SV_DW + vfo + (2 * (P + 1) + (I - 8)) * WTT * SVLD;
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) vq[(P + 1) & 1][I - 8][pl].u = *reinterpret_cast<const u32x4_t*>(b + pl * 8);
+                    for (int pl = 0; pl < PLN; ++pl) vq[(P + 1) & 1][I - 8][pl].u = *reinterpret_cast<const u32x4_t*>(b + pl * 8);
                 }
                 if constexpr (!(ABL & 1)) {                 // transform(c+1), half row
                     if constexpr (I == 1) {
@@ -331,15 +338,24 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
                             for (int e = 0; e < 4; ++e) O[e] = __builtin_fmaf(sz, Tb[e], Ta[e]);
                         }
                     }
-                    if constexpr (I == 6) {
+                    if constexpr (NP == 3) {                // fp16 form: two v_fma_mix per value, the planes come out packed
+                        if constexpr (I == 6) cut2h(O[0], O[1], u_[0], r1_[0]);
+                        if constexpr (I == 7) cut2h(O[2], O[3], u_[1], r1_[1]);
+                        if constexpr (I == 10) {
+                            unsigned* d = vnext + ((xi * 4 + (isY ? nuY : nuX)) * WTT + ts) * SVLD + g * 2;
+                            *reinterpret_cast<u32x2_t*>(d) = u32x2_t{u_[0], u_[1]};
+                            *reinterpret_cast<u32x2_t*>(d + 8) = u32x2_t{r1_[0], r1_[1]};
+                        }
+                    }
+                    if constexpr (NP != 3 && I == 6) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { u_[e] = __float_as_uint(O[e]); r1_[e] = __float_as_uint(O[e] - __uint_as_float(u_[e] & 0xFFFF0000u)); }
                     }
-                    if constexpr (I == 7) {
+                    if constexpr (NP != 3 && I == 7) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) r2_[e] = __float_as_uint(__uint_as_float(r1_[e]) - __uint_as_float(r1_[e] & 0xFFFF0000u));
                     }
-                    if constexpr (I == 10) {
+                    if constexpr (NP != 3 && I == 10) {
                         u32x2_t ph, pm, pl;
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
@@ -446,6 +462,9 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
         yb[0][r] = (rb[0] + rb[1]) + rb[2];
         ya[1][r] = (-ra[2] - ra[3]) + ra[1];
         yb[1][r] = (-rb[2] - rb[3]) + rb[1];
+        if constexpr (NP == 3) {                            // the weights carry 2^EMB_WSHIFT (exact to undo)
+            ya[0][r] *= EMB_OSCALE; yb[0][r] *= EMB_OSCALE; ya[1][r] *= EMB_OSCALE; yb[1][r] *= EMB_OSCALE;
+        }
     }
     const long long rowstep = (long long)a.W * a.Cout;
 #pragma unroll

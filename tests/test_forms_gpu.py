@@ -1,5 +1,6 @@
-"""Every selectable MFMA form stays parity-green: the default suite runs the default forms (aggregator
-query MLP and Winograd convs on bf16 MFMA over exact three-plane cuts); this file re-runs a small
+"""Every selectable MFMA form stays parity-green: the default suite runs the default forms (aggregator query MLP of a lone bag on
+bf16 MFMA over exact three-plane cuts, six products; batches and — since round 5 — every conv of the embedder on fp16 MFMA over
+two-plane cuts, three products); this file re-runs a small
 aggregator + embedder check in subprocesses with the alternatives selected.  The product library has ONE form; the
 knobs (read once per process: DSMIL_MLP=f32 / s9, DSMIL_WINO=f32 / s9, DSMIL_CONV=f32) exist in the experiment build
 only (libdsmil_hip_expt.so, built by __graft_entry__.build() next to the product library)."""
@@ -14,12 +15,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 @pytest.mark.parametrize("env,form", [({"DSMIL_MLP": "f32", "DSMIL_WINO": "f32", "DSMIL_CONV": "f32"}, 0),
-                                      ({"DSMIL_MLP": "s9", "DSMIL_WINO": "s9"}, 9), ({}, 6)])
+                                      ({"DSMIL_MLP": "s9", "DSMIL_WINO": "s9"}, 9),
+                                      ({"DSMIL_WINO": "s6", "DSMIL_CONV": "s6", "DSMIL_FORM_CHECK_LIB": "expt"}, 6),   # the embedder's round 2-4 form
+                                      ({}, 6)])
 def test_alternative_mfma_forms(env, form):
     e = dict(os.environ)
     for k in ("DSMIL_MLP", "DSMIL_WINO", "DSMIL_CONV"):
         e.pop(k, None)
     e.update(env)
+    e.pop("DSMIL_FORM_CHECK_LIB", None)
     if env:   # alternative forms live in the experiment build
         lib = os.path.join(os.path.dirname(HERE), "dsmil-wsi_amd", "libdsmil_hip_expt.so")
         assert os.path.exists(lib), "python dsmil-wsi_amd/build.py --variant expt -DDSMIL_EXPERIMENTS (done by __graft_entry__.build())"

@@ -9,7 +9,7 @@ import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
-MASKS = [("full", 0), ("variant: nt feature loads", 64), ("variant: weights 7 ahead", 128), ("variant: both", 192), ("no_weight_loads", 1), ("no_feature_loads", 2), ("no_mfma", 4), ("no_value_sum", 8),
+MASKS = [("full", 0), ("variant: nt feature loads", 64), ("variant: weights 7 ahead", 128), ("variant: both", 192), ("variant: refill per two cuts", 256), ("no_weight_loads", 1), ("no_feature_loads", 2), ("no_mfma", 4), ("no_value_sum", 8),
          ("no_cut", 16), ("no_w_no_x", 3), ("no_w_x_mfma", 7), ("nothing", 31)]
 
 
