@@ -95,7 +95,7 @@ ACT_BYTES_PER_PATCH = (3 * 224 * 224 * 4 + 112 * 112 * 64 * 4          # stem
                              for p, h in ((56, 28), (28, 14), (14, 7))))           # 3 stride-1 convs, 2 residual kernels
 
 
-KERNEL_TABLE = "r04_kernel_table.json"   # the latest committed per-kernel table (tools/kernel_table.py)
+KERNEL_TABLE = "r05_kernel_table.json"   # the latest committed per-kernel table (tools/kernel_table.py)
 
 
 def _kernel_table(leg):
@@ -542,8 +542,11 @@ def embedder_leg(cx):
                        "distinct_batches": len(xs),
                        "parity": "unpinned (torchvision absent, the reference ships no embedder vectors); two independent restatements",
                        "collective": "all_gather_into_tensor([%d,512] f32) per pass, %d rank(s)" % (Bp, world) if cx.collectives else "none"},
-            "roofline": {"kernel": "conv kernels of one forward: 9 x k_conv_wino_w1 + 4 x k_conv_wino_s3 (Winograd F(2x2,3x3), bf16 "
-                                   "MFMA over exact 3-plane cuts) + 6 direct convs", "bound": "mfma",
+            "roofline": {"kernel": "conv kernels of one forward: 9 x k_conv_wino_w1 + 4 x k_conv_wino_s3 (Winograd F(2x2,3x3)) + 6 direct "
+                                   "convs, all on %s" % ({3: "fp16 MFMA over two-plane cuts, 3 plane products per fp32 MAC",
+                                                           6: "bf16 MFMA over exact 3-plane cuts, 6 plane products",
+                                                           9: "bf16 MFMA over exact 3-plane cuts, 9 plane products",
+                                                           0: "f32 MFMA"}.get(wino_np, "?")), "bound": "mfma",
                          # algorithmic (direct-form) rate of the conv kernels; NOT compared with a peak: Winograd does
                          # 2.25x fewer multiplies than the direct form, so this rate may exceed the f32 MFMA peak
                          "achieved": round(ach, 2) if ach else None, "unit": "TFLOP/s",

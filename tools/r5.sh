@@ -43,6 +43,11 @@ pmc_fused)
     n=$(echo $c | tr ' ' '_' | cut -c1-40)
     (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -f csv -d $OUT/pmc_fused_$n -o p -- python $R/tools/train_fused.py 1 60 > $OUT/pmc_fused_$n.log 2>&1)
   done; find $OUT -name "*counter_collection.csv" | head;;
+pmc_single)
+  for c in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
+    n=$(echo $c | tr ' ' '_' | cut -c1-40)
+    (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -f csv -d $OUT/pmc_single_$n -o p -- python $R/tools/single_bag.py c16 > $OUT/pmc_single_$n.log 2>&1)
+  done; find $OUT -name "*counter_collection.csv" | head;;
 pmc_agg|pmc_emb)
   W=aggregator,aggregator_bf16; [ $stage = pmc_emb ] && W=embedder
   for c in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
