@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
                 // MFMA slots: 2 NP per pair-block, the two positions alternating (no MFMA waits for the one before).  NP = 6 / 9:
                 // one per step (12 / 18 steps).  NP = 3 (fp16 form): six MFMAs in the block's twelve steps — steps 0 1, 4 5, 8 9 —
                 // so that the pieces of the other work still sit between MFMAs
+                // (an MFMA behind every OTHER step instead — 0 2 4 .. 10 — measured the same: 63.2 k against 62.6 k patches/s)
                 constexpr bool has_mfma = NP == 3 ? (I % 4) < 2 : true;
                 constexpr int k = NP == 3 ? I / 4 : I / 2, j = I & 1;
                 if constexpr (has_mfma) {
