@@ -45,6 +45,9 @@ def build_parser():
                    help="new, default off: drop background tiles before embedding — keep a tile iff mean(FIND_EDGES band sums) / "
                         "tile_size^2 > T, the criterion deepzoom_tiler.py:56-61 applies while tiling (its -t, 15); "
                         "single-magnification bags only")
+    p.add_argument("--precision", default="fp32", choices=("fp32", "half"),
+                   help="(new, default fp32 = the parity path) half: the native trunk rounds every conv operand to one fp16 "
+                        "plane (f32 accumulation, fp32 norms): ~2e-3 feature error, faster; the reference has no such switch")
     p.add_argument("--save_npy", action="store_true",
                    help="(new) also write each bag's features as float32 <bag>.npy next to the '%%.4f' CSV: lossless "
                         "and ~6x smaller/faster to load than the text detour of compute_feats.py:80-82")
@@ -91,6 +94,7 @@ def main(argv=None):
     if args.magnification == "tree" and args.weights_high is not None and args.weights_low is not None:
         ic_h = mil.IClassifier(resnet, num_feats, output_class=args.num_classes).to(device)
         ic_l = mil.IClassifier(copy.deepcopy(resnet), num_feats, output_class=args.num_classes).to(device)
+        ic_h.embed_precision = ic_l.embed_precision = args.precision
         if imagenet:
             print("Use ImageNet features.")
         else:
@@ -98,6 +102,7 @@ def main(argv=None):
             load_embedder(ic_l, args.weights_low, "embedder-low.pth", args, device)
     else:
         i_classifier = mil.IClassifier(resnet, num_feats, output_class=args.num_classes).to(device)
+        i_classifier.embed_precision = args.precision
         if imagenet:
             print("Use ImageNet features.")
         else:

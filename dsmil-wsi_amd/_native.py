@@ -109,6 +109,11 @@ SIGNATURES = {
                                             ctypes.c_int32, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                             c_f32p, ctypes.c_int32, c_f32p, c_f32p, ctypes.c_void_p,
                                             ctypes.c_size_t, ctypes.c_void_p]),
+    "dsmil_resnet_pack_ex": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), c_f32p, ctypes.c_int32, ctypes.c_void_p]),
+    "dsmil_resnet_forward_ex": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                               ctypes.c_int32, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                               c_f32p, ctypes.c_int32, c_f32p, c_f32p, ctypes.c_void_p,
+                                               ctypes.c_size_t, ctypes.c_int32, ctypes.c_void_p]),
     "dsmil_tile_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                         ctypes.c_void_p]),
     "dsmil_fc_forward": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,

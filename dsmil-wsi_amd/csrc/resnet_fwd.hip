@@ -77,18 +77,22 @@ typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 constexpr int NPD = 3;                        // the product library's form
 constexpr int EMB_WSHIFT = 8;
 constexpr float EMB_WSCALE = 256.f, EMB_OSCALE = 1.f / 256.f;
-template <int NP> __host__ __device__ constexpr int emb_planes() { return NP == 3 ? 2 : 3; }
+//   1      fp16 x 1 plane (RNE), one product: the OPT-IN reduced-precision path (dsmil_resnet_forward_ex, precision = 1):
+//          operands rounded to 11 significand bits, f32 accumulation, fp32 activations / InstanceNorm between the layers
+template <int NP> __host__ __device__ constexpr int emb_planes() { return NP == 1 ? 1 : (NP == 3 ? 2 : 3); }
+template <int NP> __host__ __device__ constexpr bool emb_f16() { return NP == 3 || NP == 1; }
 // (operand plane of the activations, of the weights) per product, smallest terms first
 template <int NP> struct PlaneProducts;
 template <> struct PlaneProducts<9> { static constexpr int N = 9; static constexpr int X[9] = {2, 1, 2, 2, 0, 1, 1, 0, 0}, W[9] = {2, 2, 1, 0, 2, 1, 0, 1, 0}; };
 template <> struct PlaneProducts<6> { static constexpr int N = 6; static constexpr int X[6] = {2, 0, 1, 1, 0, 0}, W[6] = {0, 2, 1, 0, 1, 0}; };
 template <> struct PlaneProducts<3> { static constexpr int N = 3; static constexpr int X[3] = {1, 0, 0}, W[3] = {0, 1, 0}; };
+template <> struct PlaneProducts<1> { static constexpr int N = 1; static constexpr int X[1] = {0}, W[1] = {0}; };
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 // one 32x32x16 plane product on the matrix pipe: fp16 operands for NP = 3, bf16 otherwise (same rate, same layout)
 template <int NP>
 __device__ __forceinline__ f32x16 plane_mfma(const u32x4_t& a, const u32x4_t& b, const f32x16& c) {
-    if constexpr (NP == 3) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    if constexpr (emb_f16<NP>()) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
@@ -107,8 +111,21 @@ __device__ __forceinline__ unsigned short pack_h1(float v) { const _Float16 h = 
 
 // cut 4 fp32 values into operand planes, 2 packed dwords per plane: NP = 3 -> (h0, h1, -) fp16; else three bf16 planes
 // (truncation: exact)
+__device__ __forceinline__ unsigned cut2h1(float a, float b) {   // one plane: (rne16(a), rne16(b))
+    unsigned h;
+    const float one = 1.f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "v"(one));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "v"(one));
+    return h;
+}
 template <int NP = 6>
 __device__ __forceinline__ void cut4(const f32x4& x, u32x2_t& ph, u32x2_t& pm, u32x2_t& pl) {
+    if constexpr (NP == 1) {
+        ph = u32x2_t{cut2h1(x[0], x[1]), cut2h1(x[2], x[3])};
+        pm = u32x2_t{0u, 0u};
+        pl = u32x2_t{0u, 0u};
+        return;
+    }
     if constexpr (NP == 3) {
         unsigned h0, l0, h1, l1;
         cut2h(x[0], x[1], h0, l0);
@@ -464,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
             cut4<NP>(v, ph, pm, pl);
             unsigned* d = x + (xrow + 64 * i) * S6LD + c4 * 2;
             *reinterpret_cast<u32x2_t*>(d) = ph;
-            *reinterpret_cast<u32x2_t*>(d + 8) = pm;
+            if constexpr (PLN >= 2) *reinterpret_cast<u32x2_t*>(d + 8) = pm;
             if constexpr (PLN == 3) *reinterpret_cast<u32x2_t*>(d + 16) = pl;
         }
 #pragma unroll
@@ -517,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_s6(ConvArgs a) {
             __syncthreads();
         }
     }
-    if constexpr (NP == 3) {                        // the weights carry 2^EMB_WSHIFT
+    if constexpr (emb_f16<NP>()) {                  // the weights carry 2^EMB_WSHIFT
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -537,9 +554,9 @@ __global__ void k_pack_conv_s6(const float* __restrict__ w, unsigned short* __re
         const int ci = (int)(r % I), o = (int)(r / I);
         const float v = w[i];                                   // OIHW: ((o*I + ci)*taps + t)
         const long long base = ((((long long)t * (I / 16) + ci / 16) * 3) * O + o) * 16 + (ci & 15);
-        if (np == 3) {
+        if (np == 3 || np == 1) {
             out[base] = pack_h0(v * EMB_WSCALE);
-            out[base + (long long)O * 16] = pack_h1(v * EMB_WSCALE);
+            out[base + (long long)O * 16] = np == 3 ? pack_h1(v * EMB_WSCALE) : (unsigned short)0;
             out[base + 2LL * O * 16] = 0;
             continue;
         }
@@ -1080,12 +1097,12 @@ __global__ __launch_bounds__(WNN * 128, 2) void k_conv_wino_s3(WinoArgs a) {
             unsigned* d0 = sV + (pos * WTT + ts) * SVLD + g * 2;
             cut4<NP>(o0, ph, pm, pl);
             *reinterpret_cast<u32x2_t*>(d0) = ph;
-            *reinterpret_cast<u32x2_t*>(d0 + 8) = pm;
+            if constexpr (emb_planes<NP>() >= 2) *reinterpret_cast<u32x2_t*>(d0 + 8) = pm;
             if constexpr (emb_planes<NP>() == 3) *reinterpret_cast<u32x2_t*>(d0 + 16) = pl;
             unsigned* d1 = d0 + WTT * SVLD;
             cut4<NP>(o1, ph, pm, pl);
             *reinterpret_cast<u32x2_t*>(d1) = ph;
-            *reinterpret_cast<u32x2_t*>(d1 + 8) = pm;
+            if constexpr (emb_planes<NP>() >= 2) *reinterpret_cast<u32x2_t*>(d1 + 8) = pm;
             if constexpr (emb_planes<NP>() == 3) *reinterpret_cast<u32x2_t*>(d1 + 16) = pl;
         }
     };
@@ -1167,7 +1184,7 @@ __global__ __launch_bounds__(WNN * 128, 2) void k_conv_wino_s3(WinoArgs a) {
             // weight load to just before its use (an s_waitcnt vmcnt(0) in front of each MFMA group: 413 us against 257)
             __builtin_amdgcn_sched_barrier(0);
             if (DSMIL_WEXPT_ON(a, 16)) {   // ablation: no MFMAs (operands kept live)
-                asm volatile("" ::"v"(va[0].u), "v"(va[1].u), "v"(wb[0].u), "v"(wb[1].u));
+                asm volatile("" ::"v"(va[0].u), "v"(wb[0].u));
                 continue;
             }
             // smallest products first (PlaneProducts<NP>)
@@ -1203,7 +1220,7 @@ __global__ __launch_bounds__(WNN * 128, 2) void k_conv_wino_s3(WinoArgs a) {
         if (keep == 123.456f) a.y[0] = keep;
         return;
     }
-    wino_epilogue(a, acc, smem, lane, wn, wp, n0, img0, ty0, tx0, tpi, pb, NP == 3 ? EMB_OSCALE : 1.f);
+    wino_epilogue(a, acc, smem, lane, wn, wp, n0, img0, ty0, tx0, tpi, pb, emb_f16<NP>() ? EMB_OSCALE : 1.f);
 }
 
 #include "wino_w1.h"        // k_conv_wino_w1: the same unit for one wave per SIMD
@@ -1242,9 +1259,9 @@ __global__ void k_pack_wino_s3(const float* __restrict__ w, unsigned short* __re
                     ? (((((long long)(o >> 5) * (I / 16) + ci / 16) * 16 + (xi * 4 + nu)) * 3) * 32 + (o & 31)) * 16 + (ci & 15)
                     : ((((long long)(xi * 4 + nu) * (I / 16) + ci / 16) * 3) * O + o) * 16 + (ci & 15);
                 const long long pstride = tiled ? 32 * 16 : (long long)O * 16;
-                if (np == 3) {   // two fp16 planes of 2^EMB_WSHIFT U (see PlaneProducts)
+                if (np == 3 || np == 1) {   // two (one) fp16 planes of 2^EMB_WSHIFT U (see PlaneProducts)
                     out[base] = pack_h0(v * EMB_WSCALE);
-                    out[base + pstride] = pack_h1(v * EMB_WSCALE);
+                    out[base + pstride] = np == 3 ? pack_h1(v * EMB_WSCALE) : (unsigned short)0;
                     out[base + 2 * pstride] = 0;
                     continue;
                 }
@@ -1521,9 +1538,9 @@ __global__ void k_pack_stem_s6(const float* __restrict__ w, unsigned short* __re
         const int row = k >> 3, kw = k & 7;
         float v = 0.f;
         if (row < 21 && kw < 7) v = w[co * 147 + (row / 7) * 49 + (row % 7) * 7 + kw];
-        if (np == 3) {   // two fp16 planes of 2^EMB_WSHIFT w (see PlaneProducts)
+        if (np == 3 || np == 1) {   // two (one) fp16 planes of 2^EMB_WSHIFT w (see PlaneProducts)
             out[i] = pack_h0(v * EMB_WSCALE);
-            out[64 * SS_LDW + i] = pack_h1(v * EMB_WSCALE);
+            out[64 * SS_LDW + i] = np == 3 ? pack_h1(v * EMB_WSCALE) : (unsigned short)0;
             out[2 * 64 * SS_LDW + i] = 0;
             continue;
         }
@@ -1599,6 +1616,10 @@ __global__ __launch_bounds__(512, 2) void k_stem_s6(const void* __restrict__ xin
         for (int q = 0; q < SS_PPT; ++q) {
             const int e2 = tid + 512 * q;                   // pair index
             if (2 * e2 < SS_WIN) {
+                if constexpr (NP == 1) {
+                    dst[e2] = cut2h1(wreg[q][0], wreg[q][1]);
+                    continue;
+                }
                 if constexpr (NP == 3) {
                     unsigned h, l;
                     cut2h(wreg[q][0], wreg[q][1], h, l);
@@ -1658,7 +1679,7 @@ __global__ __launch_bounds__(512, 2) void k_stem_s6(const void* __restrict__ xin
                 for (int t = 0; t < 2; ++t)
                     acc[t] = plane_mfma<NP>(xa[PP::X[k]].u, wb[t][PP::W[k]].u, acc[t]);
         }
-        if constexpr (NP == 3) {                            // the weights carry 2^EMB_WSHIFT
+        if constexpr (emb_f16<NP>()) {                      // the weights carry 2^EMB_WSHIFT
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[0][r] *= EMB_OSCALE; acc[1][r] *= EMB_OSCALE; }
         }
@@ -2030,7 +2051,16 @@ inline bool use_wino(const ConvSpec& s) {  // 3x3 stride-1 convs run as Winograd
 // Experiment builds: DSMIL_WINO = h3 (default) | s6 | s9 | f32: which MFMA form the Winograd convs use (read once per process;
 // the packed weights and the kernels must agree): h3 = fp16 MFMA over two-plane cuts, three products (PlaneProducts, round 5);
 // s6 / s9 = bf16 MFMA over exact three-plane cuts with the 6 largest / all 9 plane products; f32 = v_mfma_f32_32x32x2_f32
+// dsmil_resnet_pack_ex / dsmil_resnet_forward_ex with precision = 1 (the opt-in reduced-precision path): the form of THIS call on
+// THIS host thread; 0 = the process form below
+thread_local int g_form_override = 0;
+struct FormOverride {
+    int saved;
+    explicit FormOverride(int np) : saved(g_form_override) { g_form_override = np; }
+    ~FormOverride() { g_form_override = saved; }
+};
 inline int wino_form() {
+    if (g_form_override) return g_form_override;
 #ifdef DSMIL_EXPERIMENTS
     static const int form = [] {
         const char* e = getenv("DSMIL_WINO");
@@ -2101,6 +2131,7 @@ inline unsigned long long* wino_trace_buffer() {
 // k_stem_s6; weights cut at pack time); f32 = v_mfma_f32_32x32x2_f32 (k_conv / k_stem).  Read once per process; the packed
 // weights and the kernels must agree.
 inline int conv_np() {   // plane products of the direct convs (0 = the f32 form)
+    if (g_form_override) return g_form_override;
 #ifdef DSMIL_EXPERIMENTS
     static const int np = [] {
         const char* e = getenv("DSMIL_CONV");
@@ -2291,6 +2322,7 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
                 allow_lds((const void*)kern, l);
                 hipLaunchKernelGGL(kern, grid, dim3(256), l, st, wa);
             };
+            const bool half1 = wino_form() == 1;   // the opt-in one-plane path (dsmil_resnet_forward_ex)
 #ifdef DSMIL_EXPERIMENTS
             static const int ncu = [] {
                 int dev = 0, n = 0;
@@ -2316,7 +2348,18 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
 #else
             constexpr int which = 0;
 #endif
-            if (which == 1) {
+            if (half1) {
+                if (use_w1(s)) {
+                    const dim3 gridw(grid.x * (unsigned)(s.cout / 128));
+                    const size_t lds_w1 = (size_t)(2 * SV_DW + 2 * WRAW_MAX * SRLD + 256 + 1024) * sizeof(float);
+                    auto gow1 = [&](auto kern) {
+                        allow_lds((const void*)kern, lds_w1);
+                        hipLaunchKernelGGL(kern, gridw, dim3(256), lds_w1, st, wa);
+                    };
+                    if (in_mean) gow1(k_conv_wino_w1<true, 1>); else gow1(k_conv_wino_w1<false, 1>);
+                } else if (in_mean) go(k_conv_wino_s3<true, 2, true, 1>, lds_ls);
+                else go(k_conv_wino_s3<false, 2, false, 1>, lds);
+            } else if (which == 1) {
 #ifdef DSMIL_EXPERIMENTS
                 if (in_mean) { if (np9) go_pp(k_conv_wino_pp<true, 9, PP_UD>); else go_pp(k_conv_wino_pp<true, 6, PP_UD>); }
                 else { if (np9) go_pp(k_conv_wino_pp<false, 9, PP_UD>); else go_pp(k_conv_wino_pp<false, 6, PP_UD>); }
@@ -2418,6 +2461,13 @@ int run_conv(hipStream_t st, const float* x, const float* wpk, const float* in_m
             if (force == 22 && s.cout % 128 == 0) shape = 22;
         }
 #endif
+        if (conv_np() == 1) {   // the opt-in one-plane path
+            switch (shape) {
+                case 24: if (norm) go(k_conv_s6<2, 4, true, 1>, 64, 256); else go(k_conv_s6<2, 4, false, 1>, 64, 256); break;
+                case 22: if (norm) go(k_conv_s6<2, 2, true, 1>, 64, 128); else go(k_conv_s6<2, 2, false, 1>, 64, 128); break;
+                default: if (norm) go(k_conv_s6<4, 2, true, 1>, 128, 64); else go(k_conv_s6<4, 2, false, 1>, 128, 64); break;
+            }
+        } else
 #ifdef DSMIL_EXPERIMENTS
         if (conv_np() == 6) {   // DSMIL_CONV=s6: the bf16 three-plane form
             switch (shape) {
@@ -2607,17 +2657,22 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
 #else
         constexpr bool stem6 = false;
 #endif
+        const bool stem1 = conv_np() == 1;   // the opt-in one-plane path
         if (fuse) {
             // the pooled raw map goes straight to the max-pool's destination; the raw-map region holds the halo rows
             const size_t ldsp = SS_LDS + SS_POOL_LDS;
-            if (stem6) {
+            if (stem1) {
+                if (u8) stem_go(k_stem_s6<true, true, 1>, ldsp, buf[0], y0, d.Hp, d.Wp); else stem_go(k_stem_s6<false, true, 1>, ldsp, buf[0], y0, d.Hp, d.Wp);
+            } else if (stem6) {
 #ifdef DSMIL_EXPERIMENTS
                 if (u8) stem_go(k_stem_s6<true, true, 6>, ldsp, buf[0], y0, d.Hp, d.Wp); else stem_go(k_stem_s6<false, true, 6>, ldsp, buf[0], y0, d.Hp, d.Wp);
 #endif
             } else if (u8) stem_go(k_stem_s6<true, true, NPD>, ldsp, buf[0], y0, d.Hp, d.Wp);
             else stem_go(k_stem_s6<false, true, NPD>, ldsp, buf[0], y0, d.Hp, d.Wp);
         } else if (s6) {
-            if (stem6) {
+            if (stem1) {
+                if (u8) stem_go(k_stem_s6<true, false, 1>, SS_LDS, y0, nullptr, 0, 0); else stem_go(k_stem_s6<false, false, 1>, SS_LDS, y0, nullptr, 0, 0);
+            } else if (stem6) {
 #ifdef DSMIL_EXPERIMENTS
                 if (u8) stem_go(k_stem_s6<true, false, 6>, SS_LDS, y0, nullptr, 0, 0); else stem_go(k_stem_s6<false, false, 6>, SS_LDS, y0, nullptr, 0, 0);
 #endif
@@ -2737,6 +2792,22 @@ int dsmil_resnet_forward(int32_t depth, const void* x, int32_t x_is_u8_nhwc, int
     if ((bn_mean == nullptr) != (bn_rstd == nullptr)) return DSMIL_E_INVALID;
     return resnet18in_forward_impl(x, x_is_u8_nhwc != 0, B, H, W, conv1_w, packed, fc_w, fc_b, C, feats, classes, ws,
                                    ws_bytes, stream, bn_mean, bn_rstd, depth);
+}
+
+int dsmil_resnet_pack_ex(int32_t depth, const float* const* conv_w, float* packed, int32_t precision, void* stream) {
+    if (precision != 0 && precision != 1) return DSMIL_E_INVALID;
+    FormOverride fo(precision == 1 ? 1 : 0);
+    return dsmil_resnet_pack(depth, conv_w, packed, stream);
+}
+
+int dsmil_resnet_forward_ex(int32_t depth, const void* x, int32_t x_is_u8_nhwc, int32_t B, int32_t H, int32_t W,
+                            const float* conv1_w, const float* packed, const float* bn_mean, const float* bn_rstd,
+                            const float* fc_w, const float* fc_b, int32_t C, float* feats, float* classes, void* ws,
+                            size_t ws_bytes, int32_t precision, void* stream) {
+    if (precision != 0 && precision != 1) return DSMIL_E_INVALID;
+    FormOverride fo(precision == 1 ? 1 : 0);
+    return dsmil_resnet_forward(depth, x, x_is_u8_nhwc, B, H, W, conv1_w, packed, bn_mean, bn_rstd, fc_w, fc_b, C, feats, classes,
+                                ws, ws_bytes, stream);
 }
 
 int dsmil_resnet18bn_forward(const void* x, int32_t x_is_u8_nhwc, int32_t B, int32_t H, int32_t W,

@@ -160,12 +160,12 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
         unsigned* dX = vdst + ((xi * 4 + nuX) * WTT + ts) * SVLD + g * 2;
         cut4<NP>(X, ph, pm, pl);
         *reinterpret_cast<u32x2_t*>(dX) = ph;
-        *reinterpret_cast<u32x2_t*>(dX + 8) = pm;
+        if constexpr (PLN >= 2) *reinterpret_cast<u32x2_t*>(dX + 8) = pm;
         if constexpr (PLN == 3) *reinterpret_cast<u32x2_t*>(dX + 16) = pl;
         unsigned* dY = vdst + ((xi * 4 + nuY) * WTT + ts) * SVLD + g * 2;
         cut4<NP>(Y, ph, pm, pl);
         *reinterpret_cast<u32x2_t*>(dY) = ph;
-        *reinterpret_cast<u32x2_t*>(dY + 8) = pm;
+        if constexpr (PLN >= 2) *reinterpret_cast<u32x2_t*>(dY + 8) = pm;
         if constexpr (PLN == 3) *reinterpret_cast<u32x2_t*>(dY + 16) = pl;
     };
     // ---- weights, TILED for this kernel (k_pack_wino_s3, tiled = 1): [Cout/32][C/16][16 pos][3 planes][32 couts][16] bf16 —
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
                 // one per step (12 / 18 steps).  NP = 3 (fp16 form): six MFMAs in the block's twelve steps — steps 0 1, 4 5, 8 9 —
                 // so that the pieces of the other work still sit between MFMAs
                 // (an MFMA behind every OTHER step instead — 0 2 4 .. 10 — measured the same: 63.2 k against 62.6 k patches/s)
-                constexpr bool has_mfma = NP == 3 ? (I % 4) < 2 : true;
-                constexpr int k = NP == 3 ? I / 4 : I / 2, j = I & 1;
+                constexpr bool has_mfma = NP == 3 ? (I % 4) < 2 : (NP == 1 ? I < 2 : true);   // (NP = 1, the reduced-precision path: two)
+                constexpr int k = NP == 3 ? I / 4 : (NP == 1 ? 0 : I / 2), j = I & 1;
                 if constexpr (has_mfma) {
                     if constexpr (!(ABL & 16))
                         acc[2 * P + j] = plane_mfma<NP>(va[j][PP::X[k]].u, wb[j][PP::W[k]].u, acc[2 * P + j]);
@@ -339,6 +339,14 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
                             for (int e = 0; e < 4; ++e) O[e] = __builtin_fmaf(sz, Tb[e], Ta[e]);
                         }
                     }
+                    if constexpr (NP == 1) {                // one fp16 plane
+                        if constexpr (I == 6) u_[0] = cut2h1(O[0], O[1]);
+                        if constexpr (I == 7) u_[1] = cut2h1(O[2], O[3]);
+                        if constexpr (I == 10) {
+                            unsigned* d = vnext + ((xi * 4 + (isY ? nuY : nuX)) * WTT + ts) * SVLD + g * 2;
+                            *reinterpret_cast<u32x2_t*>(d) = u32x2_t{u_[0], u_[1]};
+                        }
+                    }
                     if constexpr (NP == 3) {                // fp16 form: two v_fma_mix per value, the planes come out packed
                         if constexpr (I == 6) cut2h(O[0], O[1], u_[0], r1_[0]);
                         if constexpr (I == 7) cut2h(O[2], O[3], u_[1], r1_[1]);
@@ -348,15 +356,15 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
                             *reinterpret_cast<u32x2_t*>(d + 8) = u32x2_t{r1_[0], r1_[1]};
                         }
                     }
-                    if constexpr (NP != 3 && I == 6) {
+                    if constexpr (NP != 3 && NP != 1 && I == 6) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { u_[e] = __float_as_uint(O[e]); r1_[e] = __float_as_uint(O[e] - __uint_as_float(u_[e] & 0xFFFF0000u)); }
                     }
-                    if constexpr (NP != 3 && I == 7) {
+                    if constexpr (NP != 3 && NP != 1 && I == 7) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) r2_[e] = __float_as_uint(__uint_as_float(r1_[e]) - __uint_as_float(r1_[e] & 0xFFFF0000u));
                     }
-                    if constexpr (NP != 3 && I == 10) {
+                    if constexpr (NP != 3 && NP != 1 && I == 10) {
                         u32x2_t ph, pm, pl;
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w1(WinoArgs a) {
         yb[0][r] = (rb[0] + rb[1]) + rb[2];
         ya[1][r] = (-ra[2] - ra[3]) + ra[1];
         yb[1][r] = (-rb[2] - rb[3]) + rb[1];
-        if constexpr (NP == 3) {                            // the weights carry 2^EMB_WSHIFT (exact to undo)
+        if constexpr (emb_f16<NP>()) {                      // the weights carry 2^EMB_WSHIFT (exact to undo)
             ya[0][r] *= EMB_OSCALE; yb[0][r] *= EMB_OSCALE; ya[1][r] *= EMB_OSCALE; yb[1][r] *= EMB_OSCALE;
         }
     }

@@ -52,6 +52,9 @@ class IClassifier(nn.Module):
         super().__init__()
         self.feature_extractor = feature_extractor
         self.fc = nn.Linear(feature_size, output_class)
+        # not part of the reference API: "fp32" (the parity path) or "half" — OPT-IN reduced precision of the native trunk
+        # (every conv operand rounded to one fp16 plane, f32 accumulation; ~2e-3 feature error: ops.resnet18in_forward)
+        self.embed_precision = "fp32"
 
     def forward(self, x):
         fe = self.feature_extractor
@@ -69,10 +72,11 @@ class IClassifier(nn.Module):
             head_trains = grad_on and (self.fc.weight.requires_grad or self.fc.bias.requires_grad)
             if not head_trains:
                 # features and instance logits from the same launch sequence (uint8: ToTensor fused in the stem)
-                return ops.resnet18in_forward(x, trunk[0], self.fc.weight, self.fc.bias, bn_norms=trunk[1])
+                return ops.resnet18in_forward(x, trunk[0], self.fc.weight, self.fc.bias, bn_norms=trunk[1],
+                                              precision=self.embed_precision)
             # frozen trunk + trainable linear head (what compute_feats.py:168-173 / attention_map.py set up):
             # the reference differentiates through self.fc (dsmil.py:24), so the head goes through autograd
-            feats, _ = ops.resnet18in_forward(x, trunk[0], bn_norms=trunk[1])
+            feats, _ = ops.resnet18in_forward(x, trunk[0], bn_norms=trunk[1], precision=self.embed_precision)
             return feats, _FCFunction.apply(feats, self.fc.weight, self.fc.bias)
         if x.dtype == torch.uint8:
             # no native stem will take the bytes: apply VF.to_tensor here (compute_feats.py:35-39)

@@ -584,13 +584,13 @@ def resnet_depth_of(convs):
     return None
 
 
-def _packed_resnet_weights(convs, depth=18):
+def _packed_resnet_weights(convs, depth=18, precision=0):
     """Device buffer with the non-stem conv weights re-laid-out for the kernels (dsmil_resnet_pack:
     Winograd-transformed or [tap][Cout][Cin]).  Cached per weight set; rebuilt when any tensor was
     modified in place (``_version``), re-assigned or moved (``data_ptr``).  The entry keeps the source
     tensors alive: a freed weight's address cannot come back as a different model's weight."""
     dev = convs[0].device
-    key = (str(dev), depth) + tuple(_tkey(w) for w in convs)
+    key = (str(dev), depth, int(precision)) + tuple(_tkey(w) for w in convs)
     ent = _pack_cache.get(key)
     if ent is not None:
         ent[3].wait(dev, ent[0])
@@ -600,8 +600,8 @@ def _packed_resnet_weights(convs, depth=18):
     keep = [_f32c(w.detach(), "conv weight") for w in convs]
     arr = (ctypes.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
     with torch.cuda.device(dev):
-        rc = L.dsmil_resnet_pack(depth, arr, _ptr(buf), _stream(dev))
-    _native.check(rc, "dsmil_resnet_pack")
+        rc = L.dsmil_resnet_pack_ex(depth, arr, _ptr(buf), int(precision), _stream(dev))
+    _native.check(rc, "dsmil_resnet_pack_ex")
     _pack_cache.put(key, (buf, keep, list(convs), _Ready(dev)))
     return buf
 
@@ -635,14 +635,19 @@ def _folded_bn(norms, dev):
     return m, r
 
 
-def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None):
+def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None, precision="fp32"):
     """x: [B,3,H,W] fp32 CUDA in [0,1] (what VF.to_tensor yields), OR decoded images as uint8
     [B,H,W,3] CUDA (the /255 + HWC->CHW of to_tensor is then fused into the stem, bit-identically);
     convs: the trunk's conv weights in torchvision state_dict order (20 for ResNet-18, 36 for ResNet-34, 53 for
     ResNet-50, 104 for ResNet-101).
     ``bn_norms``: the eval-mode BatchNorm2d modules of a `--norm_layer batch` trunk, in the same order;
-    None = InstanceNorm.  One native launch sequence (dsmil_resnet_forward).
+    None = InstanceNorm.  One native launch sequence (dsmil_resnet_forward_ex).
+    ``precision``: "fp32" (default: fp32-class, the parity path) or "half" (OPT-IN: every conv operand rounded to one fp16
+    plane, f32 accumulation, fp32 activations / norms — ~2e-3 feature error, not the 1e-4 bar; include/dsmil_hip.h).
     Returns (feats [B,512 | 2048], classes [B,C] or None)."""
+    if precision not in ("fp32", "half"):
+        raise ValueError("precision must be 'fp32' or 'half'")
+    prec = 1 if precision == "half" else 0
     u8 = x.dtype == torch.uint8
     if u8:
         if not x.is_cuda:
@@ -668,7 +673,7 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None):
     fc_b = _f32c(fc_b.detach(), "fc_b") if fc_b is not None else None
     C = fc_w.shape[0] if fc_w is not None else 0
     classes = torch.empty((B, C), dtype=torch.float32, device=dev) if fc_w is not None else None
-    packed = _packed_resnet_weights(convs, depth)
+    packed = _packed_resnet_weights(convs, depth, prec)
     conv1 = _f32c(convs[0].detach(), "conv1.weight")
     nbytes = L.dsmil_resnet_workspace_bytes(depth, B, H, W)
     if nbytes == 0:
@@ -680,10 +685,10 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None):
         if bn_m.numel() != L.dsmil_resnet_norm_channels(depth):
             raise ValueError("BatchNorm channel counts do not match the trunk")
     with torch.cuda.device(dev):
-        rc = L.dsmil_resnet_forward(depth, _ptr(x), 1 if u8 else 0, B, H, W, _ptr(conv1), _ptr(packed), _ptr(bn_m),
-                                    _ptr(bn_r), _ptr(fc_w), _ptr(fc_b), C, _ptr(feats), _ptr(classes), _ptr(ws),
-                                    ws.numel(), _stream(dev))
-    _native.check(rc, "dsmil_resnet_forward")
+        rc = L.dsmil_resnet_forward_ex(depth, _ptr(x), 1 if u8 else 0, B, H, W, _ptr(conv1), _ptr(packed), _ptr(bn_m),
+                                       _ptr(bn_r), _ptr(fc_w), _ptr(fc_b), C, _ptr(feats), _ptr(classes), _ptr(ws),
+                                       ws.numel(), prec, _stream(dev))
+    _native.check(rc, "dsmil_resnet_forward_ex")
     return feats, classes
 
 

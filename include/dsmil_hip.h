@@ -319,10 +319,10 @@ int dsmil_resnet18bn_forward(const void* x, int32_t x_is_u8_nhwc, int32_t B, int
 size_t dsmil_resnet_workspace_bytes(int32_t depth, int32_t B, int32_t H, int32_t W);
 int32_t dsmil_resnet_feature_dim(int32_t depth);
 int32_t dsmil_resnet_num_convs(int32_t depth);
-/* Which matrix pipe the trunk's convolutions run on (for roofline accounting): bf16 plane products per fp32 MAC
- * of the Winograd convs (3x3 stride 1) and of the direct convs (3x3 stride 2, 1x1) — 9 / 6 = bf16 MFMA over exact
- * three-plane cuts, 0 = v_mfma_f32_32x32x2_f32.  The product library has one form (6 / 6); experiment builds read
- * DSMIL_WINO / DSMIL_CONV once per process. */
+/* Which matrix pipe the trunk's convolutions run on (for roofline accounting): plane products per fp32 MAC of the
+ * Winograd convs (3x3 stride 1) and of the direct convs (3x3 stride 2, 1x1) — 3 = fp16 MFMA over two-plane cuts (round 5,
+ * the product form), 9 / 6 = bf16 MFMA over exact three-plane cuts, 0 = v_mfma_f32_32x32x2_f32.  The product library has
+ * one form (3 / 3); experiment builds read DSMIL_WINO / DSMIL_CONV once per process. */
 int dsmil_resnet_mfma_forms(int32_t* wino_products, int32_t* direct_products);
 int32_t dsmil_resnet_norm_channels(int32_t depth);
 size_t dsmil_resnet_packed_bytes(int32_t depth);
@@ -331,6 +331,20 @@ int dsmil_resnet_forward(int32_t depth, const void* x, int32_t x_is_u8_nhwc, int
                          int32_t W, const float* conv1_w, const float* packed, const float* bn_mean,
                          const float* bn_rstd, const float* fc_w, const float* fc_b, int32_t C,
                          float* feats, float* classes, void* ws, size_t ws_bytes, void* stream);
+
+/* OPT-IN reduced precision (round 5; no reference counterpart: the reference embeds in fp32, compute_feats.py:70-76).
+ * precision = 0: the calls above (fp32-class: every conv as three fp16 plane products of two-plane cuts, csrc/resnet_fwd.hip
+ * PlaneProducts<3>).  precision = 1: every conv operand — activations behind the norm + ReLU, and the weights — is rounded to ONE
+ * fp16 plane (11 significand bits, round to nearest); products accumulate in f32 on the same MFMA; activations between the layers,
+ * InstanceNorm statistics and the pooling stay fp32.  Feature error against the fp32-class path: ~2e-3 abs on features of O(1)
+ * (tools/form_error_study.py `f16x1`, tests/test_resnet_gpu.py) — NOT the 1e-4 parity bar; for callers who ask for it
+ * (compute_feats.py --precision half).  The packed image must come from dsmil_resnet_pack_ex with the SAME precision (same size as
+ * dsmil_resnet_packed_bytes). */
+int dsmil_resnet_pack_ex(int32_t depth, const float* const* conv_w, float* packed, int32_t precision, void* stream);
+int dsmil_resnet_forward_ex(int32_t depth, const void* x, int32_t x_is_u8_nhwc, int32_t B, int32_t H, int32_t W,
+                            const float* conv1_w, const float* packed, const float* bn_mean, const float* bn_rstd,
+                            const float* fc_w, const float* fc_b, int32_t C, float* feats, float* classes, void* ws,
+                            size_t ws_bytes, int32_t precision, void* stream);
 
 /* ---- background filters of the reference's tilers on decoded tiles -------------------------
  * tiles_nhwc: device uint8 [B,H,W,3] (W <= 1024).  out: device uint64 [B,4] = per tile

@@ -51,6 +51,30 @@ def test_embedder_vs_oracle(B, H, W):
     np.testing.assert_allclose(c.cpu().numpy(), ref_c, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,W,u8", [(5, 224, 224, False), (33, 224, 224, True), (2, 225, 231, False)])
+def test_opt_in_half_precision_path_within_its_stated_tolerance(B, H, W, u8):
+    """IClassifier.embed_precision = "half" (dsmil_resnet_forward_ex, precision = 1; compute_feats.py --precision half): every
+    conv operand rounded to ONE fp16 plane, f32 accumulation, fp32 norms.  NOT the 1e-4 parity path: the bar stated in
+    include/dsmil_hip.h is 5e-3 abs on features of O(1) (measured ~2e-3: tools/form_error_study.py f16x1); the default path of
+    the same module stays at 1e-4, and the two differ (the switch does something)."""
+    ic, w = _build(seed=11)
+    x = torch.from_numpy(make_patches(40 + B, B, H, W))
+    ref_f, ref_c = _ref(x, w, ic)
+    icg = ic.cuda()
+    xin = (x * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous().cuda() if u8 else x.cuda()
+    if u8:
+        ref_f, ref_c = _ref(xin.cpu().permute(0, 3, 1, 2).to(torch.float32).div(255), w, ic)
+    with torch.no_grad():
+        f32, c32 = icg(xin)
+        icg.embed_precision = "half"
+        fh, ch = icg(xin)
+        icg.embed_precision = "fp32"
+    np.testing.assert_allclose(f32.cpu().numpy(), ref_f, atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(fh.cpu().numpy(), ref_f, atol=5e-3, rtol=0)
+    np.testing.assert_allclose(ch.cpu().numpy(), ref_c, atol=5e-3, rtol=0)
+    assert float((fh - f32).abs().max()) > 1e-5
+
+
 @pytest.mark.parametrize("B,H,W", [(256, 224, 224), (7, 224, 224), (33, 224, 224), (255, 224, 224), (257, 224, 224),
                                    (3, 250, 250), (2, 225, 231), (9, 231, 225)])
 def test_embedder_at_the_benchmarked_batch_and_odd_sizes(B, H, W):
