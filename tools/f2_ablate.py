@@ -47,6 +47,8 @@ if __name__ == "__main__":
             line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
             print(f"stagger {units:3d} x 64 cycles per eighth  {line[0] if line else r.stderr[-300:]}", flush=True)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == "masks":     # an explicit list: python tools/f2_ablate.py masks 0,512
+        MASKS = [(f"mask {m}", int(m)) for m in sys.argv[2].split(",")]
     for name, mask in MASKS:
         e = dict(os.environ, DSMIL_NATIVE_LIB="libdsmil_hip_expt.so", DSMIL_F2_ABL=str(mask))
         r = subprocess.run([sys.executable, __file__, "one"], env=e, capture_output=True, text=True, timeout=300)
