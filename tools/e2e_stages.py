@@ -29,6 +29,9 @@ for it in range(3):
     ta = T()
     out = pl.multiscale_attention_map(wsi, e_lo, e_hi, net, [0.5, 0.5], colors)
     print("whole multiscale_attention_map: %.1f ms" % (1e3 * (T() - ta)))
+    tb = T()
+    pl.box_downsample_u8(wsi, 4)
+    print("box_downsample_u8 alone: %.1f ms" % (1e3 * (T() - tb)))
     t0 = T()
     low, high, parent, pos = pl.pyramid_tiles(wsi, 224, 4)
     t1 = T()
@@ -43,7 +46,7 @@ for it in range(3):
     prob = np.atleast_1d(torch.sigmoid(pred).squeeze().cpu().numpy())
     An, pn = A.cpu().numpy(), pos.cpu().numpy()
     t5 = T()
-    cmap = pl.attention_colormap(An, pn, prob, [0.5, 0.5], colors, None, "slide", lambda *_: None)
+    cmap = pl.attention_colormap(An, pn, prob, [0.5, 0.5], colors, None, "slide", lambda *_: None, upsample_device=dev)
     t6 = T()
     print("ms: tiling %.1f  embed_low %.1f  embed_high %.1f  concat+aggregate %.1f  d2h %.1f  colormap %.1f  total %.1f" %
           tuple(1e3 * x for x in (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t6 - t0)), cmap.shape)
