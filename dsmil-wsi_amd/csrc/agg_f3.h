@@ -1,0 +1,404 @@
+// agg_f3.h — k_attend_f3: k_attend_f2's arithmetic (fp32 bags, two fp16 planes by round-to-nearest per operand, three plane
+// products on v_mfma_f32_32x32x16_f16, every feature byte read ONCE) with the query weights RESIDENT IN REGISTERS.
+//
+// Why (round 5, DESIGN.md §3 "what bounds the tile").  k_attend_f2 pulls its weight planes from L2 for every 64-row tile:
+// 320 KB of weights next to 128 KB of features through the CU's 64 B/clk vector L1 — the tile's bound, whatever the grid size
+// (the launch on 64 workgroups takes the same time per tile as on 256).  Taller tiles would amortise the weights but do not
+// fit LDS.  k_attend_bf16_res (agg_res.h) showed the way out for bf16 bags: one wave per SIMD may hold 512 registers, so
+//   * one 256-thread workgroup per CU; wave w keeps the A fragments of ITS 32 hidden / query units for the whole launch:
+//     W1 (two fp16 planes x K <= 512: up to 256 registers) in the ACCUMULATOR half of the register file, W2 (64 registers)
+//     in VGPRs.  No weight byte moves after the prologue, so a short tile costs nothing:
+//   * tile = 32 rows, TWO plane buffers in LDS (row-major [row][plane][K] fp16 with a 16-B pad: B fragments, the value
+//     sum's k-contiguous reads and the cut's writes are all conflict-free).  While tile t is in GEMM 1, every wave cuts
+//     ITS eight rows of tile t+1 out of a register ring (filled a tile earlier, as k_attend_f2's cutters do) into the other
+//     buffer and refills the ring with tile t+2 — the cut (16 v_fma_mix per 64 k), the plane writes and the loads sit in
+//     the shadow of the 96 MFMAs;
+//   * a workgroup owns a CONTIGUOUS run of tiles (k_attend_bf16_res's scheme): consecutive tiles belong to the same bag, the
+//     softmax reference is a constant of the bag (tanh bounds the queries: |s| <= sum_j |q_max[j]| / sqrt(128) — no tile
+//     maximum, no rescaling), the value sum accumulates ACROSS tiles in eight registers per class (lane = k-octet, wave =
+//     eight rows of every tile: no cross-lane reduction per tile) and ONE partial per (workgroup, bag) is written:
+//     slot = blockIdx.x + bag, merged by k_finish's segment mode.
+// Per-row power-of-two scales, the cut, the three products, the packed weight image (k_pack_agg_f2) and the error class are
+// k_attend_f2's (agg_f2.h); so are the tests (tests/test_agg_gpu.py::test_batch_form_*).
+// Only the two-layer query (dsmil.py:31-32 nonlinear, the default) and C <= 2: everything else stays on k_attend_f2.
+// LDS: planes 2 x 32 x (4 K + 16) B (129 KiB at K = 512) | hidden planes 32 x 528 B | 4.8 KiB scratch = 150.3 KiB.
+// Barriers per 32-row tile: S (planes of this tile complete, the other buffer and the scratch released), B1 (hidden row
+// maxima), B2 (hidden planes), T1 (partial scores).
+#pragma once
+#include "agg_f2.h"
+
+namespace {
+
+constexpr int F3_BM = 32;                   // rows per tile
+constexpr int F3_THREADS = 256;             // one wave per SIMD
+constexpr int F3_MAX_WG = 1024;             // (= RS_MAX_WG: the workspace holds that many + n_bags partial slots)
+constexpr int F3_HROW = 528;                // bytes per row of the hidden planes: 2 planes x 256 B + 16 pad
+constexpr int F3_SCR = 1216;                // floats of scratch
+__host__ __device__ constexpr int f3_row_bytes(int K) { return 4 * K + 16; }
+__host__ __device__ constexpr int f3_lds_bytes(int K) { return 2 * F3_BM * f3_row_bytes(K) + F3_BM * F3_HROW + F3_SCR * 4; }
+
+struct F3Work {
+    int bag;
+    long long off0, Nb, row0;
+};
+
+// first item in [item, end) whose tile lies inside its bag (evaluated identically by every wave)
+__device__ __forceinline__ bool f3_fetch(const AttendArgs& a, int tiles_per_bag, int end, int& item, F3Work& w) {
+    while (item < end) {
+        const int b = item / tiles_per_bag, tile = item - b * tiles_per_bag;
+        const int bag = a.bag0 + b;
+        // (through the constant address space: scalar loads.  As plain loads behind the tile's stores hipcc makes them VECTOR loads
+        // with a uniform address, and their vmcnt(0) then waits for every refill of the feature ring issued before them)
+        const __attribute__((address_space(4))) long long* offs = (const __attribute__((address_space(4))) long long*)(uintptr_t)a.offsets;
+        const long long off0 = offs[bag];
+        const long long Nb = offs[bag + 1] - off0;
+        const long long row0 = (long long)tile * F3_BM;
+        if (row0 < Nb) {
+            w.bag = bag; w.off0 = off0; w.Nb = Nb; w.row0 = row0;
+            return true;
+        }
+        ++item;
+    }
+    return false;
+}
+
+// NK1 = K / 32 in {4, 8, 12, 16}; a.wpk = the image of k_pack_agg_f2; rowmax[logical row] = max_k |x| (k_logits_stream);
+// a.nonlinear, a.C <= 2, vals == feats.  Workgroup g owns the tile items [g per_wg, (g + 1) per_wg) of the (bag, tile) list
+// (tiles_per_bag items per bag) and writes partial slot g + bag for every bag it touches.
+template <int NK1, bool TWO>
+__global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const float* __restrict__ rowmax, int tiles_per_bag,
+                                                             int n_items, int per_wg) {
+    static_assert(NK1 % 4 == 0 && NK1 >= 4 && NK1 <= 16, "K a multiple of 128 up to 512");
+    constexpr int K = 32 * NK1, NKS = 2 * NK1, NG = NK1 / 2;   // 16-k steps of GEMM 1; 64-k groups of the feature ring
+    constexpr int RB = f3_row_bytes(K), BUF = F3_BM * RB;
+    constexpr int NC = TWO ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* sX = reinterpret_cast<char*>(smem);              // [2 buffers][32 rows][plane 2][K] fp16 + pad
+    char* sH = sX + 2 * BUF;                               // [32 rows][plane 2][128] fp16 + pad; at a flush: [4 waves][NC][K] floats
+    float* scr = reinterpret_cast<float*>(sH + F3_BM * F3_HROW);
+    float* sS = scr;            // [4 waves][2 classes][32 rows] partial scores
+    float* sMax = scr + 256;    // [4 waves][32 rows] hidden-layer row maxima
+    float* sBias = scr + 384;   // [2][128]: q.0 / q.2 biases
+    float* sPall = scr + 640;   // [4 waves][2 classes][32 rows]: every wave's private value-sum weights p / row scale
+    float* sInvAll = scr + 896; // [2 buffers][32 rows]: 1 / row scale of the rows whose planes sit in that buffer
+    float* sQ = scr + 960;      // [2 classes][128]: critical queries of the current bag
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const f32x4* wimg = reinterpret_cast<const f32x4*>(a.wpk);
+    const float* trailer = reinterpret_cast<const float*>(wimg + (long long)(NKS + 8) * F2_CHUNK_F4);
+    const float* feats = reinterpret_cast<const float*>(a.feats);
+    const float scale = 0.08838834764831845f;              // 1/sqrt(128), dsmil.py:56
+
+    int item = (int)blockIdx.x * per_wg;
+    const int item_end = item + per_wg < n_items ? item + per_wg : n_items;
+    F3Work cur, nxt, nn;
+    if (!f3_fetch(a, tiles_per_bag, item_end, item, cur)) return;   // (block-uniform)
+
+    // ---- resident weights: this wave's A fragments of every 16-k step, both planes.  W1 is pinned to the accumulator file
+    //      (an MFMA may take its A operand from there; the empty asm makes the tuple live there for the whole launch), W2 and
+    //      everything the VALU touches stay in VGPRs.
+    F2Frag w1[NKS][2], w2[8][2];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) w1[s][p].f = wimg[(long long)s * F2_CHUNK_F4 + (2 * wave + p) * 64 + lane];
+#pragma unroll
+    for (int st = 0; st < 8; ++st)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) w2[st][p].f = wimg[(long long)(NKS + st) * F2_CHUNK_F4 + (2 * wave + p) * 64 + lane];
+    const float ia1 = trailer[0], ia2 = trailer[1];
+    sBias[tid] = tid < QD ? a.q0_b[tid] : a.q2_b[tid - QD];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)                         // (behind ALL the loads: a pin waits for its tuple)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) asm volatile("" : "+a"(w1[s][p].f));
+
+    // ---- the feature stream of this wave: rows 8 wave .. 8 wave + 7 of every tile; lane (rr = lane & 7, o = lane >> 3) holds
+    //      the k-octet o of every 64-k group of row 8 wave + rr
+    const int rr = lane & 7, o = lane >> 3;
+    const int myrow = 8 * wave + rr;
+    f32x4 ring[NG][2];
+    // row lookups of a tile for this lane: the row's max |x| and its physical row (two loads; row_done turns them into the
+    // scale and the source pointer — kept apart so that the caller decides where the wait goes)
+    auto row_raw = [&](const F3Work& w, float& rm, long long& phys, long long& logical) {
+        long long gr = w.row0 + myrow;
+        if (gr >= w.Nb) gr = w.Nb - 1;                    // rows past the bag end are cut like the last row, weight 0
+        rm = rowmax[w.off0 + gr];
+        // (branch-free row map: a load behind a branch is waited for at the join — with the identity map the load reads a valid
+        // dummy word instead)
+        const long long* mp = a.rowmap ? reinterpret_cast<const long long*>(a.rowmap) + (w.off0 + gr) : reinterpret_cast<const long long*>(a.offsets);
+        phys = *mp;                                       // (the mapped row, or the dummy word)
+        logical = w.off0 + gr;
+    };
+    auto row_done = [&](float rm, long long phys, long long logical, float& sc, float& sinv) -> const float* {
+        sc = f2_scale(rm, sinv);
+        return feats + (a.rowmap ? phys : logical) * (long long)K + 8 * o;
+    };
+    auto row_src = [&](const F3Work& w, float& sc, float& sinv) -> const float* {
+        float rm;
+        long long phys, logical;
+        row_raw(w, rm, phys, logical);
+        asm volatile("" : "+v"(phys));
+        return row_done(rm, phys, logical, sc, sinv);
+    };
+    auto fill = [&](const float* src, int c) {
+        ring[c][0] = *(const DSMIL_GLOBAL f32x4*)(src + 64 * c);
+        ring[c][1] = *(const DSMIL_GLOBAL f32x4*)(src + 64 * c + 4);
+    };
+    // group c of the ring -> the two planes of its eight values, into plane buffer pb
+    char* const cut_dst = sX + myrow * RB + 16 * o;
+    auto cut_write = [&](int pb, int c, float sc) {
+        F2Frag f[2];
+        split2h_scaled(ring[c][0], ring[c][1], sc, f);
+        char* d = cut_dst + pb * BUF + 128 * c;
+        *reinterpret_cast<f32x4*>(d) = f[0].f;
+        *reinterpret_cast<f32x4*>(d + 2 * K) = f[1].f;
+    };
+
+    float sc_c = 1.f, sinv_c = 1.f, sc_n = 1.f, sinv_n = 1.f, sc_nn = 1.f, sinv_nn = 1.f;
+    const float* src_c = row_src(cur, sc_c, sinv_c);
+#pragma unroll
+    for (int c = 0; c < NG; ++c) fill(src_c, c);
+    int it_n = item + 1;
+    bool has_next = f3_fetch(a, tiles_per_bag, item_end, it_n, nxt);
+    const float* src_n = has_next ? row_src(nxt, sc_n, sinv_n) : src_c;
+    if (!has_next) { nxt = cur; sc_n = sc_c; sinv_n = sinv_c; }
+    // tile 0: cut into buffer 0, ring <- tile 1
+#pragma unroll
+    for (int c = 0; c < NG; ++c) {
+        cut_write(0, c, sc_c);
+        fill(src_n, c);
+    }
+    if (o == 0) sInvAll[myrow] = sinv_c;
+    int it_nn = it_n + 1;
+    bool has_nn = has_next && f3_fetch(a, tiles_per_bag, item_end, it_nn, nn);
+    const float* src_nn = has_nn ? row_src(nn, sc_nn, sinv_nn) : src_n;
+    if (!has_nn) { nn = nxt; sc_nn = sc_n; sinv_nn = sinv_n; }
+
+    // running sums of the bag inside this workgroup's run
+    float bacc[NC][8];
+    float l_run[NC];
+    float m_bag[NC];
+    auto reset_acc = [&]() {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            l_run[c] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bacc[c][e] = 0.f;
+        }
+    };
+    reset_acc();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) m_bag[c] = 0.f;
+    int qbag = -1;
+    float* sPw = sPall + wave * 64;
+
+    for (int t = 0;; ++t) {
+        const int buf = t & 1;
+        if (cur.bag != qbag) {
+            // a new bag: its critical queries -> LDS (the previous tile's readers are behind its T1; the S barrier below
+            // publishes them), the softmax reference from the same values
+            __syncthreads();
+            if (tid < NC * QD) sQ[tid] = a.qmax[(long long)cur.bag * a.C * QD + tid];
+            qbag = cur.bag;
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < NC; ++c) m_bag[c] = wave_sum(fabsf(sQ[c * QD + lane]) + fabsf(sQ[c * QD + 64 + lane])) * scale;
+        }
+        // the tile after the one after next: its record (scalar loads), its rows' maxima and addresses (two vector loads, issued
+        // BEFORE this tile's ring refills and consumed at the end of the tile: the wait then leaves the refills in flight)
+        int it_n3 = it_nn + 1;
+        F3Work n3 = nn;
+        float rm_n3;
+        long long phys_n3, log_n3;
+        const bool has_n3 = has_nn && f3_fetch(a, tiles_per_bag, item_end, it_n3, n3);
+        if (!has_n3) n3 = nn;
+        row_raw(n3, rm_n3, phys_n3, log_n3);                    // (unconditional: no tile behind -> a harmless re-read of nn's rows)
+        __syncthreads();                                  // S
+        const char* xb_ = sX + buf * BUF + l31 * RB + 16 * hi;
+        const float* sInv = sInvAll + buf * F3_BM;
+        // ---- GEMM 1: H^T[j][n] += W1[j][k] x[n][k], j = this wave's 32 units, n = the 32 rows; Behind every fourth step: one 64-k group of the NEXT tile is cut
+        //      into the other buffer and its ring slot refilled with the tile after next.
+        f32x16 Hm;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Hm[r] = 0.f;
+        {
+            F2Frag xa[2], xn[2];
+            xa[0].f = *reinterpret_cast<const f32x4*>(xb_);
+            xa[1].f = *reinterpret_cast<const f32x4*>(xb_ + 2 * K);
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                if (s + 1 < NKS) {
+                    xn[0].f = *reinterpret_cast<const f32x4*>(xb_ + 32 * (s + 1));
+                    xn[1].f = *reinterpret_cast<const f32x4*>(xb_ + 2 * K + 32 * (s + 1));
+                }
+                Hm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[s][1].v, xa[0].v, Hm, 0, 0, 0);   // (smallest products first)
+                Hm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[s][0].v, xa[1].v, Hm, 0, 0, 0);
+                Hm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[s][0].v, xa[0].v, Hm, 0, 0, 0);
+                if (s % 4 == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    cut_write(buf ^ 1, s / 4, sc_n);
+                    fill(src_nn, s / 4);                  // (pinned: hipcc otherwise sinks all sixteen loads to the end of GEMM 1)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (s + 1 < NKS) { xa[0] = xn[0]; xa[1] = xn[1]; }
+            }
+        }
+        if (o == 0) sInvAll[(buf ^ 1) * F3_BM + myrow] = sinv_n;
+        // ---- un-scale, bias, ReLU: reg 4q+e <-> unit 32 wave + 8q + 4hi + e, row l31
+        const float iv1 = ia1 * sInv[l31];
+        float hmax = 0.f;
+        f32x16 H;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + 32 * wave + 8 * q + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = fmaxf(fmaf(Hm[4 * q + e], iv1, bq[e]), 0.f);
+                H[4 * q + e] = v;
+                hmax = fmaxf(hmax, v);
+            }
+        }
+        hmax = fmaxf(hmax, __shfl_xor(hmax, 32, 64));
+        if (hi == 0) sMax[wave * F3_BM + l31] = hmax;
+        __syncthreads();                                  // B1
+        float hsc, hinv;
+        hsc = f2_scale(fmaxf(fmaxf(sMax[l31], sMax[F3_BM + l31]), fmaxf(sMax[2 * F3_BM + l31], sMax[3 * F3_BM + l31])), hinv);
+        // registers 8sx .. 8sx+7 are, for row l31, the 8 hidden units of GEMM-2 step 2 wave + sx (the k permutation the packed
+        // W2 carries): scale, cut, publish
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+            const f32x4 h0 = {H[8 * sx], H[8 * sx + 1], H[8 * sx + 2], H[8 * sx + 3]};
+            const f32x4 h1 = {H[8 * sx + 4], H[8 * sx + 5], H[8 * sx + 6], H[8 * sx + 7]};
+            F2Frag f[2];
+            split2h_scaled(h0, h1, hsc, f);
+            char* d = sH + l31 * F3_HROW + ((2 * wave + sx) * 2 + hi) * 16;
+            *reinterpret_cast<f32x4*>(d) = f[0].f;
+            *reinterpret_cast<f32x4*>(d + 256) = f[1].f;
+        }
+        __syncthreads();                                  // B2
+        f32x16 Qm;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Qm[r] = 0.f;
+        {
+            const char* hb_ = sH + l31 * F3_HROW + 16 * hi;
+            F2Frag xa[2], xn[2];
+            xa[0].f = *reinterpret_cast<const f32x4*>(hb_);
+            xa[1].f = *reinterpret_cast<const f32x4*>(hb_ + 256);
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                if (st + 1 < 8) {
+                    xn[0].f = *reinterpret_cast<const f32x4*>(hb_ + 32 * (st + 1));
+                    xn[1].f = *reinterpret_cast<const f32x4*>(hb_ + 256 + 32 * (st + 1));
+                }
+                Qm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[st][1].v, xa[0].v, Qm, 0, 0, 0);
+                Qm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[st][0].v, xa[1].v, Qm, 0, 0, 0);
+                Qm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[st][0].v, xa[0].v, Qm, 0, 0, 0);
+                if (st + 1 < 8) { xa[0] = xn[0]; xa[1] = xn[1]; }
+            }
+        }
+        // ---- tanh; partial scores over this wave's 32 query units (dsmil.py:55-56)
+        {
+            const float iv2 = ia2 * hinv;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + QD + 32 * wave + 8 * q + 4 * hi);
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(sQ + 32 * wave + 8 * q + 4 * hi);
+                f32x4 u1 = u0;
+                if constexpr (TWO) u1 = *reinterpret_cast<const f32x4*>(sQ + QD + 32 * wave + 8 * q + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float qv = fast_tanh(fmaf(Qm[4 * q + e], iv2, bq[e]));
+                    s0 = fmaf(qv, u0[e], s0);
+                    if constexpr (TWO) s1 = fmaf(qv, u1[e], s1);
+                }
+            }
+            s0 += __shfl_xor(s0, 32, 64);
+            if constexpr (TWO) s1 += __shfl_xor(s1, 32, 64);
+            if (hi == 0) {
+                sS[(wave * 2 + 0) * F3_BM + l31] = s0;
+                if constexpr (TWO) sS[(wave * 2 + 1) * F3_BM + l31] = s1;
+            }
+        }
+        __syncthreads();                                  // T1
+        // ---- scores, softmax weights relative to the bag's constant reference: every wave for itself (lane & 31 = row; the
+        //      same values in every wave), weights for its own eight rows' value sum into its private strip
+        {
+            const long long grow = cur.row0 + l31;
+            const bool valid = grow < cur.Nb;
+            const float rinv = sInv[l31];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float s = ((sS[(0 * 2 + c) * F3_BM + l31] + sS[(1 * 2 + c) * F3_BM + l31]) +
+                                 (sS[(2 * 2 + c) * F3_BM + l31] + sS[(3 * 2 + c) * F3_BM + l31])) * scale;
+                const float p = valid ? expf(s - m_bag[c]) : 0.f;
+                if (hi == 0) l_run[c] += p;
+                if (wave == 0 && hi == 0 && valid) a.scores[(cur.off0 + grow) * (long long)a.C + c] = s;
+                if (hi == 0) sPw[c * F3_BM + l31] = p * rinv;
+            }
+        }
+        // ---- value sum (dsmil.py:57) from the resident planes: lane = k-octet, this wave's rows 8 wave .. 8 wave + 7
+        if (lane < K / 8) {
+            const char* xv = sX + buf * BUF + (8 * wave) * RB + 16 * lane;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                F2Frag f0, f1;
+                f0.f = *reinterpret_cast<const f32x4*>(xv + j * RB);
+                f1.f = *reinterpret_cast<const f32x4*>(xv + j * RB + 2 * K);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float w = sPw[c * F3_BM + 8 * wave + j];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        bacc[c][e] = fmaf((float)f0.v[e], w, bacc[c][e]);
+                        bacc[c][e] = fmaf((float)f1.v[e], w, bacc[c][e]);
+                    }
+                }
+            }
+        }
+        // ---- end of this workgroup's part of the bag: one (m, l, B) partial, slot = blockIdx.x + bag
+        if (!has_next || nxt.bag != cur.bag) {
+            const long long slot = (long long)blockIdx.x + cur.bag;
+            float* red = reinterpret_cast<float*>(sH);    // [4 waves][NC][K] (the hidden planes are consumed)
+            __syncthreads();
+            if (lane < K / 8) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    float* d = red + (wave * NC + c) * K + 8 * lane;
+                    *reinterpret_cast<f32x4*>(d) = f32x4{bacc[c][0], bacc[c][1], bacc[c][2], bacc[c][3]};
+                    *reinterpret_cast<f32x4*>(d + 4) = f32x4{bacc[c][4], bacc[c][5], bacc[c][6], bacc[c][7]};
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < NC * K; i += F3_THREADS) {
+                const int c = i / K, k = i - c * K;
+                const float v = (red[(0 * NC + c) * K + k] + red[(1 * NC + c) * K + k]) + (red[(2 * NC + c) * K + k] + red[(3 * NC + c) * K + k]);
+                a.part_B[(slot * a.C + c) * (long long)a.Kv + k] = v;
+            }
+            if (wave == 0) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float lsum = wave_sum(hi == 0 ? l_run[c] : 0.f);
+                    if (lane == 0) {
+                        float* ml = a.part_ml + (slot * a.C + c) * 2;
+                        ml[0] = m_bag[c];
+                        ml[1] = lsum;
+                    }
+                }
+            }
+            reset_acc();
+        }
+        if (!has_next) break;
+        cur = nxt; nxt = nn; nn = n3;
+        has_next = has_nn; has_nn = has_n3;
+        it_nn = it_n3;
+        sc_c = sc_n; sinv_c = sinv_n;
+        sc_n = sc_nn; sinv_n = sinv_nn; src_n = src_nn;
+        asm volatile("" : "+v"(rm_n3), "+v"(phys_n3));   // (the lookups are consumed HERE, a tile after they were issued)
+        src_nn = row_done(rm_n3, phys_n3, log_n3, sc_nn, sinv_nn);
+    }
+}
+
+}  // namespace

@@ -43,6 +43,7 @@
 #include "agg_split.h"
 #include "agg_hs.h"
 #include "agg_f2.h"
+#include "agg_f3.h"
 #include "agg_res.h"
 #include "lds_attr.h"
 
@@ -1231,6 +1232,7 @@ int device_cus() {
 // separate k_qmax launch
 std::atomic<int> g_inline_query{1};
 // dsmil_agg_batch_form(): 1 = batches of fp32 bags take k_attend_f2 (default), 0 = k_query_attend_split (rounds 2-4)
+// ... 2 = k_attend_f3 (weights resident in registers, 32-row tiles; two-layer query, C <= 2 — k_attend_f2 otherwise)
 std::atomic<int> g_use_f2{1};
 
 // The in-launch hand-off needs its producers to RUN while tiles spin on their flags.  Producers are the first workgroups of
@@ -1305,6 +1307,37 @@ int launch_attend_f2(const AttendArgs& a, const float* rowmax, long long max_row
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(F2_THREADS), F2_LDS_BYTES, st, a, rowmax, tiles_per_bag, (int)n_items);
     dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
+// batches of fp32 bags, two-layer query, C <= 2: 32-row tiles, the query weights resident in registers (agg_f3.h)
+template <int NK1>
+int launch_attend_f3_k(const AttendArgs& a, const float* rowmax, long long max_rows, int n_bags, hipStream_t st, int* seg_per, int* seg_T) {
+    void (*fn)(AttendArgs, const float*, int, int, int) = a.C == 2 ? k_attend_f3<NK1, true> : k_attend_f3<NK1, false>;
+    constexpr int lds = f3_lds_bytes(32 * NK1);
+    if (!dsmil_lds::allow((const void*)fn, lds)) return DSMIL_E_LAUNCH;
+    int cus = device_cus();
+    if (cus <= 0) cus = 256;
+    if (cus > F3_MAX_WG) cus = F3_MAX_WG;
+    const long long tiles_per_bag = (max_rows + F3_BM - 1) / F3_BM;
+    const long long n_items = tiles_per_bag * n_bags;
+    if (n_items > 0x7fffffffLL) return DSMIL_E_UNSUPPORTED;
+    const long long per = (n_items + cus - 1) / cus;   // contiguous runs of tile items per workgroup (k_attend_bf16_res's scheme)
+    const unsigned grid = (unsigned)((n_items + per - 1) / per);
+    *seg_per = (int)per;
+    *seg_T = (int)tiles_per_bag;
+    const int slot = dsmil_prof::begin(dsmil_prof::CH_ATTEND, st);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(F3_THREADS), lds, st, a, rowmax, (int)tiles_per_bag, (int)n_items, (int)per);
+    dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+int launch_attend_f3(const AttendArgs& a, const float* rowmax, long long max_rows, int n_bags, hipStream_t st, int* seg_per, int* seg_T) {
+    switch (a.K / 32) {
+        case 4: return launch_attend_f3_k<4>(a, rowmax, max_rows, n_bags, st, seg_per, seg_T);
+        case 8: return launch_attend_f3_k<8>(a, rowmax, max_rows, n_bags, st, seg_per, seg_T);
+        case 12: return launch_attend_f3_k<12>(a, rowmax, max_rows, n_bags, st, seg_per, seg_T);
+        case 16: return launch_attend_f3_k<16>(a, rowmax, max_rows, n_bags, st, seg_per, seg_T);
+        default: return DSMIL_E_UNSUPPORTED;
+    }
 }
 
 int mlp_mode() {
@@ -1416,7 +1449,7 @@ int dsmil_abi_version(void) { return DSMIL_ABI_VERSION; }
 
 int dsmil_agg_mlp_form(void) { return mlp_mode(); }
 int dsmil_agg_batch_form(int mode) {
-    if (mode == 0 || mode == 1) return g_use_f2.exchange(mode);
+    if (mode >= 0 && mode <= 2) return g_use_f2.exchange(mode);
     return g_use_f2.load();
 }
 int dsmil_agg_inline_query(int mode) {
@@ -1622,7 +1655,9 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
 #ifdef DSMIL_EXPERIMENTS
         if (a.expt & 512) bf16_res = false;
 #endif
-        if (use_f2) { rc = launch_attend_f2(a, rowmax, max_rows, nb, st); hs_bm = F2_BM; }
+        const bool use_f3 = use_f2 && p->nonlinear && C <= 2 && g_use_f2.load(std::memory_order_relaxed) == 2;
+        if (use_f3) { rc = launch_attend_f3(a, rowmax, max_rows, nb, st, &seg_per, &seg_T); hs_bm = F3_BM; }
+        else if (use_f2) { rc = launch_attend_f2(a, rowmax, max_rows, nb, st); hs_bm = F2_BM; }
         else if (bf16_res) rc = launch_attend_bf16_res(a, max_rows, nb, st, &seg_per, &seg_T);
         else if (bf16_dma) rc = launch_attend_bf16_dma(a, max_rows, nb, st);
         else if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, nb, st) : launch_attend_bf16<1>(a, max_rows, nb, st);
@@ -1646,7 +1681,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     if (!DSMIL_EXPT_ON(a, 64)) {
         dim3 grid((unsigned)L.nchunk_max, (unsigned)n_bags);
         if (Kv % 4 == 0)
-            hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, seg_per ? RS_BM : (hs_bm ? hs_bm : BM), sh.ml_out, seg_per, seg_T);
+            hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, hs_bm ? hs_bm : (seg_per ? RS_BM : BM), sh.ml_out, seg_per, seg_T);
         else
             hipLaunchKernelGGL(k_finish<1>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM, sh.ml_out, 0, 0);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;

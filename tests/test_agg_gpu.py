@@ -205,9 +205,12 @@ def test_varlen_batch_equals_per_bag(golden):
             np.testing.assert_allclose(u.cpu().numpy(), v.detach().cpu().numpy(), atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("tag", ["c16", "tcga", "linq"])
-def test_batch_form_f2_vs_oracle_and_six_product_form(tag):
-    """k_attend_f2 (round 5: resident 64-row tiles, fp16 two-plane cuts of the row-scaled operands, three plane products) on
+def test_batch_form_f2_vs_oracle_and_six_product_form(tag, form):
+    """form 1: k_attend_f2 (round 5: resident 64-row tiles, fp16 two-plane cuts of the row-scaled operands, three plane
+    products); form 2: k_attend_f3 (the same arithmetic, 32-row tiles, the query weights resident in registers, one partial
+    per (workgroup, bag); a linear query stays on k_attend_f2) — on
     a ragged batch in the 128-row regime whose bags live on very different scales (rows x 1e-3, x 1, x 300; one bag with a
     1e4 dynamic range between its rows): every output within the parity bar of the fp64 oracle, and within 2e-5 of the
     six-product bf16 form of rounds 2-4 (dsmil_agg_batch_form(0)) — the two forms are the same fp32-class arithmetic."""
@@ -228,13 +231,13 @@ def test_batch_form_f2_vs_oracle_and_six_product_form(tag):
             x *= (10.0 ** np.random.default_rng(5).uniform(-2, 2, size=(n, 1))).astype(np.float32)
         bags.append(x)
     x = torch.from_numpy(np.concatenate(bags)).cuda()
-    prev = L.dsmil_agg_batch_form(1)
+    prev = L.dsmil_agg_batch_form(form)
     try:
         got = [t.clone() for t in ops.agg_forward(x, lengths, p, nonlinear=nonlinear)]
         L.dsmil_agg_batch_form(0)
         old = [t.clone() for t in ops.agg_forward(x, lengths, p, nonlinear=nonlinear)]
     finally:
-        L.dsmil_agg_batch_form(prev if prev in (0, 1) else 1)
+        L.dsmil_agg_batch_form(prev)
     off = np.concatenate([[0], np.cumsum(lengths)])
     for b, n in enumerate(lengths):
         sl = slice(int(off[b]), int(off[b + 1]))
@@ -251,11 +254,20 @@ def test_batch_form_f2_vs_oracle_and_six_product_form(tag):
         np.testing.assert_allclose(pred, old[1][b:b + 1].cpu().numpy(), atol=2e-5 * sc, rtol=1e-5)
 
 
-def test_batch_form_f2_narrow_features_row_map_and_repeatability():
-    """k_attend_f2 at K = 256 (units past K store nothing), through a row map (dropout_patches as an index list), ten runs
-    bit-identical, vs the fp64 oracle on the gathered rows."""
+@pytest.mark.parametrize("form", [1, 2])
+def test_batch_form_f2_narrow_features_row_map_and_repeatability(form):
+    """k_attend_f2 / k_attend_f3 at K = 256 (units past K store nothing), through a row map (dropout_patches as an index
+    list), ten runs bit-identical, vs the fp64 oracle on the gathered rows."""
     from dsmil_wsi_amd import ops, _native
     L = _native.lib()
+    prev = L.dsmil_agg_batch_form(form)
+    try:
+        _narrow_row_map_case(L, ops)
+    finally:
+        L.dsmil_agg_batch_form(prev)
+
+
+def _narrow_row_map_case(L, ops):
     rng = np.random.default_rng(12)
     K, C = 256, 2
     w = {"fc_w": rng.normal(0, 0.05, (C, K)), "fc_b": rng.normal(0, 0.05, (C,)), "q0_w": rng.normal(0, 0.05, (128, K)),

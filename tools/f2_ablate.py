@@ -21,6 +21,8 @@ def one():
     from dsmil_wsi_amd.synthetic import load_weights
     import numpy as np
     L = _native.lib()
+    if os.environ.get("DSMIL_BATCH_FORM"):               # 1 = k_attend_f2, 2 = k_attend_f3
+        L.dsmil_agg_batch_form(int(os.environ["DSMIL_BATCH_FORM"]))
     p = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in load_weights(os.environ.get("F2_TAG", "c16")).items()}
     n_bags, rows = 64, 10000
     x = torch.randn(n_bags * rows, 512, device="cuda")
