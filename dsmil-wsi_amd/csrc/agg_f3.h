@@ -37,6 +37,35 @@ constexpr int F3_SCR = 1216;                // floats of scratch
 __host__ __device__ constexpr int f3_row_bytes(int K) { return 4 * K + 16; }
 __host__ __device__ constexpr int f3_lds_bytes(int K) { return 2 * F3_BM * f3_row_bytes(K) + F3_BM * F3_HROW + F3_SCR * 4; }
 
+// v_mfma_f32_32x32x16_f16 as inline asm (k_attend_bf16_res's recipe, agg_res.h): the A operand in the accumulator file ("a":
+// the resident W1) or in a VGPR (W2), the accumulator in VGPRs.  With the builtin hipcc put the ACCUMULATORS into the
+// accumulator file, moved W1 fragments out through v_mov copies and — its scheduler in minimum-pressure mode — issued every LDS
+// read right in front of its MFMA (stamps: 5 200 cycles for the 96 MFMAs of a tile).  Inside an asm statement nothing is padded:
+// *0 variants start a chain from the inline constant 0, F3_NOP() stands between the last MFMA and the VALU reads of its result.
+__device__ __forceinline__ void f3_mfma_a(f32x16& acc, const f32x4& a_agpr, const f32x4& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a_agpr), "v"(b));
+}
+__device__ __forceinline__ void f3_mfma_a0(f32x16& acc, const f32x4& a_agpr, const f32x4& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(a_agpr), "v"(b));
+}
+__device__ __forceinline__ void f3_mfma_v(f32x16& acc, const f32x4& a, const f32x4& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void f3_mfma_v0(f32x16& acc, const f32x4& a, const f32x4& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+#define F3_NOP() asm volatile("s_nop 15" ::: "memory")   // 16 states >= the 12 an 8-pass MFMA result needs before a VALU read
+
+// f(integral_constant<int, I>) for I = B .. E-1: every index inside the body is a constant expression (register arrays stay
+// registers whatever the optimiser's pass order)
+template <int B, int E, class F>
+__device__ __forceinline__ void f3_static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        f3_static_for<B + 1, E>(f);
+    }
+}
+
 struct F3Work {
     int bag;
     long long off0, Nb, row0;
@@ -65,13 +94,15 @@ __device__ __forceinline__ bool f3_fetch(const AttendArgs& a, int tiles_per_bag,
 // NK1 = K / 32 in {4, 8, 12, 16}; a.wpk = the image of k_pack_agg_f2; rowmax[logical row] = max_k |x| (k_logits_stream);
 // a.nonlinear, a.C <= 2, vals == feats.  Workgroup g owns the tile items [g per_wg, (g + 1) per_wg) of the (bag, tile) list
 // (tiles_per_bag items per bag) and writes partial slot g + bag for every bag it touches.
-template <int NK1, bool TWO>
+template <int NK1, bool TWO, int DBG = 0>   // DBG 1 (experiment builds, with DSMIL_EXPT=64: k_finish skipped): wave 0 stores s_memtime stamps
+                                            // of the phase boundaries into the tile's 32 rows of A (C = 1; tools/f3_stamps.py)
 __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const float* __restrict__ rowmax, int tiles_per_bag,
                                                              int n_items, int per_wg) {
     static_assert(NK1 % 4 == 0 && NK1 >= 4 && NK1 <= 16, "K a multiple of 128 up to 512");
     constexpr int K = 32 * NK1, NKS = 2 * NK1, NG = NK1 / 2;   // 16-k steps of GEMM 1; 64-k groups of the feature ring
     constexpr int RB = f3_row_bytes(K), BUF = F3_BM * RB;
     constexpr int NC = TWO ? 2 : 1;
+    constexpr bool W2_STREAM = NK1 > 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sX = reinterpret_cast<char*>(smem);              // [2 buffers][32 rows][plane 2][K] fp16 + pad
     char* sH = sX + 2 * BUF;                               // [32 rows][plane 2][128] fp16 + pad; at a flush: [4 waves][NC][K] floats
@@ -103,10 +134,15 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
     for (int s = 0; s < NKS; ++s)
 #pragma unroll
         for (int p = 0; p < 2; ++p) w1[s][p].f = wimg[(long long)s * F2_CHUNK_F4 + (2 * wave + p) * 64 + lane];
+    // (W2's second plane is NOT resident at K = 512: 2 x 256 + 64 weight registers left too few for the LDS reads of GEMM 1 to
+    // run ahead of their MFMAs — hipcc issued every read right in front of its MFMA.  Its 32 KB per tile come from L2 behind
+    // GEMM 1, under the hidden-layer exchange.)
+    const f32x4* w2p1 = wimg + (long long)NKS * F2_CHUNK_F4 + (2 * wave + 1) * 64 + lane;
 #pragma unroll
-    for (int st = 0; st < 8; ++st)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) w2[st][p].f = wimg[(long long)(NKS + st) * F2_CHUNK_F4 + (2 * wave + p) * 64 + lane];
+    for (int st = 0; st < 8; ++st) {
+        w2[st][0].f = wimg[(long long)(NKS + st) * F2_CHUNK_F4 + (2 * wave) * 64 + lane];
+        if constexpr (!W2_STREAM) w2[st][1].f = w2p1[(long long)st * F2_CHUNK_F4];
+    }
     const float ia1 = trailer[0], ia2 = trailer[1];
     sBias[tid] = tid < QD ? a.q0_b[tid] : a.q2_b[tid - QD];
 #pragma unroll
@@ -156,6 +192,40 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
         *reinterpret_cast<f32x4*>(d + 2 * K) = f[1].f;
     };
 
+    // the same cut in pieces that fit into the gaps between the MFMAs of GEMM 1 (a wave issues in order: a 16-instruction cut
+    // behind three queued MFMAs leaves the matrix pipe idle — stamps: 250 cycles per group, 2 000 per tile; four v_fma_mix
+    // per gap still 150 per group): two v_fma_mix per gap, then the two plane writes, then the refill
+    F2Frag cutf[2];
+    auto cut_piece = [&](int pb, auto s_c, auto j_c, float sc, const float* refill_src) {   // behind MFMA j of step s
+        constexpr int s_ = decltype(s_c)::value, j = decltype(j_c)::value;
+        constexpr int c = s_ / 4, ph = (s_ % 4) * 3 + j;  // group c owns the twelve gaps of steps 4c .. 4c+3
+        if constexpr (c < NG) {
+            char* d = cut_dst + pb * BUF + 128 * c;
+            if constexpr (ph < 8) {                       // pair ph / 2: its first plane (even ph), its second (odd ph) — two v_fma_mix per gap
+                constexpr int i = ph / 2;
+                const float va = i < 2 ? ring[c][0][(2 * i) & 3] : ring[c][1][(2 * i) & 3];
+                const float vb = i < 2 ? ring[c][0][(2 * i + 1) & 3] : ring[c][1][(2 * i + 1) & 3];
+                if constexpr (ph % 2 == 0) {
+                    unsigned h;
+                    asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(h) : "v"(va), "v"(vb), "v"(sc));
+                    cutf[0].u[i] = h;
+                } else {
+                    unsigned l;
+                    const unsigned h = cutf[0].u[i];
+                    asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                        : "=&v"(l) : "v"(va), "v"(vb), "v"(sc), "v"(h));
+                    cutf[1].u[i] = l;
+                }
+            } else if constexpr (ph == 8) {
+                *reinterpret_cast<f32x4*>(d) = cutf[0].f;
+            } else if constexpr (ph == 9) {
+                *reinterpret_cast<f32x4*>(d + 2 * K) = cutf[1].f;
+            } else if constexpr (ph == 10) {
+                if constexpr (DBG != 4) fill(refill_src, c);   // (DBG 4: timing without the refills)
+            }
+        }
+    };
+
     float sc_c = 1.f, sinv_c = 1.f, sc_n = 1.f, sinv_n = 1.f, sc_nn = 1.f, sinv_nn = 1.f;
     const float* src_c = row_src(cur, sc_c, sinv_c);
 #pragma unroll
@@ -194,8 +264,15 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
     int qbag = -1;
     float* sPw = sPall + wave * 64;
 
+    unsigned long long stamps[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) stamps[i] = 0;
+    auto STAMP = [&](int i) {
+        if constexpr (DBG >= 1) stamps[i] = __builtin_readcyclecounter();
+    };
     for (int t = 0;; ++t) {
         const int buf = t & 1;
+        STAMP(0);
         if (cur.bag != qbag) {
             // a new bag: its critical queries -> LDS (the previous tile's readers are behind its T1; the S barrier below
             // publishes them), the softmax reference from the same values
@@ -216,36 +293,53 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
         if (!has_n3) n3 = nn;
         row_raw(n3, rm_n3, phys_n3, log_n3);                    // (unconditional: no tile behind -> a harmless re-read of nn's rows)
         __syncthreads();                                  // S
+        STAMP(1);
         const char* xb_ = sX + buf * BUF + l31 * RB + 16 * hi;
         const float* sInv = sInvAll + buf * F3_BM;
         // ---- GEMM 1: H^T[j][n] += W1[j][k] x[n][k], j = this wave's 32 units, n = the 32 rows; Behind every fourth step: one 64-k group of the NEXT tile is cut
         //      into the other buffer and its ring slot refilled with the tile after next.
-        f32x16 Hm;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Hm[r] = 0.f;
+        // (two accumulators taken in turn by consecutive MFMAs: back to back on ONE accumulator a 32x32x16 MFMA issues every
+        // ~60 cycles instead of 32 — stamps: 5 964 cycles for the 96 MFMAs of a tile)
+        f32x16 Hacc[2];
         {
-            F2Frag xa[2], xn[2];
-            xa[0].f = *reinterpret_cast<const f32x4*>(xb_);
-            xa[1].f = *reinterpret_cast<const f32x4*>(xb_ + 2 * K);
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                if (s + 1 < NKS) {
-                    xn[0].f = *reinterpret_cast<const f32x4*>(xb_ + 32 * (s + 1));
-                    xn[1].f = *reinterpret_cast<const f32x4*>(xb_ + 2 * K + 32 * (s + 1));
-                }
-                Hm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[s][1].v, xa[0].v, Hm, 0, 0, 0);   // (smallest products first)
-                Hm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[s][0].v, xa[1].v, Hm, 0, 0, 0);
-                Hm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[s][0].v, xa[0].v, Hm, 0, 0, 0);
-                if (s % 4 == 1) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    cut_write(buf ^ 1, s / 4, sc_n);
-                    fill(src_nn, s / 4);                  // (pinned: hipcc otherwise sinks all sixteen loads to the end of GEMM 1)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (s + 1 < NKS) { xa[0] = xn[0]; xa[1] = xn[1]; }
-            }
+            F2Frag xs[3][2];                              // B fragments, read two steps ahead of their MFMAs (order pinned below)
+            auto rd = [&](int s_, F2Frag (&d)[2]) {
+                d[0].f = *reinterpret_cast<const f32x4*>(xb_ + 32 * s_);
+                d[1].f = *reinterpret_cast<const f32x4*>(xb_ + 2 * K + 32 * s_);
+            };
+            rd(0, xs[0]);
+            rd(1, xs[1]);
+            f3_static_for<0, NKS>([&](auto s_c) {
+                constexpr int s = decltype(s_c)::value;
+                using J0 = std::integral_constant<int, 0>;
+                using J1 = std::integral_constant<int, 1>;
+                using J2 = std::integral_constant<int, 2>;
+                if constexpr (DBG != 3 && s + 2 < NKS) rd(s + 2, xs[(s + 2) % 3]);   // (DBG 3: timing without the LDS reads of GEMM 1)
+                __builtin_amdgcn_sched_barrier(0);
+                // (two accumulators taken in turn: back to back on ONE accumulator the MFMAs issue every ~60 cycles instead of 32)
+                if constexpr (s == 0) f3_mfma_a0(Hacc[0], w1[s][1].f, xs[s % 3][0].f);
+                else f3_mfma_a(Hacc[s & 1], w1[s][1].f, xs[s % 3][0].f);
+                if constexpr (DBG != 2) cut_piece(buf ^ 1, s_c, J0{}, sc_n, src_nn);   // (DBG 2: timing without the cut of the next tile)
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (s == 0) f3_mfma_a0(Hacc[1], w1[s][0].f, xs[s % 3][1].f);
+                else f3_mfma_a(Hacc[~s & 1], w1[s][0].f, xs[s % 3][1].f);
+                if constexpr (DBG != 2) cut_piece(buf ^ 1, s_c, J1{}, sc_n, src_nn);
+                __builtin_amdgcn_sched_barrier(0);
+                f3_mfma_a(Hacc[s & 1], w1[s][0].f, xs[s % 3][0].f);
+                if constexpr (DBG != 2) cut_piece(buf ^ 1, s_c, J2{}, sc_n, src_nn);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (s == 7) STAMP(10);
+                if constexpr (s == 15) STAMP(11);
+                if constexpr (s == 23) STAMP(12);
+            });
+            F3_NOP();
         }
         if (o == 0) sInvAll[(buf ^ 1) * F3_BM + myrow] = sinv_n;
+        if constexpr (W2_STREAM) {
+#pragma unroll
+            for (int st = 0; st < 8; ++st) w2[st][1].f = *(const DSMIL_GLOBAL f32x4*)(w2p1 + (long long)st * F2_CHUNK_F4);
+        }
+        STAMP(2);
         // ---- un-scale, bias, ReLU: reg 4q+e <-> unit 32 wave + 8q + 4hi + e, row l31
         const float iv1 = ia1 * sInv[l31];
         float hmax = 0.f;
@@ -255,7 +349,7 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
             const f32x4 bq = *reinterpret_cast<const f32x4*>(sBias + 32 * wave + 8 * q + 4 * hi);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float v = fmaxf(fmaf(Hm[4 * q + e], iv1, bq[e]), 0.f);
+                const float v = fmaxf(fmaf(Hacc[0][4 * q + e] + Hacc[1][4 * q + e], iv1, bq[e]), 0.f);
                 H[4 * q + e] = v;
                 hmax = fmaxf(hmax, v);
             }
@@ -263,6 +357,7 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
         hmax = fmaxf(hmax, __shfl_xor(hmax, 32, 64));
         if (hi == 0) sMax[wave * F3_BM + l31] = hmax;
         __syncthreads();                                  // B1
+        STAMP(3);
         float hsc, hinv;
         hsc = f2_scale(fmaxf(fmaxf(sMax[l31], sMax[F3_BM + l31]), fmaxf(sMax[2 * F3_BM + l31], sMax[3 * F3_BM + l31])), hinv);
         // registers 8sx .. 8sx+7 are, for row l31, the 8 hidden units of GEMM-2 step 2 wave + sx (the k permutation the packed
@@ -278,26 +373,34 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
             *reinterpret_cast<f32x4*>(d + 256) = f[1].f;
         }
         __syncthreads();                                  // B2
-        f32x16 Qm;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Qm[r] = 0.f;
+        STAMP(4);
+        f32x16 Qacc[2];
         {
             const char* hb_ = sH + l31 * F3_HROW + 16 * hi;
-            F2Frag xa[2], xn[2];
-            xa[0].f = *reinterpret_cast<const f32x4*>(hb_);
-            xa[1].f = *reinterpret_cast<const f32x4*>(hb_ + 256);
+            F2Frag hs[3][2];
+            auto rdh = [&](int st_, F2Frag (&d)[2]) {
+                d[0].f = *reinterpret_cast<const f32x4*>(hb_ + 32 * st_);
+                d[1].f = *reinterpret_cast<const f32x4*>(hb_ + 256 + 32 * st_);
+            };
+            rdh(0, hs[0]);
+            rdh(1, hs[1]);
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                if (st + 1 < 8) {
-                    xn[0].f = *reinterpret_cast<const f32x4*>(hb_ + 32 * (st + 1));
-                    xn[1].f = *reinterpret_cast<const f32x4*>(hb_ + 256 + 32 * (st + 1));
+                if (st + 2 < 8) rdh(st + 2, hs[(st + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st == 0) {
+                    f3_mfma_v0(Qacc[0], w2[st][1].f, hs[st % 3][0].f);
+                    f3_mfma_v0(Qacc[1], w2[st][0].f, hs[st % 3][1].f);
+                } else {
+                    f3_mfma_v(Qacc[st & 1], w2[st][1].f, hs[st % 3][0].f);
+                    f3_mfma_v(Qacc[~st & 1], w2[st][0].f, hs[st % 3][1].f);
                 }
-                Qm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[st][1].v, xa[0].v, Qm, 0, 0, 0);
-                Qm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[st][0].v, xa[1].v, Qm, 0, 0, 0);
-                Qm = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[st][0].v, xa[0].v, Qm, 0, 0, 0);
-                if (st + 1 < 8) { xa[0] = xn[0]; xa[1] = xn[1]; }
+                f3_mfma_v(Qacc[st & 1], w2[st][0].f, hs[st % 3][0].f);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            F3_NOP();
         }
+        STAMP(5);
         // ---- tanh; partial scores over this wave's 32 query units (dsmil.py:55-56)
         {
             const float iv2 = ia2 * hinv;
@@ -310,7 +413,7 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
                 if constexpr (TWO) u1 = *reinterpret_cast<const f32x4*>(sQ + QD + 32 * wave + 8 * q + 4 * hi);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float qv = fast_tanh(fmaf(Qm[4 * q + e], iv2, bq[e]));
+                    const float qv = fast_tanh(fmaf(Qacc[0][4 * q + e] + Qacc[1][4 * q + e], iv2, bq[e]));
                     s0 = fmaf(qv, u0[e], s0);
                     if constexpr (TWO) s1 = fmaf(qv, u1[e], s1);
                 }
@@ -322,7 +425,9 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
                 if constexpr (TWO) sS[(wave * 2 + 1) * F3_BM + l31] = s1;
             }
         }
+        STAMP(6);
         __syncthreads();                                  // T1
+        STAMP(7);
         // ---- scores, softmax weights relative to the bag's constant reference: every wave for itself (lane & 31 = row; the
         //      same values in every wave), weights for its own eight rows' value sum into its private strip
         {
@@ -335,10 +440,11 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
                                  (sS[(2 * 2 + c) * F3_BM + l31] + sS[(3 * 2 + c) * F3_BM + l31])) * scale;
                 const float p = valid ? expf(s - m_bag[c]) : 0.f;
                 if (hi == 0) l_run[c] += p;
-                if (wave == 0 && hi == 0 && valid) a.scores[(cur.off0 + grow) * (long long)a.C + c] = s;
+                if (DBG == 0 && wave == 0 && hi == 0 && valid) a.scores[(cur.off0 + grow) * (long long)a.C + c] = s;
                 if (hi == 0) sPw[c * F3_BM + l31] = p * rinv;
             }
         }
+        STAMP(8);
         // ---- value sum (dsmil.py:57) from the resident planes: lane = k-octet, this wave's rows 8 wave .. 8 wave + 7
         if (lane < K / 8) {
             const char* xv = sX + buf * BUF + (8 * wave) * RB + 16 * lane;
@@ -356,6 +462,14 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
                         bacc[c][e] = fmaf((float)f1.v[e], w, bacc[c][e]);
                     }
                 }
+            }
+        }
+        STAMP(9);
+        if constexpr (DBG >= 1) {
+            if (tid == 0 && !TWO && cur.row0 + F3_BM <= cur.Nb) {
+                unsigned long long* so = reinterpret_cast<unsigned long long*>(a.scores + (cur.off0 + cur.row0));
+#pragma unroll
+                for (int i = 0; i < 16; ++i) so[i] = stamps[i];
             }
         }
         // ---- end of this workgroup's part of the bag: one (m, l, B) partial, slot = blockIdx.x + bag

@@ -1313,6 +1313,13 @@ int launch_attend_f2(const AttendArgs& a, const float* rowmax, long long max_row
 template <int NK1>
 int launch_attend_f3_k(const AttendArgs& a, const float* rowmax, long long max_rows, int n_bags, hipStream_t st, int* seg_per, int* seg_T) {
     void (*fn)(AttendArgs, const float*, int, int, int) = a.C == 2 ? k_attend_f3<NK1, true> : k_attend_f3<NK1, false>;
+#ifdef DSMIL_EXPERIMENTS
+    static const int f3_dbg = expt_env("DSMIL_F3_DBG");
+    if (NK1 == 16 && a.C == 1 && f3_dbg == 1) fn = k_attend_f3<16, false, 1>;
+    if (NK1 == 16 && a.C == 1 && f3_dbg == 2) fn = k_attend_f3<16, false, 2>;
+    if (NK1 == 16 && a.C == 1 && f3_dbg == 3) fn = k_attend_f3<16, false, 3>;
+    if (NK1 == 16 && a.C == 1 && f3_dbg == 4) fn = k_attend_f3<16, false, 4>;
+#endif
     constexpr int lds = f3_lds_bytes(32 * NK1);
     if (!dsmil_lds::allow((const void*)fn, lds)) return DSMIL_E_LAUNCH;
     int cus = device_cus();
