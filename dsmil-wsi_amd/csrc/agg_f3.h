@@ -71,22 +71,34 @@ struct F3Work {
     long long off0, Nb, row0;
 };
 
-// first item in [item, end) whose tile lies inside its bag (evaluated identically by every wave)
-__device__ __forceinline__ bool f3_fetch(const AttendArgs& a, int tiles_per_bag, int end, int& item, F3Work& w) {
-    while (item < end) {
-        const int b = item / tiles_per_bag, tile = item - b * tiles_per_bag;
-        const int bag = a.bag0 + b;
-        // (through the constant address space: scalar loads.  As plain loads behind the tile's stores hipcc makes them VECTOR loads
-        // with a uniform address, and their vmcnt(0) then waits for every refill of the feature ring issued before them)
-        const __attribute__((address_space(4))) long long* offs = (const __attribute__((address_space(4))) long long*)(uintptr_t)a.offsets;
+// position in the (bag, tile) item list: item = b * tiles_per_bag + tile, kept WITHOUT a division per step (the quotient by a
+// run-time divisor is ~40 instructions; the lookahead runs once per tile in front of a barrier)
+struct F3Cur {
+    int item, b, tile;
+};
+__device__ __forceinline__ F3Cur f3_next(F3Cur c, int tiles_per_bag) {
+    ++c.item;
+    if (++c.tile == tiles_per_bag) { c.tile = 0; ++c.b; }
+    return c;
+}
+
+// first item at or behind c, below `end`, whose tile lies inside its bag (evaluated identically by every wave); c is left on it
+__device__ __forceinline__ bool f3_fetch(const AttendArgs& a, int tiles_per_bag, int end, F3Cur& c, F3Work& w) {
+    // (through the constant address space: scalar loads.  As plain loads behind the tile's stores hipcc makes them VECTOR loads
+    // with a uniform address, and their vmcnt(0) then waits for every refill of the feature ring issued before them)
+    const __attribute__((address_space(4))) long long* offs = (const __attribute__((address_space(4))) long long*)(uintptr_t)a.offsets;
+    while (c.item < end) {
+        const int bag = a.bag0 + c.b;
         const long long off0 = offs[bag];
         const long long Nb = offs[bag + 1] - off0;
-        const long long row0 = (long long)tile * F3_BM;
+        const long long row0 = (long long)c.tile * F3_BM;
         if (row0 < Nb) {
             w.bag = bag; w.off0 = off0; w.Nb = Nb; w.row0 = row0;
             return true;
         }
-        ++item;
+        c.item += tiles_per_bag - c.tile;                 // the rest of this bag's items lie behind its end
+        c.tile = 0;
+        ++c.b;
     }
     return false;
 }
@@ -121,10 +133,13 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
     const float* feats = reinterpret_cast<const float*>(a.feats);
     const float scale = 0.08838834764831845f;              // 1/sqrt(128), dsmil.py:56
 
-    int item = (int)blockIdx.x * per_wg;
-    const int item_end = item + per_wg < n_items ? item + per_wg : n_items;
+    F3Cur pos;
+    pos.item = (int)blockIdx.x * per_wg;
+    pos.b = pos.item / tiles_per_bag;
+    pos.tile = pos.item - pos.b * tiles_per_bag;
+    const int item_end = pos.item + per_wg < n_items ? pos.item + per_wg : n_items;
     F3Work cur, nxt, nn;
-    if (!f3_fetch(a, tiles_per_bag, item_end, item, cur)) return;   // (block-uniform)
+    if (!f3_fetch(a, tiles_per_bag, item_end, pos, cur)) return;   // (block-uniform)
 
     // ---- resident weights: this wave's A fragments of every 16-k step, both planes.  W1 is pinned to the accumulator file
     //      (an MFMA may take its A operand from there; the empty asm makes the tuple live there for the whole launch), W2 and
@@ -230,8 +245,8 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
     const float* src_c = row_src(cur, sc_c, sinv_c);
 #pragma unroll
     for (int c = 0; c < NG; ++c) fill(src_c, c);
-    int it_n = item + 1;
-    bool has_next = f3_fetch(a, tiles_per_bag, item_end, it_n, nxt);
+    F3Cur pos_n = f3_next(pos, tiles_per_bag);
+    bool has_next = f3_fetch(a, tiles_per_bag, item_end, pos_n, nxt);
     const float* src_n = has_next ? row_src(nxt, sc_n, sinv_n) : src_c;
     if (!has_next) { nxt = cur; sc_n = sc_c; sinv_n = sinv_c; }
     // tile 0: cut into buffer 0, ring <- tile 1
@@ -241,8 +256,8 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
         fill(src_n, c);
     }
     if (o == 0) sInvAll[myrow] = sinv_c;
-    int it_nn = it_n + 1;
-    bool has_nn = has_next && f3_fetch(a, tiles_per_bag, item_end, it_nn, nn);
+    F3Cur pos_nn = f3_next(pos_n, tiles_per_bag);
+    bool has_nn = has_next && f3_fetch(a, tiles_per_bag, item_end, pos_nn, nn);
     const float* src_nn = has_nn ? row_src(nn, sc_nn, sinv_nn) : src_n;
     if (!has_nn) { nn = nxt; sc_nn = sc_n; sinv_nn = sinv_n; }
 
@@ -285,11 +300,11 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
         }
         // the tile after the one after next: its record (scalar loads), its rows' maxima and addresses (two vector loads, issued
         // BEFORE this tile's ring refills and consumed at the end of the tile: the wait then leaves the refills in flight)
-        int it_n3 = it_nn + 1;
+        F3Cur pos_n3 = f3_next(pos_nn, tiles_per_bag);
         F3Work n3 = nn;
         float rm_n3;
         long long phys_n3, log_n3;
-        const bool has_n3 = has_nn && f3_fetch(a, tiles_per_bag, item_end, it_n3, n3);
+        const bool has_n3 = has_nn && f3_fetch(a, tiles_per_bag, item_end, pos_n3, n3);
         if (!has_n3) n3 = nn;
         row_raw(n3, rm_n3, phys_n3, log_n3);                    // (unconditional: no tile behind -> a harmless re-read of nn's rows)
         __syncthreads();                                  // S
@@ -507,7 +522,7 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
         if (!has_next) break;
         cur = nxt; nxt = nn; nn = n3;
         has_next = has_nn; has_nn = has_n3;
-        it_nn = it_n3;
+        pos_nn = pos_n3;
         sc_c = sc_n; sinv_c = sinv_n;
         sc_n = sc_nn; sinv_n = sinv_nn; src_n = src_nn;
         asm volatile("" : "+v"(rm_n3), "+v"(phys_n3));   // (the lookups are consumed HERE, a tile after they were issued)
