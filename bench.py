@@ -33,7 +33,7 @@ HIP streams (ops.StreamPool, default 3: one workspace per stream): the HBM-bound
 MFMA-bound attend kernel of another, and the few-round kernels of one embedder forward fill each other's tails.
 `--streams 1` keeps one pass in flight.
 
-`roofline` is for the dominant kernel of the headline leg (k_attend_f2), timed live with HIP events on its
+`roofline` is for the dominant kernel of the headline leg (k_attend_f3), timed live with HIP events on its
 launch stream inside the library.  With several streams a launch's start-to-end interval inside the timed region also
 contains the kernels co-running with it, so the kernel's OWN duration is measured in a second region right after the
 timed one (same inputs, one pass in flight, 300 passes); the in-region interval is reported beside it.
@@ -354,10 +354,12 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
     peak_exec = PEAK_BF16_MFMA_TFLOPS / form if form else PEAK_F32_MFMA_TFLOPS
     t_roof_f32 = max(flops_per_bag(N, K, C) / (PEAK_F32_MFMA_TFLOPS * 1e12), bytes_per_bag(N, K, C) / (PEAK_HBM_GBS * 1e9))
     t_roof_exec = max(flops_per_bag(N, K, C) / (peak_exec * 1e12), bytes_per_bag(N, K, C) / (PEAK_HBM_GBS * 1e9))
-    f2 = (form == 6 and int(cx.L.dsmil_agg_batch_form(-1)) == 1 and int(cx.L.dsmil_agg_tile_rows(nb, nb * N)) == 128
+    batch_form = int(cx.L.dsmil_agg_batch_form(-1))
+    f2 = (form == 6 and batch_form in (1, 2) and int(cx.L.dsmil_agg_tile_rows(nb, nb * N)) == 128
           and K % 128 == 0 and K <= 512)
+    f2_kernel = "k_attend_f3" if (batch_form == 2 and C <= 2) else "k_attend_f2"   # (bench weights: the two-layer query)
     if f2:
-        # k_attend_f2 (round 5): every feature byte read once, the query MLP as THREE fp16 plane products per fp32 MAC.  The
+        # k_attend_f2 / k_attend_f3 (round 5): every feature byte read once, the query MLP as THREE fp16 plane products per fp32 MAC.  The
         # executed matrix work of a launch (3 x algorithmic FLOPs at the 2.5 PF f16 / bf16 dense rate) is shorter than its
         # algorithmic bytes at 8 TB/s, so HBM is the roof that binds this kernel; the matrix-pipe figure is kept beside it.
         by = bytes_per_bag(N, K, C) * nb
@@ -365,7 +367,7 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
         peak3 = PEAK_BF16_MFMA_TFLOPS / 3
         t_roof_exec = max(flops_per_bag(N, K, C) / (peak3 * 1e12), bytes_per_bag(N, K, C) / (PEAK_HBM_GBS * 1e9))
         line["roofline"] = {
-            "kernel": "k_attend_f2", "bound": "hbm", "achieved": round(gbs, 1) if gbs else None, "peak": PEAK_HBM_GBS,
+            "kernel": f2_kernel, "bound": "hbm", "achieved": round(gbs, 1) if gbs else None, "peak": PEAK_HBM_GBS,
             "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4) if gbs else None,
             "bound_is": "algorithmic bytes / 8 TB/s = %.3f ms per launch > 3 x algorithmic FLOPs / 2.5 PF = %.3f ms (fp16 MFMA over two-plane cuts, three plane products per fp32 MAC)"
                         % (by / (PEAK_HBM_GBS * 1e9) * 1e3, 3 * fl / (PEAK_BF16_MFMA_TFLOPS * 1e12) * 1e3),
@@ -373,7 +375,7 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
             "mfma_achieved_tflops": round(achieved, 2) if achieved else None, "mfma_peak_tflops": round(peak3, 1),
             "mfma_frac": round(achieved / peak3, 4) if achieved else None,
             "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4) if achieved else None,
-            "traffic": _pmc("pmc_k_attend_f2.json", "hbm_bytes_per_launch") if (nb, N, K) == (64, 10000, 512) else None,
+            "traffic": _pmc("pmc_%s.json" % f2_kernel, "hbm_bytes_per_launch") if (nb, N, K) == (64, 10000, 512) else None,
             "alg_bytes_per_launch": by, "kernel_ms": round(kern_ms, 4), "launches": launches, "alg_flops_per_launch": fl,
             "kernel_ms_in_timed_region": round(kern_region_ms, 4),
             "kernel_ms_is": "average HIP-event duration of the kernel with ONE pass in flight (300 passes on one stream right after the timed region, same inputs): the kernel's own time. Inside the timed region config.streams passes overlap, so a launch's start-to-end interval (kernel_ms_in_timed_region) also contains the co-running streams' kernels and is not a measure of the kernel",

@@ -1231,9 +1231,9 @@ int device_cus() {
 // dsmil_agg_inline_query(): 1 = the critical row's query may run inside the k_attend_hs launch (default), 0 = always the
 // separate k_qmax launch
 std::atomic<int> g_inline_query{1};
-// dsmil_agg_batch_form(): 1 = batches of fp32 bags take k_attend_f2 (default), 0 = k_query_attend_split (rounds 2-4)
-// ... 2 = k_attend_f3 (weights resident in registers, 32-row tiles; two-layer query, C <= 2 — k_attend_f2 otherwise)
-std::atomic<int> g_use_f2{1};
+// dsmil_agg_batch_form(): 2 (default) = batches of fp32 bags take k_attend_f3 (weights resident in registers, 32-row tiles;
+// two-layer query and C <= 2 — k_attend_f2 otherwise), 1 = k_attend_f2 always, 0 = k_query_attend_split (rounds 2-4)
+std::atomic<int> g_use_f2{2};
 
 // The in-launch hand-off needs its producers to RUN while tiles spin on their flags.  Producers are the first workgroups of
 // every grid row and the hardware dispatches a grid in order, but HIP promises neither: the query is inlined only when

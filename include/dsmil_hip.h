@@ -139,11 +139,14 @@ int dsmil_agg_mlp_form(void);
 int dsmil_agg_inline_query(int mode);
 
 /* Which kernel a BATCH of fp32 bags (>= 512 tiles of 128 rows; v = Identity; K a multiple of 128 up to 512) takes for
- * dsmil.py:49-57: mode 1 (default) = k_attend_f2 — 64-row tiles resident in LDS from the query MLP to the value sum (every
- * feature byte read once), the MLP on fp16 MFMA over two-plane cuts of the row-scaled operands, three plane products
- * (fp32-class accuracy: csrc/agg_f2.h, tools/form_error_study.py); mode 0 = k_query_attend_split of rounds 2-4 (bf16 MFMA,
- * exact three-plane cuts, six products, the tile read twice).  Process-wide; returns the previous mode; any other `mode`
- * only queries.  tests/test_agg_gpu.py compares the two. */
+ * dsmil.py:49-57.  All modes are the same fp32-class arithmetic (tests/test_agg_gpu.py compares them):
+ *   2 (default)  k_attend_f3 (csrc/agg_f3.h) for the two-layer query with C <= 2: the query weights stay in registers for
+ *                the whole launch, 32-row tiles resident in LDS from the query MLP to the value sum (every feature byte read
+ *                once), fp16 MFMA over two-plane cuts of the row-scaled operands, three plane products, one partial per
+ *                (workgroup, bag); every other case as mode 1;
+ *   1            k_attend_f2 (csrc/agg_f2.h): the same arithmetic on 64-row tiles, weights streamed from L2 per tile;
+ *   0            k_query_attend_split of rounds 2-4 (bf16 MFMA, exact three-plane cuts, six products, the tile read twice).
+ * Process-wide; returns the previous mode; any other `mode` only queries. */
 int dsmil_agg_batch_form(int mode);
 
 /* Options of dsmil_agg_forward_ex (all optional; a NULL opts or an all-zero struct = dsmil_agg_forward):

@@ -48,14 +48,15 @@ table = {"source": f"profiles/{tag}_agg, profiles/{tag}_emb: rocprofv3 --kernel-
 rows, pmc = load("agg")
 feat32, feat16 = NB * N * K * 4, NB * N * K * 2
 mlp_flops = NB * (2 * N * K * Q + 2 * N * Q * Q)
-passes32 = max(int(r["Calls"]) for r in rows if r["Name"].startswith("k_query_attend_split") or r["Name"].startswith("k_attend_f2"))
+passes32 = max(int(r["Calls"]) for r in rows if r["Name"].startswith("k_query_attend_split") or r["Name"].startswith("k_attend_f2") or r["Name"].startswith("k_attend_f3"))
 passes16 = max(int(r["Calls"]) for r in rows if r["Name"].startswith("k_attend_bf16_res"))
 agg32, agg16 = [], []
 for r in rows:
     k, calls = r["Name"], int(r["Calls"])
-    if k.startswith("k_attend_f2"):
+    if k.startswith("k_attend_f2") or k.startswith("k_attend_f3"):
         agg32.append(row(r, pmc, 1, alg_bytes=feat32, executed_mfma_flops=3 * mlp_flops, alg_flops=mlp_flops,
-                         note="round 5: 64-row tiles resident in LDS (features read once), query MLP as 3 fp16 plane products per fp32 MAC"))
+                         note="round 5: tiles resident in LDS (features read once), query MLP as 3 fp16 plane products per fp32 MAC"
+                              + ("; 32-row tiles, query weights resident in registers, one partial per (workgroup, bag)" if k.startswith("k_attend_f3") else "; 64-row tiles, weights from L2 per tile")))
     elif k.startswith("k_query_attend_split"):
         agg32.append(row(r, pmc, 1, alg_bytes=feat32, executed_mfma_flops=6 * mlp_flops, alg_flops=mlp_flops,
                          note="query MLP as 6 bf16 plane products per fp32 MAC; features read twice (MLP, value sum)"))

@@ -63,6 +63,7 @@ how = "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate rocprofv3 --pmc passes (tools/r
 if which == "agg":
     for fname, pref, alg in (("pmc_k_query_attend.json", "k_query_attend_split", 1337271040),
                              ("pmc_k_attend_f2.json", "k_attend_f2", 1337271040),
+                             ("pmc_k_attend_f3.json", "k_attend_f3", 1337271040),
                              ("pmc_k_attend_bf16_res.json", "k_attend_bf16_res", 676774912),
                              ("pmc_k_query_attend_bf16.json", "k_query_attend_bf16", 676774912)):
         ks = [k for k in out if k.startswith(pref) and "hbm_bytes_per_launch" in out[k]]
