@@ -663,16 +663,19 @@ __global__ __launch_bounds__(256, 2) void k_tn_split(TnArgs a) {
             S3Frag fb[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) fb[p].f = *reinterpret_cast<const f32x4*>(&sB[(p * 64 + 32 * ct + l31) * TN_LDW + 4 * j]);
+            // (the two accumulators in turn: back to back on ONE accumulator a 32x32x16 MFMA issues every ~60 cycles instead of
+            // 32 — measured on k_attend_f3; the products of each accumulator keep their order, the results their bits)
+            S3Frag fa[2][3];
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                S3Frag fa[3];
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
-                    fa[p].f = *reinterpret_cast<const f32x4*>(&sA[(p * QD + 32 * (2 * up + tt) + l31) * TN_LDW + 4 * j]);
+                    fa[tt][p].f = *reinterpret_cast<const f32x4*>(&sA[(p * QD + 32 * (2 * up + tt) + l31) * TN_LDW + 4 * j]);
 #pragma unroll
-                for (int qq = P0; qq < 9; ++qq)
-                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S3_PA(qq)].v, fb[S3_PB(qq)].v, acc[tt], 0, 0, 0);
-            }
+            for (int qq = P0; qq < 9; ++qq)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tt][S3_PA(qq)].v, fb[S3_PB(qq)].v, acc[tt], 0, 0, 0);
         }
     };
     if constexpr (WIDE) {
