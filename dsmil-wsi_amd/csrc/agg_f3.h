@@ -6,13 +6,15 @@
 // (the launch on 64 workgroups takes the same time per tile as on 256).  Taller tiles would amortise the weights but do not
 // fit LDS.  k_attend_bf16_res (agg_res.h) showed the way out for bf16 bags: one wave per SIMD may hold 512 registers, so
 //   * one 256-thread workgroup per CU; wave w keeps the A fragments of ITS 32 hidden / query units for the whole launch:
-//     W1 (two fp16 planes x K <= 512: up to 256 registers) in the ACCUMULATOR half of the register file, W2 (64 registers)
-//     in VGPRs.  No weight byte moves after the prologue, so a short tile costs nothing:
+//     W1 (two fp16 planes x K <= 512: up to 256 registers) in the ACCUMULATOR half of the register file, W2's first plane in
+//     VGPRs (its second plane too up to K = 256; at K = 512 it is re-read from L2 once per tile, under the hidden-layer
+//     exchange: 32 KB).  The MFMAs are inline asm with "a" weight operands and VGPR accumulators (k_attend_bf16_res's recipe;
+//     f3_mfma_* below say why).  No W1 byte moves after the prologue, so a short tile costs nothing:
 //   * tile = 32 rows, TWO plane buffers in LDS (row-major [row][plane][K] fp16 with a 16-B pad: B fragments, the value
 //     sum's k-contiguous reads and the cut's writes are all conflict-free).  While tile t is in GEMM 1, every wave cuts
 //     ITS eight rows of tile t+1 out of a register ring (filled a tile earlier, as k_attend_f2's cutters do) into the other
-//     buffer and refills the ring with tile t+2 — the cut (16 v_fma_mix per 64 k), the plane writes and the loads sit in
-//     the shadow of the 96 MFMAs;
+//     buffer and refills the ring with tile t+2 — the cut in two-instruction pieces BETWEEN the 96 MFMAs (a wave issues in
+//     order: a whole group behind three queued MFMAs left the matrix pipe idle), then the plane writes, then the loads;
 //   * a workgroup owns a CONTIGUOUS run of tiles (k_attend_bf16_res's scheme): consecutive tiles belong to the same bag, the
 //     softmax reference is a constant of the bag (tanh bounds the queries: |s| <= sum_j |q_max[j]| / sqrt(128) — no tile
 //     maximum, no rescaling), the value sum accumulates ACROSS tiles in eight registers per class (lane = k-octet, wave =
@@ -329,19 +331,19 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
                 using J0 = std::integral_constant<int, 0>;
                 using J1 = std::integral_constant<int, 1>;
                 using J2 = std::integral_constant<int, 2>;
-                if constexpr (DBG != 3 && s + 2 < NKS) rd(s + 2, xs[(s + 2) % 3]);   // (DBG 3: timing without the LDS reads of GEMM 1)
+                if constexpr (DBG != 3 && DBG != 5 && s + 2 < NKS) rd(s + 2, xs[(s + 2) % 3]);   // (DBG 3: timing without the LDS reads of GEMM 1)
                 __builtin_amdgcn_sched_barrier(0);
                 // (two accumulators taken in turn: back to back on ONE accumulator the MFMAs issue every ~60 cycles instead of 32)
                 if constexpr (s == 0) f3_mfma_a0(Hacc[0], w1[s][1].f, xs[s % 3][0].f);
                 else f3_mfma_a(Hacc[s & 1], w1[s][1].f, xs[s % 3][0].f);
-                if constexpr (DBG != 2) cut_piece(buf ^ 1, s_c, J0{}, sc_n, src_nn);   // (DBG 2: timing without the cut of the next tile)
+                if constexpr (DBG != 2 && DBG != 5) cut_piece(buf ^ 1, s_c, J0{}, sc_n, src_nn);   // (DBG 2: timing without the cut of the next tile)
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (s == 0) f3_mfma_a0(Hacc[1], w1[s][0].f, xs[s % 3][1].f);
                 else f3_mfma_a(Hacc[~s & 1], w1[s][0].f, xs[s % 3][1].f);
-                if constexpr (DBG != 2) cut_piece(buf ^ 1, s_c, J1{}, sc_n, src_nn);
+                if constexpr (DBG != 2 && DBG != 5) cut_piece(buf ^ 1, s_c, J1{}, sc_n, src_nn);
                 __builtin_amdgcn_sched_barrier(0);
                 f3_mfma_a(Hacc[s & 1], w1[s][0].f, xs[s % 3][0].f);
-                if constexpr (DBG != 2) cut_piece(buf ^ 1, s_c, J2{}, sc_n, src_nn);
+                if constexpr (DBG != 2 && DBG != 5) cut_piece(buf ^ 1, s_c, J2{}, sc_n, src_nn);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (s == 7) STAMP(10);
                 if constexpr (s == 15) STAMP(11);

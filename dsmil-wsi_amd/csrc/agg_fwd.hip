@@ -1319,6 +1319,7 @@ int launch_attend_f3_k(const AttendArgs& a, const float* rowmax, long long max_r
     if (NK1 == 16 && a.C == 1 && f3_dbg == 2) fn = k_attend_f3<16, false, 2>;
     if (NK1 == 16 && a.C == 1 && f3_dbg == 3) fn = k_attend_f3<16, false, 3>;
     if (NK1 == 16 && a.C == 1 && f3_dbg == 4) fn = k_attend_f3<16, false, 4>;
+    if (NK1 == 16 && a.C == 1 && f3_dbg == 5) fn = k_attend_f3<16, false, 5>;
 #endif
     constexpr int lds = f3_lds_bytes(32 * NK1);
     if (!dsmil_lds::allow((const void*)fn, lds)) return DSMIL_E_LAUNCH;

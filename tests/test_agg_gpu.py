@@ -291,6 +291,35 @@ def _narrow_row_map_case(L, ops):
         _cmp((ref[0][sl], ref[1][b:b + 1], ref[2][sl], ref[3][b:b + 1]), r[0], r[1], r[2], r[3], r[4], ref[4][b].cpu().numpy())
 
 
+@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("K,C", [(128, 1), (384, 2)])
+def test_batch_forms_at_other_feature_widths(K, C, form):
+    """The K = 128 and K = 384 instantiations of k_attend_f2 / k_attend_f3 (K = 512 and 256 are covered above) on a ragged batch
+    whose workgroup runs cross bag boundaries (bags of 1, 31, 33 and 8 191 rows between long ones), vs the fp64 oracle."""
+    from dsmil_wsi_amd import ops, _native
+    L = _native.lib()
+    rng = np.random.default_rng(100 + K)
+    w = {"fc_w": rng.normal(0, 0.05, (C, K)), "fc_b": rng.normal(0, 0.05, (C,)), "q0_w": rng.normal(0, 0.06, (128, K)),
+         "q0_b": rng.normal(0, 0.05, (128,)), "q2_w": rng.normal(0, 0.08, (128, 128)), "q2_b": rng.normal(0, 0.05, (128,)),
+         "fcc_w": rng.normal(0, 0.05, (C, C, K)), "fcc_b": rng.normal(0, 0.05, (C,))}
+    w = {k: v.astype(np.float32) for k, v in w.items()}
+    p = {k: torch.from_numpy(v).cuda() for k, v in w.items()}
+    lengths = [9000, 1, 8191, 31, 12000, 33, 7000, 9500, 10000, 6100, 5000, 4000]
+    assert L.dsmil_agg_tile_rows(len(lengths), sum(lengths)) == 128
+    bags = [make_bag(700 + K + i, n, K) for i, n in enumerate(lengths)]
+    x = torch.from_numpy(np.concatenate(bags)).cuda()
+    prev = L.dsmil_agg_batch_form(form)
+    try:
+        got = [t.clone() for t in ops.agg_forward(x, lengths, p)]
+    finally:
+        L.dsmil_agg_batch_form(prev)
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    for b in range(len(lengths)):
+        sl = slice(int(off[b]), int(off[b + 1]))
+        r = orc.milnet_forward(bags[b], w, dtype="f64")
+        _cmp((got[0][sl], got[1][b:b + 1], got[2][sl], got[3][b:b + 1]), r[0], r[1], r[2], r[3], r[4], got[4][b].cpu().numpy())
+
+
 def test_large_batch_uses_wide_tiles_and_matches():
     """>= 512 tiles of 128 rows switches the launcher to 4-wave workgroups."""
     import dsmil_wsi_amd._native as nat
