@@ -23,7 +23,7 @@
 // Per-row power-of-two scales, the cut, the three products, the packed weight image (k_pack_agg_f2) and the error class are
 // k_attend_f2's (agg_f2.h); so are the tests (tests/test_agg_gpu.py::test_batch_form_*).
 // Only the two-layer query (dsmil.py:31-32 nonlinear, the default) and C <= 2: everything else stays on k_attend_f2.
-// LDS: planes 2 x 32 x (4 K + 16) B (129 KiB at K = 512) | hidden planes 32 x 528 B | 4.8 KiB scratch = 150.3 KiB.
+// LDS: planes 2 x 32 x (4 K + 16) B (129 KiB at K = 512) | hidden planes 32 x 528 B | 6.3 KiB scratch = 151.8 KiB.
 // Barriers per 32-row tile: S (planes of this tile complete, the other buffer and the scratch released), B1 (hidden row
 // maxima), B2 (hidden planes), T1 (partial scores).
 #pragma once
@@ -35,7 +35,7 @@ constexpr int F3_BM = 32;                   // rows per tile
 constexpr int F3_THREADS = 256;             // one wave per SIMD
 constexpr int F3_MAX_WG = 1024;             // (= RS_MAX_WG: the workspace holds that many + n_bags partial slots)
 constexpr int F3_HROW = 528;                // bytes per row of the hidden planes: 2 planes x 256 B + 16 pad
-constexpr int F3_SCR = 1216;                // floats of scratch
+constexpr int F3_SCR = 1600;                // floats of scratch
 __host__ __device__ constexpr int f3_row_bytes(int K) { return 4 * K + 16; }
 __host__ __device__ constexpr int f3_lds_bytes(int K) { return 2 * F3_BM * f3_row_bytes(K) + F3_BM * F3_HROW + F3_SCR * 4; }
 
@@ -121,12 +121,14 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
     char* sX = reinterpret_cast<char*>(smem);              // [2 buffers][32 rows][plane 2][K] fp16 + pad
     char* sH = sX + 2 * BUF;                               // [32 rows][plane 2][128] fp16 + pad; at a flush: [4 waves][NC][K] floats
     float* scr = reinterpret_cast<float*>(sH + F3_BM * F3_HROW);
-    float* sS = scr;            // [4 waves][2 classes][32 rows] partial scores
-    float* sMax = scr + 256;    // [4 waves][32 rows] hidden-layer row maxima
-    float* sBias = scr + 384;   // [2][128]: q.0 / q.2 biases
-    float* sPall = scr + 640;   // [4 waves][2 classes][32 rows]: every wave's private value-sum weights p / row scale
-    float* sInvAll = scr + 896; // [2 buffers][32 rows]: 1 / row scale of the rows whose planes sit in that buffer
-    float* sQ = scr + 960;      // [2 classes][128]: critical queries of the current bag
+    // (partial results of the two lane halves go to LDS side by side: an exchange between the halves is a ds_bpermute round trip
+    // in the middle of a dependent chain, two per tile)
+    float* sS = scr;            // [4 waves][2 halves][2 classes][32 rows] partial scores
+    float* sMax = scr + 512;    // [4 waves][2 halves][32 rows] hidden-layer row maxima
+    float* sBias = scr + 768;   // [2][128]: q.0 / q.2 biases
+    float* sPall = scr + 1024;  // [4 waves][2 classes][32 rows]: every wave's private value-sum weights p / row scale
+    float* sInvAll = scr + 1280; // [2 buffers][32 rows]: 1 / row scale of the rows whose planes sit in that buffer
+    float* sQ = scr + 1344;     // [2 classes][128]: critical queries of the current bag
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -285,7 +287,12 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
 #pragma unroll
     for (int i = 0; i < 16; ++i) stamps[i] = 0;
     auto STAMP = [&](int i) {
-        if constexpr (DBG >= 1) stamps[i] = __builtin_readcyclecounter();
+        if constexpr (DBG >= 1) {                         // (pinned: hipcc otherwise sinks work past the counter read)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory");
+            stamps[i] = __builtin_readcyclecounter();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     for (int t = 0;; ++t) {
         const int buf = t & 1;
@@ -371,12 +378,16 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
                 hmax = fmaxf(hmax, v);
             }
         }
-        hmax = fmaxf(hmax, __shfl_xor(hmax, 32, 64));
-        if (hi == 0) sMax[wave * F3_BM + l31] = hmax;
+        sMax[(wave * 2 + hi) * F3_BM + l31] = hmax;
         __syncthreads();                                  // B1
         STAMP(3);
         float hsc, hinv;
-        hsc = f2_scale(fmaxf(fmaxf(sMax[l31], sMax[F3_BM + l31]), fmaxf(sMax[2 * F3_BM + l31], sMax[3 * F3_BM + l31])), hinv);
+        {
+            float m = sMax[l31];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) m = fmaxf(m, sMax[i * F3_BM + l31]);
+            hsc = f2_scale(m, hinv);
+        }
         // registers 8sx .. 8sx+7 are, for row l31, the 8 hidden units of GEMM-2 step 2 wave + sx (the k permutation the packed
         // W2 carries): scale, cut, publish
 #pragma unroll
@@ -435,12 +446,8 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
                     if constexpr (TWO) s1 = fmaf(qv, u1[e], s1);
                 }
             }
-            s0 += __shfl_xor(s0, 32, 64);
-            if constexpr (TWO) s1 += __shfl_xor(s1, 32, 64);
-            if (hi == 0) {
-                sS[(wave * 2 + 0) * F3_BM + l31] = s0;
-                if constexpr (TWO) sS[(wave * 2 + 1) * F3_BM + l31] = s1;
-            }
+            sS[((wave * 2 + hi) * 2 + 0) * F3_BM + l31] = s0;
+            if constexpr (TWO) sS[((wave * 2 + hi) * 2 + 1) * F3_BM + l31] = s1;
         }
         STAMP(6);
         __syncthreads();                                  // T1
@@ -453,8 +460,8 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
             const float rinv = sInv[l31];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const float s = ((sS[(0 * 2 + c) * F3_BM + l31] + sS[(1 * 2 + c) * F3_BM + l31]) +
-                                 (sS[(2 * 2 + c) * F3_BM + l31] + sS[(3 * 2 + c) * F3_BM + l31])) * scale;
+                auto part = [&](int i) { return sS[(i * 2 + c) * F3_BM + l31]; };   // i = 2 wave + half: a fixed order
+                const float s = (((part(0) + part(1)) + (part(2) + part(3))) + ((part(4) + part(5)) + (part(6) + part(7)))) * scale;
                 const float p = valid ? expf(s - m_bag[c]) : 0.f;
                 if (hi == 0) l_run[c] += p;
                 if (DBG == 0 && wave == 0 && hi == 0 && valid) a.scores[(cur.off0 + grow) * (long long)a.C + c] = s;
@@ -520,6 +527,11 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
                 }
             }
             reset_acc();
+        }
+        STAMP(13);
+        if constexpr (DBG >= 1) {
+            if (tid == 0 && !TWO && cur.row0 + F3_BM <= cur.Nb)
+                reinterpret_cast<unsigned long long*>(a.scores + (cur.off0 + cur.row0))[13] = stamps[13];
         }
         if (!has_next) break;
         cur = nxt; nxt = nn; nn = n3;

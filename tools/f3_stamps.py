@@ -28,7 +28,7 @@ rows_ = []
 for b in range(n_bags):
     for t in range(rows // 32):
         r0 = b * rows + t * 32
-        st = A[r0:r0 + 32].view(np.uint64)[:13].astype(np.int64)
+        st = A[r0:r0 + 32].view(np.uint64)[:14].astype(np.int64)
         if st[0] > 0 and st[9] > st[0]:
             rows_.append(st)
 st = np.array(rows_)
@@ -37,6 +37,7 @@ print(f"{len(st)} tiles")
 for n, v in zip(names[1:], np.median(d, axis=0)):
     print(f"  -> {n:34s} {v:8.0f}")
 print("  GEMM 1 quarters (steps 0-7, 8-15, 16-23, 24-31):", np.median(np.diff(st[:, [1, 10, 11, 12, 2]], axis=1), axis=0))
+print("  value sum end -> flush check done:", np.median(st[:, 13] - st[:, 9]))
 print(f"  stamped part of the tile: median {np.median(st[:, 9] - st[:, 0]):.0f}")
 # tile-to-tile period: consecutive tiles of one workgroup are consecutive tiles of a bag
 per = []
