@@ -697,7 +697,7 @@ __global__ __launch_bounds__(F2_THREADS, 1) void k_attend_f2(AttendArgs a, const
 // fp32 query weights -> two fp16 planes (round to nearest) of the power-of-two scaled values, MFMA-fragment order:
 //   chunk s < nks (GEMM 1):  [t][p][lane (l31,hi)][e] = plane_p(a1 W1[32t + l31][16s + 8hi + e])   (0 past K)
 //   chunk nks + 2t + sx:     [t2][p][lane][e] = plane_p(a2 W2[32t2 + l31][32t + 16sx + (e&3) + 8(e>>2) + 4hi])
-//   trailer (behind chunk nks + 8): {1 / a1, 1 / a2}
+//   trailer (behind chunk nks + 8): {1 / a1, 1 / a2, max_j ||W1[j]||_1}
 // a1 / a2 from max |W1| / max |W2| (f2_scale), computed by every workgroup for itself (same values everywhere).
 __global__ __launch_bounds__(256) void k_pack_agg_f2(const float* __restrict__ q0_w, const float* __restrict__ q2_w,
                                                      _Float16* __restrict__ out, int K, int nks) {
@@ -735,10 +735,24 @@ __global__ __launch_bounds__(256) void k_pack_agg_f2(const float* __restrict__ q
         const _Float16 h = (_Float16)v;
         out[i] = p == 0 ? h : (_Float16)(v - (float)h);
     }
-    if (blockIdx.x == 0 && tid == 0) {
-        float* tr = reinterpret_cast<float*>(out + (long long)(nks + 8) * per);
-        tr[0] = i1;
-        tr[1] = i2;
+    if (blockIdx.x == 0) {
+        // trailer[2] = max_j sum_k |W1[j][k]|: with a row's max |x| it bounds the hidden layer of that row (k_attend_f3 scales its
+        // hidden planes by that bound instead of exchanging the row's maximum between the waves)
+        __shared__ float s_n1[4];
+        float n1 = 0.f;
+        for (int j = wave; j < QD; j += 4) {
+            float sum = 0.f;
+            for (int k = lane; k < K; k += 64) sum += fabsf(q0_w[(long long)j * K + k]);
+            n1 = fmaxf(n1, wave_sum(sum));
+        }
+        if (lane == 0) s_n1[wave] = n1;
+        __syncthreads();
+        if (tid == 0) {
+            float* tr = reinterpret_cast<float*>(out + (long long)(nks + 8) * per);
+            tr[0] = i1;
+            tr[1] = i2;
+            tr[2] = fmaxf(fmaxf(s_n1[0], s_n1[1]), fmaxf(s_n1[2], s_n1[3]));
+        }
     }
 }
 
