@@ -85,14 +85,16 @@ __device__ __forceinline__ F3Cur f3_next(F3Cur c, int tiles_per_bag) {
 }
 
 // first item at or behind c, below `end`, whose tile lies inside its bag (evaluated identically by every wave); c is left on it
-__device__ __forceinline__ bool f3_fetch(const AttendArgs& a, int tiles_per_bag, int end, F3Cur& c, F3Work& w) {
+// (hint = the item in front: consecutive tiles mostly share the bag, whose record then needs no load at all)
+__device__ __forceinline__ bool f3_fetch(const AttendArgs& a, int tiles_per_bag, int end, F3Cur& c, F3Work& w, const F3Work* hint = nullptr) {
     // (through the constant address space: scalar loads.  As plain loads behind the tile's stores hipcc makes them VECTOR loads
     // with a uniform address, and their vmcnt(0) then waits for every refill of the feature ring issued before them)
     const __attribute__((address_space(4))) long long* offs = (const __attribute__((address_space(4))) long long*)(uintptr_t)a.offsets;
     while (c.item < end) {
         const int bag = a.bag0 + c.b;
-        const long long off0 = offs[bag];
-        const long long Nb = offs[bag + 1] - off0;
+        long long off0, Nb;
+        if (hint && hint->bag == bag) { off0 = hint->off0; Nb = hint->Nb; }
+        else { off0 = offs[bag]; Nb = offs[bag + 1] - off0; }
         const long long row0 = (long long)c.tile * F3_BM;
         if (row0 < Nb) {
             w.bag = bag; w.off0 = off0; w.Nb = Nb; w.row0 = row0;
@@ -247,7 +249,9 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
             } else if constexpr (ph == 9) {
                 *reinterpret_cast<f32x4*>(d + 2 * K) = cutf[1].f;
             } else if constexpr (ph == 10) {
-                if constexpr (DBG != 4) fill(refill_src, c);   // (DBG 4: timing without the refills)
+                // (the last two groups are refilled from GEMM 2's gaps: the loads of W2's second plane are issued between the
+                // two GEMMs, and the in-order vmcnt wait for them would otherwise include HBM loads a few hundred cycles old)
+                if constexpr (DBG != 4 && c < NG - 2) fill(refill_src, c);   // (DBG 4: timing without the refills)
             }
         }
     };
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
         F3Work n3 = nn;
         float rm_n3;
         long long phys_n3, log_n3;
-        const bool has_n3 = has_nn && f3_fetch(a, tiles_per_bag, item_end, pos_n3, n3);
+        const bool has_n3 = has_nn && f3_fetch(a, tiles_per_bag, item_end, pos_n3, n3, &nn);
         if (!has_n3) n3 = nn;
         row_raw(n3, rm_n3, phys_n3, log_n3);                    // (unconditional: no tile behind -> a harmless re-read of nn's rows)
         __syncthreads();                                  // S
@@ -420,6 +424,8 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
                     f3_mfma_v(Qacc[~st & 1], w2[st][0].f, hs[st % 3][1].f);
                 }
                 f3_mfma_v(Qacc[st & 1], w2[st][0].f, hs[st % 3][0].f);
+                if (DBG != 4 && st == 1) fill(src_nn, NG - 2);
+                if (DBG != 4 && st == 3) fill(src_nn, NG - 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             F3_NOP();
