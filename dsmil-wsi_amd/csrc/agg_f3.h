@@ -119,6 +119,7 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
     constexpr int RB = f3_row_bytes(K), BUF = F3_BM * RB;
     constexpr int NC = TWO ? 2 : 1;
     constexpr bool W2_STREAM = NK1 > 8;
+    constexpr int NMOVE = 2;                               // ring groups refilled from GEMM 2's gaps instead of GEMM 1's (4 measured: 0.83 of k_attend_f2 against 0.81)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sX = reinterpret_cast<char*>(smem);              // [2 buffers][32 rows][plane 2][K] fp16 + pad
     char* sH = sX + 2 * BUF;                               // [32 rows][plane 2][128] fp16 + pad; at a flush: [4 waves][NC][K] floats
@@ -249,9 +250,9 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
             } else if constexpr (ph == 9) {
                 *reinterpret_cast<f32x4*>(d + 2 * K) = cutf[1].f;
             } else if constexpr (ph == 10) {
-                // (the last two groups are refilled from GEMM 2's gaps: the loads of W2's second plane are issued between the
+                // (the last NMOVE groups are refilled from GEMM 2's gaps: the loads of W2's second plane are issued between the
                 // two GEMMs, and the in-order vmcnt wait for them would otherwise include HBM loads a few hundred cycles old)
-                if constexpr (DBG != 4 && c < NG - 2) fill(refill_src, c);   // (DBG 4: timing without the refills)
+                if constexpr (DBG != 4 && c < NG - NMOVE) fill(refill_src, c);   // (DBG 4: timing without the refills)
             }
         }
     };
@@ -424,8 +425,7 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
                     f3_mfma_v(Qacc[~st & 1], w2[st][0].f, hs[st % 3][1].f);
                 }
                 f3_mfma_v(Qacc[st & 1], w2[st][0].f, hs[st % 3][0].f);
-                if (DBG != 4 && st == 1) fill(src_nn, NG - 2);
-                if (DBG != 4 && st == 3) fill(src_nn, NG - 1);
+                if (DBG != 4 && st < NMOVE) fill(src_nn, NG - NMOVE + st);
                 __builtin_amdgcn_sched_barrier(0);
             }
             F3_NOP();
