@@ -20,8 +20,11 @@
 //     maximum, no rescaling), the value sum accumulates ACROSS tiles in eight registers per class (lane = k-octet, wave =
 //     eight rows of every tile: no cross-lane reduction per tile) and ONE partial per (workgroup, bag) is written:
 //     slot = blockIdx.x + bag, merged by k_finish's segment mode.
-// Per-row power-of-two scales, the cut, the three products, the packed weight image (k_pack_agg_f2) and the error class are
-// k_attend_f2's (agg_f2.h); so are the tests (tests/test_agg_gpu.py::test_batch_form_*).
+//   * the hidden planes are scaled by a BOUND of the row's hidden maximum (weight norm x the row's feature maximum; the norm
+//     rides in the packed image's trailer) instead of the maximum itself, which would have to be exchanged between the waves:
+//     a power-of-two scale leaves fp16 significands alone (tests/test_f16_planes.py), so the results do not change.
+// Per-row power-of-two feature scales, the cut, the three products, the packed weight image (k_pack_agg_f2) and the error class
+// are k_attend_f2's (agg_f2.h); so are the tests (tests/test_agg_gpu.py::test_batch_form_*).
 // Only the two-layer query (dsmil.py:31-32 nonlinear, the default) and C <= 2: everything else stays on k_attend_f2.
 // LDS: planes 2 x 32 x (4 K + 16) B (129 KiB at K = 512) | hidden planes 32 x 528 B | 6.3 KiB scratch = 151.8 KiB.
 // Barriers per 32-row tile: S (planes of this tile complete, the other buffer and the scratch released), B2 (hidden
