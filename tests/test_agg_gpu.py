@@ -3,6 +3,8 @@ reference itself and (2) the numpy oracle on seeded inputs.  Needs a real MI355X
 
 Tolerances: critical index exact on tie-free scores; instance logits, bag
 logits and B within 1e-4 abs; A within 1e-6 abs + 1e-3 rel (its values are ~1/N)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -318,6 +320,17 @@ def test_batch_forms_at_other_feature_widths(K, C, form):
         sl = slice(int(off[b]), int(off[b + 1]))
         r = orc.milnet_forward(bags[b], w, dtype="f64")
         _cmp((got[0][sl], got[1][b:b + 1], got[2][sl], got[3][b:b + 1]), r[0], r[1], r[2], r[3], r[4], got[4][b].cpu().numpy())
+
+
+def test_batch_form_f3_random_ragged_batches_soak():
+    """tools/f3_soak.py, six rounds: random ragged batches (bags of 1 .. 20 000 rows, per-bag scales over six decades, K in
+    {128, 256, 384, 512}, C in {1, 2}) through k_attend_f3 twice (bit-identical) and through k_query_attend_split (same
+    critical instances, outputs within the forms' common error class)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "f3_soak.py"), "6"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_large_batch_uses_wide_tiles_and_matches():
