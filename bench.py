@@ -302,11 +302,14 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
         for _ in range(5):
             ops.agg_forward(one, [N], w)
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(50):
-            ops.agg_forward(one, [N], w)
-        torch.cuda.synchronize()
-        single_ms = (time.perf_counter() - t1) / 50 * 1e3
+        single_ms = None
+        for _ in range(3):   # best of three rounds of 50 calls: the probe is host-inclusive and boxes differ in host speed
+            t1 = time.perf_counter()
+            for _ in range(50):
+                ops.agg_forward(one, [N], w)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t1) / 50 * 1e3
+            single_ms = ms if single_ms is None else min(single_ms, ms)
     A = out[2]
     s = A.view(nb, N, C).sum(1)
     if not os.environ.get("DSMIL_EXPT"):   # ablation runs of experiment builds compute garbage on purpose
