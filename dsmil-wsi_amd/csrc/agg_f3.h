@@ -122,7 +122,7 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
     constexpr int RB = f3_row_bytes(K), BUF = F3_BM * RB;
     constexpr int NC = TWO ? 2 : 1;
     constexpr bool W2_STREAM = NK1 > 8;
-    constexpr int NMOVE = 2;                               // ring groups refilled from GEMM 2's gaps instead of GEMM 1's (4 measured: 0.83 of k_attend_f2 against 0.81)
+    constexpr int NMOVE = 2;                               // ring groups refilled from GEMM 2's gaps instead of GEMM 1's (measured, kernel time relative to k_attend_f2 on the same box: 1 -> 0.84, 2 -> 0.81, 3 -> 0.83, 4 -> 0.83)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sX = reinterpret_cast<char*>(smem);              // [2 buffers][32 rows][plane 2][K] fp16 + pad
     char* sH = sX + 2 * BUF;                               // [32 rows][plane 2][128] fp16 + pad; at a flush: [4 waves][NC][K] floats
