@@ -48,6 +48,14 @@ constexpr int R0 = 128;          // rows per workgroup of k_logits_argmax
 // no LDS.  (Rounds 1-4 wrote these as six __shfl_xor stages, which hipcc lowers to ds_bpermute_b32: six dependent LDS round
 // trips of ~100 cycles each; k_qmax is a chain of 32 such sums, the tile softmax of k_attend_hs of four.)  Fixed order:
 // ((r0 + r1) + (r2 + r3)) over the rows, rotation order inside a row — deterministic, NOT the xor tree's rounding.
+// PRECONDITION: all 64 lanes active (EXEC == ~0): the DPP rotations and v_readlane read the VGPRs of inactive lanes as they
+// are (stale), where ds_bpermute returned 0.  Every caller reduces in wave-uniform control flow and feeds the neutral element
+// from lanes without data; experiment builds (-DDSMIL_EXPERIMENTS) trap on a partial wave.
+#ifdef DSMIL_EXPERIMENTS
+#define DSMIL_FULL_WAVE() do { if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap(); } while (0)
+#else
+#define DSMIL_FULL_WAVE() do { } while (0)
+#endif
 __device__ __forceinline__ float dpp_row_sum(float v) {
 #define DSMIL_ROR(n) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xf, 0xf, false))
     DSMIL_ROR(8); DSMIL_ROR(4); DSMIL_ROR(2); DSMIL_ROR(1);
@@ -61,12 +69,14 @@ __device__ __forceinline__ float dpp_row_max(float v) {
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {
+    DSMIL_FULL_WAVE();
     v = dpp_row_sum(v);
     const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
     return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
+    DSMIL_FULL_WAVE();
     v = dpp_row_max(v);
     const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));

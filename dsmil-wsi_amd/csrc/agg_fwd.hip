@@ -1234,6 +1234,15 @@ std::atomic<int> g_inline_query{1};
 // dsmil_agg_batch_form(): 2 (default) = batches of fp32 bags take k_attend_f3 (weights resident in registers, 32-row tiles;
 // two-layer query and C <= 2 — k_attend_f2 otherwise), 1 = k_attend_f2 always, 0 = k_query_attend_split (rounds 2-4)
 std::atomic<int> g_use_f2{2};
+// dsmil_agg_persistent_grid(): workgroups of the persistent batch kernels (k_attend_f3 / k_attend_f2 / k_attend_bf16_res).
+// A CONSTANT (256 = the CUs of an unpartitioned MI355X), not the visible CU count: the run length `per` fixes which tiles
+// share a partial, i.e. the fp32 summation order, so the outputs must not depend on the box (partition mode, masked CUs).
+std::atomic<int> g_persistent_grid{256};
+int persistent_grid(int cap) {
+    int g = g_persistent_grid.load(std::memory_order_relaxed);
+    if (g <= 0) g = 256;
+    return g < cap ? g : cap;
+}
 
 // The in-launch hand-off needs its producers to RUN while tiles spin on their flags.  Producers are the first workgroups of
 // every grid row and the hardware dispatches a grid in order, but HIP promises neither: the query is inlined only when
@@ -1296,8 +1305,7 @@ int launch_attend_f2(const AttendArgs& a, const float* rowmax, long long max_row
     const int tiles_per_bag = (int)((max_rows + F2_BM - 1) / F2_BM);
     const long long n_items = (long long)tiles_per_bag * n_bags;
     if (n_items > 0x7fffffffLL) return DSMIL_E_UNSUPPORTED;
-    int cus = device_cus();
-    if (cus <= 0) cus = 256;
+    int cus = persistent_grid(1 << 20);
 #ifdef DSMIL_EXPERIMENTS
     static const int f2_grid = expt_env("DSMIL_F2_GRID");
     if (f2_grid > 0) cus = f2_grid;
@@ -1323,9 +1331,7 @@ int launch_attend_f3_k(const AttendArgs& a, const float* rowmax, long long max_r
 #endif
     constexpr int lds = f3_lds_bytes(32 * NK1);
     if (!dsmil_lds::allow((const void*)fn, lds)) return DSMIL_E_LAUNCH;
-    int cus = device_cus();
-    if (cus <= 0) cus = 256;
-    if (cus > F3_MAX_WG) cus = F3_MAX_WG;
+    const int cus = persistent_grid(F3_MAX_WG);
     const long long tiles_per_bag = (max_rows + F3_BM - 1) / F3_BM;
     const long long n_items = tiles_per_bag * n_bags;
     if (n_items > 0x7fffffffLL) return DSMIL_E_UNSUPPORTED;
@@ -1388,10 +1394,7 @@ void (*bf16_res_fn(const AttendArgs& a))(AttendArgs, int, int, int) {
                     : (a.nonlinear ? k_attend_bf16_res<NCH, false, true> : k_attend_bf16_res<NCH, false, false>);
 }
 int launch_attend_bf16_res(AttendArgs a, long long max_rows, int n_bags, hipStream_t st, int* seg_per, int* seg_T) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        return DSMIL_E_LAUNCH;
-    if (cus > RS_MAX_WG) cus = RS_MAX_WG;
+    const int cus = persistent_grid(RS_MAX_WG);
     typedef void (*res_fn)(AttendArgs, int, int, int);
     res_fn fn = a.K == 512 ? bf16_res_fn<8>(a) : bf16_res_fn<4>(a);
 #ifdef DSMIL_EXPERIMENTS
@@ -1460,6 +1463,11 @@ int dsmil_agg_batch_form(int mode) {
     if (mode >= 0 && mode <= 2) return g_use_f2.exchange(mode);
     return g_use_f2.load();
 }
+int dsmil_agg_persistent_grid(int n) {
+    if (n >= 1 && n <= 1024) return g_persistent_grid.exchange(n);
+    return g_persistent_grid.load();
+}
+int dsmil_device_cus(void) { return device_cus(); }
 int dsmil_agg_inline_query(int mode) {
     if (mode == 0 || mode == 1) return g_inline_query.exchange(mode);
     return g_inline_query.load();

@@ -2184,11 +2184,8 @@ Dims dims_for(int H, int W) {
 // prologue, 6.1 k per chunk).  E.g. 14 x 14 maps at bs 256: 4 images x 1 x 7 tiles (448 units, 87 % of the slots) and
 // 1 image x 4 x 7 (512 units, 77 %) both take 4 rounds of two cout blocks; the second has the 10 k shorter epilogue.
 void wino_shape(int B, int TY, int TX, int& IB, int& TYB, int& TXB, int cb = 0, int nchunks = 0) {
-    static const int ncu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        return n > 0 ? n : 256;
-    }();
+    constexpr int ncu = 256;   // a CONSTANT (unpartitioned MI355X), not the visible CU count: the unit shape fixes which tiles share a
+                               // statistics partial, i.e. the fp32 summation order — results must not depend on the box
     double best = -1.0;
     IB = 1; TYB = 1; TXB = TX < WTT ? TX : WTT;
     for (int txb = 1; txb <= TX && txb <= WTT; ++txb) {

@@ -322,7 +322,7 @@ def agg_forward(feats, lengths, w, classes_in=None, vals=None, nonlinear=True, o
                                           _stream(dev))
         else:
             split = _split_params(keep[2], keep[4], nonlinear, dev)
-            # batches in the 128-row-tile regime take k_attend_f2 (K a multiple of 64 up to 512, v = Identity): its weight image
+            # batches in the 128-row-tile regime take k_attend_f3 / k_attend_f2 (K a multiple of 128 up to 512, v = Identity): its weight image
             f2 = None
             if (split is not None and L.dsmil_agg_tile_rows(n_bags, total) == 128 and K % 128 == 0 and K <= 512 and vals is feats
                     and classes_in is None):
@@ -584,6 +584,9 @@ def resnet_depth_of(convs):
     return None
 
 
+RESNET_MAX_ABS_WEIGHT = 100.0   # < 65504 / (2^8 * 2.25): see _packed_resnet_weights
+
+
 def _packed_resnet_weights(convs, depth=18, precision=0):
     """Device buffer with the non-stem conv weights re-laid-out for the kernels (dsmil_resnet_pack:
     Winograd-transformed or [tap][Cout][Cin]).  Cached per weight set; rebuilt when any tensor was
@@ -598,6 +601,13 @@ def _packed_resnet_weights(convs, depth=18, precision=0):
     L = _native.lib()
     buf = torch.empty(L.dsmil_resnet_packed_bytes(depth) // 4, dtype=torch.float32, device=dev)
     keep = [_f32c(w.detach(), "conv weight") for w in convs]
+    # The conv operands are cut into fp16 planes of the 2^8-scaled weights (csrc/resnet_fwd.hip, EMB_WSHIFT); a Winograd
+    # weight transform grows a 3x3 kernel by at most 2.25x, so |w| must stay below 65504 / (256 * 2.25) = 113.7 or a plane
+    # overflows to inf.  Checked ONCE per weight set (this function is cached on the weights' versions): one host read.
+    wmax = float(torch.stack([w.abs().amax() for w in keep]).amax())
+    if not wmax < RESNET_MAX_ABS_WEIGHT:   # (also catches NaN)
+        raise ValueError(f"conv weight magnitude {wmax:g} is outside the native embedder's range (|w| < {RESNET_MAX_ABS_WEIGHT:g}: "
+                         "its operands are fp16 planes of the 2^8-scaled weights)")
     arr = (ctypes.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
     with torch.cuda.device(dev):
         rc = L.dsmil_resnet_pack_ex(depth, arr, _ptr(buf), int(precision), _stream(dev))
@@ -607,6 +617,7 @@ def _packed_resnet_weights(convs, depth=18, precision=0):
 
 
 _bn_cache = _LRU()
+_bn_checked = _LRU()
 
 
 def _folded_bn(norms, dev):
@@ -689,6 +700,16 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None, precision=
                                        _ptr(bn_r), _ptr(fc_w), _ptr(fc_b), C, _ptr(feats), _ptr(classes), _ptr(ws),
                                        ws.numel(), prec, _stream(dev))
     _native.check(rc, "dsmil_resnet_forward_ex")
+    if bn_norms is not None:
+        # A frozen-BatchNorm trunk has no bound on its activations (InstanceNorm output is bounded by sqrt(H W)); an activation
+        # past fp16's 65504 would turn into inf / NaN features.  The FIRST forward of every folded-BatchNorm set is checked
+        # (one host read per weight set, none afterwards).
+        key = ("bn_finite", bn_m.data_ptr(), bn_m._version, packed.data_ptr())
+        if _bn_checked.get(key) is None:
+            if not bool(torch.isfinite(feats).all()):
+                raise FloatingPointError("the frozen-BatchNorm trunk produced non-finite features: an activation left the fp16 "
+                                         "operand range of the native conv kernels (|a| < 65504)")
+            _bn_checked.put(key, True)
     return feats, classes
 
 

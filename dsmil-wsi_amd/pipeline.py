@@ -328,15 +328,25 @@ def attention_colormap(A, pos_arr, bag_prediction, thres, colors, class_names=No
     if upsample_device is not None and torch.device(upsample_device).type == "cuda":
         # the 32 x 32 byte replication on the GPU + one D2H copy of the finished map (np.repeat twice: 18 ms for a
         # 3072 x 3328 map, a broadcast + reshape copy 35 ms)
-        # into PINNED host memory (torch's host allocator caches the block between calls): a pageable `.cpu()` of the 30 MB
-        # map cost 14 of the 18.6 ms of this function; the array keeps its block alive, every call returns a fresh one
+        # through ONE cached PINNED staging block (a pageable `.cpu()` of the 30 MB map cost 14 of the 18.6 ms of this
+        # function); the returned array is a pageable copy of it
         t = torch.from_numpy(small).to(upsample_device)
         up = t.repeat_interleave(32, dim=0).repeat_interleave(32, dim=1)
-        host = torch.empty(up.shape, dtype=torch.uint8, pin_memory=True)
+        host = _pinned_staging(up.numel()).view(up.shape)
         host.copy_(up, non_blocking=True)
         torch.cuda.current_stream(up.device).synchronize()
-        return host.numpy()
+        return np.array(host.numpy())   # a pageable copy: callers may keep many maps; the ONE pinned block is reused
     return np.repeat(np.repeat(small, 32, axis=0), 32, axis=1)
+
+
+_pinned = [None]
+
+
+def _pinned_staging(nbytes):
+    """One page-locked uint8 block, grown on demand and reused by every attention_colormap call of the process."""
+    if _pinned[0] is None or _pinned[0].numel() < nbytes:
+        _pinned[0] = torch.empty(int(nbytes), dtype=torch.uint8, pin_memory=True)
+    return _pinned[0][:nbytes]
 
 
 @torch.no_grad()

@@ -179,11 +179,11 @@ class FusedTrainStep:
         """One optimiser step on one bag; returns the loss (0-dim device tensor, detached)."""
         from . import ops
         g = self.group
-        self.step += 1
         with torch.no_grad():
             loss = ops.agg_train_step(bag_feats, bag_label, [p.data if p is not None else None for p in self.params], self.m,
-                                      self.v, self.step, g["lr"], g["betas"], g["eps"], g["weight_decay"],
+                                      self.v, self.step + 1, g["lr"], g["betas"], g["eps"], g["weight_decay"],
                                       nonlinear=self.nonlinear, row_map=row_map)
+        self.step += 1   # only once the native step was enqueued: a call that raised applied no update (sync() stays consistent)
         # the kernels wrote the parameters through raw pointers: tell torch (version counters key the packed-weight caches
         # of the inference path, and autograd's saved-tensor checks)
         torch.autograd.graph.increment_version(self._live)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DSMIL_ABI_VERSION 4
+#define DSMIL_ABI_VERSION 5
 #define DSMIL_Q_DIM 128 /* query width hard-coded at dsmil.py:31,33 */
 
 enum {
@@ -148,6 +148,17 @@ int dsmil_agg_inline_query(int mode);
  *   0            k_query_attend_split of rounds 2-4 (bf16 MFMA, exact three-plane cuts, six products, the tile read twice).
  * Process-wide; returns the previous mode; any other `mode` only queries. */
 int dsmil_agg_batch_form(int mode);
+
+/* (ABI 5) Workgroups of the persistent batch kernels (k_attend_f3 / k_attend_f2 / k_attend_bf16_res).  The default is the
+ * CONSTANT 256 (the CUs of an unpartitioned MI355X), not the visible CU count: the run of tiles a workgroup owns fixes which
+ * tiles share a partial and with it the fp32 summation order, so the outputs are bit-identical on every box (partition
+ * mode, masked CUs) — tests/test_agg_gpu.py checks two other grids against the fp64 oracle.  n in 1..1024 sets it
+ * (process-wide) and returns the previous value; any other n only queries. */
+int dsmil_agg_persistent_grid(int n);
+
+/* Compute units of the current device as the library sees them (256 on MI355X); <= 0 without a device.  Diagnostic: recorded
+ * by bench.py and the soak so that a result can be tied to the box it ran on. */
+int dsmil_device_cus(void);
 
 /* Options of dsmil_agg_forward_ex (all optional; a NULL opts or an all-zero struct = dsmil_agg_forward):
  *   packed_split  the plane-cut query weights of forms 6 / 9 prepared ONCE per weight set instead of on every

@@ -28,7 +28,7 @@ def _check(out, ref, N):
     np.testing.assert_allclose(A, ref[2], atol=1e-6, rtol=3e-2)
     np.testing.assert_allclose(B.reshape(ref[3].shape), ref[3], atol=2e-3, rtol=2e-2)
     np.testing.assert_allclose(pred, ref[1], atol=2e-3, rtol=2e-2)
-    np.testing.assert_allclose(A.sum(axis=0), 1.0, atol=1e-4)
+    np.testing.assert_allclose(A.sum(axis=0, dtype=np.float64), 1.0, atol=1e-4)
 
 
 @pytest.mark.parametrize("tag", ["tcga", "c16"])
@@ -143,7 +143,7 @@ def test_bf16_resident_tile_kernel(K, C, nonlinear, lengths):
         np.testing.assert_allclose(pred[i:i + 1], ref[1], atol=2e-3, rtol=2e-2)
         assert np.array_equal(idx[i], ref[4])
     for i in range(len(lengths)):
-        np.testing.assert_allclose(A[off[i]:off[i + 1]].sum(axis=0), 1.0, atol=1e-4)
+        np.testing.assert_allclose(A[off[i]:off[i + 1]].sum(axis=0, dtype=np.float64), 1.0, atol=1e-4)
     for _ in range(4):
         again = ops.agg_forward(x, lengths, w, nonlinear=nonlinear)
         for a_, b_ in zip(again, out):
