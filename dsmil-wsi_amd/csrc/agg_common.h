@@ -212,7 +212,36 @@ struct AttendArgs {
     const long long* qm_part_idx;
     int64_t* qm_idx;
     int qm_r0;
+    // Persistent batch kernels (k_attend_f3, k_attend_bf16_res) on RAGGED batches: tile_pre[b] = number of tiles of the bags in
+    // front of bag b, tile_pre[n_bags] = all tiles (k_tile_prefix); the tile items of the launch are then the REAL tiles only,
+    // dealt in contiguous runs.  nullptr (uniform batches: every bag max_rows long) = item b * tiles_per_bag + tile.
+    const int* tile_pre;
+    int n_bags;
 };
+
+// Largest b in [0, n_bags) with pre[b] <= item (pre non-decreasing, pre[0] = 0, item < pre[n_bags]): the bag that owns tile
+// item `item` — behind runs of equal entries (empty bags).  Uniform address: scalar loads; once per workgroup.
+__device__ __forceinline__ int tile_owner(const int* pre_, int n_bags, int item) {
+    const __attribute__((address_space(4))) int* pre = (const __attribute__((address_space(4))) int*)(uintptr_t)pre_;
+    int lo = 0, hi = n_bags;           // invariant: pre[lo] <= item < pre[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pre[mid] <= item) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+// the same with a guess (the bag of the item in front): two independent loads when the item stays in that bag or moves to the next
+__device__ __forceinline__ int tile_owner_near(const int* pre_, int n_bags, int item, int guess) {
+    const __attribute__((address_space(4))) int* pre = (const __attribute__((address_space(4))) int*)(uintptr_t)pre_;
+    if (guess >= 0 && guess < n_bags) {
+        const int g1 = pre[guess + 1], g2 = pre[guess + 2 <= n_bags ? guess + 2 : n_bags];
+        if (pre[guess] <= item) {
+            if (item < g1) return guess;
+            if (item < g2) return guess + 1;
+        }
+    }
+    return tile_owner(pre_, n_bags, item);
+}
 
 __device__ __forceinline__ long long phys_row(const int64_t* __restrict__ rowmap, long long logical) {
     return rowmap ? (long long)rowmap[logical] : logical;

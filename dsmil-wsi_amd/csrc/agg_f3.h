@@ -81,6 +81,7 @@ struct F3Work {
 struct F3Cur {
     int item, b, tile;
 };
+// (tiles_per_bag == 0: a ragged batch — the items are the real tiles, a bag ends where its rows end: f3_fetch moves on)
 __device__ __forceinline__ F3Cur f3_next(F3Cur c, int tiles_per_bag) {
     ++c.item;
     if (++c.tile == tiles_per_bag) { c.tile = 0; ++c.b; }
@@ -103,7 +104,7 @@ __device__ __forceinline__ bool f3_fetch(const AttendArgs& a, int tiles_per_bag,
             w.bag = bag; w.off0 = off0; w.Nb = Nb; w.row0 = row0;
             return true;
         }
-        c.item += tiles_per_bag - c.tile;                 // the rest of this bag's items lie behind its end
+        if (tiles_per_bag) c.item += tiles_per_bag - c.tile;   // the rest of this bag's items lie behind its end (ragged: there are none)
         c.tile = 0;
         ++c.b;
     }
@@ -144,8 +145,16 @@ __global__ __launch_bounds__(F3_THREADS, 1) void k_attend_f3(AttendArgs a, const
 
     F3Cur pos;
     pos.item = (int)blockIdx.x * per_wg;
-    pos.b = pos.item / tiles_per_bag;
-    pos.tile = pos.item - pos.b * tiles_per_bag;
+    if (a.tile_pre) {                                     // ragged batch: the real tiles only (tiles_per_bag == 0 from the host)
+        const int real = ((const __attribute__((address_space(4))) int*)(uintptr_t)a.tile_pre)[a.n_bags];
+        n_items = n_items < real ? n_items : real;        // (the host sized the runs from an upper bound)
+        if (pos.item >= n_items) return;
+        pos.b = tile_owner(a.tile_pre, a.n_bags, pos.item);
+        pos.tile = pos.item - a.tile_pre[pos.b];
+    } else {
+        pos.b = pos.item / tiles_per_bag;
+        pos.tile = pos.item - pos.b * tiles_per_bag;
+    }
     const int item_end = pos.item + per_wg < n_items ? pos.item + per_wg : n_items;
     F3Work cur, nxt, nn;
     if (!f3_fetch(a, tiles_per_bag, item_end, pos, cur)) return;   // (block-uniform)

@@ -205,7 +205,10 @@ __global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
     const float* __restrict__ fc_w, const float* __restrict__ fc_b, float* __restrict__ classes_out,
     float* __restrict__ part_val, long long* __restrict__ part_idx, int K, int C, int bag0,
     const int64_t* __restrict__ rowmap, int r0 = R0, int* __restrict__ qm_flag = nullptr,
-    TrainPrologueJob job = TrainPrologueJob{}, float* __restrict__ rowmax = nullptr) {
+    TrainPrologueJob job = TrainPrologueJob{}, float* __restrict__ rowmax = nullptr,
+    const int* __restrict__ tile_pre = nullptr, int n_bags = 0) {
+    // tile_pre (ragged batches, k_tile_prefix with BM = r0): a ONE-dimensional grid over the real tiles — tile_pre[b] of them in
+    // front of bag b — instead of (tiles of the longest bag) x n_bags workgroups of which most find nothing to do
     // rowmax (fp32 rows, k_attend_f2 follows): max_k |x[row][k]| of every LOGICAL row, a by-product of this pass over the
     // bag — the attend kernel derives the row's power-of-two scale for its fp16 plane cut from it (agg_f2.h)
     // qm_flag: the hand-off flags of the attend launch that follows (AttendArgs::qm_flag), cleared here
@@ -228,7 +231,13 @@ __global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
     extern __shared__ __attribute__((aligned(16))) float s_w[];  // [CP][Kpad]: weights, zero past K, plus one zero segment
     __shared__ float s_v[8];
     __shared__ long long s_i[8];
-    const int bag = bag0 + (int)blockIdx.y, tile = (int)blockIdx.x;
+    int bag = bag0 + (int)blockIdx.y, tile = (int)blockIdx.x;
+    if (tile_pre) {
+        if ((int)blockIdx.x >= tile_pre[n_bags]) return;
+        const int b = tile_owner(tile_pre, n_bags, (int)blockIdx.x);
+        bag = bag0 + b;
+        tile = (int)blockIdx.x - tile_pre[b];
+    }
     const long long off0 = job.blocks ? 0 : offsets[bag];       // (the job's offsets are being written by this very launch)
     const long long Nb = job.blocks ? job.N : offsets[bag + 1] - off0;
     const long long row0 = (long long)tile * r0;
@@ -974,6 +983,45 @@ __global__ __launch_bounds__(HS_THREADS, 2) void k_attend_hs(AttendArgs a) {
 // walk of a k-run is spread over 16 thread groups x float4 so that a lone 10k-row bag (313 tiles)
 // is ~5 dependent load rounds instead of ~80.
 // --------------------------------------------------------------------------------------------
+// k_tile_prefix: pre[b] = sum over the bags in front of b of ceil(N / BM), pre[n_bags] = all tiles — the item list of the
+// persistent batch kernels (AttendArgs::tile_pre, tiles of BMa rows) and of the logits pass (tiles of BMb rows) on a RAGGED
+// batch.  One 1024-thread workgroup, rounds of 1024 bags.
+__global__ __launch_bounds__(1024) void k_tile_prefix(const int64_t* __restrict__ offsets, int n_bags, int BMa, int BMb,
+                                                      int* __restrict__ pre_a, int* __restrict__ pre_b) {
+    __shared__ int s_w[2][16];
+    __shared__ int s_base[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 2) s_base[tid] = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < n_bags; b0 += 1024) {
+        const int b = b0 + tid;
+        int v[2] = {0, 0}, x[2];
+        if (b < n_bags) {
+            const long long n = offsets[b + 1] - offsets[b];
+            v[0] = (int)((n + BMa - 1) / BMa);
+            v[1] = (int)((n + BMb - 1) / BMb);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            x[q] = v[q];                                      // inclusive scan inside the wave
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(x[q], d);
+                if (lane >= d) x[q] += y;
+            }
+            if (lane == 63) s_w[q][wave] = x[q];
+        }
+        __syncthreads();
+        int before[2] = {s_base[0], s_base[1]};
+        for (int w = 0; w < wave; ++w) { before[0] += s_w[0][w]; before[1] += s_w[1][w]; }
+        if (b < n_bags) { pre_a[b] = before[0] + x[0] - v[0]; pre_b[b] = before[1] + x[1] - v[1]; }
+        __syncthreads();
+        if (tid == 1023) { s_base[0] = before[0] + x[0]; s_base[1] = before[1] + x[1]; }
+        __syncthreads();
+    }
+    if (tid == 0) { pre_a[n_bags] = s_base[0]; pre_b[n_bags] = s_base[1]; }
+}
+
 constexpr int FR = 2048;
 inline long long finish_blocks(long long max_rows, int Kv) {
     const long long a = (max_rows + FR - 1) / FR, b = (Kv + 63) / 64;
@@ -985,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_finish(
     const int64_t* __restrict__ offsets, const float* __restrict__ part_ml,
     const float* __restrict__ part_B, const float* __restrict__ fcc_w,
     float* __restrict__ A, float* __restrict__ B, float* __restrict__ pred_part, int Kv, int C, int BM,
-    float* __restrict__ ml_out = nullptr, int seg_per = 0, int seg_T = 0) {
+    float* __restrict__ ml_out = nullptr, int seg_per = 0, int seg_T = 0, const int* __restrict__ tile_pre = nullptr) {
     // seg_per > 0 (k_attend_bf16_res): the partials are per (workgroup, bag) — workgroup g owns the BM-row tile items
     // [g seg_per, (g + 1) seg_per) of the (bag, tile) list with seg_T items per bag, and wrote slot g + bag
     // ml_out != null (instance-sharded bag): leave A and B relative to this shard's max, un-normalised
@@ -997,7 +1045,8 @@ __global__ __launch_bounds__(256) void k_finish(
     long long ntile = (Nb + BM - 1) / BM;
     if (seg_per > 0 && ntile > 0) {   // (an EMPTY bag keeps ntile = 0: no workgroup wrote a partial for it — merging a slot
                                       // would read stale workspace; the bag then gets the same NaN / 0 outputs as on the tile path)
-        const long long it0 = (long long)bag * seg_T, g_lo = it0 / seg_per, g_hi = (it0 + ntile - 1) / seg_per;
+        // (ragged batches: the items are the real tiles, tile_pre[bag] of them in front of this bag — AttendArgs::tile_pre)
+        const long long it0 = tile_pre ? (long long)tile_pre[bag] : (long long)bag * seg_T, g_lo = it0 / seg_per, g_hi = (it0 + ntile - 1) / seg_per;
         slot0 = g_lo + bag;
         ntile = g_hi - g_lo + 1;
     }
@@ -1006,10 +1055,15 @@ __global__ __launch_bounds__(256) void k_finish(
     __shared__ __attribute__((aligned(16))) float s_acc[16][64];
     const int kb = (int)blockIdx.x * 64;           // this block's k-run
     const bool has_k = kb < Kv;
-    const long long rpb = (Nb + nblk - 1) / nblk;  // this block's share of the rows
+    long long rpb = (Nb + nblk - 1) / nblk;        // this block's share of the rows: an even split, but at least 256 (a short bag
+    rpb = rpb < 256 ? 256 : rpb;                   // of a ragged batch keeps its rows in few blocks; the others leave at once)
     const long long rbeg = (long long)blockIdx.x * rpb;
     const long long rend = (rbeg + rpb < Nb) ? rbeg + rpb : Nb;
     const int kq = tid & 15, tg = tid >> 4;
+    if (!has_k && rbeg >= rend && !ml_out) {   // a block of the grid (sized for the LONGEST bag) with neither rows nor a k-run of this bag
+        if (tid < C * C) pred_part[(((long long)bag * nblk + blockIdx.x) * C) * C + tid] = 0.f;
+        return;
+    }
     for (int c = 0; c < C; ++c) {
         // global max / sum of the bag
         float m = -INFINITY;
@@ -1136,7 +1190,7 @@ __global__ __launch_bounds__(256) void k_fc(const float* __restrict__ feats,
 
 // ---- host side ------------------------------------------------------------------------------
 struct WsLayout {
-    size_t part_val, part_idx, qmax, qflag, part_ml, part_B, pred_part, wsplit, wf2, rowmax, off2, total;
+    size_t part_val, part_idx, qmax, qflag, part_ml, part_B, pred_part, wsplit, wf2, rowmax, off2, tile_pre, total;
     long long slots0, slots, nchunk_max;
 };
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1182,6 +1236,7 @@ WsLayout ws_layout(int n_bags, long long total_rows, long long max_rows, int K, 
     w.wf2 = o; o = al(o + f2_image_bytes(K));     // k_attend_f2: fp16 two-plane query weights (when the caller brought none)
     w.rowmax = o; o = al(o + (size_t)total_rows * sizeof(float));   // k_attend_f2: max |x| per row (k_logits_stream)
     w.off2 = o; o = al(o + 2 * sizeof(int64_t));  // {0, N} of a lone shard (dsmil_agg_shard_*)
+    w.tile_pre = o; o = al(o + (size_t)2 * (n_bags + 1) * sizeof(int));   // ragged batches: tile prefixes of the persistent kernel and of the logits pass
     w.total = o;
     return w;
 }
@@ -1319,7 +1374,7 @@ int launch_attend_f2(const AttendArgs& a, const float* rowmax, long long max_row
 
 // batches of fp32 bags, two-layer query, C <= 2: 32-row tiles, the query weights resident in registers (agg_f3.h)
 template <int NK1>
-int launch_attend_f3_k(const AttendArgs& a, const float* rowmax, long long max_rows, int n_bags, hipStream_t st, int* seg_per, int* seg_T) {
+int launch_attend_f3_k(const AttendArgs& a, const float* rowmax, long long max_rows, long long total_rows, int n_bags, hipStream_t st, int* seg_per, int* seg_T) {
     void (*fn)(AttendArgs, const float*, int, int, int) = a.C == 2 ? k_attend_f3<NK1, true> : k_attend_f3<NK1, false>;
 #ifdef DSMIL_EXPERIMENTS
     static const int f3_dbg = expt_env("DSMIL_F3_DBG");
@@ -1332,8 +1387,10 @@ int launch_attend_f3_k(const AttendArgs& a, const float* rowmax, long long max_r
     constexpr int lds = f3_lds_bytes(32 * NK1);
     if (!dsmil_lds::allow((const void*)fn, lds)) return DSMIL_E_LAUNCH;
     const int cus = persistent_grid(F3_MAX_WG);
-    const long long tiles_per_bag = (max_rows + F3_BM - 1) / F3_BM;
-    const long long n_items = tiles_per_bag * n_bags;
+    // ragged batch (a.tile_pre): the items are the real tiles — at most total_rows / 32 + n_bags of them (the kernel reads the
+    // exact count from tile_pre[n_bags]); uniform: tiles_per_bag items per bag
+    const long long tiles_per_bag = a.tile_pre ? 0 : (max_rows + F3_BM - 1) / F3_BM;
+    const long long n_items = a.tile_pre ? total_rows / F3_BM + n_bags : tiles_per_bag * n_bags;
     if (n_items > 0x7fffffffLL) return DSMIL_E_UNSUPPORTED;
     const long long per = (n_items + cus - 1) / cus;   // contiguous runs of tile items per workgroup (k_attend_bf16_res's scheme)
     const unsigned grid = (unsigned)((n_items + per - 1) / per);
@@ -1344,12 +1401,12 @@ int launch_attend_f3_k(const AttendArgs& a, const float* rowmax, long long max_r
     dsmil_prof::end(dsmil_prof::CH_ATTEND, slot, st);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
-int launch_attend_f3(const AttendArgs& a, const float* rowmax, long long max_rows, int n_bags, hipStream_t st, int* seg_per, int* seg_T) {
+int launch_attend_f3(const AttendArgs& a, const float* rowmax, long long max_rows, long long total_rows, int n_bags, hipStream_t st, int* seg_per, int* seg_T) {
     switch (a.K / 32) {
-        case 4: return launch_attend_f3_k<4>(a, rowmax, max_rows, n_bags, st, seg_per, seg_T);
-        case 8: return launch_attend_f3_k<8>(a, rowmax, max_rows, n_bags, st, seg_per, seg_T);
-        case 12: return launch_attend_f3_k<12>(a, rowmax, max_rows, n_bags, st, seg_per, seg_T);
-        case 16: return launch_attend_f3_k<16>(a, rowmax, max_rows, n_bags, st, seg_per, seg_T);
+        case 4: return launch_attend_f3_k<4>(a, rowmax, max_rows, total_rows, n_bags, st, seg_per, seg_T);
+        case 8: return launch_attend_f3_k<8>(a, rowmax, max_rows, total_rows, n_bags, st, seg_per, seg_T);
+        case 12: return launch_attend_f3_k<12>(a, rowmax, max_rows, total_rows, n_bags, st, seg_per, seg_T);
+        case 16: return launch_attend_f3_k<16>(a, rowmax, max_rows, total_rows, n_bags, st, seg_per, seg_T);
         default: return DSMIL_E_UNSUPPORTED;
     }
 }
@@ -1393,7 +1450,7 @@ void (*bf16_res_fn(const AttendArgs& a))(AttendArgs, int, int, int) {
     return a.C == 2 ? (a.nonlinear ? k_attend_bf16_res<NCH, true, true> : k_attend_bf16_res<NCH, true, false>)
                     : (a.nonlinear ? k_attend_bf16_res<NCH, false, true> : k_attend_bf16_res<NCH, false, false>);
 }
-int launch_attend_bf16_res(AttendArgs a, long long max_rows, int n_bags, hipStream_t st, int* seg_per, int* seg_T) {
+int launch_attend_bf16_res(AttendArgs a, long long max_rows, long long total_rows, int n_bags, hipStream_t st, int* seg_per, int* seg_T) {
     const int cus = persistent_grid(RS_MAX_WG);
     typedef void (*res_fn)(AttendArgs, int, int, int);
     res_fn fn = a.K == 512 ? bf16_res_fn<8>(a) : bf16_res_fn<4>(a);
@@ -1404,8 +1461,8 @@ int launch_attend_bf16_res(AttendArgs a, long long max_rows, int n_bags, hipStre
     if (!dsmil_lds::allow((const void*)fn, RS_LDS_BYTES)) return DSMIL_E_LAUNCH;
     const int K64 = (a.K + 63) / 64 * 64;
     a.wpk = a.wpk + (size_t)QD * K64 + QD * QD;   // the fragment image sits behind the row-major one
-    const long long tiles_per_bag = (max_rows + RS_BM - 1) / RS_BM;
-    const long long n_items = tiles_per_bag * n_bags;
+    const long long tiles_per_bag = a.tile_pre ? 1 : (max_rows + RS_BM - 1) / RS_BM;   // (ragged: unused by the kernel)
+    const long long n_items = a.tile_pre ? total_rows / RS_BM + n_bags : tiles_per_bag * n_bags;
     if (n_items > 0x7fffffffLL) return DSMIL_E_UNSUPPORTED;
     // contiguous runs of tile items per workgroup: consecutive tiles belong to the same bag and share one partial
     const long long per = (n_items + cus - 1) / cus;
@@ -1604,21 +1661,33 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
                                hs_inline_fits(max_rows, nb, C);
         int* qflag = qm_inline ? (int*)(w8 + L.qflag) : nullptr;
         dim3 grid((unsigned)((max_rows + r0 - 1) / r0), (unsigned)nb);
+        // RAGGED batch in the 128-row regime (the persistent attend kernels and the streaming logits pass): the work lists are the
+        // real tiles (prefix per bag: k_tile_prefix), not n_bags x the tiles of the longest bag
+        int* tile_pre_a = nullptr;
+        int* tile_pre_l = nullptr;
+        if (NW == 4 && stream_ok && sh.phase == 0 && (long long)max_rows * nb != (long long)total_rows &&
+            total_rows / 32 + nb < 0x7fffffffLL) {
+            tile_pre_a = (int*)(w8 + L.tile_pre);
+            tile_pre_l = tile_pre_a + (nb + 1);
+            hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(1024), 0, st, offsets, nb, bf16 ? RS_BM : F3_BM, r0, tile_pre_a, tile_pre_l);
+            if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+        }
+        const dim3 grid_l = tile_pre_l ? dim3((unsigned)(total_rows / r0 + nb), 1u) : grid;   // (an upper bound of the real tiles)
         if (sh.phase == 2) {}  // the caller already knows the bag-wide critical rows
         else if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else if (bf16 && (K % 8 == 0) && !logits_old) {
             const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 63) / 64 + 1) * 64) * sizeof(float);
-            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, bf16_t>), grid, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0);
-            else hipLaunchKernelGGL((k_logits_stream<1, bf16_t>), grid, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0);
+            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, bf16_t>), grid_l, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, (int*)nullptr, TrainPrologueJob{}, (float*)nullptr, tile_pre_l, nb);
+            else hipLaunchKernelGGL((k_logits_stream<1, bf16_t>), grid_l, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, (int*)nullptr, TrainPrologueJob{}, (float*)nullptr, tile_pre_l, nb);
         }
         else if (bf16 && w4) hipLaunchKernelGGL((k_logits_argmax<4, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else if (bf16) hipLaunchKernelGGL((k_logits_argmax<1, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else if (v4 && !logits_old) {
             const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 31) / 32 + 1) * 32) * sizeof(float);
             const TrainPrologueJob job = sh.job ? *sh.job : TrainPrologueJob{};
-            dim3 gridj(grid.x + (unsigned)job.blocks, grid.y);
-            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, float>), gridj, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, qflag, job, rowmax);
-            else hipLaunchKernelGGL((k_logits_stream<1, float>), gridj, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, qflag, job, rowmax);
+            dim3 gridj(grid_l.x + (unsigned)job.blocks, grid_l.y);   // (a training step is one bag: never the flat grid)
+            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, float>), gridj, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, qflag, job, rowmax, tile_pre_l, nb);
+            else hipLaunchKernelGGL((k_logits_stream<1, float>), gridj, dim3(256), ldsw, st, f32, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, qflag, job, rowmax, tile_pre_l, nb);
         }
         else if (v4) hipLaunchKernelGGL((k_logits_argmax<4, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else hipLaunchKernelGGL((k_logits_argmax<1, false, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
@@ -1672,9 +1741,14 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         if (a.expt & 512) bf16_res = false;
 #endif
         const bool use_f3 = use_f2 && p->nonlinear && C <= 2 && g_use_f2.load(std::memory_order_relaxed) == 2;
-        if (use_f3) { rc = launch_attend_f3(a, rowmax, max_rows, nb, st, &seg_per, &seg_T); hs_bm = F3_BM; }
+        // ragged batch on a persistent kernel: the item list is the real tiles (prefix per bag), not max_rows-padded bags
+        if (tile_pre_a && (use_f3 || bf16_res)) {
+            a.tile_pre = tile_pre_a;
+            a.n_bags = nb;
+        }
+        if (use_f3) { rc = launch_attend_f3(a, rowmax, max_rows, total_rows, nb, st, &seg_per, &seg_T); hs_bm = F3_BM; }
         else if (use_f2) { rc = launch_attend_f2(a, rowmax, max_rows, nb, st); hs_bm = F2_BM; }
-        else if (bf16_res) rc = launch_attend_bf16_res(a, max_rows, nb, st, &seg_per, &seg_T);
+        else if (bf16_res) rc = launch_attend_bf16_res(a, max_rows, total_rows, nb, st, &seg_per, &seg_T);
         else if (bf16_dma) rc = launch_attend_bf16_dma(a, max_rows, nb, st);
         else if (bf16) rc = (NW == 4) ? launch_attend_bf16<4>(a, max_rows, nb, st) : launch_attend_bf16<1>(a, max_rows, nb, st);
 #ifdef DSMIL_EXPERIMENTS   // DSMIL_MLP=s9 and the ablation variants: not instantiated in the product library
@@ -1697,7 +1771,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     if (!DSMIL_EXPT_ON(a, 64)) {
         dim3 grid((unsigned)L.nchunk_max, (unsigned)n_bags);
         if (Kv % 4 == 0)
-            hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, hs_bm ? hs_bm : (seg_per ? RS_BM : BM), sh.ml_out, seg_per, seg_T);
+            hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, hs_bm ? hs_bm : (seg_per ? RS_BM : BM), sh.ml_out, seg_per, seg_T, a.tile_pre);
         else
             hipLaunchKernelGGL(k_finish<1>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM, sh.ml_out, 0, 0);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;

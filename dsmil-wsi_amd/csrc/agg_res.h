@@ -75,9 +75,13 @@ struct RsWork {
 
 // first work item in [item, end) whose tile lies inside its bag; false when the run is exhausted.  Evaluated identically
 // by every wave of the workgroup.
-__device__ __forceinline__ bool rs_fetch(const AttendArgs& a, int tiles_per_bag, int end, int& item, RsWork& w) {
+// (a.tile_pre != nullptr: a ragged batch — the items are the real tiles, tile_pre[b] of them in front of bag b; the bag of an
+// item: the bag of the item in front or the one behind it (three independent scalar loads), else by bisection)
+__device__ __forceinline__ bool rs_fetch(const AttendArgs& a, int tiles_per_bag, int end, int& item, RsWork& w, int guess = -1) {
     while (item < end) {
-        const int b = item / tiles_per_bag, tile = item - b * tiles_per_bag;
+        int b, tile;
+        if (a.tile_pre) { b = tile_owner_near(a.tile_pre, a.n_bags, item, guess); tile = item - a.tile_pre[b]; }
+        else { b = item / tiles_per_bag; tile = item - b * tiles_per_bag; }
         const int bag = a.bag0 + b;
         const long long off0 = a.offsets[bag];
         const long long Nb = a.offsets[bag + 1] - off0;
@@ -109,6 +113,10 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
     const f32x4* wpk = reinterpret_cast<const f32x4*>(a.wpk);   // chunk-major fragment image (k_pack_agg_bf16)
 
     int item = (int)blockIdx.x * per_wg;
+    if (a.tile_pre) {                                        // ragged batch: the host sized the runs from an upper bound
+        const int real = a.tile_pre[a.n_bags];
+        n_items = n_items < real ? n_items : real;
+    }
     const int item_end = item + per_wg < n_items ? item + per_wg : n_items;
     RsWork cur, nxt;
     if (!rs_fetch(a, tiles_per_bag, item_end, item, cur)) return;
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
     for (int t = 0;; ++t) {
         const int buf = t & 1;
         int in = item + 1;
-        const bool has_next = rs_fetch(a, tiles_per_bag, item_end, in, nxt);
+        const bool has_next = rs_fetch(a, tiles_per_bag, item_end, in, nxt, cur.bag - a.bag0);
         if (has_next) set_rows(nxt);
         if (cur.bag != ubag) {
             const float* qm0 = a.qmax + ((long long)cur.bag * C) * QD + 32 * wave + 4 * hi;

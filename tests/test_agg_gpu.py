@@ -556,3 +556,60 @@ def test_stream_pool_results_equal_single_stream():
         fh, ch = pl.embed_tiles(ic, src, batch_size=32, streams=3)
         torch.cuda.synchronize()
         assert fh.is_cuda and torch.equal(fh, f1) and torch.equal(ch, c1)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_ragged_batch_costs_its_rows_not_its_longest_bag(bf16):
+    """One 60 000-row bag among 300 bags of 64 rows (+ three of 9 000) in the 128-row regime: the persistent batch kernels
+    (k_attend_f3 / k_attend_bf16_res) walk the REAL tiles (k_tile_prefix: tiles in front of every bag) instead of n_bags x the
+    longest bag's tile count — parity of the long bag, short ones and the bags at the run boundaries with the fp64 oracle, two runs
+    bit-identical, and the launch costs about what a uniform batch of the same row count does (it was ~100x: the padded item list
+    gave the long bag to ONE workgroup)."""
+    import time
+    from dsmil_wsi_amd import ops, _native
+    L = _native.lib()
+    tag = "tcga" if bf16 else "c16"
+    w = load_weights(tag)
+    p = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in w.items()}
+    lengths = [64] * 150 + [60000] + [64] * 150 + [9000] * 3
+    assert L.dsmil_agg_tile_rows(len(lengths), sum(lengths)) == 128
+    bags = [make_bag(5000 + i, n, 512) for i, n in enumerate(lengths)]
+    xh = np.concatenate(bags)
+    x = torch.from_numpy(xh).cuda()
+    if bf16:
+        x = x.to(torch.bfloat16)
+    got = [t.clone() for t in ops.agg_forward(x, lengths, p)]
+    for a_, b_ in zip(ops.agg_forward(x, lengths, p), got):
+        assert torch.equal(a_, b_)
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    for b in (0, 1, 149, 150, 151, 152, 299, 300, 301, 303):
+        sl = slice(int(off[b]), int(off[b + 1]))
+        if bf16:
+            from test_agg_bf16_gpu import _round_bf16
+            r = orc.milnet_forward(_round_bf16(bags[b]), {k: _round_bf16(v) for k, v in w.items()}, dtype="f64")
+            cls, pred, A, B = [o.float().cpu().numpy() for o in (got[0][sl], got[1][b:b + 1], got[2][sl], got[3][b:b + 1])]
+            np.testing.assert_allclose(cls, r[0], atol=1e-4, rtol=1e-5)
+            np.testing.assert_allclose(A, r[2], atol=1e-6, rtol=3e-2)
+            np.testing.assert_allclose(B, r[3], atol=2e-3, rtol=2e-2)
+            np.testing.assert_allclose(pred, r[1], atol=2e-3, rtol=2e-2)
+            assert np.array_equal(got[4][b].cpu().numpy(), r[4])
+        else:
+            r = orc.milnet_forward(bags[b], w, dtype="f64")
+            _cmp((got[0][sl], got[1][b:b + 1], got[2][sl], got[3][b:b + 1]), r[0], r[1], r[2], r[3], r[4], got[4][b].cpu().numpy())
+    # cost: against a uniform batch of (about) the same number of rows
+    nb_u = 16
+    n_u = sum(lengths) // nb_u
+    xu = x[:nb_u * n_u]
+
+    def timed(xx, ll):
+        for _ in range(3):
+            ops.agg_forward(xx, ll, p)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ops.agg_forward(xx, ll, p)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 20
+    t_ragged, t_uniform = timed(x, lengths), timed(xu, [n_u] * nb_u)
+    print(f"ragged {t_ragged * 1e6:.0f} us, uniform batch of the same rows {t_uniform * 1e6:.0f} us")
+    assert t_ragged < 3.0 * t_uniform + 100e-6, (t_ragged, t_uniform)
