@@ -95,7 +95,7 @@ ACT_BYTES_PER_PATCH = (3 * 224 * 224 * 4 + 112 * 112 * 64 * 4          # stem
                              for p, h in ((56, 28), (28, 14), (14, 7))))           # 3 stride-1 convs, 2 residual kernels
 
 
-KERNEL_TABLE = "r05_kernel_table.json"   # the latest committed per-kernel table (tools/kernel_table.py)
+KERNEL_TABLE = "r06_kernel_table.json"   # the latest committed per-kernel table (tools/kernel_table.py)
 
 
 def _kernel_table(leg):
