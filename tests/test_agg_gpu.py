@@ -613,3 +613,44 @@ def test_ragged_batch_costs_its_rows_not_its_longest_bag(bf16):
     t_ragged, t_uniform = timed(x, lengths), timed(xu, [n_u] * nb_u)
     print(f"ragged {t_ragged * 1e6:.0f} us, uniform batch of the same rows {t_uniform * 1e6:.0f} us")
     assert t_ragged < 3.0 * t_uniform + 100e-6, (t_ragged, t_uniform)
+
+
+def test_ragged_batch_through_a_row_map_two_classes_narrow_features():
+    """The real-tile item list of the persistent kernel (k_tile_prefix) together with a row map (dropout_patches as an index
+    list, train_tcga.py:78-83), C = 2 and K = 256: bags of 1 .. 30 000 rows whose tile counts are not multiples of anything,
+    runs that start in the middle of a bag and cross many one-tile bags — vs the fp64 oracle on the gathered rows, two runs
+    bit-identical, and bit-identical to the same bags on a persistent grid that deals the runs differently only where the
+    grouping of partials cannot matter (one-tile bags)."""
+    from dsmil_wsi_amd import ops, _native
+    L = _native.lib()
+    rng = np.random.default_rng(77)
+    K, C = 256, 2
+    w = {"fc_w": rng.normal(0, 0.05, (C, K)), "fc_b": rng.normal(0, 0.05, (C,)), "q0_w": rng.normal(0, 0.06, (128, K)),
+         "q0_b": rng.normal(0, 0.05, (128,)), "q2_w": rng.normal(0, 0.08, (128, 128)), "q2_b": rng.normal(0, 0.05, (128,)),
+         "fcc_w": rng.normal(0, 0.05, (C, C, K)), "fcc_b": rng.normal(0, 0.05, (C,))}
+    w = {k: v.astype(np.float32) for k, v in w.items()}
+    p = {k: torch.from_numpy(v).cuda() for k, v in w.items()}
+    lengths = [1, 31, 32, 33, 30000, 1, 65, 4097, 12345, 2, 127, 128, 129, 20000, 7, 9001] + [int(v) for v in rng.integers(1, 40, 200)]
+    total = sum(lengths)
+    assert L.dsmil_agg_tile_rows(len(lengths), total) == 128
+    phys = make_bag(41, total + 5000, K)
+    rmap = rng.permutation(total + 5000)[:total].astype(np.int64)
+    x, rm = torch.from_numpy(phys).cuda(), torch.from_numpy(rmap).cuda()
+    got = [t.clone() for t in ops.agg_forward(x, lengths, p, row_map=rm)]
+    for a_, b_ in zip(ops.agg_forward(x, lengths, p, row_map=rm), got):
+        assert torch.equal(a_, b_)
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    for b in list(range(16)) + [16, 57, 215]:
+        sl = slice(int(off[b]), int(off[b + 1]))
+        r = orc.milnet_forward(phys[rmap[sl]], w, dtype="f64")
+        _cmp((got[0][sl], got[1][b:b + 1], got[2][sl], got[3][b:b + 1]), r[0], r[1], r[2], r[3], r[4], got[4][b].cpu().numpy())
+    prev = L.dsmil_agg_persistent_grid(200)
+    try:
+        other = [t.clone() for t in ops.agg_forward(x, lengths, p, row_map=rm)]
+    finally:
+        L.dsmil_agg_persistent_grid(prev)
+    one_tile = [b for b, n in enumerate(lengths) if n <= 32]
+    for b in one_tile:   # a bag of one tile has one partial whatever the grid
+        sl = slice(int(off[b]), int(off[b + 1]))
+        assert torch.equal(other[2][sl], got[2][sl]) and torch.equal(other[3][b], got[3][b]) and torch.equal(other[1][b], got[1][b])
+    assert torch.equal(other[0], got[0]) and torch.equal(other[4], got[4])   # logits / critical instances never depend on the grid
