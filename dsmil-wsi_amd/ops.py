@@ -730,3 +730,91 @@ def tile_stats(tiles):
         rc = _native.lib().dsmil_tile_stats(_ptr(tiles), B, H, W, _ptr(out), _stream(tiles.device))
     _native.check(rc, "dsmil_tile_stats")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# batched baseline-JPEG decode on the device (compute_feats.py:28,107 `Image.open` in DataLoader workers)
+# ---------------------------------------------------------------------------------------------
+JPEG_REC = np.dtype([("ecs_begin", "<i8"), ("ecs_end", "<i8"), ("width", "<i4"), ("height", "<i4"), ("ncomp", "<i4"),
+                     ("hsamp", "<i4"), ("vsamp", "<i4"), ("restart_interval", "<i4"), ("qt", "<i4", 3), ("dc", "<i4", 3),
+                     ("ac", "<i4", 3), ("status", "<i4")])   # struct dsmil_jpeg_image
+
+
+def jpeg_parse(blobs):
+    """dsmil_jpeg_parse (HOST): the files of a batch (bytes-likes) -> (data uint8 [total] numpy, plan uint8 numpy, records =
+    a structured view of the plan's per-image records: status 0 = decodable on the device, -2 = outside the decoder's scope,
+    -1 = not a JPEG)."""
+    n = len(blobs)
+    if n == 0:
+        raise ValueError("no files")
+    sizes = np.fromiter((len(b) for b in blobs), dtype=np.int64, count=n)
+    offsets = np.zeros(n + 1, np.int64)
+    np.cumsum(sizes, out=offsets[1:])
+    data = np.empty(int(offsets[-1]) + 16, np.uint8)     # (+16: the device reader may look one byte past a segment's end)
+    data[int(offsets[-1]):] = 0
+    mv = memoryview(data)
+    for b, o, s in zip(blobs, offsets[:-1], sizes):
+        mv[int(o):int(o + s)] = b
+    L = _native.lib()
+    plan = np.zeros(L.dsmil_jpeg_plan_bytes(n) + 16, np.uint8)
+    a = (-plan.ctypes.data) % 16
+    plan = plan[a:a + L.dsmil_jpeg_plan_bytes(n)]
+    _native.check(L.dsmil_jpeg_parse(data.ctypes.data, offsets.ctypes.data, n, plan.ctypes.data), "dsmil_jpeg_parse")
+    recs = plan[16:16 + JPEG_REC.itemsize * n].view(JPEG_REC)
+    return data, plan, recs
+
+
+def _pil_rgb(blob):
+    import io
+    from PIL import Image
+    with Image.open(io.BytesIO(blob)) as im:
+        return np.array(im.convert("RGB"), dtype=np.uint8, copy=True)
+
+
+def jpeg_decode(blobs, device, size=None, stats=None):
+    """A batch of JPEG files (bytes-likes) -> uint8 [n, H, W, 3] on `device`, what
+    `np.array(Image.open(f).convert("RGB"))` gives for every file (compute_feats.py:28 + the uint8 half of VF.to_tensor):
+    baseline JPEGs are decoded on the device by dsmil_jpeg_decode (bit-identical to Pillow's defaults: islow IDCT, fancy
+    upsampling), every other file (progressive, CMYK, a PNG ...) and every stream the device decoder reports as corrupt is
+    decoded with Pillow on the host and copied in — the result never depends on which path a file took.
+    ``size`` = (H, W) of the batch (default: the first decodable image's); all files must have it.
+    ``stats`` (dict, optional) gets the counts {"device": .., "pillow": ..}."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("jpeg_decode needs a CUDA(HIP) device")
+    n = len(blobs)
+    data, plan, recs = jpeg_parse(blobs)
+    ok = recs["status"] == 0
+    if size is None:
+        if ok.any():
+            j = int(np.argmax(ok))
+            size = (int(recs["height"][j]), int(recs["width"][j]))
+        else:
+            size = _pil_rgb(blobs[0]).shape[:2]
+    H, W = int(size[0]), int(size[1])
+    on_dev = ok & (recs["height"] == H) & (recs["width"] == W)
+    recs["status"][ok & ~on_dev] = -2          # another size: not this batch's launch (the Pillow path below checks the size)
+    out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+    status = torch.empty(n, dtype=torch.int32, device=dev)
+    L = _native.lib()
+    if on_dev.any():
+        d_data = torch.from_numpy(data).to(dev, non_blocking=True)
+        d_plan = torch.from_numpy(plan).to(dev, non_blocking=True)
+        nbytes = L.dsmil_jpeg_workspace_bytes(n, H, W)
+        ws = _workspace(dev, nbytes)
+        with torch.cuda.device(dev):
+            rc = L.dsmil_jpeg_decode(_ptr(d_data), _ptr(d_plan), n, H, W, _ptr(out), _ptr(status), _ptr(ws), ws.numel(), _stream(dev))
+        _native.check(rc, "dsmil_jpeg_decode")
+        st = status.cpu().numpy()
+    else:
+        st = recs["status"].copy()
+    redo = np.nonzero(st != 0)[0]
+    for i in redo:
+        a = _pil_rgb(blobs[int(i)])
+        if a.shape[:2] != (H, W):
+            raise ValueError(f"file {int(i)} of the batch is {a.shape[1]}x{a.shape[0]}, the batch is {W}x{H}")
+        out[int(i)].copy_(torch.from_numpy(a))
+    if stats is not None:
+        stats["device"] = stats.get("device", 0) + int(n - len(redo))
+        stats["pillow"] = stats.get("pillow", 0) + int(len(redo))
+    return out

