@@ -15,11 +15,11 @@
 // to the caller's Pillow path — never a wrong pixel.
 //
 // Three launches per batch, all images of a batch the same width x height:
-//   k_jpeg_huffman  one LANE per image walks its entropy-coded segment (T.81 F.2.2: 9-bit lookahead table, canonical slow path,
-//                   FF00 unstuffing, RSTn) and scatters the non-zero quantised coefficients (int16, natural order) into a
+//   k_jpeg_huffman  one LANE per image walks its entropy-coded segment (T.81 F.2.2: 12-bit lookahead table, canonical slow path,
+//                   FF00 unstuffing, RSTn) and scatters the non-zero quantised coefficients (int16, zigzag order) into a
 //                   zeroed buffer.  Huffman decoding is serial per stream; a slide has 10^4-10^5 streams, which is the
-//                   parallelism used.  The wave is tiny (no LDS, < 64 registers): it runs BESIDE the embedder's one-workgroup-
-//                   per-CU conv kernels of the previous batch.
+//                   parallelism used: 1 024-lane workgroups (four waves per SIMD hide each other's lookup latency; a batch of
+//                   8 192 tiles holds 8 compute units, the embedder's conv kernels of the previous batch keep the rest).
 //   k_jpeg_idct     one thread per 8x8 block: dequantise, jidctint.c's integer inverse DCT (CONST_BITS 13, PASS1_BITS 2), level
 //                   shift, clamp -> component planes.
 //   k_jpeg_color    one thread per output pixel: jdsample.c's triangle ("fancy") chroma upsampling with jdmainct.c's replicated
@@ -35,10 +35,10 @@ namespace {
 
 constexpr int JP_MAX_QT = DSMIL_JPEG_MAX_TABLES;   // distinct quantisation / Huffman tables per batch
 constexpr int JP_MAX_HT = DSMIL_JPEG_MAX_TABLES;
-constexpr int JP_LOOK = 9;                         // lookahead bits of the fast Huffman table
+constexpr int JP_LOOK = 12;                        // lookahead bits of the fast Huffman table
 
 struct JpHuff {                 // one Huffman table, device form
-    uint16_t look[1 << JP_LOOK];    // (length << 8) | symbol for codes of <= 9 bits, 0 otherwise
+    uint16_t look[1 << JP_LOOK];    // (length << 8) | symbol for codes of <= JP_LOOK bits, 0 otherwise
     int32_t maxcode[18];            // largest code of length l (-1: none); [17] = sentinel
     int32_t valoff[18];             // huffval index of the first code of length l minus that code
     uint8_t vals[256];
@@ -52,9 +52,6 @@ __host__ __device__ inline size_t jp_off_qt(int n) { return (jp_off_images() + (
 __host__ __device__ inline size_t jp_off_ht(int n) { return jp_off_qt(n) + (size_t)JP_MAX_QT * 64 * sizeof(uint16_t); }
 __host__ __device__ inline size_t jp_plan_bytes(int n) { return jp_off_ht(n) + (size_t)JP_MAX_HT * sizeof(JpHuff); }
 
-__device__ __constant__ uint8_t JP_ZIGZAG[64] = {
-    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
-    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 static const uint8_t JP_ZIGZAG_H[64] = {
     0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
     35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
@@ -74,41 +71,81 @@ struct JpGeom {
 // ---------------------------------------------------------------------------------------------------------------------
 // k_jpeg_huffman
 // ---------------------------------------------------------------------------------------------------------------------
+// SIMT shapes this kernel: the 64 lanes of a wave decode 64 different streams, and a wave executes the UNION of its lanes'
+// control paths.  The first form (byte-wise refill loop, 9-bit lookahead + canonical bit-by-bit slow path, zigzag lookup per
+// coefficient) ran every rare path in nearly every iteration because SOME lane needed it: ~4 000 cycles per symbol.  Now
+//   * one refill point per symbol, at most two byte-group moves, no loop; the stream sits in a 16-byte register queue (`raw` in
+//     front, `nxt` prefetched: the global load of the following eight bytes is issued when `raw` is replaced and is not waited
+//     for until `raw` runs out again); an 0xFF at the queue's front (stuffed byte or marker) is resolved in registers;
+//   * ONE table lookup per symbol for codes of up to JP_LOOK = 12 bits, from LDS; longer codes (rare symbols of the standard
+//     tables, < 0.1 % of the stream) take the canonical compare chain;
+//   * coefficients are stored in ZIGZAG order (k_jpeg_idct reads them through constant indices): no map lookup per symbol.
 struct JpBits {
-    const uint8_t* p;       // next unread byte
-    const uint8_t* end;
+    const uint8_t* p;       // address of the first byte behind `nxt`
     unsigned long long acc; // the low `n` bits are valid, MSB first
-    int n;
-    __device__ __forceinline__ void fill() {        // at least 32 valid bits afterwards (zeros behind the segment / a marker)
-        while (n <= 56) {
-            unsigned b = 0;
-            if (p < end) {
-                b = *p;
-                if (b == 0xFF) {
-                    const unsigned nx = (p + 1 < end) ? p[1] : 0xD9u;
-                    if (nx == 0) p += 2;            // a stuffed FF
-                    else b = 0;                     // a marker: stay in front of it, feed zeros (libjpeg's "insufficient data")
-                } else {
-                    ++p;
-                }
-            }
-            acc = (acc << 8) | b;
-            n += 8;
+    unsigned long long raw; // the next `rawn` bytes of the stream, first byte in the top byte
+    unsigned long long nxt; // the eight bytes behind them (prefetched)
+    int n, rawn;
+    __device__ __forceinline__ static unsigned long long load8(const uint8_t* q) {
+        unsigned long long w;
+        __builtin_memcpy(&w, q, 8);
+        return __builtin_bswap64(w);
+    }
+    __device__ __forceinline__ void init(const uint8_t* q) {
+        acc = 0; n = 0;
+        raw = load8(q); nxt = load8(q + 8); rawn = 8; p = q + 16;
+    }
+    __device__ __forceinline__ void drop(int k) {       // k <= rawn bytes leave the front of the queue
+        raw = k >= 8 ? 0ull : raw << (8 * k);
+        rawn -= k;
+        if (rawn == 0) { raw = nxt; rawn = 8; nxt = load8(p); p += 8; }
+    }
+    // one step: bytes from the queue's front into the bit buffer — a whole group while none of them is 0xFF, else one byte
+    // with the stuffing / marker rules (a marker stays at the front and feeds zeros: libjpeg's "insufficient data")
+    __device__ __forceinline__ void step() {
+        int k = (64 - n) >> 3;
+        k = k < rawn ? k : rawn;
+        const unsigned long long low = k == 8 ? 0ull : (0x0101010101010101ull >> (8 * k));
+        const unsigned long long v = ~raw | low;       // a zero byte among the top k <=> an 0xFF among the top k bytes of raw
+        if (((v - 0x0101010101010101ull) & ~v & 0x8080808080808080ull) == 0ull) {
+            acc = k == 8 ? raw : ((acc << (8 * k)) | (raw >> (64 - 8 * k)));
+            n += 8 * k;
+            drop(k);
+            return;
         }
+        unsigned b = (unsigned)(raw >> 56);
+        if (b != 0xFFu) { drop(1); }
+        else {
+            const unsigned nx = rawn >= 2 ? (unsigned)(raw >> 48) & 255u : (unsigned)(nxt >> 56);
+            if (nx == 0) {                              // a stuffed FF: both bytes leave
+                if (rawn >= 2) drop(2);
+                else { drop(1); drop(1); }
+            } else {
+                b = 0;                                  // a marker: stays
+            }
+        }
+        acc = (acc << 8) | b;
+        n += 8;
+    }
+    __device__ __forceinline__ void fill32() {          // >= 32 valid bits afterwards (a code + its magnitude bits are <= 27)
+        while (n < 32) step();                          // (one or two steps; every step moves at least one byte)
     }
     __device__ __forceinline__ unsigned peek(int k) const { return (unsigned)(acc >> (n - k)) & ((1u << k) - 1u); }
     __device__ __forceinline__ void skip(int k) { n -= k; }
-    __device__ __forceinline__ void restart() {     // byte-align, step over the RSTn marker
+    // restart: the bit buffer holds padding (and zeros fed at the marker); the queue's front must be the RSTn marker
+    __device__ __forceinline__ bool restart() {
         acc = 0; n = 0;
-        while (p + 1 < end && !(p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7)) ++p;
-        p += 2;
-        if (p > end) p = end;
+        const unsigned b0 = (unsigned)(raw >> 56);
+        const unsigned b1 = rawn >= 2 ? (unsigned)(raw >> 48) & 255u : (unsigned)(nxt >> 56);
+        if (b0 != 0xFFu || b1 < 0xD0u || b1 > 0xD7u) return false;
+        if (rawn >= 2) drop(2);
+        else { drop(1); drop(1); }
+        return true;
     }
 };
 
-// one Huffman symbol (T.81 F.2.2.3 with jdhuff.c's lookahead); -1 on a code no table entry matches
+// one Huffman symbol (T.81 F.2.2.3 with a 12-bit lookahead, jdhuff.c's scheme); the caller has >= 32 bits; -1: no such code
 __device__ __forceinline__ int jp_symbol(JpBits& b, const JpHuff* __restrict__ t) {
-    if (b.n < 16) b.fill();
     const unsigned e = t->look[b.peek(JP_LOOK)];
     if (e) {
         b.skip((int)(e >> 8));
@@ -121,66 +158,93 @@ __device__ __forceinline__ int jp_symbol(JpBits& b, const JpHuff* __restrict__ t
     b.skip(l);
     return t->vals[((code16 >> (16 - l)) + t->valoff[l]) & 255];
 }
-__device__ __forceinline__ int jp_receive_extend(JpBits& b, int s) {
-    if (b.n < s) b.fill();
+__device__ __forceinline__ int jp_receive_extend(JpBits& b, int s) {   // s in 1..15, the bits are there
     const int v = (int)b.peek(s);
     b.skip(s);
     return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
 }
 
-__global__ __launch_bounds__(64) void k_jpeg_huffman(const uint8_t* __restrict__ data, const uint8_t* __restrict__ plan, int n,
-                                                     int W, int H, int16_t* __restrict__ coef, int32_t* __restrict__ status) {
-    const int i = (int)blockIdx.x * 64 + threadIdx.x;
+// Workgroups of JP_HT threads = 16 waves, four per SIMD: a lane's decode is a chain of dependent steps, the waves of a SIMD hide
+// each other's latency, and a batch of 8 192 tiles occupies EIGHT compute units instead of one wave on each of 128 — the
+// embedder's conv kernels of the previous batch (one 512-register workgroup per CU) keep the other 248.  The batch's Huffman
+// tables (a tiler writes the same four into every tile) are staged in LDS when there are at most JP_LDS_HT of them; the lookups
+// go through generic pointers either way.
+constexpr int JP_HT = 1024;
+constexpr int JP_LDS_HT = 4;
+__global__ __launch_bounds__(JP_HT) void k_jpeg_huffman(const uint8_t* __restrict__ data, const uint8_t* __restrict__ plan, int n,
+                                                        int W, int H, int16_t* __restrict__ coef, int32_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) unsigned s_tab[JP_LDS_HT * sizeof(JpHuff) / 4];
+    const int n_ht = reinterpret_cast<const JpHeader*>(plan)->n_ht;
+    const bool in_lds = n_ht <= JP_LDS_HT;
+    if (in_lds) {
+        const unsigned* src = reinterpret_cast<const unsigned*>(plan + jp_off_ht(n));
+        for (int t = threadIdx.x; t < n_ht * (int)(sizeof(JpHuff) / 4); t += JP_HT) s_tab[t] = src[t];
+    }
+    __syncthreads();
+    const int i = (int)blockIdx.x * JP_HT + threadIdx.x;
     if (i >= n) return;
-    const dsmil_jpeg_image im = reinterpret_cast<const dsmil_jpeg_image*>(plan + jp_off_images())[i];
-    if (im.status != DSMIL_OK) { status[i] = im.status; return; }
-    const JpHuff* hts = reinterpret_cast<const JpHuff*>(plan + jp_off_ht(n));
+    const dsmil_jpeg_image* imp = reinterpret_cast<const dsmil_jpeg_image*>(plan + jp_off_images()) + i;
+    const int ist = imp->status;
+    if (ist != DSMIL_OK) { status[i] = ist; return; }
+    const JpHuff* hts = in_lds ? reinterpret_cast<const JpHuff*>(s_tab) : reinterpret_cast<const JpHuff*>(plan + jp_off_ht(n));
     const JpGeom g(W, H);
     int16_t* cimg = coef + (size_t)i * g.coef_elems();
-    const int hs = im.hsamp, vs = im.vsamp;
+    const int ncomp = imp->ncomp, hs = imp->hsamp, vs = imp->vsamp, ri = imp->restart_interval;
+    // (registers, not an indexed copy of the record: a dynamically indexed local array lives in scratch memory)
+    const JpHuff* dc0 = hts + imp->dc[0];
+    const JpHuff* ac0 = hts + imp->ac[0];
+    const JpHuff* dc1 = hts + imp->dc[1];
+    const JpHuff* ac1 = hts + imp->ac[1];
+    const JpHuff* dc2 = hts + imp->dc[2];
+    const JpHuff* ac2 = hts + imp->ac[2];
     const int mx = (W + 8 * hs - 1) / (8 * hs), my = (H + 8 * vs - 1) / (8 * vs);
     JpBits b;
-    b.p = data + im.ecs_begin; b.end = data + im.ecs_end; b.acc = 0; b.n = 0;
-    int pred[3] = {0, 0, 0};
+    b.init(data + imp->ecs_begin);
+    int pred0 = 0, pred1 = 0, pred2 = 0;
     int st = DSMIL_OK;
     int n_mcu = 0;
-    const int ri = im.restart_interval;
     const int bw = g.Wp >> 3;                          // blocks per row of a full-resolution plane (the row stride of every plane)
+    const int nblk_mcu = hs * vs + (ncomp == 3 ? 2 : 0);
     for (int yy = 0; yy < my && st == DSMIL_OK; ++yy) {
         for (int xx = 0; xx < mx && st == DSMIL_OK; ++xx) {
             if (ri && n_mcu && (n_mcu % ri) == 0) {
-                b.restart();
-                pred[0] = pred[1] = pred[2] = 0;
+                if (!b.restart()) { st = DSMIL_E_INVALID; break; }
+                pred0 = pred1 = pred2 = 0;
             }
             ++n_mcu;
-            for (int c = 0; c < im.ncomp && st == DSMIL_OK; ++c) {
-                const int ch = c ? 1 : hs, cv = c ? 1 : vs;
-                const JpHuff* dct = hts + im.dc[c];
-                const JpHuff* act = hts + im.ac[c];
-                for (int v = 0; v < cv && st == DSMIL_OK; ++v)
-                    for (int h = 0; h < ch && st == DSMIL_OK; ++h) {
-                        int16_t* blk = cimg + ((size_t)c * g.blocks_plane + (size_t)(yy * cv + v) * bw + (xx * ch + h)) * 64;
-                        int s = jp_symbol(b, dct);
-                        if (s < 0 || s > 15) { st = DSMIL_E_INVALID; break; }
-                        if (s) pred[c] += jp_receive_extend(b, s);
-                        if (pred[c]) blk[0] = (int16_t)pred[c];
-                        int k = 1;
-                        while (k < 64) {
-                            const int rs = jp_symbol(b, act);
-                            if (rs < 0) { st = DSMIL_E_INVALID; break; }
-                            const int r = rs >> 4;
-                            s = rs & 15;
-                            if (s == 0) {
-                                if (r != 15) break;            // EOB
-                                k += 16;
-                                continue;
-                            }
-                            k += r;
-                            if (k > 63) { st = DSMIL_E_INVALID; break; }
-                            blk[JP_ZIGZAG[k]] = (int16_t)jp_receive_extend(b, s);
-                            ++k;
-                        }
+            for (int bi = 0; bi < nblk_mcu && st == DSMIL_OK; ++bi) {
+                // block bi of the MCU: the hs x vs luma blocks row by row, then Cb, then Cr
+                const int c = bi < hs * vs ? 0 : bi - hs * vs + 1;
+                const int v = c ? 0 : bi / hs, h = c ? 0 : bi - v * hs;
+                const int cv = c ? 1 : vs, ch = c ? 1 : hs;
+                const JpHuff* dct = c == 0 ? dc0 : (c == 1 ? dc1 : dc2);
+                const JpHuff* act = c == 0 ? ac0 : (c == 1 ? ac1 : ac2);
+                int16_t* blk = cimg + ((size_t)c * g.blocks_plane + (size_t)(yy * cv + v) * bw + (xx * ch + h)) * 64;
+                b.fill32();
+                int s = jp_symbol(b, dct);
+                if (s < 0 || s > 15) { st = DSMIL_E_INVALID; break; }
+                int diff = 0;
+                if (s) diff = jp_receive_extend(b, s);
+                int pr = (c == 0 ? pred0 : (c == 1 ? pred1 : pred2)) + diff;
+                if (c == 0) pred0 = pr; else if (c == 1) pred1 = pr; else pred2 = pr;
+                if (pr) blk[0] = (int16_t)pr;
+                int k = 1;
+                while (k < 64) {
+                    b.fill32();
+                    const int rs = jp_symbol(b, act);
+                    if (rs < 0) { st = DSMIL_E_INVALID; break; }
+                    const int r = rs >> 4;
+                    s = rs & 15;
+                    if (s == 0) {
+                        if (r != 15) break;            // EOB
+                        k += 16;
+                        continue;
                     }
+                    k += r;
+                    if (k > 63) { st = DSMIL_E_INVALID; break; }
+                    blk[k] = (int16_t)jp_receive_extend(b, s);      // ZIGZAG position k
+                    ++k;
+                }
             }
         }
     }
@@ -202,6 +266,11 @@ __global__ __launch_bounds__(64) void k_jpeg_huffman(const uint8_t* __restrict__
 #define JP_F2053 16819
 #define JP_F2562 20995
 #define JP_F3072 25172
+
+// natural position -> zigzag position (the coefficient buffer is in zigzag order)
+__device__ constexpr int JP_UNZIG[64] = {
+    0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42, 3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53,
+    10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
 
 // one 8-point pass over x[0..7 * stride] -> o[0..7]; descale by `shift` bits (round to nearest, arithmetic shift)
 template <int SHIFT>
@@ -256,7 +325,7 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const uint8_t* __restrict__ p
     for (int col = 0; col < 8; ++col) {
         int x[8], o[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = (int)src[r * 8 + col] * (int)q[r * 8 + col];
+        for (int r = 0; r < 8; ++r) x[r] = (int)src[JP_UNZIG[r * 8 + col]] * (int)q[r * 8 + col];   // (constant indices: the loops are unrolled)
         jp_idct8<13 - 2>(x, o);
 #pragma unroll
         for (int r = 0; r < 8; ++r) ws[r][col] = o[r];
@@ -519,7 +588,7 @@ int dsmil_jpeg_decode(const uint8_t* data, const void* plan, int32_t n, int32_t 
     int16_t* coef = (int16_t*)ws;
     uint8_t* planes = (uint8_t*)ws + (size_t)n * g.coef_elems() * sizeof(int16_t);
     if (hipMemsetAsync(coef, 0, (size_t)n * g.coef_elems() * sizeof(int16_t), st) != hipSuccess) return DSMIL_E_LAUNCH;
-    hipLaunchKernelGGL(k_jpeg_huffman, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, data, (const uint8_t*)plan, n, width, height, coef, status);
+    hipLaunchKernelGGL(k_jpeg_huffman, dim3((unsigned)((n + JP_HT - 1) / JP_HT)), dim3(JP_HT), 0, st, data, (const uint8_t*)plan, n, width, height, coef, status);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     hipLaunchKernelGGL(k_jpeg_idct, dim3((unsigned)((3 * g.blocks_plane + 255) / 256), (unsigned)n), dim3(256), 0, st,
                        (const uint8_t*)plan, n, width, height, coef, planes, status);
