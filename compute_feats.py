@@ -48,6 +48,10 @@ def build_parser():
     p.add_argument("--precision", default="fp32", choices=("fp32", "half"),
                    help="(new, default fp32 = the parity path) half: the native trunk rounds every conv operand to one fp16 "
                         "plane (f32 accumulation, fp32 norms): ~2e-3 feature error, faster; the reference has no such switch")
+    p.add_argument("--gpu_decode", action="store_true",
+                   help="(new, default off) decode the tiles' JPEG files on the GPU (dsmil_jpeg_decode: baseline JPEGs, bit-identical to "
+                        "Pillow; other files take Pillow inside the same call) instead of in --num_workers DataLoader processes "
+                        "(compute_feats.py:28,55): a tenth of the PCIe bytes, no decode-bound loader")
     p.add_argument("--save_npy", action="store_true",
                    help="(new) also write each bag's features as float32 <bag>.npy next to the '%%.4f' CSV: lossless "
                         "and ~6x smaller/faster to load than the text detour of compute_feats.py:80-82")
@@ -113,6 +117,7 @@ def main(argv=None):
     os.makedirs(feats_path, exist_ok=True)
     if args.bg_threshold is not None and args.magnification == "tree":
         raise ValueError("--bg_threshold filters single-magnification bags (a pyramid bag's rows are tied to its tile tree)")
+    pipeline.GPU_DECODE[0] = bool(args.gpu_decode)
     if args.magnification == "tree":
         pipeline.compute_tree_feats(args, bags_list, ic_l, ic_h, feats_path)
     else:

@@ -84,9 +84,42 @@ def glob_patches(bag_dir, magnification="single"):
     return out
 
 
+# Default of embed_files(gpu_decode=None): the scripts set it from their --gpu_decode flag (compute_feats.py, attention_map.py)
+GPU_DECODE = [False]
+
+
+def gpu_decoded_batches(files, batch_size, device, io_threads=4, decode_batch=2048, stats=None):
+    """The loader of compute_feats.py:21-56 (`Image.open` + ToTensor in DataLoader workers) with the decode on the DEVICE: the
+    files' bytes are read by a thread pool, `decode_batch` files at a time go through ops.jpeg_decode (baseline JPEGs:
+    dsmil_jpeg_decode, bit-identical to Pillow; anything else: Pillow on the host inside the same call) and come back as uint8
+    NHWC batches of `batch_size` already on `device` — what PatchFiles(uint8=True) yields after its H2D copy, at a tenth of the
+    PCIe bytes and without worker processes.  The next chunk's files are read while the current one is embedded."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def read(path):
+        with open(path, "rb") as f:
+            return f.read()
+
+    files = list(files)
+    if not files:
+        return
+    with ThreadPoolExecutor(max_workers=max(1, int(io_threads))) as pool:
+        chunks = [files[i:i + decode_batch] for i in range(0, len(files), decode_batch)]
+        pending = pool.map(read, chunks[0])
+        size = None
+        for ci in range(len(chunks)):
+            blobs = list(pending)
+            if ci + 1 < len(chunks):
+                pending = pool.map(read, chunks[ci + 1])       # (submitted now: read while this chunk decodes and embeds)
+            imgs = ops.jpeg_decode(blobs, device, size=size, stats=stats)
+            size = tuple(imgs.shape[1:3])
+            for o in range(0, imgs.shape[0], batch_size):
+                yield {"input": imgs[o:o + batch_size]}
+
+
 @torch.no_grad()
 def embed_files(i_classifier, files, batch_size=128, num_workers=4, device=None, want_position=False,
-                sharded=True, bg_threshold=None, return_keep=False):
+                sharded=True, bg_threshold=None, return_keep=False, gpu_decode=None):
     """The hot loop of compute_feats.py:70-76 / attention_map.py:69-79.  Returns
     (feats [N,F], classes [N,C]) on `device` (and positions [N,2] if asked).  Sharded over ranks
     when torch.distributed is initialised.
@@ -96,7 +129,9 @@ def embed_files(i_classifier, files, batch_size=128, num_workers=4, device=None,
     The statistics come from dsmil_tile_stats on the decoded uint8 batch (exact integer sums, decisions identical to
     PIL's); rows, logits and positions of dropped tiles are absent from the result (N = tiles kept), as if the tiler
     had not written them.  Still ONE collective per slide: the keep flags travel with the rows.
-    ``return_keep``: also return the bool keep mask over `files` (numpy)."""
+    ``return_keep``: also return the bool keep mask over `files` (numpy).
+    ``gpu_decode`` (new, default off = GPU_DECODE[0]): decode the tiles' JPEG files on the device (gpu_decoded_batches) instead of
+    in DataLoader workers; the decoded bytes are identical, so are the features."""
     device = device or next(i_classifier.parameters()).device
     world, rank = ddist.world_rank() if sharded else (1, 0)
     n_total = len(files)
@@ -130,7 +165,11 @@ def embed_files(i_classifier, files, batch_size=128, num_workers=4, device=None,
 
     if hi > lo:
         pending = None
-        for batch in patch_loader(files[lo:hi], batch_size, num_workers, False, uint8=u8 or filt):
+        if gpu_decode is None:
+            gpu_decode = GPU_DECODE[0]
+        loader = (gpu_decoded_batches(files[lo:hi], batch_size, device, io_threads=max(1, num_workers)) if gpu_decode and u8 and on_gpu
+                  else patch_loader(files[lo:hi], batch_size, num_workers, False, uint8=u8 or filt))
+        for batch in loader:
             patches = batch["input"].to(device, non_blocking=True)
             if not filt:
                 embed(patches, None)

@@ -96,3 +96,38 @@ def test_corrupt_stream_falls_back_to_pillow():
         return
     assert np.array_equal(got[0], _pil(good)) and np.array_equal(got[2], _pil(good))
     assert got[1].shape == (64, 64, 3) and (ref1 is None or ref1.shape == (64, 64, 3))
+
+
+def test_compute_feats_with_device_decode_gives_the_same_csv(tmp_path, monkeypatch):
+    """compute_feats.py --gpu_decode (new, default off): the tiles' JPEG files are decoded by dsmil_jpeg_decode instead of by
+    Pillow in DataLoader workers (compute_feats.py:28,55) — the decoded bytes are identical, so every feature row is
+    BIT-identical to the default path's (a progressive JPEG among the tiles takes Pillow inside the same call)."""
+    import glob
+    import os
+    import zlib
+    import pandas as pd
+    from test_entry_points import _jpeg as write_tile, _simclr_checkpoint
+    from dsmil_wsi_amd import pipeline as pl
+    monkeypatch.chdir(tmp_path)
+    import compute_feats as cf
+    _simclr_checkpoint("simclr/runs/r0/checkpoints/model.pth", 31)
+    for slide in ("s1", "s2"):
+        for i in range(9):
+            write_tile(f"WSI/toy/single/0_x/{slide}/{i}_{i + 1}.jpeg", zlib.crc32(f'{slide}/{i}'.encode()) % 10000, size=224)
+    # one progressive tile: outside the device decoder's scope
+    with Image.open("WSI/toy/single/0_x/s1/0_1.jpeg") as im:
+        im.convert("RGB").save("WSI/toy/single/0_x/s1/0_1.jpeg", "JPEG", quality=70, progressive=True)
+    try:
+        cf.main(["--dataset", "toy", "--weights", "r0", "--batch_size", "4", "--num_workers", "0", "--save_npy"])
+        ref = {f: np.load(f) for f in sorted(glob.glob("datasets/toy/0_x/*.npy"))}
+        for f in ref:
+            os.remove(f)
+        cf.main(["--dataset", "toy", "--weights", "r0", "--batch_size", "4", "--num_workers", "2", "--save_npy", "--gpu_decode"])
+        assert pl.GPU_DECODE[0] is True
+        got = {f: np.load(f) for f in sorted(glob.glob("datasets/toy/0_x/*.npy"))}
+    finally:
+        pl.GPU_DECODE[0] = False
+    assert list(ref) == list(got) and len(ref) == 2
+    for f in ref:
+        assert ref[f].shape == (9, 512) and np.array_equal(ref[f], got[f]), f
+    assert len(pd.read_csv("datasets/toy/0_x/s1.csv")) == 9
