@@ -25,6 +25,9 @@ Sub-objects of the same JSON line (each measured the same way):
   slide            configs[3] per-slide strong scaling: a slide of --slide-patches uint8 tiles
                    cut contiguously over the ranks, embedded in batches, ONE all-gather of feature rows, aggregated
   slide_100k       the same with 100 000 tiles (2 slides timed)
+  decode           SURVEY §8f N3: 8 192 baseline-JPEG tiles (224x224, quality 70) decoded on the device per launch sequence,
+                   beside Pillow (the reference's decoder) on the host's cores
+  slide_jpeg       the `slide` leg starting from JPEG files in host memory: device decode on a side stream under the embedding
   e2e              configs[4]: synthetic two-level WSI -> tiles -> two embedders -> [high||low] -> MILNet(1024) ->
                    attention map, sharded by low tile, one all-gather of tree rows
 
@@ -699,6 +702,124 @@ def slide_leg(cx, n_patches, n_steps=None, host=False):
                                     ("; unmeasured on hardware beyond one GPU" if world == 1 else ""))}}
 
 
+def _jpeg_tiles(n, uniq=192, seed=5):
+    """n synthetic 224 x 224 tiles as baseline-JPEG files in host memory (bytes): `uniq` distinct tissue-like images (blocky
+    structure + noise: ~11 KB per tile at the tiler's quality 70, deepzoom_tiler.py:64,250), repeated in order."""
+    import io
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    files = []
+    for _ in range(min(uniq, n)):
+        base = rng.integers(0, 256, (30, 30, 3)).repeat(8, 0).repeat(8, 1)[:224, :224]
+        a = np.clip(base + rng.normal(0, 12, (224, 224, 3)), 0, 255).astype(np.uint8)
+        b = io.BytesIO()
+        Image.fromarray(a).save(b, "JPEG", quality=70)
+        files.append(b.getvalue())
+    return [files[i % len(files)] for i in range(n)]
+
+
+def decode_leg(cx, n_tiles=8192):
+    """dsmil_jpeg_decode alone — n_tiles baseline-JPEG tiles whose compressed bytes and parsed plan are resident
+    in HBM -> uint8 NHWC; checked against Pillow's decode of the same files (byte for byte) outside the timed region."""
+    torch, args, dev = cx.torch, cx.args, cx.dev
+    import io
+    import numpy as np
+    from PIL import Image
+    import dsmil_wsi_amd.ops as ops
+    blobs = _jpeg_tiles(n_tiles)
+    data, plan, recs = ops.jpeg_parse(blobs)
+    assert (recs["status"] == 0).all()
+    d_data, d_plan = torch.from_numpy(data).to(dev), torch.from_numpy(plan).to(dev)
+    out = torch.empty((n_tiles, 224, 224, 3), dtype=torch.uint8, device=dev)
+    status = torch.empty(n_tiles, dtype=torch.int32, device=dev)
+    ws = torch.empty(cx.L.dsmil_jpeg_workspace_bytes(n_tiles, 224, 224), dtype=torch.uint8, device=dev)
+
+    def step():
+        rc = cx.L.dsmil_jpeg_decode(d_data.data_ptr(), d_plan.data_ptr(), n_tiles, 224, 224, out.data_ptr(), status.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+        assert rc == 0
+
+    steps = max(2, min(args.steps, 10))
+    dt, inner, _, _ = cx.timed(step, steps, 1, 0.0, fixed_passes=1)
+    assert int(status.abs().sum()) == 0
+    got = out[:192].cpu().numpy()
+    for i in (0, 1, 95, 191):
+        assert np.array_equal(got[i], np.array(Image.open(io.BytesIO(blobs[i])).convert("RGB"))), "device decode != Pillow"
+    comp = sum(len(b) for b in blobs)
+    del out, ws, d_data, d_plan, status
+    torch.cuda.empty_cache()
+    line = {"metric": "tiles/sec JPEG-decoded on the device (224x224, quality 70, 4:2:0)", "value": round(cx.world * n_tiles * steps / dt, 1),
+            "unit": "tiles/s", "ms_per_batch": round(dt / steps * 1e3, 3), "dtype": "u8",
+            "config": {"workload": f"{n_tiles} baseline-JPEG tiles per launch sequence (memset + 3 launches), compressed bytes "
+                                   f"({comp / n_tiles / 1024:.1f} KiB per tile) and the parsed plan resident in HBM; output uint8 NHWC; "
+                                   "bit-identical to Pillow (checked)", "tiles": n_tiles,
+                       "compressed_bytes_per_tile": round(comp / n_tiles, 1), "huffman_workgroups": (n_tiles + 1023) // 1024},
+            "roofline": {"bound": "latency", "note": "Huffman decoding is serial per stream: one lane per tile, 1 024-lane workgroups "
+                         "— the launch holds ceil(tiles / 1024) compute units; not priced against a pipe"}}
+    if not args.no_cpu_baseline and cx.world == 1:
+        from concurrent.futures import ThreadPoolExecutor
+        cores = _usable_cores()
+
+        def dec(b):
+            return np.array(Image.open(io.BytesIO(b)).convert("RGB")).shape
+
+        t0 = time.perf_counter()
+        n1 = 0
+        while time.perf_counter() - t0 < min(3.0, args.cpu_seconds):
+            dec(blobs[n1 % 192])
+            n1 += 1
+        one = n1 / (time.perf_counter() - t0)
+        thr = min(cores, 16)
+        with ThreadPoolExecutor(thr) as pool:     # (Pillow's decoder releases the GIL)
+            t0 = time.perf_counter()
+            m = 0
+            while time.perf_counter() - t0 < min(5.0, args.cpu_seconds):
+                list(pool.map(dec, blobs[:1024]))
+                m += 1024
+            many = m / (time.perf_counter() - t0)
+        line["cpu_baseline"] = {"value": round(many, 1), "unit": "tiles/s", "cores": thr, "kind": "reference",
+                                "one_thread": round(one, 1),
+                                "sample": f"Pillow (libjpeg-turbo) Image.open(...).convert('RGB') of the same files — the reference's own "
+                                          f"decoder, compute_feats.py:28 — {m} decodes on {thr} threads, {n1} on one"}
+    return line
+
+
+def slide_jpeg_leg(cx, n_patches):
+    """The `slide` leg starting from JPEG FILES IN HOST MEMORY (what compute_feats.py:65-69 globs, read into bytes): device decode
+    of 2 048-tile chunks on a side stream under the embedding of the previous chunk (pipeline.embed_jpeg_blobs), one all-gather,
+    the aggregator.  Strong scaling: contiguous file shards over the ranks."""
+    torch, args, dev, world = cx.torch, cx.args, cx.dev, cx.world
+    from dsmil_wsi_amd import dist as dd
+    from dsmil_wsi_amd import pipeline as pl
+    from dsmil_wsi_amd.synthetic import build_net
+    ic = _build_iclassifier(cx)
+    net = build_net("tcga", dev)
+    lo, hi = dd.shard_range(n_patches, cx.rank, world)
+    blobs = _jpeg_tiles(n_patches)[lo:hi]
+    sizes = [dd.shard_range(n_patches, r, world)[1] - dd.shard_range(n_patches, r, world)[0] for r in range(world)]
+    res, stats = {}, {}
+
+    def step():
+        with torch.no_grad():
+            feats, classes = pl.embed_jpeg_blobs(ic, blobs, args.patches, decode_batch=2048, streams=args.streams, device=dev, stats=stats)
+            bag = dd.all_gather_packed([feats, classes], sizes)[0] if cx.collectives else feats
+            res["out"] = net(bag)
+
+    steps = max(2, min(args.steps, 5))
+    dt, inner, _, _ = cx.timed(step, steps, 1, 0.0, fixed_passes=1)
+    torch.cuda.synchronize()
+    assert res["out"][2].shape[0] == n_patches and torch.isfinite(res["out"][1]).all() and stats.get("pillow", 0) == 0
+    comp = sum(len(b) for b in blobs)
+    return {"metric": "patches/sec, one slide of JPEG tiles decoded on the device + embedded + gathered + aggregated",
+            "value": round(n_patches * steps / dt, 1), "unit": "patches/s", "scaling": "strong", "ms_per_slide": round(dt / steps * 1e3, 3),
+            "config": {"tiles_start_in": "host memory as baseline-JPEG files (bytes)", "h2d_bytes_per_slide": comp,
+                       "workload": f"one slide = {n_patches} JPEG tiles (224x224, quality 70), chunks of 2048 decoded by dsmil_jpeg_decode "
+                                   f"on a side stream under the previous chunk's embedding (batches of {args.patches}), one all-gather, "
+                                   f"MILNet(tcga)", "slides_timed": steps, "rccl_ranks": world, "streams": args.streams,
+                       "collectives_per_slide": 1 if cx.collectives else 0}}
+
+
 def e2e_leg(cx, low_grid):
     """BASELINE configs[4]: synthetic two-level slide -> attention map (pipeline.multiscale_attention_map)."""
     torch, args, dev, world = cx.torch, cx.args, cx.dev, cx.world
@@ -860,6 +981,11 @@ def _summary(line):
                 e[k] = r[k]
         if "ms_per_slide" in obj:
             e["ms_per_slide"] = obj["ms_per_slide"]
+        if "ms_per_batch" in obj:
+            e["ms_per_batch"] = obj["ms_per_batch"]
+        if name == "decode" and obj.get("cpu_baseline"):
+            e["pillow_tiles_per_s"] = obj["cpu_baseline"]["value"]
+            e["pillow_threads"] = obj["cpu_baseline"]["cores"]
         if "gpu_ms" in obj:
             e["gpu_ms"] = obj["gpu_ms"]
         if obj.get("config", {}).get("single_bag_forward_ms") is not None:
@@ -868,7 +994,7 @@ def _summary(line):
             e["value_one_stream"] = obj["config"]["value_one_stream"]
         out[name] = e
     put("aggregator_f32", line if line.get("unit") == "bags/s" else None)
-    for k in ("aggregator_bf16", "embedder", "embedder_half", "train_c1", "train_c2", "slide", "slide_h2d", "slide_100k", "e2e"):
+    for k in ("aggregator_bf16", "embedder", "embedder_half", "train_c1", "train_c2", "slide", "slide_h2d", "slide_100k", "decode", "slide_jpeg", "e2e"):
         put(k, line.get(k))
     return out
 
@@ -883,7 +1009,7 @@ def main():
     ap.add_argument("--feats", type=int, default=512)
     ap.add_argument("--patches", type=int, default=256, help="patches per rank per embedder pass (batch size)")
     ap.add_argument("--workload", default="all",
-                    help="comma list of aggregator, aggregator_bf16, embedder, embedder_half, train, slide, slide_h2d, slide100k, e2e; or all / both (= aggregator,embedder)")
+                    help="comma list of aggregator, aggregator_bf16, embedder, embedder_half, train, slide, slide_h2d, slide100k, decode, slide_jpeg, e2e; or all / both (= aggregator,embedder)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on each timed region")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams independent passes are dealt to (ops.StreamPool); 1 = one pass in flight")
@@ -901,7 +1027,7 @@ def main():
                     help="skip the single-bag latency probe (profiling runs: keeps per-kernel averages clean)")
     args = ap.parse_args()
     maybe_self_launch(args)
-    wl = {"all": "aggregator,aggregator_bf16,embedder,embedder_half,train,slide,slide_h2d,slide100k,e2e", "both": "aggregator,embedder"}.get(args.workload, args.workload)
+    wl = {"all": "aggregator,aggregator_bf16,embedder,embedder_half,train,slide,slide_h2d,slide100k,decode,slide_jpeg,e2e", "both": "aggregator,embedder"}.get(args.workload, args.workload)
     wl = [w for w in wl.split(",") if w]
     cx = Ctx(args)
     line = {}
@@ -923,6 +1049,10 @@ def main():
         subs["slide_h2d"] = slide_leg(cx, args.slide_patches, host=True)
     if "slide100k" in wl:   # the large slide of SURVEY §8(d) config 4 (15 GB of uint8 tiles over the ranks)
         subs["slide_100k"] = slide_leg(cx, 100000, n_steps=2)
+    if "decode" in wl:
+        subs["decode"] = decode_leg(cx)
+    if "slide_jpeg" in wl:
+        subs["slide_jpeg"] = slide_jpeg_leg(cx, args.slide_patches)
     if "e2e" in wl:
         subs["e2e"] = e2e_leg(cx, tuple(args.e2e_grid))
     if cx.rank == 0:

@@ -750,8 +750,10 @@ def jpeg_parse(blobs):
     sizes = np.fromiter((len(b) for b in blobs), dtype=np.int64, count=n)
     offsets = np.zeros(n + 1, np.int64)
     np.cumsum(sizes, out=offsets[1:])
-    data = np.empty(int(offsets[-1]) + 16, np.uint8)     # (+16: the device reader may look one byte past a segment's end)
+    # (+32: the device reader prefetches 16 bytes past its position; an EOI behind the last file stops a truncated one)
+    data = np.empty(int(offsets[-1]) + 32, np.uint8)
     data[int(offsets[-1]):] = 0
+    data[int(offsets[-1])], data[int(offsets[-1]) + 1] = 0xFF, 0xD9
     mv = memoryview(data)
     for b, o, s in zip(blobs, offsets[:-1], sizes):
         mv[int(o):int(o + s)] = b
@@ -771,14 +773,15 @@ def _pil_rgb(blob):
         return np.array(im.convert("RGB"), dtype=np.uint8, copy=True)
 
 
-def jpeg_decode(blobs, device, size=None, stats=None):
+def jpeg_decode(blobs, device, size=None, stats=None, out=None):
     """A batch of JPEG files (bytes-likes) -> uint8 [n, H, W, 3] on `device`, what
     `np.array(Image.open(f).convert("RGB"))` gives for every file (compute_feats.py:28 + the uint8 half of VF.to_tensor):
     baseline JPEGs are decoded on the device by dsmil_jpeg_decode (bit-identical to Pillow's defaults: islow IDCT, fancy
     upsampling), every other file (progressive, CMYK, a PNG ...) and every stream the device decoder reports as corrupt is
     decoded with Pillow on the host and copied in — the result never depends on which path a file took.
     ``size`` = (H, W) of the batch (default: the first decodable image's); all files must have it.
-    ``stats`` (dict, optional) gets the counts {"device": .., "pillow": ..}."""
+    ``stats`` (dict, optional) gets the counts {"device": .., "pillow": ..}.
+    ``out``: a uint8 device tensor with room for [n, H, W, 3] (a caller's staging buffer); the result is a view of it."""
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("jpeg_decode needs a CUDA(HIP) device")
@@ -794,7 +797,10 @@ def jpeg_decode(blobs, device, size=None, stats=None):
     H, W = int(size[0]), int(size[1])
     on_dev = ok & (recs["height"] == H) & (recs["width"] == W)
     recs["status"][ok & ~on_dev] = -2          # another size: not this batch's launch (the Pillow path below checks the size)
-    out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+    if out is not None and (not out.is_cuda or out.dtype != torch.uint8 or not out.is_contiguous() or out.numel() < n * H * W * 3):
+        raise ValueError("out must be a contiguous uint8 device tensor of at least n * H * W * 3 elements")
+    out = (torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev) if out is None
+           else out.view(-1)[:n * H * W * 3].view(n, H, W, 3))
     status = torch.empty(n, dtype=torch.int32, device=dev)
     L = _native.lib()
     if on_dev.any():

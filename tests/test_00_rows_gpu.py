@@ -14,6 +14,7 @@ import test_agg_bwd_gpu as t_bwd
 import test_agg_gpu as t_agg
 import test_dist_gpu as t_dist
 import test_entry_points as t_entry
+import test_jpeg_gpu as t_jpeg
 import test_resnet_gpu as t_res
 import test_tile_filter as t_tile
 
@@ -113,6 +114,12 @@ def test_row_n3_uint8_ingest_and_tile_filter():
     """N3: u8 NHWC ingest fused into the stem (bit-identical to the fp32 entry), background filter of the tilers (exact)."""
     t_res.test_uint8_nhwc_ingest_is_bit_identical_to_fp32_entry(3, 224, 224)
     t_tile.test_hip_tile_stats_are_exact(64, 224, 224)
+
+
+def test_row_n3_batched_jpeg_decode_equals_pillow():
+    """N3: the tiles' JPEG files decoded on the device (compute_feats.py:28 `Image.open`), byte for byte Pillow's decode."""
+    t_jpeg.test_device_decode_equals_pillow(224, 224)
+    t_jpeg.test_device_decode_equals_pillow(17, 23)
 
 
 def test_row_n4_other_trunks_and_aggregator_variants(golden):
