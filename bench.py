@@ -733,10 +733,10 @@ def decode_leg(cx, n_tiles=8192):
     d_data, d_plan = torch.from_numpy(data).to(dev), torch.from_numpy(plan).to(dev)
     out = torch.empty((n_tiles, 224, 224, 3), dtype=torch.uint8, device=dev)
     status = torch.empty(n_tiles, dtype=torch.int32, device=dev)
-    ws = torch.empty(cx.L.dsmil_jpeg_workspace_bytes(n_tiles, 224, 224), dtype=torch.uint8, device=dev)
+    ws = torch.empty(cx.L.dsmil_jpeg_workspace_bytes(n_tiles, 224, 224, int(data.size) - 32), dtype=torch.uint8, device=dev)
 
     def step():
-        rc = cx.L.dsmil_jpeg_decode(d_data.data_ptr(), d_plan.data_ptr(), n_tiles, 224, 224, out.data_ptr(), status.data_ptr(),
+        rc = cx.L.dsmil_jpeg_decode(d_data.data_ptr(), int(data.size) - 32, d_plan.data_ptr(), n_tiles, 224, 224, out.data_ptr(), status.data_ptr(),
                                     ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
         assert rc == 0
 

@@ -69,99 +69,139 @@ struct JpGeom {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
+// k_jpeg_unstuff — the entropy-coded segment without its byte stuffing and restart markers, as big-endian 32-bit words
+// ---------------------------------------------------------------------------------------------------------------------
+// T.81 B.1.1.5: inside the entropy-coded segment an 0xFF data byte is followed by a stuffed 0x00; RSTn markers (FF D0..D7) stand
+// between restart intervals, each interval padded to a byte boundary; any other marker (EOI) ends the segment.  Resolving that
+// inside the decoding lanes put a data-dependent branch into every refill.  One 256-thread workgroup per image copies its
+// segment once — 0x00 behind 0xFF dropped, RSTn markers dropped (the decoder byte-aligns at a restart: the marker's position
+// needs no record), everything from the first other marker on replaced by zeros (libjpeg feeds zeros behind the data too) —
+// into a buffer parallel to the batch's file bytes (unstuffing only shrinks: image i's words start at its segment's offset
+// rounded up to 4).  Byte j of the result is stored at j ^ 3, so that an aligned 32-bit load yields the stream's next 32 bits,
+// first bit in the MSB.  16 zero bytes follow the data (the reader prefetches two words).
+constexpr int JP_UT = 256;      // threads
+constexpr int JP_UB = 8;        // bytes per thread per round
+__global__ __launch_bounds__(JP_UT) void k_jpeg_unstuff(const uint8_t* __restrict__ data, const uint8_t* __restrict__ plan,
+                                                        uint8_t* __restrict__ ust) {
+    const int i = blockIdx.x;
+    const dsmil_jpeg_image* im = reinterpret_cast<const dsmil_jpeg_image*>(plan + jp_off_images()) + i;
+    if (im->status != DSMIL_OK) return;
+    const long long beg = im->ecs_begin, len = im->ecs_end - im->ecs_begin;
+    const uint8_t* src = data + beg;
+    uint8_t* dst = ust + ((beg + 3) & ~3LL);
+    __shared__ int s_cnt[JP_UT / 64];
+    __shared__ int s_stop;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long written = 0;
+    for (long long base = 0; base < len; base += JP_UT * JP_UB) {
+        if (tid == 0) s_stop = 0x7fffffff;
+        __syncthreads();
+        const long long o = base + (long long)tid * JP_UB;
+        unsigned char b[JP_UB + 2];                       // b[0] = the byte in front, b[JP_UB + 1] = the byte behind
+#pragma unroll
+        for (int k = 0; k < JP_UB + 2; ++k) {
+            const long long q = o + k - 1;
+            b[k] = (q >= 0 && q < len) ? src[q] : (unsigned char)0;
+        }
+        unsigned keep = 0;
+        int stop = 0x7fffffff;
+#pragma unroll
+        for (int k = 1; k <= JP_UB; ++k) {
+            const long long q = o + k - 1;
+            if (q >= len) break;
+            const unsigned prev = b[k - 1], cur = b[k], nxt = b[k + 1];
+            bool kp = true;
+            if (prev == 0xFF && cur == 0x00) kp = false;                                   // stuffed zero
+            else if (prev == 0xFF && cur >= 0xD0 && cur <= 0xD7) kp = false;               // second byte of RSTn
+            else if (cur == 0xFF && nxt >= 0xD0 && nxt <= 0xD7) kp = false;                // first byte of RSTn
+            else if (cur == 0xFF && nxt != 0x00) { kp = false; if (stop == 0x7fffffff) stop = (int)(q - base); }   // another marker: the end
+            if (kp) keep |= 1u << (k - 1);
+        }
+        if (stop != 0x7fffffff) atomicMin(&s_stop, stop);
+        __syncthreads();
+        const int stop_at = s_stop;                        // chunk-relative position of the first terminating marker
+#pragma unroll
+        for (int k = 0; k < JP_UB; ++k)
+            if ((int)(o - base) + k >= stop_at) keep &= ~(1u << k);
+        int cnt = __builtin_popcount(keep);
+        int incl = cnt;                                   // inclusive scan over the workgroup
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(incl, d);
+            if (lane >= d) incl += y;
+        }
+        if (lane == 63) s_cnt[wave] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < JP_UT / 64; ++w) {
+            if (w < wave) before += s_cnt[w];
+            total += s_cnt[w];
+        }
+        long long pos = written + before + incl - cnt;
+#pragma unroll
+        for (int k = 0; k < JP_UB; ++k)
+            if (keep & (1u << k)) { dst[pos ^ 3] = b[k + 1]; ++pos; }
+        written += total;
+        __syncthreads();
+        if (stop_at != 0x7fffffff) break;
+    }
+    // zeros behind the data: the rest of the last word and 16 more bytes
+    const long long zend = ((written + 3) & ~3LL) + 16;
+    for (long long q = written + tid; q < zend; q += JP_UT) dst[q ^ 3] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // k_jpeg_huffman
 // ---------------------------------------------------------------------------------------------------------------------
 // SIMT shapes this kernel: the 64 lanes of a wave decode 64 different streams, and a wave executes the UNION of its lanes'
-// control paths.  The first form (byte-wise refill loop, 9-bit lookahead + canonical bit-by-bit slow path, zigzag lookup per
-// coefficient) ran every rare path in nearly every iteration because SOME lane needed it: ~4 000 cycles per symbol.  Now
-//   * one refill point per symbol, at most two byte-group moves, no loop; the stream sits in a 16-byte register queue (`raw` in
-//     front, `nxt` prefetched: the global load of the following eight bytes is issued when `raw` is replaced and is not waited
-//     for until `raw` runs out again); an 0xFF at the queue's front (stuffed byte or marker) is resolved in registers;
+// control paths.  The first form (byte-wise refill loop with the stuffing rules, 9-bit lookahead + canonical bit-by-bit slow path,
+// zigzag lookup per coefficient) ran every rare path in nearly every iteration because SOME lane needed it: ~4 000 cycles per
+// symbol.  Now
+//   * the stream is pre-unstuffed (k_jpeg_unstuff): the reader is three 32-bit words (two current, one prefetched — the load of
+//     the word after next is issued when a word is used up and not waited for until the next one is) and a bit position; a
+//     symbol's code AND its magnitude bits (<= 27 bits) come out of ONE 32-bit window, one advance per symbol, no branch;
 //   * ONE table lookup per symbol for codes of up to JP_LOOK = 12 bits, from LDS; longer codes (rare symbols of the standard
 //     tables, < 0.1 % of the stream) take the canonical compare chain;
 //   * coefficients are stored in ZIGZAG order (k_jpeg_idct reads them through constant indices): no map lookup per symbol.
 struct JpBits {
-    const uint8_t* p;       // address of the first byte behind `nxt`
-    unsigned long long acc; // the low `n` bits are valid, MSB first
-    unsigned long long raw; // the next `rawn` bytes of the stream, first byte in the top byte
-    unsigned long long nxt; // the eight bytes behind them (prefetched)
-    int n, rawn;
-    __device__ __forceinline__ static unsigned long long load8(const uint8_t* q) {
-        unsigned long long w;
-        __builtin_memcpy(&w, q, 8);
-        return __builtin_bswap64(w);
+    const unsigned* wp;     // the word behind w2
+    unsigned w0, w1, w2;    // current word, next word, the one after (prefetched)
+    int bp;                 // bits of w0 already consumed, 0..31
+    __device__ __forceinline__ void init(const unsigned* q) { w0 = q[0]; w1 = q[1]; w2 = q[2]; wp = q + 3; bp = 0; }
+    // the next 32 bits of the stream
+    __device__ __forceinline__ unsigned window() const { return bp ? __builtin_amdgcn_alignbit(w0, w1, 32 - bp) : w0; }
+    __device__ __forceinline__ void skip(int k) {   // k <= 32
+        bp += k;
+        if (bp >= 32) { bp -= 32; w0 = w1; w1 = w2; w2 = *wp++; }
     }
-    __device__ __forceinline__ void init(const uint8_t* q) {
-        acc = 0; n = 0;
-        raw = load8(q); nxt = load8(q + 8); rawn = 8; p = q + 16;
-    }
-    __device__ __forceinline__ void drop(int k) {       // k <= rawn bytes leave the front of the queue
-        raw = k >= 8 ? 0ull : raw << (8 * k);
-        rawn -= k;
-        if (rawn == 0) { raw = nxt; rawn = 8; nxt = load8(p); p += 8; }
-    }
-    // one step: bytes from the queue's front into the bit buffer — a whole group while none of them is 0xFF, else one byte
-    // with the stuffing / marker rules (a marker stays at the front and feeds zeros: libjpeg's "insufficient data")
-    __device__ __forceinline__ void step() {
-        int k = (64 - n) >> 3;
-        k = k < rawn ? k : rawn;
-        const unsigned long long low = k == 8 ? 0ull : (0x0101010101010101ull >> (8 * k));
-        const unsigned long long v = ~raw | low;       // a zero byte among the top k <=> an 0xFF among the top k bytes of raw
-        if (((v - 0x0101010101010101ull) & ~v & 0x8080808080808080ull) == 0ull) {
-            acc = k == 8 ? raw : ((acc << (8 * k)) | (raw >> (64 - 8 * k)));
-            n += 8 * k;
-            drop(k);
-            return;
-        }
-        unsigned b = (unsigned)(raw >> 56);
-        if (b != 0xFFu) { drop(1); }
-        else {
-            const unsigned nx = rawn >= 2 ? (unsigned)(raw >> 48) & 255u : (unsigned)(nxt >> 56);
-            if (nx == 0) {                              // a stuffed FF: both bytes leave
-                if (rawn >= 2) drop(2);
-                else { drop(1); drop(1); }
-            } else {
-                b = 0;                                  // a marker: stays
-            }
-        }
-        acc = (acc << 8) | b;
-        n += 8;
-    }
-    __device__ __forceinline__ void fill32() {          // >= 32 valid bits afterwards (a code + its magnitude bits are <= 27)
-        while (n < 32) step();                          // (one or two steps; every step moves at least one byte)
-    }
-    __device__ __forceinline__ unsigned peek(int k) const { return (unsigned)(acc >> (n - k)) & ((1u << k) - 1u); }
-    __device__ __forceinline__ void skip(int k) { n -= k; }
-    // restart: the bit buffer holds padding (and zeros fed at the marker); the queue's front must be the RSTn marker
-    __device__ __forceinline__ bool restart() {
-        acc = 0; n = 0;
-        const unsigned b0 = (unsigned)(raw >> 56);
-        const unsigned b1 = rawn >= 2 ? (unsigned)(raw >> 48) & 255u : (unsigned)(nxt >> 56);
-        if (b0 != 0xFFu || b1 < 0xD0u || b1 > 0xD7u) return false;
-        if (rawn >= 2) drop(2);
-        else { drop(1); drop(1); }
-        return true;
-    }
+    __device__ __forceinline__ void restart() { skip((8 - (bp & 7)) & 7); }   // the next restart interval starts at a byte boundary
 };
 
-// one Huffman symbol (T.81 F.2.2.3 with a 12-bit lookahead, jdhuff.c's scheme); the caller has >= 32 bits; -1: no such code
-__device__ __forceinline__ int jp_symbol(JpBits& b, const JpHuff* __restrict__ t) {
-    const unsigned e = t->look[b.peek(JP_LOOK)];
+// one Huffman symbol + its magnitude (T.81 F.2.2.1 / F.2.2.3 with a 12-bit lookahead, jdhuff.c's scheme).  Returns the symbol
+// (-1: no such code) and, for its low nibble s > 0, the EXTENDed value of the s bits behind the code in `val`.
+__device__ __forceinline__ int jp_symbol(JpBits& b, const JpHuff* __restrict__ t, int& val) {
+    const unsigned win = b.window();
+    const unsigned e = t->look[win >> (32 - JP_LOOK)];
+    int len, sym;
     if (e) {
-        b.skip((int)(e >> 8));
-        return (int)(e & 255u);
+        len = (int)(e >> 8);
+        sym = (int)(e & 255u);
+    } else {
+        const int code16 = (int)(win >> 16);
+        len = JP_LOOK + 1;
+        while (len <= 16 && (code16 >> (16 - len)) > t->maxcode[len]) ++len;
+        if (len > 16) return -1;
+        sym = t->vals[((code16 >> (16 - len)) + t->valoff[len]) & 255];
     }
-    const int code16 = (int)b.peek(16);
-    int l = JP_LOOK + 1;
-    while (l <= 16 && (code16 >> (16 - l)) > t->maxcode[l]) ++l;
-    if (l > 16) return -1;
-    b.skip(l);
-    return t->vals[((code16 >> (16 - l)) + t->valoff[l]) & 255];
-}
-__device__ __forceinline__ int jp_receive_extend(JpBits& b, int s) {   // s in 1..15, the bits are there
-    const int v = (int)b.peek(s);
-    b.skip(s);
-    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+    const int s = sym & 15;
+    val = 0;
+    if (s) {
+        const int v = (int)((win << len) >> (32 - s));     // (len + s <= 31: inside the window)
+        val = v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+    }
+    b.skip(len + s);
+    return sym;
 }
 
 // Workgroups of JP_HT threads = 16 waves, four per SIMD: a lane's decode is a chain of dependent steps, the waves of a SIMD hide
@@ -169,9 +209,11 @@ __device__ __forceinline__ int jp_receive_extend(JpBits& b, int s) {   // s in 1
 // embedder's conv kernels of the previous batch (one 512-register workgroup per CU) keep the other 248.  The batch's Huffman
 // tables (a tiler writes the same four into every tile) are staged in LDS when there are at most JP_LDS_HT of them; the lookups
 // go through generic pointers either way.
-constexpr int JP_HT = 1024;
+// Batches of up to 4 096 tiles take 256-lane workgroups instead (one wave per SIMD on up to 16 compute units): the lane's chain
+// then runs at its own latency, 11 ms per 224 x 224 tile instead of 17-25 ms with four waves sharing a SIMD's issue slots.
 constexpr int JP_LDS_HT = 4;
-__global__ __launch_bounds__(JP_HT) void k_jpeg_huffman(const uint8_t* __restrict__ data, const uint8_t* __restrict__ plan, int n,
+template <int JP_HT>
+__global__ __launch_bounds__(JP_HT) void k_jpeg_huffman(const uint8_t* __restrict__ ust, const uint8_t* __restrict__ plan, int n,
                                                         int W, int H, int16_t* __restrict__ coef, int32_t* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) unsigned s_tab[JP_LDS_HT * sizeof(JpHuff) / 4];
     const int n_ht = reinterpret_cast<const JpHeader*>(plan)->n_ht;
@@ -199,7 +241,7 @@ __global__ __launch_bounds__(JP_HT) void k_jpeg_huffman(const uint8_t* __restric
     const JpHuff* ac2 = hts + imp->ac[2];
     const int mx = (W + 8 * hs - 1) / (8 * hs), my = (H + 8 * vs - 1) / (8 * vs);
     JpBits b;
-    b.init(data + imp->ecs_begin);
+    b.init(reinterpret_cast<const unsigned*>(ust + ((imp->ecs_begin + 3) & ~3LL)));
     int pred0 = 0, pred1 = 0, pred2 = 0;
     int st = DSMIL_OK;
     int n_mcu = 0;
@@ -208,7 +250,7 @@ __global__ __launch_bounds__(JP_HT) void k_jpeg_huffman(const uint8_t* __restric
     for (int yy = 0; yy < my && st == DSMIL_OK; ++yy) {
         for (int xx = 0; xx < mx && st == DSMIL_OK; ++xx) {
             if (ri && n_mcu && (n_mcu % ri) == 0) {
-                if (!b.restart()) { st = DSMIL_E_INVALID; break; }
+                b.restart();
                 pred0 = pred1 = pred2 = 0;
             }
             ++n_mcu;
@@ -220,29 +262,26 @@ __global__ __launch_bounds__(JP_HT) void k_jpeg_huffman(const uint8_t* __restric
                 const JpHuff* dct = c == 0 ? dc0 : (c == 1 ? dc1 : dc2);
                 const JpHuff* act = c == 0 ? ac0 : (c == 1 ? ac1 : ac2);
                 int16_t* blk = cimg + ((size_t)c * g.blocks_plane + (size_t)(yy * cv + v) * bw + (xx * ch + h)) * 64;
-                b.fill32();
-                int s = jp_symbol(b, dct);
+                int diff;
+                int s = jp_symbol(b, dct, diff);
                 if (s < 0 || s > 15) { st = DSMIL_E_INVALID; break; }
-                int diff = 0;
-                if (s) diff = jp_receive_extend(b, s);
-                int pr = (c == 0 ? pred0 : (c == 1 ? pred1 : pred2)) + diff;
+                const int pr = (c == 0 ? pred0 : (c == 1 ? pred1 : pred2)) + diff;
                 if (c == 0) pred0 = pr; else if (c == 1) pred1 = pr; else pred2 = pr;
                 if (pr) blk[0] = (int16_t)pr;
                 int k = 1;
                 while (k < 64) {
-                    b.fill32();
-                    const int rs = jp_symbol(b, act);
+                    int val;
+                    const int rs = jp_symbol(b, act, val);
                     if (rs < 0) { st = DSMIL_E_INVALID; break; }
                     const int r = rs >> 4;
-                    s = rs & 15;
-                    if (s == 0) {
+                    if ((rs & 15) == 0) {
                         if (r != 15) break;            // EOB
                         k += 16;
                         continue;
                     }
                     k += r;
                     if (k > 63) { st = DSMIL_E_INVALID; break; }
-                    blk[k] = (int16_t)jp_receive_extend(b, s);      // ZIGZAG position k
+                    blk[k] = (int16_t)val;             // ZIGZAG position k
                     ++k;
                 }
             }
@@ -437,10 +476,11 @@ extern "C" {
 
 size_t dsmil_jpeg_plan_bytes(int32_t n) { return n > 0 ? jp_plan_bytes(n) : 0; }
 
-size_t dsmil_jpeg_workspace_bytes(int32_t n, int32_t height, int32_t width) {
-    if (n <= 0 || height <= 0 || width <= 0 || height > 65535 || width > 65535) return 0;
+size_t dsmil_jpeg_workspace_bytes(int32_t n, int32_t height, int32_t width, int64_t data_bytes) {
+    if (n <= 0 || height <= 0 || width <= 0 || height > 65535 || width > 65535 || data_bytes <= 0) return 0;
     const JpGeom g(width, height);
-    return (size_t)n * (g.coef_elems() * sizeof(int16_t) + 3 * g.plane_bytes()) + 256;
+    // coefficients | component planes | the unstuffed streams (parallel to the file bytes, + slack for alignment and the zeros)
+    return (size_t)n * (g.coef_elems() * sizeof(int16_t) + 3 * g.plane_bytes()) + (((size_t)data_bytes + 64 + 255) & ~(size_t)255) + 256;
 }
 
 int dsmil_jpeg_parse(const uint8_t* data, const int64_t* offsets, int32_t n, void* plan) {
@@ -577,18 +617,25 @@ int dsmil_jpeg_parse(const uint8_t* data, const int64_t* offsets, int32_t n, voi
     return DSMIL_OK;
 }
 
-int dsmil_jpeg_decode(const uint8_t* data, const void* plan, int32_t n, int32_t height, int32_t width, uint8_t* out_nhwc,
-                      int32_t* status, void* ws, size_t ws_bytes, void* stream) {
-    if (!data || !plan || !out_nhwc || !status || !ws || n <= 0 || height <= 0 || width <= 0) return DSMIL_E_INVALID;
+int dsmil_jpeg_decode(const uint8_t* data, int64_t data_bytes, const void* plan, int32_t n, int32_t height, int32_t width,
+                      uint8_t* out_nhwc, int32_t* status, void* ws, size_t ws_bytes, void* stream) {
+    if (!data || !plan || !out_nhwc || !status || !ws || n <= 0 || height <= 0 || width <= 0 || data_bytes <= 0) return DSMIL_E_INVALID;
     if (height > 65535 || width > 65535 || n > 65535) return DSMIL_E_UNSUPPORTED;
     if (((uintptr_t)ws % 256) || ((uintptr_t)plan % 16)) return DSMIL_E_ALIGN;
-    if (ws_bytes < dsmil_jpeg_workspace_bytes(n, height, width)) return DSMIL_E_WORKSPACE;
+    if (ws_bytes < dsmil_jpeg_workspace_bytes(n, height, width, data_bytes)) return DSMIL_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const JpGeom g(width, height);
     int16_t* coef = (int16_t*)ws;
     uint8_t* planes = (uint8_t*)ws + (size_t)n * g.coef_elems() * sizeof(int16_t);
+    uint8_t* ust = planes + (size_t)n * 3 * g.plane_bytes();
+    ust += (256 - ((uintptr_t)ust & 255)) & 255;
     if (hipMemsetAsync(coef, 0, (size_t)n * g.coef_elems() * sizeof(int16_t), st) != hipSuccess) return DSMIL_E_LAUNCH;
-    hipLaunchKernelGGL(k_jpeg_huffman, dim3((unsigned)((n + JP_HT - 1) / JP_HT)), dim3(JP_HT), 0, st, data, (const uint8_t*)plan, n, width, height, coef, status);
+    hipLaunchKernelGGL(k_jpeg_unstuff, dim3((unsigned)n), dim3(JP_UT), 0, st, data, (const uint8_t*)plan, ust);
+    if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    if (n <= 4096)
+        hipLaunchKernelGGL(k_jpeg_huffman<256>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)ust, (const uint8_t*)plan, n, width, height, coef, status);
+    else
+        hipLaunchKernelGGL(k_jpeg_huffman<1024>, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, st, (const uint8_t*)ust, (const uint8_t*)plan, n, width, height, coef, status);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     hipLaunchKernelGGL(k_jpeg_idct, dim3((unsigned)((3 * g.blocks_plane + 255) / 256), (unsigned)n), dim3(256), 0, st,
                        (const uint8_t*)plan, n, width, height, coef, planes, status);

@@ -787,6 +787,7 @@ def jpeg_decode(blobs, device, size=None, stats=None, out=None):
         raise RuntimeError("jpeg_decode needs a CUDA(HIP) device")
     n = len(blobs)
     data, plan, recs = jpeg_parse(blobs)
+    n_data = int(data.size) - 32        # (jpeg_parse pads the batch buffer)
     ok = recs["status"] == 0
     if size is None:
         if ok.any():
@@ -806,10 +807,10 @@ def jpeg_decode(blobs, device, size=None, stats=None, out=None):
     if on_dev.any():
         d_data = torch.from_numpy(data).to(dev, non_blocking=True)
         d_plan = torch.from_numpy(plan).to(dev, non_blocking=True)
-        nbytes = L.dsmil_jpeg_workspace_bytes(n, H, W)
+        nbytes = L.dsmil_jpeg_workspace_bytes(n, H, W, n_data)
         ws = _workspace(dev, nbytes)
         with torch.cuda.device(dev):
-            rc = L.dsmil_jpeg_decode(_ptr(d_data), _ptr(d_plan), n, H, W, _ptr(out), _ptr(status), _ptr(ws), ws.numel(), _stream(dev))
+            rc = L.dsmil_jpeg_decode(_ptr(d_data), n_data, _ptr(d_plan), n, H, W, _ptr(out), _ptr(status), _ptr(ws), ws.numel(), _stream(dev))
         _native.check(rc, "dsmil_jpeg_decode")
         st = status.cpu().numpy()
     else:

@@ -382,11 +382,11 @@ int dsmil_tile_stats(const uint8_t* tiles_nhwc, int32_t B, int32_t H, int32_t W,
  *                      dsmil_jpeg_image per file at byte offset 16 of the plan (status = DSMIL_OK, or DSMIL_E_UNSUPPORTED /
  *                      DSMIL_E_INVALID for a file outside the scope — the caller decodes THOSE with Pillow) followed by the
  *                      batch's de-duplicated tables.  The caller copies data and plan to the device as they are.
- *   dsmil_jpeg_decode  data, plan: the DEVICE copies; every image with status DSMIL_OK must be width x height; out_nhwc
+ *   dsmil_jpeg_decode  data (data_bytes = offsets[n] bytes), plan: the DEVICE copies; every image with status DSMIL_OK must be width x height; out_nhwc
  *                      device uint8 [n, height, width, 3] (rows of images with another status are left untouched);
  *                      status: device int32 [n] = the record's status, or DSMIL_E_INVALID when the entropy-coded data
- *                      turned out corrupt (the image is then undefined); ws: dsmil_jpeg_workspace_bytes(n, height, width)
- *                      bytes, 256-B aligned.  A memset and three launches on `stream`, no host synchronisation. */
+ *                      turned out corrupt (the image is then undefined); ws: dsmil_jpeg_workspace_bytes(n, height, width,
+ *                      data_bytes) bytes, 256-B aligned.  A memset and four launches on `stream`, no host synchronisation. */
 #define DSMIL_JPEG_MAX_TABLES 64
 typedef struct dsmil_jpeg_image {
     int64_t ecs_begin, ecs_end;   /* entropy-coded segment: byte offsets into `data` */
@@ -399,10 +399,10 @@ typedef struct dsmil_jpeg_image {
     int32_t status;               /* DSMIL_OK, DSMIL_E_UNSUPPORTED, DSMIL_E_INVALID */
 } dsmil_jpeg_image;
 size_t dsmil_jpeg_plan_bytes(int32_t n);
-size_t dsmil_jpeg_workspace_bytes(int32_t n, int32_t height, int32_t width);
+size_t dsmil_jpeg_workspace_bytes(int32_t n, int32_t height, int32_t width, int64_t data_bytes);
 int dsmil_jpeg_parse(const uint8_t* data, const int64_t* offsets, int32_t n, void* plan);
-int dsmil_jpeg_decode(const uint8_t* data, const void* plan, int32_t n, int32_t height, int32_t width, uint8_t* out_nhwc,
-                      int32_t* status, void* ws, size_t ws_bytes, void* stream);
+int dsmil_jpeg_decode(const uint8_t* data, int64_t data_bytes, const void* plan, int32_t n, int32_t height, int32_t width,
+                      uint8_t* out_nhwc, int32_t* status, void* ws, size_t ws_bytes, void* stream);
 
 const char* dsmil_strerror(int code);
 int dsmil_abi_version(void);

@@ -40,16 +40,16 @@ for bs in (256, batch, n):
     t0 = time.perf_counter()
     parsed = [ops.jpeg_parse(c) for c in chunks]
     t_parse = time.perf_counter() - t0
-    d = [(torch.from_numpy(p[0]).to(dev), torch.from_numpy(p[1]).to(dev), len(c)) for p, c in zip(parsed, chunks)]
-    outs = [torch.empty((m, 224, 224, 3), dtype=torch.uint8, device=dev) for _, _, m in d]
-    sts = [torch.empty(m, dtype=torch.int32, device=dev) for _, _, m in d]
-    ws = torch.empty(L.dsmil_jpeg_workspace_bytes(bs, 224, 224), dtype=torch.uint8, device=dev)
+    d = [(torch.from_numpy(p[0]).to(dev), torch.from_numpy(p[1]).to(dev), len(c), int(p[0].size) - 32) for p, c in zip(parsed, chunks)]
+    outs = [torch.empty((m, 224, 224, 3), dtype=torch.uint8, device=dev) for _, _, m, _ in d]
+    sts = [torch.empty(m, dtype=torch.int32, device=dev) for _, _, m, _ in d]
+    ws = torch.empty(L.dsmil_jpeg_workspace_bytes(bs, 224, 224, max(x[3] for x in d)), dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     for rep in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for (dd, pp, m), o, s in zip(d, outs, sts):
-            rc = L.dsmil_jpeg_decode(dd.data_ptr(), pp.data_ptr(), m, 224, 224, o.data_ptr(), s.data_ptr(), ws.data_ptr(), ws.numel(), st)
+        for (dd, pp, m, nb), o, s in zip(d, outs, sts):
+            rc = L.dsmil_jpeg_decode(dd.data_ptr(), nb, pp.data_ptr(), m, 224, 224, o.data_ptr(), s.data_ptr(), ws.data_ptr(), ws.numel(), st)
             assert rc == 0
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
