@@ -412,31 +412,53 @@ __device__ __forceinline__ int jp_chroma(const uint8_t* __restrict__ P, int Wp, 
     return i == 0 ? (cs * 4 + 8) >> 4 : (cs * 3 + 3 * r0[i - 1] + r1[i - 1] + 8) >> 4;
 }
 
+// VEC4: one thread = four horizontally adjacent pixels = twelve output bytes as three aligned dwords (W % 4 == 0); the first form
+// stored every byte on its own (2.9 ms per 8 192 tiles at 0.7 TB/s).  Otherwise one pixel per thread.
+__device__ __forceinline__ unsigned jp_rgb(int Y, int cb, int cr) {
+    int r = Y + ((91881 * cr + 32768) >> 16);
+    int g = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+    int b = Y + ((116130 * cb + 32768) >> 16);
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);
+    g = g < 0 ? 0 : (g > 255 ? 255 : g);
+    b = b < 0 ? 0 : (b > 255 ? 255 : b);
+    return (unsigned)r | ((unsigned)g << 8) | ((unsigned)b << 16);
+}
+
+template <bool VEC4>
 __global__ __launch_bounds__(256) void k_jpeg_color(const uint8_t* __restrict__ plan, int n, int W, int H,
                                                     const uint8_t* __restrict__ planes, uint8_t* __restrict__ out,
                                                     const int32_t* __restrict__ status) {
     const int i = blockIdx.y;
     if (status[i] != DSMIL_OK) return;
-    const long long px = (long long)blockIdx.x * 256 + threadIdx.x;
+    constexpr int PX = VEC4 ? 4 : 1;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long px = t * PX;
     if (px >= (long long)W * H) return;
     const int y = (int)(px / W), x = (int)(px - (long long)y * W);
     const dsmil_jpeg_image* im = reinterpret_cast<const dsmil_jpeg_image*>(plan + jp_off_images()) + i;
     const JpGeom g(W, H);
     const uint8_t* P = planes + (size_t)i * 3 * g.plane_bytes();
-    const int Y = P[(size_t)y * g.Wp + x];
-    uint8_t* o = out + ((size_t)i * H * W + (size_t)px) * 3;
-    if (im->ncomp == 1) { o[0] = o[1] = o[2] = (uint8_t)Y; return; }
     const int hs = im->hsamp, vs = im->vsamp;
     const int W2 = (W + hs - 1) / hs, H2 = (H + vs - 1) / vs;      // downsampled_width / height of the chroma components
-    const int cb = jp_chroma(P + g.plane_bytes(), g.Wp, x, y, hs, vs, W2, H2) - 128;
-    const int cr = jp_chroma(P + 2 * g.plane_bytes(), g.Wp, x, y, hs, vs, W2, H2) - 128;
-    int r = Y + ((91881 * cr + 32768) >> 16);
-    int gg = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
-    int b = Y + ((116130 * cb + 32768) >> 16);
-    r = r < 0 ? 0 : (r > 255 ? 255 : r);
-    gg = gg < 0 ? 0 : (gg > 255 ? 255 : gg);
-    b = b < 0 ? 0 : (b > 255 ? 255 : b);
-    o[0] = (uint8_t)r; o[1] = (uint8_t)gg; o[2] = (uint8_t)b;
+    const bool grey = im->ncomp == 1;
+    unsigned rgb[PX];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        const int Y = P[(size_t)y * g.Wp + x + k];
+        if (grey) { rgb[k] = (unsigned)Y * 0x010101u; continue; }
+        const int cb = jp_chroma(P + g.plane_bytes(), g.Wp, x + k, y, hs, vs, W2, H2) - 128;
+        const int cr = jp_chroma(P + 2 * g.plane_bytes(), g.Wp, x + k, y, hs, vs, W2, H2) - 128;
+        rgb[k] = jp_rgb(Y, cb, cr);
+    }
+    uint8_t* o = out + ((size_t)i * H * W + (size_t)px) * 3;
+    if constexpr (VEC4) {
+        unsigned* o4 = reinterpret_cast<unsigned*>(o);             // (12 px bytes: 4-byte aligned because W % 4 == 0 and `out` is)
+        o4[0] = rgb[0] | (rgb[1] << 24);
+        o4[1] = (rgb[1] >> 8) | (rgb[2] << 16);
+        o4[2] = (rgb[2] >> 16) | (rgb[3] << 8);
+    } else {
+        o[0] = (uint8_t)rgb[0]; o[1] = (uint8_t)(rgb[0] >> 8); o[2] = (uint8_t)(rgb[0] >> 16);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -641,8 +663,12 @@ int dsmil_jpeg_decode(const uint8_t* data, int64_t data_bytes, const void* plan,
                        (const uint8_t*)plan, n, width, height, coef, planes, status);
     if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     const long long npx = (long long)width * height;
-    hipLaunchKernelGGL(k_jpeg_color, dim3((unsigned)((npx + 255) / 256), (unsigned)n), dim3(256), 0, st, (const uint8_t*)plan, n, width,
-                       height, planes, out_nhwc, status);
+    if (width % 4 == 0 && ((uintptr_t)out_nhwc % 4) == 0)
+        hipLaunchKernelGGL(k_jpeg_color<true>, dim3((unsigned)((npx / 4 + 255) / 256), (unsigned)n), dim3(256), 0, st, (const uint8_t*)plan, n,
+                           width, height, planes, out_nhwc, status);
+    else
+        hipLaunchKernelGGL(k_jpeg_color<false>, dim3((unsigned)((npx + 255) / 256), (unsigned)n), dim3(256), 0, st, (const uint8_t*)plan, n,
+                           width, height, planes, out_nhwc, status);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
