@@ -40,6 +40,9 @@ def build_parser():
     p.add_argument("--embedder_weights_low", type=str, default=None)
     p.add_argument("--embedder_weights_high", type=str, default=None)
     p.add_argument("--tree_fusion", type=str, default="cat", help="[cat|fusion]")
+    p.add_argument("--gpu_decode", action="store_true", help="(new, default off) decode the tiles' JPEG files on the GPU "
+                   "(dsmil_jpeg_decode: bit-identical to Pillow for baseline JPEGs, Pillow for everything else) instead of in "
+                   "DataLoader workers (attention_map.py:69-79)")
     return p
 
 
@@ -101,7 +104,11 @@ def main(argv=None):
         args.class_name = ["class {}".format(c) for c in range(args.num_classes)]
     if len(args.thres) != args.num_classes:
         raise ValueError("Number of thresholds does not match classes.")
-    pipeline.attention_maps(args, bags_list, milnet, embedder_low=emb_low, embedder_high=emb_high)
+    pipeline.GPU_DECODE[0] = bool(args.gpu_decode)
+    try:
+        pipeline.attention_maps(args, bags_list, milnet, embedder_low=emb_low, embedder_high=emb_high)
+    finally:
+        pipeline.GPU_DECODE[0] = False
 
 
 if __name__ == "__main__":

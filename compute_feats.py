@@ -118,10 +118,13 @@ def main(argv=None):
     if args.bg_threshold is not None and args.magnification == "tree":
         raise ValueError("--bg_threshold filters single-magnification bags (a pyramid bag's rows are tied to its tile tree)")
     pipeline.GPU_DECODE[0] = bool(args.gpu_decode)
-    if args.magnification == "tree":
-        pipeline.compute_tree_feats(args, bags_list, ic_l, ic_h, feats_path)
-    else:
-        pipeline.compute_feats(args, bags_list, i_classifier, feats_path, args.magnification)
+    try:
+        if args.magnification == "tree":
+            pipeline.compute_tree_feats(args, bags_list, ic_l, ic_h, feats_path)
+        else:
+            pipeline.compute_feats(args, bags_list, i_classifier, feats_path, args.magnification)
+    finally:
+        pipeline.GPU_DECODE[0] = False
     if ddist.world_rank()[1] == 0:  # compute_feats.py:249-260
         all_df = []
         for i, item in enumerate(sorted(glob.glob(os.path.join("datasets", args.dataset, "*" + os.path.sep)))):
