@@ -114,6 +114,7 @@ __global__ __launch_bounds__(JP_UT) void k_jpeg_unstuff(const uint8_t* __restric
             if (prev == 0xFF && cur == 0x00) kp = false;                                   // stuffed zero
             else if (prev == 0xFF && cur >= 0xD0 && cur <= 0xD7) kp = false;               // second byte of RSTn
             else if (cur == 0xFF && nxt >= 0xD0 && nxt <= 0xD7) kp = false;                // first byte of RSTn
+            else if (cur == 0xFF && nxt == 0xFF) kp = false;                               // a fill byte in front of a marker (T.81 B.1.1.2)
             else if (cur == 0xFF && nxt != 0x00) { kp = false; if (stop == 0x7fffffff) stop = (int)(q - base); }   // another marker: the end
             if (kp) keep |= 1u << (k - 1);
         }
@@ -595,6 +596,14 @@ int dsmil_jpeg_parse(const uint8_t* data, const int64_t* offsets, int32_t n, voi
         }
         if (!ok) continue;
         if (W <= 0 || H <= 0) continue;
+        {   // the file must END with EOI (a few trailing bytes tolerated): a truncated file is Pillow's to judge ("image file is
+            // truncated"), not something to decode silently with zeros behind the data
+            bool eoi = false;
+            for (int64_t q = len - 2; q >= pos && q >= len - 16; --q)
+                if (b[q] == 0xFF && b[q + 1] == 0xD9) { eoi = true; break; }
+            if (!eoi) { im.status = DSMIL_E_INVALID; continue; }
+        }
+        if (ncomp == 3 && cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B') continue;   // libjpeg takes such ids for RGB data
         if (ncomp == 3 && adobe == 0) continue;                   // Adobe RGB: no colour transform
         if (ncomp == 3 && (ch[1] != 1 || cv[1] != 1 || ch[2] != 1 || cv[2] != 1)) continue;
         if (ncomp == 1) { ch[0] = 1; cv[0] = 1; }                 // a lone component is never subsampled (T.81 A.2.2)

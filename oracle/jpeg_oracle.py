@@ -134,6 +134,9 @@ class _Bits:
                 byte = self.b[self.pos]
                 if byte == 0xFF:
                     nxt = self.b[self.pos + 1] if self.pos + 1 < self.end else 0xD9
+                    while nxt == 0xFF and self.pos + 2 < self.end:   # fill bytes (T.81 B.1.1.2)
+                        self.pos += 1
+                        nxt = self.b[self.pos + 1]
                     if nxt == 0:
                         self.pos += 2
                     else:          # a marker: feed zeros (libjpeg's behaviour at the end of the segment)
@@ -155,7 +158,7 @@ class _Bits:
         """Byte-align and step over an RSTn marker."""
         self.acc, self.n = 0, 0
         while self.pos + 1 < self.end and not (self.b[self.pos] == 0xFF and 0xD0 <= self.b[self.pos + 1] <= 0xD7):
-            self.pos += 1
+            self.pos += 1          # (also steps over fill bytes in front of the marker)
         self.pos += 2
 
 

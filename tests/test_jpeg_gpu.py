@@ -138,3 +138,38 @@ def test_compute_feats_with_device_decode_gives_the_same_csv(tmp_path, monkeypat
     for f in ref:
         assert ref[f].shape == (9, 512) and np.array_equal(ref[f], got[f]), f
     assert len(pd.read_csv("datasets/toy/0_x/s1.csv")) == 9
+
+
+def _with_fill_bytes(blob):
+    """A restart-interval JPEG with an 0xFF fill byte in front of every RSTn marker of its scan (T.81 B.1.1.2 allows any number)."""
+    import jpeg_oracle as jo
+    beg = jo.parse(blob)["ecs"][0]
+    out = bytearray(blob[:beg])
+    i = beg
+    while i < len(blob):
+        if blob[i] == 0xFF and i + 1 < len(blob) and 0xD0 <= blob[i + 1] <= 0xD7:
+            out += b"\xff"
+        out.append(blob[i])
+        i += 1
+    return bytes(out)
+
+
+def test_fill_bytes_truncation_and_rgb_component_ids():
+    """Streams a tiler does not write but the standard allows: fill bytes in front of restart markers decode like Pillow; a file
+    without its EOI is NOT decoded on the device (Pillow judges it, as in the reference's loader)."""
+    import jpeg_oracle as jo
+    from dsmil_wsi_amd import ops
+    rng = np.random.default_rng(21)
+    a = _img(rng, 64, 80, 2)
+    rst = _jpeg(a, quality=70, restart_marker_blocks=2)
+    filled = _with_fill_bytes(rst)
+    assert len(filled) > len(rst)
+    ref = _pil(filled)
+    assert np.array_equal(ref, _pil(rst)) and np.array_equal(jo.decode(filled), ref)
+    stats = {}
+    got = ops.jpeg_decode([filled, rst], "cuda", stats=stats).cpu().numpy()
+    assert stats["pillow"] == 0 and np.array_equal(got[0], ref) and np.array_equal(got[1], ref)
+    # truncated: the parser hands it to Pillow
+    cut = rst[:-2]
+    _, _, recs = ops.jpeg_parse([rst, cut])
+    assert recs["status"][0] == 0 and recs["status"][1] == -1
