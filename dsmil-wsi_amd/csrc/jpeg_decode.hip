@@ -33,8 +33,8 @@
 
 namespace {
 
-constexpr int JP_MAX_QT = DSMIL_JPEG_MAX_TABLES;   // distinct quantisation / Huffman tables per batch
-constexpr int JP_MAX_HT = DSMIL_JPEG_MAX_TABLES;
+constexpr int JP_MAX_QT = DSMIL_JPEG_MAX_QTABLES;  // distinct quantisation / Huffman tables per batch
+constexpr int JP_MAX_HT = DSMIL_JPEG_MAX_HTABLES;
 constexpr int JP_LOOK = 12;                        // lookahead bits of the fast Huffman table
 
 struct JpHuff {                 // one Huffman table, device form
@@ -181,7 +181,8 @@ struct JpBits {
 
 // one Huffman symbol + its magnitude (T.81 F.2.2.1 / F.2.2.3 with a 12-bit lookahead, jdhuff.c's scheme).  Returns the symbol
 // (-1: no such code) and, for its low nibble s > 0, the EXTENDed value of the s bits behind the code in `val`.
-__device__ __forceinline__ int jp_symbol(JpBits& b, const JpHuff* __restrict__ t, int& val) {
+template <class TP>   // TP: pointer to the table — LDS address space (ds_read) or generic
+__device__ __forceinline__ int jp_symbol(JpBits& b, TP t, int& val) {
     const unsigned win = b.window();
     const unsigned e = t->look[win >> (32 - JP_LOOK)];
     int len, sym;
@@ -213,33 +214,21 @@ __device__ __forceinline__ int jp_symbol(JpBits& b, const JpHuff* __restrict__ t
 // Batches of up to 4 096 tiles take 256-lane workgroups instead (one wave per SIMD on up to 16 compute units): the lane's chain
 // then runs at its own latency, 11 ms per 224 x 224 tile instead of 17-25 ms with four waves sharing a SIMD's issue slots.
 constexpr int JP_LDS_HT = 4;
-template <int JP_HT>
-__global__ __launch_bounds__(JP_HT) void k_jpeg_huffman(const uint8_t* __restrict__ ust, const uint8_t* __restrict__ plan, int n,
-                                                        int W, int H, int16_t* __restrict__ coef, int32_t* __restrict__ status) {
-    __shared__ __attribute__((aligned(16))) unsigned s_tab[JP_LDS_HT * sizeof(JpHuff) / 4];
-    const int n_ht = reinterpret_cast<const JpHeader*>(plan)->n_ht;
-    const bool in_lds = n_ht <= JP_LDS_HT;
-    if (in_lds) {
-        const unsigned* src = reinterpret_cast<const unsigned*>(plan + jp_off_ht(n));
-        for (int t = threadIdx.x; t < n_ht * (int)(sizeof(JpHuff) / 4); t += JP_HT) s_tab[t] = src[t];
-    }
-    __syncthreads();
-    const int i = (int)blockIdx.x * JP_HT + threadIdx.x;
-    if (i >= n) return;
-    const dsmil_jpeg_image* imp = reinterpret_cast<const dsmil_jpeg_image*>(plan + jp_off_images()) + i;
-    const int ist = imp->status;
-    if (ist != DSMIL_OK) { status[i] = ist; return; }
-    const JpHuff* hts = in_lds ? reinterpret_cast<const JpHuff*>(s_tab) : reinterpret_cast<const JpHuff*>(plan + jp_off_ht(n));
+typedef const __attribute__((address_space(3))) JpHuff* JpHuffLds;
+
+// one lane = one tile's stream; TP = how the Huffman tables are addressed (LDS: ds_read; generic: global memory)
+template <class TP>
+__device__ __forceinline__ int jp_decode_lane(TP hts, const dsmil_jpeg_image* imp, const uint8_t* __restrict__ ust, int W, int H,
+                                              int16_t* __restrict__ cimg) {
     const JpGeom g(W, H);
-    int16_t* cimg = coef + (size_t)i * g.coef_elems();
     const int ncomp = imp->ncomp, hs = imp->hsamp, vs = imp->vsamp, ri = imp->restart_interval;
     // (registers, not an indexed copy of the record: a dynamically indexed local array lives in scratch memory)
-    const JpHuff* dc0 = hts + imp->dc[0];
-    const JpHuff* ac0 = hts + imp->ac[0];
-    const JpHuff* dc1 = hts + imp->dc[1];
-    const JpHuff* ac1 = hts + imp->ac[1];
-    const JpHuff* dc2 = hts + imp->dc[2];
-    const JpHuff* ac2 = hts + imp->ac[2];
+    TP dc0 = hts + imp->dc[0];
+    TP ac0 = hts + imp->ac[0];
+    TP dc1 = hts + imp->dc[1];
+    TP ac1 = hts + imp->ac[1];
+    TP dc2 = hts + imp->dc[2];
+    TP ac2 = hts + imp->ac[2];
     const int mx = (W + 8 * hs - 1) / (8 * hs), my = (H + 8 * vs - 1) / (8 * vs);
     JpBits b;
     b.init(reinterpret_cast<const unsigned*>(ust + ((imp->ecs_begin + 3) & ~3LL)));
@@ -260,8 +249,8 @@ __global__ __launch_bounds__(JP_HT) void k_jpeg_huffman(const uint8_t* __restric
                 const int c = bi < hs * vs ? 0 : bi - hs * vs + 1;
                 const int v = c ? 0 : bi / hs, h = c ? 0 : bi - v * hs;
                 const int cv = c ? 1 : vs, ch = c ? 1 : hs;
-                const JpHuff* dct = c == 0 ? dc0 : (c == 1 ? dc1 : dc2);
-                const JpHuff* act = c == 0 ? ac0 : (c == 1 ? ac1 : ac2);
+                TP dct = c == 0 ? dc0 : (c == 1 ? dc1 : dc2);
+                TP act = c == 0 ? ac0 : (c == 1 ? ac1 : ac2);
                 int16_t* blk = cimg + ((size_t)c * g.blocks_plane + (size_t)(yy * cv + v) * bw + (xx * ch + h)) * 64;
                 int diff;
                 int s = jp_symbol(b, dct, diff);
@@ -288,7 +277,30 @@ __global__ __launch_bounds__(JP_HT) void k_jpeg_huffman(const uint8_t* __restric
             }
         }
     }
-    status[i] = st;
+    return st;
+}
+
+template <int JP_HT>
+__global__ __launch_bounds__(JP_HT) void k_jpeg_huffman(const uint8_t* __restrict__ ust, const uint8_t* __restrict__ plan, int n,
+                                                        int W, int H, int16_t* __restrict__ coef, int32_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) unsigned s_tab[JP_LDS_HT * sizeof(JpHuff) / 4];
+    const int n_ht = reinterpret_cast<const JpHeader*>(plan)->n_ht;
+    const bool in_lds = n_ht <= JP_LDS_HT;             // (uniform over the launch)
+    if (in_lds) {
+        const unsigned* src = reinterpret_cast<const unsigned*>(plan + jp_off_ht(n));
+        for (int t = threadIdx.x; t < n_ht * (int)(sizeof(JpHuff) / 4); t += JP_HT) s_tab[t] = src[t];
+    }
+    __syncthreads();
+    const int i = (int)blockIdx.x * JP_HT + threadIdx.x;
+    if (i >= n) return;
+    const dsmil_jpeg_image* imp = reinterpret_cast<const dsmil_jpeg_image*>(plan + jp_off_images()) + i;
+    const int ist = imp->status;
+    if (ist != DSMIL_OK) { status[i] = ist; return; }
+    const JpGeom g(W, H);
+    int16_t* cimg = coef + (size_t)i * g.coef_elems();
+    // two instantiations of the lane's decode: table lookups as ds_read (the usual case: a tiler's four tables) or from global memory
+    if (in_lds) status[i] = jp_decode_lane<JpHuffLds>((JpHuffLds)(s_tab), imp, ust, W, H, cimg);
+    else status[i] = jp_decode_lane<const JpHuff*>(reinterpret_cast<const JpHuff*>(plan + jp_off_ht(n)), imp, ust, W, H, cimg);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -374,8 +374,8 @@ int dsmil_tile_stats(const uint8_t* tiles_nhwc, int32_t B, int32_t H, int32_t W,
  * COMPRESSED bytes of a batch go to the device and are decoded there into uint8 NHWC — the input of
  * dsmil_resnet_forward_ex(x_is_u8_nhwc = 1) — bit for bit what Pillow's defaults produce (islow IDCT, fancy upsampling,
  * YCbCr -> RGB; a grey image gives R = G = B).  Scope: SOF0, 8 bit, Huffman, one interleaved scan, 1 or 3 components, luma
- * sampling 1x1 / 2x1 / 2x2 with 1x1 chroma, restart intervals, arbitrary tables, at most DSMIL_JPEG_MAX_TABLES distinct
- * quantisation and as many distinct Huffman tables per batch.
+ * sampling 1x1 / 2x1 / 2x2 with 1x1 chroma, restart intervals, arbitrary tables, at most DSMIL_JPEG_MAX_QTABLES distinct
+ * quantisation and DSMIL_JPEG_MAX_HTABLES distinct Huffman tables per batch (a tiler writes the same ones into every tile).
  *
  *   dsmil_jpeg_parse   HOST function (no device work): data = the files of the batch back to back in HOST memory, offsets
  *                      [n + 1]; fills `plan` (host memory, dsmil_jpeg_plan_bytes(n) bytes, 16-B aligned): one
@@ -387,7 +387,8 @@ int dsmil_tile_stats(const uint8_t* tiles_nhwc, int32_t B, int32_t H, int32_t W,
  *                      status: device int32 [n] = the record's status, or DSMIL_E_INVALID when the entropy-coded data
  *                      turned out corrupt (the image is then undefined); ws: dsmil_jpeg_workspace_bytes(n, height, width,
  *                      data_bytes) bytes, 256-B aligned.  A memset and four launches on `stream`, no host synchronisation. */
-#define DSMIL_JPEG_MAX_TABLES 64
+#define DSMIL_JPEG_MAX_QTABLES 256   /* distinct quantisation tables per batch (128 B each in the plan) */
+#define DSMIL_JPEG_MAX_HTABLES 64    /* distinct Huffman tables per batch (8.4 KiB each in the plan) */
 typedef struct dsmil_jpeg_image {
     int64_t ecs_begin, ecs_end;   /* entropy-coded segment: byte offsets into `data` */
     int32_t width, height;
