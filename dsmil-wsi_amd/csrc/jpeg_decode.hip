@@ -515,7 +515,10 @@ size_t dsmil_jpeg_workspace_bytes(int32_t n, int32_t height, int32_t width, int6
     if (n <= 0 || height <= 0 || width <= 0 || height > 65535 || width > 65535 || data_bytes <= 0) return 0;
     const JpGeom g(width, height);
     // coefficients | component planes | the unstuffed streams (parallel to the file bytes, + slack for alignment and the zeros)
-    return (size_t)n * (g.coef_elems() * sizeof(int16_t) + 3 * g.plane_bytes()) + (((size_t)data_bytes + 64 + 255) & ~(size_t)255) + 256;
+    // | overrun slack: a CORRUPT last stream can make its lane read on past the batch's bytes — at most 4 bytes per coefficient
+    // of one image (a symbol is <= 27 bits); the read must stay inside the allocation (what it decodes is garbage either way)
+    return (size_t)n * (g.coef_elems() * sizeof(int16_t) + 3 * g.plane_bytes()) + (((size_t)data_bytes + 64 + 255) & ~(size_t)255) +
+           g.coef_elems() * 4 + 512;
 }
 
 int dsmil_jpeg_parse(const uint8_t* data, const int64_t* offsets, int32_t n, void* plan) {
