@@ -87,59 +87,85 @@ def glob_patches(bag_dir, magnification="single"):
 _decode_streams = {}
 
 
+class _ChunkDecoder:
+    """Device JPEG decode of a slide's chunks on a side stream, double-buffered.
+    decode(blobs) -> uint8 [n, H, W, 3] (a view of one of two staging buffers), enqueued on the decode stream; the CALLER's
+    current stream is made to wait for it.  release() — called when the consumer has ENQUEUED its work on the chunk — marks the
+    buffer: the decode that reuses it (two chunks later) waits for that point of the consumer's stream.
+    The stream has HIGH priority: (a) its own hardware queue — the runtime multiplexes a process's normal-priority streams over
+    four hardware queues, so a fifth stream created behind the embed pool's would share one with conv kernels and the ~11 ms
+    decode launch would sit in line behind them (measured: 35.7 k instead of 55.5 k patches/s); (b) the dispatcher places the
+    decode's few workgroups as soon as compute units free up."""
+
+    def __init__(self, device, decode_batch, stats=None):
+        self.dev = torch.device(device)
+        self.ds = _decode_streams.get(str(self.dev))
+        if self.ds is None:
+            self.ds = _decode_streams[str(self.dev)] = torch.cuda.Stream(device=self.dev, priority=-1)
+        self.decode_batch, self.stats = decode_batch, stats
+        self.bufs, self.free_ev = [None, None], [None, None]
+        self.size, self.k, self.last = None, 0, None
+
+    def decode(self, blobs):
+        k = self.k
+        self.k ^= 1
+        with torch.cuda.stream(self.ds):                  # (the inputs are host bytes: nothing of the caller's stream to wait for)
+            if self.free_ev[k] is not None:
+                self.ds.wait_event(self.free_ev[k])       # the consumer's work on the chunk that used this buffer
+            imgs = ops.jpeg_decode(blobs, self.dev, size=self.size, stats=self.stats, out=self.bufs[k])
+            if self.bufs[k] is None and imgs.shape[0] == self.decode_batch:
+                self.bufs[k] = imgs                       # (a short last chunk is not worth keeping)
+            self.size = tuple(imgs.shape[1:3])
+            ev = torch.cuda.Event()
+            ev.record(self.ds)
+        return imgs, ev, k
+
+    def acquire(self, item):
+        """Make the caller's current stream wait for a decode()'s result; returns the images."""
+        imgs, ev, k = item
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(ev)
+        imgs.record_stream(cur)
+        return imgs
+
+    def release(self, item):
+        e = torch.cuda.Event()
+        e.record(torch.cuda.current_stream(self.dev))
+        self.free_ev[item[2]] = e
+
+    def finish(self):
+        torch.cuda.current_stream(self.dev).wait_stream(self.ds)
+
+
 @torch.no_grad()
 def embed_jpeg_blobs(i_classifier, blobs, batch_size=256, decode_batch=2048, streams=3, device=None, stats=None):
     """A slide's tiles as JPEG FILES IN HOST MEMORY (bytes-likes) -> (feats [N,F], classes [N,C]) on the device: chunks of
     `decode_batch` files are decoded on the device (ops.jpeg_decode) on a side stream into one of two staging buffers while the
-    previous chunk is embedded (embed_tiles: batches of `batch_size` over `streams` HIP streams) — the decode's 1 024-lane
+    previous chunk is embedded (embed_tiles: batches of `batch_size` over `streams` HIP streams) — the decode's 256-lane
     workgroups hold a handful of compute units, the conv kernels the rest.  compute_feats.py:55-76 with the loader's Pillow
-    workers and the 150 KB-per-tile H2D copy replaced by an ~11 KB-per-tile copy and three launches per chunk."""
+    workers and the 150 KB-per-tile H2D copy replaced by an ~11 KB-per-tile copy and four launches per chunk."""
     dev = torch.device(device) if device is not None else next(i_classifier.parameters()).device
     n = len(blobs)
     F_, C_ = i_classifier.fc.in_features, i_classifier.fc.out_features
     if n == 0:
         return torch.zeros((0, F_), device=dev), torch.zeros((0, C_), device=dev)
-    main = torch.cuda.current_stream(dev)
-    ds = _decode_streams.get(str(dev))
-    if ds is None:
-        # HIGH priority: (a) its own hardware queue — the runtime multiplexes a process's normal-priority streams over four
-        # hardware queues, so a fifth stream created behind the embed pool's would share one with conv kernels and the 25 ms
-        # decode launch would sit in line behind them (measured: 35.7 k instead of 55.5 k patches/s); (b) the dispatcher places
-        # the decode's few workgroups as soon as compute units free up
-        ds = _decode_streams[str(dev)] = torch.cuda.Stream(device=dev, priority=-1)
+    dec = _ChunkDecoder(dev, decode_batch, stats)
     chunks = [blobs[i:i + decode_batch] for i in range(0, n, decode_batch)]
-    bufs, free_ev = [None, None], [None, None]
-    size = [None]
-
-    def decode(ci):
-        k = ci % 2
-        with torch.cuda.stream(ds):                      # (the inputs are host bytes: nothing of `main` to wait for)
-            if free_ev[k] is not None:
-                ds.wait_event(free_ev[k])                # the embed of the chunk that used this buffer two chunks ago
-            imgs = ops.jpeg_decode(chunks[ci], dev, size=size[0], stats=stats, out=bufs[k])
-            if bufs[k] is None:
-                bufs[k] = imgs if imgs.shape[0] == decode_batch else None   # (a short last chunk is not worth keeping)
-            size[0] = tuple(imgs.shape[1:3])
-            ev = torch.cuda.Event()
-            ev.record(ds)
-        return imgs, ev
-
     fl, cl = [], []
-    cur = decode(0)
+    cur = dec.decode(chunks[0])
     for ci in range(len(chunks)):
-        imgs, ev = cur
-        main.wait_event(ev)
-        f, c = embed_tiles(i_classifier, imgs, batch_size, streams=streams, device=dev)   # enqueued; joined into `main`
-        e2 = torch.cuda.Event()
-        e2.record(main)
-        free_ev[ci % 2] = e2
-        imgs.record_stream(main)
+        imgs = dec.acquire(cur)
+        f, c = embed_tiles(i_classifier, imgs, batch_size, streams=streams, device=dev)   # enqueued; joined into this stream
+        dec.release(cur)
         if ci + 1 < len(chunks):
-            cur = decode(ci + 1)       # the host waits here for the decode's status while the GPU embeds chunk ci
+            cur = dec.decode(chunks[ci + 1])   # the host waits here for the decode's status while the GPU embeds chunk ci
         fl.append(f)
         cl.append(c)
-    main.wait_stream(ds)
+    dec.finish()
     return torch.cat(fl), torch.cat(cl)
+
+
+DECODE_BATCH = [2048]   # files per device-decode chunk of embed_files(gpu_decode=True) (tests lower it to walk the double buffer)
 
 
 # Default of embed_files(gpu_decode=None): the scripts set it from their --gpu_decode flag (compute_feats.py, attention_map.py)
@@ -151,7 +177,8 @@ def gpu_decoded_batches(files, batch_size, device, io_threads=4, decode_batch=20
     files' bytes are read by a thread pool, `decode_batch` files at a time go through ops.jpeg_decode (baseline JPEGs:
     dsmil_jpeg_decode, bit-identical to Pillow; anything else: Pillow on the host inside the same call) and come back as uint8
     NHWC batches of `batch_size` already on `device` — what PatchFiles(uint8=True) yields after its H2D copy, at a tenth of the
-    PCIe bytes and without worker processes.  The next chunk's files are read while the current one is embedded."""
+    PCIe bytes and without worker processes.  The next chunk is read and decoded (on the side stream of _ChunkDecoder) when the
+    consumer has taken — i.e. enqueued its work on — the last batch of the current one."""
     from concurrent.futures import ThreadPoolExecutor
 
     def read(path):
@@ -161,18 +188,19 @@ def gpu_decoded_batches(files, batch_size, device, io_threads=4, decode_batch=20
     files = list(files)
     if not files:
         return
+    dec = _ChunkDecoder(device, decode_batch, stats)
     with ThreadPoolExecutor(max_workers=max(1, int(io_threads))) as pool:
         chunks = [files[i:i + decode_batch] for i in range(0, len(files), decode_batch)]
-        pending = pool.map(read, chunks[0])
-        size = None
+        cur = dec.decode(list(pool.map(read, chunks[0])))
         for ci in range(len(chunks)):
-            blobs = list(pending)
-            if ci + 1 < len(chunks):
-                pending = pool.map(read, chunks[ci + 1])       # (submitted now: read while this chunk decodes and embeds)
-            imgs = ops.jpeg_decode(blobs, device, size=size, stats=stats)
-            size = tuple(imgs.shape[1:3])
+            pending = pool.map(read, chunks[ci + 1]) if ci + 1 < len(chunks) else None   # (read while this chunk is consumed)
+            imgs = dec.acquire(cur)
             for o in range(0, imgs.shape[0], batch_size):
                 yield {"input": imgs[o:o + batch_size]}
+            dec.release(cur)                              # the consumer's work on this chunk is enqueued by now
+            if pending is not None:
+                cur = dec.decode(list(pending))
+        dec.finish()
 
 
 @torch.no_grad()
@@ -225,7 +253,8 @@ def embed_files(i_classifier, files, batch_size=128, num_workers=4, device=None,
         pending = None
         if gpu_decode is None:
             gpu_decode = GPU_DECODE[0]
-        loader = (gpu_decoded_batches(files[lo:hi], batch_size, device, io_threads=max(1, num_workers)) if gpu_decode and u8 and on_gpu
+        loader = (gpu_decoded_batches(files[lo:hi], batch_size, device, io_threads=max(1, num_workers), decode_batch=DECODE_BATCH[0])
+                  if gpu_decode and u8 and on_gpu
                   else patch_loader(files[lo:hi], batch_size, num_workers, False, uint8=u8 or filt))
         for batch in loader:
             patches = batch["input"].to(device, non_blocking=True)

@@ -173,3 +173,36 @@ def test_fill_bytes_truncation_and_rgb_component_ids():
     cut = rst[:-2]
     _, _, recs = ops.jpeg_parse([rst, cut])
     assert recs["status"][0] == 0 and recs["status"][1] == -1
+
+
+def test_chunked_decode_walks_both_staging_buffers(tmp_path):
+    """embed_files(gpu_decode=True) and embed_jpeg_blobs over SEVEN chunks of 8 files (the two staging buffers are each reused
+    three times, the decode of chunk i+1 runs on the side stream under the embedding of chunk i): feature rows bit-identical to the
+    Pillow loader's, in order."""
+    import os
+    from test_resnet_gpu import _build
+    from dsmil_wsi_amd import pipeline as pl
+    rng = np.random.default_rng(31)
+    files, blobs = [], []
+    for i in range(53):
+        b = _jpeg(_img(rng, 96, 96, i % 3), quality=70)
+        f = os.path.join(tmp_path, f"{i}_{i + 1}.jpeg")
+        with open(f, "wb") as fh:
+            fh.write(b)
+        files.append(f)
+        blobs.append(b)
+    ic, _ = _build(seed=11)
+    ic = ic.cuda()
+    ref_f, ref_c = pl.embed_files(ic, files, batch_size=4, num_workers=0, gpu_decode=False)
+    old = pl.DECODE_BATCH[0]
+    pl.DECODE_BATCH[0] = 8
+    try:
+        got_f, got_c = pl.embed_files(ic, files, batch_size=4, num_workers=2, gpu_decode=True)
+    finally:
+        pl.DECODE_BATCH[0] = old
+    assert torch.equal(ref_f, got_f) and torch.equal(ref_c, got_c)
+    st = {}
+    f2, c2 = pl.embed_jpeg_blobs(ic, blobs, batch_size=4, decode_batch=8, streams=3, stats=st)
+    torch.cuda.synchronize()
+    assert st == {"device": 53, "pillow": 0}
+    assert torch.equal(ref_f, f2) and torch.equal(ref_c, c2)
