@@ -269,6 +269,11 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
     w = {k: torch.from_numpy(v).to(dev) for k, v in wnp.items()}
     g = torch.Generator(device=dev).manual_seed(1234 + cx.rank)
     bf16 = dtype == "bf16"
+    # streams of THIS leg: the bf16 pass wants exactly one other batch's logits / q_max / combine kernels under each
+    # persistent attend launch (the co-resident forms of round 6, dsmil_agg_logits_form): two streams; a third batch only
+    # queues a second attend launch behind the first (measured: 238 k bags/s on two, 229 k on three, distinct batches)
+    n_streams = args.streams_bf16 if (bf16 and args.streams > 1) else args.streams
+    pool = cx.pool if n_streams == args.streams else (ops.StreamPool(n_streams, dev) if n_streams > 1 else None)
     # one DISTINCT batch per stream: passes in flight together are different batches of bags in a real job, so no pass
     # may ride another's cache fills (3 x 1.31 GB fp32)
     n_batches = max(1, args.streams)
@@ -288,13 +293,14 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
         return ops.agg_forward(batches[turn[0] % n_batches], lengths, w, offsets=offsets)
 
     def step():
-        out[:] = cx.run(one)
+        out[:] = pool.run(one) if pool is not None else one()
 
     dt, inner, kern_ms_tot, launches = cx.timed(step, args.steps, args.warmup, args.min_seconds, channel=0)
     kern_alone_ms, _ = cx.kernel_alone(one, 0, passes=300)
     # the same passes with ONE in flight (no stream pool), beside the pooled headline
     value_1s = None
-    if cx.pool is not None:
+    if pool is not None:
+        pool.join()
         def step1():
             out[:] = one()
         dt1, inner1, _, _ = cx.timed(step1, max(2, args.steps // 4), 1, args.min_seconds / 4)
@@ -334,7 +340,8 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
                                    f"HBM-resident", "passes_per_step": inner, "bags_per_pass_per_gpu": nb, "rows": N,
                        "feats": K, "classes": C, "tile_rows": int(cx.L.dsmil_agg_tile_rows(nb, nb * N)),
                        "parallelism": f"bag-sharded x{world}", "timed_region_s": round(dt, 3),
-                       "streams": args.streams, "distinct_batches": n_batches,
+                       "streams": n_streams, "distinct_batches": n_batches,
+                       "logits_form": int(cx.L.dsmil_agg_logits_form(-1)),
                        "value_one_stream": round(value_1s, 1) if value_1s else None,
                        "single_bag_forward_ms": round(single_ms, 4) if single_ms is not None else None,
                        "single_bag_forward_ms_is": "median of five rounds of 50 back-to-back forwards of one 10 000-row bag, host-inclusive" if single_ms is not None else None,
@@ -1013,6 +1020,9 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on each timed region")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams independent passes are dealt to (ops.StreamPool); 1 = one pass in flight")
+    ap.add_argument("--streams-bf16", type=int, default=2,
+                    help="streams of the aggregator_bf16 leg when --streams > 1 (its co-resident kernels pair one batch's "
+                         "logits pass with another's attend kernel)")
     ap.add_argument("--slide-patches", type=int, default=10000)
     ap.add_argument("--e2e-grid", type=int, nargs=2, default=(24, 26), help="low-magnification tile grid of the e2e slide")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)

@@ -55,6 +55,7 @@ SIGNATURES = {
     "dsmil_agg_inline_query": (ctypes.c_int, [ctypes.c_int]),
     "dsmil_agg_batch_form": (ctypes.c_int, [ctypes.c_int]),
     "dsmil_agg_persistent_grid": (ctypes.c_int, [ctypes.c_int]),
+    "dsmil_agg_logits_form": (ctypes.c_int, [ctypes.c_int]),
     "dsmil_device_cus": (ctypes.c_int, []),
     "dsmil_agg_packed_f2_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
     "dsmil_agg_pack_f2": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),

@@ -348,6 +348,168 @@ __global__ __launch_bounds__(256, (CP == 1 ? 6 : 3)) void k_logits_stream(
 }
 
 // --------------------------------------------------------------------------------------------
+// k_logits_pipe (round 6): k_logits_stream's work for the BATCH path of the bf16 aggregator (K = 512, C <= 2), shaped to run
+// BESIDE a resident k_attend_bf16_res workgroup of another stream.  That kernel owns every CU for the whole launch (150 KiB of
+// LDS, one wave per SIMD) — but since round 6 its waves hold 432 of a SIMD's 512 registers (agg_res.h), so ONE 80-register
+// wave fits next to each of them, with the 4 KiB of LDS this kernel needs.  The second read of the features (dsmil.py:50-52
+// needs the whole bag before any score) then runs UNDER the MFMA kernel of the batch in front instead of behind it.  What
+// that asks of this kernel:
+//   * <= 80 registers and no scratch (__launch_bounds__(256, 6); in-bag row indices in 32 bits, no class loop);
+//   * its bytes in flight per CU are 4 waves x 4..8 KiB — they have to be in flight ALL the time: the stream is a continuous
+//     pipeline of two 4-segment register sets running across the 8-row groups of a wave (the burst form has nothing in flight
+//     while it reduces and stores a group).  Every load is unconditional — the last prefetch of a wave is peeled off, not
+//     predicated (a conditional load makes hipcc's vmcnt model wait for the youngest load).
+// Same tile geometry, partial layout and fmaf order as k_logits_stream: bit-identical logits and partials.
+// --------------------------------------------------------------------------------------------
+template <int CP>   // classes: 1 or 2 (= C).  (No row map: the bf16 entry point has none — its lookups would be loads in the same
+                    // in-order queue as the stream.)
+__global__ __launch_bounds__(256, 6) void k_logits_pipe(
+    const bf16_t* __restrict__ feats, const int64_t* __restrict__ offsets,
+    const float* __restrict__ fc_w, const float* __restrict__ fc_b, float* __restrict__ classes_out,
+    float* __restrict__ part_val, long long* __restrict__ part_idx, int bag0,
+    int r0, const int* __restrict__ tile_pre, int n_bags) {
+    constexpr int K = 512, SEG = 64;         // 8 segments of 64 bf16 (128 B) per row; lane j of a row's 8 takes 16 B of each
+    __shared__ __attribute__((aligned(16))) float s_w[CP * K];
+    __shared__ float s_v[8];
+    __shared__ int s_i[8];
+    int bag = bag0 + (int)blockIdx.y, tile = (int)blockIdx.x;
+    if (tile_pre) {
+        if ((int)blockIdx.x >= tile_pre[n_bags]) return;
+        const int b = tile_owner(tile_pre, n_bags, (int)blockIdx.x);
+        bag = bag0 + b;
+        tile = (int)blockIdx.x - tile_pre[b];
+    }
+    const long long off0 = offsets[bag];
+    const long long Nbl = offsets[bag + 1] - off0;
+    const long long row0l = (long long)tile * r0;
+    if (row0l >= Nbl) return;
+    const int Nb = (int)Nbl, row0 = (int)row0l;              // (a bag of the batch path has < 2^31 rows: n_items check of the host)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 7, rr = lane >> 3;
+    const int ngrp = r0 >> 5, rpw = r0 >> 2;                 // 8-row groups per wave, rows per wave
+    const int wbase = row0 + wave * rpw;
+    int ng = 0;
+    if (wbase < Nb) { const int left = (Nb - wbase + 7) >> 3; ng = left < ngrp ? left : ngrp; }
+    for (int i = tid; i < CP * K; i += 256) s_w[i] = fc_w[i];
+    __syncthreads();
+    const float b0 = fc_b[0], b1 = fc_b[CP - 1];
+    float bv0 = -INFINITY, bv1 = -INFINITY;
+    int bi0 = 0x7fffffff, bi1 = 0x7fffffff;
+    if (ng > 0) {
+        typedef StreamVec<bf16_t> SV;
+        const bf16_t* fbase = feats + j * 8;
+        auto row_of = [&](int g) { const int r = wbase + g * 8 + rr; return r < Nb ? r : Nb - 1; };
+        auto ptr_of = [&](int r) { return fbase + (off0 + r) * (long long)K; };
+        SV va[4], vb[4];
+        float a0 = 0.f, a1 = 0.f;
+        // One 16-B piece (8 bf16 of one row) at a time: its 8 (16) weights come out of LDS inside an asm statement that also
+        // takes the running sums as in/out operands — so hipcc can neither hoist the loop-invariant weight reads out of the
+        // row loop (64-128 registers) nor gather the unpack work of all pieces in front of one long fma chain (both happened:
+        // 50-120 scratch accesses inside the load pipeline, each of them a vmcnt(0) wait).  The LDS round trip per piece is
+        // exposed on purpose: this wave is the filler beside an MFMA wave, its loads are in flight either way.
+        const unsigned wad = (unsigned)(size_t)(__attribute__((address_space(3))) float*)s_w + j * 32;
+        auto piece = [&](const SV& v, auto off_tag) {
+            constexpr int OFF = decltype(off_tag)::value;     // byte offset of the segment's weights inside s_w
+            f32x4 wa, wb, wc, wd;
+            if constexpr (CP == 2) {
+                asm volatile("ds_read_b128 %0, %6 offset:%7\n\tds_read_b128 %1, %6 offset:%8\n\t"
+                             "ds_read_b128 %2, %6 offset:%9\n\tds_read_b128 %3, %6 offset:%10\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(wa), "=&v"(wb), "=&v"(wc), "=&v"(wd), "+v"(a0), "+v"(a1)
+                             : "v"(wad), "n"(OFF), "n"(OFF + 16), "n"(OFF + K * 4), "n"(OFF + K * 4 + 16) : "memory");
+            } else {
+                asm volatile("ds_read_b128 %0, %3 offset:%4\n\tds_read_b128 %1, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(wa), "=&v"(wb), "+v"(a0) : "v"(wad), "n"(OFF), "n"(OFF + 16) : "memory");
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a0 = fmaf(v.at(e), wa[e], a0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a0 = fmaf(v.at(4 + e), wb[e], a0);
+            if constexpr (CP == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a1 = fmaf(v.at(e), wc[e], a1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a1 = fmaf(v.at(4 + e), wd[e], a1);
+            }
+        };
+        auto consume_lo = [&](const SV (&v)[4]) {
+            piece(v[0], std::integral_constant<int, 0 * 256>{}); piece(v[1], std::integral_constant<int, 1 * 256>{});
+            piece(v[2], std::integral_constant<int, 2 * 256>{}); piece(v[3], std::integral_constant<int, 3 * 256>{});
+        };
+        auto consume_hi = [&](const SV (&v)[4]) {
+            piece(v[0], std::integral_constant<int, 4 * 256>{}); piece(v[1], std::integral_constant<int, 5 * 256>{});
+            piece(v[2], std::integral_constant<int, 6 * 256>{}); piece(v[3], std::integral_constant<int, 7 * 256>{});
+        };
+        // finish one 8-row group: lane reduction (3 xor-shuffles), bias, stores, running arg-max
+        auto finish_rows = [&](int g, int r) {
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) {
+                a0 += __shfl_xor(a0, m, 64);
+                if constexpr (CP == 2) a1 += __shfl_xor(a1, m, 64);
+            }
+            a0 += b0;
+            a1 += b1;
+            if (j == 0 && wbase + g * 8 + rr < Nb) {
+                float* o = classes_out + (off0 + r) * (long long)CP;
+                o[0] = a0;
+                if constexpr (CP == 2) o[1] = a1;
+            }
+            // rows past the end were clamped to Nb-1: a duplicate can never beat itself (same index)
+            if (a0 > bv0 || (a0 == bv0 && r < bi0)) { bv0 = a0; bi0 = r; }
+            if (CP == 2 && (a1 > bv1 || (a1 == bv1 && r < bi1))) { bv1 = a1; bi1 = r; }
+            a0 = 0.f;
+            a1 = 0.f;
+        };
+        int r = row_of(0);
+        const bf16_t* x = ptr_of(r);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) va[u].load(x + u * SEG);
+#pragma unroll 1
+        for (int g = 0; g + 1 < ng; ++g) {
+            const int rn = row_of(g + 1);
+            const bf16_t* xn = ptr_of(rn);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) vb[u].load(x + (4 + u) * SEG);
+            consume_lo(va);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) va[u].load(xn + u * SEG);
+            consume_hi(vb);
+            finish_rows(g, r);
+            r = rn;
+            x = xn;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vb[u].load(x + (4 + u) * SEG);
+        consume_lo(va);
+        consume_hi(vb);
+        finish_rows(ng - 1, r);
+    }
+    // best over the wave's 8 row lanes (lanes of one row agree), then over the 4 waves
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) {
+        const float ov0 = __shfl_xor(bv0, m, 64);
+        const int oi0 = __shfl_xor(bi0, m, 64);
+        if (ov0 > bv0 || (ov0 == bv0 && oi0 < bi0)) { bv0 = ov0; bi0 = oi0; }
+        if constexpr (CP == 2) {
+            const float ov1 = __shfl_xor(bv1, m, 64);
+            const int oi1 = __shfl_xor(bi1, m, 64);
+            if (ov1 > bv1 || (ov1 == bv1 && oi1 < bi1)) { bv1 = ov1; bi1 = oi1; }
+        }
+    }
+    if (lane == 0) { s_v[wave] = bv0; s_i[wave] = bi0; s_v[4 + wave] = bv1; s_i[4 + wave] = bi1; }
+    __syncthreads();
+    if (tid < CP) {
+        const int h = tid * 4;
+        float bv = s_v[h];
+        int bi = s_i[h];
+        for (int w = 1; w < 4; ++w)
+            if (s_v[h + w] > bv || (s_v[h + w] == bv && s_i[h + w] < bi)) { bv = s_v[h + w]; bi = s_i[h + w]; }
+        const long long slot = off0 / r0 + bag + tile;
+        part_val[slot * CP + tid] = bv;
+        part_idx[slot * CP + tid] = bi == 0x7fffffff ? 0x7fffffffffffffffLL : (long long)bi;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // k_qmax: one workgroup per (bag, class).  Finishes the arg-max over the bag's tile partials
 // (dsmil.py:52), then q_max = q(feats[idx]) (dsmil.py:53-54) on the VALU, 8 hidden units in
 // flight per wave so the dependent shuffle chains overlap.
@@ -1028,8 +1190,11 @@ inline long long finish_blocks(long long max_rows, int Kv) {
     return a > b ? (a > 1 ? a : 1) : b;
 }
 
-template <int VEC>
-__global__ __launch_bounds__(256) void k_finish(
+// UB: tiles in flight per thread group of the B walk.  UB = 2 is the LEAN form of the bf16 batch path (round 6): <= 80
+// registers, so that it runs beside a resident k_attend_bf16_res workgroup of another stream like k_logits_pipe does (its bags
+// have <= ~3 partials each; same summation order: a thread group walks its tiles in sequence whatever the unroll).
+template <int VEC, int UB = 8>
+__global__ __launch_bounds__(256, (UB == 8 ? 1 : 6)) void k_finish(
     const int64_t* __restrict__ offsets, const float* __restrict__ part_ml,
     const float* __restrict__ part_B, const float* __restrict__ fcc_w,
     float* __restrict__ A, float* __restrict__ B, float* __restrict__ pred_part, int Kv, int C, int BM,
@@ -1060,6 +1225,7 @@ __global__ __launch_bounds__(256) void k_finish(
     const long long rbeg = (long long)blockIdx.x * rpb;
     const long long rend = (rbeg + rpb < Nb) ? rbeg + rpb : Nb;
     const int kq = tid & 15, tg = tid >> 4;
+    constexpr int UA = UB == 8 ? 8 : 4;            // rows per thread in flight of the A pass
     if (!has_k && rbeg >= rend && !ml_out) {   // a block of the grid (sized for the LONGEST bag) with neither rows nor a k-run of this bag
         if (tid < C * C) pred_part[(((long long)bag * nblk + blockIdx.x) * C) * C + tid] = 0.f;
         return;
@@ -1087,15 +1253,15 @@ __global__ __launch_bounds__(256) void k_finish(
         // A = exp(s - m) / l for this block's rows
         // (eight rows per thread in flight: as `*p = f(*p)` in a loop every load waits for the store before it — a block's
         // share is at most FR = 2048 rows, i.e. ONE round of loads instead of up to eight dependent round trips)
-        for (long long r0 = rbeg + tid; r0 < rend; r0 += 256 * 8) {
-            float sv[8];
+        for (long long r0 = rbeg + tid; r0 < rend; r0 += 256 * UA) {
+            float sv[UA];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UA; ++u) {
                 const long long r = r0 + 256 * u;
                 sv[u] = A[(off0 + (r < rend ? r : rend - 1)) * (long long)C + c];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UA; ++u) {
                 const long long r = r0 + 256 * u;
                 if (r < rend) A[(off0 + r) * (long long)C + c] = expf(sv[u] - m) * il;
             }
@@ -1111,18 +1277,18 @@ __global__ __launch_bounds__(256) void k_finish(
         const float* pm = part_ml + (slot0 * C + c) * 2;
         // rounds of eight tiles, the last one padded with clamped re-reads that are not added (an unrolled run-time trip
         // count leaves a one-load-at-a-time remainder loop: 157 tiles / 16 groups = 2 rounds of 4 + 2 dependent round trips)
-        for (long long t0 = tg; t0 < ntile; t0 += 16 * 8) {
-            float wv[8];
-            f32x4 bv[8];
+        for (long long t0 = tg; t0 < ntile; t0 += 16 * UB) {
+            float wv[UB];
+            f32x4 bv[UB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 long long t = t0 + 16 * u;
                 t = t < ntile ? t : ntile - 1;
                 wv[u] = pm[t * C * 2];
                 bv[u] = load4<VEC>(pb + t * C * (long long)Kv, kb + kq * 4, Kv);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 if (t0 + 16 * u < ntile) {
                     const float w = expf(wv[u] - m);
 #pragma unroll
@@ -1293,6 +1459,33 @@ std::atomic<int> g_use_f2{2};
 // A CONSTANT (256 = the CUs of an unpartitioned MI355X), not the visible CU count: the run length `per` fixes which tiles
 // share a partial, i.e. the fp32 summation order, so the outputs must not depend on the box (partition mode, masked CUs).
 std::atomic<int> g_persistent_grid{256};
+// DSMIL_LOGITS_PIPE=0: the bf16 batch path keeps k_logits_stream (A/B of the co-resident logits pass, round 6)
+// dsmil_agg_logits_form(): bf16 batches of K = 512 rows, C <= 2 have a second set of kernels around the persistent attend
+// kernel — k_logits_pipe, a 4-wave k_qmax, the lean k_finish — that fit beside a resident k_attend_bf16_res workgroup of
+// ANOTHER stream's batch.  2 = always, 0 = never (k_logits_stream, 16-wave k_qmax, k_finish: what every other shape takes),
+// 1 (default) = when the library has recently been called on more than one stream: alone on the chip the co-resident
+// kernels are ~6 % slower per pass (a narrower q_max launch, fewer bytes in flight per wave), beside another stream's attend
+// kernel they make the pass 12-17 % faster.  Bit-identical outputs in every mode.
+std::atomic<int> g_logits_form{1};
+bool several_streams_recently(hipStream_t st) {   // the last four batch calls did not all come in on this stream
+    static std::atomic<uintptr_t> ring[4];
+    static std::atomic<unsigned> pos{0};
+    const uintptr_t me = (uintptr_t)st + 1;       // (0 = empty slot; the null stream is a stream)
+    bool several = false;
+    for (auto& r : ring) {
+        const uintptr_t v = r.load(std::memory_order_relaxed);
+        several |= (v != 0 && v != me);
+    }
+    ring[pos.fetch_add(1, std::memory_order_relaxed) & 3].store(me, std::memory_order_relaxed);
+    return several;
+}
+constexpr int PIPE_R0 = 512;   // rows per k_logits_pipe workgroup (workgroups enter a CU's one free slot one at a time)
+constexpr int PIPE_QT = 256;   // threads of the k_qmax launch in front of a co-resident pass
+bool coresident_wanted(hipStream_t st) {
+    const int form = g_logits_form.load(std::memory_order_relaxed);
+    const bool several = several_streams_recently(st);      // (always recorded, whatever the mode)
+    return form == 2 || (form == 1 && several);
+}
 int persistent_grid(int cap) {
     int g = g_persistent_grid.load(std::memory_order_relaxed);
     if (g <= 0) g = 256;
@@ -1520,6 +1713,10 @@ int dsmil_agg_batch_form(int mode) {
     if (mode >= 0 && mode <= 2) return g_use_f2.exchange(mode);
     return g_use_f2.load();
 }
+int dsmil_agg_logits_form(int mode) {
+    if (mode >= 0 && mode <= 2) return g_logits_form.exchange(mode);
+    return g_logits_form.load();
+}
 int dsmil_agg_persistent_grid(int n) {
     if (n >= 1 && n <= 1024) return g_persistent_grid.exchange(n);
     return g_persistent_grid.load();
@@ -1634,6 +1831,7 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     constexpr int logits_old = 0, no_hs = 0, no_qmi = 0, no_f2 = 0;
 #endif
     int seg_per = 0, seg_T = 0;   // k_attend_bf16_res: partials per (workgroup, bag), see k_finish
+    bool lean_tail = false;       // the bf16 batch path whose logits / q_max / combine kernels fit beside a resident attend workgroup
     int hs_bm = 0;                // k_attend_hs: rows per tile (the partial slots follow it)
     {
         // Tried and rejected here (round 1, numbers in DESIGN.md §3): (a) chunking the batch and running
@@ -1645,7 +1843,14 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         // rows per workgroup of the logits pass: 32 instead of R0 when there are few rows (the 32-row-tile regime of pick_nw)
         // and the streaming kernel runs
         const bool stream_ok = !classes_in && !logits_old && ((bf16 && (K % 8 == 0)) || (!bf16 && v4));
-        const int r0 = (NW == 1 && stream_ok && sh.phase != 2) ? 32 : R0;
+        // bf16 batches of K = 512 rows: the continuous-pipeline logits kernel that fits beside a resident k_attend_bf16_res
+        // workgroup of another stream (k_logits_pipe); its workgroups take more rows (they are dispatched one at a time into
+        // the one free slot of a CU) and its k_qmax launch is 4 waves wide so that it fits the same slot
+        const bool lpipe = bf16 && stream_ok && !logits_old && K == 512 && C <= 2 && NW == 4 && sh.phase == 0 &&
+                           !rowmap && max_rows < 0x7fffffffLL && coresident_wanted(st);
+        const int r0 = lpipe ? PIPE_R0 : (NW == 1 && stream_ok && sh.phase != 2) ? 32 : R0;
+        const int qmax_t = lpipe ? PIPE_QT : QMAX_T;
+        lean_tail = lpipe;
         // few rows, fp32: k_attend_hs (below); with the streaming logits kernel before it, the critical row's query runs
         // inside the attend launch (AttendArgs::qm_flag) instead of as k_qmax between the two
         bool use_hs = !bf16 && NW == 1 && v4 && !no_hs && mlp_mode() == 6;
@@ -1677,7 +1882,12 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
         else if (classes_in) hipLaunchKernelGGL((k_logits_argmax<1, true, float>), grid, dim3(256), 0, st, f32, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
         else if (bf16 && (K % 8 == 0) && !logits_old) {
             const size_t ldsw = (size_t)(C >= 2 ? 2 : 1) * (((K + 63) / 64 + 1) * 64) * sizeof(float);
-            if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, bf16_t>), grid_l, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, (int*)nullptr, TrainPrologueJob{}, (float*)nullptr, tile_pre_l, nb);
+            // batches of K = 512 rows: the continuous-pipeline form that fits beside a resident k_attend_bf16_res workgroup
+            if (lpipe) {
+                if (C == 2) hipLaunchKernelGGL(k_logits_pipe<2>, grid_l, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, b0, r0, tile_pre_l, nb);
+                else hipLaunchKernelGGL(k_logits_pipe<1>, grid_l, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, b0, r0, tile_pre_l, nb);
+            }
+            else if (C >= 2) hipLaunchKernelGGL((k_logits_stream<2, bf16_t>), grid_l, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, (int*)nullptr, TrainPrologueJob{}, (float*)nullptr, tile_pre_l, nb);
             else hipLaunchKernelGGL((k_logits_stream<1, bf16_t>), grid_l, dim3(256), ldsw, st, b16, offsets, p->fc_w, p->fc_b, classes_out, part_val, part_idx, K, C, b0, rowmap, r0, (int*)nullptr, TrainPrologueJob{}, (float*)nullptr, tile_pre_l, nb);
         }
         else if (bf16 && w4) hipLaunchKernelGGL((k_logits_argmax<4, false, bf16_t>), grid, dim3(256), 0, st, b16, offsets, p->fc_w, p->fc_b, classes_in, classes_out, part_val, part_idx, K, C, b0, rowmap);
@@ -1707,8 +1917,8 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
             if (r4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
             else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, sh.crit_rows, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 2, (float*)nullptr);
         }
-        else if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), gq, dim3(QMAX_T), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0);
-        else if (bf16) hipLaunchKernelGGL((k_qmax<1, bf16_t>), gq, dim3(QMAX_T), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0);
+        else if (bf16 && w4) hipLaunchKernelGGL((k_qmax<4, bf16_t>), gq, dim3(qmax_t), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0);
+        else if (bf16) hipLaunchKernelGGL((k_qmax<1, bf16_t>), gq, dim3(qmax_t), 0, st, b16, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0);
         else if (v4) hipLaunchKernelGGL((k_qmax<4, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0);
         else hipLaunchKernelGGL((k_qmax<1, float>), gq, dim3(QMAX_T), 0, st, f32, offsets, part_val, part_idx, p->q0_w, p->q0_b, p->q2_w, p->q2_b, qmax, idx, K, C, p->nonlinear, b0, 0, (float*)nullptr, rowmap, r0);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
@@ -1770,7 +1980,9 @@ static int agg_forward_impl(const void* feats, const void* vals, const int64_t* 
     // 4. combine (skipped under the stamp-trace knob, which leaves its stamps in A)
     if (!DSMIL_EXPT_ON(a, 64)) {
         dim3 grid((unsigned)L.nchunk_max, (unsigned)n_bags);
-        if (Kv % 4 == 0)
+        if (Kv % 4 == 0 && lean_tail && seg_per && !hs_bm)
+            hipLaunchKernelGGL((k_finish<4, 2>), grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, RS_BM, sh.ml_out, seg_per, seg_T, a.tile_pre);
+        else if (Kv % 4 == 0)
             hipLaunchKernelGGL(k_finish<4>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, hs_bm ? hs_bm : (seg_per ? RS_BM : BM), sh.ml_out, seg_per, seg_T, a.tile_pre);
         else
             hipLaunchKernelGGL(k_finish<1>, grid, dim3(256), 0, st, offsets, part_ml, part_B, p->fcc_w, A, B, pred_part, Kv, C, BM, sh.ml_out, 0, 0);

@@ -29,10 +29,18 @@
 //     workgroup's part of the bag, accumulators rescaled when it moves) and are written once per (workgroup, bag):
 //     partial slot = blockIdx.x + bag (a workgroup's bags and a bag's workgroups are both contiguous runs, so the
 //     staircase is collision-free).  k_finish merges <= ~3 partials per bag instead of 79.
-// LDS map: sX [2 buffers][8 chunks][64 rows][128 B] (16-B slot c of row r holds global slot c ^ f(r), f(r) = (r&6)|((r>>4)&1)
+// LDS map (153 600 B): sX [2 buffers][8 chunks][64 rows][128 B] (16-B slot c of row r holds global slot c ^ f(r), f(r) = (r&6)|((r>>4)&1)
 // on the row's index inside its 32-row group: conflict-free ds_read_b128 of the MFMA fragments and conflict-free
 // transposed reads), then 16 KiB sH: the hidden layer [64 rows][16 blocks x 16 B] (block b of row n at b ^ (n & 15));
-// then 4 KiB of softmax scratch (partial scores, bf16 planes of p, rescale factors).
+// then 4 KiB of softmax scratch (partial scores, bf16 planes of p, rescale factors), then 2 KiB of constants (b1 | b2 * 2 log2 e
+// | the current bag's critical queries [2][128]).
+// Register / LDS budget (round 6).  The kernel holds every CU for the whole launch, so whatever else a forward needs — the
+// logits pass, the critical query, the combine — waited for it, and three streams bought 5 %.  Its per-unit constants (biases,
+// the bag's critical queries: 64 long-lived VGPRs) now live in 2 KiB of LDS and are read where they are used; the K = 512
+// instantiations come to 240 VGPRs + 192 AGPRs (W1 128, W2 32, the value sum's accumulators 32) = 432 of a SIMD's 512
+// registers and 150 KiB of LDS: ONE 80-register wave of another kernel fits beside each wave, with 10 KiB of LDS.
+// k_logits_pipe, the 4-wave k_qmax launch and the lean k_finish (agg_fwd.hip, dsmil_agg_logits_form) are cut to that slot:
+// with two or more streams in flight the second read of the features (the next batch's logits) runs UNDER this kernel.
 // Barriers per tile (all four waves): S (tile landed for everybody; the previous tile's buffer and scratch are released),
 // Bh (hidden layer written), E1 (partial scores), E3 (planes + rescale factors).
 #pragma once
@@ -48,7 +56,8 @@ constexpr int RS_BUF_F4 = RS_MAXCH * RS_CH_F4;   // float4 per tile buffer (64 K
 constexpr int RS_THREADS = 256;             // one wave per SIMD
 constexpr int RS_MAX_WG = 1024;             // upper bound of the persistent grid (the workspace holds RS_MAX_WG + n_bags partial slots)
 constexpr int RS_SCRATCH_BYTES = 4096;      // softmax scratch: partial scores 2 KiB, bf16 planes of p 768 B, rescale factors
-constexpr int RS_LDS_BYTES = (2 * RS_BUF_F4 + RS_BM * 16) * 16 + RS_SCRATCH_BYTES;   // 2 x 64 KiB + 16 KiB + 4 KiB = 151 552
+constexpr int RS_CONST_BYTES = 2048;        // biases b1 | b2 * 2 log2(e) (1 KiB), the bag's critical queries [2 classes][128] (1 KiB)
+constexpr int RS_LDS_BYTES = (2 * RS_BUF_F4 + RS_BM * 16) * 16 + RS_SCRATCH_BYTES + RS_CONST_BYTES;   // 2 x 64 KiB + 16 KiB + 4 KiB + 2 KiB = 153 600
 
 typedef short rs_v4s __attribute__((ext_vector_type(4)));
 
@@ -105,6 +114,10 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
     float* sS = reinterpret_cast<float*>(sH + RS_BM * 16);   // own scratch (not aliased: no barrier between GEMM 2 and the scores): [4 waves][2 classes][64 rows] partial scores
     unsigned short* sPl = reinterpret_cast<unsigned short*>(sS + 4 * 2 * RS_BM);   // [3 planes][2 classes][64 rows] bf16 planes of p
     float* sF = reinterpret_cast<float*>(sPl + 3 * 2 * RS_BM);                     // [2] rescale factor of the running sums per class
+    // per-unit constants live in LDS, not in registers (round 6: 64 long-lived VGPRs of this wave went back to the SIMD's file,
+    // see the register budget in the header): read as broadcast ds_read_b128 where they are used
+    float* sBias = reinterpret_cast<float*>(reinterpret_cast<char*>(sS) + RS_SCRATCH_BYTES);   // [128] b1, [128] b2 * 2 log2(e)
+    float* sU = sBias + 2 * QD;                                                     // [2 classes][128] critical queries of the current bag
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -165,21 +178,16 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
         const f32x4* src_w = wpk + (long long)(q >> 2) * 1024 + ((q & 3) * 4 + wave) * 64 + lane;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(w1[q]) : "v"(src_w) : "memory");
     }
-    f32x4 b1[4], b2c[4];     // biases of units 32 wave + 8g + 4hi + e; b2c = b2 * 2 log2(e): folded into tanh's first fma
+    // biases of the 128 hidden / query units; b2c = b2 * 2 log2(e): folded into tanh's first fma
     constexpr float TANH_C = 2.8853900817779268f;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        b1[g] = *reinterpret_cast<const f32x4*>(a.q0_b + 32 * wave + 8 * g + 4 * hi);
-        b2c[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    if (tid < QD) sBias[tid] = a.q0_b[tid];
+    else sBias[tid] = NL ? a.q2_b[tid - QD] * TANH_C : 0.f;
     if constexpr (NL) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const f32x4* src_w = wpk + (long long)(NCH + (q >> 2)) * 1024 + ((q & 3) * 4 + wave) * 64 + lane;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(w2[q]) : "v"(src_w) : "memory");
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) b2c[g] = *reinterpret_cast<const f32x4*>(a.q2_b + 32 * wave + 8 * g + 4 * hi) * TANH_C;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the resident weights (and the first tile's pieces) have landed
     __builtin_amdgcn_sched_barrier(0);
@@ -213,21 +221,21 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
     reset_acc();
     // critical queries of the current bag, this wave's 32 units (reloaded when the bag changes: a vector load issued
     // while the next tile's pieces are in flight would wait for them in the in-order vmcnt queue)
-    f32x4 u0[4], u1[4];
     int ubag = -1;
+    const float* sBw = sBias + 32 * wave + 4 * hi;     // this lane's units 32 wave + 8 g + 4 hi + e: f32x4 at + 8 g
+    const float* sUw = sU + 32 * wave + 4 * hi;
 
     for (int t = 0;; ++t) {
         const int buf = t & 1;
         int in = item + 1;
         const bool has_next = rs_fetch(a, tiles_per_bag, item_end, in, nxt, cur.bag - a.bag0);
         if (has_next) set_rows(nxt);
-        if (cur.bag != ubag) {
-            const float* qm0 = a.qmax + ((long long)cur.bag * C) * QD + 32 * wave + 4 * hi;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u0[g] = *reinterpret_cast<const f32x4*>(qm0 + 8 * g);
-                u1[g] = TWO ? *reinterpret_cast<const f32x4*>(qm0 + QD + 8 * g) : u0[g];
-            }
+        const bool new_bag = cur.bag != ubag;                               // workgroup-uniform
+        float uval = 0.f;
+        if (new_bag) {
+            // thread (class, unit) fetches one critical-query value; it goes to LDS behind the S wait below (the scores of the
+            // previous tile were read in front of its barrier E1, the next reads come behind this tile's barriers S and Bh)
+            if (tid < QD * (TWO ? 2 : 1)) uval = a.qmax[((long long)cur.bag * C) * QD + tid];
             ubag = cur.bag;
             if constexpr (NL) {
                 // the bag's softmax reference (waves 0 / 1 = classes 0 / 1): every wave sums its class's 128 |q_max| alike
@@ -238,6 +246,8 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
         RS_STAMP();                                                         // 0: tile start
         // ---- the tile has landed: own pieces (everything this wave ever issued), then everybody's
         S3_WAIT_VM(0);
+        if (new_bag) sU[tid] = uval;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                       // S
         RS_STAMP();                                                         // 1
         // ---- GEMM 1 (transposed): H^T[j][n] += W1[j][k] X[n][k]; j = this wave's 32 units, n = all 64 rows.
@@ -278,6 +288,9 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
             // ---- bias, round to bf16, ReLU (on the packed pair: a negative bf16 is a negative int16), publish: block
             //      ((wave, sidx), hi) of row n holds the 8 hidden units that accumulator registers 8 sidx .. 8 sidx + 7 of
             //      this lane carry — a ready B fragment of GEMM 2
+            f32x4 b1[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b1[g] = *reinterpret_cast<const f32x4*>(sBw + 8 * g);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int n = 32 * r + l31;
@@ -328,6 +341,9 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
                 RS_NOP();
             }
         } else {
+            f32x4 b1[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b1[g] = *reinterpret_cast<const f32x4*>(sBw + 8 * g);
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -337,6 +353,13 @@ __global__ __launch_bounds__(RS_THREADS, 1) void k_attend_bf16_res(AttendArgs a,
         // ---- tanh; partial scores over this wave's 32 query units (dsmil.py:55-56).  Written stage by stage over 16 values
         //      so that the exp / rcp chains of different values overlap.
         {
+            f32x4 b2c[4], u0[4], u1[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (NL) b2c[g] = *reinterpret_cast<const f32x4*>(sBw + QD + 8 * g);
+                u0[g] = *reinterpret_cast<const f32x4*>(sUw + 8 * g);
+                if constexpr (TWO) u1[g] = *reinterpret_cast<const f32x4*>(sUw + QD + 8 * g);
+            }
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 float q[16];

@@ -103,7 +103,9 @@ class StreamPool:
     HBM speed with idle matrix cores, `k_query_attend_split` is MFMA-bound at half the HBM rate — and a batch of bags
     cannot overlap them (the critical instance must be known before any score).  Two INDEPENDENT batches can: dealt to
     different streams, the logits pass of one runs under the attend kernel of the other (measured on 64 x 10 000 x 512
-    bags: 73.4 k bags/s on one stream, 78.2 k on two, 80.0 k on three).  Each stream has its own workspace
+    bags: 73.4 k bags/s on one stream, 78.2 k on two, 80.0 k on three; round 6, bf16 bags: the persistent attend kernel
+    leaves one 80-register slot per SIMD and the logits / q_max / combine kernels are cut to it — 190 k bags/s on one
+    stream, 250-260 k on two or three, `dsmil_agg_logits_form`).  Each stream has its own workspace
     (`_workspace`); outputs are allocated on the stream that produces them; `join()` makes the caller's stream wait
     for everything submitted.
 

@@ -156,6 +156,18 @@ int dsmil_agg_batch_form(int mode);
  * (process-wide) and returns the previous value; any other n only queries. */
 int dsmil_agg_persistent_grid(int n);
 
+/* (ABI 5, round 6) The kernels around the persistent attend kernel of a bf16 BATCH (K = 512, C <= 2; dsmil.py:50-54 — the
+ * instance logits, the critical instance and its query — and the combine of dsmil.py:57-61).  The co-resident forms
+ * (k_logits_pipe, a 4-wave k_qmax, the lean k_finish) hold <= 80 registers per lane and a few KiB of LDS, so one wave of them
+ * fits on every SIMD beside the resident k_attend_bf16_res workgroup of ANOTHER stream's batch (432 of a SIMD's 512
+ * registers): with two or more streams in flight the second read of the features runs under the MFMA kernel of the batch in
+ * front instead of behind it (+12-17 % bags/s); alone on the chip they are ~6 % slower than the plain forms.
+ *   1 (default)  co-resident forms when the last few batch calls arrived on more than one stream, else the plain forms;
+ *   2            always the co-resident forms;      0   never (k_logits_stream, 16-wave k_qmax, k_finish).
+ * Outputs are bit-identical in every mode (tests/test_agg_bf16_gpu.py).  Process-wide; returns the previous mode; any other
+ * `mode` only queries. */
+int dsmil_agg_logits_form(int mode);
+
 /* Compute units of the current device as the library sees them (256 on MI355X); <= 0 without a device.  Diagnostic: recorded
  * by bench.py and the soak so that a result can be tied to the box it ran on. */
 int dsmil_device_cus(void);

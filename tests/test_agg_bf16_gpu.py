@@ -148,3 +148,48 @@ def test_bf16_resident_tile_kernel(K, C, nonlinear, lengths):
         again = ops.agg_forward(x, lengths, w, nonlinear=nonlinear)
         for a_, b_ in zip(again, out):
             assert torch.equal(a_, b_)
+    # round 6: the co-resident logits / q_max / combine kernels (dsmil_agg_logits_form 2 = always; they exist for K = 512,
+    # C <= 2; the default takes them when calls arrive on several streams) against the kernels every other shape takes
+    # (form 0): same arithmetic in the same order, bit for bit
+    from dsmil_wsi_amd import _native
+    L = _native.lib()
+    prev = L.dsmil_agg_logits_form(2)
+    try:
+        forced = ops.agg_forward(x, lengths, w, nonlinear=nonlinear)
+        L.dsmil_agg_logits_form(0)
+        plain = ops.agg_forward(x, lengths, w, nonlinear=nonlinear)
+        torch.cuda.synchronize()
+    finally:
+        L.dsmil_agg_logits_form(prev)
+    assert prev == 1
+    for a_, b_, c_ in zip(forced, plain, out):
+        assert torch.equal(a_, c_) and torch.equal(b_, c_)
+
+
+def test_coresident_passes_on_three_streams_equal_the_serial_result():
+    """Round 6: with several streams in flight the logits / q_max / combine kernels of one batch run on the SAME compute
+    units as the persistent attend kernel of another (registers and LDS are budgeted for it, agg_res.h).  Sharing a CU
+    must not change a bit: three different batches dealt to a three-stream pool, 12 rounds, against their one-stream
+    results on the plain kernels."""
+    import dsmil_wsi_amd.ops as ops
+    from dsmil_wsi_amd import _native
+    L = _native.lib()
+    w = {k: torch.from_numpy(v).cuda() for k, v in load_weights("tcga").items()}
+    lengths = [2400] * 32
+    xs = [torch.from_numpy(make_bag(7100 + i, sum(lengths), 512)).cuda().to(torch.bfloat16) for i in range(3)]
+    prev = L.dsmil_agg_logits_form(0)
+    try:
+        want = [[t.clone() for t in ops.agg_forward(x, lengths, w)] for x in xs]
+        torch.cuda.synchronize()
+    finally:
+        L.dsmil_agg_logits_form(prev)
+    pool = ops.StreamPool(3)
+    got = []
+    for r in range(12):
+        x = xs[r % 3]
+        got.append(pool.run(lambda x=x: [t.clone() for t in ops.agg_forward(x, lengths, w)]))
+    pool.join()
+    torch.cuda.synchronize()
+    for r, g in enumerate(got):
+        for a_, b_ in zip(g, want[r % 3]):
+            assert torch.equal(a_, b_)
