@@ -601,7 +601,18 @@ def _packed_resnet_weights(convs, depth=18, precision=0):
         ent[3].wait(dev, ent[0])
         return ent[0]
     L = _native.lib()
-    buf = torch.empty(L.dsmil_resnet_packed_bytes(depth) // 4, dtype=torch.float32, device=dev)
+    nbytes = L.dsmil_resnet_packed_bytes(depth)
+    if int(precision) == 2:     # the bf16-activation trunk: experiment builds only (csrc/experiments/resnet_b16.h)
+        try:
+            fn = L.dsmil_resnet_packed_bytes_ex
+        except AttributeError:
+            raise ValueError("precision 'bf16' exists in experiment builds of the library only "
+                             "(build.py --variant expt -DDSMIL_EXPERIMENTS, DSMIL_NATIVE_LIB=libdsmil_hip_expt.so)") from None
+        fn.restype, fn.argtypes = ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]
+        nbytes = fn(depth, 2)
+        if nbytes == 0:
+            raise ValueError(f"precision 'bf16' is not implemented for a depth-{depth} trunk")
+    buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
     keep = [_f32c(w.detach(), "conv weight") for w in convs]
     # The conv operands are cut into fp16 planes of the 2^8-scaled weights (csrc/resnet_fwd.hip, EMB_WSHIFT); a Winograd
     # weight transform grows a 3x3 kernel by at most 2.25x, so |w| must stay below 65504 / (256 * 2.25) = 113.7 or a plane
@@ -655,12 +666,16 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None, precision=
     ResNet-50, 104 for ResNet-101).
     ``bn_norms``: the eval-mode BatchNorm2d modules of a `--norm_layer batch` trunk, in the same order;
     None = InstanceNorm.  One native launch sequence (dsmil_resnet_forward_ex).
-    ``precision``: "fp32" (default: fp32-class, the parity path) or "half" (OPT-IN: every conv operand rounded to one fp16
-    plane, f32 accumulation, fp32 activations / norms — ~2e-3 feature error, not the 1e-4 bar; include/dsmil_hip.h).
+    ``precision``: "fp32" (default: fp32-class, the parity path), "half" (OPT-IN: every conv operand rounded to one fp16
+    plane, f32 accumulation, fp32 activations / norms — ~2e-3 feature error, not the 1e-4 bar; include/dsmil_hip.h) or
+    "bf16" (EXPERIMENT builds of the library only, round 6: bf16 ACTIVATIONS behind the stem, one bf16 MFMA product per MAC,
+    f32 accumulation and InstanceNorm statistics — measured slower than the fp32 trunk and not shipped).
     Returns (feats [B,512 | 2048], classes [B,C] or None)."""
-    if precision not in ("fp32", "half"):
-        raise ValueError("precision must be 'fp32' or 'half'")
-    prec = 1 if precision == "half" else 0
+    if precision not in ("fp32", "half", "bf16"):
+        raise ValueError("precision must be 'fp32', 'half' or 'bf16'")
+    prec = {"fp32": 0, "half": 1, "bf16": 2}[precision]
+    if prec == 2 and bn_norms is not None:
+        raise ValueError("precision 'bf16' is implemented for InstanceNorm trunks")
     u8 = x.dtype == torch.uint8
     if u8:
         if not x.is_cuda:
