@@ -4,7 +4,9 @@ row and runs first).
 
 * the in-launch hand-off of the critical query (k_attend_hs) under load with a NaN-poisoned workspace, forward and train step,
   bit for bit against the separate-launch path;
-* tests/soak_f3.py: random ragged, six-decade-scaled batches through k_attend_f3 against the fp64 oracle.
+* tests/soak_f3.py: random ragged, six-decade-scaled batches through k_attend_f3 against the fp64 oracle;
+* the co-resident bf16 pass (k_logits_pipe / 4-wave k_qmax / lean k_finish beside another stream's k_attend_bf16_res) on two and
+  three streams over ragged batches, 120 + 120 passes, bit for bit against the one-stream result of the plain kernels.
 """
 import os
 import subprocess
@@ -140,3 +142,37 @@ def test_batch_form_f3_random_ragged_batches_soak():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "soak_f3.py"), "6"], capture_output=True, text=True, timeout=900)
     print(r.stdout[-3000:])
     assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_coresident_bf16_pass_soak_on_two_and_three_streams():
+    """Round 6: the kernels of one bf16 batch share compute units with the persistent attend kernel of another (registers and
+    LDS are budgeted for it: csrc/agg_res.h, dsmil_agg_logits_form).  Sharing a CU must never change a bit: three RAGGED
+    batches (short bags, one long bag, partial last tiles) dealt to two, then three streams, 120 passes each, every output of
+    every pass compared with the one-stream result of the plain kernels (form 0)."""
+    import dsmil_wsi_amd.ops as ops
+    from dsmil_wsi_amd import _native
+    L = _native.lib()
+    w = {k: torch.from_numpy(v).cuda() for k, v in load_weights("tcga").items()}
+    rng = np.random.default_rng(606)
+    batches = []
+    for i in range(3):
+        lengths = [int(n) for n in rng.integers(900, 4000, size=28)] + [30000 + 517 * i, 1, 129]
+        x = torch.from_numpy(make_bag(8100 + i, sum(lengths), 512)).cuda().to(torch.bfloat16)
+        batches.append((x, lengths))
+    prev = L.dsmil_agg_logits_form(0)
+    try:
+        want = [[t.clone() for t in ops.agg_forward(x, lengths, w)] for x, lengths in batches]
+        torch.cuda.synchronize()
+    finally:
+        L.dsmil_agg_logits_form(prev)
+    for streams in (2, 3):
+        pool = ops.StreamPool(streams)
+        got = []
+        for r in range(120):
+            x, lengths = batches[r % 3]
+            got.append(pool.run(lambda x=x, lengths=lengths: [t.clone() for t in ops.agg_forward(x, lengths, w)]))
+        pool.join()
+        torch.cuda.synchronize()
+        for r, g in enumerate(got):
+            for k, (a_, b_) in enumerate(zip(g, want[r % 3])):
+                assert torch.equal(a_, b_), (streams, r, k)
