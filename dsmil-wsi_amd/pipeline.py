@@ -110,8 +110,9 @@ class _ChunkDecoder:
         k = self.k
         self.k ^= 1
         with torch.cuda.stream(self.ds):                  # (the inputs are host bytes: nothing of the caller's stream to wait for)
-            if self.free_ev[k] is not None:
-                self.ds.wait_event(self.free_ev[k])       # the consumer's work on the chunk that used this buffer
+            if self.free_ev[k] is not None:               # the consumer's work on the chunk that used this buffer (one event,
+                for e in (self.free_ev[k] if isinstance(self.free_ev[k], list) else [self.free_ev[k]]):   # or one per stream)
+                    self.ds.wait_event(e)
             imgs = ops.jpeg_decode(blobs, self.dev, size=self.size, stats=self.stats, out=self.bufs[k])
             if self.bufs[k] is None and imgs.shape[0] == self.decode_batch:
                 self.bufs[k] = imgs                       # (a short last chunk is not worth keeping)
@@ -149,22 +150,71 @@ def embed_jpeg_blobs(i_classifier, blobs, batch_size=256, decode_batch=2048, str
     F_, C_ = i_classifier.fc.in_features, i_classifier.fc.out_features
     if n == 0:
         return torch.zeros((0, F_), device=dev), torch.zeros((0, C_), device=dev)
-    dec = _ChunkDecoder(dev, decode_batch, stats)
     chunks = [blobs[i:i + decode_batch] for i in range(0, n, decode_batch)]
+    return _embed_jpeg_chunks(i_classifier, chunks, batch_size, decode_batch, streams, dev, stats)
+
+
+def _embed_jpeg_chunks(i_classifier, chunks, batch_size, decode_batch, streams, dev, stats=None):
+    """embed_jpeg_blobs over a sequence of chunks (lists of bytes-likes; entries may be concurrent.futures-style lazily read:
+    anything with .result() is resolved when its chunk is decoded)."""
+    def resolve(chunk):
+        return [b.result() if hasattr(b, "result") else b for b in chunk]
+
+    dec = _ChunkDecoder(dev, decode_batch, stats)
     fl, cl = [], []
-    cur = dec.decode(chunks[0])
+    cur = dec.decode(resolve(chunks[0]))
+    pool = stream_pool(dev, streams) if streams > 1 else None
+    if pool is None:
+        for ci in range(len(chunks)):
+            imgs = dec.acquire(cur)
+            f, c = embed_tiles(i_classifier, imgs, batch_size, streams=1, device=dev)
+            dec.release(cur)
+            if ci + 1 < len(chunks):
+                cur = dec.decode(resolve(chunks[ci + 1]))
+            fl.append(f)
+            cl.append(c)
+        dec.finish()
+        return torch.cat(fl), torch.cat(cl)
+    # The batches of ALL chunks go round-robin over the pool's streams, and a pool stream waits for the DECODE of the chunk it
+    # is about to read — not for the caller's stream: embed_tiles per chunk joined the pool into the caller's stream and the next
+    # chunk's first batches waited for that join, i.e. the pipeline drained at every chunk boundary (8 batches on 3 streams:
+    # the last round of a chunk is two batches wide): 53 k -> 61 k patches/s for a 10 000-tile slide (bench.py `slide_jpeg`).
+    caller = torch.cuda.current_stream(dev)
+    for s_ in pool.streams:
+        s_.wait_stream(caller)                            # (weights / earlier work of the caller's stream)
+    bi = 0
     for ci in range(len(chunks)):
-        imgs = dec.acquire(cur)
-        f, c = embed_tiles(i_classifier, imgs, batch_size, streams=streams, device=dev)   # enqueued; joined into this stream
-        dec.release(cur)
+        imgs, ev, k = cur
+        used = set()
+        for lo in range(0, imgs.shape[0], batch_size):
+            s_ = pool.streams[bi % len(pool.streams)]
+            bi += 1
+            if id(s_) not in used:
+                s_.wait_event(ev)                         # this chunk's decode
+                used.add(id(s_))
+            with torch.cuda.stream(s_):
+                f, c = i_classifier(imgs[lo:lo + batch_size])
+            fl.append(f)
+            cl.append(c)
+        done = []
+        for s_ in pool.streams:                           # the staging buffer is free when every stream is past this chunk
+            if id(s_) in used:
+                imgs.record_stream(s_)
+                e = torch.cuda.Event()
+                e.record(s_)
+                done.append(e)
+        dec.free_ev[k] = done
         if ci + 1 < len(chunks):
-            cur = dec.decode(chunks[ci + 1])   # the host waits here for the decode's status while the GPU embeds chunk ci
-        fl.append(f)
-        cl.append(c)
-    dec.finish()
+            cur = dec.decode(resolve(chunks[ci + 1]))   # the host waits here for the decode's status while the GPU embeds chunk ci
+    for s_ in pool.streams:
+        caller.wait_stream(s_)
+    caller.wait_stream(dec.ds)
+    for t in fl + cl:                                     # produced on a pool stream, consumed (and freed) on the caller's
+        t.record_stream(caller)
     return torch.cat(fl), torch.cat(cl)
 
 
+EMBED_STREAMS = [3]     # HIP streams of embed_files' device-decode path (batches dealt round-robin, ops.StreamPool)
 DECODE_BATCH = [2048]   # files per device-decode chunk of embed_files(gpu_decode=True) (tests lower it to walk the double buffer)
 
 
@@ -249,10 +299,26 @@ def embed_files(i_classifier, files, batch_size=128, num_workers=4, device=None,
             ev.synchronize()          # recorded one batch ago: the next batch's decode and H2D ran meanwhile
         embed(patches, torch.nonzero(keep_h)[:, 0].to(device, non_blocking=True))
 
-    if hi > lo:
+    if gpu_decode is None:
+        gpu_decode = GPU_DECODE[0]
+    if hi > lo and gpu_decode and u8 and on_gpu and not filt:
+        # Round 6: the device-decode path deals its batches to the stream pool (the loop below embeds batch by batch on ONE
+        # stream: ~59 k patches/s at bs 256 against 65 k on three) — the files of a chunk are read by a thread pool while the
+        # chunk in front is decoded and embedded; same bytes, same batches, same features
+        from concurrent.futures import ThreadPoolExecutor
+
+        def read(path):
+            with open(path, "rb") as f:
+                return f.read()
+
+        mine = list(files[lo:hi])
+        with ThreadPoolExecutor(max_workers=max(1, int(num_workers))) as tp:
+            chunks = [[tp.submit(read, f_) for f_ in mine[i:i + DECODE_BATCH[0]]] for i in range(0, len(mine), DECODE_BATCH[0])]
+            f_, c_ = _embed_jpeg_chunks(i_classifier, chunks, batch_size, DECODE_BATCH[0], EMBED_STREAMS[0], torch.device(device))
+        feats_l.append(f_)
+        cls_l.append(c_)
+    elif hi > lo:
         pending = None
-        if gpu_decode is None:
-            gpu_decode = GPU_DECODE[0]
         loader = (gpu_decoded_batches(files[lo:hi], batch_size, device, io_threads=max(1, num_workers), decode_batch=DECODE_BATCH[0])
                   if gpu_decode and u8 and on_gpu
                   else patch_loader(files[lo:hi], batch_size, num_workers, False, uint8=u8 or filt))
@@ -662,6 +728,8 @@ def embed_tiles(i_classifier, tiles, batch_size=256, streams=3, device=None):
             x = x.to(dev, non_blocking=True)    # allocated and filled on the stream that consumes it
         return i_classifier(x)
 
+    # (round 6, measured and not kept: the copies on their OWN stream, 3 / 6 / 12 batches ahead of the forwards — 165-170 ms
+    # per 10 000-tile slide against 159 ms with each copy on the stream that consumes it)
     for lo in range(0, tiles.shape[0], batch_size):
         f, c = pool.run(one, lo) if pool is not None else one(lo)
         fl.append(f)

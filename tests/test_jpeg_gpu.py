@@ -123,12 +123,12 @@ def test_compute_feats_with_device_decode_gives_the_same_csv(tmp_path, monkeypat
         for f in ref:
             os.remove(f)
         seen = {}
-        real = pl.gpu_decoded_batches
+        real = pl._embed_jpeg_chunks      # (round 6: the device-decode path of embed_files deals its batches to the stream pool)
 
         def spy(*a, **k):
             seen["calls"] = seen.get("calls", 0) + 1
             return real(*a, **k)
-        monkeypatch.setattr(pl, "gpu_decoded_batches", spy)
+        monkeypatch.setattr(pl, "_embed_jpeg_chunks", spy)
         cf.main(["--dataset", "toy", "--weights", "r0", "--batch_size", "4", "--num_workers", "2", "--save_npy", "--gpu_decode"])
         assert seen.get("calls", 0) == 2 and pl.GPU_DECODE[0] is False      # one call per bag; the flag is reset behind main()
         got = {f: np.load(f) for f in sorted(glob.glob("datasets/toy/0_x/*.npy"))}
