@@ -614,6 +614,55 @@ def embedder_leg(cx, precision="fp32"):
                                                    % (ACT_BYTES_PER_PATCH / 1e6, t_exec_patch * 1e6)}}
 
 
+def embedder_bf16_leg(cx):
+    """precision = "bf16" (round 6): the OPT-IN bf16-ACTIVATION trunk (dsmil_resnet_forward_ex precision 2, csrc/resnet_b16.h):
+    bf16 activations behind the stem, one bf16 MFMA product per MAC, f32 accumulation and InstanceNorm statistics — BASELINE.md's
+    "1 patch, bf16 MFMA / f32 accumulate" row.  Its own leg and tolerance, never the headline embedder."""
+    torch, args, dev, world = cx.torch, cx.args, cx.dev, cx.world
+    ic = _build_iclassifier(cx)
+    ic.embed_precision = "bf16"
+    Bp = args.patches
+    g = torch.Generator(device=dev).manual_seed(7 + cx.rank)
+    xs = [torch.rand((Bp, 3, 224, 224), generator=g, device=dev, dtype=torch.float32) for _ in range(max(1, args.streams))]
+    keep = []
+    turn = [0]
+
+    def one():
+        turn[0] += 1
+        with torch.no_grad():
+            feats, c = ic(xs[turn[0] % len(xs)])
+        return feats
+
+    def step():
+        keep[:] = [cx.run(one)]
+
+    dt, inner, _, launches = cx.timed(step, args.steps, args.warmup, args.min_seconds, channel=1)
+    _, conv_alone_ms = cx.kernel_alone(one, 1, passes=40)
+    assert torch.isfinite(keep[0]).all()
+    passes = args.steps * inner
+    value = world * Bp * passes / dt
+    conv_flops = (FLOPS_PER_PATCH - STEM_FLOPS_PER_PATCH) * Bp          # direct-form FLOPs of the 19 convs behind the stem, per forward
+    frac = conv_flops / (PEAK_BF16_MFMA_TFLOPS * 1e12) / (conv_alone_ms * 1e-3) if conv_alone_ms > 0 else None
+    return {"metric": "patches/sec embedded (ResNet-18-IN, 224x224, bs=%d), OPT-IN bf16 activations" % Bp,
+            "value": round(value, 1), "unit": "patches/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_pass": round(dt / passes * 1e3, 3),
+            "dtype": "bf16 activations and conv operands behind the stem (one bf16 MFMA product per MAC), f32 accumulate, f32 InstanceNorm statistics",
+            "tolerance": "feature error <= 5e-2 max / 8e-3 mean abs against the fp64 restatement on features of O(1) (measured 2e-2 / "
+                         "3e-3; tests/test_resnet_gpu.py) — NOT the 1e-4 parity bar of the `embedder` leg",
+            "config": {"workload": f"IClassifier(ResNet-18 InstanceNorm, fc=Identity)+Linear(512,2), {Bp} synthetic 224x224 patches "
+                                   f"per GPU per pass, kaiming(seed 11) weights", "passes_per_step": inner,
+                       "timed_region_s": round(dt, 3), "streams": args.streams, "distinct_batches": len(xs)},
+            "roofline": {"kernel": "the 19 conv launches behind the stem: 13 x k_conv_b16v2 (3x3 / 1, flat padded positions) + 6 x "
+                                   "k_conv_b16g (3x3 / 2, 1x1 / 2), bf16 MFMA, one product", "bound": "mfma",
+                         "achieved": round(conv_flops / (conv_alone_ms * 1e-3) / 1e12, 2) if conv_alone_ms > 0 else None,
+                         "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(frac, 4) if frac else None,
+                         "frac_is": "direct-form FLOPs of the 19 convs / bf16 MFMA peak / their HIP-event time with one forward in flight "
+                                    "(the kernels also compute the zero border of the padded layout: 7 % of the positions at 56 x 56, 65 % at 7 x 7)",
+                         "traffic": None, "conv_ms_per_forward": round(conv_alone_ms, 3), "launches": launches,
+                         # BASELINE.md's row for this precision: 3.627 GFLOP / 2.5 PFLOP/s = 689 252 patches/s
+                         "whole_path_frac_of_roofline": round(value / world / (PEAK_BF16_MFMA_TFLOPS * 1e12 / FLOPS_PER_PATCH), 4)}}
+
+
 def cpu_baseline_embedder(budget_s):
     """oracle/resnet_oracle.py (the torch-CPU restatement of the torchvision backbone, fp32) on the host cores, bounded."""
     import torch
@@ -1001,7 +1050,7 @@ def _summary(line):
             e["value_one_stream"] = obj["config"]["value_one_stream"]
         out[name] = e
     put("aggregator_f32", line if line.get("unit") == "bags/s" else None)
-    for k in ("aggregator_bf16", "embedder", "embedder_half", "train_c1", "train_c2", "slide", "slide_h2d", "slide_100k", "decode", "slide_jpeg", "e2e"):
+    for k in ("aggregator_bf16", "embedder", "embedder_half", "embedder_bf16", "train_c1", "train_c2", "slide", "slide_h2d", "slide_100k", "decode", "slide_jpeg", "e2e"):
         put(k, line.get(k))
     return out
 
@@ -1016,7 +1065,7 @@ def main():
     ap.add_argument("--feats", type=int, default=512)
     ap.add_argument("--patches", type=int, default=256, help="patches per rank per embedder pass (batch size)")
     ap.add_argument("--workload", default="all",
-                    help="comma list of aggregator, aggregator_bf16, embedder, embedder_half, train, slide, slide_h2d, slide100k, decode, slide_jpeg, e2e; or all / both (= aggregator,embedder)")
+                    help="comma list of aggregator, aggregator_bf16, embedder, embedder_half, embedder_bf16, train, slide, slide_h2d, slide100k, decode, slide_jpeg, e2e; or all / both (= aggregator,embedder)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on each timed region")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams independent passes are dealt to (ops.StreamPool); 1 = one pass in flight")
@@ -1037,7 +1086,7 @@ def main():
                     help="skip the single-bag latency probe (profiling runs: keeps per-kernel averages clean)")
     args = ap.parse_args()
     maybe_self_launch(args)
-    wl = {"all": "aggregator,aggregator_bf16,embedder,embedder_half,train,slide,slide_h2d,slide100k,decode,slide_jpeg,e2e", "both": "aggregator,embedder"}.get(args.workload, args.workload)
+    wl = {"all": "aggregator,aggregator_bf16,embedder,embedder_half,embedder_bf16,train,slide,slide_h2d,slide100k,decode,slide_jpeg,e2e", "both": "aggregator,embedder"}.get(args.workload, args.workload)
     wl = [w for w in wl.split(",") if w]
     cx = Ctx(args)
     line = {}
@@ -1053,6 +1102,8 @@ def main():
         subs["embedder"] = embedder_leg(cx)
     if "embedder_half" in wl:   # OPT-IN reduced precision (BASELINE.md §2, row "bf16 MFMA / f32 accumulate"): its own leg and tolerance
         subs["embedder_half"] = embedder_leg(cx, precision="half")
+    if "embedder_bf16" in wl:   # OPT-IN bf16-activation trunk (round 6): its own leg and tolerance
+        subs["embedder_bf16"] = embedder_bf16_leg(cx)
     if "slide" in wl:
         subs["slide"] = slide_leg(cx, args.slide_patches)
     if "slide_h2d" in wl:

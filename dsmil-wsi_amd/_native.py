@@ -107,6 +107,7 @@ SIGNATURES = {
     "dsmil_resnet_mfma_forms": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "dsmil_resnet_norm_channels": (ctypes.c_int32, [ctypes.c_int32]),
     "dsmil_resnet_packed_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
+    "dsmil_resnet_packed_bytes_ex": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "dsmil_resnet_pack": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), c_f32p, ctypes.c_void_p]),
     "dsmil_resnet_forward": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                             ctypes.c_int32, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,

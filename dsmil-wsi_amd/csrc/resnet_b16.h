@@ -1,0 +1,568 @@
+// resnet_b16.h — the OPT-IN bf16-activation trunk of the patch embedder (dsmil_resnet_forward_ex, precision = 2;
+// compute_feats.py:146-170 / dsmil.py:14-25 behind the stem).  Included by resnet_fwd.hip.
+//
+// What it is for: BASELINE.md's "1 patch, bf16 MFMA / f32 accumulate" row.  The fp32-class trunk (precision 0) keeps fp32
+// activations in HBM, cuts every operand into two fp16 planes and forms three plane products per MAC; its opt-in one-plane
+// form (precision 1) drops two of the three products but keeps the fp32 activations, the cuts and the Winograd transforms —
+// 1.2x.  This trunk stores the ACTIVATIONS in bf16 and multiplies them as they are: one v_mfma_f32_32x32x16_bf16 per
+// 32 x 32 x 16 block, f32 accumulation, f32 InstanceNorm statistics: 1.55-1.6x the fp32-class trunk.  It is NOT the 1e-4 parity
+// path: features agree with the fp32 trunk to bf16 rounding (max 2e-2, mean 3e-3 of features of magnitude ~1;
+// tests/test_resnet_gpu.py states the bar).  BasicBlock trunks (ResNet-18 / 34) with InstanceNorm; everything else returns
+// DSMIL_E_UNSUPPORTED.
+//
+// Data layout: every activation is bf16 NHWC with a ONE-PIXEL ZERO BORDER, [B][H + 2][W + 2][C], and a convolution works on
+// the FLATTENED padded positions q = (n (H+2) + y) (W+2) + x:
+//   * a 3 x 3 / stride-1 conv has the same padded grid on both sides, so tap (dy, dx) of output position q is input position
+//     q + dy (W+2) + dx — no bounds logic, no im2col: a workgroup's BM output positions need the BM + 2 consecutive input
+//     positions [q0 - 1, q0 + BM + 1) of three input rows (dy = -1, 0, +1), each staged ONCE into LDS as a plain clamped copy
+//     and used for the three dx taps by shifting the fragment address by one position;
+//   * border positions are computed like any other and written as zeros, which is what keeps the border zero for the
+//     next conv (the waste is (H+2)(W+2) / (H W): 7 % at 56 x 56, 65 % at 7 x 7);
+//   * strided convs (3 x 3 / 2, 1 x 1 / 2) stage one tap at a time through per-position offsets.
+// Kernels: k_b16_pad (fp32 NHWC stem output -> padded bf16); k_conv_b16v2 / k_conv_b16g (implicit GEMM, M = positions, N =
+// output channels: BOTH operands go through LDS — activations with a 16-B pad per position, weights in MFMA fragment order,
+// both conflict-free ds_read_b128 —, staged one stage ahead by plain loads whose only wait is the ds_write at the top of the
+// next stage, so the in-order vmcnt queue never couples a fragment read to a staging load; 128 x 64 wave tiles (6 fragment
+// reads per 8 MFMAs); ONE LDS buffer and TWO workgroups per CU: one multiplies while the other stores its next stage and
+// sits at its barriers); k_stats_b16 / k_apply_b16 (InstanceNorm in two flat passes: per-(image, chunk, channel) partial sums
+// in a fixed order — no atomics, bit-reproducible —, then normalise + residual + ReLU in place); k_pool_b16 (last block:
+// normalise + residual + ReLU + average pool -> fp32 feature row).
+// History of the conv kernel (bs 256, per 3 x 3 / 1 conv at 128+ channels; DESIGN.md §4 "Round 6"): 64 x 64 wave tiles with the
+// weight fragments loaded per lane from L2 inside the loop: 306 us (the fragment loads shared the vmcnt queue with the
+// staging loads: every stage began with an HBM round trip); both operands through LDS, 128 x 64 wave tiles, one workgroup per
+// CU with two LDS buffers: 142 us; one buffer, two workgroups per CU: 96 us.  What holds it now: layer 1 (64 channels) is
+// memory-bound (110 MB in, 110 MB out per conv: 45 us of 112), layer 4 computes 65 % border positions, and two thirds of a
+// stage are not MFMA time.
+#pragma once
+
+namespace b16 {
+
+
+struct ConvGeo {
+    int B, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride;
+    int cin_c;                     // channels per staged chunk (32: stride-1 form, 64: strided form)
+    long long M;                   // B (Ho+2) (Wo+2) output positions
+    long long Min;                 // B (Hi+2) (Wi+2) input positions
+};
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned f2bf(float f) {           // round to nearest even (no NaN handling: the inputs are finite)
+    const unsigned u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+// fp32 NHWC [B][H][W][C] (the stem's normalised, pooled output) -> bf16 padded [B][H+2][W+2][C]
+__global__ __launch_bounds__(256) void k_b16_pad(const float* __restrict__ x, unsigned short* __restrict__ out, int B, int H, int W, int C) {
+    const int oc = C >> 3;
+    const long long total = (long long)B * (H + 2) * (W + 2) * oc;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int o = (int)(i % oc);
+        const long long q = i / oc;
+        const int xx = (int)(q % (W + 2));
+        const long long r = q / (W + 2);
+        const int yy = (int)(r % (H + 2));
+        const int n = (int)(r / (H + 2));
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (yy >= 1 && yy <= H && xx >= 1 && xx <= W) {
+            const float* s = x + (((long long)n * H + yy - 1) * W + xx - 1) * C + o * 8;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
+            v = u32x4_t{pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(b[0], b[1]), pack2(b[2], b[3])};
+        }
+        *reinterpret_cast<u32x4_t*>(out + q * C + o * 8) = v;
+    }
+}
+
+// OIHW fp32 -> bf16 MFMA B-operand fragments: [chunk][tap][k-step of 16][32-cout block][lane][8]: lane l holds output channel
+// 32 nb + (l & 31), input channels chunk cin_c + 16 ks + 8 (l >> 5) + e
+__global__ void k_pack_b16(const float* __restrict__ w, unsigned short* __restrict__ out, int O, int I, int ks, int cin_c) {
+    const int ntap = ks * ks, ksteps = cin_c / 16, nb_tot = O / 32, nchunk = I / cin_c;
+    const long long total = (long long)nchunk * ntap * ksteps * nb_tot * 64 * 8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        long long r = i >> 9;
+        const int nb = (int)(r % nb_tot); r /= nb_tot;
+        const int kst = (int)(r % ksteps); r /= ksteps;
+        const int tap = (int)(r % ntap);
+        const int chunk = (int)(r / ntap);
+        const int co = nb * 32 + (lane & 31), ci = chunk * cin_c + kst * 16 + (lane >> 5) * 8 + e;
+        out[i] = (unsigned short)f2bf(w[((long long)co * I + ci) * ntap + tap]);
+    }
+}
+
+// ---- the 3 x 3 / stride-1 convolution, second form (k_conv_b16v2): BOTH operands through LDS, staged one stage ahead by plain
+//      loads whose only wait is the ds_write at the end of the stage (no other vector-memory load in the loop: the in-order
+//      vmcnt queue holds nothing but the next stage), 128 x 64 wave tiles (6 fragment reads per 8 MFMAs).
+//      Stage = (32-channel chunk, dy): the window of BMv + 2 positions (80 B per position: 64 B + 16 B pad) and the three dx taps'
+//      weight fragments of the workgroup's NT output channels (fragment order: lane-linear, conflict-free).
+//      Weight image: [chunk32][tap][2 k-steps][Cout / 32][64 lanes][8] (k_pack_b16 with cin_c = 32).
+template <int BMv, int NT, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void k_conv_b16v2(const unsigned short* __restrict__ in, const unsigned short* __restrict__ wpk,
+                                                       unsigned short* __restrict__ out, ConvGeo g) {
+    static_assert(WM * WN == 4 && BMv == WM * 128 && NT == WN * 64, "wave tile 128 positions x 64 channels");
+    constexpr int NPOS = BMv + 2, ROWB = 80;
+    constexpr int A_BYTES = NPOS * ROWB, B_BYTES = 3 * 2 * (NT / 32) * 1024, ST_BYTES = (A_BYTES + B_BYTES + 15) / 16 * 16;
+    constexpr int NIA = (NPOS * 4 + 255) / 256, NIB = B_BYTES / 16 / 256;     // 16-B pieces per thread and stage
+    static_assert(B_BYTES % (16 * 256) == 0, "weight pieces per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned char s_int[BMv];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, hi = lane >> 5;
+    const long long q0 = (long long)blockIdx.x * BMv;
+    const int Wp = g.Wo + 2, Hp = g.Ho + 2;
+#ifdef DSMIL_EXPERIMENTS
+    const int abl = g.stride >> 8;                    // timing ablations: 1 = no epilogue stores, 2 = no MFMAs, 4 = no staging loads
+#else
+    constexpr int abl = 0;
+#endif
+    const int nchunk = g.Cin >> 5, nb_tot = g.Cout >> 5, nb_wg = (int)blockIdx.y * (NT / 32);
+    for (int m = tid; m < BMv; m += 256) {
+        const long long q = q0 + m;
+        const int r = (int)(q % ((long long)Hp * Wp)), yo = r / Wp, xo = r - yo * Wp;
+        s_int[m] = (q < g.M && yo >= 1 && yo <= g.Ho && xo >= 1 && xo <= g.Wo) ? 1 : 0;
+    }
+    // staging plan of this thread: window pieces (position, 16-B piece of its 64 B), weight pieces (linear)
+    long long apos[NIA];
+    int adst[NIA], apc[NIA];
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        int p = i * 256 + tid;
+        p = p < NPOS * 4 ? p : NPOS * 4 - 1;                 // clamped duplicates write the same bytes
+        const int pos = p >> 2, piece = p & 3;
+        apos[i] = q0 - 1 + pos;
+        apc[i] = piece * 8;
+        adst[i] = pos * ROWB + piece * 16;
+    }
+    const u32x4_t* wp4 = reinterpret_cast<const u32x4_t*>(wpk);
+    u32x4_t ra[NIA], rb[NIB];
+    const int nstage = nchunk * 3;
+    auto stage_load = [&](int s) {
+        if (abl & 4) return;
+        const int chunk = s / 3, dy = s - chunk * 3;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            long long p = apos[i] + (long long)(dy - 1) * Wp;
+            p = p < 0 ? 0 : (p >= g.Min ? g.Min - 1 : p);
+            ra[i] = *reinterpret_cast<const u32x4_t*>(in + p * g.Cin + chunk * 32 + apc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) {
+            // piece i * 256 + tid of the stage's weights: (tap dx, k-step, block, lane) = lane-linear in [dx][ks][NT / 32][64]
+            const int pidx = i * 256 + tid, per = (NT / 32) * 64;
+            const int tk = pidx / per, rest = pidx - tk * per;          // tk = dx * 2 + ks
+            const int tap = dy * 3 + (tk >> 1), ks = tk & 1;
+            rb[i] = wp4[(((long long)(chunk * 9 + tap) * 2 + ks) * nb_tot + nb_wg) * 64 + rest];
+        }
+    };
+    auto stage_store = [&](unsigned char* b) {
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) *reinterpret_cast<u32x4_t*>(b + adst[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) *reinterpret_cast<u32x4_t*>(b + A_BYTES + (i * 256 + tid) * 16) = rb[i];
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    // ONE LDS buffer, TWO workgroups per CU: while one workgroup stores its next stage and waits at its barriers the other one
+    // multiplies; the loads of stage s + 1 are issued right behind the store of stage s and have that stage's MFMAs (and the
+    // other workgroup's) to land
+    stage_load(0);
+    for (int s = 0; s < nstage; ++s) {
+        __syncthreads();                                       // the fragments of stage s - 1 have been read by every wave
+        stage_store(smem);
+        __syncthreads();
+        stage_load(s + 1 < nstage ? s + 1 : s);
+        const unsigned char* Sb = smem;
+        if (abl & 2) continue;
+#pragma unroll
+        for (int tk = 0; tk < 6; ++tk) {
+            const int dx = tk >> 1, ks = tk & 1;
+            const unsigned char* Ab = Sb + (dx + wm * 128 + l31) * ROWB + ks * 32 + hi * 16;
+            const unsigned char* Bb = Sb + A_BYTES + ((tk * (NT / 32) + wn * 2) * 64 + lane) * 16;
+            u32x4_t af[4], bf[2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[a] = *reinterpret_cast<const u32x4_t*>(Ab + a * 32 * ROWB);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(Bb + j * 1024);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[a][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[a]), __builtin_bit_cast(bf16x8_t, bf[j]), acc[a][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = wm * 128 + a * 32 + 8 * (i >> 2) + 4 * hi + (i & 3);
+            const long long q = q0 + m;
+            if (q < g.M && !(abl & 1)) {   // (two channels per store through a lane exchange: measured 6-12 % SLOWER than these 2-byte stores)
+                const bool inside = s_int[m] != 0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    out[q * g.Cout + (nb_wg + wn * 2 + j) * 32 + l31] = inside ? (unsigned short)f2bf(acc[a][j][i]) : (unsigned short)0;
+            }
+        }
+}
+
+// ---- strided convolutions (3 x 3 / 2, 1 x 1 / 2) in the same two-workgroups-per-CU form: stage = (64-channel chunk, tap), the
+//      256 positions of the workgroup gathered through per-position offsets (144 B per position: 128 B + 16 B pad), the tap's
+//      weight fragments of 128 output channels; 128 x 64 wave tiles.  Weight image: k_pack_b16 with cin_c = 64.
+__global__ __launch_bounds__(256, 2) void k_conv_b16g(const unsigned short* __restrict__ in, const unsigned short* __restrict__ wpk,
+                                                      unsigned short* __restrict__ out, ConvGeo g) {
+    constexpr int BMv = 256, NT = 128, ROWB = 144, A_BYTES = BMv * ROWB, NIA = 8, NIB = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned char s_int[BMv];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const long long q0 = (long long)blockIdx.x * BMv;
+    const int Wp = g.Wo + 2, Hp = g.Ho + 2, Wip = g.Wi + 2;
+    const int ntap = g.ks * g.ks, nchunk = g.Cin >> 6, nb_tot = g.Cout >> 5, nb_wg = (int)blockIdx.y * (NT / 32);
+    {
+        const long long q = q0 + tid;
+        const int r = (int)(q % ((long long)Hp * Wp)), yo = r / Wp, xo = r - yo * Wp;
+        s_int[tid] = (q < g.M && yo >= 1 && yo <= g.Ho && xo >= 1 && xo <= g.Wo) ? 1 : 0;
+    }
+    int soff[NIA];                                   // element offset of the position's centre tap + this thread's piece
+    const int piece = tid & 7;
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        const int pos = i * 32 + (tid >> 3);
+        const long long q = q0 + pos;
+        const long long n = q / ((long long)Hp * Wp);
+        const int r = (int)(q - n * Hp * Wp), yo = r / Wp, xo = r - yo * Wp;
+        const bool inside = q < g.M && yo >= 1 && yo <= g.Ho && xo >= 1 && xo <= g.Wo;
+        const int yi = g.stride * (yo - 1) + 1, xi = g.stride * (xo - 1) + 1;
+        soff[i] = (inside ? (int)(((n * (g.Hi + 2) + yi) * Wip + xi) * g.Cin) : (Wip + 1) * g.Cin) + piece * 8;
+    }
+    const u32x4_t* wp4 = reinterpret_cast<const u32x4_t*>(wpk);
+    u32x4_t ra[NIA], rb[NIB];
+    const int nstage = nchunk * ntap;
+    auto stage_load = [&](int s) {
+        const int chunk = s / ntap, t = s - chunk * ntap;
+        const int dy = g.ks == 3 ? t / 3 - 1 : 0, dx = g.ks == 3 ? t % 3 - 1 : 0;
+        const int eo = (dy * Wip + dx) * g.Cin + chunk * 64;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) ra[i] = *reinterpret_cast<const u32x4_t*>(in + soff[i] + eo);
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) rb[i] = wp4[(((long long)(chunk * ntap + t) * 4 + i) * nb_tot + nb_wg) * 64 + tid];
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) *reinterpret_cast<u32x4_t*>(smem + (i * 32 + (tid >> 3)) * ROWB + piece * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) *reinterpret_cast<u32x4_t*>(smem + A_BYTES + (i * 256 + tid) * 16) = rb[i];
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    stage_load(0);
+    for (int s = 0; s < nstage; ++s) {
+        __syncthreads();
+        stage_store();
+        __syncthreads();
+        stage_load(s + 1 < nstage ? s + 1 : s);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned char* Ab = smem + (wm * 128 + l31) * ROWB + ks * 32 + hi * 16;
+            const unsigned char* Bb = smem + A_BYTES + ((ks * (NT / 32) + wn * 2) * 64 + lane) * 16;
+            u32x4_t af[4], bf[2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[a] = *reinterpret_cast<const u32x4_t*>(Ab + a * 32 * ROWB);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(Bb + j * 1024);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[a][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[a]), __builtin_bit_cast(bf16x8_t, bf[j]), acc[a][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = wm * 128 + a * 32 + 8 * (i >> 2) + 4 * hi + (i & 3);
+            const long long q = q0 + m;
+            if (q < g.M) {   // (two channels per store through a lane exchange: measured 6-12 % SLOWER than these 2-byte stores)
+                const bool inside = s_int[m] != 0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    out[q * g.Cout + (nb_wg + wn * 2 + j) * 32 + l31] = inside ? (unsigned short)f2bf(acc[a][j][i]) : (unsigned short)0;
+            }
+        }
+}
+
+// ---- InstanceNorm statistics: partial (sum, sum of squares) per (image, pixel chunk, channel), f32, fixed order
+__global__ __launch_bounds__(256) void k_stats_b16(const unsigned short* __restrict__ x, float* __restrict__ part, int H, int W, int C, int S) {
+    __shared__ float sh[2][2048];
+    const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int OC = C >> 3, PL = 256 / OC, o = tid % OC, pl = tid / OC;
+    const int HW = H * W, per = (HW + S - 1) / S, p_lo = s * per, p_hi = (p_lo + per < HW) ? p_lo + per : HW;
+    float sm[8], sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
+    for (int p = p_lo + pl; p < p_hi; p += PL) {
+        const int y = p / W, xx = p - y * W;
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + (((long long)n * (H + 2) + y + 1) * (W + 2) + xx + 1) * C + o * 8);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float a = bf_lo(v[d]), b = bf_hi(v[d]);
+            sm[2 * d] += a; sq[2 * d] = fmaf(a, a, sq[2 * d]);
+            sm[2 * d + 1] += b; sq[2 * d + 1] = fmaf(b, b, sq[2 * d + 1]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sh[0][pl * C + o * 8 + e] = sm[e]; sh[1][pl * C + o * 8 + e] = sq[e]; }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < PL; ++k) { a += sh[0][k * C + c]; b += sh[1][k * C + c]; }
+        float* dst = part + (((long long)n * S + s) * C + c) * 2;
+        dst[0] = a;
+        dst[1] = b;
+    }
+}
+
+// mean / rstd of this thread's eight channels from the S partials (biased variance, eps 1e-5: nn.InstanceNorm2d)
+__device__ __forceinline__ void b16_stats8(const float* __restrict__ part, int n, int S, int C, int c0, int HW, float (&mu)[8], float (&rs)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float a = 0.f, b = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const float* p = part + (((long long)n * S + s) * C + c0 + e) * 2;
+            a += p[0];
+            b += p[1];
+        }
+        const float m = a / (float)HW;
+        float var = b / (float)HW - m * m;
+        var = var > 0.f ? var : 0.f;
+        mu[e] = m;
+        rs[e] = 1.0f / sqrtf(var + 1e-5f);
+    }
+}
+
+// ---- y = [relu]( (x - mean) rstd [+ identity] ) on every padded position of an image (border -> 0), in place or not
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void k_apply_b16(const unsigned short* x, const unsigned short* __restrict__ idn,
+                                                   unsigned short* y, const float* __restrict__ part, int H, int W, int C, int S) {   // (x may be y)
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int OC = C >> 3, PL = 256 / OC, o = tid % OC, pl = tid / OC;
+    const int PP = (H + 2) * (W + 2), r0 = (int)blockIdx.x * PL * 8;
+    float mu[8], rs[8];
+    b16_stats8(part, n, S, C, o * 8, H * W, mu, rs);
+    // all eight positions' loads go out before the first use (clamped, unconditional: one round trip per workgroup instead of
+    // eight dependent ones), then eight normalise / store groups
+    u32x4_t v[8], iv[8];
+    long long eo[8];
+    bool live[8], inside[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        int pos = r0 + it * PL + pl;
+        live[it] = pos < PP;
+        pos = live[it] ? pos : PP - 1;
+        const int yy = pos / (W + 2), xx = pos - yy * (W + 2);
+        inside[it] = yy >= 1 && yy <= H && xx >= 1 && xx <= W;
+        eo[it] = ((long long)n * PP + pos) * C + o * 8;
+        v[it] = *reinterpret_cast<const u32x4_t*>(x + eo[it]);
+        if constexpr (RES) iv[it] = *reinterpret_cast<const u32x4_t*>(idn + eo[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        u32x4_t out = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float a = (bf_lo(v[it][d]) - mu[2 * d]) * rs[2 * d], b = (bf_hi(v[it][d]) - mu[2 * d + 1]) * rs[2 * d + 1];
+            if constexpr (RES) { a += bf_lo(iv[it][d]); b += bf_hi(iv[it][d]); }
+            if constexpr (RELU) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+            out[d] = inside[it] ? pack2(a, b) : 0u;
+        }
+        if (live[it]) *reinterpret_cast<u32x4_t*>(y + eo[it]) = out;
+    }
+}
+
+// ---- last block: feats[n][c] = mean over pixels of relu((x - mean) rstd + identity)   (dsmil.py:21-23's flatten(avgpool))
+__global__ __launch_bounds__(256) void k_pool_b16(const unsigned short* __restrict__ x, const unsigned short* __restrict__ idn,
+                                                  const float* __restrict__ part, float* __restrict__ feats, int H, int W, int C, int S) {
+    const int n = blockIdx.y, c = (int)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int HW = H * W;
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float* p = part + (((long long)n * S + s) * C + c) * 2;
+        a += p[0];
+        b += p[1];
+    }
+    const float m = a / (float)HW;
+    float var = b / (float)HW - m * m;
+    var = var > 0.f ? var : 0.f;
+    const float r = 1.0f / sqrtf(var + 1e-5f);
+    float acc = 0.f;
+    for (int yy = 1; yy <= H; ++yy)
+        for (int xx = 1; xx <= W; ++xx) {
+            const long long eo = (((long long)n * (H + 2) + yy) * (W + 2) + xx) * C + c;
+            const float v = (__uint_as_float((unsigned)x[eo] << 16) - m) * r + __uint_as_float((unsigned)idn[eo] << 16);
+            acc += fmaxf(v, 0.f);
+        }
+    feats[(long long)n * C + c] = acc / (float)HW;
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+inline bool v2_conv(const ConvSpec& s) { return s.ks == 3 && s.stride == 1 && s.pad == 1 && s.cin % 32 == 0 && s.cout % 64 == 0; }
+inline bool g2_conv(const ConvSpec& s) { return !v2_conv(s) && s.cin % 64 == 0 && s.cout % 128 == 0; }
+inline int chunk_for(const ConvSpec& s) { return v2_conv(s) ? 32 : 64; }
+inline size_t conv_packed_elems(const ConvSpec& s) { return (size_t)s.cout * s.cin * s.ks * s.ks; }   // bf16 elements
+
+inline bool arch_ok(const Arch& A) { return !A.bottleneck; }
+inline size_t packed_bytes(const Arch& A) {
+    size_t e = 0;
+    for (int i = 1; i < A.nconv; ++i) e += (conv_packed_elems(A.specs[i]) + 127) & ~(size_t)127;
+    return e * 2;
+}
+inline size_t pack_off(const Arch& A, int ci) {   // bytes
+    size_t e = 0;
+    for (int i = 1; i < ci; ++i) e += (conv_packed_elems(A.specs[i]) + 127) & ~(size_t)127;
+    return e * 2;
+}
+inline int pack_all(const Arch& A, const float* const* conv_w, unsigned short* dst, hipStream_t st) {
+    for (int i = 1; i < A.nconv; ++i) {
+        const ConvSpec& s = A.specs[i];
+        if (!v2_conv(s) && !g2_conv(s)) return DSMIL_E_UNSUPPORTED;
+        hipLaunchKernelGGL(k_pack_b16, dim3(512), dim3(256), 0, st, conv_w[i], (unsigned short*)((char*)dst + pack_off(A, i)), s.cout, s.cin, s.ks, chunk_for(s));
+    }
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
+inline int run_conv(hipStream_t st, const unsigned short* in, const unsigned short* wpk, unsigned short* out, int B, int Hi, int Wi, const ConvSpec& s, int* Ho_, int* Wo_) {
+    ConvGeo g;
+    g.B = B; g.Hi = Hi; g.Wi = Wi; g.Cin = s.cin; g.Cout = s.cout; g.ks = s.ks; g.stride = s.stride;
+    g.Ho = (Hi + 2 * s.pad - s.ks) / s.stride + 1;
+    g.Wo = (Wi + 2 * s.pad - s.ks) / s.stride + 1;
+    g.cin_c = chunk_for(s);
+    g.M = (long long)B * (g.Ho + 2) * (g.Wo + 2);
+    g.Min = (long long)B * (Hi + 2) * (Wi + 2);
+    *Ho_ = g.Ho; *Wo_ = g.Wo;
+    if ((s.ks != 3 && s.ks != 1) || (s.ks == 3 && s.pad != 1) || (s.ks == 1 && s.pad != 0) || s.cin % g.cin_c) return DSMIL_E_UNSUPPORTED;
+    const int pslot = dsmil_prof::begin(dsmil_prof::CH_CONV, st);
+    struct ProfEnd { int slot; hipStream_t st; ~ProfEnd() { dsmil_prof::end(dsmil_prof::CH_CONV, slot, st); } } prof_end{pslot, st};
+    if (v2_conv(s)) {
+        g.cin_c = 32;
+#ifdef DSMIL_EXPERIMENTS
+        static const int abl = [] { const char* e = getenv("DSMIL_B16_ABL"); return e ? atoi(e) : 0; }();
+        g.stride |= abl << 8;
+#endif
+        if (s.cout % 128 == 0) {
+            constexpr int BMv = 256, NT = 128;
+            const size_t lds = (size_t)((((BMv + 2) * 80 + 3 * 2 * (NT / 32) * 1024) + 15) / 16 * 16);
+            allow_lds((const void*)k_conv_b16v2<BMv, NT, 2, 2>, lds);
+            hipLaunchKernelGGL((k_conv_b16v2<BMv, NT, 2, 2>), dim3((unsigned)((g.M + BMv - 1) / BMv), s.cout / NT), dim3(256), lds, st, in, wpk, out, g);
+        } else {
+            constexpr int BMv = 512, NT = 64;
+            const size_t lds = (size_t)((((BMv + 2) * 80 + 3 * 2 * (NT / 32) * 1024) + 15) / 16 * 16);
+            allow_lds((const void*)k_conv_b16v2<BMv, NT, 4, 1>, lds);
+            hipLaunchKernelGGL((k_conv_b16v2<BMv, NT, 4, 1>), dim3((unsigned)((g.M + BMv - 1) / BMv), s.cout / NT), dim3(256), lds, st, in, wpk, out, g);
+        }
+        return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+    }
+    if (g2_conv(s) && g.Min * s.cin < 0x7fffffffLL) {
+        g.cin_c = 64;
+        const size_t lds = 256 * 144 + 4 * 4 * 1024;
+        allow_lds((const void*)k_conv_b16g, lds);
+        hipLaunchKernelGGL(k_conv_b16g, dim3((unsigned)((g.M + 255) / 256), s.cout / 128), dim3(256), lds, st, in, wpk, out, g);
+        return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+    }
+    return DSMIL_E_UNSUPPORTED;   // (every conv of a BasicBlock trunk is one of the two forms above)
+}
+
+inline int stat_chunks(int HW) { return HW >= 2048 ? 8 : HW >= 512 ? 4 : HW >= 128 ? 2 : 1; }
+
+inline int run_stats(hipStream_t st, const unsigned short* x, float* part, int B, int H, int W, int C) {
+    const int S = stat_chunks(H * W);
+    hipLaunchKernelGGL(k_stats_b16, dim3((unsigned)S, (unsigned)B), dim3(256), 0, st, x, part, H, W, C, S);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+inline int run_apply(hipStream_t st, const unsigned short* x, const unsigned short* idn, unsigned short* y, const float* part, int B, int H, int W, int C, bool relu) {
+    const int S = stat_chunks(H * W), PL = 256 / (C / 8), PP = (H + 2) * (W + 2);
+    const dim3 grid((unsigned)((PP + PL * 8 - 1) / (PL * 8)), (unsigned)B);
+    if (idn) hipLaunchKernelGGL((k_apply_b16<true, true>), grid, dim3(256), 0, st, x, idn, y, part, H, W, C, S);
+    else if (relu) hipLaunchKernelGGL((k_apply_b16<false, true>), grid, dim3(256), 0, st, x, idn, y, part, H, W, C, S);
+    else hipLaunchKernelGGL((k_apply_b16<false, false>), grid, dim3(256), 0, st, x, idn, y, part, H, W, C, S);
+    return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
+}
+
+// bytes the trunk needs behind the stem (four activation buffers of the largest padded map + the statistics partials)
+inline size_t act_bytes(int B, int Hp, int Wp) { return al256((size_t)B * (Hp + 2) * (Wp + 2) * 64 * 2); }
+inline size_t part_bytes(int B) { return al256((size_t)B * 8 * 512 * 2 * 4); }
+inline size_t scratch_bytes(int B, int Hp, int Wp) { return 4 * act_bytes(B, Hp, Wp) + part_bytes(B); }
+
+// The trunk behind the stem.  x0: the stem's normalised pooled output, fp32 NHWC [B][Hp][Wp][64]; scratch: scratch_bytes().
+inline int trunk(hipStream_t st, const Arch& A, const float* x0, const unsigned short* wpk, void* scratch, int B, int Hp, int Wp, float* feats) {
+    char* s8 = (char*)scratch;
+    const size_t ab = act_bytes(B, Hp, Wp);
+    unsigned short* bufs[4];
+    for (int i = 0; i < 4; ++i) bufs[i] = (unsigned short*)(s8 + i * ab);
+    float* part = (float*)(s8 + 4 * ab);
+    unsigned short* cur = bufs[0];
+    unsigned short* r1 = bufs[1];
+    unsigned short* r2 = bufs[2];
+    unsigned short* rd = bufs[3];
+    {
+        const long long total = (long long)B * (Hp + 2) * (Wp + 2) * 8;
+        long long blocks = (total + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(k_b16_pad, dim3((unsigned)blocks), dim3(256), 0, st, x0, cur, B, Hp, Wp, 64);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    }
+    int ci = 1, Hc = Hp, Wc = Wp;
+    for (int l = 1; l <= 4; ++l) {
+        for (int b = 0; b < A.nblk[l - 1]; ++b) {
+            const bool last = (l == 4 && b == A.nblk[3] - 1), down = l > 1 && b == 0;
+            const ConvSpec& s1 = A.specs[ci];
+            const ConvSpec& s2 = A.specs[ci + 1];
+            int Ho, Wo, H2, W2, rc;
+            // conv1 -> IN -> ReLU (in place)
+            if ((rc = run_conv(st, cur, (const unsigned short*)((const char*)wpk + pack_off(A, ci)), r1, B, Hc, Wc, s1, &Ho, &Wo))) return rc;
+            if ((rc = run_stats(st, r1, part, B, Ho, Wo, s1.cout))) return rc;
+            if ((rc = run_apply(st, r1, nullptr, r1, part, B, Ho, Wo, s1.cout, true))) return rc;
+            // downsample branch: 1x1 stride 2 -> IN (no ReLU), in place
+            const unsigned short* idn = cur;
+            if (down) {
+                const ConvSpec& sd = A.specs[ci + 2];
+                int Hd, Wd;
+                if ((rc = run_conv(st, cur, (const unsigned short*)((const char*)wpk + pack_off(A, ci + 2)), rd, B, Hc, Wc, sd, &Hd, &Wd))) return rc;
+                if (Hd != Ho || Wd != Wo) return DSMIL_E_UNSUPPORTED;
+                if ((rc = run_stats(st, rd, part, B, Hd, Wd, sd.cout))) return rc;
+                if ((rc = run_apply(st, rd, nullptr, rd, part, B, Hd, Wd, sd.cout, false))) return rc;
+                idn = rd;
+            }
+            // conv2 -> IN, + identity, ReLU
+            if ((rc = run_conv(st, r1, (const unsigned short*)((const char*)wpk + pack_off(A, ci + 1)), r2, B, Ho, Wo, s2, &H2, &W2))) return rc;
+            if ((rc = run_stats(st, r2, part, B, H2, W2, s2.cout))) return rc;
+            if (last) {
+                const int S = stat_chunks(H2 * W2);
+                hipLaunchKernelGGL(k_pool_b16, dim3((unsigned)((s2.cout + 255) / 256), (unsigned)B), dim3(256), 0, st, r2, idn, part, feats, H2, W2, s2.cout, S);
+                if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+            } else {
+                if ((rc = run_apply(st, r2, idn, r2, part, B, H2, W2, s2.cout, true))) return rc;
+                unsigned short* t = cur; cur = r2; r2 = t;     // the block's output becomes the next input; its old input is free
+            }
+            ci += down ? 3 : 2;
+            Hc = H2; Wc = W2;
+        }
+    }
+    return DSMIL_OK;
+}
+
+}  // namespace b16

@@ -2032,15 +2032,12 @@ inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 // hipFuncAttributeMaxDynamicSharedMemorySize once per (device, kernel), not once per launch (lds_attr.h: the attribute
 // applies to the current device only, so a process that drives several GPUs must set it on each)
 inline void allow_lds(const void* kern, size_t bytes) { (void)dsmil_lds::allow(kern, (int)bytes); }
-#ifdef DSMIL_EXPERIMENTS
 }  // namespace
-// EXPERIMENT builds only (round 6, measured and not shipped: 45 k patches/s against 59 k for the fp32-class trunk on the same
-// box — DESIGN.md §4 "Round 6"): a bf16-ACTIVATION trunk behind the stem, dsmil_resnet_pack_ex / dsmil_resnet_forward_ex with
-// precision = 2.  Needs Arch / ConvSpec / allow_lds, lives in namespace b16.
-#include "experiments/resnet_b16.h"
+// Round 6: the opt-in bf16-ACTIVATION trunk behind the stem (dsmil_resnet_pack_ex / dsmil_resnet_forward_ex, precision = 2).
+// Needs Arch / ConvSpec / allow_lds, lives in namespace b16.
+#include "resnet_b16.h"
 namespace {
 thread_local bool g_b16_trunk = false;    // precision = 2 on THIS host thread: one-plane stem, then b16::trunk
-#endif
 inline bool stem_fuse() {   // expt builds: DSMIL_STEM_FUSE=0 keeps the stem + k_norm_relu_maxpool pair (A/B, bit-identity test)
 #ifdef DSMIL_EXPERIMENTS
     static const int off = [] { const char* e = getenv("DSMIL_STEM_FUSE"); return (e && !strcmp(e, "0")) ? 1 : 0; }();
@@ -2704,9 +2701,8 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
                                 buf[0], B, d.H1, d.W1, d.Hp, d.Wp, 64);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
-#ifdef DSMIL_EXPERIMENTS
     if (g_b16_trunk) {
-        // the bf16-activation trunk (experiment builds): its four activation buffers and statistics partials take the raw-map region (the
+        // the bf16-activation trunk: its four activation buffers and statistics partials take the raw-map region (the
         // stem's pooled output sits in buf[0]; the halo rows in y0 are dead behind k_pool_fix_norm); its weight image sits
         // behind the regular packed image
         if (!b16::arch_ok(A) || bn_m) return DSMIL_E_UNSUPPORTED;
@@ -2717,7 +2713,6 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
         if (classes) return dsmil_fc_forward(feats, B, A.feat, C, fc_w, fc_b, classes, stream);
         return DSMIL_OK;
     }
-#endif
     // ---- layers 1..4, nblk[l] BasicBlocks each.  cur = block input (materialised, normalised)
     float* cur = buf[0];
     float* y1 = buf[1];
@@ -2814,42 +2809,32 @@ int dsmil_resnet_forward(int32_t depth, const void* x, int32_t x_is_u8_nhwc, int
                                    ws_bytes, stream, bn_mean, bn_rstd, depth);
 }
 
-#ifdef DSMIL_EXPERIMENTS
-// experiment builds: precision 2 = the bf16-activation trunk (its packed image is larger: dsmil_resnet_packed_bytes_ex)
+// precision 2 = the bf16-activation trunk (its packed image is larger)
 size_t dsmil_resnet_packed_bytes_ex(int32_t depth, int32_t precision) {
     const Arch* A = arch_of(depth);
     if (!A || precision < 0 || precision > 2) return 0;
     if (precision == 2) return b16::arch_ok(*A) ? dsmil_resnet_packed_bytes(depth) + b16::packed_bytes(*A) : 0;
     return dsmil_resnet_packed_bytes(depth);
 }
-constexpr int MAX_PRECISION = 2;
-#else
-constexpr int MAX_PRECISION = 1;
-#endif
 
 int dsmil_resnet_pack_ex(int32_t depth, const float* const* conv_w, float* packed, int32_t precision, void* stream) {
-    if (precision < 0 || precision > MAX_PRECISION) return DSMIL_E_INVALID;
+    if (precision < 0 || precision > 2) return DSMIL_E_INVALID;
     FormOverride fo(precision >= 1 ? 1 : 0);
     const int rc = dsmil_resnet_pack(depth, conv_w, packed, stream);
-#ifdef DSMIL_EXPERIMENTS
-    if (rc == DSMIL_OK && precision == 2) {
-        const Arch* A = arch_of(depth);
-        if (!b16::arch_ok(*A)) return DSMIL_E_UNSUPPORTED;
-        return b16::pack_all(*A, conv_w, (unsigned short*)((char*)packed + dsmil_resnet_packed_bytes(depth)), (hipStream_t)stream);
-    }
-#endif
-    return rc;
+    if (rc != DSMIL_OK || precision != 2) return rc;
+    const Arch* A = arch_of(depth);
+    if (!b16::arch_ok(*A)) return DSMIL_E_UNSUPPORTED;
+    return b16::pack_all(*A, conv_w, (unsigned short*)((char*)packed + dsmil_resnet_packed_bytes(depth)), (hipStream_t)stream);
 }
 
 int dsmil_resnet_forward_ex(int32_t depth, const void* x, int32_t x_is_u8_nhwc, int32_t B, int32_t H, int32_t W,
                             const float* conv1_w, const float* packed, const float* bn_mean, const float* bn_rstd,
                             const float* fc_w, const float* fc_b, int32_t C, float* feats, float* classes, void* ws,
                             size_t ws_bytes, int32_t precision, void* stream) {
-    if (precision < 0 || precision > MAX_PRECISION) return DSMIL_E_INVALID;
+    if (precision < 0 || precision > 2) return DSMIL_E_INVALID;
+    if (precision == 2 && (bn_mean || bn_rstd)) return DSMIL_E_UNSUPPORTED;
     FormOverride fo(precision >= 1 ? 1 : 0);
-#ifdef DSMIL_EXPERIMENTS
     struct B16Flag { bool saved; explicit B16Flag(bool on) : saved(g_b16_trunk) { g_b16_trunk = on; } ~B16Flag() { g_b16_trunk = saved; } } bf(precision == 2);
-#endif
     return dsmil_resnet_forward(depth, x, x_is_u8_nhwc, B, H, W, conv1_w, packed, bn_mean, bn_rstd, fc_w, fc_b, C, feats, classes,
                                 ws, ws_bytes, stream);
 }

@@ -52,8 +52,9 @@ class IClassifier(nn.Module):
         super().__init__()
         self.feature_extractor = feature_extractor
         self.fc = nn.Linear(feature_size, output_class)
-        # not part of the reference API: "fp32" (the parity path) or "half" — OPT-IN reduced precision of the native trunk
-        # (every conv operand rounded to one fp16 plane, f32 accumulation; ~2e-3 feature error: ops.resnet18in_forward)
+        # not part of the reference API: "fp32" (the parity path), "half" or "bf16" — OPT-IN reduced precisions of the native
+        # trunk (one fp16 plane per conv operand, ~2e-3 feature error; bf16 activations behind the stem, ~2e-2:
+        # ops.resnet18in_forward)
         self.embed_precision = "fp32"
 
     def forward(self, x):

@@ -601,17 +601,10 @@ def _packed_resnet_weights(convs, depth=18, precision=0):
         ent[3].wait(dev, ent[0])
         return ent[0]
     L = _native.lib()
-    nbytes = L.dsmil_resnet_packed_bytes(depth)
-    if int(precision) == 2:     # the bf16-activation trunk: experiment builds only (csrc/experiments/resnet_b16.h)
-        try:
-            fn = L.dsmil_resnet_packed_bytes_ex
-        except AttributeError:
-            raise ValueError("precision 'bf16' exists in experiment builds of the library only "
-                             "(build.py --variant expt -DDSMIL_EXPERIMENTS, DSMIL_NATIVE_LIB=libdsmil_hip_expt.so)") from None
-        fn.restype, fn.argtypes = ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]
-        nbytes = fn(depth, 2)
-        if nbytes == 0:
-            raise ValueError(f"precision 'bf16' is not implemented for a depth-{depth} trunk")
+    nbytes = L.dsmil_resnet_packed_bytes_ex(depth, int(precision))
+    if nbytes == 0:
+        raise ValueError(f"precision {precision} is not implemented for a depth-{depth} trunk "
+                         "(the bf16-activation trunk: ResNet-18 / 34 with InstanceNorm)")
     buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
     keep = [_f32c(w.detach(), "conv weight") for w in convs]
     # The conv operands are cut into fp16 planes of the 2^8-scaled weights (csrc/resnet_fwd.hip, EMB_WSHIFT); a Winograd
@@ -668,8 +661,8 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None, precision=
     None = InstanceNorm.  One native launch sequence (dsmil_resnet_forward_ex).
     ``precision``: "fp32" (default: fp32-class, the parity path), "half" (OPT-IN: every conv operand rounded to one fp16
     plane, f32 accumulation, fp32 activations / norms — ~2e-3 feature error, not the 1e-4 bar; include/dsmil_hip.h) or
-    "bf16" (EXPERIMENT builds of the library only, round 6: bf16 ACTIVATIONS behind the stem, one bf16 MFMA product per MAC,
-    f32 accumulation and InstanceNorm statistics — measured slower than the fp32 trunk and not shipped).
+    "bf16" (OPT-IN, round 6: bf16 ACTIVATIONS behind the stem, one bf16 MFMA product per MAC, f32 accumulation and InstanceNorm
+    statistics — ResNet-18 / 34 InstanceNorm trunks; features agree with the fp32 trunk to bf16 rounding, ~2e-2; 1.55-1.6x).
     Returns (feats [B,512 | 2048], classes [B,C] or None)."""
     if precision not in ("fp32", "half", "bf16"):
         raise ValueError("precision must be 'fp32', 'half' or 'bf16'")

@@ -75,6 +75,74 @@ def test_opt_in_half_precision_path_within_its_stated_tolerance(B, H, W, u8):
     assert float((fh - f32).abs().max()) > 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,u8", [(5, 224, 224, False), (33, 224, 224, True), (256, 224, 224, False), (2, 225, 231, False),
+                                      (3, 96, 128, False), (2, 128, 160, False)])
+def test_opt_in_bf16_activation_trunk_within_its_stated_tolerance(B, H, W, u8):
+    """IClassifier.embed_precision = "bf16" (dsmil_resnet_forward_ex, precision = 2; compute_feats.py --precision bf16; round 6):
+    behind the stem every activation is STORED in bf16 (NHWC with a one-pixel zero border) and every conv is one bf16 MFMA
+    product per MAC with f32 accumulation, f32 InstanceNorm statistics (csrc/resnet_b16.h).  NOT the 1e-4 parity path: the bar
+    stated in include/dsmil_hip.h is bf16 rounding through 16 conv + norm layers — max 5e-2 abs, mean 8e-3 abs on features of
+    O(1) against the fp64 oracle (measured: 2e-2 / 3e-3).  Batch sizes whose 256- / 512-position tiles straddle images, odd and
+    small patch sizes (225 x 231 -> 57 x 58 -> ... -> 8 x 8; 96 x 128 -> 24 x 32 -> 3 x 4: below that an InstanceNorm over a
+    handful of bf16 pixels amplifies the rounding — 64 x 64 patches, 2 x 2 maps in layer 4, reach 0.12), uint8 input.  Two runs are bit-identical
+    (no atomics: the statistics are fixed-order partial sums)."""
+    ic, w = _build(seed=11)
+    x = torch.from_numpy(make_patches(40 + B, B, H, W))
+    icg = ic.cuda()
+    xin = (x * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous().cuda() if u8 else x.cuda()
+    xr = xin.cpu().permute(0, 3, 1, 2).to(torch.float32).div(255) if u8 else x
+    sub = list(range(B)) if B <= 33 else [0, 1, 7, 100, 255]          # (the oracle runs in fp64 on the CPU)
+    ref_f, ref_c = _ref(xr[sub], w, ic)
+    with torch.no_grad():
+        icg.embed_precision = "bf16"
+        try:
+            fb, cb = icg(xin)
+            fb2, _ = icg(xin)
+        finally:
+            icg.embed_precision = "fp32"
+    assert fb.shape == (B, 512) and torch.isfinite(fb).all() and torch.equal(fb, fb2)
+    err = np.abs(fb.cpu().numpy()[sub] - ref_f)
+    assert err.max() < 5e-2 and err.mean() < 8e-3, (err.max(), err.mean())
+    assert np.abs(cb.cpu().numpy()[sub] - ref_c).max() < 5e-2
+    assert err.max() > 1e-4          # (the switch does something)
+
+
+def test_bf16_activation_trunk_resnet34_and_unsupported_trunks():
+    """precision "bf16" on `--backbone resnet34` (blocks [3,4,6,3]) against oracle/resnet_numpy.py; a frozen-BatchNorm trunk
+    and a Bottleneck trunk are refused (ValueError), not silently run at another precision."""
+    from dsmil_wsi_amd.resnet import resnet34, resnet50
+    import dsmil_wsi_amd.ops as ops
+    from dsmil_wsi_amd.modules import resnet_convs_of
+    g = torch.Generator().manual_seed(41)
+    res = resnet34(norm_layer=nn.InstanceNorm2d)
+    res.fc = nn.Identity()
+    with torch.no_grad():
+        for m in res.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / (m.weight.shape[0] * m.weight.shape[2] ** 2)) ** 0.5)
+    ic = dsmil.IClassifier(res, 512, output_class=2).eval()
+    for p in ic.parameters():
+        p.requires_grad = False
+    x = torch.from_numpy(make_patches(78, 3, 224, 224))
+    rf = rnp.resnet_features(x.numpy(), {k: v.numpy() for k, v in res.state_dict().items()}, 34, "instance")
+    icg = ic.cuda()
+    icg.embed_precision = "bf16"
+    with torch.no_grad():
+        f, _ = icg(x.cuda())
+    err = np.abs(f.cpu().numpy() - rf)
+    assert err.max() < 8e-2 and err.mean() < 1.2e-2, (err.max(), err.mean())      # 32 conv + norm layers instead of 16
+    # refused: frozen BatchNorm, Bottleneck
+    icb = _build_bn(seed=5).cuda()
+    icb.embed_precision = "bf16"
+    with pytest.raises(ValueError), torch.no_grad():
+        icb(x.cuda())
+    r50 = resnet50(norm_layer=nn.InstanceNorm2d)
+    r50.fc = nn.Identity()
+    convs50 = [t.cuda() for t in resnet_convs_of(r50)[0]]
+    with pytest.raises(ValueError), torch.no_grad():
+        ops.resnet18in_forward(x.cuda(), convs50, precision="bf16")
+
+
 @pytest.mark.parametrize("B,H,W", [(256, 224, 224), (7, 224, 224), (33, 224, 224), (255, 224, 224), (257, 224, 224),
                                    (3, 250, 250), (2, 225, 231), (9, 231, 225)])
 def test_embedder_at_the_benchmarked_batch_and_odd_sizes(B, H, W):
