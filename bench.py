@@ -687,7 +687,7 @@ def cpu_baseline_embedder(budget_s):
                       f"at the thread count that ran fastest in a short trial"}
 
 
-def slide_leg(cx, n_patches, n_steps=None, host=False):
+def slide_leg(cx, n_patches, n_steps=None, host=False, precision="fp32"):
     """ONE slide of n_patches ordered tiles (uint8 NHWC, resident), cut contiguously over the
     ranks, embedded in batches of --patches, ONE all-gather of the [N_r,512] rows, then the aggregator on the bag.
     Strong scaling: the slide is fixed, per-rank work shrinks with N.
@@ -699,6 +699,7 @@ def slide_leg(cx, n_patches, n_steps=None, host=False):
     from dsmil_wsi_amd import pipeline as pl
     from dsmil_wsi_amd.synthetic import build_net
     ic = _build_iclassifier(cx)
+    ic.embed_precision = precision   # "bf16" (`slide_bf16`): the opt-in bf16-activation trunk (its tolerance: the `embedder_bf16` leg)
     net = build_net("tcga", dev)
     lo, hi = dd.shard_range(n_patches, cx.rank, world)
     g = torch.Generator(device=dev).manual_seed(99)   # every rank draws the same slide and keeps its rows
@@ -740,7 +741,7 @@ def slide_leg(cx, n_patches, n_steps=None, host=False):
     torch.cuda.synchronize()
     out = res["out"]
     assert out[2].shape[0] == n_patches and torch.isfinite(out[1]).all()
-    return {"metric": "patches/sec, one slide %sembedded + gathered + aggregated" % ("copied H2D + " if host else ""),
+    return {"metric": "patches/sec, one slide %sembedded%s + gathered + aggregated" % ("copied H2D + " if host else "", " (OPT-IN bf16 activations)" if precision == "bf16" else ""),
             "value": round(n_patches * steps / dt, 1),
             "unit": "patches/s", "scaling": "strong", "ms_per_slide": round(dt / steps * 1e3, 3),
             "last_slide_ms": {"embed": round(ev[0].elapsed_time(ev[1]), 3), "all_gather": round(ev[1].elapsed_time(ev[2]), 3),
@@ -1050,7 +1051,7 @@ def _summary(line):
             e["value_one_stream"] = obj["config"]["value_one_stream"]
         out[name] = e
     put("aggregator_f32", line if line.get("unit") == "bags/s" else None)
-    for k in ("aggregator_bf16", "embedder", "embedder_half", "embedder_bf16", "train_c1", "train_c2", "slide", "slide_h2d", "slide_100k", "decode", "slide_jpeg", "e2e"):
+    for k in ("aggregator_bf16", "embedder", "embedder_half", "embedder_bf16", "train_c1", "train_c2", "slide", "slide_bf16", "slide_h2d", "slide_100k", "decode", "slide_jpeg", "e2e"):
         put(k, line.get(k))
     return out
 
@@ -1065,7 +1066,7 @@ def main():
     ap.add_argument("--feats", type=int, default=512)
     ap.add_argument("--patches", type=int, default=256, help="patches per rank per embedder pass (batch size)")
     ap.add_argument("--workload", default="all",
-                    help="comma list of aggregator, aggregator_bf16, embedder, embedder_half, embedder_bf16, train, slide, slide_h2d, slide100k, decode, slide_jpeg, e2e; or all / both (= aggregator,embedder)")
+                    help="comma list of aggregator, aggregator_bf16, embedder, embedder_half, embedder_bf16, train, slide, slide_bf16, slide_h2d, slide100k, decode, slide_jpeg, e2e; or all / both (= aggregator,embedder)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on each timed region")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams independent passes are dealt to (ops.StreamPool); 1 = one pass in flight")
@@ -1086,7 +1087,7 @@ def main():
                     help="skip the single-bag latency probe (profiling runs: keeps per-kernel averages clean)")
     args = ap.parse_args()
     maybe_self_launch(args)
-    wl = {"all": "aggregator,aggregator_bf16,embedder,embedder_half,embedder_bf16,train,slide,slide_h2d,slide100k,decode,slide_jpeg,e2e", "both": "aggregator,embedder"}.get(args.workload, args.workload)
+    wl = {"all": "aggregator,aggregator_bf16,embedder,embedder_half,embedder_bf16,train,slide,slide_bf16,slide_h2d,slide100k,decode,slide_jpeg,e2e", "both": "aggregator,embedder"}.get(args.workload, args.workload)
     wl = [w for w in wl.split(",") if w]
     cx = Ctx(args)
     line = {}
@@ -1106,6 +1107,8 @@ def main():
         subs["embedder_bf16"] = embedder_bf16_leg(cx)
     if "slide" in wl:
         subs["slide"] = slide_leg(cx, args.slide_patches)
+    if "slide_bf16" in wl:   # the `slide` leg on the opt-in bf16-activation trunk (round 6)
+        subs["slide_bf16"] = slide_leg(cx, args.slide_patches, precision="bf16")
     if "slide_h2d" in wl:
         subs["slide_h2d"] = slide_leg(cx, args.slide_patches, host=True)
     if "slide100k" in wl:   # the large slide of SURVEY §8(d) config 4 (15 GB of uint8 tiles over the ranks)
