@@ -10,14 +10,17 @@
 // tests/test_resnet_gpu.py states the bar).  BasicBlock trunks (ResNet-18 / 34) with InstanceNorm; everything else returns
 // DSMIL_E_UNSUPPORTED.
 //
-// Data layout: every activation is bf16 NHWC with a ONE-PIXEL ZERO BORDER, [B][H + 2][W + 2][C], and a convolution works on
-// the FLATTENED padded positions q = (n (H+2) + y) (W+2) + x:
-//   * a 3 x 3 / stride-1 conv has the same padded grid on both sides, so tap (dy, dx) of output position q is input position
-//     q + dy (W+2) + dx — no bounds logic, no im2col: a workgroup's BM output positions need the BM + 2 consecutive input
+// Data layout: every activation is bf16 NHWC with SHARED zero borders: image n owns rows n (H+1) .. n (H+1) + H of a flat
+// [rows][W + 1][C] array — its row 0 is zero (the row above the image AND the row below the image in front), column W of
+// every row is zero (the pixel right of a row AND the pixel left of the next one) — and one more zero row closes the last
+// image: (H+1)(W+1) positions per image instead of (H+2)(W+2) with private borders (31 % border work at 7 x 7 instead of
+// 65 %).  A convolution works on the FLATTENED positions q = (n (H+1) + y)(W+1) + x:
+//   * a 3 x 3 / stride-1 conv has the same grid on both sides, so tap (dy, dx) of output position q is input position
+//     q + dy (W+1) + dx — no bounds logic, no im2col: a workgroup's BM output positions need the BM + 2 consecutive input
 //     positions [q0 - 1, q0 + BM + 1) of three input rows (dy = -1, 0, +1), each staged ONCE into LDS as a plain clamped copy
 //     and used for the three dx taps by shifting the fragment address by one position;
-//   * border positions are computed like any other and written as zeros, which is what keeps the border zero for the
-//     next conv (the waste is (H+2)(W+2) / (H W): 7 % at 56 x 56, 65 % at 7 x 7);
+//   * border positions are computed like any other and written as zeros, which is what keeps the borders zero for the
+//     next conv;
 //   * strided convs (3 x 3 / 2, 1 x 1 / 2) stage one tap at a time through per-position offsets.
 // Kernels: k_b16_pad (fp32 NHWC stem output -> padded bf16); k_conv_b16v2 / k_conv_b16g (implicit GEMM, M = positions, N =
 // output channels: BOTH operands go through LDS — activations with a 16-B pad per position, weights in MFMA fragment order,
@@ -31,8 +34,9 @@
 // weight fragments loaded per lane from L2 inside the loop: 306 us (the fragment loads shared the vmcnt queue with the
 // staging loads: every stage began with an HBM round trip); both operands through LDS, 128 x 64 wave tiles, one workgroup per
 // CU with two LDS buffers: 142 us; one buffer, two workgroups per CU: 96 us.  What holds it now: layer 1 (64 channels) is
-// memory-bound (110 MB in, 110 MB out per conv: 45 us of 112), layer 4 computes 65 % border positions, and two thirds of a
-// stage are not MFMA time.
+// memory-bound (110 MB in, 110 MB out per conv: 45 us of 112), a 7 x 7 conv is a chain of 48 stages whose staging loads have
+// one stage's MFMAs to cross a memory round trip, and two thirds of a stage are not MFMA time.  Private borders
+// ([H+2][W+2] per image) -> shared borders: 111.8 k -> 120.4 k patches/s on three streams.
 #pragma once
 
 namespace b16 {
@@ -41,11 +45,15 @@ namespace b16 {
 struct ConvGeo {
     int B, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride;
     int cin_c;                     // channels per staged chunk (32: stride-1 form, 64: strided form)
-    long long M;                   // B (Ho+2) (Wo+2) output positions
-    long long Min;                 // B (Hi+2) (Wi+2) input positions
+    long long M;                   // output positions: B (Ho+1) (Wo+1) + (Wo+1)
+    long long Mint;                // B (Ho+1) (Wo+1): the positions that belong to an image
+    long long Min;                 // input positions
 };
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// positions of a [B][H][W] map in the shared-border layout (see the header): (H+1)(W+1) per image + one closing zero row
+__host__ __device__ __forceinline__ long long npos(int B, int H, int W) { return (long long)B * (H + 1) * (W + 1) + (W + 1); }
 
 __device__ __forceinline__ unsigned f2bf(float f) {           // round to nearest even (no NaN handling: the inputs are finite)
     const unsigned u = __float_as_uint(f);
@@ -55,24 +63,44 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) { return f2bf(lo) 
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 
-// fp32 NHWC [B][H][W][C] (the stem's normalised, pooled output) -> bf16 padded [B][H+2][W+2][C]
+// fp32 NHWC [B][H][W][C] (the stem's normalised, pooled output) -> the bf16 shared-border layout
 __global__ __launch_bounds__(256) void k_b16_pad(const float* __restrict__ x, unsigned short* __restrict__ out, int B, int H, int W, int C) {
     const int oc = C >> 3;
-    const long long total = (long long)B * (H + 2) * (W + 2) * oc;
+    const long long total = npos(B, H, W) * oc;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int o = (int)(i % oc);
         const long long q = i / oc;
-        const int xx = (int)(q % (W + 2));
-        const long long r = q / (W + 2);
-        const int yy = (int)(r % (H + 2));
-        const int n = (int)(r / (H + 2));
+        const int xx = (int)(q % (W + 1));
+        const long long r = q / (W + 1);
+        const int yy = (int)(r % (H + 1));
+        const int n = (int)(r / (H + 1));
         u32x4_t v = {0u, 0u, 0u, 0u};
-        if (yy >= 1 && yy <= H && xx >= 1 && xx <= W) {
-            const float* s = x + (((long long)n * H + yy - 1) * W + xx - 1) * C + o * 8;
+        if (n < B && yy >= 1 && xx < W) {
+            const float* s = x + (((long long)n * H + yy - 1) * W + xx) * C + o * 8;
             const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
             v = u32x4_t{pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(b[0], b[1]), pack2(b[2], b[3])};
         }
         *reinterpret_cast<u32x4_t*>(out + q * C + o * 8) = v;
+    }
+}
+
+// the zeros of the shared-border layout around data another kernel wrote (k_pool_fix_norm): row 0 of every image, column W of
+// every row, the closing row
+__global__ __launch_bounds__(256) void k_b16_borders(unsigned short* __restrict__ out, int B, int H, int W, int C) {
+    const int oc = C >> 3, per_img = (W + 1) + H;                 // row 0 (W + 1 positions) + column W of rows 1..H
+    const long long total = ((long long)B * per_img + (W + 1)) * oc;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int o = (int)(i % oc);
+        const long long b = i / oc;
+        long long q;
+        if (b >= (long long)B * per_img) {
+            q = (long long)B * (H + 1) * (W + 1) + (b - (long long)B * per_img);          // the closing row
+        } else {
+            const int n = (int)(b / per_img), k = (int)(b - (long long)n * per_img);
+            q = k <= W ? (long long)n * (H + 1) * (W + 1) + k                                    // row 0
+                       : ((long long)n * (H + 1) + (k - W)) * (W + 1) + W;                          // column W of row k - W
+        }
+        *reinterpret_cast<u32x4_t*>(out + q * C + o * 8) = u32x4_t{0u, 0u, 0u, 0u};
     }
 }
 
@@ -112,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_b16v2(const unsigned short* __r
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, hi = lane >> 5;
     const long long q0 = (long long)blockIdx.x * BMv;
-    const int Wp = g.Wo + 2, Hp = g.Ho + 2;
+    const int Wp = g.Wo + 1, Hp = g.Ho + 1;              // row pitch / rows per image of the shared-border layout
 #ifdef DSMIL_EXPERIMENTS
     const int abl = g.stride >> 8;                    // timing ablations: 1 = no epilogue stores, 2 = no MFMAs, 4 = no staging loads
 #else
@@ -122,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_b16v2(const unsigned short* __r
     for (int m = tid; m < BMv; m += 256) {
         const long long q = q0 + m;
         const int r = (int)(q % ((long long)Hp * Wp)), yo = r / Wp, xo = r - yo * Wp;
-        s_int[m] = (q < g.M && yo >= 1 && yo <= g.Ho && xo >= 1 && xo <= g.Wo) ? 1 : 0;
+        s_int[m] = (q < g.Mint && yo >= 1 && xo < g.Wo) ? 1 : 0;
     }
     // staging plan of this thread: window pieces (position, 16-B piece of its 64 B), weight pieces (linear)
     long long apos[NIA];
@@ -224,12 +252,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_b16g(const unsigned short* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
     const long long q0 = (long long)blockIdx.x * BMv;
-    const int Wp = g.Wo + 2, Hp = g.Ho + 2, Wip = g.Wi + 2;
+    const int Wp = g.Wo + 1, Hp = g.Ho + 1, Wip = g.Wi + 1;
     const int ntap = g.ks * g.ks, nchunk = g.Cin >> 6, nb_tot = g.Cout >> 5, nb_wg = (int)blockIdx.y * (NT / 32);
     {
         const long long q = q0 + tid;
         const int r = (int)(q % ((long long)Hp * Wp)), yo = r / Wp, xo = r - yo * Wp;
-        s_int[tid] = (q < g.M && yo >= 1 && yo <= g.Ho && xo >= 1 && xo <= g.Wo) ? 1 : 0;
+        s_int[tid] = (q < g.Mint && yo >= 1 && xo < g.Wo) ? 1 : 0;
     }
     int soff[NIA];                                   // element offset of the position's centre tap + this thread's piece
     const int piece = tid & 7;
@@ -239,9 +267,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_b16g(const unsigned short* __re
         const long long q = q0 + pos;
         const long long n = q / ((long long)Hp * Wp);
         const int r = (int)(q - n * Hp * Wp), yo = r / Wp, xo = r - yo * Wp;
-        const bool inside = q < g.M && yo >= 1 && yo <= g.Ho && xo >= 1 && xo <= g.Wo;
-        const int yi = g.stride * (yo - 1) + 1, xi = g.stride * (xo - 1) + 1;
-        soff[i] = (inside ? (int)(((n * (g.Hi + 2) + yi) * Wip + xi) * g.Cin) : (Wip + 1) * g.Cin) + piece * 8;
+        const bool inside = q < g.Mint && yo >= 1 && xo < g.Wo;
+        const int yi = g.stride * (yo - 1) + 1, xi = g.stride * xo;        // rows 1-based (row 0 of an image is zero), columns 0-based
+        soff[i] = (inside ? (int)(((n * (g.Hi + 1) + yi) * Wip + xi) * g.Cin) : (Wip + 1) * g.Cin) + piece * 8;
     }
     const u32x4_t* wp4 = reinterpret_cast<const u32x4_t*>(wpk);
     u32x4_t ra[NIA], rb[NIB];
@@ -251,7 +279,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_b16g(const unsigned short* __re
         const int dy = g.ks == 3 ? t / 3 - 1 : 0, dx = g.ks == 3 ? t % 3 - 1 : 0;
         const int eo = (dy * Wip + dx) * g.Cin + chunk * 64;
 #pragma unroll
-        for (int i = 0; i < NIA; ++i) ra[i] = *reinterpret_cast<const u32x4_t*>(in + soff[i] + eo);
+        for (int i = 0; i < NIA; ++i) {
+            // (image 0, output (1, 0), tap (-1, -1) is position -1: the zero at the end of the row in front of the tensor's first —
+            // read position 0 instead, another zero)
+            const int e = soff[i] + eo;
+            ra[i] = *reinterpret_cast<const u32x4_t*>(in + (e < 0 ? piece * 8 : e));
+        }
 #pragma unroll
         for (int i = 0; i < NIB; ++i) rb[i] = wp4[(((long long)(chunk * ntap + t) * 4 + i) * nb_tot + nb_wg) * 64 + tid];
     };
@@ -316,7 +349,7 @@ __global__ __launch_bounds__(256) void k_stats_b16(const unsigned short* __restr
     for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
     for (int p = p_lo + pl; p < p_hi; p += PL) {
         const int y = p / W, xx = p - y * W;
-        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + (((long long)n * (H + 2) + y + 1) * (W + 2) + xx + 1) * C + o * 8);
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + (((long long)n * (H + 1) + y + 1) * (W + 1) + xx) * C + o * 8);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const float a = bf_lo(v[d]), b = bf_hi(v[d]);
@@ -360,7 +393,7 @@ __global__ __launch_bounds__(256) void k_apply_b16(const unsigned short* x, cons
                                                    unsigned short* y, const float* __restrict__ part, int H, int W, int C, int S) {   // (x may be y)
     const int n = blockIdx.y, tid = threadIdx.x;
     const int OC = C >> 3, PL = 256 / OC, o = tid % OC, pl = tid / OC;
-    const int PP = (H + 2) * (W + 2), r0 = (int)blockIdx.x * PL * 8;
+    const int PP = (H + 1) * (W + 1), r0 = (int)blockIdx.x * PL * 8;
     float mu[8], rs[8];
     b16_stats8(part, n, S, C, o * 8, H * W, mu, rs);
     // all eight positions' loads go out before the first use (clamped, unconditional: one round trip per workgroup instead of
@@ -373,8 +406,8 @@ __global__ __launch_bounds__(256) void k_apply_b16(const unsigned short* x, cons
         int pos = r0 + it * PL + pl;
         live[it] = pos < PP;
         pos = live[it] ? pos : PP - 1;
-        const int yy = pos / (W + 2), xx = pos - yy * (W + 2);
-        inside[it] = yy >= 1 && yy <= H && xx >= 1 && xx <= W;
+        const int yy = pos / (W + 1), xx = pos - yy * (W + 1);
+        inside[it] = yy >= 1 && xx < W;
         eo[it] = ((long long)n * PP + pos) * C + o * 8;
         v[it] = *reinterpret_cast<const u32x4_t*>(x + eo[it]);
         if constexpr (RES) iv[it] = *reinterpret_cast<const u32x4_t*>(idn + eo[it]);
@@ -411,8 +444,8 @@ __global__ __launch_bounds__(256) void k_pool_b16(const unsigned short* __restri
     const float r = 1.0f / sqrtf(var + 1e-5f);
     float acc = 0.f;
     for (int yy = 1; yy <= H; ++yy)
-        for (int xx = 1; xx <= W; ++xx) {
-            const long long eo = (((long long)n * (H + 2) + yy) * (W + 2) + xx) * C + c;
+        for (int xx = 0; xx < W; ++xx) {
+            const long long eo = (((long long)n * (H + 1) + yy) * (W + 1) + xx) * C + c;
             const float v = (__uint_as_float((unsigned)x[eo] << 16) - m) * r + __uint_as_float((unsigned)idn[eo] << 16);
             acc += fmaxf(v, 0.f);
         }
@@ -451,8 +484,9 @@ inline int run_conv(hipStream_t st, const unsigned short* in, const unsigned sho
     g.Ho = (Hi + 2 * s.pad - s.ks) / s.stride + 1;
     g.Wo = (Wi + 2 * s.pad - s.ks) / s.stride + 1;
     g.cin_c = chunk_for(s);
-    g.M = (long long)B * (g.Ho + 2) * (g.Wo + 2);
-    g.Min = (long long)B * (Hi + 2) * (Wi + 2);
+    g.M = npos(B, g.Ho, g.Wo);
+    g.Mint = (long long)B * (g.Ho + 1) * (g.Wo + 1);
+    g.Min = npos(B, Hi, Wi);
     *Ho_ = g.Ho; *Wo_ = g.Wo;
     if ((s.ks != 3 && s.ks != 1) || (s.ks == 3 && s.pad != 1) || (s.ks == 1 && s.pad != 0) || s.cin % g.cin_c) return DSMIL_E_UNSUPPORTED;
     const int pslot = dsmil_prof::begin(dsmil_prof::CH_CONV, st);
@@ -494,7 +528,7 @@ inline int run_stats(hipStream_t st, const unsigned short* x, float* part, int B
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 inline int run_apply(hipStream_t st, const unsigned short* x, const unsigned short* idn, unsigned short* y, const float* part, int B, int H, int W, int C, bool relu) {
-    const int S = stat_chunks(H * W), PL = 256 / (C / 8), PP = (H + 2) * (W + 2);
+    const int S = stat_chunks(H * W), PL = 256 / (C / 8), PP = (H + 1) * (W + 1);
     const dim3 grid((unsigned)((PP + PL * 8 - 1) / (PL * 8)), (unsigned)B);
     if (idn) hipLaunchKernelGGL((k_apply_b16<true, true>), grid, dim3(256), 0, st, x, idn, y, part, H, W, C, S);
     else if (relu) hipLaunchKernelGGL((k_apply_b16<false, true>), grid, dim3(256), 0, st, x, idn, y, part, H, W, C, S);
@@ -503,11 +537,12 @@ inline int run_apply(hipStream_t st, const unsigned short* x, const unsigned sho
 }
 
 // bytes the trunk needs behind the stem (four activation buffers of the largest padded map + the statistics partials)
-inline size_t act_bytes(int B, int Hp, int Wp) { return al256((size_t)B * (Hp + 2) * (Wp + 2) * 64 * 2); }
+inline size_t act_bytes(int B, int Hp, int Wp) { return al256((size_t)npos(B, Hp, Wp) * 64 * 2); }
 inline size_t part_bytes(int B) { return al256((size_t)B * 8 * 512 * 2 * 4); }
 inline size_t scratch_bytes(int B, int Hp, int Wp) { return 4 * act_bytes(B, Hp, Wp) + part_bytes(B); }
 
-// The trunk behind the stem.  x0: the stem's normalised pooled output, fp32 NHWC [B][Hp][Wp][64]; scratch: scratch_bytes().
+// The trunk behind the stem.  x0: the stem's normalised pooled output, fp32 NHWC [B][Hp][Wp][64] — or nullptr when the stem
+// has already written it as bf16 into the first activation buffer (k_pool_fix_norm); scratch: scratch_bytes().
 inline int trunk(hipStream_t st, const Arch& A, const float* x0, const unsigned short* wpk, void* scratch, int B, int Hp, int Wp, float* feats) {
     char* s8 = (char*)scratch;
     const size_t ab = act_bytes(B, Hp, Wp);
@@ -518,11 +553,15 @@ inline int trunk(hipStream_t st, const Arch& A, const float* x0, const unsigned 
     unsigned short* r1 = bufs[1];
     unsigned short* r2 = bufs[2];
     unsigned short* rd = bufs[3];
-    {
-        const long long total = (long long)B * (Hp + 2) * (Wp + 2) * 8;
+    if (x0) {
+        const long long total = npos(B, Hp, Wp) * 8;
         long long blocks = (total + 255) / 256;
         if (blocks > 16384) blocks = 16384;
         hipLaunchKernelGGL(k_b16_pad, dim3((unsigned)blocks), dim3(256), 0, st, x0, cur, B, Hp, Wp, 64);
+        if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
+    } else {   // the stem's k_pool_fix_norm wrote the interior of `cur`: its borders
+        const long long total = ((long long)B * (Wp + 1 + Hp) + Wp + 1) * 8;
+        hipLaunchKernelGGL(k_b16_borders, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cur, B, Hp, Wp, 64);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     }
     int ci = 1, Hc = Hp, Wc = Wp;

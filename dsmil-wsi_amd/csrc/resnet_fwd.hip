@@ -1779,9 +1779,12 @@ __global__ __launch_bounds__(512, 2) void k_stem_s6(const void* __restrict__ xin
 
 // POOL path, second half: fold the row from the tile above into the first pool row of every tile row, then IN + ReLU
 // (in place on the pooled raw map; the same arithmetic as k_norm_relu_maxpool for r > 0, so the result is bit-identical)
+// b16 != nullptr (the opt-in bf16-activation trunk, resnet_b16.h): the normalised map goes out as bf16 into that trunk's
+// shared-border layout ([rows][Wp + 1][64], row 0 of an image and column Wp are zero: written by k_b16_borders) instead of
+// fp32 in place — the trunk's first conv reads it as it is
 __global__ __launch_bounds__(256) void k_pool_fix_norm(float* __restrict__ p, const float* __restrict__ halo,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                       int B, int Hp, int Wp, int Wo, int tiles_y) {
+                                                       int B, int Hp, int Wp, int Wo, int tiles_y, unsigned short* __restrict__ b16 = nullptr) {
     const int c4 = threadIdx.x & 15;
     const unsigned np = (unsigned)B * Hp * Wp;
     for (unsigned pp = blockIdx.x * 16 + threadIdx.x / 16; pp < np; pp += gridDim.x * 16) {
@@ -1806,7 +1809,15 @@ __global__ __launch_bounds__(256) void k_pool_fix_norm(float* __restrict__ p, co
         const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + (long long)n * 64 + c4 * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) m[e] = fmaxf((m[e] - mu[e]) * rs[e], 0.f);
-        *reinterpret_cast<f32x4*>(o) = m;
+        if (b16) {
+            auto bf = [](float f) { const unsigned u = __float_as_uint(f); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };   // RNE
+            const size_t q = ((size_t)n * (Hp + 1) + py + 1) * (Wp + 1) + px;
+            unsigned* d = reinterpret_cast<unsigned*>(b16 + q * 64 + c4 * 4);
+            d[0] = bf(m[0]) | (bf(m[1]) << 16);
+            d[1] = bf(m[2]) | (bf(m[3]) << 16);
+        } else {
+            *reinterpret_cast<f32x4*>(o) = m;
+        }
     }
 }
 
@@ -2644,6 +2655,8 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
     float* part = (float*)(w8 + L.part);
 
     // ---- stem: conv1 -> IN -> ReLU -> maxpool
+    size_t b16_halo_bytes = 0;
+    bool b16_direct = false;
     {
         const bool s6 = conv_s6();   // DSMIL_CONV: the stem follows the direct convs' MFMA form
         const int tx = (d.W1 + 15) / 16, ty = s6 ? (d.H1 + SS_TR - 1) / SS_TR : (d.H1 + 7) / 8;
@@ -2695,8 +2708,11 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
         const long long total = (long long)B * d.Hp * d.Wp * 16;
         long long blocks = (total + 255) / 256;
         if (blocks > 8192) blocks = 8192;
+        // the bf16-activation trunk takes the stem's output as bf16 in its own layout, behind the halo rows of the raw-map region
+        b16_halo_bytes = al256((size_t)B * ty * d.W1 * 64 * sizeof(float));
+        b16_direct = g_b16_trunk && fuse && b16_halo_bytes + b16::scratch_bytes(B, d.Hp, d.Wp) <= L.buf[0] - L.y0;
         if (fuse) hipLaunchKernelGGL(k_pool_fix_norm, dim3((unsigned)blocks), dim3(256), 0, st, buf[0], y0, mean[0], rstd[0],
-                                     B, d.Hp, d.Wp, d.W1, ty);
+                                     B, d.Hp, d.Wp, d.W1, ty, b16_direct ? (unsigned short*)(w8 + L.y0 + b16_halo_bytes) : (unsigned short*)nullptr);
         else hipLaunchKernelGGL(k_norm_relu_maxpool, dim3((unsigned)blocks), dim3(256), 0, st, y0, mean[0], rstd[0],
                                 buf[0], B, d.H1, d.W1, d.Hp, d.Wp, 64);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
@@ -2708,7 +2724,8 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
         if (!b16::arch_ok(A) || bn_m) return DSMIL_E_UNSUPPORTED;
         if (b16::scratch_bytes(B, d.Hp, d.Wp) > L.buf[0] - L.y0) return DSMIL_E_UNSUPPORTED;
         const unsigned short* wpk16 = (const unsigned short*)((const char*)packed + dsmil_resnet_packed_bytes(depth));
-        const int rc = b16::trunk(st, A, buf[0], wpk16, w8 + L.y0, B, d.Hp, d.Wp, feats);
+        // (b16_direct: k_pool_fix_norm has already written the trunk's input, bf16, behind the halo rows)
+        const int rc = b16::trunk(st, A, b16_direct ? nullptr : buf[0], wpk16, w8 + L.y0 + (b16_direct ? b16_halo_bytes : 0), B, d.Hp, d.Wp, feats);
         if (rc != DSMIL_OK) return rc;
         if (classes) return dsmil_fc_forward(feats, B, A.feat, C, fc_w, fc_b, classes, stream);
         return DSMIL_OK;
