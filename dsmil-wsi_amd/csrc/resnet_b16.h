@@ -22,18 +22,20 @@
 //   * border positions are computed like any other and written as zeros, which is what keeps the borders zero for the
 //     next conv;
 //   * strided convs (3 x 3 / 2, 1 x 1 / 2) stage one tap at a time through per-position offsets.
-// Kernels: k_b16_pad (fp32 NHWC stem output -> padded bf16); k_conv_b16v2 / k_conv_b16g (implicit GEMM, M = positions, N =
-// output channels: BOTH operands go through LDS — activations with a 16-B pad per position, weights in MFMA fragment order,
-// both conflict-free ds_read_b128 —, staged one stage ahead by plain loads whose only wait is the ds_write at the top of the
-// next stage, so the in-order vmcnt queue never couples a fragment read to a staging load; 128 x 64 wave tiles (6 fragment
-// reads per 8 MFMAs); ONE LDS buffer and TWO workgroups per CU: one multiplies while the other stores its next stage and
-// sits at its barriers); k_stats_b16 / k_apply_b16 (InstanceNorm in two flat passes: per-(image, chunk, channel) partial sums
+// Kernels: k_b16_pad / k_b16_borders (the stem's output into the layout); k_conv_b16w / k_conv_b16g (implicit GEMM, M =
+// positions, N = output channels: BOTH operands go through LDS — activations with a 16-B pad per position, weights in MFMA
+// fragment order, both conflict-free ds_read_b128 —, staged one stage ahead by plain loads whose only wait is the ds_write at
+// the top of the next stage, so the in-order vmcnt queue never couples a fragment read to a staging load; 128 x 64 wave tiles
+// (6 fragment reads per 8 MFMAs); ONE LDS buffer and TWO workgroups per CU: one multiplies while the other stores its next
+// stage and sits at its barriers; the 3 x 3 / 1 form stages the workgroup's whole input WINDOW once per 16-channel chunk and
+// runs all nine taps on it); k_stats_b16 / k_apply_b16 (InstanceNorm in two flat passes: per-(image, chunk, channel) partial sums
 // in a fixed order — no atomics, bit-reproducible —, then normalise + residual + ReLU in place); k_pool_b16 (last block:
 // normalise + residual + ReLU + average pool -> fp32 feature row).
 // History of the conv kernel (bs 256, per 3 x 3 / 1 conv at 128+ channels; DESIGN.md §4 "Round 6"): 64 x 64 wave tiles with the
 // weight fragments loaded per lane from L2 inside the loop: 306 us (the fragment loads shared the vmcnt queue with the
-// staging loads: every stage began with an HBM round trip); both operands through LDS, 128 x 64 wave tiles, one workgroup per
-// CU with two LDS buffers: 142 us; one buffer, two workgroups per CU: 96 us.  What holds it now: layer 1 (64 channels) is
+// staging loads: every stage began with an HBM round trip); both operands through LDS, 128 x 64 wave tiles, stage = (32
+// channels, one tap row), one workgroup per CU with two LDS buffers: 142 us; one buffer, two workgroups per CU: 96 us; shared
+// borders, stage = (16 channels, all nine taps on one staged window): 70-77 us at 14 x 14 / 28 x 28.  What holds it now: layer 1 (64 channels) is
 // memory-bound (110 MB in, 110 MB out per conv: 45 us of 112), a 7 x 7 conv is a chain of 48 stages whose staging loads have
 // one stage's MFMAs to cross a memory round trip, and two thirds of a stage are not MFMA time.  Private borders
 // ([H+2][W+2] per image) -> shared borders: 111.8 k -> 120.4 k patches/s on three streams.
@@ -51,6 +53,7 @@ struct ConvGeo {
 };
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int B16W_NIA = 6;     // k_conv_b16w: 16-B window pieces per thread: (BM + 2 (W+1) + 2) positions x 2 pieces <= 6 x 256
 
 // positions of a [B][H][W] map in the shared-border layout (see the header): (H+1)(W+1) per image + one closing zero row
 __host__ __device__ __forceinline__ long long npos(int B, int H, int W) { return (long long)B * (H + 1) * (W + 1) + (W + 1); }
@@ -121,75 +124,68 @@ __global__ void k_pack_b16(const float* __restrict__ w, unsigned short* __restri
     }
 }
 
-// ---- the 3 x 3 / stride-1 convolution, second form (k_conv_b16v2): BOTH operands through LDS, staged one stage ahead by plain
-//      loads whose only wait is the ds_write at the end of the stage (no other vector-memory load in the loop: the in-order
-//      vmcnt queue holds nothing but the next stage), 128 x 64 wave tiles (6 fragment reads per 8 MFMAs).
-//      Stage = (32-channel chunk, dy): the window of BMv + 2 positions (80 B per position: 64 B + 16 B pad) and the three dx taps'
-//      weight fragments of the workgroup's NT output channels (fragment order: lane-linear, conflict-free).
-//      Weight image: [chunk32][tap][2 k-steps][Cout / 32][64 lanes][8] (k_pack_b16 with cin_c = 32).
+// ---- the 3 x 3 / stride-1 convolution, WINDOW form (k_conv_b16w): stage = a 16-channel chunk with ALL NINE taps.  The
+//      workgroup's whole input window — the BMv + 2 (W+1) + 2 consecutive positions [q0 - (W+1) - 1, q0 + BMv + (W+1) + 1) —
+//      is staged ONCE per chunk (48 B per position: 32 B + 16 B pad) instead of once per (chunk, dy): every input byte crosses
+//      the CU's port ~1.2-1.5x instead of 3x, a conv has Cin / 16 stages instead of 3 Cin / 32, and a stage holds 72 MFMAs per
+//      wave instead of 48 for its staging loads to land under.  Tap (dy, dx) of output m is window position m + dy (W+1) + dx.
+//      Weight image: k_pack_b16 with cin_c = 16 ([chunk16][tap][1][Cout / 32][64][8]).
 template <int BMv, int NT, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void k_conv_b16v2(const unsigned short* __restrict__ in, const unsigned short* __restrict__ wpk,
-                                                       unsigned short* __restrict__ out, ConvGeo g) {
+__global__ __launch_bounds__(256, 2) void k_conv_b16w(const unsigned short* __restrict__ in, const unsigned short* __restrict__ wpk,
+                                                      unsigned short* __restrict__ out, ConvGeo g) {
     static_assert(WM * WN == 4 && BMv == WM * 128 && NT == WN * 64, "wave tile 128 positions x 64 channels");
-    constexpr int NPOS = BMv + 2, ROWB = 80;
-    constexpr int A_BYTES = NPOS * ROWB, B_BYTES = 3 * 2 * (NT / 32) * 1024, ST_BYTES = (A_BYTES + B_BYTES + 15) / 16 * 16;
-    constexpr int NIA = (NPOS * 4 + 255) / 256, NIB = B_BYTES / 16 / 256;     // 16-B pieces per thread and stage
-    static_assert(B_BYTES % (16 * 256) == 0, "weight pieces per thread");
+    constexpr int ROWB = 48;
+    constexpr int B_PIECES = 9 * (NT / 32) * 64, B_BYTES = B_PIECES * 16;
+    constexpr int NIB = (B_PIECES + 255) / 256;
+    constexpr int NIA = B16W_NIA;                             // window pieces per thread (the host checks that they suffice)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned char s_int[BMv];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, hi = lane >> 5;
     const long long q0 = (long long)blockIdx.x * BMv;
-    const int Wp = g.Wo + 1, Hp = g.Ho + 1;              // row pitch / rows per image of the shared-border layout
-#ifdef DSMIL_EXPERIMENTS
-    const int abl = g.stride >> 8;                    // timing ablations: 1 = no epilogue stores, 2 = no MFMAs, 4 = no staging loads
-#else
-    constexpr int abl = 0;
-#endif
-    const int nchunk = g.Cin >> 5, nb_tot = g.Cout >> 5, nb_wg = (int)blockIdx.y * (NT / 32);
+    const int Wp = g.Wo + 1, Hp = g.Ho + 1;
+    const int npw = BMv + 2 * Wp + 2, A_BYTES = (npw * ROWB + 15) / 16 * 16;
+    const int nstage = g.Cin >> 4, nb_tot = g.Cout >> 5, nb_wg = (int)blockIdx.y * (NT / 32);
     for (int m = tid; m < BMv; m += 256) {
         const long long q = q0 + m;
         const int r = (int)(q % ((long long)Hp * Wp)), yo = r / Wp, xo = r - yo * Wp;
         s_int[m] = (q < g.Mint && yo >= 1 && xo < g.Wo) ? 1 : 0;
     }
-    // staging plan of this thread: window pieces (position, 16-B piece of its 64 B), weight pieces (linear)
-    long long apos[NIA];
-    int adst[NIA], apc[NIA];
+    long long aoff[NIA];                 // element offset of the window piece (clamped into the tensor: the same for every stage)
+    int adst[NIA];
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
         int p = i * 256 + tid;
-        p = p < NPOS * 4 ? p : NPOS * 4 - 1;                 // clamped duplicates write the same bytes
-        const int pos = p >> 2, piece = p & 3;
-        apos[i] = q0 - 1 + pos;
-        apc[i] = piece * 8;
+        p = p < npw * 2 ? p : npw * 2 - 1;                    // clamped duplicates write the same bytes
+        const int pos = p >> 1, piece = p & 1;
+        long long q = q0 - Wp - 1 + pos;
+        q = q < 0 ? 0 : (q >= g.Min ? g.Min - 1 : q);
+        aoff[i] = q * g.Cin + piece * 8;
         adst[i] = pos * ROWB + piece * 16;
     }
     const u32x4_t* wp4 = reinterpret_cast<const u32x4_t*>(wpk);
     u32x4_t ra[NIA], rb[NIB];
-    const int nstage = nchunk * 3;
     auto stage_load = [&](int s) {
-        if (abl & 4) return;
-        const int chunk = s / 3, dy = s - chunk * 3;
 #pragma unroll
-        for (int i = 0; i < NIA; ++i) {
-            long long p = apos[i] + (long long)(dy - 1) * Wp;
-            p = p < 0 ? 0 : (p >= g.Min ? g.Min - 1 : p);
-            ra[i] = *reinterpret_cast<const u32x4_t*>(in + p * g.Cin + chunk * 32 + apc[i]);
-        }
+        for (int i = 0; i < NIA; ++i) ra[i] = *reinterpret_cast<const u32x4_t*>(in + aoff[i] + s * 16);
 #pragma unroll
         for (int i = 0; i < NIB; ++i) {
-            // piece i * 256 + tid of the stage's weights: (tap dx, k-step, block, lane) = lane-linear in [dx][ks][NT / 32][64]
-            const int pidx = i * 256 + tid, per = (NT / 32) * 64;
-            const int tk = pidx / per, rest = pidx - tk * per;          // tk = dx * 2 + ks
-            const int tap = dy * 3 + (tk >> 1), ks = tk & 1;
-            rb[i] = wp4[(((long long)(chunk * 9 + tap) * 2 + ks) * nb_tot + nb_wg) * 64 + rest];
+            int pidx = i * 256 + tid;
+            pidx = pidx < B_PIECES ? pidx : B_PIECES - 1;
+            constexpr int per = (NT / 32) * 64;
+            const int tap = pidx / per, rest = pidx - tap * per;
+            rb[i] = wp4[((long long)(s * 9 + tap) * nb_tot + nb_wg) * 64 + rest];
         }
     };
-    auto stage_store = [&](unsigned char* b) {
+    auto stage_store = [&]() {
 #pragma unroll
-        for (int i = 0; i < NIA; ++i) *reinterpret_cast<u32x4_t*>(b + adst[i]) = ra[i];
+        for (int i = 0; i < NIA; ++i) *reinterpret_cast<u32x4_t*>(smem + adst[i]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < NIB; ++i) *reinterpret_cast<u32x4_t*>(b + A_BYTES + (i * 256 + tid) * 16) = rb[i];
+        for (int i = 0; i < NIB; ++i) {
+            int pidx = i * 256 + tid;
+            pidx = pidx < B_PIECES ? pidx : B_PIECES - 1;
+            *reinterpret_cast<u32x4_t*>(smem + A_BYTES + pidx * 16) = rb[i];
+        }
     };
     f32x16 acc[4][2];
 #pragma unroll
@@ -198,22 +194,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_b16v2(const unsigned short* __r
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    // ONE LDS buffer, TWO workgroups per CU: while one workgroup stores its next stage and waits at its barriers the other one
-    // multiplies; the loads of stage s + 1 are issued right behind the store of stage s and have that stage's MFMAs (and the
-    // other workgroup's) to land
     stage_load(0);
     for (int s = 0; s < nstage; ++s) {
         __syncthreads();                                       // the fragments of stage s - 1 have been read by every wave
-        stage_store(smem);
+        stage_store();
         __syncthreads();
         stage_load(s + 1 < nstage ? s + 1 : s);
-        const unsigned char* Sb = smem;
-        if (abl & 2) continue;
 #pragma unroll
-        for (int tk = 0; tk < 6; ++tk) {
-            const int dx = tk >> 1, ks = tk & 1;
-            const unsigned char* Ab = Sb + (dx + wm * 128 + l31) * ROWB + ks * 32 + hi * 16;
-            const unsigned char* Bb = Sb + A_BYTES + ((tk * (NT / 32) + wn * 2) * 64 + lane) * 16;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const unsigned char* Ab = smem + (dy * Wp + dx + wm * 128 + l31) * ROWB + hi * 16;
+            const unsigned char* Bb = smem + A_BYTES + ((tap * (NT / 32) + wn * 2) * 64 + lane) * 16;
             u32x4_t af[4], bf[2];
 #pragma unroll
             for (int a = 0; a < 4; ++a) af[a] = *reinterpret_cast<const u32x4_t*>(Ab + a * 32 * ROWB);
@@ -232,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_b16v2(const unsigned short* __r
         for (int i = 0; i < 16; ++i) {
             const int m = wm * 128 + a * 32 + 8 * (i >> 2) + 4 * hi + (i & 3);
             const long long q = q0 + m;
-            if (q < g.M && !(abl & 1)) {   // (two channels per store through a lane exchange: measured 6-12 % SLOWER than these 2-byte stores)
+            if (q < g.M) {
                 const bool inside = s_int[m] != 0;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -347,15 +338,26 @@ __global__ __launch_bounds__(256) void k_stats_b16(const unsigned short* __restr
     float sm[8], sq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
-    for (int p = p_lo + pl; p < p_hi; p += PL) {
-        const int y = p / W, xx = p - y * W;
-        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + (((long long)n * (H + 1) + y + 1) * (W + 1) + xx) * C + o * 8);
+    // four pixels per step, their loads in front of the adds (clamped re-reads past the end are not added): same order of adds
+    for (int p0 = p_lo + pl; p0 < p_hi; p0 += 4 * PL) {
+        u32x4_t v[4];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const float a = bf_lo(v[d]), b = bf_hi(v[d]);
-            sm[2 * d] += a; sq[2 * d] = fmaf(a, a, sq[2 * d]);
-            sm[2 * d + 1] += b; sq[2 * d + 1] = fmaf(b, b, sq[2 * d + 1]);
+        for (int k = 0; k < 4; ++k) {
+            int p = p0 + k * PL;
+            p = p < p_hi ? p : p_hi - 1;
+            const int y = p / W, xx = p - y * W;
+            v[k] = *reinterpret_cast<const u32x4_t*>(x + (((long long)n * (H + 1) + y + 1) * (W + 1) + xx) * C + o * 8);
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (p0 + k * PL < p_hi) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const float a = bf_lo(v[k][d]), b = bf_hi(v[k][d]);
+                    sm[2 * d] += a; sq[2 * d] = fmaf(a, a, sq[2 * d]);
+                    sm[2 * d + 1] += b; sq[2 * d + 1] = fmaf(b, b, sq[2 * d + 1]);
+                }
+            }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sh[0][pl * C + o * 8 + e] = sm[e]; sh[1][pl * C + o * 8 + e] = sq[e]; }
@@ -369,18 +371,36 @@ __global__ __launch_bounds__(256) void k_stats_b16(const unsigned short* __restr
     }
 }
 
-// mean / rstd of this thread's eight channels from the S partials (biased variance, eps 1e-5: nn.InstanceNorm2d)
+// mean / rstd of this thread's eight channels from the S partials (biased variance, eps 1e-5: nn.InstanceNorm2d).  The eight
+// channels' (sum, sum of squares) pairs of one partial are 64 contiguous bytes: four 16-B loads per partial, all S partials
+// requested before the first add (c0 is a multiple of 8: 16-B aligned)
 __device__ __forceinline__ void b16_stats8(const float* __restrict__ part, int n, int S, int C, int c0, int HW, float (&mu)[8], float (&rs)[8]) {
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = 0.f; b[e] = 0.f; }
+    for (int s0 = 0; s0 < S; s0 += 4) {          // S is 1, 2, 4 or 8
+        f32x4 v[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int s = s0 + k < S ? s0 + k : S - 1;         // (clamped re-read, not added)
+            const f32x4* p = reinterpret_cast<const f32x4*>(part + (((long long)n * S + s) * C + c0) * 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[k][q] = p[q];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (s0 + k < S) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[2 * q] += v[k][q][0]; b[2 * q] += v[k][q][1];
+                    a[2 * q + 1] += v[k][q][2]; b[2 * q + 1] += v[k][q][3];
+                }
+            }
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        float a = 0.f, b = 0.f;
-        for (int s = 0; s < S; ++s) {
-            const float* p = part + (((long long)n * S + s) * C + c0 + e) * 2;
-            a += p[0];
-            b += p[1];
-        }
-        const float m = a / (float)HW;
-        float var = b / (float)HW - m * m;
+        const float m = a[e] / (float)HW;
+        float var = b[e] / (float)HW - m * m;
         var = var > 0.f ? var : 0.f;
         mu[e] = m;
         rs[e] = 1.0f / sqrtf(var + 1e-5f);
@@ -455,7 +475,7 @@ __global__ __launch_bounds__(256) void k_pool_b16(const unsigned short* __restri
 // ---- host side ------------------------------------------------------------------------------------------------------
 inline bool v2_conv(const ConvSpec& s) { return s.ks == 3 && s.stride == 1 && s.pad == 1 && s.cin % 32 == 0 && s.cout % 64 == 0; }
 inline bool g2_conv(const ConvSpec& s) { return !v2_conv(s) && s.cin % 64 == 0 && s.cout % 128 == 0; }
-inline int chunk_for(const ConvSpec& s) { return v2_conv(s) ? 32 : 64; }
+inline int chunk_for(const ConvSpec& s) { return v2_conv(s) ? 16 : 64; }
 inline size_t conv_packed_elems(const ConvSpec& s) { return (size_t)s.cout * s.cin * s.ks * s.ks; }   // bf16 elements
 
 inline bool arch_ok(const Arch& A) { return !A.bottleneck; }
@@ -492,21 +512,20 @@ inline int run_conv(hipStream_t st, const unsigned short* in, const unsigned sho
     const int pslot = dsmil_prof::begin(dsmil_prof::CH_CONV, st);
     struct ProfEnd { int slot; hipStream_t st; ~ProfEnd() { dsmil_prof::end(dsmil_prof::CH_CONV, slot, st); } } prof_end{pslot, st};
     if (v2_conv(s)) {
-        g.cin_c = 32;
-#ifdef DSMIL_EXPERIMENTS
-        static const int abl = [] { const char* e = getenv("DSMIL_B16_ABL"); return e ? atoi(e) : 0; }();
-        g.stride |= abl << 8;
-#endif
+        g.cin_c = 16;
+        const int Wp = g.Wo + 1;
         if (s.cout % 128 == 0) {
             constexpr int BMv = 256, NT = 128;
-            const size_t lds = (size_t)((((BMv + 2) * 80 + 3 * 2 * (NT / 32) * 1024) + 15) / 16 * 16);
-            allow_lds((const void*)k_conv_b16v2<BMv, NT, 2, 2>, lds);
-            hipLaunchKernelGGL((k_conv_b16v2<BMv, NT, 2, 2>), dim3((unsigned)((g.M + BMv - 1) / BMv), s.cout / NT), dim3(256), lds, st, in, wpk, out, g);
+            if ((BMv + 2 * Wp + 2) * 2 > B16W_NIA * 256) return DSMIL_E_UNSUPPORTED;        // (maps wider than ~250 pixels)
+            const size_t lds = (size_t)(((BMv + 2 * Wp + 2) * 48 + 15) / 16 * 16) + 9 * (NT / 32) * 1024;
+            allow_lds((const void*)k_conv_b16w<BMv, NT, 2, 2>, lds);
+            hipLaunchKernelGGL((k_conv_b16w<BMv, NT, 2, 2>), dim3((unsigned)((g.M + BMv - 1) / BMv), s.cout / NT), dim3(256), lds, st, in, wpk, out, g);
         } else {
             constexpr int BMv = 512, NT = 64;
-            const size_t lds = (size_t)((((BMv + 2) * 80 + 3 * 2 * (NT / 32) * 1024) + 15) / 16 * 16);
-            allow_lds((const void*)k_conv_b16v2<BMv, NT, 4, 1>, lds);
-            hipLaunchKernelGGL((k_conv_b16v2<BMv, NT, 4, 1>), dim3((unsigned)((g.M + BMv - 1) / BMv), s.cout / NT), dim3(256), lds, st, in, wpk, out, g);
+            if ((BMv + 2 * Wp + 2) * 2 > B16W_NIA * 256) return DSMIL_E_UNSUPPORTED;
+            const size_t lds = (size_t)(((BMv + 2 * Wp + 2) * 48 + 15) / 16 * 16) + 9 * (NT / 32) * 1024;
+            allow_lds((const void*)k_conv_b16w<BMv, NT, 4, 1>, lds);
+            hipLaunchKernelGGL((k_conv_b16w<BMv, NT, 4, 1>), dim3((unsigned)((g.M + BMv - 1) / BMv), s.cout / NT), dim3(256), lds, st, in, wpk, out, g);
         }
         return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
     }

@@ -370,8 +370,9 @@ int dsmil_resnet_pack_ex(int32_t depth, const float* const* conv_w, float* packe
 /* (ABI 5, round 6) precision = 2: the OPT-IN bf16-ACTIVATION trunk (csrc/resnet_b16.h; BASELINE.md's "bf16 MFMA / f32 accumulate"
  * row): behind the stem (which runs as in precision 1) every activation is stored in bf16 — NHWC with a one-pixel zero border —
  * and every conv is ONE bf16 MFMA product per MAC with f32 accumulation; InstanceNorm statistics are f32.  ResNet-18 / 34 with
- * InstanceNorm and patches of at least 64 x 64 only (everything else: DSMIL_E_UNSUPPORTED); features agree with precision 0 to
- * bf16 rounding (max ~2e-2, mean ~3e-3 on features of magnitude ~1), NOT to the 1e-4 bar; 1.55-1.6x the rate of precision 0.
+ * InstanceNorm and patches between 64 x 64 and ~1000 pixels wide only (everything else: DSMIL_E_UNSUPPORTED); features agree with
+ * precision 0 to bf16 rounding (max ~2e-2, mean ~3e-3 on features of magnitude ~1), NOT to the 1e-4 bar; 1.75-2x the rate of
+ * precision 0.
  * Its packed image is LARGER: size it with dsmil_resnet_packed_bytes_ex(depth, 2) (0 = unsupported depth / precision;
  * precision 0 / 1 = dsmil_resnet_packed_bytes).  Workspace as for the other precisions.  The reference has no such switch;
  * compute_feats.py --precision bf16 exposes it. */
