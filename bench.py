@@ -614,13 +614,15 @@ def embedder_leg(cx, precision="fp32"):
                                                    % (ACT_BYTES_PER_PATCH / 1e6, t_exec_patch * 1e6)}}
 
 
-def embedder_bf16_leg(cx):
-    """precision = "bf16" (round 6): the OPT-IN bf16-ACTIVATION trunk (dsmil_resnet_forward_ex precision 2, csrc/resnet_b16.h):
-    bf16 activations behind the stem, one bf16 MFMA product per MAC, f32 accumulation and InstanceNorm statistics — BASELINE.md's
-    "1 patch, bf16 MFMA / f32 accumulate" row.  Its own leg and tolerance, never the headline embedder."""
+def embedder_16_leg(cx, precision):
+    """The OPT-IN 16-bit-ACTIVATION trunk (round 6, csrc/resnet_b16.h): activations stored in 16 bits behind the stem, one 16-bit
+    MFMA product per MAC, f32 accumulation and InstanceNorm statistics — BASELINE.md's "1 patch, bf16 MFMA / f32 accumulate" row.
+    precision "bf16" (dsmil_resnet_forward_ex precision 2) or "half" (precision 3, fp16 activations: what `--precision half` takes on
+    a ResNet-18 / 34 InstanceNorm trunk).  Its own legs and tolerances, never the headline embedder."""
     torch, args, dev, world = cx.torch, cx.args, cx.dev, cx.world
     ic = _build_iclassifier(cx)
-    ic.embed_precision = "bf16"
+    ic.embed_precision = precision
+    f16 = precision == "half"
     Bp = args.patches
     g = torch.Generator(device=dev).manual_seed(7 + cx.rank)
     xs = [torch.rand((Bp, 3, 224, 224), generator=g, device=dev, dtype=torch.float32) for _ in range(max(1, args.streams))]
@@ -643,21 +645,24 @@ def embedder_bf16_leg(cx):
     value = world * Bp * passes / dt
     conv_flops = (FLOPS_PER_PATCH - STEM_FLOPS_PER_PATCH) * Bp          # direct-form FLOPs of the 19 convs behind the stem, per forward
     frac = conv_flops / (PEAK_BF16_MFMA_TFLOPS * 1e12) / (conv_alone_ms * 1e-3) if conv_alone_ms > 0 else None
-    return {"metric": "patches/sec embedded (ResNet-18-IN, 224x224, bs=%d), OPT-IN bf16 activations" % Bp,
+    el = "fp16" if f16 else "bf16"
+    return {"metric": "patches/sec embedded (ResNet-18-IN, 224x224, bs=%d), OPT-IN %s activations" % (Bp, el),
             "value": round(value, 1), "unit": "patches/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
             "ms_per_pass": round(dt / passes * 1e3, 3),
-            "dtype": "bf16 activations and conv operands behind the stem (one bf16 MFMA product per MAC), f32 accumulate, f32 InstanceNorm statistics",
-            "tolerance": "feature error <= 5e-2 max / 8e-3 mean abs against the fp64 restatement on features of O(1) (measured 2e-2 / "
-                         "3e-3; tests/test_resnet_gpu.py) — NOT the 1e-4 parity bar of the `embedder` leg",
+            "dtype": f"{el} activations and conv operands behind the stem (one {el} MFMA product per MAC), f32 accumulate, f32 InstanceNorm statistics",
+            "tolerance": ("feature error <= 5e-3 abs against the fp64 restatement on features of O(1) (measured 2.6e-3 max / 4.6e-4 mean; "
+                          "tests/test_resnet_gpu.py)" if f16 else
+                          "feature error <= 5e-2 max / 8e-3 mean abs against the fp64 restatement on features of O(1) (measured 2e-2 / "
+                          "3e-3; tests/test_resnet_gpu.py)") + " — NOT the 1e-4 parity bar of the `embedder` leg",
             "config": {"workload": f"IClassifier(ResNet-18 InstanceNorm, fc=Identity)+Linear(512,2), {Bp} synthetic 224x224 patches "
                                    f"per GPU per pass, kaiming(seed 11) weights", "passes_per_step": inner,
                        "timed_region_s": round(dt, 3), "streams": args.streams, "distinct_batches": len(xs)},
-            "roofline": {"kernel": "the 19 conv launches behind the stem: 13 x k_conv_b16v2 (3x3 / 1, flat padded positions) + 6 x "
-                                   "k_conv_b16g (3x3 / 2, 1x1 / 2), bf16 MFMA, one product", "bound": "mfma",
+            "roofline": {"kernel": "the 19 conv launches behind the stem: 13 x k_conv_b16w (3x3 / 1, flat positions, window staging) + 6 x "
+                                   f"k_conv_b16g (3x3 / 2, 1x1 / 2), {el} MFMA, one product", "bound": "mfma",
                          "achieved": round(conv_flops / (conv_alone_ms * 1e-3) / 1e12, 2) if conv_alone_ms > 0 else None,
                          "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(frac, 4) if frac else None,
-                         "frac_is": "direct-form FLOPs of the 19 convs / bf16 MFMA peak / their HIP-event time with one forward in flight "
-                                    "(the kernels also compute the zero border of the padded layout: 7 % of the positions at 56 x 56, 65 % at 7 x 7)",
+                         "frac_is": "direct-form FLOPs of the 19 convs / 16-bit MFMA peak / their HIP-event time with one forward in flight "
+                                    "(the kernels also compute the zero borders of the layout: 3.5 % of the positions at 56 x 56, 31 % at 7 x 7)",
                          "traffic": None, "conv_ms_per_forward": round(conv_alone_ms, 3), "launches": launches,
                          # BASELINE.md's row for this precision: 3.627 GFLOP / 2.5 PFLOP/s = 689 252 patches/s
                          "whole_path_frac_of_roofline": round(value / world / (PEAK_BF16_MFMA_TFLOPS * 1e12 / FLOPS_PER_PATCH), 4)}}
@@ -699,7 +704,7 @@ def slide_leg(cx, n_patches, n_steps=None, host=False, precision="fp32"):
     from dsmil_wsi_amd import pipeline as pl
     from dsmil_wsi_amd.synthetic import build_net
     ic = _build_iclassifier(cx)
-    ic.embed_precision = precision   # "bf16" (`slide_bf16`): the opt-in bf16-activation trunk (its tolerance: the `embedder_bf16` leg)
+    ic.embed_precision = precision   # "half" / "bf16" (`slide_half`, `slide_bf16`): the opt-in 16-bit-activation trunk (tolerances: the `embedder_half` / `embedder_bf16` legs)
     net = build_net("tcga", dev)
     lo, hi = dd.shard_range(n_patches, cx.rank, world)
     g = torch.Generator(device=dev).manual_seed(99)   # every rank draws the same slide and keeps its rows
@@ -741,7 +746,7 @@ def slide_leg(cx, n_patches, n_steps=None, host=False, precision="fp32"):
     torch.cuda.synchronize()
     out = res["out"]
     assert out[2].shape[0] == n_patches and torch.isfinite(out[1]).all()
-    return {"metric": "patches/sec, one slide %sembedded%s + gathered + aggregated" % ("copied H2D + " if host else "", " (OPT-IN bf16 activations)" if precision == "bf16" else ""),
+    return {"metric": "patches/sec, one slide %sembedded%s + gathered + aggregated" % ("copied H2D + " if host else "", " (OPT-IN %s activations)" % ("bf16" if precision == "bf16" else "fp16") if precision != "fp32" else ""),
             "value": round(n_patches * steps / dt, 1),
             "unit": "patches/s", "scaling": "strong", "ms_per_slide": round(dt / steps * 1e3, 3),
             "last_slide_ms": {"embed": round(ev[0].elapsed_time(ev[1]), 3), "all_gather": round(ev[1].elapsed_time(ev[2]), 3),
@@ -1051,7 +1056,7 @@ def _summary(line):
             e["value_one_stream"] = obj["config"]["value_one_stream"]
         out[name] = e
     put("aggregator_f32", line if line.get("unit") == "bags/s" else None)
-    for k in ("aggregator_bf16", "embedder", "embedder_half", "embedder_bf16", "train_c1", "train_c2", "slide", "slide_bf16", "slide_h2d", "slide_100k", "decode", "slide_jpeg", "e2e"):
+    for k in ("aggregator_bf16", "embedder", "embedder_half", "embedder_bf16", "train_c1", "train_c2", "slide", "slide_half", "slide_bf16", "slide_h2d", "slide_100k", "decode", "slide_jpeg", "e2e"):
         put(k, line.get(k))
     return out
 
@@ -1066,7 +1071,7 @@ def main():
     ap.add_argument("--feats", type=int, default=512)
     ap.add_argument("--patches", type=int, default=256, help="patches per rank per embedder pass (batch size)")
     ap.add_argument("--workload", default="all",
-                    help="comma list of aggregator, aggregator_bf16, embedder, embedder_half, embedder_bf16, train, slide, slide_bf16, slide_h2d, slide100k, decode, slide_jpeg, e2e; or all / both (= aggregator,embedder)")
+                    help="comma list of aggregator, aggregator_bf16, embedder, embedder_half, embedder_bf16, train, slide, slide_half, slide_bf16, slide_h2d, slide100k, decode, slide_jpeg, e2e; or all / both (= aggregator,embedder)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on each timed region")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams independent passes are dealt to (ops.StreamPool); 1 = one pass in flight")
@@ -1087,7 +1092,7 @@ def main():
                     help="skip the single-bag latency probe (profiling runs: keeps per-kernel averages clean)")
     args = ap.parse_args()
     maybe_self_launch(args)
-    wl = {"all": "aggregator,aggregator_bf16,embedder,embedder_half,embedder_bf16,train,slide,slide_bf16,slide_h2d,slide100k,decode,slide_jpeg,e2e", "both": "aggregator,embedder"}.get(args.workload, args.workload)
+    wl = {"all": "aggregator,aggregator_bf16,embedder,embedder_half,embedder_bf16,train,slide,slide_half,slide_bf16,slide_h2d,slide100k,decode,slide_jpeg,e2e", "both": "aggregator,embedder"}.get(args.workload, args.workload)
     wl = [w for w in wl.split(",") if w]
     cx = Ctx(args)
     line = {}
@@ -1102,12 +1107,14 @@ def main():
     if "embedder" in wl:
         subs["embedder"] = embedder_leg(cx)
     if "embedder_half" in wl:   # OPT-IN reduced precision (BASELINE.md §2, row "bf16 MFMA / f32 accumulate"): its own leg and tolerance
-        subs["embedder_half"] = embedder_leg(cx, precision="half")
+        subs["embedder_half"] = embedder_16_leg(cx, "half")
     if "embedder_bf16" in wl:   # OPT-IN bf16-activation trunk (round 6): its own leg and tolerance
-        subs["embedder_bf16"] = embedder_bf16_leg(cx)
+        subs["embedder_bf16"] = embedder_16_leg(cx, "bf16")
     if "slide" in wl:
         subs["slide"] = slide_leg(cx, args.slide_patches)
-    if "slide_bf16" in wl:   # the `slide` leg on the opt-in bf16-activation trunk (round 6)
+    if "slide_half" in wl:   # the `slide` leg on the opt-in fp16-activation trunk (round 6: what --precision half takes)
+        subs["slide_half"] = slide_leg(cx, args.slide_patches, precision="half")
+    if "slide_bf16" in wl:   # ... and on bf16 activations
         subs["slide_bf16"] = slide_leg(cx, args.slide_patches, precision="bf16")
     if "slide_h2d" in wl:
         subs["slide_h2d"] = slide_leg(cx, args.slide_patches, host=True)

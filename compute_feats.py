@@ -46,10 +46,10 @@ def build_parser():
                         "tile_size^2 > T, the criterion deepzoom_tiler.py:56-61 applies while tiling (its -t, 15); "
                         "single-magnification bags only")
     p.add_argument("--precision", default="fp32", choices=("fp32", "half", "bf16"),
-                   help="(new, default fp32 = the parity path) half: the native trunk rounds every conv operand to one fp16 "
-                        "plane (f32 accumulation, fp32 norms): ~2e-3 feature error, 1.2x; bf16: bf16 ACTIVATIONS behind the stem, one "
-                        "bf16 MFMA product per MAC (ResNet-18 / 34 with InstanceNorm): ~2e-2 feature error, 1.6x; the reference "
-                        "has no such switch")
+                   help="(new, default fp32 = the parity path) half: fp16 ACTIVATIONS behind the stem, one fp16 MFMA product per "
+                        "MAC, f32 accumulation and norm statistics (ResNet-18 / 34 with InstanceNorm; other trunks: fp32 activations, "
+                        "one fp16 plane per conv operand): ~2.6e-3 feature error, 2x; bf16: the same trunk on bf16 activations "
+                        "(fp32's range): ~2e-2; the reference has no such switch")
     p.add_argument("--gpu_decode", action="store_true",
                    help="(new, default off) decode the tiles' JPEG files on the GPU (dsmil_jpeg_decode: baseline JPEGs, bit-identical to "
                         "Pillow; other files take Pillow inside the same call) instead of in --num_workers DataLoader processes "

@@ -147,6 +147,8 @@ SIGNATURES = {
                                          ctypes.c_size_t, ctypes.c_void_p]),
 }
 
+DSMIL_E_UNSUPPORTED = -2    # include/dsmil_hip.h
+
 _lib = None
 
 

@@ -58,15 +58,35 @@ constexpr int B16W_NIA = 6;     // k_conv_b16w: 16-B window pieces per thread: (
 // positions of a [B][H][W] map in the shared-border layout (see the header): (H+1)(W+1) per image + one closing zero row
 __host__ __device__ __forceinline__ long long npos(int B, int H, int W) { return (long long)B * (H + 1) * (W + 1) + (W + 1); }
 
-__device__ __forceinline__ unsigned f2bf(float f) {           // round to nearest even (no NaN handling: the inputs are finite)
-    const unsigned u = __float_as_uint(f);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+// 16-bit element type of the trunk: bf16 (F16 = false: fp32's range, 8 significant bits) or fp16 (F16 = true: 11 significant bits,
+// values must stay inside +-65504 — InstanceNorm outputs and the conv sums of ordinary weights do; the binding checks the first
+// forward of a weight set for non-finite features).  Same kernels, same layout, same MFMA rate.
+template <bool F16>
+__device__ __forceinline__ unsigned cvt16(float f) {          // round to nearest even (no NaN handling: the inputs are finite)
+    if constexpr (F16) {
+        const _Float16 h = (_Float16)f;
+        return (unsigned)__builtin_bit_cast(unsigned short, h);
+    } else {
+        const unsigned u = __float_as_uint(f);
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    }
 }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
-__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+template <bool F16> __device__ __forceinline__ unsigned pack2(float lo, float hi) { return cvt16<F16>(lo) | (cvt16<F16>(hi) << 16); }
+template <bool F16> __device__ __forceinline__ float el_lo(unsigned w) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu));
+    else return __uint_as_float(w << 16);
+}
+template <bool F16> __device__ __forceinline__ float el_hi(unsigned w) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+    else return __uint_as_float(w & 0xffff0000u);
+}
+template <bool F16> __device__ __forceinline__ f32x16 mfma16(const u32x4_t& a, const u32x4_t& b, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
 
 // fp32 NHWC [B][H][W][C] (the stem's normalised, pooled output) -> the bf16 shared-border layout
+template <bool F16>
 __global__ __launch_bounds__(256) void k_b16_pad(const float* __restrict__ x, unsigned short* __restrict__ out, int B, int H, int W, int C) {
     const int oc = C >> 3;
     const long long total = npos(B, H, W) * oc;
@@ -81,7 +101,7 @@ __global__ __launch_bounds__(256) void k_b16_pad(const float* __restrict__ x, un
         if (n < B && yy >= 1 && xx < W) {
             const float* s = x + (((long long)n * H + yy - 1) * W + xx) * C + o * 8;
             const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
-            v = u32x4_t{pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(b[0], b[1]), pack2(b[2], b[3])};
+            v = u32x4_t{pack2<F16>(a[0], a[1]), pack2<F16>(a[2], a[3]), pack2<F16>(b[0], b[1]), pack2<F16>(b[2], b[3])};
         }
         *reinterpret_cast<u32x4_t*>(out + q * C + o * 8) = v;
     }
@@ -109,6 +129,7 @@ __global__ __launch_bounds__(256) void k_b16_borders(unsigned short* __restrict_
 
 // OIHW fp32 -> bf16 MFMA B-operand fragments: [chunk][tap][k-step of 16][32-cout block][lane][8]: lane l holds output channel
 // 32 nb + (l & 31), input channels chunk cin_c + 16 ks + 8 (l >> 5) + e
+template <bool F16>
 __global__ void k_pack_b16(const float* __restrict__ w, unsigned short* __restrict__ out, int O, int I, int ks, int cin_c) {
     const int ntap = ks * ks, ksteps = cin_c / 16, nb_tot = O / 32, nchunk = I / cin_c;
     const long long total = (long long)nchunk * ntap * ksteps * nb_tot * 64 * 8;
@@ -120,7 +141,7 @@ __global__ void k_pack_b16(const float* __restrict__ w, unsigned short* __restri
         const int tap = (int)(r % ntap);
         const int chunk = (int)(r / ntap);
         const int co = nb * 32 + (lane & 31), ci = chunk * cin_c + kst * 16 + (lane >> 5) * 8 + e;
-        out[i] = (unsigned short)f2bf(w[((long long)co * I + ci) * ntap + tap]);
+        out[i] = (unsigned short)cvt16<F16>(w[((long long)co * I + ci) * ntap + tap]);
     }
 }
 
@@ -130,7 +151,7 @@ __global__ void k_pack_b16(const float* __restrict__ w, unsigned short* __restri
 //      the CU's port ~1.2-1.5x instead of 3x, a conv has Cin / 16 stages instead of 3 Cin / 32, and a stage holds 72 MFMAs per
 //      wave instead of 48 for its staging loads to land under.  Tap (dy, dx) of output m is window position m + dy (W+1) + dx.
 //      Weight image: k_pack_b16 with cin_c = 16 ([chunk16][tap][1][Cout / 32][64][8]).
-template <int BMv, int NT, int WM, int WN>
+template <int BMv, int NT, int WM, int WN, bool F16>
 __global__ __launch_bounds__(256, 2) void k_conv_b16w(const unsigned short* __restrict__ in, const unsigned short* __restrict__ wpk,
                                                       unsigned short* __restrict__ out, ConvGeo g) {
     static_assert(WM * WN == 4 && BMv == WM * 128 && NT == WN * 64, "wave tile 128 positions x 64 channels");
@@ -214,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_b16w(const unsigned short* __re
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[a][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[a]), __builtin_bit_cast(bf16x8_t, bf[j]), acc[a][j], 0, 0, 0);
+                    acc[a][j] = mfma16<F16>(af[a], bf[j], acc[a][j]);
         }
     }
 #pragma unroll
@@ -227,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_b16w(const unsigned short* __re
                 const bool inside = s_int[m] != 0;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    out[q * g.Cout + (nb_wg + wn * 2 + j) * 32 + l31] = inside ? (unsigned short)f2bf(acc[a][j][i]) : (unsigned short)0;
+                    out[q * g.Cout + (nb_wg + wn * 2 + j) * 32 + l31] = inside ? (unsigned short)cvt16<F16>(acc[a][j][i]) : (unsigned short)0;
             }
         }
 }
@@ -235,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_b16w(const unsigned short* __re
 // ---- strided convolutions (3 x 3 / 2, 1 x 1 / 2) in the same two-workgroups-per-CU form: stage = (64-channel chunk, tap), the
 //      256 positions of the workgroup gathered through per-position offsets (144 B per position: 128 B + 16 B pad), the tap's
 //      weight fragments of 128 output channels; 128 x 64 wave tiles.  Weight image: k_pack_b16 with cin_c = 64.
+template <bool F16>
 __global__ __launch_bounds__(256, 2) void k_conv_b16g(const unsigned short* __restrict__ in, const unsigned short* __restrict__ wpk,
                                                       unsigned short* __restrict__ out, ConvGeo g) {
     constexpr int BMv = 256, NT = 128, ROWB = 144, A_BYTES = BMv * ROWB, NIA = 8, NIB = 4;
@@ -311,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_b16g(const unsigned short* __re
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[a][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[a]), __builtin_bit_cast(bf16x8_t, bf[j]), acc[a][j], 0, 0, 0);
+                    acc[a][j] = mfma16<F16>(af[a], bf[j], acc[a][j]);
         }
     }
 #pragma unroll
@@ -324,12 +346,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_b16g(const unsigned short* __re
                 const bool inside = s_int[m] != 0;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    out[q * g.Cout + (nb_wg + wn * 2 + j) * 32 + l31] = inside ? (unsigned short)f2bf(acc[a][j][i]) : (unsigned short)0;
+                    out[q * g.Cout + (nb_wg + wn * 2 + j) * 32 + l31] = inside ? (unsigned short)cvt16<F16>(acc[a][j][i]) : (unsigned short)0;
             }
         }
 }
 
 // ---- InstanceNorm statistics: partial (sum, sum of squares) per (image, pixel chunk, channel), f32, fixed order
+template <bool F16>
 __global__ __launch_bounds__(256) void k_stats_b16(const unsigned short* __restrict__ x, float* __restrict__ part, int H, int W, int C, int S) {
     __shared__ float sh[2][2048];
     const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
@@ -353,7 +376,7 @@ __global__ __launch_bounds__(256) void k_stats_b16(const unsigned short* __restr
             if (p0 + k * PL < p_hi) {
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const float a = bf_lo(v[k][d]), b = bf_hi(v[k][d]);
+                    const float a = el_lo<F16>(v[k][d]), b = el_hi<F16>(v[k][d]);
                     sm[2 * d] += a; sq[2 * d] = fmaf(a, a, sq[2 * d]);
                     sm[2 * d + 1] += b; sq[2 * d + 1] = fmaf(b, b, sq[2 * d + 1]);
                 }
@@ -408,7 +431,7 @@ __device__ __forceinline__ void b16_stats8(const float* __restrict__ part, int n
 }
 
 // ---- y = [relu]( (x - mean) rstd [+ identity] ) on every padded position of an image (border -> 0), in place or not
-template <bool RES, bool RELU>
+template <bool RES, bool RELU, bool F16>
 __global__ __launch_bounds__(256) void k_apply_b16(const unsigned short* x, const unsigned short* __restrict__ idn,
                                                    unsigned short* y, const float* __restrict__ part, int H, int W, int C, int S) {   // (x may be y)
     const int n = blockIdx.y, tid = threadIdx.x;
@@ -437,16 +460,17 @@ __global__ __launch_bounds__(256) void k_apply_b16(const unsigned short* x, cons
         u32x4_t out = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            float a = (bf_lo(v[it][d]) - mu[2 * d]) * rs[2 * d], b = (bf_hi(v[it][d]) - mu[2 * d + 1]) * rs[2 * d + 1];
-            if constexpr (RES) { a += bf_lo(iv[it][d]); b += bf_hi(iv[it][d]); }
+            float a = (el_lo<F16>(v[it][d]) - mu[2 * d]) * rs[2 * d], b = (el_hi<F16>(v[it][d]) - mu[2 * d + 1]) * rs[2 * d + 1];
+            if constexpr (RES) { a += el_lo<F16>(iv[it][d]); b += el_hi<F16>(iv[it][d]); }
             if constexpr (RELU) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
-            out[d] = inside[it] ? pack2(a, b) : 0u;
+            out[d] = inside[it] ? pack2<F16>(a, b) : 0u;
         }
         if (live[it]) *reinterpret_cast<u32x4_t*>(y + eo[it]) = out;
     }
 }
 
 // ---- last block: feats[n][c] = mean over pixels of relu((x - mean) rstd + identity)   (dsmil.py:21-23's flatten(avgpool))
+template <bool F16>
 __global__ __launch_bounds__(256) void k_pool_b16(const unsigned short* __restrict__ x, const unsigned short* __restrict__ idn,
                                                   const float* __restrict__ part, float* __restrict__ feats, int H, int W, int C, int S) {
     const int n = blockIdx.y, c = (int)blockIdx.x * 256 + threadIdx.x;
@@ -466,7 +490,7 @@ __global__ __launch_bounds__(256) void k_pool_b16(const unsigned short* __restri
     for (int yy = 1; yy <= H; ++yy)
         for (int xx = 0; xx < W; ++xx) {
             const long long eo = (((long long)n * (H + 1) + yy) * (W + 1) + xx) * C + c;
-            const float v = (__uint_as_float((unsigned)x[eo] << 16) - m) * r + __uint_as_float((unsigned)idn[eo] << 16);
+            const float v = (el_lo<F16>((unsigned)x[eo]) - m) * r + el_lo<F16>((unsigned)idn[eo]);
             acc += fmaxf(v, 0.f);
         }
     feats[(long long)n * C + c] = acc / (float)HW;
@@ -489,15 +513,17 @@ inline size_t pack_off(const Arch& A, int ci) {   // bytes
     for (int i = 1; i < ci; ++i) e += (conv_packed_elems(A.specs[i]) + 127) & ~(size_t)127;
     return e * 2;
 }
-inline int pack_all(const Arch& A, const float* const* conv_w, unsigned short* dst, hipStream_t st) {
+inline int pack_all(const Arch& A, const float* const* conv_w, unsigned short* dst, hipStream_t st, bool f16) {
     for (int i = 1; i < A.nconv; ++i) {
         const ConvSpec& s = A.specs[i];
         if (!v2_conv(s) && !g2_conv(s)) return DSMIL_E_UNSUPPORTED;
-        hipLaunchKernelGGL(k_pack_b16, dim3(512), dim3(256), 0, st, conv_w[i], (unsigned short*)((char*)dst + pack_off(A, i)), s.cout, s.cin, s.ks, chunk_for(s));
+        if (f16) hipLaunchKernelGGL(k_pack_b16<true>, dim3(512), dim3(256), 0, st, conv_w[i], (unsigned short*)((char*)dst + pack_off(A, i)), s.cout, s.cin, s.ks, chunk_for(s));
+        else hipLaunchKernelGGL(k_pack_b16<false>, dim3(512), dim3(256), 0, st, conv_w[i], (unsigned short*)((char*)dst + pack_off(A, i)), s.cout, s.cin, s.ks, chunk_for(s));
     }
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
+template <bool F16>
 inline int run_conv(hipStream_t st, const unsigned short* in, const unsigned short* wpk, unsigned short* out, int B, int Hi, int Wi, const ConvSpec& s, int* Ho_, int* Wo_) {
     ConvGeo g;
     g.B = B; g.Hi = Hi; g.Wi = Wi; g.Cin = s.cin; g.Cout = s.cout; g.ks = s.ks; g.stride = s.stride;
@@ -518,22 +544,22 @@ inline int run_conv(hipStream_t st, const unsigned short* in, const unsigned sho
             constexpr int BMv = 256, NT = 128;
             if ((BMv + 2 * Wp + 2) * 2 > B16W_NIA * 256) return DSMIL_E_UNSUPPORTED;        // (maps wider than ~250 pixels)
             const size_t lds = (size_t)(((BMv + 2 * Wp + 2) * 48 + 15) / 16 * 16) + 9 * (NT / 32) * 1024;
-            allow_lds((const void*)k_conv_b16w<BMv, NT, 2, 2>, lds);
-            hipLaunchKernelGGL((k_conv_b16w<BMv, NT, 2, 2>), dim3((unsigned)((g.M + BMv - 1) / BMv), s.cout / NT), dim3(256), lds, st, in, wpk, out, g);
+            allow_lds((const void*)k_conv_b16w<BMv, NT, 2, 2, F16>, lds);
+            hipLaunchKernelGGL((k_conv_b16w<BMv, NT, 2, 2, F16>), dim3((unsigned)((g.M + BMv - 1) / BMv), s.cout / NT), dim3(256), lds, st, in, wpk, out, g);
         } else {
             constexpr int BMv = 512, NT = 64;
             if ((BMv + 2 * Wp + 2) * 2 > B16W_NIA * 256) return DSMIL_E_UNSUPPORTED;
             const size_t lds = (size_t)(((BMv + 2 * Wp + 2) * 48 + 15) / 16 * 16) + 9 * (NT / 32) * 1024;
-            allow_lds((const void*)k_conv_b16w<BMv, NT, 4, 1>, lds);
-            hipLaunchKernelGGL((k_conv_b16w<BMv, NT, 4, 1>), dim3((unsigned)((g.M + BMv - 1) / BMv), s.cout / NT), dim3(256), lds, st, in, wpk, out, g);
+            allow_lds((const void*)k_conv_b16w<BMv, NT, 4, 1, F16>, lds);
+            hipLaunchKernelGGL((k_conv_b16w<BMv, NT, 4, 1, F16>), dim3((unsigned)((g.M + BMv - 1) / BMv), s.cout / NT), dim3(256), lds, st, in, wpk, out, g);
         }
         return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
     }
     if (g2_conv(s) && g.Min * s.cin < 0x7fffffffLL) {
         g.cin_c = 64;
         const size_t lds = 256 * 144 + 4 * 4 * 1024;
-        allow_lds((const void*)k_conv_b16g, lds);
-        hipLaunchKernelGGL(k_conv_b16g, dim3((unsigned)((g.M + 255) / 256), s.cout / 128), dim3(256), lds, st, in, wpk, out, g);
+        allow_lds((const void*)k_conv_b16g<F16>, lds);
+        hipLaunchKernelGGL(k_conv_b16g<F16>, dim3((unsigned)((g.M + 255) / 256), s.cout / 128), dim3(256), lds, st, in, wpk, out, g);
         return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
     }
     return DSMIL_E_UNSUPPORTED;   // (every conv of a BasicBlock trunk is one of the two forms above)
@@ -541,17 +567,19 @@ inline int run_conv(hipStream_t st, const unsigned short* in, const unsigned sho
 
 inline int stat_chunks(int HW) { return HW >= 2048 ? 8 : HW >= 512 ? 4 : HW >= 128 ? 2 : 1; }
 
+template <bool F16>
 inline int run_stats(hipStream_t st, const unsigned short* x, float* part, int B, int H, int W, int C) {
     const int S = stat_chunks(H * W);
-    hipLaunchKernelGGL(k_stats_b16, dim3((unsigned)S, (unsigned)B), dim3(256), 0, st, x, part, H, W, C, S);
+    hipLaunchKernelGGL(k_stats_b16<F16>, dim3((unsigned)S, (unsigned)B), dim3(256), 0, st, x, part, H, W, C, S);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
+template <bool F16>
 inline int run_apply(hipStream_t st, const unsigned short* x, const unsigned short* idn, unsigned short* y, const float* part, int B, int H, int W, int C, bool relu) {
     const int S = stat_chunks(H * W), PL = 256 / (C / 8), PP = (H + 1) * (W + 1);
     const dim3 grid((unsigned)((PP + PL * 8 - 1) / (PL * 8)), (unsigned)B);
-    if (idn) hipLaunchKernelGGL((k_apply_b16<true, true>), grid, dim3(256), 0, st, x, idn, y, part, H, W, C, S);
-    else if (relu) hipLaunchKernelGGL((k_apply_b16<false, true>), grid, dim3(256), 0, st, x, idn, y, part, H, W, C, S);
-    else hipLaunchKernelGGL((k_apply_b16<false, false>), grid, dim3(256), 0, st, x, idn, y, part, H, W, C, S);
+    if (idn) hipLaunchKernelGGL((k_apply_b16<true, true, F16>), grid, dim3(256), 0, st, x, idn, y, part, H, W, C, S);
+    else if (relu) hipLaunchKernelGGL((k_apply_b16<false, true, F16>), grid, dim3(256), 0, st, x, idn, y, part, H, W, C, S);
+    else hipLaunchKernelGGL((k_apply_b16<false, false, F16>), grid, dim3(256), 0, st, x, idn, y, part, H, W, C, S);
     return hipGetLastError() == hipSuccess ? DSMIL_OK : DSMIL_E_LAUNCH;
 }
 
@@ -562,7 +590,8 @@ inline size_t scratch_bytes(int B, int Hp, int Wp) { return 4 * act_bytes(B, Hp,
 
 // The trunk behind the stem.  x0: the stem's normalised pooled output, fp32 NHWC [B][Hp][Wp][64] — or nullptr when the stem
 // has already written it as bf16 into the first activation buffer (k_pool_fix_norm); scratch: scratch_bytes().
-inline int trunk(hipStream_t st, const Arch& A, const float* x0, const unsigned short* wpk, void* scratch, int B, int Hp, int Wp, float* feats) {
+template <bool F16>
+inline int trunk_t(hipStream_t st, const Arch& A, const float* x0, const unsigned short* wpk, void* scratch, int B, int Hp, int Wp, float* feats) {
     char* s8 = (char*)scratch;
     const size_t ab = act_bytes(B, Hp, Wp);
     unsigned short* bufs[4];
@@ -576,7 +605,7 @@ inline int trunk(hipStream_t st, const Arch& A, const float* x0, const unsigned 
         const long long total = npos(B, Hp, Wp) * 8;
         long long blocks = (total + 255) / 256;
         if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(k_b16_pad, dim3((unsigned)blocks), dim3(256), 0, st, x0, cur, B, Hp, Wp, 64);
+        hipLaunchKernelGGL(k_b16_pad<F16>, dim3((unsigned)blocks), dim3(256), 0, st, x0, cur, B, Hp, Wp, 64);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
     } else {   // the stem's k_pool_fix_norm wrote the interior of `cur`: its borders
         const long long total = ((long long)B * (Wp + 1 + Hp) + Wp + 1) * 8;
@@ -591,29 +620,29 @@ inline int trunk(hipStream_t st, const Arch& A, const float* x0, const unsigned 
             const ConvSpec& s2 = A.specs[ci + 1];
             int Ho, Wo, H2, W2, rc;
             // conv1 -> IN -> ReLU (in place)
-            if ((rc = run_conv(st, cur, (const unsigned short*)((const char*)wpk + pack_off(A, ci)), r1, B, Hc, Wc, s1, &Ho, &Wo))) return rc;
-            if ((rc = run_stats(st, r1, part, B, Ho, Wo, s1.cout))) return rc;
-            if ((rc = run_apply(st, r1, nullptr, r1, part, B, Ho, Wo, s1.cout, true))) return rc;
+            if ((rc = run_conv<F16>(st, cur, (const unsigned short*)((const char*)wpk + pack_off(A, ci)), r1, B, Hc, Wc, s1, &Ho, &Wo))) return rc;
+            if ((rc = run_stats<F16>(st, r1, part, B, Ho, Wo, s1.cout))) return rc;
+            if ((rc = run_apply<F16>(st, r1, nullptr, r1, part, B, Ho, Wo, s1.cout, true))) return rc;
             // downsample branch: 1x1 stride 2 -> IN (no ReLU), in place
             const unsigned short* idn = cur;
             if (down) {
                 const ConvSpec& sd = A.specs[ci + 2];
                 int Hd, Wd;
-                if ((rc = run_conv(st, cur, (const unsigned short*)((const char*)wpk + pack_off(A, ci + 2)), rd, B, Hc, Wc, sd, &Hd, &Wd))) return rc;
+                if ((rc = run_conv<F16>(st, cur, (const unsigned short*)((const char*)wpk + pack_off(A, ci + 2)), rd, B, Hc, Wc, sd, &Hd, &Wd))) return rc;
                 if (Hd != Ho || Wd != Wo) return DSMIL_E_UNSUPPORTED;
-                if ((rc = run_stats(st, rd, part, B, Hd, Wd, sd.cout))) return rc;
-                if ((rc = run_apply(st, rd, nullptr, rd, part, B, Hd, Wd, sd.cout, false))) return rc;
+                if ((rc = run_stats<F16>(st, rd, part, B, Hd, Wd, sd.cout))) return rc;
+                if ((rc = run_apply<F16>(st, rd, nullptr, rd, part, B, Hd, Wd, sd.cout, false))) return rc;
                 idn = rd;
             }
             // conv2 -> IN, + identity, ReLU
-            if ((rc = run_conv(st, r1, (const unsigned short*)((const char*)wpk + pack_off(A, ci + 1)), r2, B, Ho, Wo, s2, &H2, &W2))) return rc;
-            if ((rc = run_stats(st, r2, part, B, H2, W2, s2.cout))) return rc;
+            if ((rc = run_conv<F16>(st, r1, (const unsigned short*)((const char*)wpk + pack_off(A, ci + 1)), r2, B, Ho, Wo, s2, &H2, &W2))) return rc;
+            if ((rc = run_stats<F16>(st, r2, part, B, H2, W2, s2.cout))) return rc;
             if (last) {
                 const int S = stat_chunks(H2 * W2);
-                hipLaunchKernelGGL(k_pool_b16, dim3((unsigned)((s2.cout + 255) / 256), (unsigned)B), dim3(256), 0, st, r2, idn, part, feats, H2, W2, s2.cout, S);
+                hipLaunchKernelGGL(k_pool_b16<F16>, dim3((unsigned)((s2.cout + 255) / 256), (unsigned)B), dim3(256), 0, st, r2, idn, part, feats, H2, W2, s2.cout, S);
                 if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
             } else {
-                if ((rc = run_apply(st, r2, idn, r2, part, B, H2, W2, s2.cout, true))) return rc;
+                if ((rc = run_apply<F16>(st, r2, idn, r2, part, B, H2, W2, s2.cout, true))) return rc;
                 unsigned short* t = cur; cur = r2; r2 = t;     // the block's output becomes the next input; its old input is free
             }
             ci += down ? 3 : 2;
@@ -621,6 +650,10 @@ inline int trunk(hipStream_t st, const Arch& A, const float* x0, const unsigned 
         }
     }
     return DSMIL_OK;
+}
+
+inline int trunk(hipStream_t st, const Arch& A, const float* x0, const unsigned short* wpk, void* scratch, int B, int Hp, int Wp, float* feats, bool f16) {
+    return f16 ? trunk_t<true>(st, A, x0, wpk, scratch, B, Hp, Wp, feats) : trunk_t<false>(st, A, x0, wpk, scratch, B, Hp, Wp, feats);
 }
 
 }  // namespace b16

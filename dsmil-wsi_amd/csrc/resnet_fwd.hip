@@ -1784,7 +1784,8 @@ __global__ __launch_bounds__(512, 2) void k_stem_s6(const void* __restrict__ xin
 // fp32 in place — the trunk's first conv reads it as it is
 __global__ __launch_bounds__(256) void k_pool_fix_norm(float* __restrict__ p, const float* __restrict__ halo,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                       int B, int Hp, int Wp, int Wo, int tiles_y, unsigned short* __restrict__ b16 = nullptr) {
+                                                       int B, int Hp, int Wp, int Wo, int tiles_y, unsigned short* __restrict__ b16 = nullptr,
+                                                       int b16_is_f16 = 0) {
     const int c4 = threadIdx.x & 15;
     const unsigned np = (unsigned)B * Hp * Wp;
     for (unsigned pp = blockIdx.x * 16 + threadIdx.x / 16; pp < np; pp += gridDim.x * 16) {
@@ -1810,7 +1811,11 @@ __global__ __launch_bounds__(256) void k_pool_fix_norm(float* __restrict__ p, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) m[e] = fmaxf((m[e] - mu[e]) * rs[e], 0.f);
         if (b16) {
-            auto bf = [](float f) { const unsigned u = __float_as_uint(f); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };   // RNE
+            auto bf = [&](float f) -> unsigned {   // RNE to bf16, or to fp16 (the fp16-activation trunk)
+                if (b16_is_f16) { const _Float16 h = (_Float16)f; return (unsigned)__builtin_bit_cast(unsigned short, h); }
+                const unsigned u = __float_as_uint(f);
+                return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+            };
             const size_t q = ((size_t)n * (Hp + 1) + py + 1) * (Wp + 1) + px;
             unsigned* d = reinterpret_cast<unsigned*>(b16 + q * 64 + c4 * 4);
             d[0] = bf(m[0]) | (bf(m[1]) << 16);
@@ -2048,7 +2053,7 @@ inline void allow_lds(const void* kern, size_t bytes) { (void)dsmil_lds::allow(k
 // Needs Arch / ConvSpec / allow_lds, lives in namespace b16.
 #include "resnet_b16.h"
 namespace {
-thread_local bool g_b16_trunk = false;    // precision = 2 on THIS host thread: one-plane stem, then b16::trunk
+thread_local int g_b16_trunk = 0;    // precision 2 / 3 on THIS host thread: one-plane stem, then b16::trunk on bf16 (1) / fp16 (2) activations
 inline bool stem_fuse() {   // expt builds: DSMIL_STEM_FUSE=0 keeps the stem + k_norm_relu_maxpool pair (A/B, bit-identity test)
 #ifdef DSMIL_EXPERIMENTS
     static const int off = [] { const char* e = getenv("DSMIL_STEM_FUSE"); return (e && !strcmp(e, "0")) ? 1 : 0; }();
@@ -2712,7 +2717,7 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
         b16_halo_bytes = al256((size_t)B * ty * d.W1 * 64 * sizeof(float));
         b16_direct = g_b16_trunk && fuse && b16_halo_bytes + b16::scratch_bytes(B, d.Hp, d.Wp) <= L.buf[0] - L.y0;
         if (fuse) hipLaunchKernelGGL(k_pool_fix_norm, dim3((unsigned)blocks), dim3(256), 0, st, buf[0], y0, mean[0], rstd[0],
-                                     B, d.Hp, d.Wp, d.W1, ty, b16_direct ? (unsigned short*)(w8 + L.y0 + b16_halo_bytes) : (unsigned short*)nullptr);
+                                     B, d.Hp, d.Wp, d.W1, ty, b16_direct ? (unsigned short*)(w8 + L.y0 + b16_halo_bytes) : (unsigned short*)nullptr, g_b16_trunk == 2 ? 1 : 0);
         else hipLaunchKernelGGL(k_norm_relu_maxpool, dim3((unsigned)blocks), dim3(256), 0, st, y0, mean[0], rstd[0],
                                 buf[0], B, d.H1, d.W1, d.Hp, d.Wp, 64);
         if (hipGetLastError() != hipSuccess) return DSMIL_E_LAUNCH;
@@ -2725,7 +2730,7 @@ static int resnet18in_forward_impl(const void* x_nchw, bool u8, int32_t B, int32
         if (b16::scratch_bytes(B, d.Hp, d.Wp) > L.buf[0] - L.y0) return DSMIL_E_UNSUPPORTED;
         const unsigned short* wpk16 = (const unsigned short*)((const char*)packed + dsmil_resnet_packed_bytes(depth));
         // (b16_direct: k_pool_fix_norm has already written the trunk's input, bf16, behind the halo rows)
-        const int rc = b16::trunk(st, A, b16_direct ? nullptr : buf[0], wpk16, w8 + L.y0 + (b16_direct ? b16_halo_bytes : 0), B, d.Hp, d.Wp, feats);
+        const int rc = b16::trunk(st, A, b16_direct ? nullptr : buf[0], wpk16, w8 + L.y0 + (b16_direct ? b16_halo_bytes : 0), B, d.Hp, d.Wp, feats, g_b16_trunk == 2);
         if (rc != DSMIL_OK) return rc;
         if (classes) return dsmil_fc_forward(feats, B, A.feat, C, fc_w, fc_b, classes, stream);
         return DSMIL_OK;
@@ -2829,29 +2834,29 @@ int dsmil_resnet_forward(int32_t depth, const void* x, int32_t x_is_u8_nhwc, int
 // precision 2 = the bf16-activation trunk (its packed image is larger)
 size_t dsmil_resnet_packed_bytes_ex(int32_t depth, int32_t precision) {
     const Arch* A = arch_of(depth);
-    if (!A || precision < 0 || precision > 2) return 0;
-    if (precision == 2) return b16::arch_ok(*A) ? dsmil_resnet_packed_bytes(depth) + b16::packed_bytes(*A) : 0;
+    if (!A || precision < 0 || precision > 3) return 0;
+    if (precision >= 2) return b16::arch_ok(*A) ? dsmil_resnet_packed_bytes(depth) + b16::packed_bytes(*A) : 0;
     return dsmil_resnet_packed_bytes(depth);
 }
 
 int dsmil_resnet_pack_ex(int32_t depth, const float* const* conv_w, float* packed, int32_t precision, void* stream) {
-    if (precision < 0 || precision > 2) return DSMIL_E_INVALID;
+    if (precision < 0 || precision > 3) return DSMIL_E_INVALID;
     FormOverride fo(precision >= 1 ? 1 : 0);
     const int rc = dsmil_resnet_pack(depth, conv_w, packed, stream);
-    if (rc != DSMIL_OK || precision != 2) return rc;
+    if (rc != DSMIL_OK || precision < 2) return rc;
     const Arch* A = arch_of(depth);
     if (!b16::arch_ok(*A)) return DSMIL_E_UNSUPPORTED;
-    return b16::pack_all(*A, conv_w, (unsigned short*)((char*)packed + dsmil_resnet_packed_bytes(depth)), (hipStream_t)stream);
+    return b16::pack_all(*A, conv_w, (unsigned short*)((char*)packed + dsmil_resnet_packed_bytes(depth)), (hipStream_t)stream, precision == 3);
 }
 
 int dsmil_resnet_forward_ex(int32_t depth, const void* x, int32_t x_is_u8_nhwc, int32_t B, int32_t H, int32_t W,
                             const float* conv1_w, const float* packed, const float* bn_mean, const float* bn_rstd,
                             const float* fc_w, const float* fc_b, int32_t C, float* feats, float* classes, void* ws,
                             size_t ws_bytes, int32_t precision, void* stream) {
-    if (precision < 0 || precision > 2) return DSMIL_E_INVALID;
-    if (precision == 2 && (bn_mean || bn_rstd)) return DSMIL_E_UNSUPPORTED;
+    if (precision < 0 || precision > 3) return DSMIL_E_INVALID;
+    if (precision >= 2 && (bn_mean || bn_rstd)) return DSMIL_E_UNSUPPORTED;
     FormOverride fo(precision >= 1 ? 1 : 0);
-    struct B16Flag { bool saved; explicit B16Flag(bool on) : saved(g_b16_trunk) { g_b16_trunk = on; } ~B16Flag() { g_b16_trunk = saved; } } bf(precision == 2);
+    struct B16Flag { int saved; explicit B16Flag(int v) : saved(g_b16_trunk) { g_b16_trunk = v; } ~B16Flag() { g_b16_trunk = saved; } } bf(precision >= 2 ? precision - 1 : 0);
     return dsmil_resnet_forward(depth, x, x_is_u8_nhwc, B, H, W, conv1_w, packed, bn_mean, bn_rstd, fc_w, fc_b, C, feats, classes,
                                 ws, ws_bytes, stream);
 }

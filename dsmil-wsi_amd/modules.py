@@ -53,8 +53,8 @@ class IClassifier(nn.Module):
         self.feature_extractor = feature_extractor
         self.fc = nn.Linear(feature_size, output_class)
         # not part of the reference API: "fp32" (the parity path), "half" or "bf16" — OPT-IN reduced precisions of the native
-        # trunk (one fp16 plane per conv operand, ~2e-3 feature error; bf16 activations behind the stem, ~2e-2:
-        # ops.resnet18in_forward)
+        # trunk (fp16 activations behind the stem / one fp16 plane per conv operand: ~2.6e-3 feature error; bf16 activations:
+        # ~2e-2 — ops.resnet18in_forward)
         self.embed_precision = "fp32"
 
     def forward(self, x):

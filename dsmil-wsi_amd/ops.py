@@ -624,6 +624,7 @@ def _packed_resnet_weights(convs, depth=18, precision=0):
 
 _bn_cache = _LRU()
 _bn_checked = _LRU()
+_f16_trunk_ok = _LRU()     # weight set -> its fp16-activation trunk produced finite features (checked once)
 
 
 def _folded_bn(norms, dev):
@@ -659,10 +660,12 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None, precision=
     ResNet-50, 104 for ResNet-101).
     ``bn_norms``: the eval-mode BatchNorm2d modules of a `--norm_layer batch` trunk, in the same order;
     None = InstanceNorm.  One native launch sequence (dsmil_resnet_forward_ex).
-    ``precision``: "fp32" (default: fp32-class, the parity path), "half" (OPT-IN: every conv operand rounded to one fp16
-    plane, f32 accumulation, fp32 activations / norms — ~2e-3 feature error, not the 1e-4 bar; include/dsmil_hip.h) or
-    "bf16" (OPT-IN, round 6: bf16 ACTIVATIONS behind the stem, one bf16 MFMA product per MAC, f32 accumulation and InstanceNorm
-    statistics — ResNet-18 / 34 InstanceNorm trunks; features agree with the fp32 trunk to bf16 rounding, ~2e-2; 1.55-1.6x).
+    ``precision``: "fp32" (default: fp32-class, the parity path); "half" (OPT-IN reduced precision, <= 5e-3 feature error, not
+    the 1e-4 bar): fp16 ACTIVATIONS behind the stem, one fp16 MFMA product per MAC, f32 accumulation and InstanceNorm statistics
+    (round 6, csrc/resnet_b16.h: ResNet-18 / 34 InstanceNorm trunks, ~2.6e-3, 2x the fp32 path) — and where that trunk does not
+    apply (frozen BatchNorm, Bottleneck trunks, patches under 64 x 64 or wider than ~1000 pixels, weights whose conv sums leave
+    fp16's range) the older form: fp32 activations, every conv operand rounded to one fp16 plane (~2.6e-3, 1.2x); "bf16"
+    (OPT-IN): the same trunk on bf16 activations — fp32's range, 8 significant bits: ~2e-2 feature error; include/dsmil_hip.h.
     Returns (feats [B,512 | 2048], classes [B,C] or None)."""
     if precision not in ("fp32", "half", "bf16"):
         raise ValueError("precision must be 'fp32', 'half' or 'bf16'")
@@ -694,7 +697,6 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None, precision=
     fc_b = _f32c(fc_b.detach(), "fc_b") if fc_b is not None else None
     C = fc_w.shape[0] if fc_w is not None else 0
     classes = torch.empty((B, C), dtype=torch.float32, device=dev) if fc_w is not None else None
-    packed = _packed_resnet_weights(convs, depth, prec)
     conv1 = _f32c(convs[0].detach(), "conv1.weight")
     nbytes = L.dsmil_resnet_workspace_bytes(depth, B, H, W)
     if nbytes == 0:
@@ -705,10 +707,33 @@ def resnet18in_forward(x, convs, fc_w=None, fc_b=None, bn_norms=None, precision=
         bn_m, bn_r = _folded_bn(bn_norms, dev)
         if bn_m.numel() != L.dsmil_resnet_norm_channels(depth):
             raise ValueError("BatchNorm channel counts do not match the trunk")
-    with torch.cuda.device(dev):
-        rc = L.dsmil_resnet_forward_ex(depth, _ptr(x), 1 if u8 else 0, B, H, W, _ptr(conv1), _ptr(packed), _ptr(bn_m),
-                                       _ptr(bn_r), _ptr(fc_w), _ptr(fc_b), C, _ptr(feats), _ptr(classes), _ptr(ws),
-                                       ws.numel(), prec, _stream(dev))
+
+    def run(p):
+        packed = _packed_resnet_weights(convs, depth, p)
+        with torch.cuda.device(dev):
+            return packed, L.dsmil_resnet_forward_ex(depth, _ptr(x), 1 if u8 else 0, B, H, W, _ptr(conv1), _ptr(packed), _ptr(bn_m),
+                                                     _ptr(bn_r), _ptr(fc_w), _ptr(fc_b), C, _ptr(feats), _ptr(classes), _ptr(ws),
+                                                     ws.numel(), p, _stream(dev))
+
+    rc = None
+    if prec == 1 and bn_norms is None and L.dsmil_resnet_packed_bytes_ex(depth, 3) != 0:
+        # "half": the fp16-ACTIVATION trunk (precision 3) where it applies ...
+        wkey = ("f16act",) + tuple(_tkey(w) for w in convs)
+        ent = _f16_trunk_ok.get(wkey)              # (ok, the weights: an entry keeps its sources alive, so a freed tensor's address
+        state = None if ent is None else ent[0]    # cannot come back as another model's)  None: not tried, True / False: checked once
+        if state is not False:
+            packed, rc = run(3)
+            if rc == _native.DSMIL_E_UNSUPPORTED:  # (patch size outside the trunk's range)
+                rc = None
+            elif rc == 0 and state is None:
+                # fp16 activations: the conv sums of THIS weight set must stay inside +-65504 — checked on its first forward
+                # (one host read per weight set); a set that leaves the range keeps the one-plane form below
+                ok = bool(torch.isfinite(feats).all())
+                _f16_trunk_ok.put(wkey, (ok, list(convs)))
+                if not ok:
+                    rc = None
+    if rc is None:   # ... else (and for every other precision) the form the caller named
+        packed, rc = run(prec)
     _native.check(rc, "dsmil_resnet_forward_ex")
     if bn_norms is not None:
         # A frozen-BatchNorm trunk has no bound on its activations (InstanceNorm output is bounded by sqrt(H W)); an activation

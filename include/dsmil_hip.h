@@ -373,9 +373,13 @@ int dsmil_resnet_pack_ex(int32_t depth, const float* const* conv_w, float* packe
  * InstanceNorm and patches between 64 x 64 and ~1000 pixels wide only (everything else: DSMIL_E_UNSUPPORTED); features agree with
  * precision 0 to bf16 rounding (max ~2e-2, mean ~3e-3 on features of magnitude ~1), NOT to the 1e-4 bar; 1.75-2x the rate of
  * precision 0.
- * Its packed image is LARGER: size it with dsmil_resnet_packed_bytes_ex(depth, 2) (0 = unsupported depth / precision;
- * precision 0 / 1 = dsmil_resnet_packed_bytes).  Workspace as for the other precisions.  The reference has no such switch;
- * compute_feats.py --precision bf16 exposes it. */
+ * precision = 3: the SAME trunk on fp16 activations (11 significant bits instead of 8: features within ~2.6e-3 of precision 0,
+ * the class of precision 1, at the rate of precision 2) — activations and conv sums must stay inside fp16's +-65504: true for
+ * InstanceNorm trunks with ordinary weights; a caller checks the first forward of a weight set for non-finite features (the
+ * Python binding does, and falls back to precision 1).  compute_feats.py --precision half takes it where it applies.
+ * The packed image of precisions 2 / 3 is LARGER: size it with dsmil_resnet_packed_bytes_ex(depth, precision) (0 = unsupported
+ * depth / precision; precision 0 / 1 = dsmil_resnet_packed_bytes).  Workspace as for the other precisions.  The reference has
+ * no such switch; compute_feats.py --precision bf16 exposes precision 2. */
 size_t dsmil_resnet_packed_bytes_ex(int32_t depth, int32_t precision);
 int dsmil_resnet_forward_ex(int32_t depth, const void* x, int32_t x_is_u8_nhwc, int32_t B, int32_t H, int32_t W,
                             const float* conv1_w, const float* packed, const float* bn_mean, const float* bn_rstd,
