@@ -273,7 +273,17 @@ def aggregator_leg(cx, weights_tag, dtype, single_bag=True):
     # persistent attend launch (the co-resident forms of round 6, dsmil_agg_logits_form): two streams; a third batch only
     # queues a second attend launch behind the first (measured: 238 k bags/s on two, 229 k on three, distinct batches)
     n_streams = args.streams_bf16 if (bf16 and args.streams > 1) else args.streams
-    pool = cx.pool if n_streams == args.streams else (ops.StreamPool(n_streams, dev) if n_streams > 1 else None)
+    if n_streams == args.streams or cx.pool is None:
+        pool = cx.pool
+    elif n_streams > 1 and n_streams < len(cx.pool.streams):
+        # the first n_streams streams of the run's pool, not new ones: every stream a process creates shifts the hardware queue
+        # the next one lands on (a later leg's side stream then shares a queue with its conv kernels: slide_jpeg 59 k -> 55 k)
+        import copy
+        pool = copy.copy(cx.pool)
+        pool.streams = cx.pool.streams[:n_streams]
+        pool._i = 0
+    else:
+        pool = ops.StreamPool(n_streams, dev) if n_streams > 1 else None
     # one DISTINCT batch per stream: passes in flight together are different batches of bags in a real job, so no pass
     # may ride another's cache fills (3 x 1.31 GB fp32)
     n_batches = max(1, args.streams)
