@@ -442,6 +442,29 @@ def _check_bg_filter(size, atol):
     np.testing.assert_allclose(got, ref, atol=atol)
 
 
+@pytest.mark.gpu
+def test_compute_feats_reduced_precision_flags_on_gpu(tmp_path, monkeypatch):
+    """compute_feats.py --precision half | bf16 (new, default fp32): the opt-in 16-bit-activation trunk (csrc/resnet_b16.h) behind
+    the reference's command line.  The rows of the default run are the reference's features (1e-4 bar, elsewhere); `half` must
+    stay within 5e-3 of them, `bf16` within 5e-2 — the bars stated in include/dsmil_hip.h — and both must differ from them."""
+    import zlib
+    import glob
+    monkeypatch.chdir(tmp_path)
+    import compute_feats as cf
+    _simclr_checkpoint("simclr/runs/r0/checkpoints/model.pth", 31)
+    for i in range(10):
+        _jpeg(f"WSI/toy/single/0_x/s1/{i}_{i + 1}.jpeg", zlib.crc32(f"p/{i}".encode()) % 10000, size=224)
+    rows = {}
+    for prec in ("fp32", "half", "bf16"):
+        cf.main(["--dataset", "toy", "--weights", "r0", "--batch_size", "4", "--num_workers", "0", "--save_npy", "--precision", prec])
+        (f,) = glob.glob("datasets/toy/0_x/*.npy")
+        rows[prec] = np.load(f)
+        os.remove(f)
+    assert rows["fp32"].shape == (10, 512)
+    dh, db = np.abs(rows["half"] - rows["fp32"]).max(), np.abs(rows["bf16"] - rows["fp32"]).max()
+    assert 1e-6 < dh < 5e-3 and 1e-4 < db < 5e-2, (dh, db)
+
+
 def test_compute_feats_background_filter_matches_pil_decisions(workdir):
     """compute_feats.py --bg_threshold (new, default off): the tilers' FIND_EDGES criterion (deepzoom_tiler.py:56-61)
     applied to the decoded tiles before embedding; the decisions equal PIL's own, the kept rows equal the oracle's."""
