@@ -892,14 +892,16 @@ def slide_jpeg_leg(cx, n_patches):
                        "collectives_per_slide": 1 if cx.collectives else 0}}
 
 
-def e2e_leg(cx, low_grid):
-    """BASELINE configs[4]: synthetic two-level slide -> attention map (pipeline.multiscale_attention_map)."""
+def e2e_leg(cx, low_grid, precision="fp32"):
+    """BASELINE configs[4]: synthetic two-level slide -> attention map (pipeline.multiscale_attention_map).
+    precision "half" (`e2e_half`): both embedders on the opt-in fp16-activation trunk (tolerance: the `embedder_half` leg)."""
     torch, args, dev, world = cx.torch, cx.args, cx.dev, cx.world
     import numpy as np
     from dsmil_wsi_amd import pipeline as pl
     from dsmil_wsi_amd.synthetic import build_net
     gy, gx = low_grid
     e_lo, e_hi = _build_iclassifier(cx, seed=11), _build_iclassifier(cx, seed=12)
+    e_lo.embed_precision = e_hi.embed_precision = precision
     net = build_net("tree", dev)
     g = torch.Generator(device=dev).manual_seed(2024)
     wsi = torch.randint(0, 256, (gy * 896, gx * 896, 3), generator=g, device=dev, dtype=torch.uint8)
@@ -914,7 +916,7 @@ def e2e_leg(cx, low_grid):
     out = res["out"]
     n_high, n_low = gy * gx * 16, gy * gx
     assert out["feats"].shape == (n_high, 1024) and torch.isfinite(out["pred"]).all()
-    return {"metric": "slides/sec, multi-scale end to end (tile -> 2-scale embed -> concat -> aggregate -> attention map)",
+    return {"metric": "slides/sec, multi-scale end to end (tile -> 2-scale embed -> concat -> aggregate -> attention map)" + (", OPT-IN fp16 activations" if precision == "half" else ""),
             "value": round(steps / dt, 4), "unit": "slides/s", "scaling": "strong", "ms_per_slide": round(dt / steps * 1e3, 2),
             "patches_per_s": round((n_high + n_low) * steps / dt, 1),
             "config": {"workload": f"synthetic uint8 slide {gy * 896}x{gx * 896}: {n_low} low tiles + {n_high} high tiles (224x224), "
@@ -1066,7 +1068,7 @@ def _summary(line):
             e["value_one_stream"] = obj["config"]["value_one_stream"]
         out[name] = e
     put("aggregator_f32", line if line.get("unit") == "bags/s" else None)
-    for k in ("aggregator_bf16", "embedder", "embedder_half", "embedder_bf16", "train_c1", "train_c2", "slide", "slide_half", "slide_bf16", "slide_h2d", "slide_100k", "decode", "slide_jpeg", "e2e"):
+    for k in ("aggregator_bf16", "embedder", "embedder_half", "embedder_bf16", "train_c1", "train_c2", "slide", "slide_half", "slide_bf16", "slide_h2d", "slide_100k", "decode", "slide_jpeg", "e2e", "e2e_half"):
         put(k, line.get(k))
     return out
 
@@ -1081,7 +1083,7 @@ def main():
     ap.add_argument("--feats", type=int, default=512)
     ap.add_argument("--patches", type=int, default=256, help="patches per rank per embedder pass (batch size)")
     ap.add_argument("--workload", default="all",
-                    help="comma list of aggregator, aggregator_bf16, embedder, embedder_half, embedder_bf16, train, slide, slide_half, slide_bf16, slide_h2d, slide100k, decode, slide_jpeg, e2e; or all / both (= aggregator,embedder)")
+                    help="comma list of aggregator, aggregator_bf16, embedder, embedder_half, embedder_bf16, train, slide, slide_half, slide_bf16, slide_h2d, slide100k, decode, slide_jpeg, e2e, e2e_half; or all / both (= aggregator,embedder)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on each timed region")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams independent passes are dealt to (ops.StreamPool); 1 = one pass in flight")
@@ -1102,7 +1104,7 @@ def main():
                     help="skip the single-bag latency probe (profiling runs: keeps per-kernel averages clean)")
     args = ap.parse_args()
     maybe_self_launch(args)
-    wl = {"all": "aggregator,aggregator_bf16,embedder,embedder_half,embedder_bf16,train,slide,slide_half,slide_bf16,slide_h2d,slide100k,decode,slide_jpeg,e2e", "both": "aggregator,embedder"}.get(args.workload, args.workload)
+    wl = {"all": "aggregator,aggregator_bf16,embedder,embedder_half,embedder_bf16,train,slide,slide_half,slide_bf16,slide_h2d,slide100k,decode,slide_jpeg,e2e,e2e_half", "both": "aggregator,embedder"}.get(args.workload, args.workload)
     wl = [w for w in wl.split(",") if w]
     cx = Ctx(args)
     line = {}
@@ -1136,6 +1138,8 @@ def main():
         subs["slide_jpeg"] = slide_jpeg_leg(cx, args.slide_patches)
     if "e2e" in wl:
         subs["e2e"] = e2e_leg(cx, tuple(args.e2e_grid))
+    if "e2e_half" in wl:
+        subs["e2e_half"] = e2e_leg(cx, tuple(args.e2e_grid), precision="half")
     if cx.rank == 0:
         if not line:   # a run without the headline leg (profiling): promote the first sub-object
             k0 = next(iter(subs))
