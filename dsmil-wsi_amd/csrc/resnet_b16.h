@@ -28,7 +28,7 @@
 // the top of the next stage, so the in-order vmcnt queue never couples a fragment read to a staging load; 128 x 64 wave tiles
 // (6 fragment reads per 8 MFMAs); ONE LDS buffer and TWO workgroups per CU: one multiplies while the other stores its next
 // stage and sits at its barriers; the 3 x 3 / 1 form stages the workgroup's whole input WINDOW once per 16-channel chunk and
-// runs all nine taps on it); k_stats_b16 / k_apply_b16 (InstanceNorm in two flat passes: per-(image, chunk, channel) partial sums
+// runs all nine taps on it; k_conv_b16n: the 64-channel layer with the window's 64 channels staged once per workgroup); k_stats_b16 / k_apply_b16 (InstanceNorm in two flat passes: per-(image, chunk, channel) partial sums
 // in a fixed order — no atomics, bit-reproducible —, then normalise + residual + ReLU in place); k_pool_b16 (last block:
 // normalise + residual + ReLU + average pool -> fp32 feature row).
 // History of the conv kernel (bs 256, per 3 x 3 / 1 conv at 128+ channels; DESIGN.md §4 "Round 6"): 64 x 64 wave tiles with the
@@ -53,6 +53,7 @@ struct ConvGeo {
 };
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int B16N_NIA = 16;    // k_conv_b16n: (256 + 2 (W+1) + 2) positions x 8 pieces <= 16 x 256  (maps up to ~126 pixels wide)
 constexpr int B16W_NIA = 6;     // k_conv_b16w: 16-B window pieces per thread: (BM + 2 (W+1) + 2) positions x 2 pieces <= 6 x 256
 
 // positions of a [B][H][W] map in the shared-border layout (see the header): (H+1)(W+1) per image + one closing zero row
@@ -249,6 +250,108 @@ __global__ __launch_bounds__(256, 2) void k_conv_b16w(const unsigned short* __re
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     out[q * g.Cout + (nb_wg + wn * 2 + j) * 32 + l31] = inside ? (unsigned short)cvt16<F16>(acc[a][j][i]) : (unsigned short)0;
+            }
+        }
+}
+
+// ---- the window form for NARROW layers (Cin = Cout = 64: layer 1): the whole window with ALL 64 input channels is staged ONCE
+//      per workgroup (144 B per position: 128 B + 16 B pad) and only the weights change per 16-channel stage.  k_conv_b16w's
+//      16-channel stages touch every 128-B position row once each, four times per conv, and the rows do not stay in L2 between
+//      them (504 MB of fabric traffic per conv against 212 MB algorithmic, profiles/r06_emb16).  256 positions x 64 channels per
+//      workgroup, 64 x 64 wave tiles (four fragment reads per four MFMAs), two workgroups per CU (one loads its window while
+//      the other multiplies).  Weight image as for k_conv_b16w (cin_c = 16).
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void k_conv_b16n(const unsigned short* __restrict__ in, const unsigned short* __restrict__ wpk,
+                                                      unsigned short* __restrict__ out, ConvGeo g) {
+    constexpr int BMv = 256, NT = 64, CIN = 64, ROWB = CIN * 2 + 16;
+    constexpr int B_PIECES = 9 * (NT / 32) * 64, B_BYTES = B_PIECES * 16;       // one 16-channel stage: 18 KiB
+    constexpr int NIB = (B_PIECES + 255) / 256;
+    constexpr int NIA = B16N_NIA;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned char s_int[BMv];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;   // wave tile: positions 64 (wm) x channels 32 (wn) ... x2 blocks each way
+    const long long q0 = (long long)blockIdx.x * BMv;
+    const int Wp = g.Wo + 1, Hp = g.Ho + 1;
+    const int npw = BMv + 2 * Wp + 2, A_BYTES = (npw * ROWB + 15) / 16 * 16;
+    const int nb_tot = g.Cout >> 5;
+    {
+        const long long q = q0 + tid;
+        const int r = (int)(q % ((long long)Hp * Wp)), yo = r / Wp, xo = r - yo * Wp;
+        s_int[tid] = (q < g.Mint && yo >= 1 && xo < g.Wo) ? 1 : 0;
+    }
+    // the window, all 64 channels: once
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        int p = i * 256 + tid;
+        p = p < npw * 8 ? p : npw * 8 - 1;
+        const int pos = p >> 3, piece = p & 7;
+        long long q = q0 - Wp - 1 + pos;
+        q = q < 0 ? 0 : (q >= g.Min ? g.Min - 1 : q);
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(in + q * CIN + piece * 8);
+        *reinterpret_cast<u32x4_t*>(smem + pos * ROWB + piece * 16) = v;
+    }
+    const u32x4_t* wp4 = reinterpret_cast<const u32x4_t*>(wpk);
+    u32x4_t rb[NIB];
+    auto w_load = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) {
+            int pidx = i * 256 + tid;
+            pidx = pidx < B_PIECES ? pidx : B_PIECES - 1;
+            constexpr int per = (NT / 32) * 64;
+            const int tap = pidx / per, rest = pidx - tap * per;
+            rb[i] = wp4[((long long)(s * 9 + tap) * nb_tot) * 64 + rest];
+        }
+    };
+    auto w_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) {
+            int pidx = i * 256 + tid;
+            pidx = pidx < B_PIECES ? pidx : B_PIECES - 1;
+            *reinterpret_cast<u32x4_t*>(smem + A_BYTES + pidx * 16) = rb[i];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    w_load(0);
+    constexpr int NSTAGE = CIN / 16;
+    for (int s = 0; s < NSTAGE; ++s) {
+        __syncthreads();                                       // (first pass: the window is written; later: stage s - 1 has been read)
+        w_store();
+        __syncthreads();
+        w_load(s + 1 < NSTAGE ? s + 1 : s);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const unsigned char* Ab = smem + (dy * Wp + dx + wm * 128 + l31) * ROWB + s * 32 + hi * 16;
+            const unsigned char* Bb = smem + A_BYTES + ((tap * (NT / 32)) * 64 + lane) * 16;
+            u32x4_t af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const u32x4_t*>(Ab + (wn * 64 + a * 32) * ROWB);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(Bb + j * 1024);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][j] = mfma16<F16>(af[a], bf[j], acc[a][j]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = wm * 128 + wn * 64 + a * 32 + 8 * (i >> 2) + 4 * hi + (i & 3);
+            const long long q = q0 + m;
+            if (q < g.M) {
+                const bool inside = s_int[m] != 0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    out[q * g.Cout + j * 32 + l31] = inside ? (unsigned short)cvt16<F16>(acc[a][j][i]) : (unsigned short)0;
             }
         }
 }
@@ -546,6 +649,10 @@ inline int run_conv(hipStream_t st, const unsigned short* in, const unsigned sho
             const size_t lds = (size_t)(((BMv + 2 * Wp + 2) * 48 + 15) / 16 * 16) + 9 * (NT / 32) * 1024;
             allow_lds((const void*)k_conv_b16w<BMv, NT, 2, 2, F16>, lds);
             hipLaunchKernelGGL((k_conv_b16w<BMv, NT, 2, 2, F16>), dim3((unsigned)((g.M + BMv - 1) / BMv), s.cout / NT), dim3(256), lds, st, in, wpk, out, g);
+        } else if (s.cin == 64 && s.cout == 64 && (256 + 2 * Wp + 2) * 8 <= B16N_NIA * 256) {
+            const size_t lds = (size_t)(((256 + 2 * Wp + 2) * 144 + 15) / 16 * 16) + 9 * 2 * 1024;
+            allow_lds((const void*)k_conv_b16n<F16>, lds);
+            hipLaunchKernelGGL(k_conv_b16n<F16>, dim3((unsigned)((g.M + 255) / 256), 1), dim3(256), lds, st, in, wpk, out, g);
         } else {
             constexpr int BMv = 512, NT = 64;
             if ((BMv + 2 * Wp + 2) * 2 > B16W_NIA * 256) return DSMIL_E_UNSUPPORTED;
