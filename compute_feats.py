@@ -49,7 +49,7 @@ def build_parser():
                    help="(new, default fp32 = the parity path) half: fp16 ACTIVATIONS behind the stem, one fp16 MFMA product per "
                         "MAC, f32 accumulation and norm statistics (ResNet-18 / 34 with InstanceNorm; other trunks: fp32 activations, "
                         "one fp16 plane per conv operand): ~2.6e-3 feature error, 2x; bf16: the same trunk on bf16 activations "
-                        "(fp32's range): ~2e-2; the reference has no such switch")
+                        "(fp32's range): ~2e-2 (ResNet-34: ~1e-2 / ~5e-2); the reference has no such switch")
     p.add_argument("--gpu_decode", action="store_true",
                    help="(new, default off) decode the tiles' JPEG files on the GPU (dsmil_jpeg_decode: baseline JPEGs, bit-identical to "
                         "Pillow; other files take Pillow inside the same call) instead of in --num_workers DataLoader processes "
