@@ -27,7 +27,8 @@ Sub-objects of the same JSON line (each measured the same way):
   slide_100k       the same with 100 000 tiles (2 slides timed)
   decode           SURVEY §8f N3: 8 192 baseline-JPEG tiles (224x224, quality 70) decoded on the device per launch sequence,
                    beside Pillow (the reference's decoder) on the host's cores
-  slide_jpeg       the `slide` leg starting from JPEG files in host memory: device decode on a side stream under the embedding
+  slide_jpeg       the `slide` leg starting from JPEG files in host memory: device decode on side streams under the embedding
+  slide_jpeg_half  the same on the opt-in fp16-activation trunk (the decodes have half the time to hide in)
   e2e              configs[4]: synthetic two-level WSI -> tiles -> two embedders -> [high||low] -> MILNet(1024) ->
                    attention map, sharded by low tile, one all-gather of tree rows
 
@@ -857,15 +858,17 @@ def decode_leg(cx, n_tiles=8192):
     return line
 
 
-def slide_jpeg_leg(cx, n_patches):
+def slide_jpeg_leg(cx, n_patches, precision="fp32"):
     """The `slide` leg starting from JPEG FILES IN HOST MEMORY (what compute_feats.py:65-69 globs, read into bytes): device decode
     of 2 048-tile chunks on a side stream under the embedding of the previous chunk (pipeline.embed_jpeg_blobs), one all-gather,
-    the aggregator.  Strong scaling: contiguous file shards over the ranks."""
+    the aggregator.  Strong scaling: contiguous file shards over the ranks.  precision "half" (`slide_jpeg_half`): the embedder on
+    the opt-in fp16-activation trunk (tolerance: the `embedder_half` leg) — the decode has half the time to hide in."""
     torch, args, dev, world = cx.torch, cx.args, cx.dev, cx.world
     from dsmil_wsi_amd import dist as dd
     from dsmil_wsi_amd import pipeline as pl
     from dsmil_wsi_amd.synthetic import build_net
     ic = _build_iclassifier(cx)
+    ic.embed_precision = precision
     net = build_net("tcga", dev)
     lo, hi = dd.shard_range(n_patches, cx.rank, world)
     blobs = _jpeg_tiles(n_patches)[lo:hi]
@@ -883,7 +886,7 @@ def slide_jpeg_leg(cx, n_patches):
     torch.cuda.synchronize()
     assert res["out"][2].shape[0] == n_patches and torch.isfinite(res["out"][1]).all() and stats.get("pillow", 0) == 0
     comp = sum(len(b) for b in blobs)
-    return {"metric": "patches/sec, one slide of JPEG tiles decoded on the device + embedded + gathered + aggregated",
+    return {"metric": "patches/sec, one slide of JPEG tiles decoded on the device + embedded + gathered + aggregated" + (", OPT-IN fp16 activations" if precision == "half" else ""),
             "value": round(n_patches * steps / dt, 1), "unit": "patches/s", "scaling": "strong", "ms_per_slide": round(dt / steps * 1e3, 3),
             "config": {"tiles_start_in": "host memory as baseline-JPEG files (bytes)", "h2d_bytes_per_slide": comp,
                        "workload": f"one slide = {n_patches} JPEG tiles (224x224, quality 70), chunks of 2048 decoded by dsmil_jpeg_decode "
@@ -1068,7 +1071,7 @@ def _summary(line):
             e["value_one_stream"] = obj["config"]["value_one_stream"]
         out[name] = e
     put("aggregator_f32", line if line.get("unit") == "bags/s" else None)
-    for k in ("aggregator_bf16", "embedder", "embedder_half", "embedder_bf16", "train_c1", "train_c2", "slide", "slide_half", "slide_bf16", "slide_h2d", "slide_100k", "decode", "slide_jpeg", "e2e", "e2e_half"):
+    for k in ("aggregator_bf16", "embedder", "embedder_half", "embedder_bf16", "train_c1", "train_c2", "slide", "slide_half", "slide_bf16", "slide_h2d", "slide_100k", "decode", "slide_jpeg", "e2e", "e2e_half", "slide_jpeg_half"):
         put(k, line.get(k))
     return out
 
@@ -1083,7 +1086,7 @@ def main():
     ap.add_argument("--feats", type=int, default=512)
     ap.add_argument("--patches", type=int, default=256, help="patches per rank per embedder pass (batch size)")
     ap.add_argument("--workload", default="all",
-                    help="comma list of aggregator, aggregator_bf16, embedder, embedder_half, embedder_bf16, train, slide, slide_half, slide_bf16, slide_h2d, slide100k, decode, slide_jpeg, e2e, e2e_half; or all / both (= aggregator,embedder)")
+                    help="comma list of aggregator, aggregator_bf16, embedder, embedder_half, embedder_bf16, train, slide, slide_half, slide_bf16, slide_h2d, slide100k, decode, slide_jpeg, e2e, e2e_half, slide_jpeg_half; or all / both (= aggregator,embedder)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on each timed region")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams independent passes are dealt to (ops.StreamPool); 1 = one pass in flight")
@@ -1104,7 +1107,7 @@ def main():
                     help="skip the single-bag latency probe (profiling runs: keeps per-kernel averages clean)")
     args = ap.parse_args()
     maybe_self_launch(args)
-    wl = {"all": "aggregator,aggregator_bf16,embedder,embedder_half,embedder_bf16,train,slide,slide_half,slide_bf16,slide_h2d,slide100k,decode,slide_jpeg,e2e,e2e_half", "both": "aggregator,embedder"}.get(args.workload, args.workload)
+    wl = {"all": "aggregator,aggregator_bf16,embedder,embedder_half,embedder_bf16,train,slide,slide_half,slide_bf16,slide_h2d,slide100k,decode,slide_jpeg,e2e,e2e_half,slide_jpeg_half", "both": "aggregator,embedder"}.get(args.workload, args.workload)
     wl = [w for w in wl.split(",") if w]
     cx = Ctx(args)
     line = {}
@@ -1140,6 +1143,8 @@ def main():
         subs["e2e"] = e2e_leg(cx, tuple(args.e2e_grid))
     if "e2e_half" in wl:
         subs["e2e_half"] = e2e_leg(cx, tuple(args.e2e_grid), precision="half")
+    if "slide_jpeg_half" in wl:   # (last: every stream a leg creates shifts the hardware queues of the legs behind it)
+        subs["slide_jpeg_half"] = slide_jpeg_leg(cx, args.slide_patches, precision="half")
     if cx.rank == 0:
         if not line:   # a run without the headline leg (profiling): promote the first sub-object
             k0 = next(iter(subs))

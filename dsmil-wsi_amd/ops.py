@@ -808,15 +808,19 @@ def _pil_rgb(blob):
         return np.array(im.convert("RGB"), dtype=np.uint8, copy=True)
 
 
-def jpeg_decode(blobs, device, size=None, stats=None, out=None):
-    """A batch of JPEG files (bytes-likes) -> uint8 [n, H, W, 3] on `device`, what
-    `np.array(Image.open(f).convert("RGB"))` gives for every file (compute_feats.py:28 + the uint8 half of VF.to_tensor):
-    baseline JPEGs are decoded on the device by dsmil_jpeg_decode (bit-identical to Pillow's defaults: islow IDCT, fancy
-    upsampling), every other file (progressive, CMYK, a PNG ...) and every stream the device decoder reports as corrupt is
-    decoded with Pillow on the host and copied in — the result never depends on which path a file took.
-    ``size`` = (H, W) of the batch (default: the first decodable image's); all files must have it.
-    ``stats`` (dict, optional) gets the counts {"device": .., "pillow": ..}.
-    ``out``: a uint8 device tensor with room for [n, H, W, 3] (a caller's staging buffer); the result is a view of it."""
+class _JpegPending:
+    """A device decode in flight (jpeg_decode_begin): the launch is enqueued, its per-file status not yet read."""
+    __slots__ = ("out", "blobs", "H", "W", "st_host", "st_np", "ev")
+
+
+def jpeg_decode_begin(blobs, device, size=None, out=None, before_launch=None):
+    """The first half of jpeg_decode: parse on the host, copy, ENQUEUE the device decode on the current stream and the copy of its
+    per-file status into pinned memory — no host wait.  `.ev` (None when no file of the batch is decodable on the device) is
+    recorded behind both; `.out` is the result tensor, complete once jpeg_decode_end has run.  A caller with several chunks keeps
+    a decode or two in flight this way instead of waiting for every chunk's status before it enqueues anything else
+    (pipeline._embed_jpeg_chunks).  `before_launch()` runs between the host-to-device copies of the files and the decode launch:
+    the place for a stream wait on whoever still reads `out` — in front of the copies it would hold the HOST, the copy of a
+    pageable buffer returns only when it has run."""
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("jpeg_decode needs a CUDA(HIP) device")
@@ -837,26 +841,60 @@ def jpeg_decode(blobs, device, size=None, stats=None, out=None):
         raise ValueError("out must be a contiguous uint8 device tensor of at least n * H * W * 3 elements")
     out = (torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev) if out is None
            else out.view(-1)[:n * H * W * 3].view(n, H, W, 3))
-    status = torch.empty(n, dtype=torch.int32, device=dev)
-    L = _native.lib()
+    p = _JpegPending()
+    p.out, p.blobs, p.H, p.W, p.st_host, p.st_np, p.ev = out, blobs, H, W, None, None, None
     if on_dev.any():
+        L = _native.lib()
+        status = torch.empty(n, dtype=torch.int32, device=dev)
         d_data = torch.from_numpy(data).to(dev, non_blocking=True)
         d_plan = torch.from_numpy(plan).to(dev, non_blocking=True)
         nbytes = L.dsmil_jpeg_workspace_bytes(n, H, W, n_data)
         ws = _workspace(dev, nbytes)
+        if before_launch is not None:
+            before_launch()
         with torch.cuda.device(dev):
             rc = L.dsmil_jpeg_decode(_ptr(d_data), n_data, _ptr(d_plan), n, H, W, _ptr(out), _ptr(status), _ptr(ws), ws.numel(), _stream(dev))
         _native.check(rc, "dsmil_jpeg_decode")
-        st = status.cpu().numpy()
+        p.st_host = torch.empty(n, dtype=torch.int32, pin_memory=True)
+        p.st_host.copy_(status, non_blocking=True)
+        p.ev = torch.cuda.Event()
+        p.ev.record(torch.cuda.current_stream(dev))
     else:
-        st = recs["status"].copy()
+        if before_launch is not None:
+            before_launch()
+        p.st_np = recs["status"].copy()
+    return p
+
+
+def jpeg_decode_end(p, stats=None):
+    """The second half: wait for the status, decode what the device did not (other formats, other coding processes, streams it
+    reports as corrupt) with Pillow and copy those files in on the CURRENT stream.  Returns (out, files redone)."""
+    if p.ev is not None:
+        p.ev.synchronize()
+        st = p.st_host.numpy()
+    else:
+        st = p.st_np
     redo = np.nonzero(st != 0)[0]
     for i in redo:
-        a = _pil_rgb(blobs[int(i)])
-        if a.shape[:2] != (H, W):
-            raise ValueError(f"file {int(i)} of the batch is {a.shape[1]}x{a.shape[0]}, the batch is {W}x{H}")
-        out[int(i)].copy_(torch.from_numpy(a))
+        a = _pil_rgb(p.blobs[int(i)])
+        if a.shape[:2] != (p.H, p.W):
+            raise ValueError(f"file {int(i)} of the batch is {a.shape[1]}x{a.shape[0]}, the batch is {p.W}x{p.H}")
+        p.out[int(i)].copy_(torch.from_numpy(a))
     if stats is not None:
-        stats["device"] = stats.get("device", 0) + int(n - len(redo))
+        stats["device"] = stats.get("device", 0) + int(len(st) - len(redo))
         stats["pillow"] = stats.get("pillow", 0) + int(len(redo))
-    return out
+    p.blobs = None
+    return p.out, int(len(redo))
+
+
+def jpeg_decode(blobs, device, size=None, stats=None, out=None):
+    """A batch of JPEG files (bytes-likes) -> uint8 [n, H, W, 3] on `device`, what
+    `np.array(Image.open(f).convert("RGB"))` gives for every file (compute_feats.py:28 + the uint8 half of VF.to_tensor):
+    baseline JPEGs are decoded on the device by dsmil_jpeg_decode (bit-identical to Pillow's defaults: islow IDCT, fancy
+    upsampling), every other file (progressive, CMYK, a PNG ...) and every stream the device decoder reports as corrupt is
+    decoded with Pillow on the host and copied in — the result never depends on which path a file took.
+    ``size`` = (H, W) of the batch (default: the first decodable image's); all files must have it.
+    ``stats`` (dict, optional) gets the counts {"device": .., "pillow": ..}.
+    ``out``: a uint8 device tensor with room for [n, H, W, 3] (a caller's staging buffer); the result is a view of it.
+    (= jpeg_decode_begin + jpeg_decode_end, the two halves a pipelining caller uses.)"""
+    return jpeg_decode_end(jpeg_decode_begin(blobs, device, size=size, out=out), stats=stats)[0]

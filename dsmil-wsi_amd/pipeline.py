@@ -97,29 +97,52 @@ class _ChunkDecoder:
     decode launch would sit in line behind them (measured: 35.7 k instead of 55.5 k patches/s); (b) the dispatcher places the
     decode's few workgroups as soon as compute units free up."""
 
-    def __init__(self, device, decode_batch, stats=None):
+    def __init__(self, device, decode_batch, stats=None, nbuf=2, nstreams=1):
         self.dev = torch.device(device)
-        self.ds = _decode_streams.get(str(self.dev))
-        if self.ds is None:
-            self.ds = _decode_streams[str(self.dev)] = torch.cuda.Stream(device=self.dev, priority=-1)
+        pool = _decode_streams.setdefault(str(self.dev), [])
+        while len(pool) < nstreams:                       # (created once per process and device, high priority: see above)
+            pool.append(torch.cuda.Stream(device=self.dev, priority=-1))
+        self.dss = pool[:nstreams]
+        self.ds = self.dss[0]
         self.decode_batch, self.stats = decode_batch, stats
-        self.bufs, self.free_ev = [None, None], [None, None]
-        self.size, self.k, self.last = None, 0, None
+        self.bufs, self.free_ev = [None] * nbuf, [None] * nbuf
+        self.size, self.k, self.n, self.last = None, 0, 0, None
+
+    def begin(self, blobs):
+        """Enqueue the decode of a chunk into the next staging buffer, on the next decode stream; no host wait
+        (ops.jpeg_decode_begin)."""
+        k = self.k
+        self.k = (k + 1) % len(self.bufs)
+        ds = self.dss[self.n % len(self.dss)]
+        self.n += 1
+        def buffer_free():                                # the consumer's work on the chunk that used this buffer (one event, or
+            if self.free_ev[k] is not None:               # one per stream) — waited for BEHIND the files' host-to-device copies:
+                for e in (self.free_ev[k] if isinstance(self.free_ev[k], list) else [self.free_ev[k]]):   # a pageable copy
+                    ds.wait_event(e)                      # queued behind this wait held the host until the buffer was free
+
+        with torch.cuda.stream(ds):                       # (the inputs are host bytes: nothing of the caller's stream to wait for)
+            p = ops.jpeg_decode_begin(blobs, self.dev, size=self.size, out=self.bufs[k], before_launch=buffer_free)
+            if self.bufs[k] is None and p.out.shape[0] == self.decode_batch:
+                self.bufs[k] = p.out                      # (a short last chunk is not worth keeping)
+                for d2 in self.dss:                       # (allocated on one decode stream, written by the others later)
+                    if d2 is not ds:
+                        p.out.record_stream(d2)
+            self.size = tuple(p.out.shape[1:3])
+        return p, k, ds
+
+    def end(self, item):
+        """Wait for a begin()'s status, redo on the host what the device did not decode -> (imgs, event, buffer index)."""
+        p, k, ds = item
+        with torch.cuda.stream(ds):
+            imgs, redone = ops.jpeg_decode_end(p, stats=self.stats)
+            ev = p.ev
+            if ev is None or redone:                      # host-decoded files were copied in on the side stream just now
+                ev = torch.cuda.Event()                   # (behind a later chunk's decode if one is already queued there)
+                ev.record(ds)
+        return imgs, ev, k
 
     def decode(self, blobs):
-        k = self.k
-        self.k ^= 1
-        with torch.cuda.stream(self.ds):                  # (the inputs are host bytes: nothing of the caller's stream to wait for)
-            if self.free_ev[k] is not None:               # the consumer's work on the chunk that used this buffer (one event,
-                for e in (self.free_ev[k] if isinstance(self.free_ev[k], list) else [self.free_ev[k]]):   # or one per stream)
-                    self.ds.wait_event(e)
-            imgs = ops.jpeg_decode(blobs, self.dev, size=self.size, stats=self.stats, out=self.bufs[k])
-            if self.bufs[k] is None and imgs.shape[0] == self.decode_batch:
-                self.bufs[k] = imgs                       # (a short last chunk is not worth keeping)
-            self.size = tuple(imgs.shape[1:3])
-            ev = torch.cuda.Event()
-            ev.record(self.ds)
-        return imgs, ev, k
+        return self.end(self.begin(blobs))
 
     def acquire(self, item):
         """Make the caller's current stream wait for a decode()'s result; returns the images."""
@@ -135,7 +158,8 @@ class _ChunkDecoder:
         self.free_ev[item[2]] = e
 
     def finish(self):
-        torch.cuda.current_stream(self.dev).wait_stream(self.ds)
+        for ds in self.dss:
+            torch.cuda.current_stream(self.dev).wait_stream(ds)
 
 
 @torch.no_grad()
@@ -160,11 +184,12 @@ def _embed_jpeg_chunks(i_classifier, chunks, batch_size, decode_batch, streams, 
     def resolve(chunk):
         return [b.result() if hasattr(b, "result") else b for b in chunk]
 
-    dec = _ChunkDecoder(dev, decode_batch, stats)
-    fl, cl = [], []
-    cur = dec.decode(resolve(chunks[0]))
     pool = stream_pool(dev, streams) if streams > 1 else None
+    ahead = max(1, min(DECODE_AHEAD[0], len(chunks)))
+    dec = _ChunkDecoder(dev, decode_batch, stats, nbuf=2 if pool is None else ahead + 1, nstreams=1 if pool is None else DECODE_STREAMS[0])
+    fl, cl = [], []
     if pool is None:
+        cur = dec.decode(resolve(chunks[0]))
         for ci in range(len(chunks)):
             imgs = dec.acquire(cur)
             f, c = embed_tiles(i_classifier, imgs, batch_size, streams=1, device=dev)
@@ -179,12 +204,22 @@ def _embed_jpeg_chunks(i_classifier, chunks, batch_size, decode_batch, streams, 
     # is about to read — not for the caller's stream: embed_tiles per chunk joined the pool into the caller's stream and the next
     # chunk's first batches waited for that join, i.e. the pipeline drained at every chunk boundary (8 batches on 3 streams:
     # the last round of a chunk is two batches wide): 53 k -> 61 k patches/s for a 10 000-tile slide (bench.py `slide_jpeg`).
+    # SEVERAL decodes in flight (DECODE_AHEAD, on DECODE_STREAMS side streams, one staging buffer more): a decode is ~11 ms of
+    # latency whatever the chunk size (one lane per tile in the Huffman kernel; 17-25 ms beside the conv kernels) and the host
+    # must read its status before it may hand the chunk on.  With one decode in flight the host sat in that wait and THEN
+    # enqueued the chunk's ~500 launches, so the next decode started late and a 16-bit trunk (15 ms per 2 048 tiles) ran out of
+    # decoded tiles: 115 ms per 10 000-tile slide against 75 ms from decoded tiles; now 98 ms (the first decode, which nothing
+    # can hide, + ~10 ms of the decodes' share of the device).  The fp32-class trunk (31 ms per chunk) never waited: unchanged.
     caller = torch.cuda.current_stream(dev)
     for s_ in pool.streams:
         s_.wait_stream(caller)                            # (weights / earlier work of the caller's stream)
+    pending, nxt = [], 0
+    while nxt < len(chunks) and len(pending) < ahead:
+        pending.append(dec.begin(resolve(chunks[nxt])))
+        nxt += 1
     bi = 0
     for ci in range(len(chunks)):
-        imgs, ev, k = cur
+        imgs, ev, k = dec.end(pending.pop(0))
         used = set()
         for lo in range(0, imgs.shape[0], batch_size):
             s_ = pool.streams[bi % len(pool.streams)]
@@ -204,17 +239,22 @@ def _embed_jpeg_chunks(i_classifier, chunks, batch_size, decode_batch, streams, 
                 e.record(s_)
                 done.append(e)
         dec.free_ev[k] = done
-        if ci + 1 < len(chunks):
-            cur = dec.decode(resolve(chunks[ci + 1]))   # the host waits here for the decode's status while the GPU embeds chunk ci
+        if nxt < len(chunks):
+            pending.append(dec.begin(resolve(chunks[nxt])))   # chunk ci + 2, into the buffer chunk ci - 1 was embedded from
+            nxt += 1
     for s_ in pool.streams:
         caller.wait_stream(s_)
-    caller.wait_stream(dec.ds)
+    for ds in dec.dss:
+        caller.wait_stream(ds)
     for t in fl + cl:                                     # produced on a pool stream, consumed (and freed) on the caller's
         t.record_stream(caller)
     return torch.cat(fl), torch.cat(cl)
 
 
 EMBED_STREAMS = [3]     # HIP streams of embed_files' device-decode path (batches dealt round-robin, ops.StreamPool)
+DECODE_AHEAD = [3]      # decodes in flight in front of the chunk being embedded (staging buffers: one more; tools/_ahead sweep:
+                        # 1 decode stream x 1 ahead 115 ms per 10 000-tile slide on the fp16-activation trunk, 2 x 3: 98 ms)
+DECODE_STREAMS = [2]    # decode streams of the pooled path: the Huffman kernel is latency-bound on a handful of compute units
 DECODE_BATCH = [2048]   # files per device-decode chunk of embed_files(gpu_decode=True) (tests lower it to walk the double buffer)
 
 

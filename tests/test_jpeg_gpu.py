@@ -206,3 +206,44 @@ def test_chunked_decode_walks_both_staging_buffers(tmp_path):
     torch.cuda.synchronize()
     assert st == {"device": 53, "pillow": 0}
     assert torch.equal(ref_f, f2) and torch.equal(ref_c, c2)
+
+
+def test_decodes_in_flight_with_host_decoded_files_and_a_chunk_without_a_device_launch():
+    """pipeline.embed_jpeg_blobs keeps several decodes in flight (ops.jpeg_decode_begin / _end, DECODE_AHEAD on DECODE_STREAMS
+    side streams, the staging buffers reused round-robin).  Thirteen chunks of 4 files: progressive files (host-decoded inside
+    jpeg_decode_end, copied in behind later chunks' launches) in several chunks, ONE chunk with no file for the device at all
+    (no launch, no event of its own) — rows bit-identical to the embedding of Pillow's decode, in order, for 1-3 decodes ahead on
+    1-2 streams; and the two halves used directly equal jpeg_decode."""
+    from test_resnet_gpu import _build
+    from dsmil_wsi_amd import ops, pipeline as pl
+    rng = np.random.default_rng(47)
+    blobs = []
+    for i in range(51):
+        prog = i in (5, 22, 23, 49) or 28 <= i < 32          # chunk 7 (files 28-31) is all-progressive
+        blobs.append(_jpeg(_img(rng, 96, 96, i % 3), quality=70, progressive=prog))
+    n_prog = 8
+    ic, _ = _build(seed=13)
+    ic = ic.cuda()
+    tiles = torch.from_numpy(np.stack([_pil(b) for b in blobs])).cuda()
+    ref_f, ref_c = pl.embed_tiles(ic, tiles, 4, streams=1)
+    old = pl.DECODE_AHEAD[0], pl.DECODE_STREAMS[0]
+    try:
+        for ahead, nst in ((1, 1), (2, 2), (3, 2), (3, 1)):
+            pl.DECODE_AHEAD[0], pl.DECODE_STREAMS[0] = ahead, nst
+            for _ in range(2):
+                st = {}
+                f, c = pl.embed_jpeg_blobs(ic, blobs, batch_size=4, decode_batch=4, streams=3, stats=st)
+                torch.cuda.synchronize()
+                assert st == {"device": 51 - n_prog, "pillow": n_prog}, (ahead, nst, st)
+                assert torch.equal(ref_f, f) and torch.equal(ref_c, c), (ahead, nst)
+    finally:
+        pl.DECODE_AHEAD[0], pl.DECODE_STREAMS[0] = old
+    # the halves by hand, two decodes in flight on the current stream, a wait hook in front of the launch
+    called = []
+    p0 = ops.jpeg_decode_begin(blobs[:8], "cuda", before_launch=lambda: called.append(0))
+    p1 = ops.jpeg_decode_begin(blobs[28:32], "cuda", before_launch=lambda: called.append(1))
+    assert called == [0, 1] and p0.ev is not None and p1.ev is None
+    o0, r0 = ops.jpeg_decode_end(p0)
+    o1, r1 = ops.jpeg_decode_end(p1)
+    assert (r0, r1) == (1, 4)
+    assert torch.equal(o0, tiles[:8]) and torch.equal(o1, tiles[28:32])
