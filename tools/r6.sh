@@ -48,8 +48,10 @@ pmc_single)
     n=$(echo $c | tr ' ' '_' | cut -c1-40)
     (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c -f csv -d $OUT/pmc_single_$n -o p -- python $R/tools/single_bag.py c16 > $OUT/pmc_single_$n.log 2>&1)
   done; find $OUT -name "*counter_collection.csv" | head;;
-pmc_agg|pmc_emb)
-  W=aggregator,aggregator_bf16; [ $stage = pmc_emb ] && W=embedder
+prof_emb16)
+  prof emb16 python $R/bench.py --workload embedder_half --streams 1 --steps 3 --warmup 1 --min-seconds 0.1 --no-cpu-baseline;;
+pmc_agg|pmc_emb|pmc_emb16)
+  W=aggregator,aggregator_bf16; [ $stage = pmc_emb ] && W=embedder; [ $stage = pmc_emb16 ] && W=embedder_half
   for c in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
     n=$(echo $c | tr ' ' '_' | cut -c1-40)
     (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -f csv -d $OUT/${stage}_$n -o p -- python $R/bench.py --workload $W --streams 1 --steps 3 --warmup 1 --min-seconds 0.05 --no-cpu-baseline --no-single-bag > $OUT/${stage}_$n.log 2>&1)
