@@ -143,5 +143,12 @@ def test_row_r2_multiscale_end_to_end():
     t_entry.test_multiscale_end_to_end_on_gpu()
 
 
+def test_row_a5_a6_opt_in_16_bit_activation_trunks():
+    """BASELINE.md's bf16 embedder row (round 6, opt-in): the bf16-activation trunk and the fp16-activation trunk (`--precision
+    bf16` / `half`) against the oracle at their own stated bars — NOT the 1e-4 parity path of the rows above."""
+    t_res.test_opt_in_bf16_activation_trunk_within_its_stated_tolerance(33, 224, 224, True)
+    t_res.test_opt_in_half_precision_path_within_its_stated_tolerance(33, 224, 224, True)
+
+
 def test_bit_identity_at_the_headline_shape():
     t_agg.test_repeated_runs_are_bit_identical(64, 10000)

@@ -19,6 +19,8 @@ def mk(seed):
     for p in ic.parameters(): p.requires_grad = False
     return ic
 e_lo, e_hi = mk(11), mk(12)
+if len(sys.argv) > 1:                      # python tools/e2e_stages.py half
+    e_lo.embed_precision = e_hi.embed_precision = sys.argv[1]
 net = build_net("tree", dev)
 gy, gx = 24, 26
 wsi = torch.randint(0, 256, (gy * 896, gx * 896, 3), device=dev, dtype=torch.uint8)
