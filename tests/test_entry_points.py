@@ -215,6 +215,16 @@ def test_pyramid_tiles_of_a_synthetic_slide():
         box = wsi[ly * 4 * T:(ly + 1) * 4 * T, lx * 4 * T:(lx + 1) * 4 * T].view(T, 4, T, 4, 3).double().mean((1, 3))
         assert torch.equal(low[li], torch.floor(box + 0.5).to(torch.uint8))
     assert len({tuple(p) for p in pos.tolist()}) == 96
+    # a rank's range of low tiles (dist.shard_range) = the slice of the whole; the copy moves 8-byte words when a tile row is
+    # a multiple of 8 bytes (T = 16: 48) and bytes otherwise (T = 14: 42) — same tiles
+    l2, h2, p2, q2 = pl.pyramid_tiles(wsi, tile=T, factor=4, lo=1, hi=5)
+    assert torch.equal(l2, low[1:5]) and torch.equal(h2, high[16:80]) and torch.equal(q2, pos[16:80]) and p2.tolist() == [i // 16 for i in range(64)]
+    T2 = 14
+    w2 = torch.randint(0, 256, (2 * T2 * 4, 3 * T2 * 4, 3), generator=g, dtype=torch.uint8)
+    _, h3, _, q3 = pl.pyramid_tiles(w2, tile=T2, factor=4)
+    for k in (0, 41, 95):
+        r, c = q3[k].tolist()
+        assert torch.equal(h3[k], w2[r * T2:(r + 1) * T2, c * T2:(c + 1) * T2])
 
 
 @pytest.mark.gpu
