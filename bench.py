@@ -29,6 +29,7 @@ Sub-objects of the same JSON line (each measured the same way):
                    beside Pillow (the reference's decoder) on the host's cores
   slide_jpeg       the `slide` leg starting from JPEG files in host memory: device decode on side streams under the embedding
   slide_jpeg_half  the same on the opt-in fp16-activation trunk (the decodes have half the time to hide in)
+  feats_csv        the bag's feature file (compute_feats.py:80-82) through dsmil_csv_format_f32, beside pandas (host only)
   e2e              configs[4]: synthetic two-level WSI -> tiles -> two embedders -> [high||low] -> MILNet(1024) ->
                    attention map, sharded by low tile, one all-gather of tree rows
 
@@ -895,6 +896,39 @@ def slide_jpeg_leg(cx, n_patches, precision="fp32"):
                        "collectives_per_slide": 1 if cx.collectives else 0}}
 
 
+def feats_csv_leg(cx, rows=10000, cols=512):
+    """The reference's feature file of one bag (compute_feats.py:80-82, `to_csv(float_format='%.4f')`; HOST work, rank 0's cores):
+    pipeline.save_feats_csv (dsmil_csv_format_f32: the same bytes) beside pandas formatting the same rows — timed on a tenth of the
+    bag and scaled (pandas needs ~5 s for the whole one)."""
+    import io
+    import tempfile
+    import numpy as np
+    import pandas as pd
+    from dsmil_wsi_amd import pipeline as pl
+    rng = np.random.default_rng(12)
+    feats = rng.standard_normal((rows, cols)).astype(np.float32)
+    n_ref = max(1, rows // 10)
+    b = io.StringIO()
+    t0 = time.perf_counter()
+    pd.DataFrame(feats[:n_ref]).to_csv(b, index=False, float_format="%.4f")
+    t_pd = (time.perf_counter() - t0) * rows / n_ref
+    assert pl.feats_csv_bytes(feats[:n_ref]) == b.getvalue().encode()
+    with tempfile.TemporaryDirectory() as d:
+        pl.save_feats_csv(feats, os.path.join(d, "w.csv"))
+        ts = []
+        for i in range(5):
+            t0 = time.perf_counter()
+            pl.save_feats_csv(feats, os.path.join(d, f"b{i}.csv"))
+            ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[len(ts) // 2]
+    return {"metric": "bags/sec written as the reference's feature CSV (10 000 x 512, '%.4f')", "value": round(1.0 / t, 2), "unit": "bags/s",
+            "ms_per_bag": round(t * 1e3, 1), "dtype": "f32 -> decimal text, exact (ties to even)",
+            "cpu_baseline": {"value": round(1.0 / t_pd, 3), "unit": "bags/s", "cores": 1, "kind": "reference",
+                             "sample": f"pandas DataFrame.to_csv(float_format='%.4f') of {n_ref} x {cols} rows, scaled to {rows}: the reference's own call (compute_feats.py:82)"},
+            "config": {"workload": f"one bag = {rows} x {cols} float32 features -> CSV bytes identical to pandas', median of 5",
+                       "threads": pl.CSV_THREADS[0], "bytes_per_bag": int(len(pl.feats_csv_bytes(feats[:n_ref])) * rows / n_ref)}}
+
+
 def e2e_leg(cx, low_grid, precision="fp32"):
     """BASELINE configs[4]: synthetic two-level slide -> attention map (pipeline.multiscale_attention_map).
     precision "half" (`e2e_half`): both embedders on the opt-in fp16-activation trunk (tolerance: the `embedder_half` leg)."""
@@ -1060,6 +1094,9 @@ def _summary(line):
             e["ms_per_slide"] = obj["ms_per_slide"]
         if "ms_per_batch" in obj:
             e["ms_per_batch"] = obj["ms_per_batch"]
+        if "ms_per_bag" in obj:
+            e["ms_per_bag"] = obj["ms_per_bag"]
+            e["pandas_bags_per_s"] = obj["cpu_baseline"]["value"]
         if name == "decode" and obj.get("cpu_baseline"):
             e["pillow_tiles_per_s"] = obj["cpu_baseline"]["value"]
             e["pillow_threads"] = obj["cpu_baseline"]["cores"]
@@ -1071,7 +1108,7 @@ def _summary(line):
             e["value_one_stream"] = obj["config"]["value_one_stream"]
         out[name] = e
     put("aggregator_f32", line if line.get("unit") == "bags/s" else None)
-    for k in ("aggregator_bf16", "embedder", "embedder_half", "embedder_bf16", "train_c1", "train_c2", "slide", "slide_half", "slide_bf16", "slide_h2d", "slide_100k", "decode", "slide_jpeg", "e2e", "e2e_half", "slide_jpeg_half"):
+    for k in ("aggregator_bf16", "embedder", "embedder_half", "embedder_bf16", "train_c1", "train_c2", "slide", "slide_half", "slide_bf16", "slide_h2d", "slide_100k", "decode", "slide_jpeg", "e2e", "e2e_half", "slide_jpeg_half", "feats_csv"):
         put(k, line.get(k))
     return out
 
@@ -1086,7 +1123,7 @@ def main():
     ap.add_argument("--feats", type=int, default=512)
     ap.add_argument("--patches", type=int, default=256, help="patches per rank per embedder pass (batch size)")
     ap.add_argument("--workload", default="all",
-                    help="comma list of aggregator, aggregator_bf16, embedder, embedder_half, embedder_bf16, train, slide, slide_half, slide_bf16, slide_h2d, slide100k, decode, slide_jpeg, e2e, e2e_half, slide_jpeg_half; or all / both (= aggregator,embedder)")
+                    help="comma list of aggregator, aggregator_bf16, embedder, embedder_half, embedder_bf16, train, slide, slide_half, slide_bf16, slide_h2d, slide100k, decode, slide_jpeg, e2e, e2e_half, slide_jpeg_half, feats_csv; or all / both (= aggregator,embedder)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on each timed region")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams independent passes are dealt to (ops.StreamPool); 1 = one pass in flight")
@@ -1107,7 +1144,7 @@ def main():
                     help="skip the single-bag latency probe (profiling runs: keeps per-kernel averages clean)")
     args = ap.parse_args()
     maybe_self_launch(args)
-    wl = {"all": "aggregator,aggregator_bf16,embedder,embedder_half,embedder_bf16,train,slide,slide_half,slide_bf16,slide_h2d,slide100k,decode,slide_jpeg,e2e,e2e_half,slide_jpeg_half", "both": "aggregator,embedder"}.get(args.workload, args.workload)
+    wl = {"all": "aggregator,aggregator_bf16,embedder,embedder_half,embedder_bf16,train,slide,slide_half,slide_bf16,slide_h2d,slide100k,decode,slide_jpeg,e2e,e2e_half,slide_jpeg_half,feats_csv", "both": "aggregator,embedder"}.get(args.workload, args.workload)
     wl = [w for w in wl.split(",") if w]
     cx = Ctx(args)
     line = {}
@@ -1145,6 +1182,8 @@ def main():
         subs["e2e_half"] = e2e_leg(cx, tuple(args.e2e_grid), precision="half")
     if "slide_jpeg_half" in wl:   # (last: every stream a leg creates shifts the hardware queues of the legs behind it)
         subs["slide_jpeg_half"] = slide_jpeg_leg(cx, args.slide_patches, precision="half")
+    if "feats_csv" in wl and cx.rank == 0:   # host-only: the reference's feature file of one bag (rank 0's cores)
+        subs["feats_csv"] = feats_csv_leg(cx)
     if cx.rank == 0:
         if not line:   # a run without the headline leg (profiling): promote the first sub-object
             k0 = next(iter(subs))

@@ -123,6 +123,8 @@ SIGNATURES = {
     "dsmil_jpeg_plan_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
     "dsmil_jpeg_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64]),
     "dsmil_jpeg_parse": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
+    "dsmil_csv_format_f32": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                              ctypes.c_void_p, ctypes.c_int64]),
     "dsmil_jpeg_decode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dsmil_fc_forward": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
@@ -147,7 +149,9 @@ SIGNATURES = {
                                          ctypes.c_size_t, ctypes.c_void_p]),
 }
 
-DSMIL_E_UNSUPPORTED = -2    # include/dsmil_hip.h
+DSMIL_E_INVALID = -1        # include/dsmil_hip.h
+DSMIL_E_UNSUPPORTED = -2
+DSMIL_E_WORKSPACE = -3
 
 _lib = None
 

@@ -2,7 +2,9 @@
 own CPU module path (dsmil.MILNet on CPU tensors, dsmil-wsi_amd/modules.py `_forward_cpu`) against vectors the
 reference itself produced (tests/golden/make_golden.py ran /root/reference/dsmil.py): SURVEY §8(d) config 1 asks
 for outputs identical to the reference module within 1e-6 on the same bags.  No oracle involved: product vs
-reference-generated golden, forward and autograd gradients.  CPU only."""
+reference-generated golden, forward and autograd gradients.  CPU only — and the 1e-6 bar is for the host the vectors were
+generated on (this container, where the driver runs the CPU suite): another host's BLAS blocks the K = 512 sums differently and
+lands a few fp32 ulps away (1.5e-6 on the GPU box's 256-core host, 5 of 370 cases), as the reference itself would."""
 import hashlib
 
 import numpy as np

@@ -1,0 +1,94 @@
+"""The reference's feature files (compute_feats.py:80-82: `pd.DataFrame(feats).to_csv(path, index=False, float_format='%.4f')`,
+read back by train_tcga.py:27-32): dsmil_csv_format_f32 / pipeline.feats_csv_bytes / save_feats_csv write the SAME BYTES as pandas
+— exact decimal rounding (ties to even), NaN, infinities, negative zero, subnormals, values of 1e9 and more — and the writer
+thread of the compute_feats loops leaves complete files behind.  HOST code only: runs without a GPU."""
+import ctypes
+import io
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import dsmil  # noqa: F401
+from dsmil_wsi_amd import _native, pipeline as pl
+
+
+def _pandas_bytes(a, decimals=4):
+    b = io.StringIO()
+    pd.DataFrame(a).to_csv(b, index=False, float_format=f"%.{decimals}f")
+    return b.getvalue().encode()
+
+
+def _edge_matrix(rng, rows=300, cols=64):
+    a = rng.standard_normal((rows, cols)).astype(np.float32)
+    a[0, :12] = [0.0, -0.0, 1e-5, -1e-5, 0.00005, -0.00005, 0.03125, 0.09375, np.nan, np.inf, -np.inf, 3.4e38]
+    a[1, :10] = [1e9, -1e9, 999999999.0, 123456.789, 1e-30, -1e-30, 0.99995, 2.5, 1e-45, -1e-45]
+    a[2, :] = np.arange(cols, dtype=np.float32) / np.float32(32768.0)                       # exact binary fractions: ties
+    a[3, :] = (rng.integers(-2 ** 20, 2 ** 20, cols) / np.float32(2 ** 15)).astype(np.float32)
+    a[4, :] = (rng.integers(-2 ** 23, 2 ** 23, cols).astype(np.float64) / 2 ** 5).astype(np.float32)   # k / 32: '.03125' ties
+    a[5, :] = np.float32(10.0) ** rng.integers(-12, 12, cols).astype(np.float32)
+    return a
+
+
+@pytest.mark.parametrize("decimals", [4, 0, 1, 6, 9])
+def test_same_bytes_as_pandas(decimals):
+    rng = np.random.default_rng(3 + decimals)
+    a = _edge_matrix(rng)
+    assert pl.feats_csv_bytes(a, decimals=decimals) == _pandas_bytes(a, decimals)
+    assert pl.feats_csv_bytes(a, decimals=decimals, threads=1) == pl.feats_csv_bytes(a, decimals=decimals, threads=5)
+
+
+def test_every_kind_of_float32_bit_pattern():
+    """Random BIT PATTERNS: all exponents, subnormals, NaNs with payloads, both infinities."""
+    rng = np.random.default_rng(17)
+    a = rng.integers(0, 2 ** 32, (2000, 50), dtype=np.uint64).astype(np.uint32).view(np.float32)
+    assert pl.feats_csv_bytes(a) == _pandas_bytes(a)
+
+
+def test_a_bag_sized_file_round_trips_like_the_reference(tmp_path):
+    rng = np.random.default_rng(5)
+    feats = (rng.standard_normal((1200, 512)) * rng.choice([1e-3, 1.0, 30.0], (1200, 1))).astype(np.float32)
+    path = os.path.join(tmp_path, "datasets", "toy", "s1.csv")
+    pl.save_feats_csv(feats, path, npy=True)
+    with open(path, "rb") as fh:
+        assert fh.read() == _pandas_bytes(feats)
+    back = pd.read_csv(path)                                # train_tcga.py:27
+    assert list(back.columns) == [str(i) for i in range(512)] and back.shape == (1200, 512)
+    assert np.abs(back.to_numpy() - feats).max() <= 5.0001e-5 + 1e-6 * np.abs(feats).max()
+    assert np.array_equal(np.load(os.path.splitext(path)[0] + ".npy"), feats)
+    # not a float32 matrix: pandas itself writes the file
+    p2 = os.path.join(tmp_path, "d", "x.csv")
+    pl.save_feats_csv(feats[:5].astype(np.float64), p2)
+    with open(p2, "rb") as fh:
+        assert fh.read() == _pandas_bytes(feats[:5].astype(np.float64))
+    assert pl.feats_csv_bytes(np.zeros((0, 3), np.float32)) == b"0,1,2\n"
+
+
+def test_c_abi_argument_checks_and_strided_rows():
+    L = _native.lib()
+    a = np.arange(12, dtype=np.float32).reshape(3, 4) / 8
+    buf = np.empty(3 * 4 * 64, np.uint8)
+    w = L.dsmil_csv_format_f32(a.ctypes.data, 3, 2, 4, 4, buf.ctypes.data, buf.size)      # the first two columns of every row
+    assert buf[:w].tobytes() == b"0.0000,0.1250\n0.5000,0.6250\n1.0000,1.1250\n"
+    assert L.dsmil_csv_format_f32(a.ctypes.data, 3, 4, 4, 4, buf.ctypes.data, 100) == _native.DSMIL_E_WORKSPACE
+    for bad in ((None, 3, 4, 4, 4), (a.ctypes.data, 3, 0, 4, 4), (a.ctypes.data, 3, 4, 3, 4), (a.ctypes.data, 3, 4, 4, 10), (a.ctypes.data, -1, 4, 4, 4)):
+        assert L.dsmil_csv_format_f32(*bad, buf.ctypes.data, buf.size) == _native.DSMIL_E_INVALID
+    assert L.dsmil_csv_format_f32(a.ctypes.data, 0, 4, 4, 4, buf.ctypes.data, buf.size) == 0
+    assert ctypes.sizeof(ctypes.c_int64) == 8
+
+
+def test_writer_thread_finishes_the_files_and_reports_failures(tmp_path):
+    rng = np.random.default_rng(9)
+    bags = [rng.standard_normal((50 + 7 * i, 16)).astype(np.float32) for i in range(6)]
+    with pl.FeatWriter(depth=2) as w:
+        for i, b in enumerate(bags):
+            w.save(b, os.path.join(tmp_path, "out", f"b{i}.csv"))
+    for i, b in enumerate(bags):
+        with open(os.path.join(tmp_path, "out", f"b{i}.csv"), "rb") as fh:
+            assert fh.read() == _pandas_bytes(b)
+    blocker = os.path.join(tmp_path, "file")
+    open(blocker, "w").close()
+    with pytest.raises(OSError):
+        with pl.FeatWriter() as w:
+            w.save(bags[0], os.path.join(blocker, "sub", "b.csv"))      # a directory cannot be made under a file

@@ -65,10 +65,13 @@ def test_compute_feats_single_matches_oracle(workdir):
         ref = ro.resnet18_in_features(x, w).numpy()
     got = pd.read_csv("datasets/toy/1_tumor/s2.csv").to_numpy()
     assert got.shape == (3, 512)
-    np.testing.assert_allclose(got, ref, atol=8e-5)
+    # (this test is not GPU-marked: it checks the script on the CPU module path; run on a GPU box — without `-m "not gpu"` — the
+    # script takes the HIP embedder, whose parity bar is 1e-4, under the same CSV quantum)
+    on_gpu = torch.cuda.is_available()
+    np.testing.assert_allclose(got, ref, atol=1.6e-4 if on_gpu else 8e-5)
     exact = np.load("datasets/toy/1_tumor/s2.npy")           # --save_npy: the unquantised rows
     assert exact.dtype == np.float32 and exact.shape == (3, 512)
-    np.testing.assert_allclose(exact, ref, atol=3e-5)
+    np.testing.assert_allclose(exact, ref, atol=1e-4 if on_gpu else 3e-5)
     np.testing.assert_allclose(got, exact, atol=5.1e-5)  # half the '%.4f' CSV quantum + fp32 order effects
 
 
