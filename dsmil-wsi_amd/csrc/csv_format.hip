@@ -69,3 +69,73 @@ extern "C" int64_t dsmil_csv_format_f32(const float* x, int64_t rows, int64_t co
     }
     return (int64_t)(p - out);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dsmil_csv_parse_f32 — the way back (train_tcga.py:27-32 `pd.read_csv(path)` -> `torch.tensor(..., dtype=torch.float32)`):
+// rows of decimal fields -> float32.  A plain decimal field of at most 15 significant digits and at most 22 decimals is
+// n / 10^f with n < 2^53 and 10^f exact in double: ONE correctly rounded division — the double pandas' parser produces for
+// the '%.4f' fields the reference writes (its xstrtod divides by 1e4 once as well) — then the same round-to-nearest cast to
+// float32 as torch's.  Everything else (exponents, more digits, 'inf', 'nan') goes through strtod; an empty field is NaN.
+// Blank lines are skipped (pandas' default).  Returns the number of rows parsed, or DSMIL_E_INVALID for a field that is not a
+// number / a row of another width / too many rows for `out` — the caller then lets pandas read the file.
+extern "C" int64_t dsmil_csv_parse_f32(const char* text, int64_t nbytes, int64_t cols, float* out, int64_t max_rows) {
+    if (!text || !out || nbytes < 0 || cols <= 0 || max_rows < 0) return DSMIL_E_INVALID;
+    static const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16,
+                                   1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char* p = text;
+    const char* const end = text + nbytes;
+    int64_t rows = 0;
+    while (p < end) {
+        // a blank line?
+        if (*p == '\n') { ++p; continue; }
+        if (*p == '\r' && p + 1 < end && p[1] == '\n') { p += 2; continue; }
+        if (rows >= max_rows) return DSMIL_E_INVALID;
+        float* dst = out + rows * cols;
+        for (int64_t c = 0; c < cols; ++c) {
+            const char* f0 = p;
+            bool neg = false;
+            if (p < end && (*p == '-' || *p == '+')) { neg = *p == '-'; ++p; }
+            uint64_t n = 0;
+            int nd = 0, nf = 0;
+            bool any = false, plain = true;
+            while (p < end && *p >= '0' && *p <= '9') { if (nd < 19) { n = n * 10 + (uint64_t)(*p - '0'); } if (n || nd) ++nd; any = true; ++p; }
+            if (p < end && *p == '.') {
+                ++p;
+                while (p < end && *p >= '0' && *p <= '9') { if (nd < 19) { n = n * 10 + (uint64_t)(*p - '0'); } if (n || nd) ++nd; ++nf; any = true; ++p; }
+            }
+            if (p < end && *p != ',' && *p != '\n' && *p != '\r') plain = false;     // an exponent, 'inf', 'nan', or junk
+            double v;
+            if (plain && any && nd <= 15 && nf <= 22) {
+                v = (double)n / P10[nf];
+                if (neg) v = -v;
+            } else if (plain && !any && p == f0) {
+                v = NAN;                                                              // an empty field
+            } else {
+                // the general case: the field as a C string through strtod
+                const char* q = f0;
+                while (q < end && *q != ',' && *q != '\n' && *q != '\r') ++q;
+                char tmp[64];
+                const size_t len = (size_t)(q - f0);
+                if (len == 0 || len >= sizeof(tmp)) return DSMIL_E_INVALID;
+                std::memcpy(tmp, f0, len);
+                tmp[len] = 0;
+                char* e = nullptr;
+                v = std::strtod(tmp, &e);
+                if (e != tmp + len) return DSMIL_E_INVALID;
+                p = q;
+            }
+            dst[c] = (float)v;
+            if (c + 1 < cols) {
+                if (p >= end || *p != ',') return DSMIL_E_INVALID;
+                ++p;
+            }
+        }
+        if (p < end && *p == '\r') ++p;
+        if (p < end) {
+            if (*p != '\n') return DSMIL_E_INVALID;
+            ++p;
+        }
+        ++rows;
+    }
+    return rows;
+}

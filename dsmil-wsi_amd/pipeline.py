@@ -455,6 +455,53 @@ def feats_csv_bytes(arr, decimals=4, threads=None):
     return head + b"".join(parts)
 
 
+def read_feats_csv(path, threads=None):
+    """A feature file written by compute_feats.py:80-82 -> float32 [N, F], what `torch.tensor(pd.read_csv(path).to_numpy(),
+    dtype=torch.float32)` gives (train_tcga.py:27-32 + :49): the header line is skipped as pandas consumes it, the data rows
+    go through dsmil_csv_parse_f32 in chunks on a few host threads.  None when the file is not a plain numeric table (the
+    caller lets pandas read it).  0.93 s -> ~0.1 s for a 10 000 x 512 bag."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import _native
+    with open(path, "rb") as fh:
+        raw = fh.read()
+    nl = raw.find(b"\n")
+    if nl < 0:
+        return None
+    cols = raw[:nl].count(b",") + 1
+    buf = np.frombuffer(raw, np.uint8)
+    n = len(raw)
+    threads = max(1, int(CSV_THREADS[0] if threads is None else threads))
+    cuts = [nl + 1]
+    for t in range(1, threads):                          # chunk boundaries right behind a line break
+        want = nl + 1 + (n - nl - 1) * t // threads
+        k = raw.find(b"\n", max(want, cuts[-1]))
+        if k < 0:
+            break
+        if k + 1 > cuts[-1]:
+            cuts.append(k + 1)
+    cuts.append(n)
+    L = _native.lib()
+
+    def chunk(i):
+        lo, hi = cuts[i], cuts[i + 1]
+        if hi <= lo:
+            return np.zeros((0, cols), np.float32)
+        max_rows = raw.count(b"\n", lo, hi) + 1
+        out = np.empty((max_rows, cols), np.float32)
+        r = L.dsmil_csv_parse_f32(buf.ctypes.data + lo, hi - lo, cols, out.ctypes.data, max_rows)
+        return None if r < 0 else out[:r]
+
+    idx = list(range(len(cuts) - 1))
+    if len(idx) == 1:
+        parts = [chunk(0)]
+    else:
+        with ThreadPoolExecutor(max_workers=len(idx)) as tp:
+            parts = list(tp.map(chunk, idx))
+    if any(p is None for p in parts):
+        return None
+    return parts[0] if len(parts) == 1 else np.concatenate(parts)
+
+
 def save_feats_csv(feats, path, npy=False):
     """compute_feats.py:80-82 — the pandas CSV, header 0..F-1, '%.4f' (the same bytes, formatted by feats_csv_bytes; anything
     that is not a float32 matrix goes through pandas itself); with ``npy`` also the exact float32 rows as <bag>.npy

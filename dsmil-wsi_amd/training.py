@@ -29,7 +29,12 @@ def get_bag_feats(csv_file_df, args):
         feats_csv_path = "datasets/tcga-dataset/tcga_lung_data_feats/" + csv_file_df.iloc[0].split("/")[1] + ".csv"
     else:
         feats_csv_path = csv_file_df.iloc[0]
-    feats = shuffle(pd.read_csv(feats_csv_path)).reset_index(drop=True).to_numpy()
+    # (train_tcga.py:32; the file through dsmil_csv_parse_f32 — the float32 values torch.tensor(..., float32) makes of pandas'
+    # float64 ones, ~10x faster than pd.read_csv — and sklearn's shuffle of the ROWS draws the same permutation for an array as
+    # for the DataFrame; a file that is not a plain numeric table is left to pandas)
+    from .pipeline import read_feats_csv
+    arr = read_feats_csv(feats_csv_path)
+    feats = shuffle(arr) if arr is not None else shuffle(pd.read_csv(feats_csv_path)).reset_index(drop=True).to_numpy()
     label = np.zeros(args.num_classes)
     if args.num_classes == 1:
         label[0] = csv_file_df.iloc[1]

@@ -440,6 +440,13 @@ int dsmil_jpeg_decode(const uint8_t* data, int64_t data_bytes, const void* plan,
  * pandas writes).  out: at least 64 bytes per value.  Returns the number of bytes written, DSMIL_E_WORKSPACE when `cap` is too
  * small, DSMIL_E_INVALID for bad arguments.  Thread-safe (the caller formats row blocks in parallel). */
 int64_t dsmil_csv_format_f32(const float* x, int64_t rows, int64_t cols, int64_t row_stride, int32_t decimals, char* out, int64_t cap);
+/* ... and the way back (train_tcga.py:27-32 `pd.read_csv(path)`, then `torch.tensor(..., dtype=torch.float32)`): text = the
+ * DATA rows of a feature file (the caller skips the header line), `cols` fields per row -> out float32 [max_rows, cols].  HOST
+ * function, thread-safe (the caller parses chunks that end at a line break in parallel).  A '%.4f' field parses to the double
+ * pandas' parser gives (one correctly rounded division by 10^4) and is cast to float32 as torch casts it; exponents, 'inf',
+ * 'nan', long fields go through strtod; an empty field is NaN; blank lines are skipped.  Returns the rows parsed, or
+ * DSMIL_E_INVALID (a field that is not a number, a row of another width, more than max_rows rows: let pandas read the file). */
+int64_t dsmil_csv_parse_f32(const char* text, int64_t nbytes, int64_t cols, float* out, int64_t max_rows);
 
 const char* dsmil_strerror(int code);
 int dsmil_abi_version(void);

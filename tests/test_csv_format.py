@@ -92,3 +92,77 @@ def test_writer_thread_finishes_the_files_and_reports_failures(tmp_path):
     with pytest.raises(OSError):
         with pl.FeatWriter() as w:
             w.save(bags[0], os.path.join(blocker, "sub", "b.csv"))      # a directory cannot be made under a file
+
+
+def test_reading_a_feature_file_gives_the_float32_values_of_the_pandas_path(tmp_path):
+    """train_tcga.py:27-32 + :49 — pd.read_csv -> float64 -> torch.tensor(float32): pipeline.read_feats_csv (dsmil_csv_parse_f32)
+    gives the same BITS, on any number of threads, and sklearn's shuffle permutes the array as it permutes the DataFrame."""
+    import torch
+    from sklearn.utils import shuffle
+    rng = np.random.default_rng(23)
+    feats = (rng.standard_normal((3000, 96)) * rng.choice([1e-3, 1.0, 300.0], (3000, 1))).astype(np.float32)
+    feats[0, :8] = [0.0, -0.0, np.nan, np.inf, -np.inf, 1e15, 1e9, -1e-5]
+    path = os.path.join(tmp_path, "bag.csv")
+    pl.save_feats_csv(feats, path)
+    ref = torch.tensor(pd.read_csv(path).to_numpy(), dtype=torch.float32).numpy()
+    for th in (1, 3, 8):
+        got = pl.read_feats_csv(path, threads=th)
+        assert got.dtype == np.float32 and got.shape == ref.shape
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), th
+    np.random.seed(4)
+    a = torch.tensor(shuffle(pd.read_csv(path)).reset_index(drop=True).to_numpy(), dtype=torch.float32).numpy()
+    np.random.seed(4)
+    b = shuffle(pl.read_feats_csv(path))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_parser_on_fields_the_writer_does_not_produce(tmp_path):
+    """Other writers' files: exponents, more digits than the fast path takes, '+', CRLF line ends, blank lines, empty fields —
+    equal to pandas' values after the float32 cast; a non-numeric field or a ragged row hands the file to pandas (None)."""
+    import torch
+    text = ("a,b,c,d\r\n"
+            "1.5e-3,+2.25,-0.000123456789012345678,12345678901234567890\r\n"
+            "\r\n"
+            ",inf,-inf,nan\r\n"
+            "7,0.1,1E5,-3.\n"
+            "\n"
+            ".5,-.25,100,1e-40")
+    path = os.path.join(tmp_path, "other.csv")
+    with open(path, "w", newline="") as fh:
+        fh.write(text)
+    ref = torch.tensor(pd.read_csv(path).to_numpy(), dtype=torch.float32).numpy()
+    got = pl.read_feats_csv(path)
+    assert got.shape == (4, 4) == ref.shape
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_array_equal(np.nan_to_num(got, nan=7.0), np.nan_to_num(ref, nan=7.0))
+    for bad in ("0,1\n1.0,abc\n", "0,1\n1.0\n", "0,1\n1.0,2.0,3.0\n"):
+        with open(path, "w") as fh:
+            fh.write(bad)
+        assert pl.read_feats_csv(path) is None
+    L = _native.lib()
+    out = np.empty((2, 2), np.float32)
+    t = np.frombuffer(b"1,2\n3,4\n5,6\n", np.uint8)
+    assert L.dsmil_csv_parse_f32(t.ctypes.data, t.size, 2, out.ctypes.data, 2) == _native.DSMIL_E_INVALID      # more rows than room
+    assert L.dsmil_csv_parse_f32(t.ctypes.data, 8, 2, out.ctypes.data, 2) == 2 and out.tolist() == [[1.0, 2.0], [3.0, 4.0]]
+    assert L.dsmil_csv_parse_f32(None, 8, 2, out.ctypes.data, 2) == _native.DSMIL_E_INVALID
+
+
+def test_generate_pt_files_reads_bags_like_the_reference(tmp_path, monkeypatch):
+    """training.get_bag_feats (train_tcga.py:21-38): label, the shuffled float32 rows and the path — against the pandas path of
+    the reference under the same numpy seed."""
+    import argparse
+    import torch
+    from sklearn.utils import shuffle
+    from dsmil_wsi_amd import training
+    rng = np.random.default_rng(31)
+    feats = rng.standard_normal((257, 32)).astype(np.float32)
+    path = os.path.join(tmp_path, "s7.csv")
+    pl.save_feats_csv(feats, path)
+    row = pd.Series([path, 1])
+    args = argparse.Namespace(dataset="toy", num_classes=2)
+    np.random.seed(11)
+    label, got, p = training.get_bag_feats(row, args)
+    np.random.seed(11)
+    ref = shuffle(pd.read_csv(path)).reset_index(drop=True).to_numpy()
+    assert p == path and label.tolist() == [0.0, 1.0]
+    assert np.array_equal(torch.tensor(np.array(got), dtype=torch.float32).numpy(), torch.tensor(ref, dtype=torch.float32).numpy())
