@@ -548,11 +548,15 @@ class FeatWriter:
         self.tp = ThreadPoolExecutor(max_workers=1)
         self.pending, self.depth = [], max(1, int(depth))
 
-    def save(self, feats, path, npy=False):
-        arr = feats.detach().cpu().numpy() if torch.is_tensor(feats) else np.asarray(feats)   # (the D2H copy: here, in order)
+    def submit(self, fn, *args, **kwargs):
+        """Any file-writing call (the attention maps' PNG encode, attention_map.py:104) behind the loop, in order."""
         while len(self.pending) >= self.depth:
             self.pending.pop(0).result()
-        self.pending.append(self.tp.submit(save_feats_csv, arr, path, npy))
+        self.pending.append(self.tp.submit(fn, *args, **kwargs))
+
+    def save(self, feats, path, npy=False):
+        arr = feats.detach().cpu().numpy() if torch.is_tensor(feats) else np.asarray(feats)   # (the D2H copy: here, in order)
+        self.submit(save_feats_csv, arr, path, npy)
 
     def close(self):
         try:
@@ -744,6 +748,27 @@ def attention_maps(args, bags_list, milnet, colors=None, rng=None, embedder_low=
     if tree and (embedder_low is None or embedder_high is None):
         raise ValueError("multi-scale attention maps need the low- and the high-magnification embedder")
     out = []
+    writer = FeatWriter()        # the PNG encode of a slide's map (0.2 s for a 3 000 x 3 000 map) runs while the next slide is embedded
+    try:
+        _attention_map_slides(args, bags_list, milnet, embedder_low, embedder_high, tree, colors, rank, writer, out)
+    finally:
+        writer.close()
+    return out
+
+
+def _save_png(arr, path):
+    from PIL import Image
+    Image.fromarray(arr).save(path)
+
+
+def _save_scores(A, pos_arr, path):
+    import pandas as pd
+    df = pd.DataFrame(A)
+    df["pos"] = [str(s) for s in pos_arr]
+    df.to_csv(path, index=False)
+
+
+def _attention_map_slides(args, bags_list, milnet, embedder_low, embedder_high, tree, colors, rank, writer, out):
     for bag in bags_list:
         if tree:
             feats, files, _ = tree_feats_of_bag(bag, embedder_low, embedder_high, getattr(args, "tree_fusion", "cat"),
@@ -763,14 +788,10 @@ def attention_maps(args, bags_list, milnet, colors=None, rng=None, embedder_low=
         cmap = attention_colormap(A.cpu().numpy(), pos_arr, pred, args.thres, colors, args.class_name, bag)
         slide = bag.rstrip(os.sep).split(os.sep)[-1]
         if rank == 0:
-            Image.fromarray(cmap).save(os.path.join(args.map_path, slide + ".png"))
+            writer.submit(_save_png, cmap, os.path.join(args.map_path, slide + ".png"))
             if getattr(args, "export_scores", 0):
-                import pandas as pd
-                df = pd.DataFrame(A.cpu().numpy())
-                df["pos"] = [str(s) for s in pos_arr]
-                df.to_csv(os.path.join(args.score_path, slide + ".csv"), index=False)
+                writer.submit(_save_scores, A.cpu().numpy(), pos_arr, os.path.join(args.score_path, slide + ".csv"))
         out.append((slide, pred, cmap))
-    return out
 
 
 # ---------------------------------------------------------------------------------------------
