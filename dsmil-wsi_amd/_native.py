@@ -123,6 +123,7 @@ SIGNATURES = {
     "dsmil_jpeg_plan_bytes": (ctypes.c_size_t, [ctypes.c_int32]),
     "dsmil_jpeg_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64]),
     "dsmil_jpeg_parse": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
+    "dsmil_read_files": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "dsmil_csv_parse_f32": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]),
     "dsmil_csv_format_f32": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                               ctypes.c_void_p, ctypes.c_int64]),

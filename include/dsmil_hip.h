@@ -447,6 +447,12 @@ int64_t dsmil_csv_format_f32(const float* x, int64_t rows, int64_t cols, int64_t
  * 'nan', long fields go through strtod; an empty field is NaN; blank lines are skipped.  Returns the rows parsed, or
  * DSMIL_E_INVALID (a field that is not a number, a row of another width, more than max_rows rows: let pandas read the file). */
 int64_t dsmil_csv_parse_f32(const char* text, int64_t nbytes, int64_t cols, float* out, int64_t max_rows);
+/* The loader's file reads (compute_feats.py:21-56: DataLoader workers open every tile file) — HOST function, thread-safe: n files
+ * (paths: NUL-terminated strings back to back, path_off[i] = offset of path i) back to back into `out`; with out == NULL only
+ * their sizes (the caller sizes the buffer from the returned total).  sizes[i] = bytes of file i, -1 when it cannot be opened or
+ * read.  Returns the total bytes, DSMIL_E_WORKSPACE when `cap` is too small, DSMIL_E_INVALID for bad arguments.  One call per
+ * group of files from a Python thread holds no interpreter lock: 25 us of interpreter time per file otherwise, serialised. */
+int64_t dsmil_read_files(const char* paths, const int64_t* path_off, int32_t n, uint8_t* out, int64_t cap, int64_t* sizes);
 
 const char* dsmil_strerror(int code);
 int dsmil_abi_version(void);

@@ -166,3 +166,34 @@ def test_generate_pt_files_reads_bags_like_the_reference(tmp_path, monkeypatch):
     ref = shuffle(pd.read_csv(path)).reset_index(drop=True).to_numpy()
     assert p == path and label.tolist() == [0.0, 1.0]
     assert np.array_equal(torch.tensor(np.array(got), dtype=torch.float32).numpy(), torch.tensor(ref, dtype=torch.float32).numpy())
+
+
+def test_read_files_gives_the_files_bytes_and_raises_like_open(tmp_path):
+    """pipeline.read_files (dsmil_read_files: the loader's file reads, compute_feats.py:21-56, one C call per group of files): the
+    bytes `open(p, 'rb').read()` gives, an empty file, a missing file (FileNotFoundError as the Python loader would raise), and the
+    raw C-ABI: sizes only / a buffer that is too small."""
+    rng = np.random.default_rng(2)
+    paths, ref = [], []
+    for i in range(70):
+        b = b"" if i == 5 else rng.integers(0, 256, int(rng.integers(1, 30000)), dtype=np.uint8).tobytes()
+        p = os.path.join(tmp_path, f"t{i}.jpeg")
+        with open(p, "wb") as fh:
+            fh.write(b)
+        paths.append(p)
+        ref.append(b)
+    got = pl.read_files(paths)
+    assert len(got) == 70 and all(bytes(g) == r for g, r in zip(got, ref))
+    assert pl.read_files([]) == []
+    with pytest.raises(FileNotFoundError):
+        pl.read_files(paths[:3] + [os.path.join(tmp_path, "missing.jpeg")])
+    L = _native.lib()
+    enc = [os.fsencode(p) for p in paths[:4]]
+    blob = np.frombuffer(b"\0".join(enc) + b"\0", np.uint8)
+    off = np.zeros(4, np.int64)
+    np.cumsum([len(e) + 1 for e in enc[:-1]], out=off[1:])
+    sizes = np.empty(4, np.int64)
+    total = L.dsmil_read_files(blob.ctypes.data, off.ctypes.data, 4, None, 0, sizes.ctypes.data)
+    assert total == sum(len(r) for r in ref[:4]) and sizes.tolist() == [len(r) for r in ref[:4]]
+    small = np.empty(max(1, total - 1), np.uint8)
+    assert L.dsmil_read_files(blob.ctypes.data, off.ctypes.data, 4, small.ctypes.data, total - 1, sizes.ctypes.data) == _native.DSMIL_E_WORKSPACE
+    assert L.dsmil_read_files(None, off.ctypes.data, 4, None, 0, sizes.ctypes.data) == _native.DSMIL_E_INVALID
